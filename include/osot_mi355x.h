@@ -1,0 +1,247 @@
+/* include/osot_mi355x.h -- the drop-in C-ABI of the MI355X-native OpenSoT hot path.
+ *
+ * Plain C: opaque handles, POD structs, raw pointers + sizes, int error codes; no C++/Eigen/torch
+ * types cross this boundary and no exception does.  Implemented by
+ * opensot_amd/csrc/libosot_mi355x.so (hand-written HIP for gfx950).
+ *
+ * What each group replaces in the reference (ADVRHumanoids/OpenSoT @2024-10-24; paths relative to
+ * the reference root):
+ *
+ *  osot_plan_desc ................ the *result* of the stack algebra (src/utils/AutoStack.cpp:7-331,
+ *                                  examples/cpp/coman_ik.cpp:425-449): levels -> leaf task blocks,
+ *                                  box-bound producers, global constraint-row producers.  Static.
+ *  osot_stack_update ............. AutoStack::update()            src/utils/AutoStack.cpp:385-393
+ *                                  (-> Task::update Task.h:375-400, tasks::Aggregated::_update
+ *                                  src/tasks/Aggregated.cpp:92-132, constraints::Aggregated::update
+ *                                  src/constraints/Aggregated.cpp:60-257 and the leaf _update()s)
+ *  osot_ihqp_solve ............... Solver::solve() = iHQP::solve  src/solvers/iHQP.cpp:263-358
+ *                                  (computeCostFunction :129-162, optimality rows :164-170,
+ *                                  one BackEnd::solve per level, QPOasesBackEnd.cpp:248-307)
+ *  osot_backend_* ................ the BackEnd plugin surface     include/OpenSoT/solvers/BackEnd.h:23-171
+ *                                  and its C factory `create_instance`
+ *                                  (src/solvers/QPOasesBackEnd.cpp:14-24), batch-of-one, host pointers
+ *  osot_allgather_dq ............. new surface (the reference has no multi-instance API): collects the
+ *                                  per-rank dq shards; RCCL all-gather on the solve stream
+ *
+ * All batched arrays are INSTANCE-MAJOR, row-major inside an instance, fp64, resident in HBM:
+ *   X[B][rows][n]  ->  element (i, r, c) at ((i*rows)+r)*n + c.
+ * One wavefront solves one instance, so an instance's rows are a single contiguous, coalesced read.
+ */
+#ifndef OSOT_MI355X_H
+#define OSOT_MI355X_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OSOT_MAX_LEVELS 8
+#define OSOT_MAX_TASKS 8      /* leaf task blocks per level   */
+#define OSOT_MAX_BOUNDS 4     /* box-bound producers          */
+#define OSOT_MAX_ROWBLOCKS 4  /* global constraint-row blocks */
+#define OSOT_MAX_VARS 64      /* one lane per variable        */
+
+/* error codes (the reference returns bool / throws std::runtime_error) */
+enum {
+    OSOT_OK = 0,
+    OSOT_ERR_INVALID = 1,      /* bad argument / size mismatch (BackEnd.cpp:23-27, :47-60)          */
+    OSOT_ERR_UNSUPPORTED = 2,  /* plan uses something this build does not implement                 */
+    OSOT_ERR_HIP = 3,          /* a HIP runtime call failed (osot_last_error() has the text)        */
+    OSOT_ERR_NOT_SOLVED = 4,   /* batch-of-one back-end: QP infeasible / iteration limit            */
+    OSOT_ERR_COMM = 5          /* RCCL failure                                                       */
+};
+
+/* per-instance status written by osot_ihqp_solve (the reference's `bool` per solve,
+ * iHQP.cpp:279-347; failed instances return dq = 0 like examples/cpp/coman_ik.cpp:189-190) */
+enum {
+    OSOT_STATUS_SOLVED = 0,
+    OSOT_STATUS_INFEASIBLE = 1,
+    OSOT_STATUS_MAX_ITER = 2,
+    OSOT_STATUS_NOT_PD = 3      /* Cholesky of H + eps I broke down */
+};
+
+/* ---- static stack plan ---------------------------------------------------------------------- */
+typedef enum {
+    OSOT_TASK_GENERIC = 0,   /* tasks::GenericTask (src/tasks/GenericTask.cpp:5-56): A and b supplied   */
+    OSOT_TASK_CARTESIAN = 1, /* velocity::Cartesian (src/tasks/velocity/Cartesian.cpp:68-105, 279-285)  */
+    OSOT_TASK_COM = 2,       /* velocity::CoM (src/tasks/velocity/CoM.cpp:59-74, 145-149)               */
+    OSOT_TASK_POSTURAL = 3   /* velocity::Postural (src/tasks/velocity/Postural.cpp:50-62, 97-100);
+                                A = I is implicit (never stored); must be the last block of its level */
+} osot_task_kind;
+
+typedef struct {
+    int kind;                /* osot_task_kind */
+    int rows;                /* 6 / 3 / n / user-defined */
+    double weight;           /* scalar on this block's W: `0.1*l_wrist` (AutoStack.cpp:16-47) */
+    double lambda;           /* Task::setLambda; enters b only (Cartesian.cpp:284, CoM.cpp:148) */
+    double orientation_gain; /* Cartesian::setOrientationErrorGain (Cartesian.cpp:283) */
+} osot_task_desc;
+
+typedef struct {
+    int n_tasks;
+    osot_task_desc task[OSOT_MAX_TASKS]; /* tasks::Aggregated row order (Aggregated.cpp:113-132) */
+} osot_level_desc;
+
+typedef enum {
+    OSOT_BOUND_GENERIC = 0,        /* l,u supplied */
+    OSOT_BOUND_JOINT_LIMITS = 1,   /* velocity::JointLimits (src/constraints/velocity/JointLimits.cpp:37-58) */
+    OSOT_BOUND_VELOCITY_LIMITS = 2 /* velocity::VelocityLimits (…/VelocityLimits.cpp:72-89) */
+} osot_bound_kind;
+
+typedef struct {
+    int kind;       /* osot_bound_kind */
+    double scaling; /* JointLimits boundScaling */
+    double dT;      /* VelocityLimits dT */
+} osot_bound_desc;
+
+typedef enum {
+    OSOT_ROWS_GENERIC = 0,  /* constraints::GenericConstraint / TaskToConstraint rows: C, lo, up supplied */
+    OSOT_ROWS_COLLISION = 1 /* velocity::CollisionAvoidance rows (…/CollisionAvoidance.cpp:96-152):
+                               -J_d dq <= max(0, s (d - d_min)) for pairs within the detection threshold */
+} osot_rows_kind;
+
+typedef struct {
+    int kind;  /* osot_rows_kind */
+    int rows;  /* for COLLISION: max_pairs */
+    double d_threshold, detection_threshold, bound_scaling;
+} osot_rows_desc;
+
+typedef struct {
+    int n;         /* number of variables (<= OSOT_MAX_VARS) */
+    int n_levels;
+    osot_level_desc level[OSOT_MAX_LEVELS];
+    int n_bounds;  /* 0 = no box (iHQP.cpp:340-344 then never calls updateBounds) */
+    osot_bound_desc bound[OSOT_MAX_BOUNDS];
+    int n_rowblocks;
+    osot_rows_desc rowblock[OSOT_MAX_ROWBLOCKS];
+    double eps_abs;  /* absolute epsilon on diag(H): 1e3 * 2.221e-16 * eps_factor
+                        (QPOasesBackEnd.cpp:57,67; qpOASES Options.cpp:147) */
+    int max_iter;    /* active-set iteration cap per level; 0 = default (the reference's nWSR is 13200,
+                        QPOasesBackEnd.cpp:30) */
+} osot_plan_desc;
+
+/* ---- assembled, batched QP data (device pointers) ------------------------------------------ */
+typedef struct {
+    int B;                              /* instances in this call (<= max_batch of the solver) */
+    const double* A[OSOT_MAX_LEVELS];   /* [B][ma_k][n], ma_k = rows of the non-Postural blocks */
+    const double* b[OSOT_MAX_LEVELS];   /* [B][m_k] */
+    const double* w[OSOT_MAX_LEVELS];   /* [B][m_k] diagonal of W_k; NULL = identity */
+    const double* c[OSOT_MAX_LEVELS];   /* [B][n] Task::getc(); NULL = 0 */
+    const double* C;                    /* [B][nc][n] global rows (all row blocks stacked) */
+    const double* lo;                   /* [B][nc] */
+    const double* up;                   /* [B][nc] */
+    const double* l;                    /* [B][n] merged box; NULL iff plan.n_bounds == 0 */
+    const double* u;                    /* [B][n] */
+    const unsigned char* level_active;  /* HOST pointer, [n_levels] iHQP::setActiveStack
+                                           (iHQP.cpp:391-395); NULL = all active */
+    double* dq;                         /* out [B][n]: x of the last active level (iHQP.cpp:349) */
+    double* x_levels;                   /* out [B][n_levels][n], may be NULL */
+    int* status;                        /* out [B] OSOT_STATUS_* */
+    int* iterations;                    /* out [B] active-set iterations summed over levels; may be NULL */
+} osot_qp_batch;
+
+/* ---- leaf inputs of AutoStack::update (device pointers) ------------------------------------ */
+/* meaning of (p0, p1, p2) by kind:
+ *   TASK_CARTESIAN : p0 = actual pose  [B][12] (R row-major 9, then p 3), p1 = desired pose [B][12],
+ *                    p2 = desired twist [B][6] (NULL = 0)
+ *   TASK_COM       : p0 = actual CoM [B][3], p1 = desired CoM [B][3], p2 = desired velocity [B][3] (NULL = 0)
+ *   TASK_POSTURAL  : p0 = q [B][n], p1 = q_desired [B][n], p2 = v_desired [B][n] (NULL = 0)
+ *   TASK_GENERIC   : p0 = b [B][rows] (copied);  p1, p2 unused
+ *   BOUND_JOINT_LIMITS    : p0 = q - q_neutral [B][n], p1 = q_min [B][n], p2 = q_max [B][n]
+ *   BOUND_VELOCITY_LIMITS : p0 = qdot_max [B][n]
+ *   BOUND_GENERIC         : p0 = l [B][n], p1 = u [B][n]
+ *   ROWS_COLLISION : p0 = distance Jacobians J_d [B][rows][n] (ordered by distance), p1 = distances [B][rows]
+ *   ROWS_GENERIC   : p0 = C [B][rows][n], p1 = lo [B][rows], p2 = up [B][rows]
+ * Task Jacobians are NOT passed here: the producer writes them straight into their row range of
+ * osot_qp_batch.A[k] (zero-copy stacking; the reference copies them twice through MatrixPiler,
+ * src/tasks/Aggregated.cpp:113-132). */
+typedef struct { const double *p0, *p1, *p2; } osot_leaf_ptrs;
+
+typedef struct {
+    int B;
+    osot_leaf_ptrs task[OSOT_MAX_LEVELS][OSOT_MAX_TASKS];
+    osot_leaf_ptrs bound[OSOT_MAX_BOUNDS];
+    osot_leaf_ptrs rows[OSOT_MAX_ROWBLOCKS];
+} osot_leaf_batch;
+
+/* writable view of the assembled arrays that osot_stack_update fills (same shapes as osot_qp_batch) */
+typedef struct {
+    double* b[OSOT_MAX_LEVELS];
+    double* w[OSOT_MAX_LEVELS];
+    double* C;
+    double* lo;
+    double* up;
+    double* l;
+    double* u;
+} osot_assembled_out;
+
+typedef struct osot_solver osot_solver;
+
+/* library / device */
+const char* osot_version(void);
+const char* osot_last_error(void);           /* thread-local text of the last failure */
+int osot_device_count(int* count);
+
+/* plan-derived sizes (host only, no GPU needed) */
+int osot_plan_validate(const osot_plan_desc* plan);
+int osot_plan_level_rows(const osot_plan_desc* plan, int level, int* m_total, int* m_stored);
+int osot_plan_constraint_rows(const osot_plan_desc* plan, int* nc);
+
+/* solver object: owns the per-plan device workspace for up to max_batch instances on `device` */
+int osot_solver_create(const osot_plan_desc* plan, int max_batch, int device, osot_solver** out);
+int osot_solver_destroy(osot_solver* s);
+
+/* AutoStack::update() for B instances: leaf inputs -> b_k, w_k, merged box, constraint rows.
+ * Stream-ordered on `hip_stream` (a hipStream_t passed as void*, NULL = default stream). */
+int osot_stack_update(osot_solver* s, const osot_leaf_batch* leaf, const osot_assembled_out* out,
+                      void* hip_stream);
+
+/* Solver::solve() for B instances: the whole iHQP cascade in one launch. Stream-ordered. */
+int osot_ihqp_solve(osot_solver* s, const osot_qp_batch* batch, void* hip_stream);
+
+/* average device time (ms) of the cascade kernel over the launches recorded since the last call
+ * with reset != 0; measured with hipEvents on the launch stream. *launches receives the count. */
+int osot_solver_kernel_time_ms(osot_solver* s, int reset, double* avg_ms, int* launches);
+int osot_solver_set_timing(osot_solver* s, int enabled);
+
+/* ---- batch-of-one BackEnd surface (host pointers; mirrors BackEnd.h) ------------------------ */
+typedef struct osot_backend osot_backend;
+/* create_instance(number_of_variables, number_of_constraints, hessian_type, eps_regularisation)
+ * (QPOasesBackEnd.cpp:14-24). eps_regularisation is the FACTOR; absolute eps = 2.221e-13 * factor. */
+int osot_backend_create(int number_of_variables, int number_of_constraints, int hessian_type,
+                        double eps_regularisation, osot_backend** out);
+int osot_backend_destroy(osot_backend* be);
+/* matrices row-major; A is nc x nv; l/u may be NULL (no box) */
+int osot_backend_init_problem(osot_backend* be, const double* H, const double* g, const double* A,
+                              const double* lA, const double* uA, const double* l, const double* u);
+int osot_backend_update_task(osot_backend* be, const double* H, const double* g);
+int osot_backend_update_constraints(osot_backend* be, const double* A, const double* lA,
+                                    const double* uA, int number_of_constraints);
+int osot_backend_update_bounds(osot_backend* be, const double* l, const double* u);
+int osot_backend_solve(osot_backend* be);
+int osot_backend_get_solution(osot_backend* be, double* x);
+int osot_backend_get_objective(osot_backend* be, double* f);
+int osot_backend_set_eps_regularisation(osot_backend* be, double eps_abs);
+int osot_backend_get_eps_regularisation(osot_backend* be, double* eps_abs);
+int osot_backend_get_num_variables(osot_backend* be, int* nv);
+int osot_backend_get_num_constraints(osot_backend* be, int* nc);
+
+/* batched generic QP: B independent problems of the SAME shape in BackEnd convention, device
+ * pointers, one wavefront each.  H: [B][n][n], g: [B][n], A: [B][nc][n], ...; x out [B][n]. */
+int osot_qp_solve_batch(int B, int n, int nc, const double* H, const double* g, const double* A,
+                        const double* lA, const double* uA, const double* l, const double* u,
+                        double eps_abs, int max_iter, double* x, int* status, int* iterations,
+                        void* hip_stream);
+
+/* ---- multi-GPU: collect solved dq shards ---------------------------------------------------- */
+typedef struct osot_comm osot_comm;
+/* unique id exchange is the caller's job (e.g. torch.distributed broadcast of the 128-byte id) */
+int osot_comm_unique_id(void* id128);
+int osot_comm_create(const void* id128, int rank, int world, int device, osot_comm** out);
+int osot_comm_destroy(osot_comm* c);
+/* all ranks: recv[world*count] <- concat_r send_r[count] (fp64), on hip_stream */
+int osot_allgather_dq(osot_comm* c, const double* send, double* recv, long long count, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

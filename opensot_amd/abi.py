@@ -1,0 +1,151 @@
+"""ctypes mirror of include/osot_mi355x.h (structs, enums, prototypes).
+
+Host-side plumbing only: the product's arithmetic lives in opensot_amd/csrc (HIP, gfx950).
+"""
+import ctypes as C
+import os
+
+MAX_LEVELS, MAX_TASKS, MAX_BOUNDS, MAX_ROWBLOCKS, MAX_VARS = 8, 8, 4, 4, 64
+
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NOT_SOLVED, ERR_COMM = range(6)
+STATUS_SOLVED, STATUS_INFEASIBLE, STATUS_MAX_ITER, STATUS_NOT_PD = range(4)
+TASK_GENERIC, TASK_CARTESIAN, TASK_COM, TASK_POSTURAL = range(4)
+BOUND_GENERIC, BOUND_JOINT_LIMITS, BOUND_VELOCITY_LIMITS = range(3)
+ROWS_GENERIC, ROWS_COLLISION = range(2)
+# OpenSoT::HessianType (include/OpenSoT/Task.h:33-41)
+HST_UNDEFINED, HST_ZERO, HST_IDENTITY, HST_POSDEF, HST_POSDEF_NULLSPACE, HST_SEMIDEF, HST_UNKNOWN = range(7)
+
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int)
+
+
+class TaskDesc(C.Structure):
+    _fields_ = [("kind", C.c_int), ("rows", C.c_int), ("weight", C.c_double),
+                ("lambda_", C.c_double), ("orientation_gain", C.c_double)]
+
+
+class LevelDesc(C.Structure):
+    _fields_ = [("n_tasks", C.c_int), ("task", TaskDesc * MAX_TASKS)]
+
+
+class BoundDesc(C.Structure):
+    _fields_ = [("kind", C.c_int), ("scaling", C.c_double), ("dT", C.c_double)]
+
+
+class RowsDesc(C.Structure):
+    _fields_ = [("kind", C.c_int), ("rows", C.c_int), ("d_threshold", C.c_double),
+                ("detection_threshold", C.c_double), ("bound_scaling", C.c_double)]
+
+
+class PlanDesc(C.Structure):
+    _fields_ = [("n", C.c_int), ("n_levels", C.c_int), ("level", LevelDesc * MAX_LEVELS),
+                ("n_bounds", C.c_int), ("bound", BoundDesc * MAX_BOUNDS),
+                ("n_rowblocks", C.c_int), ("rowblock", RowsDesc * MAX_ROWBLOCKS),
+                ("eps_abs", C.c_double), ("max_iter", C.c_int)]
+
+
+class QpBatch(C.Structure):
+    _fields_ = [("B", C.c_int),
+                ("A", C.c_void_p * MAX_LEVELS), ("b", C.c_void_p * MAX_LEVELS),
+                ("w", C.c_void_p * MAX_LEVELS), ("c", C.c_void_p * MAX_LEVELS),
+                ("C", C.c_void_p), ("lo", C.c_void_p), ("up", C.c_void_p),
+                ("l", C.c_void_p), ("u", C.c_void_p),
+                ("level_active", C.c_void_p),
+                ("dq", C.c_void_p), ("x_levels", C.c_void_p),
+                ("status", C.c_void_p), ("iterations", C.c_void_p)]
+
+
+class LeafPtrs(C.Structure):
+    _fields_ = [("p0", C.c_void_p), ("p1", C.c_void_p), ("p2", C.c_void_p)]
+
+
+class LeafBatch(C.Structure):
+    _fields_ = [("B", C.c_int),
+                ("task", (LeafPtrs * MAX_TASKS) * MAX_LEVELS),
+                ("bound", LeafPtrs * MAX_BOUNDS),
+                ("rows", LeafPtrs * MAX_ROWBLOCKS)]
+
+
+class AssembledOut(C.Structure):
+    _fields_ = [("b", C.c_void_p * MAX_LEVELS), ("w", C.c_void_p * MAX_LEVELS),
+                ("C", C.c_void_p), ("lo", C.c_void_p), ("up", C.c_void_p),
+                ("l", C.c_void_p), ("u", C.c_void_p)]
+
+
+# every symbol include/osot_mi355x.h declares (tests/test_abi_symbols.py checks the .so exports all)
+SYMBOLS = [
+    "osot_version", "osot_last_error", "osot_device_count",
+    "osot_plan_validate", "osot_plan_level_rows", "osot_plan_constraint_rows",
+    "osot_solver_create", "osot_solver_destroy", "osot_stack_update", "osot_ihqp_solve",
+    "osot_solver_kernel_time_ms", "osot_solver_set_timing",
+    "osot_backend_create", "osot_backend_destroy", "osot_backend_init_problem",
+    "osot_backend_update_task", "osot_backend_update_constraints", "osot_backend_update_bounds",
+    "osot_backend_solve", "osot_backend_get_solution", "osot_backend_get_objective",
+    "osot_backend_set_eps_regularisation", "osot_backend_get_eps_regularisation",
+    "osot_backend_get_num_variables", "osot_backend_get_num_constraints",
+    "osot_qp_solve_batch",
+    "osot_comm_unique_id", "osot_comm_create", "osot_comm_destroy", "osot_allgather_dq",
+]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libosot_mi355x.so")
+_lib = None
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library.  There is NO fallback: a missing .so is a hard error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryMissing(
+            f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). opensot_amd has no CPU fallback.")
+    # torch bundles its own libamdhip64/librccl; import it FIRST so that our library binds to the same
+    # (single) HIP runtime instance whose streams and allocations we are handed.
+    import torch  # noqa: F401
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp = C.c_void_p
+    L.osot_version.restype = C.c_char_p
+    L.osot_last_error.restype = C.c_char_p
+    L.osot_device_count.argtypes = [ip]
+    L.osot_plan_validate.argtypes = [C.POINTER(PlanDesc)]
+    L.osot_plan_level_rows.argtypes = [C.POINTER(PlanDesc), C.c_int, ip, ip]
+    L.osot_plan_constraint_rows.argtypes = [C.POINTER(PlanDesc), ip]
+    L.osot_solver_create.argtypes = [C.POINTER(PlanDesc), C.c_int, C.c_int, C.POINTER(vp)]
+    L.osot_solver_destroy.argtypes = [vp]
+    L.osot_stack_update.argtypes = [vp, C.POINTER(LeafBatch), C.POINTER(AssembledOut), vp]
+    L.osot_ihqp_solve.argtypes = [vp, C.POINTER(QpBatch), vp]
+    L.osot_solver_kernel_time_ms.argtypes = [vp, C.c_int, dp, ip]
+    L.osot_solver_set_timing.argtypes = [vp, C.c_int]
+    L.osot_backend_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(vp)]
+    L.osot_backend_destroy.argtypes = [vp]
+    L.osot_backend_init_problem.argtypes = [vp, dp, dp, dp, dp, dp, dp, dp]
+    L.osot_backend_update_task.argtypes = [vp, dp, dp]
+    L.osot_backend_update_constraints.argtypes = [vp, dp, dp, dp, C.c_int]
+    L.osot_backend_update_bounds.argtypes = [vp, dp, dp]
+    L.osot_backend_solve.argtypes = [vp]
+    L.osot_backend_get_solution.argtypes = [vp, dp]
+    L.osot_backend_get_objective.argtypes = [vp, dp]
+    L.osot_backend_set_eps_regularisation.argtypes = [vp, C.c_double]
+    L.osot_backend_get_eps_regularisation.argtypes = [vp, dp]
+    L.osot_backend_get_num_variables.argtypes = [vp, ip]
+    L.osot_backend_get_num_constraints.argtypes = [vp, ip]
+    L.osot_qp_solve_batch.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp,
+                                      C.c_double, C.c_int, vp, vp, vp, vp]
+    L.osot_comm_unique_id.argtypes = [vp]
+    L.osot_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.osot_comm_destroy.argtypes = [vp]
+    L.osot_allgather_dq.argtypes = [vp, vp, vp, C.c_longlong, vp]
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    if rc != OK:
+        msg = lib().osot_last_error()
+        raise RuntimeError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")

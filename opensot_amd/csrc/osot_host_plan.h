@@ -1,0 +1,107 @@
+// osot_host_plan.h -- host-side translation of the C-ABI plan into kernel arguments (no HIP calls).
+#pragma once
+#include <cstddef>
+#include <cstring>
+#include "../../include/osot_mi355x.h"
+#include "osot_kernels.h"
+
+namespace osot {
+
+inline int plan_level_rows(const osot_plan_desc* p, int k, int* m_total, int* m_stored) {
+    if (!p || k < 0 || k >= p->n_levels) return OSOT_ERR_INVALID;
+    int m = 0, ma = 0;
+    const osot_level_desc& lv = p->level[k];
+    for (int j = 0; j < lv.n_tasks; ++j) {
+        m += lv.task[j].rows;
+        if (lv.task[j].kind != OSOT_TASK_POSTURAL) ma += lv.task[j].rows;
+    }
+    if (m_total) *m_total = m;
+    if (m_stored) *m_stored = ma;
+    return OSOT_OK;
+}
+
+inline int plan_constraint_rows(const osot_plan_desc* p, int* nc) {
+    if (!p) return OSOT_ERR_INVALID;
+    int s = 0;
+    for (int j = 0; j < p->n_rowblocks; ++j) s += p->rowblock[j].rows;
+    if (nc) *nc = s;
+    return OSOT_OK;
+}
+
+inline int plan_validate(const osot_plan_desc* p, const char** why) {
+    static const char* ok = "";
+    *why = ok;
+    if (!p) { *why = "null plan"; return OSOT_ERR_INVALID; }
+    if (p->n < 1 || p->n > OSOT_MAX_VARS) { *why = "n out of range (1..64)"; return OSOT_ERR_INVALID; }
+    if (p->n_levels < 1 || p->n_levels > OSOT_MAX_LEVELS) { *why = "n_levels out of range"; return OSOT_ERR_INVALID; }
+    if (p->n_bounds < 0 || p->n_bounds > OSOT_MAX_BOUNDS) { *why = "n_bounds out of range"; return OSOT_ERR_INVALID; }
+    if (p->n_rowblocks < 0 || p->n_rowblocks > OSOT_MAX_ROWBLOCKS) { *why = "n_rowblocks out of range"; return OSOT_ERR_INVALID; }
+    if (!(p->eps_abs >= 0.0)) { *why = "negative eps"; return OSOT_ERR_INVALID; }
+    int flat = 0;
+    for (int k = 0; k < p->n_levels; ++k) {
+        const osot_level_desc& lv = p->level[k];
+        if (lv.n_tasks < 1 || lv.n_tasks > OSOT_MAX_TASKS) { *why = "n_tasks out of range"; return OSOT_ERR_INVALID; }
+        flat += lv.n_tasks;
+        for (int j = 0; j < lv.n_tasks; ++j) {
+            const osot_task_desc& t = lv.task[j];
+            if (t.rows < 1) { *why = "task with no rows"; return OSOT_ERR_INVALID; }
+            switch (t.kind) {
+                case OSOT_TASK_GENERIC: break;
+                case OSOT_TASK_CARTESIAN: if (t.rows != 6) { *why = "Cartesian task must have 6 rows"; return OSOT_ERR_INVALID; } break;
+                case OSOT_TASK_COM: if (t.rows != 3) { *why = "CoM task must have 3 rows"; return OSOT_ERR_INVALID; } break;
+                case OSOT_TASK_POSTURAL:
+                    if (t.rows != p->n) { *why = "Postural task must have n rows"; return OSOT_ERR_INVALID; }
+                    if (j != lv.n_tasks - 1) { *why = "Postural must be the last block of its level"; return OSOT_ERR_UNSUPPORTED; }
+                    break;
+                default: *why = "unknown task kind"; return OSOT_ERR_UNSUPPORTED;
+            }
+            if (!(t.weight >= 0.0)) { *why = "negative task weight"; return OSOT_ERR_INVALID; }
+        }
+    }
+    if (flat > OSOT_KMAX_FLAT_TASKS) { *why = "too many leaf tasks in total"; return OSOT_ERR_UNSUPPORTED; }
+    for (int j = 0; j < p->n_bounds; ++j)
+        if (p->bound[j].kind < 0 || p->bound[j].kind > OSOT_BOUND_VELOCITY_LIMITS) { *why = "unknown bound kind"; return OSOT_ERR_UNSUPPORTED; }
+    for (int j = 0; j < p->n_rowblocks; ++j) {
+        if (p->rowblock[j].kind < 0 || p->rowblock[j].kind > OSOT_ROWS_COLLISION) { *why = "unknown row-block kind"; return OSOT_ERR_UNSUPPORTED; }
+        if (p->rowblock[j].rows < 1 || p->rowblock[j].rows > 256) { *why = "row block size out of range (1..256)"; return OSOT_ERR_INVALID; }
+    }
+    return OSOT_OK;
+}
+
+inline int lds_layout(int n, int T, int n_opt, int n_rows, int* opt_off, int* rowstate_off) {
+    const int S = n | 1;
+    int d = 2 * n * S + 4 * T;
+    *opt_off = d;
+    d += (n_opt > 0 ? n_opt : 1);
+    d = (d + 1) & ~1;
+    *rowstate_off = d;
+    d += ((n_rows > 0 ? n_rows : 1) + 1) / 2;
+    d = (d + 1) & ~1;
+    return d;
+}
+
+// returns OSOT_OK and fills P, the team width T (32/64) and the dynamic LDS bytes per 64-lane workgroup
+inline int make_dev_plan(const osot_plan_desc& p, const unsigned char* level_active, DevPlan& P, int& T,
+                         size_t& lds_bytes) {
+    std::memset(&P, 0, sizeof(P));
+    P.n = p.n;
+    P.S = p.n | 1;
+    P.L = p.n_levels;
+    plan_constraint_rows(&p, &P.nc);
+    P.optoff[0] = 0;
+    P.active_mask = 0;
+    for (int k = 0; k < p.n_levels; ++k) {
+        plan_level_rows(&p, k, &P.m[k], &P.ma[k]);
+        P.optoff[k + 1] = P.optoff[k] + P.m[k];
+        if (!level_active || level_active[k]) P.active_mask |= (1u << k);
+    }
+    const int nrows_max = P.nc + P.optoff[p.n_levels];
+    P.max_iter = p.max_iter > 0 ? p.max_iter : 20 * (p.n + nrows_max) + 100;
+    P.eps_abs = p.eps_abs;
+    T = (p.n <= 32) ? 32 : 64;
+    P.lds_team_doubles = lds_layout(p.n, T, P.optoff[p.n_levels], nrows_max, &P.lds_opt_off, &P.lds_rowstate_off);
+    lds_bytes = (size_t)(64 / T) * P.lds_team_doubles * sizeof(double);
+    return OSOT_OK;
+}
+
+}  // namespace osot

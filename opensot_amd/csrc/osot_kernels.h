@@ -1,0 +1,422 @@
+// osot_kernels.h -- the gfx950 kernels of the OpenSoT hot path.
+//
+//   osot_cascade_kernel<T> ... Solver::solve() = iHQP::solve (src/solvers/iHQP.cpp:263-358) for B
+//                              instances: per level  H = A'WA, g = -A'Wb + c  (iHQP.cpp:129-162),
+//                              constraints = global rows + optimality rows of the higher levels
+//                              (iHQP.cpp:282-333), one strictly convex QP (QPOasesBackEnd.cpp:248-307),
+//                              x of the last active level is the answer (iHQP.cpp:349).  All levels
+//                              run in ONE launch; H, its factor, J and the working set never leave LDS.
+//   osot_qp_kernel<T> ........ B generic QPs in BackEnd convention (BackEnd.h:125-150).
+//   osot_update_kernel ....... AutoStack::update() (src/utils/AutoStack.cpp:385-393): leaf -> b, W,
+//                              merged box, collision rows.  HBM-bound, one 64-lane block per instance.
+//
+// Mapping: a team of T lanes per instance (T = 32 for n <= 32: two instances per wavefront; T = 64 for
+// n <= 64), one wavefront per workgroup, instance-major fp64 arrays so a team's reads of its stacked
+// Jacobian rows are single contiguous 8n-byte segments.
+#pragma once
+#include "osot_qp_core.h"
+
+#define OSOT_KMAX_LEVELS 8
+#define OSOT_KMAX_TASKS 8
+#define OSOT_KMAX_FLAT_TASKS 24
+#define OSOT_KMAX_BOUNDS 4
+#define OSOT_KMAX_ROWBLOCKS 4
+
+namespace osot {
+
+struct DevPlan {
+    int n, S, L, nc;
+    int m[OSOT_KMAX_LEVELS];        // rows per level
+    int ma[OSOT_KMAX_LEVELS];       // rows stored in A_k (the rest is Postural's implicit identity)
+    int optoff[OSOT_KMAX_LEVELS + 1];  // prefix sums of m[]
+    int max_iter;
+    unsigned active_mask;           // bit k: level k active (iHQP::setActiveStack)
+    double eps_abs;
+    // LDS carve-up per team
+    int lds_team_doubles;           // doubles per team (M1, M2, V, opt) rounded so ints follow aligned
+    int lds_opt_off;                // offset (doubles) of the optimality right-hand sides
+    int lds_rowstate_off;           // offset (doubles) of the int rowstate array
+};
+
+struct DevBatch {
+    int B;
+    const double* A[OSOT_KMAX_LEVELS];
+    const double* b[OSOT_KMAX_LEVELS];
+    const double* w[OSOT_KMAX_LEVELS];
+    const double* c[OSOT_KMAX_LEVELS];
+    const double* C;
+    const double* lo;
+    const double* up;
+    const double* l;
+    const double* u;
+    double* dq;
+    double* x_levels;
+    int* status;
+    int* iterations;
+};
+
+// rows seen by level k: [ global C ; A_0 ; ... ; A_{k-1} ]  (iHQP.cpp:282-333)
+struct CascadeRows {
+    const DevPlan* P;
+    const DevBatch* D;
+    const double* opt;   // LDS: A_j x_j
+    long long inst;
+    __device__ __forceinline__ int level_of(int rr, int& q) const {
+        int j = 0;
+        while (rr >= P->optoff[j + 1]) ++j;
+        q = rr - P->optoff[j];
+        return j;
+    }
+    __device__ __forceinline__ double elem(int r, int lane) const {
+        const int n = P->n;
+        if (lane >= n) return 0.0;
+        if (r < P->nc) return D->C[(inst * P->nc + r) * n + lane];
+        int q;
+        const int j = level_of(r - P->nc, q);
+        if (!((P->active_mask >> j) & 1u)) return 0.0;           // inactive level: 0*x in [-1,1]
+        if (q < P->ma[j]) return D->A[j][(inst * P->ma[j] + q) * n + lane];
+        return (lane == q - P->ma[j]) ? 1.0 : 0.0;               // Postural identity row
+    }
+    __device__ __forceinline__ double lo(int r) const {
+        if (r < P->nc) return D->lo[inst * P->nc + r];
+        int q;
+        const int j = level_of(r - P->nc, q);
+        if (!((P->active_mask >> j) & 1u)) return -1.0;          // iHQP.cpp:301-309
+        return opt[r - P->nc];
+    }
+    __device__ __forceinline__ double up(int r) const {
+        if (r < P->nc) return D->up[inst * P->nc + r];
+        int q;
+        const int j = level_of(r - P->nc, q);
+        if (!((P->active_mask >> j) & 1u)) return 1.0;
+        return opt[r - P->nc];
+    }
+};
+
+template <int T>
+__global__ void __launch_bounds__(64) osot_cascade_kernel(const DevPlan P, const DevBatch D) {
+    OSOT_DYNAMIC_LDS(osot_smem);
+    constexpr int TPB = 64 / T;
+    const int team = threadIdx.x / T;
+    const int tl = threadIdx.x % T;
+    const long long inst = (long long)blockIdx.x * TPB + team;
+    if (inst >= D.B) return;
+    const int n = P.n, S = P.S;
+    double* base = reinterpret_cast<double*>(osot_smem) + (size_t)team * P.lds_team_doubles;
+    TeamCtx<T> c;
+    c.tl = tl; c.n = n; c.S = S;
+    c.M1 = base;
+    c.M2 = base + n * S;
+    c.V = base + 2 * n * S;
+    double* opt = base + P.lds_opt_off;
+    c.rowstate = reinterpret_cast<int*>(base + P.lds_rowstate_off);
+    const bool valid = tl < n;
+    double* V0 = c.V;
+
+    const bool has_box = D.l != nullptr;
+    const double lb = (has_box && valid) ? D.l[inst * n + tl] : -INFINITY;
+    const double ub = (has_box && valid) ? D.u[inst * n + tl] : INFINITY;
+
+    CascadeRows rows;
+    rows.P = &P; rows.D = &D; rows.opt = opt; rows.inst = inst;
+
+    double x = 0.0;
+    int status = QP_SOLVED;
+    int iters_total = 0;
+    bool any = false;
+    for (int k = 0; k < P.L; ++k) {
+        if (!((P.active_mask >> k) & 1u)) continue;
+        const int m = P.m[k], ma = P.ma[k];
+        // ---- H = A'WA + eps I (lane = column, accumulated in registers), g = -A'Wb + c ----------
+        double h[T];
+#pragma unroll
+        for (int i = 0; i < T; ++i) h[i] = 0.0;
+        double g = 0.0;
+        const double* Ak = D.A[k] ? D.A[k] + inst * ma * n : nullptr;
+        const double* bk = D.b[k] + inst * m;
+        const double* wk = D.w[k] ? D.w[k] + inst * m : nullptr;
+        for (int r = 0; r < ma; ++r) {
+            const double a = valid ? Ak[r * n + tl] : 0.0;
+            const double wr = wk ? wk[r] : 1.0;
+            const double br = bk[r];
+            double* Vr = V0 + (r & 1) * T;   // double-buffered staging row
+            Vr[tl] = a;
+            team_sync();
+            const double wa = wr * a;
+#pragma unroll
+            for (int i = 0; i < T; ++i) h[i] += wa * Vr[i];
+            g -= wa * br;
+        }
+        if (m > ma && valid) {   // Postural block: A = I (Postural.cpp:37)
+            const double wi = wk ? wk[ma + tl] : 1.0;
+            g -= wi * bk[ma + tl];
+#pragma unroll
+            for (int i = 0; i < T; ++i) if (i == tl) h[i] += wi;
+        }
+        if (D.c[k] && valid) g += D.c[k][inst * n + tl];
+        team_sync();
+        if (valid) {
+#pragma unroll
+            for (int i = 0; i < T; ++i) if (i < n) c.M1[i * S + tl] = h[i] + ((i == tl) ? P.eps_abs : 0.0);
+        }
+        team_sync();
+
+        const int nrows = P.nc + P.optoff[k];
+        int iters = 0;
+        const int st = gi_solve<T>(c, rows, nrows, g, has_box, lb, ub, P.max_iter, x, iters);
+        iters_total += iters;
+        if (st != QP_SOLVED) { status = st; break; }
+        any = true;
+        if (D.x_levels && valid) D.x_levels[(inst * P.L + k) * n + tl] = x;
+        // optimality right-hand sides A_k x_k for the lower levels (iHQP.cpp:164-170)
+        if (k + 1 < P.L) {
+            for (int q = 0; q < m; ++q) {
+                double a;
+                if (q < ma) a = valid ? Ak[q * n + tl] : 0.0;
+                else a = (tl == q - ma) ? 1.0 : 0.0;
+                const double v = team_sum<T>(a * x);
+                if (tl == 0) opt[P.optoff[k] + q] = v;
+            }
+            team_sync();
+        }
+    }
+    if (status != QP_SOLVED || !any) x = 0.0;   // failed instances return dq = 0 (coman_ik.cpp:189-190)
+    if (valid) D.dq[inst * n + tl] = x;
+    if (tl == 0) {
+        D.status[inst] = status;
+        if (D.iterations) D.iterations[inst] = iters_total;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// generic batched QP in BackEnd convention
+// ---------------------------------------------------------------------------------------------------
+struct DevQP {
+    int B, n, S, nc, max_iter;
+    double eps_abs;
+    const double* H;   // [B][n][n]
+    const double* g;   // [B][n]
+    const double* A;   // [B][nc][n]
+    const double* lA;
+    const double* uA;
+    const double* l;   // may be null
+    const double* u;
+    double* x;
+    int* status;
+    int* iterations;
+    int lds_team_doubles, lds_rowstate_off;
+};
+
+struct PlainRows {
+    const DevQP* Q;
+    long long inst;
+    __device__ __forceinline__ double elem(int r, int lane) const {
+        return lane < Q->n ? Q->A[(inst * Q->nc + r) * Q->n + lane] : 0.0;
+    }
+    __device__ __forceinline__ double lo(int r) const { return Q->lA[inst * Q->nc + r]; }
+    __device__ __forceinline__ double up(int r) const { return Q->uA[inst * Q->nc + r]; }
+};
+
+template <int T>
+__global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
+    OSOT_DYNAMIC_LDS(osot_smem);
+    constexpr int TPB = 64 / T;
+    const int team = threadIdx.x / T;
+    const int tl = threadIdx.x % T;
+    const long long inst = (long long)blockIdx.x * TPB + team;
+    if (inst >= Q.B) return;
+    const int n = Q.n, S = Q.S;
+    double* base = reinterpret_cast<double*>(osot_smem) + (size_t)team * Q.lds_team_doubles;
+    TeamCtx<T> c;
+    c.tl = tl; c.n = n; c.S = S;
+    c.M1 = base; c.M2 = base + n * S; c.V = base + 2 * n * S;
+    c.rowstate = reinterpret_cast<int*>(base + Q.lds_rowstate_off);
+    const bool valid = tl < n;
+    if (valid) {
+        const double* H = Q.H + inst * n * n;
+        for (int i = 0; i < n; ++i) c.M1[i * S + tl] = H[i * n + tl] + ((i == tl) ? Q.eps_abs : 0.0);
+    }
+    team_sync();
+    const double g = valid ? Q.g[inst * n + tl] : 0.0;
+    const bool has_box = Q.l != nullptr;
+    const double lb = (has_box && valid) ? Q.l[inst * n + tl] : -INFINITY;
+    const double ub = (has_box && valid) ? Q.u[inst * n + tl] : INFINITY;
+    PlainRows rows;
+    rows.Q = &Q; rows.inst = inst;
+    double x = 0.0;
+    int iters = 0;
+    const int st = gi_solve<T>(c, rows, Q.nc, g, has_box, lb, ub, Q.max_iter, x, iters);
+    if (valid) Q.x[inst * n + tl] = (st == QP_SOLVED) ? x : 0.0;
+    if (tl == 0) {
+        Q.status[inst] = st;
+        if (Q.iterations) Q.iterations[inst] = iters;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// AutoStack::update(): leaf inputs -> b, W diagonal, merged box, constraint rows
+// ---------------------------------------------------------------------------------------------------
+struct DevTask { int level, kind, rows, off; double weight, lambda, ogain; const double *p0, *p1, *p2; };
+struct DevBound { int kind; double scaling, dT; const double *p0, *p1, *p2; };
+struct DevRowBlock { int kind, rows, off; double d_threshold, detection_threshold, bound_scaling; const double *p0, *p1, *p2; };
+
+struct DevUpdate {
+    int B, n, L, nc;
+    int m[OSOT_KMAX_LEVELS];
+    int ntasks;                      // all levels, flat (kernel arguments are limited to 4 KB)
+    DevTask task[OSOT_KMAX_FLAT_TASKS];
+    int nbounds;
+    DevBound bound[OSOT_KMAX_BOUNDS];
+    int nrowblocks;
+    DevRowBlock rowblock[OSOT_KMAX_ROWBLOCKS];
+    double* b[OSOT_KMAX_LEVELS];
+    double* w[OSOT_KMAX_LEVELS];
+    double* C;
+    double* lo;
+    double* up;
+    double* l;
+    double* u;
+};
+
+// Eigen's Quaterniond(Matrix3d) as invoked by cartesian_utils::computeCartesianError
+// (src/utils/cartesian_utils.cpp:83-84); R row-major, q = (x, y, z, w)
+__device__ inline void rot_to_quat(const double* R, double* q) {
+    double t = R[0] + R[4] + R[8];
+    if (t > 0.0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (R[7] - R[5]) * t;
+        q[1] = (R[2] - R[6]) * t;
+        q[2] = (R[3] - R[1]) * t;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[i * 3 + i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0);
+        q[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t;
+        q[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+        q[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+    }
+}
+
+// velocity::Cartesian::update_b (src/tasks/velocity/Cartesian.cpp:279-285) with the quaternion error
+// of include/OpenSoT/utils/cartesian_utils.h:144-164; one lane computes the 6 entries
+__device__ inline void cartesian_b(const double* Ta, const double* Td, const double* twist,
+                                   double lambda, double ogain, double* b6) {
+    double q[4], qd[4];
+    rot_to_quat(Ta, q);
+    rot_to_quat(Td, qd);
+    const double dot = q[0] * qd[0] + q[1] * qd[1] + q[2] * qd[2] + q[3] * qd[3];
+    const double sg = (dot < 0.0) ? -1.0 : 1.0;
+    const double qx = sg * q[0], qy = sg * q[1], qz = sg * q[2], qw = sg * q[3];
+    double eo[3];
+    eo[0] = qd[3] * qx - qw * qd[0] + (-qd[2] * qy + qd[1] * qz);
+    eo[1] = qd[3] * qy - qw * qd[1] + (qd[2] * qx - qd[0] * qz);
+    eo[2] = qd[3] * qz - qw * qd[2] + (-qd[1] * qx + qd[0] * qy);
+    for (int i = 0; i < 3; ++i) {
+        const double tw_p = twist ? twist[i] : 0.0, tw_o = twist ? twist[3 + i] : 0.0;
+        b6[i] = tw_p + lambda * (Td[9 + i] - Ta[9 + i]);
+        b6[3 + i] = tw_o + lambda * (-ogain * eo[i]);
+    }
+}
+
+__global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
+    const long long inst = blockIdx.x;
+    const int t = threadIdx.x;
+    const int n = U.n;
+    if (inst >= U.B) return;
+    // ---- tasks: b and diag(W) (tasks::Aggregated::generateAll / generateWeight, Aggregated.cpp:113-132, 265-279)
+    {
+        for (int j = 0; j < U.ntasks; ++j) {
+            const DevTask& tk = U.task[j];
+            const int k = tk.level;
+            double* bk = U.b[k] + inst * U.m[k];
+            double* wk = U.w[k] ? U.w[k] + inst * U.m[k] : nullptr;
+            if (wk) for (int r = t; r < tk.rows; r += 64) wk[tk.off + r] = tk.weight;
+            if (tk.kind == 1) {           // Cartesian
+                if (t == 0) {
+                    double b6[6];
+                    cartesian_b(tk.p0 + inst * 12, tk.p1 + inst * 12, tk.p2 ? tk.p2 + inst * 6 : nullptr,
+                                tk.lambda, tk.ogain, b6);
+                    for (int i = 0; i < 6; ++i) bk[tk.off + i] = b6[i];
+                }
+            } else if (tk.kind == 2) {    // CoM (CoM.cpp:145-149)
+                if (t < 3) bk[tk.off + t] = (tk.p2 ? tk.p2[inst * 3 + t] : 0.0) +
+                                            tk.lambda * (tk.p1[inst * 3 + t] - tk.p0[inst * 3 + t]);
+            } else if (tk.kind == 3) {    // Postural (Postural.cpp:97-100)
+                for (int r = t; r < n; r += 64)
+                    bk[tk.off + r] = (tk.p2 ? tk.p2[inst * n + r] : 0.0) +
+                                     tk.lambda * (tk.p1[inst * n + r] - tk.p0[inst * n + r]);
+            } else {                      // Generic: b supplied
+                for (int r = t; r < tk.rows; r += 64) bk[tk.off + r] = tk.p0[inst * tk.rows + r];
+            }
+        }
+    }
+    // ---- box: min/max merge (constraints::Aggregated, Aggregated.cpp:141-148)
+    if (U.nbounds > 0) {
+        for (int i = t; i < n; i += 64) {
+            double l = 0.0, u = 0.0;
+            for (int j = 0; j < U.nbounds; ++j) {
+                const DevBound& bd = U.bound[j];
+                double l2, u2;
+                if (bd.kind == 1) {        // JointLimits.cpp:47-52
+                    const double q = bd.p0[inst * n + i];
+                    u2 = fmax((bd.p2[inst * n + i] - q) * bd.scaling, 0.0);
+                    l2 = fmin((bd.p1[inst * n + i] - q) * bd.scaling, 0.0);
+                } else if (bd.kind == 2) { // VelocityLimits.cpp:81-89
+                    const double v = fabs(bd.p0[inst * n + i]) * bd.dT;
+                    l2 = -1.0 * v; u2 = 1.0 * v;
+                } else { l2 = bd.p0[inst * n + i]; u2 = bd.p1[inst * n + i]; }
+                if (j == 0) { l = l2; u = u2; } else { u = fmin(u, u2); l = fmax(l, l2); }
+            }
+            U.l[inst * n + i] = l;
+            U.u[inst * n + i] = u;
+        }
+    }
+    // ---- global rows
+    for (int j = 0; j < U.nrowblocks; ++j) {
+        const DevRowBlock& rb = U.rowblock[j];
+        double* Cb = U.C + (inst * U.nc + rb.off) * n;
+        double* lob = U.lo + inst * U.nc + rb.off;
+        double* upb = U.up + inst * U.nc + rb.off;
+        if (rb.kind == 1) {   // CollisionAvoidance.cpp:96-152
+            const double* Jd = rb.p0 + inst * rb.rows * n;
+            const double* dist = rb.p1 + inst * rb.rows;
+            // compaction of the pairs within the detection threshold, in order
+            OSOT_STATIC_LDS(int, src_of_row, 256);
+            OSOT_STATIC_LDS(int, n_used_s, 1);
+            int& n_used = n_used_s[0];
+            if (t == 0) {
+                int row = 0;
+                for (int i = 0; i < rb.rows && row < rb.rows; ++i) {
+                    if (rb.detection_threshold > 0 && dist[i] > rb.detection_threshold) continue;
+                    src_of_row[row++] = i;
+                }
+                n_used = row;
+            }
+            __syncthreads();
+            for (int r = 0; r < rb.rows; ++r) {
+                const bool used = r < n_used;
+                const int src = used ? src_of_row[r] : 0;
+                for (int i = t; i < n; i += 64) Cb[r * n + i] = used ? -Jd[src * n + i] : 0.0;
+                if (t == 0) {
+                    if (used) {
+                        const double ub = rb.bound_scaling * (dist[src] - rb.d_threshold);
+                        upb[r] = ub < 0.0 ? 0.0 : ub;
+                    } else upb[r] = 1.7976931348623157e308;
+                    lob[r] = -1.7976931348623157e308;
+                }
+            }
+            __syncthreads();
+        } else {
+            for (int e = t; e < rb.rows * n; e += 64) Cb[e] = rb.p0[inst * rb.rows * n + e];
+            for (int r = t; r < rb.rows; r += 64) { lob[r] = rb.p1[inst * rb.rows + r]; upb[r] = rb.p2[inst * rb.rows + r]; }
+        }
+    }
+}
+
+}  // namespace osot

@@ -1,0 +1,114 @@
+"""Static stack plan: the result of OpenSoT's stack algebra, described once for B instances.
+
+Mirrors what `(com/(0.1*l_wrist + r_wrist)/postural) << jl << vl` builds in the reference
+(src/utils/AutoStack.cpp:7-331, examples/cpp/coman_ik.cpp:425-449): levels of leaf task blocks,
+box-bound producers and global constraint-row producers.  Pure description, no arithmetic.
+"""
+from dataclasses import dataclass, field
+from typing import List
+
+from . import abi
+
+EPS_BASE = 1.0e3 * 2.221e-16  # qpOASES Options.cpp:147 x Constants.hpp:50 (QPOasesBackEnd.cpp:57)
+
+
+def eps_abs_from_factor(factor: float) -> float:
+    """BackEndFactory's eps_regularisation factor -> absolute epsilon (QPOasesBackEnd.cpp:57,67)."""
+    return EPS_BASE * factor
+
+
+@dataclass
+class Task:
+    kind: int
+    rows: int
+    weight: float = 1.0
+    lam: float = 1.0
+    orientation_gain: float = 1.0
+    name: str = ""
+
+
+@dataclass
+class Bound:
+    kind: int
+    scaling: float = 1.0
+    dT: float = 0.0
+    name: str = ""
+
+
+@dataclass
+class Rows:
+    kind: int
+    rows: int
+    d_threshold: float = 0.0
+    detection_threshold: float = 0.0
+    bound_scaling: float = 1.0
+    name: str = ""
+
+
+@dataclass
+class StackPlan:
+    n: int
+    levels: List[List[Task]]
+    bounds: List[Bound] = field(default_factory=list)
+    rowblocks: List[Rows] = field(default_factory=list)
+    eps_abs: float = eps_abs_from_factor(2e2)  # iHQP default eps_regularisation (iHQP.h:32)
+    max_iter: int = 0
+
+    # ---- derived sizes -------------------------------------------------------------------
+    @property
+    def L(self):
+        return len(self.levels)
+
+    def m(self, k):
+        return sum(t.rows for t in self.levels[k])
+
+    def ma(self, k):
+        """rows of level k stored explicitly (Postural's identity block is implicit)."""
+        return sum(t.rows for t in self.levels[k] if t.kind != abi.TASK_POSTURAL)
+
+    @property
+    def nc(self):
+        return sum(r.rows for r in self.rowblocks)
+
+    def task_row_offset(self, k, j):
+        return sum(t.rows for t in self.levels[k][:j])
+
+    def rows_offset(self, j):
+        return sum(r.rows for r in self.rowblocks[:j])
+
+    def validate(self):
+        assert 1 <= self.n <= abi.MAX_VARS
+        assert 1 <= self.L <= abi.MAX_LEVELS
+        for lev in self.levels:
+            assert 1 <= len(lev) <= abi.MAX_TASKS
+            for j, t in enumerate(lev):
+                if t.kind == abi.TASK_POSTURAL:
+                    assert j == len(lev) - 1 and t.rows == self.n
+                if t.kind == abi.TASK_CARTESIAN:
+                    assert t.rows == 6
+                if t.kind == abi.TASK_COM:
+                    assert t.rows == 3
+        assert len(self.bounds) <= abi.MAX_BOUNDS and len(self.rowblocks) <= abi.MAX_ROWBLOCKS
+
+    def to_c(self) -> abi.PlanDesc:
+        self.validate()
+        p = abi.PlanDesc()
+        p.n = self.n
+        p.n_levels = self.L
+        for k, lev in enumerate(self.levels):
+            p.level[k].n_tasks = len(lev)
+            for j, t in enumerate(lev):
+                d = p.level[k].task[j]
+                d.kind, d.rows, d.weight, d.lambda_, d.orientation_gain = (
+                    t.kind, t.rows, t.weight, t.lam, t.orientation_gain)
+        p.n_bounds = len(self.bounds)
+        for j, b in enumerate(self.bounds):
+            p.bound[j].kind, p.bound[j].scaling, p.bound[j].dT = b.kind, b.scaling, b.dT
+        p.n_rowblocks = len(self.rowblocks)
+        for j, r in enumerate(self.rowblocks):
+            d = p.rowblock[j]
+            d.kind, d.rows, d.d_threshold, d.detection_threshold, d.bound_scaling = (
+                r.kind, r.rows, r.d_threshold, r.detection_threshold, r.bound_scaling)
+        p.eps_abs = self.eps_abs
+        p.max_iter = self.max_iter
+        return p

@@ -1,0 +1,229 @@
+"""Host-side mirror of the reference's per-cycle interface for B stacks at once.
+
+    stack.update()      -> BatchedStack.update(leaf)         (AutoStack::update, AutoStack.cpp:385-393)
+    solver.solve(dq)    -> BatchedStack.solve()              (iHQP::solve, iHQP.cpp:263-358)
+    BackEnd (one QP)    -> BackEnd class below               (BackEnd.h:23-171, same method names)
+
+All arithmetic happens in libosot_mi355x.so (HIP, gfx950) through the C-ABI of include/osot_mi355x.h.
+torch is used for device memory and streams only.  There is no CPU fallback: importing works without
+a GPU (so that host logic can be tested), but every compute call needs the HIP library and a device.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import abi
+from .plan import StackPlan
+
+
+def _dev_ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class BatchedStack:
+    """B independent instances of one static stack (same topology, different numbers)."""
+
+    def __init__(self, plan: StackPlan, max_batch: int, device: int = 0, want_levels: bool = True):
+        self.plan = plan
+        self.max_batch = int(max_batch)
+        self.device = torch.device("cuda", device)
+        self._lib = abi.lib()   # raises NativeLibraryMissing when the HIP extension is not built
+        self._cplan = plan.to_c()
+        h = C.c_void_p()
+        abi.check(self._lib.osot_solver_create(C.byref(self._cplan), self.max_batch, device, C.byref(h)),
+                  "osot_solver_create")
+        self._h = h
+        n, L, B = plan.n, plan.L, self.max_batch
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self.A = [torch.zeros((B, plan.ma(k), n), **f64) if plan.ma(k) else None for k in range(L)]
+        self.b = [torch.zeros((B, plan.m(k)), **f64) for k in range(L)]
+        self.w = [torch.ones((B, plan.m(k)), **f64) for k in range(L)]
+        self.c = [None] * L
+        nc = plan.nc
+        self.C = torch.zeros((B, nc, n), **f64) if nc else None
+        self.lo = torch.zeros((B, nc), **f64) if nc else None
+        self.up = torch.zeros((B, nc), **f64) if nc else None
+        self.l = torch.zeros((B, n), **f64) if plan.bounds else None
+        self.u = torch.zeros((B, n), **f64) if plan.bounds else None
+        self.dq = torch.zeros((B, n), **f64)
+        self.x_levels = torch.zeros((B, L, n), **f64) if want_levels else None
+        self.status = torch.zeros((B,), dtype=torch.int32, device=self.device)
+        self.iterations = torch.zeros((B,), dtype=torch.int32, device=self.device)
+        self._leaf_keep = None
+        self.level_active = None   # iHQP::setActiveStack (iHQP.cpp:391-395)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.osot_solver_destroy(h)
+            self._h = None
+
+    # ---- data movement helpers (plumbing) ------------------------------------------------------
+    def load_leaf(self, leaf):
+        """numpy leaf dict (opensot_amd.synth layout) -> device tensors; Jacobians go straight into
+        the stacked A_k buffers (zero-copy aggregation: the producer owns those row ranges)."""
+        B = leaf["B"]
+        assert B <= self.max_batch
+        to = lambda a: None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).to(self.device)
+        for k in range(self.plan.L):
+            if self.A[k] is not None:
+                self.A[k][:B].copy_(to(leaf["A"][k]))
+        dev = {"B": B,
+               "task": [[tuple(to(x) for x in t) for t in lev] for lev in leaf["task"]],
+               "bound": [tuple(to(x) for x in t) for t in leaf["bound"]],
+               "rows": [tuple(to(x) for x in t) for t in leaf["rows"]]}
+        return dev
+
+    def load_assembled(self, asm):
+        """numpy assembled dict (oracle layout) -> the device buffers; used by tests that by-pass update()."""
+        B = asm["B"]
+        for k in range(self.plan.L):
+            if self.A[k] is not None:
+                self.A[k][:B].copy_(torch.as_tensor(asm["A"][k]))
+            self.b[k][:B].copy_(torch.as_tensor(asm["b"][k]))
+            if asm["w"][k] is not None:
+                self.w[k][:B].copy_(torch.as_tensor(asm["w"][k]))
+        if self.C is not None:
+            self.C[:B].copy_(torch.as_tensor(asm["C"])); self.lo[:B].copy_(torch.as_tensor(asm["lo"]))
+            self.up[:B].copy_(torch.as_tensor(asm["up"]))
+        if self.l is not None:
+            self.l[:B].copy_(torch.as_tensor(asm["l"])); self.u[:B].copy_(torch.as_tensor(asm["u"]))
+        return B
+
+    # ---- AutoStack::update ------------------------------------------------------------------------
+    def update(self, dev_leaf):
+        lb = abi.LeafBatch()
+        lb.B = dev_leaf["B"]
+        for k, lev in enumerate(dev_leaf["task"]):
+            for j, (p0, p1, p2) in enumerate(lev):
+                lp = lb.task[k][j]
+                lp.p0, lp.p1, lp.p2 = _dev_ptr(p0), _dev_ptr(p1), _dev_ptr(p2)
+        for j, (p0, p1, p2) in enumerate(dev_leaf["bound"]):
+            lb.bound[j].p0, lb.bound[j].p1, lb.bound[j].p2 = _dev_ptr(p0), _dev_ptr(p1), _dev_ptr(p2)
+        for j, (p0, p1, p2) in enumerate(dev_leaf["rows"]):
+            lb.rows[j].p0, lb.rows[j].p1, lb.rows[j].p2 = _dev_ptr(p0), _dev_ptr(p1), _dev_ptr(p2)
+        out = abi.AssembledOut()
+        for k in range(self.plan.L):
+            out.b[k] = _dev_ptr(self.b[k]); out.w[k] = _dev_ptr(self.w[k])
+        out.C, out.lo, out.up = _dev_ptr(self.C), _dev_ptr(self.lo), _dev_ptr(self.up)
+        out.l, out.u = _dev_ptr(self.l), _dev_ptr(self.u)
+        self._leaf_keep = dev_leaf
+        abi.check(self._lib.osot_stack_update(self._h, C.byref(lb), C.byref(out), _stream_ptr(self.device)),
+                  "osot_stack_update")
+        return lb.B
+
+    # ---- Solver::solve ------------------------------------------------------------------------------
+    def _qp_batch(self, B):
+        qb = abi.QpBatch()
+        qb.B = B
+        for k in range(self.plan.L):
+            qb.A[k] = _dev_ptr(self.A[k]); qb.b[k] = _dev_ptr(self.b[k])
+            qb.w[k] = _dev_ptr(self.w[k]); qb.c[k] = _dev_ptr(self.c[k])
+        qb.C, qb.lo, qb.up = _dev_ptr(self.C), _dev_ptr(self.lo), _dev_ptr(self.up)
+        qb.l, qb.u = _dev_ptr(self.l), _dev_ptr(self.u)
+        qb.dq, qb.x_levels = _dev_ptr(self.dq), _dev_ptr(self.x_levels)
+        qb.status, qb.iterations = _dev_ptr(self.status), _dev_ptr(self.iterations)
+        if self.level_active is not None:
+            self._act = (C.c_ubyte * self.plan.L)(*[1 if a else 0 for a in self.level_active])
+            qb.level_active = C.cast(self._act, C.c_void_p)
+        return qb
+
+    def solve(self, B):
+        """stream-ordered; results in self.dq[:B], self.status[:B] (device)."""
+        qb = self._qp_batch(B)
+        abi.check(self._lib.osot_ihqp_solve(self._h, C.byref(qb), _stream_ptr(self.device)), "osot_ihqp_solve")
+
+    def set_timing(self, on):
+        abi.check(self._lib.osot_solver_set_timing(self._h, 1 if on else 0), "osot_solver_set_timing")
+
+    def kernel_time_ms(self, reset=True):
+        avg = C.c_double(0.0); cnt = C.c_int(0)
+        abi.check(self._lib.osot_solver_kernel_time_ms(self._h, 1 if reset else 0, C.byref(avg), C.byref(cnt)),
+                  "osot_solver_kernel_time_ms")
+        return avg.value, cnt.value
+
+
+class BackEnd:
+    """OpenSoT::solvers::BackEnd for one QP (include/OpenSoT/solvers/BackEnd.h), same method names and
+    bool returns; matrices are numpy row-major.  `eps_regularisation` is the factory's FACTOR
+    (BackEndFactory.cpp:4-17)."""
+
+    def __init__(self, number_of_variables, number_of_constraints, hessian_type=abi.HST_SEMIDEF,
+                 eps_regularisation=2e2):
+        self._lib = abi.lib()
+        h = C.c_void_p()
+        abi.check(self._lib.osot_backend_create(number_of_variables, number_of_constraints, hessian_type,
+                                                eps_regularisation, C.byref(h)), "osot_backend_create")
+        self._h = h
+        self.nv = number_of_variables
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.osot_backend_destroy(h)
+            self._h = None
+
+    @staticmethod
+    def _p(a):
+        if a is None:
+            return None, None
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.size == 0:
+            return a, None
+        return a, a.ctypes.data_as(abi.dp)
+
+    def initProblem(self, H, g, A, lA, uA, l, u):
+        ks = [self._p(a) for a in (H, g, A, lA, uA, l, u)]
+        nc = C.c_int(0)
+        self._lib.osot_backend_get_num_constraints(self._h, C.byref(nc))
+        rows = 0 if ks[2][0] is None else (ks[2][0].shape[0] if ks[2][0].ndim == 2 else 0)
+        if rows != nc.value:
+            return False   # "A.rows() != _A.rows()" (QPOasesBackEnd.cpp:91-94)
+        return self._lib.osot_backend_init_problem(self._h, *[k[1] for k in ks]) == abi.OK
+
+    def updateTask(self, H, g):
+        (H_, hp), (g_, gp) = self._p(H), self._p(g)
+        if H_.shape != (self.nv, self.nv) or g_.shape[0] != self.nv:
+            return False   # BackEnd.cpp:23-41
+        return self._lib.osot_backend_update_task(self._h, hp, gp) == abi.OK
+
+    def updateConstraints(self, A, lA, uA):
+        (A_, ap), (l_, lp), (u_, up) = self._p(A), self._p(lA), self._p(uA)
+        rows = A_.shape[0] if A_ is not None and A_.ndim == 2 else 0
+        if rows and A_.shape[1] != self.nv:
+            return False
+        if (l_ is not None and l_.shape[0] != rows) or (u_ is not None and u_.shape[0] != rows):
+            return False   # BackEnd.cpp:47-60
+        return self._lib.osot_backend_update_constraints(self._h, ap, lp, up, rows) == abi.OK
+
+    def updateBounds(self, l, u):
+        (l_, lp), (u_, up) = self._p(l), self._p(u)
+        if l_ is not None and (l_.shape[0] != self.nv or u_.shape[0] != self.nv):
+            return False
+        return self._lib.osot_backend_update_bounds(self._h, lp, up) == abi.OK
+
+    def solve(self):
+        return self._lib.osot_backend_solve(self._h) == abi.OK
+
+    def getSolution(self):
+        x = np.zeros(self.nv)
+        self._lib.osot_backend_get_solution(self._h, x.ctypes.data_as(abi.dp))
+        return x
+
+    def getObjective(self):
+        f = C.c_double(0.0)
+        self._lib.osot_backend_get_objective(self._h, C.byref(f))
+        return f.value
+
+    def getEpsRegularisation(self):
+        e = C.c_double(0.0)
+        self._lib.osot_backend_get_eps_regularisation(self._h, C.byref(e))
+        return e.value
+
+    def setEpsRegularisation(self, eps):
+        return self._lib.osot_backend_set_eps_regularisation(self._h, eps) == abi.OK

@@ -1,0 +1,151 @@
+"""Seeded synthetic humanoid stacks for the BASELINE.json configurations.
+
+Produces (StackPlan, leaf) where `leaf` holds the per-instance inputs that the reference obtains from
+XBot::ModelInterface (Jacobians, poses, CoM, q) plus references and limits, as numpy fp64 arrays.
+No solving happens here.  There is no robot model on this path (xbot2_interface is un-vendored):
+Jacobians are N(0, 0.3^2) with kinematic-chain sparsity, poses are random rigid transforms.
+
+leaf layout (all instance-major):
+  leaf["A"][k]            : [B][ma_k][n]   stacked task Jacobians of level k (Postural rows implicit)
+  leaf["task"][k][j]      : (p0, p1, p2)   per osot_leaf_ptrs in include/osot_mi355x.h
+  leaf["bound"][j]        : (p0, p1, p2)
+  leaf["rows"][j]         : (p0, p1, p2)
+"""
+import numpy as np
+
+from . import abi
+from .plan import Bound, Rows, StackPlan, Task, eps_abs_from_factor
+
+# 32-DoF humanoid column map: 6 floating-base + 7 + 7 (arms) + 6 + 6 (legs)
+_BASE = list(range(0, 6))
+_LIMBS = {
+    "l_arm": list(range(6, 13)),
+    "r_arm": list(range(13, 20)),
+    "l_leg": list(range(20, 26)),
+    "r_leg": list(range(26, 32)),
+}
+
+
+def _rot_exp(w):
+    """Rodrigues: exp([w]x) for w [..., 3] -> [..., 3, 3]."""
+    th = np.linalg.norm(w, axis=-1, keepdims=True)
+    th = np.where(th < 1e-12, 1e-12, th)
+    k = w / th
+    K = np.zeros(w.shape[:-1] + (3, 3))
+    K[..., 0, 1], K[..., 0, 2] = -k[..., 2], k[..., 1]
+    K[..., 1, 0], K[..., 1, 2] = k[..., 2], -k[..., 0]
+    K[..., 2, 0], K[..., 2, 1] = -k[..., 1], k[..., 0]
+    s, c = np.sin(th)[..., None], np.cos(th)[..., None]
+    return np.eye(3) + s * K + (1 - c) * (K @ K)
+
+
+def _pose(R, p):
+    return np.concatenate([R.reshape(R.shape[0], 9), p], axis=1)
+
+
+def _limb_jacobian(rng, B, rows, n, cols):
+    J = np.zeros((B, rows, n))
+    J[:, :, cols] = rng.normal(0.0, 0.3, size=(B, rows, len(cols)))
+    return J
+
+
+def _cartesian_leaf(rng, B):
+    R = _rot_exp(rng.normal(0.0, 0.2, size=(B, 3)))
+    p = rng.uniform(-1.0, 1.0, size=(B, 3))
+    dth = rng.normal(size=(B, 3))
+    dth *= (rng.uniform(0.0, 0.1, size=(B, 1)) / np.linalg.norm(dth, axis=1, keepdims=True))
+    dp = rng.normal(size=(B, 3))
+    dp *= (rng.uniform(0.0, 0.05, size=(B, 1)) / np.linalg.norm(dp, axis=1, keepdims=True))
+    Rd = R @ _rot_exp(dth)
+    pd = p + dp
+    return _pose(R, p), _pose(Rd, pd), None
+
+
+def _box_leaf(rng, B, n, jl=True, vl=True):
+    bounds, leaf = [], []
+    if jl:
+        half = rng.uniform(0.5, 2.5, size=(B, n))
+        qmin, qmax = -half, half
+        q = rng.uniform(qmin, qmax)
+        # some joints sit close to a limit so that the joint-limit side of the box binds
+        near = rng.random((B, n)) < 0.1
+        q = np.where(near, qmax - rng.uniform(0.0, 0.01, size=(B, n)), q)
+        bounds.append(Bound(abi.BOUND_JOINT_LIMITS, scaling=1.0, name="joint_limits"))
+        leaf.append((q, qmin, qmax))
+    if vl:
+        bounds.append(Bound(abi.BOUND_VELOCITY_LIMITS, dT=0.01, name="velocity_limits"))
+        leaf.append((np.full((B, n), 2.0), None, None))
+    return bounds, leaf
+
+
+def make_velocity_stack(config, B, seed=None, n=32, eps_factor=1e6, P=16):
+    """config in {"C2", "C3", "C4"}; returns (plan, leaf)."""
+    assert n == 32, "the synthetic humanoid column map is 32-DoF"
+    cfg_id = {"C2": 2, "C3": 3, "C4": 4}[config]
+    rng = np.random.default_rng(1000 * cfg_id if seed is None else seed)
+
+    def cart(name, limb, weight=1.0, lam=0.1):
+        t = Task(abi.TASK_CARTESIAN, 6, weight=weight, lam=lam, name=name)
+        J = _limb_jacobian(rng, B, 6, n, _BASE + _LIMBS[limb])
+        return t, J, _cartesian_leaf(rng, B)
+
+    def com(lam=0.1):
+        t = Task(abi.TASK_COM, 3, lam=lam, name="com")
+        J = rng.normal(0.0, 0.3, size=(B, 3, n))
+        p = rng.uniform(-0.2, 0.2, size=(B, 3))
+        pd = p + rng.uniform(-0.05, 0.05, size=(B, 3))
+        return t, J, (p, pd, None)
+
+    def postural(weight=1.0, lam=0.01, q=None):
+        t = Task(abi.TASK_POSTURAL, n, weight=weight, lam=lam, name="postural")
+        qq = rng.uniform(-1.0, 1.0, size=(B, n)) if q is None else q
+        qd = qq + rng.normal(0.0, 0.1, size=(B, n))
+        return t, None, (qq, qd, None)
+
+    if config == "C2":
+        # one level, soft priorities (cf. coman_ik.cpp:429): r_wrist + 1e-4*postural, joint-limit box
+        bounds, bleaf = _box_leaf(rng, B, n, jl=True, vl=False)
+        blocks = [[cart("r_wrist", "r_arm", lam=1.0), postural(weight=1e-4, lam=1.0, q=bleaf[0][0])]]
+        rowblocks, rleaf = [], []
+    else:
+        bounds, bleaf = _box_leaf(rng, B, n, jl=True, vl=True)
+        blocks = [
+            [com()],
+            [cart("l_wrist", "l_arm", weight=0.1), cart("r_wrist", "r_arm"),
+             cart("l_sole", "l_leg"), cart("r_sole", "r_leg")],
+            [postural(q=bleaf[0][0])],
+        ]
+        rowblocks, rleaf = [], []
+        if config == "C4":
+            # self-collision rows (CollisionAvoidance.cpp:96-152): P candidate pairs sorted by distance,
+            # about 30 % beyond the detection threshold (-> unused zero rows)
+            Jd = np.zeros((B, P, n))
+            for r in range(P):
+                cols = rng.choice(np.arange(6, n), size=14, replace=False)
+                Jd[:, r, cols] = rng.normal(0.0, 0.3, size=(B, 14))
+            d = np.sort(rng.uniform(0.0, 0.072, size=(B, P)), axis=1)
+            rowblocks.append(Rows(abi.ROWS_COLLISION, P, d_threshold=0.0, detection_threshold=0.05,
+                                  bound_scaling=1.0, name="self_collision"))
+            rleaf.append((Jd, d, None))
+
+    levels, A, tleaf = [], [], []
+    for lev in blocks:
+        levels.append([t for (t, _, _) in lev])
+        Js = [J for (_, J, _) in lev if J is not None]
+        A.append(np.ascontiguousarray(np.concatenate(Js, axis=1)) if Js else None)
+        tleaf.append([lf for (_, _, lf) in lev])
+    plan = StackPlan(n=n, levels=levels, bounds=bounds, rowblocks=rowblocks,
+                     eps_abs=eps_abs_from_factor(eps_factor))
+    leaf = {"B": B, "A": A, "task": tleaf, "bound": bleaf, "rows": rleaf}
+    return plan, leaf
+
+
+def perturb(leaf, rng, scale=0.01):
+    """temporally coherent next cycle: every float input moves by ~1 % (MPC-rollout-like)."""
+    def j(a):
+        return None if a is None else a * (1.0 + scale * rng.standard_normal(a.shape))
+    out = {"B": leaf["B"], "A": [j(a) for a in leaf["A"]],
+           "task": [[tuple(j(x) for x in t) for t in lev] for lev in leaf["task"]],
+           "bound": [tuple(j(x) for x in t) for t in leaf["bound"]],
+           "rows": [tuple(j(x) for x in t) for t in leaf["rows"]]}
+    return out

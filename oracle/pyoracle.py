@@ -1,0 +1,242 @@
+"""oracle/pyoracle.py -- TEST INFRASTRUCTURE ONLY.
+
+ctypes view of oracle/liboracle.so (the plain-C restatement, oracle/osot_oracle.c).  Imported by
+tests/, tests/golden/make_golden.py, __graft_entry__.smoke() and bench.py's cpu_baseline leg --
+never by opensot_amd.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+_REF_SO = os.path.join(_HERE, "_ref", "libqpoases_ref.so")
+ORC_MAX_LEVELS = 8
+BE_EIQP_REFFORM, BE_EIQP_EQ, BE_QPOASES_REF = 0, 1, 2
+INFTY = 1.0e20
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int)
+
+# kinds, duplicated from include/osot_mi355x.h on purpose (the oracle must not import the product)
+TASK_GENERIC, TASK_CARTESIAN, TASK_COM, TASK_POSTURAL = range(4)
+BOUND_GENERIC, BOUND_JOINT_LIMITS, BOUND_VELOCITY_LIMITS = range(3)
+ROWS_GENERIC, ROWS_COLLISION = range(2)
+
+
+class OrcBatch(C.Structure):
+    _fields_ = [("n", C.c_int), ("L", C.c_int), ("B", C.c_int),
+                ("m", C.c_int * ORC_MAX_LEVELS), ("ma", C.c_int * ORC_MAX_LEVELS),
+                ("A", dp * ORC_MAX_LEVELS), ("b", dp * ORC_MAX_LEVELS),
+                ("w", dp * ORC_MAX_LEVELS), ("c", dp * ORC_MAX_LEVELS),
+                ("nc", C.c_int), ("C", dp), ("lo", dp), ("up", dp), ("l", dp), ("u", dp),
+                ("eps_abs", C.c_double), ("active", C.POINTER(C.c_ubyte))]
+
+
+_lib = None
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/external/qpOASES-ext/src") and (force or not os.path.exists(_REF_SO)):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+def ref_available():
+    return os.path.exists(_REF_SO)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.orc_eiquadprog.restype = C.c_double
+        L.orc_eiquadprog.argtypes = [C.c_int, dp, dp, C.c_int, dp, dp, C.c_int, dp, dp, dp, C.c_double, ip, ip, ip]
+        L.orc_backend_solve.argtypes = [C.c_int, C.c_int, dp, dp, C.c_int, dp, dp, dp, dp, dp, C.c_double, dp, ip]
+        L.orc_cost_function.argtypes = [C.POINTER(OrcBatch), C.c_int, C.c_int, dp, dp]
+        L.orc_ihqp_solve.argtypes = [C.POINTER(OrcBatch), C.c_int, C.c_int, C.c_void_p, dp, dp, ip]
+        L.orc_ihqp_solve_batch.restype = C.c_double
+        L.orc_ihqp_solve_batch.argtypes = [C.POINTER(OrcBatch), C.c_int, C.c_int, C.c_int, dp, dp, ip,
+                                           C.POINTER(C.c_longlong)]
+        L.orc_ref_load.argtypes = [C.c_char_p]
+        L.orc_ref_configure.argtypes = [C.c_double, C.c_double]
+        L.orc_rot_to_quat.argtypes = [dp, dp]
+        L.orc_cartesian_error.argtypes = [dp, dp, dp, dp, dp, dp]
+        L.orc_cartesian_b.argtypes = [dp, dp, dp, dp, dp, C.c_double, C.c_double, dp]
+        L.orc_com_b.argtypes = [dp, dp, dp, C.c_double, dp]
+        L.orc_postural_b.argtypes = [C.c_int, dp, dp, dp, C.c_double, dp]
+        L.orc_joint_limits.argtypes = [C.c_int, dp, dp, dp, C.c_double, dp, dp]
+        L.orc_velocity_limits.argtypes = [C.c_int, dp, C.c_double, dp, dp]
+        L.orc_merge_box.argtypes = [C.c_int, dp, dp, dp, dp]
+        L.orc_collision_rows.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp, C.c_double, C.c_double,
+                                         C.c_double, dp, dp, dp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(dp)
+
+
+def _c(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+# --------------------------------------------------------------------------------------------
+# AutoStack::update restatement: leaf -> assembled arrays
+# --------------------------------------------------------------------------------------------
+def assemble(plan, leaf):
+    """plan: any object with .n, .levels (lists of tasks with kind/rows/weight/lam/orientation_gain),
+    .bounds, .rowblocks, .eps_abs; leaf: dict from opensot_amd.synth.  Returns the assembled dict."""
+    L = lib()
+    n, B = plan.n, leaf["B"]
+    out = {"n": n, "B": B, "L": len(plan.levels), "eps_abs": plan.eps_abs,
+           "m": [], "ma": [], "A": [], "b": [], "w": [], "c": []}
+    zeros6 = np.zeros(6)
+    zerosn = np.zeros(n)
+    for k, lev in enumerate(plan.levels):
+        m = sum(t.rows for t in lev)
+        ma = sum(t.rows for t in lev if t.kind != TASK_POSTURAL)
+        b = np.zeros((B, m))
+        w = np.ones((B, m))
+        off = 0
+        for j, t in enumerate(lev):
+            p0, p1, p2 = (_c(x) for x in leaf["task"][k][j])
+            w[:, off:off + t.rows] = t.weight   # scalar * W (AutoStack.cpp:16-47), W = I by default
+            for i in range(B):
+                bi = b[i, off:off + t.rows]
+                if t.kind == TASK_CARTESIAN:
+                    tw = p2[i] if p2 is not None else zeros6
+                    L.orc_cartesian_b(_p(p0[i, :9]), _p(p0[i, 9:]), _p(p1[i, :9]), _p(p1[i, 9:]),
+                                      _p(tw), t.lam, t.orientation_gain, _p(bi))
+                elif t.kind == TASK_COM:
+                    L.orc_com_b(_p(p0[i]), _p(p1[i]), _p(p2[i] if p2 is not None else zeros6[:3]),
+                                t.lam, _p(bi))
+                elif t.kind == TASK_POSTURAL:
+                    L.orc_postural_b(n, _p(p0[i]), _p(p1[i]), _p(p2[i] if p2 is not None else zerosn),
+                                     t.lam, _p(bi))
+                else:  # GENERIC: b supplied (GenericTask.cpp:5-56)
+                    bi[:] = p0[i]
+            off += t.rows
+        out["m"].append(m); out["ma"].append(ma)
+        out["A"].append(_c(leaf["A"][k]) if ma else None)
+        out["b"].append(b); out["w"].append(w); out["c"].append(None)
+    # box (constraints::Aggregated, Aggregated.cpp:141-148)
+    if plan.bounds:
+        l = np.full((B, n), -np.inf)
+        u = np.full((B, n), np.inf)
+        l2 = np.zeros(n); u2 = np.zeros(n)
+        for j, bd in enumerate(plan.bounds):
+            p0, p1, p2 = (_c(x) for x in leaf["bound"][j])
+            for i in range(B):
+                if bd.kind == BOUND_JOINT_LIMITS:
+                    L.orc_joint_limits(n, _p(p0[i]), _p(p1[i]), _p(p2[i]), bd.scaling, _p(l2), _p(u2))
+                elif bd.kind == BOUND_VELOCITY_LIMITS:
+                    L.orc_velocity_limits(n, _p(p0[i]), bd.dT, _p(l2), _p(u2))
+                else:
+                    l2[:] = p0[i]; u2[:] = p1[i]
+                if j == 0:
+                    l[i] = l2; u[i] = u2
+                else:
+                    L.orc_merge_box(n, _p(l[i]), _p(u[i]), _p(l2), _p(u2))
+        out["l"], out["u"] = l, u
+    else:
+        out["l"] = out["u"] = None
+    # global rows
+    nc = sum(r.rows for r in plan.rowblocks)
+    out["nc"] = nc
+    if nc:
+        Cm = np.zeros((B, nc, n)); lo = np.zeros((B, nc)); up = np.zeros((B, nc))
+        off = 0
+        for j, rb in enumerate(plan.rowblocks):
+            p0, p1, p2 = (_c(x) for x in leaf["rows"][j])
+            for i in range(B):
+                if rb.kind == ROWS_COLLISION:
+                    Ci = np.zeros((rb.rows, n)); loi = np.zeros(rb.rows); upi = np.zeros(rb.rows)
+                    L.orc_collision_rows(n, rb.rows, rb.rows, _p(p0[i]), _p(p1[i]), rb.d_threshold,
+                                         rb.detection_threshold, rb.bound_scaling, _p(Ci), _p(loi), _p(upi))
+                    Cm[i, off:off + rb.rows] = Ci; lo[i, off:off + rb.rows] = loi; up[i, off:off + rb.rows] = upi
+                else:
+                    Cm[i, off:off + rb.rows] = p0[i]; lo[i, off:off + rb.rows] = p1[i]; up[i, off:off + rb.rows] = p2[i]
+            off += rb.rows
+        out["C"], out["lo"], out["up"] = Cm, lo, up
+    else:
+        out["C"] = out["lo"] = out["up"] = None
+    return out
+
+
+def _orc_batch(asm, active=None, sl=None):
+    """build the C struct; returns (struct, keepalive)."""
+    P = OrcBatch()
+    keep = []
+    B = asm["B"]
+    s = slice(0, B) if sl is None else sl
+
+    def take(a):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a[s], dtype=np.float64)
+        keep.append(a)
+        return _p(a)
+
+    P.n, P.L = asm["n"], asm["L"]
+    P.B = len(range(*s.indices(B)))
+    for k in range(asm["L"]):
+        P.m[k], P.ma[k] = asm["m"][k], asm["ma"][k]
+        P.A[k] = take(asm["A"][k]); P.b[k] = take(asm["b"][k])
+        P.w[k] = take(asm["w"][k]); P.c[k] = take(asm["c"][k])
+    P.nc = asm["nc"]
+    P.C, P.lo, P.up = take(asm["C"]), take(asm["lo"]), take(asm["up"])
+    P.l, P.u = take(asm["l"]), take(asm["u"])
+    P.eps_abs = asm["eps_abs"]
+    if active is not None:
+        act = (C.c_ubyte * asm["L"])(*[1 if a else 0 for a in active])
+        keep.append(act)
+        P.active = act
+    return P, keep
+
+
+def cost_function(asm, inst, k):
+    P, keep = _orc_batch(asm)
+    n = asm["n"]
+    H = np.zeros((n, n)); g = np.zeros(n)
+    lib().orc_cost_function(C.byref(P), inst, k, _p(H), _p(g))
+    return H, g
+
+
+def ihqp_solve_batch(asm, backend=BE_EIQP_EQ, nthreads=0, cycles=1, active=None, sl=None,
+                     eps_factor=None, termination_tolerance=0.0):
+    """returns dict(dq [B][n], x_levels [B][L][n], status [B], seconds, iterations)."""
+    L = lib()
+    if backend == BE_QPOASES_REF:
+        if not L.orc_ref_load(_REF_SO.encode()):
+            raise RuntimeError("oracle/_ref/libqpoases_ref.so not available")
+        if eps_factor is None:
+            eps_factor = asm["eps_abs"] / (1.0e3 * 2.221e-16)
+        L.orc_ref_configure(eps_factor, termination_tolerance)
+    P, keep = _orc_batch(asm, active, sl)
+    B, n, Ln = P.B, asm["n"], asm["L"]
+    dq = np.zeros((B, n)); xl = np.zeros((B, Ln, n))
+    status = np.zeros(B, dtype=np.int32)
+    it = C.c_longlong(0)
+    if nthreads <= 0:
+        nthreads = os.cpu_count() or 1
+    sec = L.orc_ihqp_solve_batch(C.byref(P), backend, nthreads, cycles, _p(dq), _p(xl),
+                                 status.ctypes.data_as(ip), C.byref(it))
+    return {"dq": dq, "x_levels": xl, "status": status, "seconds": sec, "iterations": it.value,
+            "threads": nthreads}
+
+
+def backend_solve(H, g, A, lA, uA, l, u, eps_abs, form=BE_EIQP_EQ):
+    """one QP in BackEnd convention through the restated Goldfarb-Idnani routine."""
+    H, g, A, lA, uA, l, u = map(_c, (H, g, A, lA, uA, l, u))
+    n = g.shape[0]
+    nc = 0 if A is None else A.shape[0]
+    x = np.zeros(n)
+    it = C.c_int(0)
+    ok = lib().orc_backend_solve(form, n, _p(H), _p(g), nc, _p(A), _p(lA), _p(uA), _p(l), _p(u),
+                                 eps_abs, _p(x), C.byref(it))
+    return bool(ok), x, it.value
