@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- whole-body QP solves/s of the MI355X hot path (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one resident batch: AutoStack::update (leaf -> b, W, box,
+rows) + the 3-level iHQP cascade (H/g assembly + one QP per level) for every instance of the shard.
+Workload at N=1: BASELINE.json configs[2], batch 4096 x 32-DoF, 3 levels (CoM / 4 Cartesian / Postural),
+joint-limit and velocity-limit box, eps factor 1e6 (the reference benchmark's value, coman_ik.cpp:453).
+N>1: weak scaling, 4096 instances per GPU, instances sharded contiguously over ranks (no data-path
+collective: they are independent), one RCCL all-gather of the solved dq shards per step.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+# algorithmic figures per instance-solve for the C3 stack (formulas restated in DESIGN.md)
+ALGO_BYTES_PER_SOLVE_C3 = (3 + 24) * 32 * 8 + 59 * 8 + 59 * 8 + 2 * 32 * 8 + 32 * 8   # A rows + b + w + box + dq
+FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (AMD public spec; not in MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algo_flops_per_solve(plan):
+    """nominal flops of one cascade (SURVEY.md 8d formulas): per level symmetric H build m n (n+1),
+    g 2 m n, Cholesky n^3/3, two triangular solves 2 n^2, Schur on c equality rows c n^2 + c^2 n + c^3/3
+    + 2 c n + 2 c^2, plus 2 m_j n for each optimality right-hand side."""
+    n = plan.n
+    total = 0.0
+    c = plan.nc
+    for k in range(plan.L):
+        m = plan.m(k)
+        total += m * n * (n + 1) + 2 * m * n + n ** 3 / 3.0 + 2 * n * n
+        total += c * n * n + c * c * n + c ** 3 / 3.0 + 2 * c * n + 2 * c * c
+        if k + 1 < plan.L:
+            total += 2 * m * n
+        c += m
+    return total
+
+
+def cpu_baseline(plan, leaf_sample, seconds_target=12.0):
+    """CPU path timed on this host: the reference's own qpOASES (oracle/_ref, kind 'reference') when the
+    prebuilt library is present, otherwise the plain-C port (kind 'port'); restated cascade around it."""
+    from oracle import pyoracle as po
+    asm = po.assemble(plan, leaf_sample)
+    cores = os.cpu_count() or 1
+    kind, be = ("reference", po.BE_QPOASES_REF) if po.ref_available() else ("port", po.BE_EIQP_EQ)
+    try:
+        r = po.ihqp_solve_batch(asm, be, nthreads=cores, cycles=1)
+    except Exception:
+        kind, be = "port", po.BE_EIQP_EQ
+        r = po.ihqp_solve_batch(asm, be, nthreads=cores, cycles=1)
+    per_cycle = max(r["seconds"], 1e-6)
+    cycles = int(max(1, min(200, seconds_target / per_cycle)))
+    r = po.ihqp_solve_batch(asm, be, nthreads=cores, cycles=cycles)
+    B = asm["B"]
+    return {"value": B * cycles / r["seconds"], "unit": "solves/s", "cores": cores, "kind": kind,
+            "sample": f"{B} instances of the same C3 stack x {cycles} cycles, {cores} host threads "
+                      f"({'qpOASES 3.1 hot-started across cycles' if kind == 'reference' else 'C Goldfarb-Idnani port'}), "
+                      f"{r['seconds']:.1f} s, ok={int(r['status'].sum())}/{B}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-per-gpu", type=int, default=4096)
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from opensot_amd import synth
+    from opensot_amd.solver import BatchedStack
+    from opensot_amd.parallel import shard_range
+
+    Bl = args.batch_per_gpu
+    Bg = Bl * world
+    lo, hi = shard_range(Bg, rank, world)
+    assert hi - lo == Bl
+    # every rank generates only its own shard (seed = 1000*config + rank)
+    plan, leaf = synth.make_velocity_stack(args.config, Bl, seed=3000 + rank)
+    st = BatchedStack(plan, Bl, device=local_rank, want_levels=False)
+    dev_leaf = st.load_leaf(leaf)
+    gathered = torch.empty((Bg, plan.n), dtype=torch.float64, device=st.device) if world > 1 else None
+
+    def step():
+        st.update(dev_leaf)
+        st.solve(Bl)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, st.dq[:Bl])
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    st.set_timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=st.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms, launches = st.kernel_time_ms()
+    st.set_timing(False)
+    ok = int((st.status[:Bl] == 0).sum().item())
+
+    if rank == 0:
+        solves = Bg * args.steps
+        value = solves / elapsed
+        flops = algo_flops_per_solve(plan)
+        bytes_per = ALGO_BYTES_PER_SOLVE_C3 if args.config == "C3" else None
+        kern_s = kern_ms * 1e-3
+        out = {
+            "metric": "whole-body QP solves/sec (32-DoF, 3-level stack)",
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2]: batch={Bl}/GPU x 32-DoF, 3-level iHQP "
+                                   "(CoM / l_wrist(0.1)+r_wrist+l_sole+r_sole / Postural), joint-limit & "
+                                   "velocity-limit box, eps factor 1e6; step = AutoStack::update + cascade solve"
+                                   + ("; + RCCL all-gather of dq" if world > 1 else ""),
+                       "global_batch": Bg, "n_dof": plan.n, "levels": plan.L,
+                       "rows_per_level": [plan.m(k) for k in range(plan.L)],
+                       "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
+            "solved_ok_rank0": f"{ok}/{Bl}",
+        }
+        if launches > 0 and kern_s > 0:
+            tf = Bl * flops / kern_s / 1e12
+            out["roofline"] = {
+                "bound": "mfma", "kernel": "osot_cascade_kernel<32>", "achieved": tf, "peak": FP64_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": None,
+                "avg_launch_ms": kern_ms, "launches": launches,
+                "algorithmic_flops_per_solve": flops,
+                "note": "fp64 FMA roof (nominal algorithmic flops; AI ~ 20 flop/B > machine balance ~ 10). "
+                        "peak = AMD public FP64 vector/matrix spec, not in MI355X_MICROARCH.md"}
+            if bytes_per:
+                gbs = Bl * bytes_per / kern_s / 1e9
+                out["roofline_hbm"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                                       "algorithmic_bytes_per_solve": bytes_per}
+        if not args.no_cpu_baseline and world == 1:
+            ns = min(Bl, 512)
+            sample = {"B": ns, "A": [a[:ns] if a is not None else None for a in leaf["A"]],
+                      "task": [[tuple(None if x is None else x[:ns] for x in t) for t in lev] for lev in leaf["task"]],
+                      "bound": [tuple(None if x is None else x[:ns] for x in t) for t in leaf["bound"]],
+                      "rows": [tuple(None if x is None else x[:ns] for x in t) for t in leaf["rows"]]}
+            try:
+                out["cpu_baseline"] = cpu_baseline(plan, sample)
+            except Exception as e:  # the oracle is a checker; its absence must not kill the bench line
+                out["cpu_baseline"] = {"value": None, "unit": "solves/s", "cores": 0, "kind": "port",
+                                       "sample": f"unavailable: {e}"}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

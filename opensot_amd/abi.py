@@ -108,7 +108,7 @@ def lib():
     # torch bundles its own libamdhip64/librccl; import it FIRST so that our library binds to the same
     # (single) HIP runtime instance whose streams and allocations we are handed.
     import torch  # noqa: F401
-    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.osot_version.restype = C.c_char_p
     L.osot_last_error.restype = C.c_char_p

@@ -133,10 +133,11 @@ __device__ int gi_solve(const TeamCtx<T>& c, const RowSrc& rows, int nrows, doub
         team_sync();
     }
     // ---- JT = L^-1 into M2 (lane = column) ----------------------------------------------------
+    double invd = 0.0;   // lane i: 1 / L[i][i]
     if (valid) {
         for (int i = 0; i < n; ++i) {
             double y = 0.0;
-            if (i == tl) y = 1.0 / M1[i * S + i];
+            if (i == tl) { y = 1.0 / M1[i * S + i]; invd = y; }
             else if (i > tl) {
                 double s = 0.0;
                 for (int k = tl; k < i; ++k) s += M1[i * S + k] * M2[k * S + tl];
@@ -146,16 +147,20 @@ __device__ int gi_solve(const TeamCtx<T>& c, const RowSrc& rows, int nrows, doub
         }
     }
     team_sync();
-    // ---- unconstrained minimiser x = -J J' g ---------------------------------------------------
-    V0[tl] = valid ? g : 0.0;
-    team_sync();
-    double x = 0.0;
-    {
-        double y = 0.0;
-        if (valid) for (int k = 0; k <= tl; ++k) y += M2[tl * S + k] * V0[k];
-        V1[tl] = y;
-        team_sync();
-        if (valid) for (int i = tl; i < n; ++i) x -= M2[i * S + tl] * V1[i];
+    // ---- unconstrained minimiser: L y = -g, L' x = y by substitution ----------------------------
+    // (NOT x = -J J'g: with H = A'A + eps I rank deficient, g lies in range(A') and the substitution
+    //  keeps the exact cancellation in the eps-pivots that the explicit inverse loses -- the
+    //  reference's own known-answer test TestQPOases.cpp:274-340 needs it at 1e-6)
+    double x = valid ? -g : 0.0;
+    for (int j = 0; j < n; ++j) {
+        const double yj = team_bcast<T>(x * invd, j);
+        if (tl == j) x = yj;
+        else if (valid && tl > j) x -= M1[tl * S + j] * yj;
+    }
+    for (int j = n - 1; j >= 0; --j) {
+        const double xj = team_bcast<T>(x * invd, j);
+        if (tl == j) x = xj;
+        else if (tl < j) x -= M1[j * S + tl] * xj;
     }
     team_sync();
 

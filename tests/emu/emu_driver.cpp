@@ -7,7 +7,7 @@
 
 using namespace osot;
 
-extern "C" int emu_ihqp_solve(const osot_plan_desc* plan, const osot_qp_batch* b) {
+extern "C" __attribute__((visibility("default"))) int emu_ihqp_solve(const osot_plan_desc* plan, const osot_qp_batch* b) {
     const char* why;
     int rc = plan_validate(plan, &why);
     if (rc != OSOT_OK) { fprintf(stderr, "emu: %s\n", why); return rc; }
@@ -26,7 +26,7 @@ extern "C" int emu_ihqp_solve(const osot_plan_desc* plan, const osot_qp_batch* b
     return OSOT_OK;
 }
 
-extern "C" int emu_qp_solve_batch(int B, int n, int nc, const double* H, const double* g, const double* A,
+extern "C" __attribute__((visibility("default"))) int emu_qp_solve_batch(int B, int n, int nc, const double* H, const double* g, const double* A,
                                   const double* lA, const double* uA, const double* l, const double* u,
                                   double eps_abs, int max_iter, double* x, int* status, int* iterations) {
     DevQP Q;

@@ -1,0 +1,153 @@
+"""shared test helpers (test infrastructure)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from opensot_amd import abi, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def load_golden(cfg):
+    """-> (plan, leaf, golden dict) from tests/golden/<cfg>_b32.npz (see tests/golden/make_golden.py)."""
+    z = np.load(os.path.join(GOLDEN, f"{cfg}_b32.npz"), allow_pickle=False)
+    B = int(z["B"])
+    plan, tmpl = synth.make_velocity_stack(cfg, 1, seed=0)
+    plan.eps_abs = float(z["eps_abs"])
+
+    def get(name):
+        return z[name] if name in z.files else None
+
+    leaf = {"B": B,
+            "A": [get(f"leaf_A{k}") for k in range(plan.L)],
+            "task": [[tuple(get(f"leaf_task{k}_{j}_p{i}") for i in range(3)) for j in range(len(plan.levels[k]))]
+                     for k in range(plan.L)],
+            "bound": [tuple(get(f"leaf_bound{j}_p{i}") for i in range(3)) for j in range(len(plan.bounds))],
+            "rows": [tuple(get(f"leaf_rows{j}_p{i}") for i in range(3)) for j in range(len(plan.rowblocks))]}
+    return plan, leaf, z
+
+
+_emu = None
+
+
+def emu_lib():
+    """host lock-step emulation of the product kernels (tests/emu)."""
+    global _emu
+    if _emu is None:
+        so = os.path.join(ROOT, "tests", "emu", "libosot_emu.so")
+        srcs = [os.path.join(ROOT, "tests", "emu", "emu_driver.cpp"),
+                os.path.join(ROOT, "opensot_amd", "csrc", "osot_qp_core.h"),
+                os.path.join(ROOT, "opensot_amd", "csrc", "osot_kernels.h"),
+                os.path.join(ROOT, "opensot_amd", "csrc", "osot_host_plan.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.check_call(["sh", os.path.join(ROOT, "tests", "emu", "build.sh")])
+        L = C.CDLL(so)
+        L.emu_ihqp_solve.argtypes = [C.POINTER(abi.PlanDesc), C.POINTER(abi.QpBatch)]
+        vp = C.c_void_p
+        L.emu_qp_solve_batch.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp,
+                                         C.c_double, C.c_int, vp, vp, vp]
+        _emu = L
+    return _emu
+
+
+def emu_cascade(plan, asm, active=None):
+    """run the cascade kernel body on host pointers through the emulator."""
+    B, n, L = asm["B"], asm["n"], asm["L"]
+    qb = abi.QpBatch()
+    qb.B = B
+    keep = []
+    for k in range(L):
+        for name in ("A", "b", "w", "c"):
+            a = asm[name][k]
+            if a is not None:
+                a = np.ascontiguousarray(a, dtype=np.float64)
+                keep.append(a)
+                getattr(qb, name)[k] = a.ctypes.data
+    for name in ("C", "lo", "up", "l", "u"):
+        a = asm[name]
+        if a is not None:
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            keep.append(a)
+            setattr(qb, name, a.ctypes.data)
+    dq = np.zeros((B, n)); xl = np.zeros((B, L, n))
+    st = np.full(B, -1, dtype=np.int32); it = np.zeros(B, dtype=np.int32)
+    qb.dq, qb.x_levels, qb.status, qb.iterations = dq.ctypes.data, xl.ctypes.data, st.ctypes.data, it.ctypes.data
+    if active is not None:
+        act = (C.c_ubyte * L)(*[1 if a else 0 for a in active])
+        keep.append(act)
+        qb.level_active = C.addressof(act)
+    pd = plan.to_c()
+    rc = emu_lib().emu_ihqp_solve(C.byref(pd), C.byref(qb))
+    assert rc == 0
+    return dq, xl, st, it
+
+
+def emu_qp(H, g, A, lA, uA, l, u, eps_abs=0.0, max_iter=0):
+    """B generic QPs through the emulated osot_qp_kernel; arrays are [B][...]."""
+    H = np.ascontiguousarray(H, dtype=np.float64)
+    B, n = H.shape[0], H.shape[1]
+    nc = 0 if A is None else A.shape[1]
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) if a is not None else None for a in (g, A, lA, uA, l, u)]
+    x = np.zeros((B, n)); st = np.full(B, -1, dtype=np.int32); it = np.zeros(B, dtype=np.int32)
+    p = lambda a: None if a is None else a.ctypes.data
+    rc = emu_lib().emu_qp_solve_batch(B, n, nc, p(H), *[p(a) for a in arrs], eps_abs, max_iter, p(x), p(st), p(it))
+    assert rc == 0
+    return x, st, it
+
+
+def random_qp(rng, B, n, nc, n_eq=0, box=True, scale=1.0):
+    """strictly convex random QPs with x = 0 strictly feasible for the inequalities."""
+    M = rng.normal(size=(B, n + 3, n))
+    H = np.einsum("bki,bkj->bij", M, M) * scale
+    g = rng.normal(size=(B, n)) * 3.0 * scale
+    A = rng.normal(size=(B, nc, n)) if nc else None
+    lA = uA = None
+    if nc:
+        lA = -rng.uniform(0.05, 1.0, size=(B, nc))
+        uA = rng.uniform(0.05, 1.0, size=(B, nc))
+        if n_eq:
+            v = rng.normal(size=(B, n_eq)) * 0.1
+            lA[:, :n_eq] = v; uA[:, :n_eq] = v
+        # a few one-sided rows
+        lA[:, -1] = -np.inf
+    l = u = None
+    if box:
+        l = -rng.uniform(0.05, 0.5, size=(B, n)); u = rng.uniform(0.05, 0.5, size=(B, n))
+    return H, g, A, lA, uA, l, u
+
+
+def kkt_check(H, g, A, lA, uA, l, u, x, eps_abs, tol=1e-7):
+    """primal feasibility + existence of multipliers with the right signs (least squares on the active set)."""
+    n = x.shape[0]
+    Hr = H + eps_abs * np.eye(n)
+    grad = Hr @ x + g
+    normals, signs = [], []
+    if l is not None:
+        assert (x >= l - tol).all() and (x <= u + tol).all()
+        for i in range(n):
+            if abs(x[i] - l[i]) <= tol:
+                e = np.zeros(n); e[i] = 1; normals.append(e); signs.append(+1 if l[i] < u[i] else 0)
+            elif abs(x[i] - u[i]) <= tol:
+                e = np.zeros(n); e[i] = -1; normals.append(e); signs.append(+1)
+    if A is not None and A.shape[0]:
+        ax = A @ x
+        assert (ax >= np.maximum(lA, -1e20) - tol).all() and (ax <= np.minimum(uA, 1e20) + tol).all()
+        for r in range(A.shape[0]):
+            if lA[r] == uA[r]:
+                normals.append(A[r]); signs.append(0)
+            elif abs(ax[r] - lA[r]) <= tol:
+                normals.append(A[r]); signs.append(+1)
+            elif abs(ax[r] - uA[r]) <= tol:
+                normals.append(-A[r]); signs.append(+1)
+    if not normals:
+        return np.abs(grad).max()
+    N = np.array(normals).T
+    lam, *_ = np.linalg.lstsq(N, grad, rcond=None)
+    resid = np.abs(N @ lam - grad).max()
+    for s, v in zip(signs, lam):
+        if s > 0:
+            assert v >= -1e-6 * (1 + np.abs(lam).max()), "negative multiplier on an active inequality"
+    return resid

@@ -1,0 +1,98 @@
+"""C-ABI checks that need no GPU: the library loads, exports every symbol include/osot_mi355x.h declares,
+validates plans and refuses bad arguments with the documented codes."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from opensot_amd import abi, synth
+from opensot_amd.plan import Bound, Rows, StackPlan, Task, eps_abs_from_factor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(abi.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return abi.lib()
+
+
+def test_header_symbols_are_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "osot_mi355x.h")).read()
+    declared = set(re.findall(r"\b(osot_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(abi.SYMBOLS), declared ^ set(abi.SYMBOLS)
+    for s in declared:
+        assert hasattr(lib, s), s
+
+
+def test_version_and_error_text(lib):
+    assert b"gfx950" in lib.osot_version()
+    assert lib.osot_plan_validate(None) == abi.ERR_INVALID
+    assert b"null" in lib.osot_last_error()
+
+
+def test_plan_sizes(lib):
+    plan, _ = synth.make_velocity_stack("C4", 1)
+    p = plan.to_c()
+    assert lib.osot_plan_validate(C.byref(p)) == abi.OK
+    m, ma = C.c_int(), C.c_int()
+    want = [(3, 3), (24, 24), (32, 0)]
+    for k in range(3):
+        assert lib.osot_plan_level_rows(C.byref(p), k, C.byref(m), C.byref(ma)) == abi.OK
+        assert (m.value, ma.value) == want[k] == (plan.m(k), plan.ma(k))
+    assert lib.osot_plan_level_rows(C.byref(p), 3, C.byref(m), C.byref(ma)) == abi.ERR_INVALID
+    nc = C.c_int()
+    assert lib.osot_plan_constraint_rows(C.byref(p), C.byref(nc)) == abi.OK and nc.value == 16 == plan.nc
+
+
+def test_plan_validation_errors(lib):
+    def code(plan):
+        p = plan.to_c() if isinstance(plan, StackPlan) else plan
+        return lib.osot_plan_validate(C.byref(p))
+    good = StackPlan(n=8, levels=[[Task(abi.TASK_GENERIC, 3)], [Task(abi.TASK_POSTURAL, 8)]])
+    assert code(good) == abi.OK
+    p = good.to_c(); p.n = 65
+    assert code(p) == abi.ERR_INVALID
+    p = good.to_c(); p.level[0].task[0].kind = 9
+    assert code(p) == abi.ERR_UNSUPPORTED
+    p = good.to_c(); p.level[0].task[0].rows = 0
+    assert code(p) == abi.ERR_INVALID
+    p = good.to_c(); p.level[1].task[0].rows = 7          # Postural must span n rows
+    assert code(p) == abi.ERR_INVALID
+    p = good.to_c(); p.eps_abs = -1.0
+    assert code(p) == abi.ERR_INVALID
+    # Postural not last in its level
+    p = StackPlan(n=8, levels=[[Task(abi.TASK_GENERIC, 3), Task(abi.TASK_GENERIC, 2)]]).to_c()
+    p.level[0].task[0].kind = abi.TASK_POSTURAL; p.level[0].task[0].rows = 8
+    assert code(p) == abi.ERR_UNSUPPORTED
+
+
+def test_backend_argument_checks_without_gpu(lib):
+    h = C.c_void_p()
+    assert lib.osot_backend_create(0, 0, abi.HST_SEMIDEF, 1.0, C.byref(h)) == abi.ERR_INVALID
+    assert lib.osot_backend_create(65, 0, abi.HST_SEMIDEF, 1.0, C.byref(h)) == abi.ERR_INVALID
+    assert lib.osot_backend_create(3, -1, abi.HST_SEMIDEF, 1.0, C.byref(h)) == abi.ERR_INVALID
+    assert lib.osot_backend_create(3, 1, abi.HST_SEMIDEF, -1.0, C.byref(h)) == abi.ERR_INVALID
+    assert lib.osot_backend_create(3, 1, abi.HST_SEMIDEF, 1.0, C.byref(h)) == abi.OK
+    e = C.c_double()
+    assert lib.osot_backend_get_eps_regularisation(h, C.byref(e)) == abi.OK
+    assert e.value == pytest.approx(2.221e-13, rel=1e-12)       # TestQPOases.cpp:798-836
+    assert lib.osot_backend_set_eps_regularisation(h, -1.0) == abi.ERR_INVALID  # "Negative eps is not allowed!"
+    l = np.array([1.0, 0, 0]); u = np.zeros(3)
+    dp = abi.dp
+    assert lib.osot_backend_update_bounds(h, l.ctypes.data_as(dp), u.ctypes.data_as(dp)) == abi.ERR_INVALID
+    assert lib.osot_backend_solve(h) == abi.ERR_INVALID          # solve() before initProblem()
+    nv, nc = C.c_int(), C.c_int()
+    lib.osot_backend_get_num_variables(h, C.byref(nv)); lib.osot_backend_get_num_constraints(h, C.byref(nc))
+    assert (nv.value, nc.value) == (3, 1)
+    assert lib.osot_backend_destroy(h) == abi.OK
+
+
+def test_eps_factor_convention():
+    assert eps_abs_from_factor(1.0) == pytest.approx(2.221e-13)
+    assert eps_abs_from_factor(2e2) == pytest.approx(4.442e-11)   # iHQP default (iHQP.h:32)
+    assert eps_abs_from_factor(1e6) == pytest.approx(2.221e-7)    # benchmark value (coman_ik.cpp:453)

@@ -1,0 +1,132 @@
+"""The product's kernel bodies (opensot_amd/csrc/osot_kernels.h, osot_qp_core.h) executed through the host
+lock-step emulation in tests/emu and compared with the oracle / golden vectors.  No GPU: this is how the
+device algorithm is debugged in the build container; the -m gpu tests repeat the comparisons on hardware."""
+import numpy as np
+import pytest
+
+from helpers import emu_cascade, emu_qp, kkt_check, load_golden, random_qp
+from opensot_amd import synth
+
+EPS = 1e3 * 2.221e-16
+
+
+@pytest.mark.parametrize("cfg", ["C2", "C3", "C4"])
+def test_cascade_vs_golden(cfg, oracle):
+    plan, leaf, z = load_golden(cfg)
+    asm = oracle.assemble(plan, leaf)
+    dq, xl, st, it = emu_cascade(plan, asm)
+    assert (st == 0).all()
+    ok = z["ok_ref"].astype(bool); okx = z["ok_exact"].astype(bool)
+    assert np.abs(dq[ok] - z["x_ref"][ok][:, -1]).max() < 1e-6      # north_star tolerance vs qpOASES
+    assert np.abs(dq[okx] - z["x_exact"][okx][:, -1]).max() < 1e-8  # vs qpOASES at tight termination
+    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+    assert np.abs(dq - ref["dq"]).max() < 1e-10
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_cascade_ragged_batches(B, oracle):
+    """odd batch sizes: the second team of the last wavefront has no instance"""
+    plan, leaf = synth.make_velocity_stack("C3", B, seed=77)
+    asm = oracle.assemble(plan, leaf)
+    dq, xl, st, it = emu_cascade(plan, asm)
+    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+    assert (st == 0).all()
+    assert np.abs(dq - ref["dq"]).max() < 1e-10
+
+
+@pytest.mark.parametrize("active", [(1, 0, 1), (0, 1, 1), (1, 1, 0), (0, 0, 1)])
+def test_inactive_levels(active, oracle):
+    """iHQP::setActiveStack (iHQP.cpp:391-395): inactive levels contribute rows 0*x in [-1,1] and are skipped;
+    the last ACTIVE level's x is returned (iHQP.cpp:349)"""
+    plan, leaf = synth.make_velocity_stack("C3", 4, seed=5)
+    asm = oracle.assemble(plan, leaf)
+    dq, xl, st, it = emu_cascade(plan, asm, active=active)
+    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1, active=active)
+    assert (st == 0).all() and (ref["status"] == 1).all()
+    assert np.abs(dq - ref["dq"]).max() < 1e-10
+
+
+def test_generic_qp_known_answers():
+    """TestQPOases.cpp:208-254, 274-340 through the batched QP kernel body"""
+    l = -10 * np.ones((1, 3)); u = 10 * np.ones((1, 3))
+    Hm = np.array([[1.0, 1, 1]]); b = np.array([10.0])
+    x, st, _ = emu_qp((Hm.T @ Hm)[None], (-Hm.T @ b)[None], np.array([[[1.0, 0, 1]]]), np.array([[20.0]]),
+                      np.array([[20.0]]), l, u, eps_abs=EPS * 1e4)
+    assert st[0] == 0
+    np.testing.assert_allclose(x[0], [10, -10, 10], atol=1e-6)
+    for Hm, b, want, tol in [(np.array([[1.0, 1, 1], [0, 1, 1]]), np.array([6.0, 5]), [1, 2.5, 2.5], 1e-6),
+                             (np.array([[1.0, 1, 1], [0, 1, 1], [1, 1, 0]]), np.array([6.0, 5, 3]), [1, 2, 3], 1e-6)]:
+        x, st, _ = emu_qp((Hm.T @ Hm)[None], (-Hm.T @ b)[None], None, None, None, l, u, eps_abs=EPS)
+        assert st[0] == 0
+        np.testing.assert_allclose(x[0], want, atol=tol)
+
+
+@pytest.mark.parametrize("n,nc,n_eq", [(5, 3, 1), (17, 9, 4), (32, 20, 6), (33, 10, 3), (50, 40, 8), (64, 12, 5)])
+def test_generic_qp_random_vs_oracle(n, nc, n_eq, oracle):
+    """random strictly convex QPs incl. the 64-lane team path (n > 32), vs the oracle and a KKT check"""
+    rng = np.random.default_rng(n * 100 + nc)
+    B = 6
+    H, g, A, lA, uA, l, u = random_qp(rng, B, n, nc, n_eq)
+    x, st, it = emu_qp(H, g, A, lA, uA, l, u, eps_abs=1e-9)
+    assert (st == 0).all()
+    for i in range(B):
+        ok, xo, _ = oracle.backend_solve(H[i], g[i], A[i], lA[i], uA[i], l[i], u[i], 1e-9)
+        assert ok
+        assert np.abs(x[i] - xo).max() < 1e-8
+        assert kkt_check(H[i], g[i], A[i], lA[i], uA[i], l[i], u[i], x[i], 1e-9) < 1e-6
+
+
+def test_dependent_and_redundant_equalities(oracle):
+    """duplicate equality rows (linearly dependent but consistent) are skipped; inconsistent ones are
+    reported infeasible (qpOASES handles LI via addConstraint_checkLI, QProblem.cpp:2847)"""
+    rng = np.random.default_rng(9)
+    n = 8
+    H = np.eye(n)[None]; g = rng.normal(size=(1, n))
+    a = rng.normal(size=n)
+    A = np.stack([a, 2 * a, rng.normal(size=n)])[None]
+    lA = np.array([[1.0, 2.0, 0.3]]); uA = lA.copy()
+    x, st, _ = emu_qp(H, g, A, lA, uA, None, None, eps_abs=0.0)
+    assert st[0] == 0
+    np.testing.assert_allclose(A[0] @ x[0], lA[0], atol=1e-10)
+    lA2 = np.array([[1.0, 2.5, 0.3]])
+    x, st, _ = emu_qp(H, g, A, lA2, lA2.copy(), None, None, eps_abs=0.0)
+    assert st[0] == 1   # OSOT_STATUS_INFEASIBLE
+
+
+def test_infeasible_box_vs_row():
+    """x0 + x1 >= 5 cannot hold inside the box [-1, 1]^2"""
+    H = np.eye(2)[None]; g = np.zeros((1, 2))
+    A = np.array([[[1.0, 1.0]]]); lA = np.array([[5.0]]); uA = np.array([[np.inf]])
+    x, st, _ = emu_qp(H, g, A, lA, uA, -np.ones((1, 2)), np.ones((1, 2)))
+    assert st[0] == 1
+    assert (x[0] == 0).all()   # failed instances return 0 (callers zero dq, coman_ik.cpp:189-190)
+
+
+def test_not_positive_definite():
+    H = np.array([[[1.0, 2.0], [2.0, 1.0]]]); g = np.ones((1, 2))
+    x, st, _ = emu_qp(H, g, None, None, None, None, None, eps_abs=0.0)
+    assert st[0] == 3
+
+
+def test_infinite_bounds_are_absent():
+    """+-inf, +-DBL_MAX and +-1e20 all mean 'no bound' (QPOasesBackEnd::checkINFTY, :339-356)"""
+    H = np.eye(2)[None]; g = np.array([[-3.0, 4.0]])
+    A = np.array([[[1.0, 0.0], [0.0, 1.0]]])
+    lA = np.array([[-np.finfo(float).max, -1e20]]); uA = np.array([[np.inf, 1e20]])
+    l = np.array([[-np.inf, -1e30]]); u = np.array([[1e20, np.finfo(float).max]])
+    x, st, it = emu_qp(H, g, A, lA, uA, l, u)
+    assert st[0] == 0 and it[0] == 0
+    np.testing.assert_allclose(x[0], [3, -4], atol=1e-14)
+
+
+def test_drop_path_is_exercised(oracle):
+    """problems whose unconstrained minimiser violates many bounds at once force partial steps / drops"""
+    rng = np.random.default_rng(21)
+    B, n, nc = 8, 12, 10
+    H, g, A, lA, uA, l, u = random_qp(rng, B, n, nc, 2, scale=1.0)
+    g *= 10.0
+    x, st, it = emu_qp(H, g, A, lA, uA, l, u, eps_abs=1e-9)
+    assert (st == 0).all()
+    for i in range(B):
+        ok, xo, _ = oracle.backend_solve(H[i], g[i], A[i], lA[i], uA[i], l[i], u[i], 1e-9)
+        assert ok and np.abs(x[i] - xo).max() < 1e-8

@@ -1,0 +1,124 @@
+"""GPU parity against the committed qpOASES golden vectors, and full-size (BASELINE.json) runs checked through
+size-independent properties: feasibility, hierarchy (optimality rows hold), KKT of the last level, permutation
+equivariance, idempotence of repeated solves, plus an oracle spot check."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden
+from opensot_amd import synth
+from opensot_amd.solver import BatchedStack
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve(plan, leaf, active=None, want_levels=True):
+    B = leaf["B"]
+    st = BatchedStack(plan, B, device=0, want_levels=want_levels)
+    st.update(st.load_leaf(leaf))
+    st.level_active = active
+    st.solve(B)
+    torch.cuda.synchronize()
+    return st
+
+
+@pytest.mark.parametrize("cfg", ["C2", "C3", "C4"])
+def test_golden_qpoases(cfg, gpu_device):
+    plan, leaf, z = load_golden(cfg)
+    st = _solve(plan, leaf)
+    B = leaf["B"]
+    dq = st.dq[:B].cpu().numpy()
+    assert (st.status[:B].cpu().numpy() == 0).all()
+    # AutoStack::update outputs: bit-exact against the oracle's leaf restatement
+    for k in range(plan.L):
+        np.testing.assert_allclose(st.b[k][:B].cpu().numpy(), z[f"asm_b{k}"], rtol=0, atol=1e-15)
+    np.testing.assert_array_equal(st.l[:B].cpu().numpy(), z["asm_l"])
+    np.testing.assert_array_equal(st.u[:B].cpu().numpy(), z["asm_u"])
+    ok = z["ok_ref"].astype(bool); okx = z["ok_exact"].astype(bool)
+    # north_star: solved joint velocities within 1e-6 of the reference qpOASES back-end (fp64)
+    assert np.abs(dq[ok] - z["x_ref"][ok][:, -1]).max() < 1e-6
+    assert np.abs(dq[okx] - z["x_exact"][okx][:, -1]).max() < 1e-8
+
+
+@pytest.mark.parametrize("cfg,B", [("C2", 1024), ("C3", 4096), ("C4", 4096)])
+def test_full_size_properties(cfg, B, oracle, gpu_device):
+    plan, leaf = synth.make_velocity_stack(cfg, B)
+    st = _solve(plan, leaf)
+    dq = st.dq[:B].cpu().numpy(); xl = st.x_levels[:B].cpu().numpy()
+    status = st.status[:B].cpu().numpy()
+    assert (status == 0).all()
+    l = st.l[:B].cpu().numpy(); u = st.u[:B].cpu().numpy()
+    # box feasibility at every level
+    for k in range(plan.L):
+        assert (xl[:, k] >= l - 1e-10).all() and (xl[:, k] <= u + 1e-10).all()
+    # hierarchy: A_j x_k == A_j x_j for all j < k (optimality rows, iHQP.cpp:164-170)
+    A = [a if a is not None else None for a in leaf["A"]]
+    for k in range(1, plan.L):
+        for j in range(k):
+            Aj = A[j] if A[j] is not None else np.broadcast_to(np.eye(plan.n), (B, plan.n, plan.n))
+            lhs = np.einsum("brn,bn->br", Aj, xl[:, k]); rhs = np.einsum("brn,bn->br", Aj, xl[:, j])
+            assert np.abs(lhs - rhs).max() < 1e-9
+    # global rows
+    if plan.nc:
+        Cx = np.einsum("brn,bn->br", st.C[:B].cpu().numpy(), dq)
+        assert (Cx <= np.minimum(st.up[:B].cpu().numpy(), 1e20) + 1e-10).all()
+    np.testing.assert_array_equal(dq, xl[:, -1])
+    # oracle spot check on a strided subset
+    sub = slice(0, B, B // 64)
+    asm = oracle.assemble(plan, {"B": len(range(*sub.indices(B))),
+                                 "A": [a[sub] if a is not None else None for a in leaf["A"]],
+                                 "task": [[tuple(None if x is None else x[sub] for x in t) for t in lev] for lev in leaf["task"]],
+                                 "bound": [tuple(None if x is None else x[sub] for x in t) for t in leaf["bound"]],
+                                 "rows": [tuple(None if x is None else x[sub] for x in t) for t in leaf["rows"]]})
+    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+    assert np.abs(dq[sub] - ref["dq"]).max() < 1e-9
+
+
+def test_permutation_equivariance_and_idempotence(gpu_device):
+    """instances are independent: permuting the batch permutes dq bit-exactly; solving twice gives identical bits"""
+    B = 512
+    plan, leaf = synth.make_velocity_stack("C3", B, seed=99)
+    st = _solve(plan, leaf)
+    dq1 = st.dq[:B].cpu().numpy().copy()
+    st.solve(B); torch.cuda.synchronize()
+    np.testing.assert_array_equal(dq1, st.dq[:B].cpu().numpy())
+    perm = np.random.default_rng(0).permutation(B)
+    pleaf = {"B": B, "A": [a[perm] if a is not None else None for a in leaf["A"]],
+             "task": [[tuple(None if x is None else x[perm] for x in t) for t in lev] for lev in leaf["task"]],
+             "bound": [tuple(None if x is None else x[perm] for x in t) for t in leaf["bound"]],
+             "rows": [tuple(None if x is None else x[perm] for x in t) for t in leaf["rows"]]}
+    st2 = _solve(plan, pleaf)
+    np.testing.assert_array_equal(dq1[perm], st2.dq[:B].cpu().numpy())
+
+
+@pytest.mark.parametrize("active", [(1, 0, 1), (0, 1, 1), (1, 1, 0)])
+def test_inactive_levels_gpu(active, oracle, gpu_device):
+    plan, leaf = synth.make_velocity_stack("C3", 64, seed=5)
+    asm = oracle.assemble(plan, leaf)
+    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1, active=active)
+    st = _solve(plan, leaf, active=active)
+    assert (st.status[:64].cpu().numpy() == 0).all()
+    assert np.abs(st.dq[:64].cpu().numpy() - ref["dq"]).max() < 1e-9
+
+
+def test_default_eps_factor(oracle, gpu_device):
+    """iHQP's default eps_regularisation 2e2 (iHQP.h:32): H + 4.4e-11 I, cond ~ 1e11 on the upper levels"""
+    plan, leaf = synth.make_velocity_stack("C3", 128, seed=17, eps_factor=2e2)
+    asm = oracle.assemble(plan, leaf)
+    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+    st = _solve(plan, leaf)
+    assert (st.status[:128].cpu().numpy() == 0).all()
+    assert np.abs(st.dq[:128].cpu().numpy() - ref["dq"]).max() < 1e-6
+
+
+def test_empty_batch_and_timing_api(gpu_device):
+    plan, leaf = synth.make_velocity_stack("C3", 8, seed=1)
+    st = BatchedStack(plan, 8, device=0)
+    st.solve(0)                       # empty input: accepted, nothing launched
+    st.set_timing(True)
+    st.update(st.load_leaf(leaf)); st.solve(8); st.solve(8)
+    torch.cuda.synchronize()
+    ms, cnt = st.kernel_time_ms()
+    assert cnt == 2 and ms > 0
+    with pytest.raises(RuntimeError):
+        st.solve(9)                   # exceeds max_batch -> OSOT_ERR_INVALID
