@@ -68,9 +68,10 @@ inline int plan_validate(const osot_plan_desc* p, const char** why) {
     return OSOT_OK;
 }
 
-inline int lds_layout(int n, int T, int n_opt, int n_rows, int* opt_off, int* rowstate_off) {
-    const int S = n | 1;
-    int d = 2 * n * S + 4 * T;
+// LDS carve-up (doubles) of one wave's slice for padded size NP; returns the total
+inline int lds_layout(int NP, int n_opt, int n_rows, int* opt_off, int* rowstate_off) {
+    const int S = NP + 1;
+    int d = 2 * NP * S + 4 * NP;
     *opt_off = d;
     d += (n_opt > 0 ? n_opt : 1);
     d = (d + 1) & ~1;
@@ -80,12 +81,11 @@ inline int lds_layout(int n, int T, int n_opt, int n_rows, int* opt_off, int* ro
     return d;
 }
 
-// returns OSOT_OK and fills P, the team width T (32/64) and the dynamic LDS bytes per 64-lane workgroup
-inline int make_dev_plan(const osot_plan_desc& p, const unsigned char* level_active, DevPlan& P, int& T,
+// returns OSOT_OK and fills P, the padded size NP (32/64) and the dynamic LDS bytes per workgroup (= wave)
+inline int make_dev_plan(const osot_plan_desc& p, const unsigned char* level_active, DevPlan& P, int& NP,
                          size_t& lds_bytes) {
     std::memset(&P, 0, sizeof(P));
     P.n = p.n;
-    P.S = p.n | 1;
     P.L = p.n_levels;
     plan_constraint_rows(&p, &P.nc);
     P.optoff[0] = 0;
@@ -98,9 +98,9 @@ inline int make_dev_plan(const osot_plan_desc& p, const unsigned char* level_act
     const int nrows_max = P.nc + P.optoff[p.n_levels];
     P.max_iter = p.max_iter > 0 ? p.max_iter : 20 * (p.n + nrows_max) + 100;
     P.eps_abs = p.eps_abs;
-    T = (p.n <= 32) ? 32 : 64;
-    P.lds_team_doubles = lds_layout(p.n, T, P.optoff[p.n_levels], nrows_max, &P.lds_opt_off, &P.lds_rowstate_off);
-    lds_bytes = (size_t)(64 / T) * P.lds_team_doubles * sizeof(double);
+    NP = (p.n <= 32) ? 32 : 64;
+    const int total = lds_layout(NP, P.optoff[p.n_levels], nrows_max, &P.lds_opt_off, &P.lds_rowstate_off);
+    lds_bytes = (size_t)total * sizeof(double);
     return OSOT_OK;
 }
 

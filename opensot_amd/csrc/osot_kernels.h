@@ -1,18 +1,18 @@
 // osot_kernels.h -- the gfx950 kernels of the OpenSoT hot path.
 //
-//   osot_cascade_kernel<T> ... Solver::solve() = iHQP::solve (src/solvers/iHQP.cpp:263-358) for B
+//   osot_cascade_kernel<NP> .. Solver::solve() = iHQP::solve (src/solvers/iHQP.cpp:263-358) for B
 //                              instances: per level  H = A'WA, g = -A'Wb + c  (iHQP.cpp:129-162),
 //                              constraints = global rows + optimality rows of the higher levels
 //                              (iHQP.cpp:282-333), one strictly convex QP (QPOasesBackEnd.cpp:248-307),
 //                              x of the last active level is the answer (iHQP.cpp:349).  All levels
 //                              run in ONE launch; H, its factor, J and the working set never leave LDS.
-//   osot_qp_kernel<T> ........ B generic QPs in BackEnd convention (BackEnd.h:125-150).
+//   osot_qp_kernel<NP> ....... B generic QPs in BackEnd convention (BackEnd.h:125-150).
 //   osot_update_kernel ....... AutoStack::update() (src/utils/AutoStack.cpp:385-393): leaf -> b, W,
 //                              merged box, collision rows.  HBM-bound, one 64-lane block per instance.
 //
-// Mapping: a team of T lanes per instance (T = 32 for n <= 32: two instances per wavefront; T = 64 for
-// n <= 64), one wavefront per workgroup, instance-major fp64 arrays so a team's reads of its stacked
-// Jacobian rows are single contiguous 8n-byte segments.
+// Mapping: ONE WAVEFRONT PER INSTANCE (one wavefront per workgroup).  NP = 32 for n <= 32 (two lanes per
+// column: the halves split every inner product), NP = 64 for n <= 64.  Instance-major fp64 arrays, so a
+// wave's reads of its stacked Jacobian rows are contiguous 8n-byte segments.
 #pragma once
 #include "osot_qp_core.h"
 
@@ -25,17 +25,16 @@
 namespace osot {
 
 struct DevPlan {
-    int n, S, L, nc;
+    int n, L, nc;
     int m[OSOT_KMAX_LEVELS];        // rows per level
     int ma[OSOT_KMAX_LEVELS];       // rows stored in A_k (the rest is Postural's implicit identity)
     int optoff[OSOT_KMAX_LEVELS + 1];  // prefix sums of m[]
     int max_iter;
     unsigned active_mask;           // bit k: level k active (iHQP::setActiveStack)
     double eps_abs;
-    // LDS carve-up per team
-    int lds_team_doubles;           // doubles per team (M1, M2, V, opt) rounded so ints follow aligned
-    int lds_opt_off;                // offset (doubles) of the optimality right-hand sides
-    int lds_rowstate_off;           // offset (doubles) of the int rowstate array
+    // LDS carve-up of the wave's slice (doubles): M1, M2, V first (sizes fixed by NP), then
+    int lds_opt_off;                // the optimality right-hand sides A_j x_j
+    int lds_rowstate_off;           // and the int rowstate array
 };
 
 struct DevBatch {
@@ -93,29 +92,30 @@ struct CascadeRows {
     }
 };
 
-template <int T>
+template <int NP>
 __global__ void __launch_bounds__(64) osot_cascade_kernel(const DevPlan P, const DevBatch D) {
     OSOT_DYNAMIC_LDS(osot_smem);
-    constexpr int TPB = 64 / T;
-    const int team = threadIdx.x / T;
-    const int tl = threadIdx.x % T;
-    const long long inst = (long long)blockIdx.x * TPB + team;
-    if (inst >= D.B) return;
-    const int n = P.n, S = P.S;
-    double* base = reinterpret_cast<double*>(osot_smem) + (size_t)team * P.lds_team_doubles;
-    TeamCtx<T> c;
-    c.tl = tl; c.n = n; c.S = S;
-    c.M1 = base;
-    c.M2 = base + n * S;
-    c.V = base + 2 * n * S;
+    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
+    const int lane = threadIdx.x;
+    const long long inst = blockIdx.x;
+    const int n = P.n;
+    double* base = reinterpret_cast<double*>(osot_smem);
+    WaveCtx<NP> w;
+    w.c = lane % NP; w.h = lane / NP; w.n = n;
+    w.M1 = base;
+    w.M2 = base + NP * S;
+    w.V = base + 2 * NP * S;
     double* opt = base + P.lds_opt_off;
-    c.rowstate = reinterpret_cast<int*>(base + P.lds_rowstate_off);
-    const bool valid = tl < n;
-    double* V0 = c.V;
+    w.rowstate = reinterpret_cast<int*>(base + P.lds_rowstate_off);
+    const int c = w.c, h = w.h;
+    const bool valid = c < n;
+    // zero the matrices once: the padding beyond n stays zero for the whole kernel
+    for (int e = lane; e < 2 * NP * S + 4 * NP; e += 64) base[e] = 0.0;
+    wave_sync();
 
     const bool has_box = D.l != nullptr;
-    const double lb = (has_box && valid) ? D.l[inst * n + tl] : -INFINITY;
-    const double ub = (has_box && valid) ? D.u[inst * n + tl] : INFINITY;
+    const double lb = (has_box && valid) ? D.l[inst * n + c] : -INFINITY;
+    const double ub = (has_box && valid) ? D.u[inst * n + c] : INFINITY;
 
     CascadeRows rows;
     rows.P = &P; rows.D = &D; rows.opt = opt; rows.inst = inst;
@@ -127,62 +127,82 @@ __global__ void __launch_bounds__(64) osot_cascade_kernel(const DevPlan P, const
     for (int k = 0; k < P.L; ++k) {
         if (!((P.active_mask >> k) & 1u)) continue;
         const int m = P.m[k], ma = P.ma[k];
-        // ---- H = A'WA + eps I (lane = column, accumulated in registers), g = -A'Wb + c ----------
-        double h[T];
-#pragma unroll
-        for (int i = 0; i < T; ++i) h[i] = 0.0;
-        double g = 0.0;
         const double* Ak = D.A[k] ? D.A[k] + inst * ma * n : nullptr;
         const double* bk = D.b[k] + inst * m;
         const double* wk = D.w[k] ? D.w[k] + inst * m : nullptr;
-        for (int r = 0; r < ma; ++r) {
-            const double a = valid ? Ak[r * n + tl] : 0.0;
-            const double wr = wk ? wk[r] : 1.0;
-            const double br = bk[r];
-            double* Vr = V0 + (r & 1) * T;   // double-buffered staging row
-            Vr[tl] = a;
-            team_sync();
-            const double wa = wr * a;
+        double g = 0.0, hdiag = 0.0;
+        const bool diag_h = (ma == 0);
+        if (!diag_h) {
+            // ---- H = A'WA + eps I, g = -A'Wb + c.  Lane (c,h) accumulates H[i][c] for i = ii*HV + h in
+            // registers; stored rows are staged four at a time through LDS for the broadcasts.
+            double hacc[NP / HV];
 #pragma unroll
-            for (int i = 0; i < T; ++i) h[i] += wa * Vr[i];
-            g -= wa * br;
-        }
-        if (m > ma && valid) {   // Postural block: A = I (Postural.cpp:37)
-            const double wi = wk ? wk[ma + tl] : 1.0;
-            g -= wi * bk[ma + tl];
+            for (int ii = 0; ii < NP / HV; ++ii) hacc[ii] = 0.0;
+            for (int r0 = 0; r0 < ma; r0 += 4) {
+                double a[4], wa[4];
 #pragma unroll
-            for (int i = 0; i < T; ++i) if (i == tl) h[i] += wi;
-        }
-        if (D.c[k] && valid) g += D.c[k][inst * n + tl];
-        team_sync();
-        if (valid) {
+                for (int u = 0; u < 4; ++u) {
+                    const int r = r0 + u;
+                    const bool in = r < ma;
+                    a[u] = (in && valid) ? Ak[r * n + c] : 0.0;
+                    const double wr = in ? (wk ? wk[r] : 1.0) : 0.0;
+                    wa[u] = wr * a[u];
+                    g -= wa[u] * (in ? bk[r] : 0.0);
+                }
+                wave_sync();   // the previous group's broadcasts are done
+                if (h == 0) {
 #pragma unroll
-            for (int i = 0; i < T; ++i) if (i < n) c.M1[i * S + tl] = h[i] + ((i == tl) ? P.eps_abs : 0.0);
+                    for (int u = 0; u < 4; ++u) w.V[u * NP + c] = a[u];
+                }
+                wave_sync();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double* Vu = w.V + u * NP + h;
+#pragma unroll
+                    for (int ii = 0; ii < NP / HV; ++ii) hacc[ii] += wa[u] * Vu[ii * HV];
+                }
+            }
+            if (m > ma && valid) {   // Postural block appended to the level: A = I (Postural.cpp:37)
+                const double wi = wk ? wk[ma + c] : 1.0;
+                g -= wi * bk[ma + c];
+#pragma unroll
+                for (int ii = 0; ii < NP / HV; ++ii) if (ii * HV + h == c) hacc[ii] += wi;
+            }
+            wave_sync();
+#pragma unroll
+            for (int ii = 0; ii < NP / HV; ++ii) {
+                const int i = ii * HV + h;
+                w.M1[i * S + c] = hacc[ii] + ((i == c && valid) ? P.eps_abs : 0.0);
+            }
+            wave_sync();
+        } else if (valid) {   // level = one Postural block: H = W + eps I is diagonal
+            const double wi = wk ? wk[c] : 1.0;
+            hdiag = wi + P.eps_abs;
+            g = -wi * bk[c];
         }
-        team_sync();
+        if (D.c[k] && valid) g += D.c[k][inst * n + c];
 
         const int nrows = P.nc + P.optoff[k];
         int iters = 0;
-        const int st = gi_solve<T>(c, rows, nrows, g, has_box, lb, ub, P.max_iter, x, iters);
+        const int st = gi_solve<NP>(w, rows, nrows, g, diag_h, hdiag, has_box, lb, ub, P.max_iter, x, iters);
         iters_total += iters;
         if (st != QP_SOLVED) { status = st; break; }
         any = true;
-        if (D.x_levels && valid) D.x_levels[(inst * P.L + k) * n + tl] = x;
+        if (D.x_levels && valid && h == 0) D.x_levels[(inst * P.L + k) * n + c] = x;
         // optimality right-hand sides A_k x_k for the lower levels (iHQP.cpp:164-170)
         if (k + 1 < P.L) {
-            for (int q = 0; q < m; ++q) {
-                double a;
-                if (q < ma) a = valid ? Ak[q * n + tl] : 0.0;
-                else a = (tl == q - ma) ? 1.0 : 0.0;
-                const double v = team_sum<T>(a * x);
-                if (tl == 0) opt[P.optoff[k] + q] = v;
+            for (int q = 0; q < ma; ++q) {
+                const double a = valid ? Ak[q * n + c] : 0.0;
+                const double v = colsum<NP>(a * x);
+                if (lane == 0) opt[P.optoff[k] + q] = v;
             }
-            team_sync();
+            if (m > ma && valid && h == 0) opt[P.optoff[k] + ma + c] = x;   // identity rows: e_c' x
+            wave_sync();
         }
     }
     if (status != QP_SOLVED || !any) x = 0.0;   // failed instances return dq = 0 (coman_ik.cpp:189-190)
-    if (valid) D.dq[inst * n + tl] = x;
-    if (tl == 0) {
+    if (valid && h == 0) D.dq[inst * n + c] = x;
+    if (lane == 0) {
         D.status[inst] = status;
         if (D.iterations) D.iterations[inst] = iters_total;
     }
@@ -192,7 +212,7 @@ __global__ void __launch_bounds__(64) osot_cascade_kernel(const DevPlan P, const
 // generic batched QP in BackEnd convention
 // ---------------------------------------------------------------------------------------------------
 struct DevQP {
-    int B, n, S, nc, max_iter;
+    int B, n, nc, max_iter;
     double eps_abs;
     const double* H;   // [B][n][n]
     const double* g;   // [B][n]
@@ -204,50 +224,51 @@ struct DevQP {
     double* x;
     int* status;
     int* iterations;
-    int lds_team_doubles, lds_rowstate_off;
+    int lds_rowstate_off;
 };
 
 struct PlainRows {
     const DevQP* Q;
     long long inst;
-    __device__ __forceinline__ double elem(int r, int lane) const {
-        return lane < Q->n ? Q->A[(inst * Q->nc + r) * Q->n + lane] : 0.0;
+    __device__ __forceinline__ double elem(int r, int col) const {
+        return col < Q->n ? Q->A[(inst * Q->nc + r) * Q->n + col] : 0.0;
     }
     __device__ __forceinline__ double lo(int r) const { return Q->lA[inst * Q->nc + r]; }
     __device__ __forceinline__ double up(int r) const { return Q->uA[inst * Q->nc + r]; }
 };
 
-template <int T>
+template <int NP>
 __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
     OSOT_DYNAMIC_LDS(osot_smem);
-    constexpr int TPB = 64 / T;
-    const int team = threadIdx.x / T;
-    const int tl = threadIdx.x % T;
-    const long long inst = (long long)blockIdx.x * TPB + team;
-    if (inst >= Q.B) return;
-    const int n = Q.n, S = Q.S;
-    double* base = reinterpret_cast<double*>(osot_smem) + (size_t)team * Q.lds_team_doubles;
-    TeamCtx<T> c;
-    c.tl = tl; c.n = n; c.S = S;
-    c.M1 = base; c.M2 = base + n * S; c.V = base + 2 * n * S;
-    c.rowstate = reinterpret_cast<int*>(base + Q.lds_rowstate_off);
-    const bool valid = tl < n;
-    if (valid) {
+    constexpr int S = WaveCtx<NP>::S;
+    const int lane = threadIdx.x;
+    const long long inst = blockIdx.x;
+    const int n = Q.n;
+    double* base = reinterpret_cast<double*>(osot_smem);
+    WaveCtx<NP> w;
+    w.c = lane % NP; w.h = lane / NP; w.n = n;
+    w.M1 = base; w.M2 = base + NP * S; w.V = base + 2 * NP * S;
+    w.rowstate = reinterpret_cast<int*>(base + Q.lds_rowstate_off);
+    const int c = w.c, h = w.h;
+    const bool valid = c < n;
+    for (int e = lane; e < 2 * NP * S + 4 * NP; e += 64) base[e] = 0.0;
+    wave_sync();
+    if (valid && h == 0) {
         const double* H = Q.H + inst * n * n;
-        for (int i = 0; i < n; ++i) c.M1[i * S + tl] = H[i * n + tl] + ((i == tl) ? Q.eps_abs : 0.0);
+        for (int i = 0; i < n; ++i) w.M1[i * S + c] = H[i * n + c] + ((i == c) ? Q.eps_abs : 0.0);
     }
-    team_sync();
-    const double g = valid ? Q.g[inst * n + tl] : 0.0;
+    wave_sync();
+    const double g = valid ? Q.g[inst * n + c] : 0.0;
     const bool has_box = Q.l != nullptr;
-    const double lb = (has_box && valid) ? Q.l[inst * n + tl] : -INFINITY;
-    const double ub = (has_box && valid) ? Q.u[inst * n + tl] : INFINITY;
+    const double lb = (has_box && valid) ? Q.l[inst * n + c] : -INFINITY;
+    const double ub = (has_box && valid) ? Q.u[inst * n + c] : INFINITY;
     PlainRows rows;
     rows.Q = &Q; rows.inst = inst;
     double x = 0.0;
     int iters = 0;
-    const int st = gi_solve<T>(c, rows, Q.nc, g, has_box, lb, ub, Q.max_iter, x, iters);
-    if (valid) Q.x[inst * n + tl] = (st == QP_SOLVED) ? x : 0.0;
-    if (tl == 0) {
+    const int st = gi_solve<NP>(w, rows, Q.nc, g, false, 0.0, has_box, lb, ub, Q.max_iter, x, iters);
+    if (valid && h == 0) Q.x[inst * n + c] = (st == QP_SOLVED) ? x : 0.0;
+    if (lane == 0) {
         Q.status[inst] = st;
         if (Q.iterations) Q.iterations[inst] = iters;
     }

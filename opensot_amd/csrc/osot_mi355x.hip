@@ -157,8 +157,7 @@ int osot_ihqp_solve(osot_solver* s, const osot_qp_batch* b, void* hip_stream) {
     D.l = pl.n_bounds ? b->l : nullptr; D.u = pl.n_bounds ? b->u : nullptr;
     D.dq = b->dq; D.x_levels = b->x_levels; D.status = b->status; D.iterations = b->iterations;
     hipStream_t st = (hipStream_t)hip_stream;
-    const int tpb = 64 / T;
-    const unsigned grid = (unsigned)((b->B + tpb - 1) / tpb);
+    const unsigned grid = (unsigned)b->B;
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (s->timing) {
         if (!s->pool.empty()) { ev = s->pool.back(); s->pool.pop_back(); }
@@ -244,19 +243,17 @@ int osot_qp_solve_batch(int B, int n, int nc, const double* H, const double* g, 
     if ((l == nullptr) != (u == nullptr)) return fail(OSOT_ERR_INVALID, "l and u must both be given or both be null");
     DevQP Q;
     std::memset(&Q, 0, sizeof(Q));
-    Q.B = B; Q.n = n; Q.S = n | 1; Q.nc = nc;
+    Q.B = B; Q.n = n; Q.nc = nc;
     Q.max_iter = max_iter > 0 ? max_iter : 20 * (n + nc) + 100;
     Q.eps_abs = eps_abs;
     Q.H = H; Q.g = g; Q.A = A; Q.lA = lA; Q.uA = uA; Q.l = l; Q.u = u;
     Q.x = x; Q.status = status; Q.iterations = iterations;
     const int T = n <= 32 ? 32 : 64;
     int opt_off;
-    Q.lds_team_doubles = lds_layout(n, T, 0, nc, &opt_off, &Q.lds_rowstate_off);
-    const size_t lds = (size_t)(64 / T) * Q.lds_team_doubles * sizeof(double);
+    const size_t lds = (size_t)lds_layout(T, 0, nc, &opt_off, &Q.lds_rowstate_off) * sizeof(double);
     int rc = (T == 32) ? ensure_lds(osot_qp_kernel<32>, lds) : ensure_lds(osot_qp_kernel<64>, lds);
     if (rc != OSOT_OK) return rc;
-    const int tpb = 64 / T;
-    const unsigned grid = (unsigned)((B + tpb - 1) / tpb);
+    const unsigned grid = (unsigned)B;
     if (T == 32) hipLaunchKernelGGL(osot_qp_kernel<32>, dim3(grid), dim3(64), lds, (hipStream_t)hip_stream, Q);
     else hipLaunchKernelGGL(osot_qp_kernel<64>, dim3(grid), dim3(64), lds, (hipStream_t)hip_stream, Q);
     HIP_TRY(hipGetLastError());

@@ -1,7 +1,6 @@
-// osot_qp_core.h -- device-side dense QP core: Cholesky, J = L^-T, dual active set.
+// osot_qp_core.h -- device-side dense QP core: Cholesky, J = L^-T, dual active set; one wavefront per QP.
 //
-// Solves, for one instance held by a team of T lanes,
-//      min 1/2 x'(H + eps I)x + g'x   s.t.  lo_r <= a_r'x <= up_r  (general rows),  lb <= x <= ub
+// Solves   min 1/2 x'(H + eps I)x + g'x   s.t.  lo_r <= a_r'x <= up_r  (general rows),  lb <= x <= ub
 // which is the problem every level of the cascade hands to OpenSoT's BackEnd
 // (include/OpenSoT/solvers/BackEnd.h:125-150; convention SURVEY.md 8b).  H + eps I is strictly convex,
 // so the minimiser is unique and any exact method reproduces the reference qpOASES x up to round-off.
@@ -17,11 +16,14 @@
 //     not formed;
 //   * the triangular solve r = R^-1 d1 only runs over the inequality part of the working set.
 //
-// LDS per team (doubles, row stride S = n|1 so that both row- and column-walks are bank-conflict
-// free for ds_read_b64):  M1[n][S]  H -> L (Cholesky) -> R (working-set factor),
-//                         M2[n][S]  JT, JT[j][k] = J[k][j]  (starts as L^-1),
-//                         V[4][T]   broadcast staging vectors.
-// Lane t owns element t of x, g, d, z, u and the box state of variable t.
+// Lane layout (osot_team.h): lane = c + NP*h, NP = padded size (32 or 64), HV = 64/NP halves.  Vectors are
+// one element per lane, replicated over h; for NP = 32 the halves split the inner range of every mat-vec.
+// LDS per wave (doubles, zero-padded beyond n, compile-time row stride S = NP+1 so that row- and column-
+// walks are bank-conflict free for ds_read_b64 and every inner-loop offset is an instruction immediate):
+//     M1[NP][S]  H -> L (Cholesky) -> R (working-set factor, upper triangular)
+//     M2[NP][S]  JT, JT[j][k] = J[k][j]  (starts as L^-1)
+//     V[4][NP]   staging vectors for broadcasts
+// All control flow is wave-uniform.
 #pragma once
 #include <osot_team.h>  // resolved through -I: csrc/ for the product, tests/emu/ for the host emulation
 
@@ -34,13 +36,15 @@ constexpr double kEqTol = 1.0e-9;      // consistency of a linearly dependent eq
 
 enum { QP_SOLVED = 0, QP_INFEASIBLE = 1, QP_MAX_ITER = 2, QP_NOT_PD = 3 };
 
-template <int T>
-struct TeamCtx {
-    int tl;         // lane within the team
-    int n, S;
-    double* M1;     // n*S
-    double* M2;     // n*S
-    double* V;      // 4*T
+template <int NP>
+struct WaveCtx {
+    static constexpr int HV = 64 / NP;
+    static constexpr int S = NP + 1;
+    int c, h;       // column index and half of this lane
+    int n;
+    double* M1;
+    double* M2;
+    double* V;      // 4*NP
     int* rowstate;  // one int per general row: 0 free, 1 lower active, 2 upper active, 3 equality
 };
 
@@ -48,161 +52,219 @@ __device__ __forceinline__ double clamp_inf(double v) {
     return v < -kInfty ? -kInfty : (v > kInfty ? kInfty : v);
 }
 
+// d_c = sum_k JT[c][k] * vec[k]   (row walk, k split over the halves)
+template <int NP>
+__device__ __forceinline__ double jt_rows_dot(const WaveCtx<NP>& w, const double* vec) {
+    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
+    const double* row = w.M2 + w.c * S + w.h;
+    const double* v = vec + w.h;
+    double acc = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < NP / HV; ++kk) acc += row[kk * HV] * v[kk * HV];
+    return halfsum<NP>(acc);
+}
+// z_c = sum_j JT[j][c] * vec[j]   (column walk, j split over the halves)
+template <int NP>
+__device__ __forceinline__ double jt_cols_dot(const WaveCtx<NP>& w, const double* vec) {
+    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
+    const double* col = w.M2 + w.h * S + w.c;
+    const double* v = vec + w.h;
+    double acc = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < NP / HV; ++jj) acc += col[jj * HV * S] * v[jj * HV];
+    return halfsum<NP>(acc);
+}
+
 // One Householder reflection that maps d2 = d[iq:] onto alpha*e_iq, applied to the columns iq.. of J
 // (rows iq.. of JT); appends (d1; alpha) as column iq of R.  z = J2 d2 is an input.
-template <int T>
-__device__ __forceinline__ void householder_add(const TeamCtx<T>& c, double d, double d2, double z,
+template <int NP>
+__device__ __forceinline__ void householder_add(const WaveCtx<NP>& w, double d, double d2, double z,
                                                 double nd2, int iq) {
-    const int tl = c.tl, n = c.n, S = c.S;
-    double* V2 = c.V + 2 * T;
-    const double d_iq = team_bcast<T>(d, iq);
-    const double nrm = sqrt(nd2);
+    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
+    const int c = w.c, h = w.h, n = w.n;
+    double* V2 = w.V + 2 * NP;
+    const double d_iq = bcast(d, iq);
+    double nrm, rnrm;
+    fast_sqrt_rsqrt(nd2, nrm, rnrm);
     const double alpha = (d_iq > 0.0) ? -nrm : nrm;
-    const double v = (tl > iq) ? d2 : ((tl == iq) ? d_iq - alpha : 0.0);
-    const double beta = 1.0 / (nd2 - alpha * d_iq);
-    V2[tl] = v * beta;
-    team_sync();
-    if (tl < n) {
-        const double w = z - alpha * c.M2[iq * S + tl];   // w = J2 v
-        for (int j = iq; j < n; ++j) c.M2[j * S + tl] -= V2[j] * w;
-        if (tl < iq) c.M1[tl * S + iq] = d;
-        else if (tl == iq) c.M1[iq * S + iq] = alpha;
+    const double v = (c > iq) ? d2 : ((c == iq) ? d_iq - alpha : 0.0);
+    const double beta = fast_rcp(nd2 - alpha * d_iq);
+    if (h == 0) V2[c] = v * beta;
+    wave_sync();
+    const double wv = z - alpha * w.M2[iq * S + c];   // w = J2 v
+    wave_sync();   // both halves have read row iq before half 0 rewrites it
+    for (int jj = iq; jj < n; jj += HV) {
+        const int j = jj + h;
+        if (j < n) w.M2[j * S + c] -= V2[j] * wv;
     }
-    team_sync();
+    if (h == 0) {
+        if (c < iq) w.M1[c * S + iq] = d;
+        else if (c == iq) w.M1[iq * S + iq] = alpha;
+    }
+    wave_sync();
 }
 
 // Remove working-set position qq: shift R, re-triangularise with Givens rotations applied to the rows
 // of R and to the matching columns of J (eiquadprog.hpp:551-617 does the same on its storage).
-template <int T>
-__device__ __forceinline__ void drop_constraint(const TeamCtx<T>& c, int qq, int& iq, int& Aq, double& uq) {
-    const int tl = c.tl, n = c.n, S = c.S;
-    const int An = team_shift_down_i<T>(Aq);
-    const double un = team_shift_down<T>(uq);
-    if (tl >= qq && tl < iq - 1) { Aq = An; uq = un; }
-    if (tl < n) {
+template <int NP>
+__device__ __forceinline__ void drop_constraint(const WaveCtx<NP>& w, int qq, int& iq, int& Aq, double& uq) {
+    constexpr int S = WaveCtx<NP>::S;
+    const int c = w.c, h = w.h, n = w.n;
+    const int An = shift_down_i<NP>(Aq);
+    const double un = shift_down<NP>(uq);
+    if (c >= qq && c < iq - 1) { Aq = An; uq = un; }
+    if (h == 0 && c < n) {
         for (int q = qq; q < iq - 1; ++q)
-            if (tl <= q + 1) c.M1[tl * S + q] = c.M1[tl * S + q + 1];
+            if (c <= q + 1) w.M1[c * S + q] = w.M1[c * S + q + 1];
     }
-    team_sync();
+    wave_sync();
     iq--;
     for (int j = qq; j < iq; ++j) {
-        const double a = c.M1[j * S + j], b = c.M1[(j + 1) * S + j];
-        team_sync();   // every lane has read the pivot pair before lane j overwrites it
-        const double h = sqrt(a * a + b * b);
-        if (h == 0.0) continue;
-        const double cg = a / h, sg = b / h;
-        if (tl >= j && tl < iq) {
-            const double r1 = c.M1[j * S + tl], r2 = c.M1[(j + 1) * S + tl];
-            c.M1[j * S + tl] = cg * r1 + sg * r2;
-            c.M1[(j + 1) * S + tl] = cg * r2 - sg * r1;
+        const double a = w.M1[j * S + j], b = w.M1[(j + 1) * S + j];
+        wave_sync();   // every lane has read the pivot pair before lane j overwrites it
+        const double hh = a * a + b * b;
+        if (hh == 0.0) continue;
+        double s_, rs_;
+        fast_sqrt_rsqrt(hh, s_, rs_);
+        const double cg = a * rs_, sg = b * rs_;
+        if (h == 0) {
+            if (c >= j && c < iq) {
+                const double r1 = w.M1[j * S + c], r2 = w.M1[(j + 1) * S + c];
+                w.M1[j * S + c] = cg * r1 + sg * r2;
+                w.M1[(j + 1) * S + c] = cg * r2 - sg * r1;
+            }
+            if (c < n) {
+                const double j1 = w.M2[j * S + c], j2 = w.M2[(j + 1) * S + c];
+                w.M2[j * S + c] = cg * j1 + sg * j2;
+                w.M2[(j + 1) * S + c] = cg * j2 - sg * j1;
+            }
         }
-        if (tl < n) {
-            const double j1 = c.M2[j * S + tl], j2 = c.M2[(j + 1) * S + tl];
-            c.M2[j * S + tl] = cg * j1 + sg * j2;
-            c.M2[(j + 1) * S + tl] = cg * j2 - sg * j1;
-        }
-        team_sync();
+        wave_sync();
     }
 }
 
-// RowSrc: double elem(int r, int lane) (a_r[lane], 0 for lane >= n), double lo(int r), double up(int r)
-// Pre: M1 holds H + eps I (lower triangle used).  Post: returns status, x is lane-distributed.
-template <int T, class RowSrc>
-__device__ int gi_solve(const TeamCtx<T>& c, const RowSrc& rows, int nrows, double g, bool has_box,
-                        double lb, double ub, int max_iter, double& x_out, int& iters_out) {
-    const int tl = c.tl, n = c.n, S = c.S;
-    double* M1 = c.M1;
-    double* M2 = c.M2;
-    double* V0 = c.V;
-    double* V1 = c.V + T;
-    const bool valid = tl < n;
+// RowSrc: double elem(int r, int col) (a_r[col], 0 for col >= n), double lo(int r), double up(int r)
+// Pre:  general H: M1 holds H + eps I (lower triangle used);  diagonal H (diag_h = true): hdiag is the
+//       lane's diagonal entry h_cc + eps and M1/M2 contents are ignored.
+// Post: returns status, x is lane-distributed (replicated over the halves).
+template <int NP, class RowSrc>
+__device__ int gi_solve(const WaveCtx<NP>& w, const RowSrc& rows, int nrows, double g, bool diag_h,
+                        double hdiag, bool has_box, double lb, double ub, int max_iter, double& x_out,
+                        int& iters_out) {
+    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
+    const int c = w.c, h = w.h, n = w.n;
+    double* M1 = w.M1;
+    double* M2 = w.M2;
+    double* V0 = w.V;
+    double* V1 = w.V + NP;
+    const bool valid = c < n;
     lb = clamp_inf(lb);
     ub = clamp_inf(ub);
+    double x;
 
-    // ---- Cholesky H + eps I = L L' in place (lane = row) -------------------------------------
-    for (int j = 0; j < n; ++j) {
-        double s = 0.0;
-        if (valid && tl >= j) {
-            s = M1[tl * S + j];
-            for (int k = 0; k < j; ++k) s -= M1[tl * S + k] * M1[j * S + k];
-        }
-        const double piv = team_bcast<T>(s, j);
-        if (!(piv > 0.0)) { x_out = 0.0; iters_out = 0; return QP_NOT_PD; }
-        const double ljj = sqrt(piv);
-        if (valid && tl >= j) M1[tl * S + j] = (tl == j) ? ljj : s / ljj;
-        team_sync();
-    }
-    // ---- JT = L^-1 into M2 (lane = column) ----------------------------------------------------
-    double invd = 0.0;   // lane i: 1 / L[i][i]
-    if (valid) {
-        for (int i = 0; i < n; ++i) {
-            double y = 0.0;
-            if (i == tl) { y = 1.0 / M1[i * S + i]; invd = y; }
-            else if (i > tl) {
-                double s = 0.0;
-                for (int k = tl; k < i; ++k) s += M1[i * S + k] * M2[k * S + tl];
-                y = -s / M1[i * S + i];
+    if (diag_h) {
+        // H + eps I diagonal (a level made of a Postural block only): L = sqrt(diag), JT = diag(1/L)
+        const bool okd = !valid || (hdiag > 0.0);
+        if (colsum<NP>(okd ? 0.0 : 1.0) != 0.0) { x_out = 0.0; iters_out = 0; return QP_NOT_PD; }
+        double sq = 1.0, rs = 1.0;
+        if (valid) fast_sqrt_rsqrt(hdiag, sq, rs);
+        for (int e = c + NP * h; e < NP * S; e += 64) M2[e] = 0.0;
+        wave_sync();
+        if (h == 0 && valid) M2[c * S + c] = rs;
+        x = valid ? -g * rs * rs : 0.0;
+        wave_sync();
+    } else {
+        // ---- Cholesky H + eps I = L L' in place (lane c = row c, k split over the halves) ----------
+        double invd = 0.0;   // lane c: 1 / L[c][c]
+        const double* rowi = M1 + c * S;
+        for (int j = 0; j < n; ++j) {
+            const double* rowj = M1 + j * S;
+            double s = 0.0;
+            const int kk_end = (j + HV - 1) / HV;
+            for (int kk = 0; kk < kk_end; ++kk) {
+                const int k = kk * HV + h;
+                const double a = rowi[k], b = rowj[k];
+                s += (k < j) ? a * b : 0.0;
             }
-            M2[i * S + tl] = y;
+            s = rowi[j] - halfsum<NP>(s);
+            const double piv = bcast(s, j);
+            if (!(piv > 0.0)) { x_out = 0.0; iters_out = 0; return QP_NOT_PD; }
+            double sq, rs;
+            fast_sqrt_rsqrt(piv, sq, rs);
+            if (h == 0 && valid && c >= j) M1[c * S + j] = (c == j) ? sq : s * rs;
+            if (c == j) invd = rs;
+            wave_sync();
         }
+        // ---- JT = L^-1 into M2 (lane c = column c, k split over the halves) -------------------------
+        for (int i = 0; i < n; ++i) {
+            const double* Li = M1 + i * S;
+            double s = 0.0;
+            const int kk_end = (i + HV - 1) / HV;
+            for (int kk = 0; kk < kk_end; ++kk) {
+                const int k = kk * HV + h;
+                const double a = Li[k], b = M2[k * S + c];
+                s += (k < i) ? a * b : 0.0;
+            }
+            s = halfsum<NP>(s);
+            const double y = (((i == c) ? 1.0 : 0.0) - s) * bcast(invd, i);
+            if (h == 0 && valid) M2[i * S + c] = y;
+            wave_sync();
+        }
+        // ---- unconstrained minimiser: L y = -g, L' x = y by substitution ---------------------------
+        // (NOT x = -J J'g: with H = A'A + eps I rank deficient, g lies in range(A') and the substitution
+        //  keeps the exact cancellation in the eps-pivots that the explicit inverse loses -- the
+        //  reference's own known-answer test TestQPOases.cpp:274-340 needs it at 1e-6)
+        x = valid ? -g : 0.0;
+        for (int j = 0; j < n; ++j) {
+            const double yj = bcast(x * invd, j);
+            if (c == j) x = yj;
+            else if (valid && c > j) x -= M1[c * S + j] * yj;
+        }
+        for (int j = n - 1; j >= 0; --j) {
+            const double xj = bcast(x * invd, j);
+            if (c == j) x = xj;
+            else if (c < j) x -= M1[j * S + c] * xj;
+        }
+        wave_sync();
     }
-    team_sync();
-    // ---- unconstrained minimiser: L y = -g, L' x = y by substitution ----------------------------
-    // (NOT x = -J J'g: with H = A'A + eps I rank deficient, g lies in range(A') and the substitution
-    //  keeps the exact cancellation in the eps-pivots that the explicit inverse loses -- the
-    //  reference's own known-answer test TestQPOases.cpp:274-340 needs it at 1e-6)
-    double x = valid ? -g : 0.0;
-    for (int j = 0; j < n; ++j) {
-        const double yj = team_bcast<T>(x * invd, j);
-        if (tl == j) x = yj;
-        else if (valid && tl > j) x -= M1[tl * S + j] * yj;
-    }
-    for (int j = n - 1; j >= 0; --j) {
-        const double xj = team_bcast<T>(x * invd, j);
-        if (tl == j) x = xj;
-        else if (tl < j) x -= M1[j * S + tl] * xj;
-    }
-    team_sync();
 
-    int iq = 0;          // size of the working set
+    int iq = 0;          // size of the working set (wave-uniform)
     int Aq = -1;         // lane q < iq: code of the constraint at working-set position q
     double uq = 0.0;     // lane q < iq: its multiplier (inequalities only)
-    int box_state = 0;   // lane i: 0 free, 1 lower bound active, 2 upper bound active
+    int box_state = 0;   // lane c: 0 free, 1 lower bound active, 2 upper bound active
     int iters = 0;
 
-    // ---- equalities first ----------------------------------------------------------------------
+    // ---- equalities first --------------------------------------------------------------------------
     for (int r = 0; r < nrows; ++r) {
         const double lo = clamp_inf(rows.lo(r)), up = clamp_inf(rows.up(r));
         const bool is_eq = (lo == up) && (lo > -kInfty) && (lo < kInfty);
-        if (tl == 0) c.rowstate[r] = is_eq ? 3 : 0;
+        if (c == 0 && h == 0) w.rowstate[r] = is_eq ? 3 : 0;
         if (!is_eq) continue;
-        const double a = rows.elem(r, tl);
-        V0[tl] = a;
-        team_sync();
-        double d = 0.0;
-        if (valid) for (int k = 0; k < n; ++k) d += M2[tl * S + k] * V0[k];
-        const double d2 = (tl >= iq) ? d : 0.0;
-        const double dd = team_sum<T>(d * d);
-        const double nd2 = team_sum<T>(d2 * d2);
-        const double resid = lo - team_sum<T>(a * x);
+        const double a = rows.elem(r, c);
+        if (h == 0) V0[c] = a;
+        wave_sync();
+        const double d = jt_rows_dot<NP>(w, V0);
+        const double d2 = (c >= iq) ? d : 0.0;
+        const double dd = colsum<NP>(d * d);
+        const double nd2 = colsum<NP>(d2 * d2);
+        const double resid = lo - colsum<NP>(a * x);
         if (!(nd2 > kDepTol2 * dd)) {   // row is (numerically) a combination of the rows already in
             if (fabs(resid) <= kEqTol * fmax(1.0, fabs(lo))) continue;   // redundant and consistent
             x_out = x; iters_out = iters; return QP_INFEASIBLE;
         }
-        V1[tl] = d2;
-        team_sync();
-        double z = 0.0;
-        if (valid) for (int j = iq; j < n; ++j) z += M2[j * S + tl] * V1[j];
-        x += (resid / nd2) * z;
-        householder_add<T>(c, d, d2, z, nd2, iq);
-        if (tl == iq) Aq = -2 - r;
+        if (h == 0) V1[c] = d2;
+        wave_sync();
+        const double z = jt_cols_dot<NP>(w, V1);
+        x += (resid * fast_rcp(nd2)) * z;
+        householder_add<NP>(w, d, d2, z, nd2, iq);
+        if (c == iq) Aq = -2 - r;
         iq++;
         iters++;
     }
     const int me = iq;
-    team_sync();
+    wave_sync();
 
-    // ---- inequality loop -------------------------------------------------------------------------
+    // ---- inequality loop -----------------------------------------------------------------------------
     int status = QP_SOLVED;
     const int kNone = 0x7fffffff;
     for (;;) {
@@ -212,20 +274,20 @@ __device__ int gi_solve(const TeamCtx<T>& c, const RowSrc& rows, int nrows, doub
         if (has_box && valid) {
             if (box_state != 1 && lb > -kInfty) {
                 const double s = x - lb;
-                if (s < -kViolTol * fmax(1.0, fabs(lb)) && s < cand) { cand = s; code = tl; }
+                if (s < -kViolTol * fmax(1.0, fabs(lb)) && s < cand) { cand = s; code = c; }
             }
             if (box_state != 2 && ub < kInfty) {
                 const double s = ub - x;
-                if (s < -kViolTol * fmax(1.0, fabs(ub)) && s < cand) { cand = s; code = n + tl; }
+                if (s < -kViolTol * fmax(1.0, fabs(ub)) && s < cand) { cand = s; code = n + c; }
             }
         }
         for (int r = 0; r < nrows; ++r) {
-            const int st = c.rowstate[r];
+            const int st = w.rowstate[r];
             if (st == 3) continue;
             const double lo = clamp_inf(rows.lo(r)), up = clamp_inf(rows.up(r));
             const bool has_lo = lo > -kInfty, has_up = up < kInfty;
             if (!has_lo && !has_up) continue;
-            const double ax = team_sum<T>(rows.elem(r, tl) * x);
+            const double ax = colsum<NP>(rows.elem(r, c) * x);
             if (st != 1 && has_lo) {
                 const double s = ax - lo;
                 if (s < -kViolTol * fmax(1.0, fabs(lo)) && s < cand) { cand = s; code = 2 * n + 2 * r; }
@@ -235,82 +297,85 @@ __device__ int gi_solve(const TeamCtx<T>& c, const RowSrc& rows, int nrows, doub
                 if (s < -kViolTol * fmax(1.0, fabs(up)) && s < cand) { cand = s; code = 2 * n + 2 * r + 1; }
             }
         }
-        team_argmin<T>(cand, code);
+        colargmin<NP>(cand, code);
+        code = uniform_i(code);
         if (code == kNone) break;   // primal feasible: optimal
         if (++iters > max_iter) { status = QP_MAX_ITER; break; }
 
         const int ip = code;
-        double s_ip = cand;
+        double s_ip = bcast(cand, 0);
         double u_new = 0.0;
         const bool ip_box = ip < 2 * n;
         const int ip_var = ip_box ? (ip < n ? ip : ip - n) : 0;
         const int ip_row = ip_box ? 0 : (ip - 2 * n) >> 1;
         const double ip_sgn = ip_box ? (ip < n ? 1.0 : -1.0) : ((ip & 1) ? -1.0 : 1.0);
         double np = 0.0;   // lane-distributed normal (general rows only)
-        if (!ip_box) np = ip_sgn * rows.elem(ip_row, tl);
+        if (!ip_box) np = ip_sgn * rows.elem(ip_row, c);
 
         bool failed = false;
         for (;;) {
             // d = J' n
-            double d = 0.0;
+            double d;
             if (ip_box) {
-                if (valid) d = ip_sgn * M2[tl * S + ip_var];
+                d = ip_sgn * M2[c * S + ip_var];
             } else {
-                V0[tl] = np;
-                team_sync();
-                if (valid) for (int k = 0; k < n; ++k) d += M2[tl * S + k] * V0[k];
+                if (h == 0) V0[c] = np;
+                wave_sync();
+                d = jt_rows_dot<NP>(w, V0);
             }
-            const double d2 = (tl >= iq) ? d : 0.0;
-            const double dd = team_sum<T>(d * d);
-            const double nd2 = team_sum<T>(d2 * d2);
+            const double d2 = (c >= iq) ? d : 0.0;
+            const double dd = colsum<NP>(d * d);
+            const double nd2 = colsum<NP>(d2 * d2);
             const bool z_ok = nd2 > kDepTol2 * dd;
             // z = J2 d2 : primal step direction
-            V1[tl] = d2;
-            team_sync();
-            double z = 0.0;
-            if (valid) for (int j = iq; j < n; ++j) z += M2[j * S + tl] * V1[j];
+            if (h == 0) V1[c] = d2;
+            wave_sync();
+            const double z = jt_cols_dot<NP>(w, V1);
             // r = R^-1 d1 restricted to the inequality part [me, iq): dual step direction
             double rr = 0.0;
             {
-                double d1 = (tl < iq) ? d : 0.0;
+                double d1 = (c < iq) ? d : 0.0;
                 for (int j = iq - 1; j >= me; --j) {
-                    const double rj = team_bcast<T>(d1, j) / M1[j * S + j];
-                    if (tl == j) rr = rj;
-                    if (tl >= me && tl < j) d1 -= M1[tl * S + j] * rj;
+                    const double rj = bcast(d1, j) * fast_rcp(M1[j * S + j]);
+                    if (c == j) rr = rj;
+                    if (c >= me && c < j) d1 -= M1[c * S + j] * rj;
                 }
             }
             // step lengths (eiquadprog.hpp:343-366)
-            double t1 = (tl >= me && tl < iq && rr > 0.0) ? fmax(uq, 0.0) / rr : INFINITY;
-            int lpos = tl;
-            team_argmin<T>(t1, lpos);
-            const double t2 = z_ok ? (-s_ip / nd2) : INFINITY;
+            double t1 = (c >= me && c < iq && rr > 0.0) ? fast_div(fmax(uq, 0.0), rr) : INFINITY;
+            int lpos = c;
+            colargmin<NP>(t1, lpos);
+            lpos = uniform_i(lpos);
+            t1 = bcast(t1, 0);
+            const double t2 = z_ok ? (-s_ip * fast_rcp(nd2)) : INFINITY;
             if (!(t1 < INFINITY) && !(t2 < INFINITY)) { failed = true; break; }   // infeasible
             if (t2 <= t1) {
                 // full step: constraint ip becomes active
                 x += t2 * z;
-                if (tl >= me && tl < iq) uq -= t2 * rr;
+                if (c >= me && c < iq) uq -= t2 * rr;
                 u_new += t2;
-                householder_add<T>(c, d, d2, z, nd2, iq);
-                if (tl == iq) { Aq = ip; uq = u_new; }
-                if (ip_box) { if (tl == ip_var) box_state = (ip < n) ? 1 : 2; }
-                else { if (tl == 0) c.rowstate[ip_row] = (ip & 1) ? 2 : 1; }
+                householder_add<NP>(w, d, d2, z, nd2, iq);
+                if (c == iq) { Aq = ip; uq = u_new; }
+                if (ip_box) { if (c == ip_var) box_state = (ip < n) ? 1 : 2; }
+                else { if (c == 0 && h == 0) w.rowstate[ip_row] = (ip & 1) ? 2 : 1; }
                 iq++;
-                team_sync();
+                wave_sync();
                 break;
             }
             // partial step (or pure dual step when z == 0): drop the blocking constraint
             if (z_ok) x += t1 * z;
-            if (tl >= me && tl < iq) uq -= t1 * rr;
+            if (c >= me && c < iq) uq -= t1 * rr;
             u_new += t1;
-            const int cdrop = team_bcast_i<T>(Aq, lpos);
-            if (cdrop < 2 * n) { if (tl == (cdrop < n ? cdrop : cdrop - n)) box_state = 0; }
-            else { if (tl == 0) c.rowstate[(cdrop - 2 * n) >> 1] = 0; }
-            drop_constraint<T>(c, lpos, iq, Aq, uq);
+            const int cdrop = bcast_i(Aq, lpos);
+            if (cdrop < 2 * n) { if (c == (cdrop < n ? cdrop : cdrop - n)) box_state = 0; }
+            else { if (c == 0 && h == 0) w.rowstate[(cdrop - 2 * n) >> 1] = 0; }
+            drop_constraint<NP>(w, lpos, iq, Aq, uq);
             if (z_ok) {
-                if (ip_box) s_ip = team_bcast<T>((ip < n) ? (x - lb) : (ub - x), ip_var);
+                if (ip_box) s_ip = bcast((ip < n) ? (x - lb) : (ub - x), ip_var);
                 else {
-                    const double ax = team_sum<T>(np * x);   // = sgn * a'x
+                    const double ax = colsum<NP>(np * x);   // = sgn * a'x
                     s_ip = (ip & 1) ? (clamp_inf(rows.up(ip_row)) + ax) : (ax - clamp_inf(rows.lo(ip_row)));
+                    s_ip = bcast(s_ip, 0);
                 }
             }
             if (++iters > max_iter) { status = QP_MAX_ITER; failed = true; break; }

@@ -1,14 +1,16 @@
-// osot_team.h -- team-of-lanes primitives for gfx950 (wave64).
+// osot_team.h -- wavefront primitives for gfx950 (wave64).
 //
-// One QP instance is solved by a TEAM of T lanes (T = 32: two instances per wavefront, T = 64: one).
-// Lane t of a team owns element t of every length-n vector; matrices live in the team's LDS slice.
-// A team never spans wavefronts, so every collective below is a wave-level data movement
-// (ds_bpermute / DPP) and the LDS hand-offs between lanes need no s_barrier: LDS instructions of one
-// wave are executed in order, the fences only stop the compiler from reordering them.
+// ONE QP instance is solved by ONE wavefront.  With NP = padded problem size (32 or 64) the 64 lanes are
+// laid out as  lane = c + NP*h :  c = column/element index, h = "half" (HV = 64/NP halves).  Every length-n
+// vector is held as one element per lane, REPLICATED across the halves; matrices live in the wave's LDS
+// slice.  For NP = 32 the two halves split the inner (k) range of every mat-vec and rank-1 update, so the
+// serial trip counts are n/2.  All control flow is wave-uniform: loop counters and working-set sizes live
+// in SGPRs, broadcasts are v_readlane, reductions are DPP row operations + v_permlane{16,32}_swap (no
+// ds_bpermute round trips), and the LDS hand-offs between lanes need no s_barrier: LDS instructions of one
+// wave execute in order, the fences below only stop the compiler from reordering them.
 //
-// tests/emu/ provides a host-side lock-step emulation of exactly this interface (same names) so the
-// kernel bodies in osot_qp_core.h can be exercised on a machine without a GPU; that header is test
-// infrastructure and is never part of the product build.
+// tests/emu/osot_team.h is the host lock-step twin of this interface (same names, same semantics) used to
+// execute the kernel bodies without a GPU; it is test infrastructure, never part of the product build.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -18,55 +20,147 @@
 
 namespace osot {
 
-// make this team's earlier LDS writes visible to its later LDS reads (other lanes of the same wave)
-__device__ __forceinline__ void team_sync() {
+// make this wave's earlier LDS writes visible to its later LDS reads (other lanes of the same wave)
+__device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int T>
-__device__ __forceinline__ double team_sum(double v) {
-#pragma unroll
-    for (int m = T / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, T);
+__device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ---- DPP helpers on doubles (two 32-bit halves) ------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+
+constexpr int DPP_XOR1 = 0xB1;          // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;          // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141;  // lane i <-> 7-i inside each 8
+constexpr int DPP_MIRROR = 0x140;       // lane i <-> 15-i inside each row of 16
+
+// sum over the 16 lanes of each DPP row; every lane of the row gets it
+__device__ __forceinline__ double row16_sum(double v) {
+    v += dpp_f64<DPP_XOR1>(v);
+    v += dpp_f64<DPP_XOR2>(v);
+    v += dpp_f64<DPP_HALF_MIRROR>(v);
+    v += dpp_f64<DPP_MIRROR>(v);
     return v;
 }
-
-template <int T>
-__device__ __forceinline__ double team_bcast(double v, int src) {
-    return __shfl(v, src, T);
+// v_permlane16_swap with both operands = v returns {even rows duplicated, odd rows duplicated}
+__device__ __forceinline__ void swap16_pair(double v, double& a, double& b) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    auto pl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto ph = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    a = __hiloint2double((int)ph[0], (int)pl[0]);
+    b = __hiloint2double((int)ph[1], (int)pl[1]);
+}
+__device__ __forceinline__ void swap32_pair(double v, double& a, double& b) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    auto pl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto ph = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    a = __hiloint2double((int)ph[0], (int)pl[0]);
+    b = __hiloint2double((int)ph[1], (int)pl[1]);
+}
+__device__ __forceinline__ void swap16_pair_i(int v, int& a, int& b) {
+    auto p = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    a = (int)p[0]; b = (int)p[1];
+}
+__device__ __forceinline__ void swap32_pair_i(int v, int& a, int& b) {
+    auto p = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    a = (int)p[0]; b = (int)p[1];
 }
 
-template <int T>
-__device__ __forceinline__ int team_bcast_i(int v, int src) {
-    return __shfl(v, src, T);
+// ---- reductions over the NP columns (lanes with equal h); every lane gets the result ------------------
+template <int NP>
+__device__ __forceinline__ double colsum(double v) {
+    v = row16_sum(v);
+    double a, b;
+    swap16_pair(v, a, b);
+    v = a + b;                       // 32 lanes of a half
+    if (NP == 64) { swap32_pair(v, a, b); v = a + b; }
+    return v;
+}
+// v(c,0) + v(c,1): combines the partial results of the two halves (identity for NP = 64)
+template <int NP>
+__device__ __forceinline__ double halfsum(double v) {
+    if (NP == 64) return v;
+    double a, b;
+    swap32_pair(v, a, b);
+    return a + b;
 }
 
-// minimum of v over the team with the payload of the (lowest-lane) minimiser; every lane gets both
-template <int T>
-__device__ __forceinline__ void team_argmin(double& v, int& payload) {
-#pragma unroll
-    for (int m = T / 2; m >= 1; m >>= 1) {
-        double ov = __shfl_xor(v, m, T);
-        int op = __shfl_xor(payload, m, T);
-        bool take = (ov < v) || (ov == v && op < payload);
-        v = take ? ov : v;
-        payload = take ? op : payload;
+// minimum over the columns with the payload of the minimiser (ties: smaller payload); every lane gets both
+__device__ __forceinline__ void argmin_step(double& v, int& p, double ov, int op) {
+    const bool take = (ov < v) || (ov == v && op < p);
+    v = take ? ov : v;
+    p = take ? op : p;
+}
+template <int NP>
+__device__ __forceinline__ void colargmin(double& v, int& p) {
+    argmin_step(v, p, dpp_f64<DPP_XOR1>(v), dpp_i32<DPP_XOR1>(p));
+    argmin_step(v, p, dpp_f64<DPP_XOR2>(v), dpp_i32<DPP_XOR2>(p));
+    argmin_step(v, p, dpp_f64<DPP_HALF_MIRROR>(v), dpp_i32<DPP_HALF_MIRROR>(p));
+    argmin_step(v, p, dpp_f64<DPP_MIRROR>(v), dpp_i32<DPP_MIRROR>(p));
+    double a, b; int pa, pb;
+    swap16_pair(v, a, b); swap16_pair_i(p, pa, pb);
+    v = a; p = pa; argmin_step(v, p, b, pb);
+    if (NP == 64) {
+        swap32_pair(v, a, b); swap32_pair_i(p, pa, pb);
+        v = a; p = pa; argmin_step(v, p, b, pb);
     }
 }
 
-template <int T>
-__device__ __forceinline__ bool team_any(bool p) {
-    int v = p ? 1 : 0;
-#pragma unroll
-    for (int m = T / 2; m >= 1; m >>= 1) v |= __shfl_xor(v, m, T);
-    return v != 0;
+// value held by lane `lane` (wave-uniform index) -> every lane (v_readlane: the result lives in SGPRs)
+__device__ __forceinline__ double bcast(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ int bcast_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
-// value held by lane (t+1) of the team (lane T-1 receives its own)
-template <int T>
-__device__ __forceinline__ double team_shift_down(double v) { return __shfl_down(v, 1, T); }
-template <int T>
-__device__ __forceinline__ int team_shift_down_i(int v) { return __shfl_down(v, 1, T); }
+// value of lane c+1 of the same half (lane NP-1 keeps its own): used to shift the working-set bookkeeping
+template <int NP>
+__device__ __forceinline__ double shift_down(double v) { return __shfl_down(v, 1, NP); }
+template <int NP>
+__device__ __forceinline__ int shift_down_i(int v) { return __shfl_down(v, 1, NP); }
+
+// ---- fp64 reciprocal / square root without the IEEE corner-case sequences -----------------------------
+// v_rcp_f64 / v_rsq_f64 seeds + Newton steps: ~1 ulp for normal arguments, far cheaper than the compiler's
+// div_scale/div_fmas/div_fixup expansion.  Arguments here are pivots/norms that are checked > 0 first.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    return r;
+}
+__device__ __forceinline__ double fast_div(double a, double b) {
+    const double r = fast_rcp(b);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+// returns sqrt(x) and 1/sqrt(x) for x > 0.  The reciprocal is taken from the corrected root so that
+// exact inputs stay exact (sqrt(1) = 1, 1/1 = 1): the reference's integer-valued known-answer tests on
+// rank-deficient H rely on exact cancellation in the eps-pivots (TestQPOases.cpp:274-340).
+__device__ __forceinline__ void fast_sqrt_rsqrt(double x, double& s, double& rs) {
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    const double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    s = g;
+    rs = fast_rcp(g);
+}
 
 }  // namespace osot

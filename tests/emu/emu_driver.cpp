@@ -19,9 +19,8 @@ extern "C" __attribute__((visibility("default"))) int emu_ihqp_solve(const osot_
     for (int k = 0; k < plan->n_levels; ++k) { D.A[k] = b->A[k]; D.b[k] = b->b[k]; D.w[k] = b->w[k]; D.c[k] = b->c[k]; }
     D.C = b->C; D.lo = b->lo; D.up = b->up; D.l = b->l; D.u = b->u;
     D.dq = b->dq; D.x_levels = b->x_levels; D.status = b->status; D.iterations = b->iterations;
-    const int tpb = 64 / T;
-    const unsigned grid = (unsigned)((b->B + tpb - 1) / tpb);
-    if (T == 32) emu::launch(osot_cascade_kernel<32>, grid, lds, 32, P, D);
+    const unsigned grid = (unsigned)b->B;
+    if (T == 32) emu::launch(osot_cascade_kernel<32>, grid, lds, 64, P, D);
     else emu::launch(osot_cascade_kernel<64>, grid, lds, 64, P, D);
     return OSOT_OK;
 }
@@ -31,17 +30,15 @@ extern "C" __attribute__((visibility("default"))) int emu_qp_solve_batch(int B, 
                                   double eps_abs, int max_iter, double* x, int* status, int* iterations) {
     DevQP Q;
     memset(&Q, 0, sizeof(Q));
-    Q.B = B; Q.n = n; Q.S = n | 1; Q.nc = nc;
+    Q.B = B; Q.n = n; Q.nc = nc;
     Q.max_iter = max_iter > 0 ? max_iter : 20 * (n + nc) + 100;
     Q.eps_abs = eps_abs;
     Q.H = H; Q.g = g; Q.A = A; Q.lA = lA; Q.uA = uA; Q.l = l; Q.u = u; Q.x = x; Q.status = status; Q.iterations = iterations;
     const int T = n <= 32 ? 32 : 64;
     int opt_off;
-    Q.lds_team_doubles = lds_layout(n, T, 0, nc, &opt_off, &Q.lds_rowstate_off);
-    const size_t lds = (size_t)(64 / T) * Q.lds_team_doubles * sizeof(double);
-    const int tpb = 64 / T;
-    const unsigned grid = (unsigned)((B + tpb - 1) / tpb);
-    if (T == 32) emu::launch(osot_qp_kernel<32>, grid, lds, 32, Q);
+    const size_t lds = (size_t)lds_layout(T, 0, nc, &opt_off, &Q.lds_rowstate_off) * sizeof(double);
+    const unsigned grid = (unsigned)B;
+    if (T == 32) emu::launch(osot_qp_kernel<32>, grid, lds, 64, Q);
     else emu::launch(osot_qp_kernel<64>, grid, lds, 64, Q);
     return OSOT_OK;
 }

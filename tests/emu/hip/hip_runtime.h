@@ -65,6 +65,25 @@ inline void exchange(const void* in, void* out, size_t bytes, int src_abs_lane, 
     }
     if (out) memcpy(out, s.lanes[src_abs_lane].slot[q & 1], bytes);
 }
+// rendezvous of the whole 64-lane wave; every lane receives all 64 deposited values
+inline void allgather(const void* in, void* out, size_t bytes) {
+    State& s = S();
+    const int me = s.cur;
+    Lane& L = s.lanes[me];
+    const unsigned long long q = ++L.seq;
+    memcpy(L.slot[q & 1], in, bytes);
+    for (;;) {
+        bool all = true;
+        for (int i = 0; i < 64; ++i)
+            if (s.lanes[i].seq < q) {
+                if (s.lanes[i].done) { fprintf(stderr, "emu: lane %d exited before a wave collective\n", i); abort(); }
+                all = false; break;
+            }
+        if (all) break;
+        yield();
+    }
+    for (int i = 0; i < 64; ++i) memcpy((char*)out + i * bytes, s.lanes[i].slot[q & 1], bytes);
+}
 inline void trampoline() {
     State& s = S();
     s.body();

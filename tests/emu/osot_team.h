@@ -1,26 +1,55 @@
 // tests/emu/osot_team.h -- TEST INFRASTRUCTURE ONLY: the host lock-step twin of
-// opensot_amd/csrc/osot_team.h (same names, same semantics), picked up by include order when the
-// kernel headers are compiled for the emulator (tests/emu/emu_driver.cpp).
+// opensot_amd/csrc/osot_team.h (same names, same semantics), picked up through the include path when the
+// kernel headers are compiled for the emulator (tests/emu/emu_driver.cpp).  Every collective is a
+// rendezvous of the whole 64-lane wave, so a missing wave_sync() between an LDS write and another lane's
+// read produces a wrong result here even though real hardware executes the wave in lock-step.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cmath>
 
 #define OSOT_DYNAMIC_LDS(name) char* name = emu::dyn_smem_ptr()
 #define OSOT_STATIC_LDS(type, name, count) static type name[count]
 
 namespace osot {
-inline void team_sync() { int z = 0; emu::exchange(&z, nullptr, sizeof(int), 0, emu::S().team_width); }
-template <int T> inline double team_sum(double v) { for (int m = T / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, T); return v; }
-template <int T> inline double team_bcast(double v, int src) { return __shfl(v, src, T); }
-template <int T> inline int team_bcast_i(int v, int src) { return __shfl(v, src, T); }
-template <int T> inline void team_argmin(double& v, int& payload) {
-    for (int m = T / 2; m >= 1; m >>= 1) {
-        double ov = __shfl_xor(v, m, T);
-        int op = __shfl_xor(payload, m, T);
-        bool take = (ov < v) || (ov == v && op < payload);
-        v = take ? ov : v; payload = take ? op : payload;
-    }
+inline int emu_lane() { return emu::S().cur; }
+inline void wave_sync() { int z = 0, out[64]; emu::allgather(&z, out, sizeof(int)); }
+inline int uniform_i(int v) { int out[64]; emu::allgather(&v, out, sizeof(int)); return out[0]; }
+
+template <int NP> inline double colsum(double v) {
+    double all[64]; emu::allgather(&v, all, sizeof(double));
+    const int h0 = (emu_lane() / NP) * NP;
+    double s = 0.0;
+    for (int i = 0; i < NP; ++i) s += all[h0 + i];
+    return s;
 }
-template <int T> inline bool team_any(bool p) { int v = p; for (int m = T / 2; m >= 1; m >>= 1) v |= __shfl_xor(v, m, T); return v != 0; }
-template <int T> inline double team_shift_down(double v) { return __shfl_down(v, 1, T); }
-template <int T> inline int team_shift_down_i(int v) { return __shfl_down(v, 1, T); }
+template <int NP> inline double halfsum(double v) {
+    double all[64]; emu::allgather(&v, all, sizeof(double));
+    if (NP == 64) return v;
+    const int c = emu_lane() % NP;
+    return all[c] + all[c + NP];
+}
+template <int NP> inline void colargmin(double& v, int& p) {
+    double av[64]; int ap[64];
+    emu::allgather(&v, av, sizeof(double)); emu::allgather(&p, ap, sizeof(int));
+    const int h0 = (emu_lane() / NP) * NP;
+    double bv = av[h0]; int bp = ap[h0];
+    for (int i = 1; i < NP; ++i)
+        if (av[h0 + i] < bv || (av[h0 + i] == bv && ap[h0 + i] < bp)) { bv = av[h0 + i]; bp = ap[h0 + i]; }
+    v = bv; p = bp;
+}
+inline double bcast(double v, int lane) { double all[64]; emu::allgather(&v, all, sizeof(double)); return all[lane]; }
+inline int bcast_i(int v, int lane) { int all[64]; emu::allgather(&v, all, sizeof(int)); return all[lane]; }
+template <int NP> inline double shift_down(double v) {
+    double all[64]; emu::allgather(&v, all, sizeof(double));
+    const int l = emu_lane(), c = l % NP;
+    return (c + 1 < NP) ? all[l + 1] : all[l];
+}
+template <int NP> inline int shift_down_i(int v) {
+    int all[64]; emu::allgather(&v, all, sizeof(int));
+    const int l = emu_lane(), c = l % NP;
+    return (c + 1 < NP) ? all[l + 1] : all[l];
+}
+inline double fast_rcp(double x) { return 1.0 / x; }
+inline double fast_div(double a, double b) { return a / b; }
+inline void fast_sqrt_rsqrt(double x, double& s, double& rs) { s = std::sqrt(x); rs = 1.0 / s; }
 }  // namespace osot
