@@ -202,6 +202,11 @@ int osot_ihqp_solve(osot_solver* s, const osot_qp_batch* batch, void* hip_stream
  * with reset != 0; measured with hipEvents on the launch stream. *launches receives the count. */
 int osot_solver_kernel_time_ms(osot_solver* s, int reset, double* avg_ms, int* launches);
 int osot_solver_set_timing(osot_solver* s, int enabled);
+/* diagnostic: run the cascade once through the instrumented instantiation of the kernel and write, per
+ * instance, OSOT_N_PHASES shader-clock cycle counts (H/g build, Cholesky, L^-1, substitution, equality
+ * phase, inequality loop, optimality rhs, total) to cycles[B][OSOT_N_PHASES] (device, int64). */
+#define OSOT_N_PHASES 8
+int osot_solver_profile_phases(osot_solver* s, const osot_qp_batch* batch, long long* cycles, void* hip_stream);
 
 /* ---- batch-of-one BackEnd surface (host pointers; mirrors BackEnd.h) ------------------------ */
 typedef struct osot_backend osot_backend;

@@ -52,6 +52,7 @@ struct DevBatch {
     double* x_levels;
     int* status;
     int* iterations;
+    long long* prof;   // [B][PH_COUNT] shader-clock cycles per phase (profiling instantiation only)
 };
 
 // rows seen by level k: [ global C ; A_0 ; ... ; A_{k-1} ]  (iHQP.cpp:282-333)
@@ -92,7 +93,7 @@ struct CascadeRows {
     }
 };
 
-template <int NP>
+template <int NP, bool PROF>
 __global__ void __launch_bounds__(64) osot_cascade_kernel(const DevPlan P, const DevBatch D) {
     OSOT_DYNAMIC_LDS(osot_smem);
     constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
@@ -124,8 +125,12 @@ __global__ void __launch_bounds__(64) osot_cascade_kernel(const DevPlan P, const
     int status = QP_SOLVED;
     int iters_total = 0;
     bool any = false;
+    long long prof[PH_COUNT];
+    if (PROF) for (int i = 0; i < PH_COUNT; ++i) prof[i] = 0;
+    const long long t_begin = PROF ? (long long)clock64() : 0;
     for (int k = 0; k < P.L; ++k) {
         if (!((P.active_mask >> k) & 1u)) continue;
+        OSOT_PH_BEGIN();
         const int m = P.m[k], ma = P.ma[k];
         const double* Ak = D.A[k] ? D.A[k] + inst * ma * n : nullptr;
         const double* bk = D.b[k] + inst * m;
@@ -184,7 +189,9 @@ __global__ void __launch_bounds__(64) osot_cascade_kernel(const DevPlan P, const
 
         const int nrows = P.nc + P.optoff[k];
         int iters = 0;
-        const int st = gi_solve<NP>(w, rows, nrows, g, diag_h, hdiag, has_box, lb, ub, P.max_iter, x, iters);
+        OSOT_PH_END(PH_HBUILD);
+        const int st = gi_solve<NP, PROF>(w, rows, nrows, g, diag_h, hdiag, has_box, lb, ub, P.max_iter, x, iters, prof);
+        if (PROF) ph_t0_ = (long long)clock64();
         iters_total += iters;
         if (st != QP_SOLVED) { status = st; break; }
         any = true;
@@ -199,6 +206,11 @@ __global__ void __launch_bounds__(64) osot_cascade_kernel(const DevPlan P, const
             if (m > ma && valid && h == 0) opt[P.optoff[k] + ma + c] = x;   // identity rows: e_c' x
             wave_sync();
         }
+        OSOT_PH_END(PH_OPT);
+    }
+    if (PROF && D.prof && lane == 0) {
+        prof[PH_TOTAL] = (long long)clock64() - t_begin;
+        for (int i = 0; i < PH_COUNT; ++i) D.prof[inst * PH_COUNT + i] = prof[i];
     }
     if (status != QP_SOLVED || !any) x = 0.0;   // failed instances return dq = 0 (coman_ik.cpp:189-190)
     if (valid && h == 0) D.dq[inst * n + c] = x;
@@ -266,7 +278,7 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
     rows.Q = &Q; rows.inst = inst;
     double x = 0.0;
     int iters = 0;
-    const int st = gi_solve<NP>(w, rows, Q.nc, g, false, 0.0, has_box, lb, ub, Q.max_iter, x, iters);
+    const int st = gi_solve<NP, false>(w, rows, Q.nc, g, false, 0.0, has_box, lb, ub, Q.max_iter, x, iters, nullptr);
     if (valid && h == 0) Q.x[inst * n + c] = (st == QP_SOLVED) ? x : 0.0;
     if (lane == 0) {
         Q.status[inst] = st;

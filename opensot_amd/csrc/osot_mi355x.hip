@@ -90,7 +90,8 @@ int osot_solver_create(const osot_plan_desc* plan, int max_batch, int device, os
     HIP_TRY(hipSetDevice(device));
     DevPlan P; int T; size_t lds;
     make_dev_plan(*plan, nullptr, P, T, lds);
-    rc = (T == 32) ? ensure_lds(osot_cascade_kernel<32>, lds) : ensure_lds(osot_cascade_kernel<64>, lds);
+    rc = (T == 32) ? ensure_lds(osot_cascade_kernel<32, false>, lds) : ensure_lds(osot_cascade_kernel<64, false>, lds);
+    if (rc == OSOT_OK) rc = (T == 32) ? ensure_lds(osot_cascade_kernel<32, true>, lds) : ensure_lds(osot_cascade_kernel<64, true>, lds);
     if (rc != OSOT_OK) return rc;
     osot_solver* s = new osot_solver();
     s->plan = *plan;
@@ -135,7 +136,18 @@ int osot_solver_kernel_time_ms(osot_solver* s, int reset, double* avg_ms, int* l
     return OSOT_OK;
 }
 
+static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream, long long* prof);
+
 int osot_ihqp_solve(osot_solver* s, const osot_qp_batch* b, void* hip_stream) {
+    return ihqp_launch(s, b, hip_stream, nullptr);
+}
+
+int osot_solver_profile_phases(osot_solver* s, const osot_qp_batch* b, long long* cycles, void* hip_stream) {
+    if (!cycles) return fail(OSOT_ERR_INVALID, "null cycles");
+    return ihqp_launch(s, b, hip_stream, cycles);
+}
+
+static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream, long long* prof) {
     if (!s || !b) return fail(OSOT_ERR_INVALID, "null solver/batch");
     if (b->B < 0 || b->B > s->max_batch) return fail(OSOT_ERR_INVALID, "batch size exceeds max_batch");
     if (b->B == 0) return OSOT_OK;   // empty batch: nothing to do
@@ -156,6 +168,7 @@ int osot_ihqp_solve(osot_solver* s, const osot_qp_batch* b, void* hip_stream) {
     D.C = P.nc ? b->C : nullptr; D.lo = b->lo; D.up = b->up;
     D.l = pl.n_bounds ? b->l : nullptr; D.u = pl.n_bounds ? b->u : nullptr;
     D.dq = b->dq; D.x_levels = b->x_levels; D.status = b->status; D.iterations = b->iterations;
+    D.prof = prof;
     hipStream_t st = (hipStream_t)hip_stream;
     const unsigned grid = (unsigned)b->B;
     std::pair<hipEvent_t, hipEvent_t> ev;
@@ -164,8 +177,13 @@ int osot_ihqp_solve(osot_solver* s, const osot_qp_batch* b, void* hip_stream) {
         else { HIP_TRY(hipEventCreate(&ev.first)); HIP_TRY(hipEventCreate(&ev.second)); }
         HIP_TRY(hipEventRecord(ev.first, st));
     }
-    if (T == 32) hipLaunchKernelGGL(osot_cascade_kernel<32>, dim3(grid), dim3(64), lds, st, P, D);
-    else hipLaunchKernelGGL(osot_cascade_kernel<64>, dim3(grid), dim3(64), lds, st, P, D);
+    if (prof) {
+        if (T == 32) hipLaunchKernelGGL((osot_cascade_kernel<32, true>), dim3(grid), dim3(64), lds, st, P, D);
+        else hipLaunchKernelGGL((osot_cascade_kernel<64, true>), dim3(grid), dim3(64), lds, st, P, D);
+    } else {
+        if (T == 32) hipLaunchKernelGGL((osot_cascade_kernel<32, false>), dim3(grid), dim3(64), lds, st, P, D);
+        else hipLaunchKernelGGL((osot_cascade_kernel<64, false>), dim3(grid), dim3(64), lds, st, P, D);
+    }
     HIP_TRY(hipGetLastError());
     if (s->timing) {
         HIP_TRY(hipEventRecord(ev.second, st));

@@ -147,10 +147,15 @@ __device__ __forceinline__ void drop_constraint(const WaveCtx<NP>& w, int qq, in
 // Pre:  general H: M1 holds H + eps I (lower triangle used);  diagonal H (diag_h = true): hdiag is the
 //       lane's diagonal entry h_cc + eps and M1/M2 contents are ignored.
 // Post: returns status, x is lane-distributed (replicated over the halves).
-template <int NP, class RowSrc>
+// phase cycle counters of the profiling instantiation (PROF = true): indices into prof[]
+enum { PH_HBUILD = 0, PH_CHOL = 1, PH_INV = 2, PH_SUBST = 3, PH_EQ = 4, PH_INEQ = 5, PH_OPT = 6, PH_TOTAL = 7, PH_COUNT = 8 };
+#define OSOT_PH_BEGIN() long long ph_t0_ = PROF ? (long long)clock64() : 0
+#define OSOT_PH_END(idx) do { if (PROF) { const long long t_ = (long long)clock64(); prof[idx] += t_ - ph_t0_; ph_t0_ = t_; } } while (0)
+
+template <int NP, bool PROF, class RowSrc>
 __device__ int gi_solve(const WaveCtx<NP>& w, const RowSrc& rows, int nrows, double g, bool diag_h,
                         double hdiag, bool has_box, double lb, double ub, int max_iter, double& x_out,
-                        int& iters_out) {
+                        int& iters_out, long long* prof) {
     constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
     const int c = w.c, h = w.h, n = w.n;
     double* M1 = w.M1;
@@ -161,6 +166,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w, const RowSrc& rows, int nrows, dou
     lb = clamp_inf(lb);
     ub = clamp_inf(ub);
     double x;
+    OSOT_PH_BEGIN();
 
     if (diag_h) {
         // H + eps I diagonal (a level made of a Postural block only): L = sqrt(diag), JT = diag(1/L)
@@ -173,6 +179,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w, const RowSrc& rows, int nrows, dou
         if (h == 0 && valid) M2[c * S + c] = rs;
         x = valid ? -g * rs * rs : 0.0;
         wave_sync();
+        OSOT_PH_END(PH_CHOL);
     } else {
         // ---- Cholesky H + eps I = L L' in place (lane c = row c, k split over the halves) ----------
         double invd = 0.0;   // lane c: 1 / L[c][c]
@@ -195,6 +202,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w, const RowSrc& rows, int nrows, dou
             if (c == j) invd = rs;
             wave_sync();
         }
+        OSOT_PH_END(PH_CHOL);
         // ---- JT = L^-1 into M2 (lane c = column c, k split over the halves) -------------------------
         for (int i = 0; i < n; ++i) {
             const double* Li = M1 + i * S;
@@ -210,6 +218,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w, const RowSrc& rows, int nrows, dou
             if (h == 0 && valid) M2[i * S + c] = y;
             wave_sync();
         }
+        OSOT_PH_END(PH_INV);
         // ---- unconstrained minimiser: L y = -g, L' x = y by substitution ---------------------------
         // (NOT x = -J J'g: with H = A'A + eps I rank deficient, g lies in range(A') and the substitution
         //  keeps the exact cancellation in the eps-pivots that the explicit inverse loses -- the
@@ -226,6 +235,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w, const RowSrc& rows, int nrows, dou
             else if (c < j) x -= M1[j * S + c] * xj;
         }
         wave_sync();
+        OSOT_PH_END(PH_SUBST);
     }
 
     int iq = 0;          // size of the working set (wave-uniform)
@@ -263,6 +273,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w, const RowSrc& rows, int nrows, dou
     }
     const int me = iq;
     wave_sync();
+    OSOT_PH_END(PH_EQ);
 
     // ---- inequality loop -----------------------------------------------------------------------------
     int status = QP_SOLVED;
@@ -382,6 +393,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w, const RowSrc& rows, int nrows, dou
         }
         if (failed) { if (status == QP_SOLVED) status = QP_INFEASIBLE; break; }
     }
+    OSOT_PH_END(PH_INEQ);
     x_out = x;
     iters_out = iters;
     return status;

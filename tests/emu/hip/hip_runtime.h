@@ -159,4 +159,5 @@ inline V __shfl_down(V v, int delta, int width) {
     emu::exchange(&v, &out, sizeof(V), (me / width) * width + src, width);
     return out;
 }
+inline long long clock64() { return 0; }
 inline void __syncthreads() { int z = 0; emu::exchange(&z, nullptr, sizeof(int), 0, 64); }

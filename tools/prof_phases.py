@@ -1,0 +1,12 @@
+import sys; sys.path.insert(0,'/root/repo')
+import numpy as np, torch
+from opensot_amd import synth
+from opensot_amd.solver import BatchedStack
+B=4096
+plan, leaf = synth.make_velocity_stack("C3", B, seed=3000)
+st = BatchedStack(plan, B, device=0, want_levels=False)
+st.update(st.load_leaf(leaf)); st.solve(B); torch.cuda.synchronize()
+cyc = st.profile_phases(B)
+m = cyc.mean(axis=0)
+for name, v in zip(st.PHASES, m): print(f"{name:14s} {v:10.0f} cycles  {100*v/m[-1]:5.1f}%")
+print("iters mean", st.iterations[:B].float().mean().item())
