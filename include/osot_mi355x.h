@@ -204,8 +204,9 @@ int osot_solver_kernel_time_ms(osot_solver* s, int reset, double* avg_ms, int* l
 int osot_solver_set_timing(osot_solver* s, int enabled);
 /* diagnostic: run the cascade once through the instrumented instantiation of the kernel and write, per
  * instance, OSOT_N_PHASES shader-clock cycle counts (H/g build, Cholesky, L^-1, substitution, equality
- * phase, inequality loop, optimality rhs, total) to cycles[B][OSOT_N_PHASES] (device, int64). */
-#define OSOT_N_PHASES 8
+ * phase, inequality loop, optimality rhs, total, then four sub-phases of the equality adds: J'a,
+ * reductions, step direction, Householder update) to cycles[B][OSOT_N_PHASES] (device, int64). */
+#define OSOT_N_PHASES 12
 int osot_solver_profile_phases(osot_solver* s, const osot_qp_batch* batch, long long* cycles, void* hip_stream);
 
 /* ---- batch-of-one BackEnd surface (host pointers; mirrors BackEnd.h) ------------------------ */

@@ -68,15 +68,16 @@ inline int plan_validate(const osot_plan_desc* p, const char** why) {
     return OSOT_OK;
 }
 
-// LDS carve-up (doubles) of one wave's slice for padded size NP; returns the total
-inline int lds_layout(int NP, int n_opt, int n_rows, int* opt_off, int* rowstate_off) {
+// LDS carve-up (doubles) of one wave's slice for padded size NP: M1, M2, V, then the row table
+// (rlo, rup, rptr: 8 B per row each; rowstate, eqlist: 4 B per row each).  Returns the total in doubles.
+inline int lds_layout(int NP, int n_rows, int* rows_off, int* rows_cap) {
     const int S = NP + 1;
     int d = 2 * NP * S + 4 * NP;
-    *opt_off = d;
-    d += (n_opt > 0 ? n_opt : 1);
     d = (d + 1) & ~1;
-    *rowstate_off = d;
-    d += ((n_rows > 0 ? n_rows : 1) + 1) / 2;
+    *rows_off = d;
+    const int cap = ((n_rows > 0 ? n_rows : 1) + 1) & ~1;
+    *rows_cap = cap;
+    d += 3 * cap + cap;   // rlo, rup, rptr + (rowstate, eqlist as ints)
     d = (d + 1) & ~1;
     return d;
 }
@@ -99,7 +100,7 @@ inline int make_dev_plan(const osot_plan_desc& p, const unsigned char* level_act
     P.max_iter = p.max_iter > 0 ? p.max_iter : 20 * (p.n + nrows_max) + 100;
     P.eps_abs = p.eps_abs;
     NP = (p.n <= 32) ? 32 : 64;
-    const int total = lds_layout(NP, P.optoff[p.n_levels], nrows_max, &P.lds_opt_off, &P.lds_rowstate_off);
+    const int total = lds_layout(NP, nrows_max, &P.lds_rows_off, &P.lds_rows_cap);
     lds_bytes = (size_t)total * sizeof(double);
     return OSOT_OK;
 }

@@ -33,8 +33,8 @@ struct DevPlan {
     unsigned active_mask;           // bit k: level k active (iHQP::setActiveStack)
     double eps_abs;
     // LDS carve-up of the wave's slice (doubles): M1, M2, V first (sizes fixed by NP), then
-    int lds_opt_off;                // the optimality right-hand sides A_j x_j
-    int lds_rowstate_off;           // and the int rowstate array
+    int lds_rows_off;               // the row table: rlo, rup, rptr (8 B per row), rowstate, eqlist (4 B per row)
+    int lds_rows_cap;               // capacity (rows), even
 };
 
 struct DevBatch {
@@ -55,46 +55,11 @@ struct DevBatch {
     long long* prof;   // [B][PH_COUNT] shader-clock cycles per phase (profiling instantiation only)
 };
 
-// rows seen by level k: [ global C ; A_0 ; ... ; A_{k-1} ]  (iHQP.cpp:282-333)
-struct CascadeRows {
-    const DevPlan* P;
-    const DevBatch* D;
-    const double* opt;   // LDS: A_j x_j
-    long long inst;
-    __device__ __forceinline__ int level_of(int rr, int& q) const {
-        int j = 0;
-        while (rr >= P->optoff[j + 1]) ++j;
-        q = rr - P->optoff[j];
-        return j;
-    }
-    __device__ __forceinline__ double elem(int r, int lane) const {
-        const int n = P->n;
-        if (lane >= n) return 0.0;
-        if (r < P->nc) return D->C[(inst * P->nc + r) * n + lane];
-        int q;
-        const int j = level_of(r - P->nc, q);
-        if (!((P->active_mask >> j) & 1u)) return 0.0;           // inactive level: 0*x in [-1,1]
-        if (q < P->ma[j]) return D->A[j][(inst * P->ma[j] + q) * n + lane];
-        return (lane == q - P->ma[j]) ? 1.0 : 0.0;               // Postural identity row
-    }
-    __device__ __forceinline__ double lo(int r) const {
-        if (r < P->nc) return D->lo[inst * P->nc + r];
-        int q;
-        const int j = level_of(r - P->nc, q);
-        if (!((P->active_mask >> j) & 1u)) return -1.0;          // iHQP.cpp:301-309
-        return opt[r - P->nc];
-    }
-    __device__ __forceinline__ double up(int r) const {
-        if (r < P->nc) return D->up[inst * P->nc + r];
-        int q;
-        const int j = level_of(r - P->nc, q);
-        if (!((P->active_mask >> j) & 1u)) return 1.0;
-        return opt[r - P->nc];
-    }
-};
-
+// Row table of level k (LDS): [ global C rows ; A_0 ; ... ; A_{k-1} ]  (iHQP.cpp:282-333).  The C entries are
+// filled once per instance, the optimality entries of level j are appended when level j has been solved
+// (lo = up = A_j x_j, iHQP.cpp:164-170; an inactive level contributes 0*x in [-1,1], iHQP.cpp:301-309).
 template <int NP, bool PROF>
-__global__ void __launch_bounds__(64) osot_cascade_kernel(const DevPlan P, const DevBatch D) {
+__global__ void __launch_bounds__(64, 2) osot_cascade_kernel(const DevPlan P, const DevBatch D) {
     OSOT_DYNAMIC_LDS(osot_smem);
     constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
     const int lane = threadIdx.x;
@@ -106,8 +71,11 @@ __global__ void __launch_bounds__(64) osot_cascade_kernel(const DevPlan P, const
     w.M1 = base;
     w.M2 = base + NP * S;
     w.V = base + 2 * NP * S;
-    double* opt = base + P.lds_opt_off;
-    w.rowstate = reinterpret_cast<int*>(base + P.lds_rowstate_off);
+    w.rlo = base + P.lds_rows_off;
+    w.rup = w.rlo + P.lds_rows_cap;
+    w.rptr = reinterpret_cast<unsigned long long*>(w.rup + P.lds_rows_cap);
+    w.rowstate = reinterpret_cast<int*>(w.rptr + P.lds_rows_cap);
+    w.eqlist = w.rowstate + P.lds_rows_cap;
     const int c = w.c, h = w.h;
     const bool valid = c < n;
     // zero the matrices once: the padding beyond n stays zero for the whole kernel
@@ -118,8 +86,13 @@ __global__ void __launch_bounds__(64) osot_cascade_kernel(const DevPlan P, const
     const double lb = (has_box && valid) ? D.l[inst * n + c] : -INFINITY;
     const double ub = (has_box && valid) ? D.u[inst * n + c] : INFINITY;
 
-    CascadeRows rows;
-    rows.P = &P; rows.D = &D; rows.opt = opt; rows.inst = inst;
+    // global rows: bounds and row addresses, lane = row
+    for (int r = lane; r < P.nc; r += 64) {
+        w.rlo[r] = clamp_inf(D.lo[inst * P.nc + r]);
+        w.rup[r] = clamp_inf(D.up[inst * P.nc + r]);
+        w.rptr[r] = reinterpret_cast<unsigned long long>(D.C + (inst * P.nc + r) * n);
+    }
+    wave_sync();
 
     double x = 0.0;
     int status = QP_SOLVED;
@@ -129,18 +102,34 @@ __global__ void __launch_bounds__(64) osot_cascade_kernel(const DevPlan P, const
     if (PROF) for (int i = 0; i < PH_COUNT; ++i) prof[i] = 0;
     const long long t_begin = PROF ? (long long)clock64() : 0;
     for (int k = 0; k < P.L; ++k) {
-        if (!((P.active_mask >> k) & 1u)) continue;
+        if (!((P.active_mask >> k) & 1u)) {
+            // inactive level: its optimality rows are 0*x in [-1, 1] (iHQP.cpp:301-309): never binding
+            if (k + 1 < P.L) {
+                const int off = P.nc + P.optoff[k];
+                for (int q = lane; q < P.m[k]; q += 64) {
+                    w.rlo[off + q] = -kInfty; w.rup[off + q] = kInfty; w.rptr[off + q] = (0x7fffffffull << 1) | 1ull;
+                }
+                wave_sync();
+            }
+            continue;
+        }
         OSOT_PH_BEGIN();
+        {   // re-derive the lane coordinates per level (see launder_i)
+            const int l2 = launder_i(lane);
+            w.c = l2 % NP; w.h = l2 / NP;
+        }
+        const int c = w.c, h = w.h;
+        const bool valid = c < n;
         const int m = P.m[k], ma = P.ma[k];
         const double* Ak = D.A[k] ? D.A[k] + inst * ma * n : nullptr;
         const double* bk = D.b[k] + inst * m;
         const double* wk = D.w[k] ? D.w[k] + inst * m : nullptr;
         double g = 0.0, hdiag = 0.0;
         const bool diag_h = (ma == 0);
+        double hacc[NP / HV];
         if (!diag_h) {
             // ---- H = A'WA + eps I, g = -A'Wb + c.  Lane (c,h) accumulates H[i][c] for i = ii*HV + h in
             // registers; stored rows are staged four at a time through LDS for the broadcasts.
-            double hacc[NP / HV];
 #pragma unroll
             for (int ii = 0; ii < NP / HV; ++ii) hacc[ii] = 0.0;
             for (int r0 = 0; r0 < ma; r0 += 4) {
@@ -164,7 +153,14 @@ __global__ void __launch_bounds__(64) osot_cascade_kernel(const DevPlan P, const
                 for (int u = 0; u < 4; ++u) {
                     const double* Vu = w.V + u * NP + h;
 #pragma unroll
-                    for (int ii = 0; ii < NP / HV; ++ii) hacc[ii] += wa[u] * Vu[ii * HV];
+                    for (int i0 = 0; i0 < NP / HV; i0 += 16) {
+                        double vv[16];
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) vv[t] = Vu[(i0 + t) * HV];
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) hacc[i0 + t] = fma(wa[u], vv[t], hacc[i0 + t]);
+                        sched_fence();   // at most 16 staged values live: keeps the kernel at 2 waves/SIMD
+                    }
                 }
             }
             if (m > ma && valid) {   // Postural block appended to the level: A = I (Postural.cpp:37)
@@ -177,7 +173,8 @@ __global__ void __launch_bounds__(64) osot_cascade_kernel(const DevPlan P, const
 #pragma unroll
             for (int ii = 0; ii < NP / HV; ++ii) {
                 const int i = ii * HV + h;
-                w.M1[i * S + c] = hacc[ii] + ((i == c && valid) ? P.eps_abs : 0.0);
+                hacc[ii] += ((i == c && valid) ? P.eps_abs : 0.0);
+                if (NP == 64) w.M1[i * S + c] = hacc[ii];   // NP = 32 factorises straight from registers
             }
             wave_sync();
         } else if (valid) {   // level = one Postural block: H = W + eps I is diagonal
@@ -190,20 +187,41 @@ __global__ void __launch_bounds__(64) osot_cascade_kernel(const DevPlan P, const
         const int nrows = P.nc + P.optoff[k];
         int iters = 0;
         OSOT_PH_END(PH_HBUILD);
-        const int st = gi_solve<NP, PROF>(w, rows, nrows, g, diag_h, hdiag, has_box, lb, ub, P.max_iter, x, iters, prof);
+        const int st = gi_solve<NP, PROF>(w, nrows, g, diag_h, hdiag, reinterpret_cast<double(&)[16]>(hacc),
+                                          has_box, lb, ub, P.max_iter, x, iters, prof);
         if (PROF) ph_t0_ = (long long)clock64();
         iters_total += iters;
         if (st != QP_SOLVED) { status = st; break; }
         any = true;
         if (D.x_levels && valid && h == 0) D.x_levels[(inst * P.L + k) * n + c] = x;
-        // optimality right-hand sides A_k x_k for the lower levels (iHQP.cpp:164-170)
+        // optimality rows A_k x = A_k x_k for the lower levels (iHQP.cpp:164-170) -> row table
         if (k + 1 < P.L) {
-            for (int q = 0; q < ma; ++q) {
-                const double a = valid ? Ak[q * n + c] : 0.0;
-                const double v = colsum<NP>(a * x);
-                if (lane == 0) opt[P.optoff[k] + q] = v;
+            const int off = P.nc + P.optoff[k];
+            for (int q0 = 0; q0 < ma; q0 += 4) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = q0 + u;
+                    const double a = (valid && q < ma) ? Ak[q * n + c] : 0.0;
+                    v[u] = a * x;
+                }
+                double s01a, s01b, s23a, s23b;
+                colsum2<NP>(v[0], v[1], s01a, s01b);
+                colsum2<NP>(v[2], v[3], s23a, s23b);
+                const double vs[4] = {s01a, s01b, s23a, s23b};
+                if (lane < 4 && q0 + lane < ma) {
+                    const int q = q0 + lane;
+                    const double val = lane == 0 ? vs[0] : (lane == 1 ? vs[1] : (lane == 2 ? vs[2] : vs[3]));
+                    w.rlo[off + q] = val;
+                    w.rup[off + q] = val;
+                    w.rptr[off + q] = reinterpret_cast<unsigned long long>(Ak + q * n);
+                }
             }
-            if (m > ma && valid && h == 0) opt[P.optoff[k] + ma + c] = x;   // identity rows: e_c' x
+            if (m > ma && valid && h == 0) {   // identity rows: e_c' x
+                w.rlo[off + ma + c] = x;
+                w.rup[off + ma + c] = x;
+                w.rptr[off + ma + c] = ((unsigned long long)c << 1) | 1ull;
+            }
             wave_sync();
         }
         OSOT_PH_END(PH_OPT);
@@ -236,17 +254,7 @@ struct DevQP {
     double* x;
     int* status;
     int* iterations;
-    int lds_rowstate_off;
-};
-
-struct PlainRows {
-    const DevQP* Q;
-    long long inst;
-    __device__ __forceinline__ double elem(int r, int col) const {
-        return col < Q->n ? Q->A[(inst * Q->nc + r) * Q->n + col] : 0.0;
-    }
-    __device__ __forceinline__ double lo(int r) const { return Q->lA[inst * Q->nc + r]; }
-    __device__ __forceinline__ double up(int r) const { return Q->uA[inst * Q->nc + r]; }
+    int lds_rows_off, lds_rows_cap;
 };
 
 template <int NP>
@@ -260,12 +268,23 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
     WaveCtx<NP> w;
     w.c = lane % NP; w.h = lane / NP; w.n = n;
     w.M1 = base; w.M2 = base + NP * S; w.V = base + 2 * NP * S;
-    w.rowstate = reinterpret_cast<int*>(base + Q.lds_rowstate_off);
+    w.rlo = base + Q.lds_rows_off;
+    w.rup = w.rlo + Q.lds_rows_cap;
+    w.rptr = reinterpret_cast<unsigned long long*>(w.rup + Q.lds_rows_cap);
+    w.rowstate = reinterpret_cast<int*>(w.rptr + Q.lds_rows_cap);
+    w.eqlist = w.rowstate + Q.lds_rows_cap;
     const int c = w.c, h = w.h;
     const bool valid = c < n;
     for (int e = lane; e < 2 * NP * S + 4 * NP; e += 64) base[e] = 0.0;
     wave_sync();
-    if (valid && h == 0) {
+    double Hc[16];
+    if (NP == 32) {
+#pragma unroll
+        for (int ii = 0; ii < 16; ++ii) {
+            const int i = 2 * ii + h;
+            Hc[ii] = (valid && i < n) ? Q.H[(inst * n + i) * n + c] + ((i == c) ? Q.eps_abs : 0.0) : 0.0;
+        }
+    } else if (valid && h == 0) {
         const double* H = Q.H + inst * n * n;
         for (int i = 0; i < n; ++i) w.M1[i * S + c] = H[i * n + c] + ((i == c) ? Q.eps_abs : 0.0);
     }
@@ -274,11 +293,15 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
     const bool has_box = Q.l != nullptr;
     const double lb = (has_box && valid) ? Q.l[inst * n + c] : -INFINITY;
     const double ub = (has_box && valid) ? Q.u[inst * n + c] : INFINITY;
-    PlainRows rows;
-    rows.Q = &Q; rows.inst = inst;
+    for (int r = lane; r < Q.nc; r += 64) {
+        w.rlo[r] = clamp_inf(Q.lA[inst * Q.nc + r]);
+        w.rup[r] = clamp_inf(Q.uA[inst * Q.nc + r]);
+        w.rptr[r] = reinterpret_cast<unsigned long long>(Q.A + (inst * Q.nc + r) * n);
+    }
+    wave_sync();
     double x = 0.0;
     int iters = 0;
-    const int st = gi_solve<NP, false>(w, rows, Q.nc, g, false, 0.0, has_box, lb, ub, Q.max_iter, x, iters, nullptr);
+    const int st = gi_solve<NP, false>(w, Q.nc, g, false, 0.0, Hc, has_box, lb, ub, Q.max_iter, x, iters, nullptr);
     if (valid && h == 0) Q.x[inst * n + c] = (st == QP_SOLVED) ? x : 0.0;
     if (lane == 0) {
         Q.status[inst] = st;

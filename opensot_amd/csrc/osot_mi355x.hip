@@ -267,8 +267,7 @@ int osot_qp_solve_batch(int B, int n, int nc, const double* H, const double* g, 
     Q.H = H; Q.g = g; Q.A = A; Q.lA = lA; Q.uA = uA; Q.l = l; Q.u = u;
     Q.x = x; Q.status = status; Q.iterations = iterations;
     const int T = n <= 32 ? 32 : 64;
-    int opt_off;
-    const size_t lds = (size_t)lds_layout(T, 0, nc, &opt_off, &Q.lds_rowstate_off) * sizeof(double);
+    const size_t lds = (size_t)lds_layout(T, nc, &Q.lds_rows_off, &Q.lds_rows_cap) * sizeof(double);
     int rc = (T == 32) ? ensure_lds(osot_qp_kernel<32>, lds) : ensure_lds(osot_qp_kernel<64>, lds);
     if (rc != OSOT_OK) return rc;
     const unsigned grid = (unsigned)B;

@@ -45,39 +45,75 @@ struct WaveCtx {
     double* M1;
     double* M2;
     double* V;      // 4*NP
-    int* rowstate;  // one int per general row: 0 free, 1 lower active, 2 upper active, 3 equality
+    // general-row table of the current QP, built in LDS by the calling kernel (one entry per row):
+    double* rlo;                  // lower bound (already clamped to +-1e20)
+    double* rup;                  // upper bound
+    unsigned long long* rptr;     // address of the row's n doubles in HBM, or (index << 1) | 1 for the unit row e_index
+    int* rowstate;                // 0 free, 1 lower active, 2 upper active, 3 equality
+    int* eqlist;                  // indices of the equality rows, in row order
 };
+
+// a_r[col] for lane-column col (0 beyond n)
+template <int NP>
+__device__ __forceinline__ double row_elem(const WaveCtx<NP>& w, int r, int col) {
+    const unsigned long long p = w.rptr[r];
+    if (p & 1ull) return (col == (int)(p >> 1)) ? 1.0 : 0.0;
+    return (col < w.n) ? reinterpret_cast<const double*>(p)[col] : 0.0;
+}
 
 __device__ __forceinline__ double clamp_inf(double v) {
     return v < -kInfty ? -kInfty : (v > kInfty ? kInfty : v);
 }
 
-// d_c = sum_k JT[c][k] * vec[k]   (row walk, k split over the halves)
+// d_c = sum_k JT[c][k] * vec[k]   (row walk, k split over the halves).  All LDS reads of a chunk are issued
+// before the first FMA (one LDS round trip per chunk) and four accumulators break the dependent chain.
 template <int NP>
 __device__ __forceinline__ double jt_rows_dot(const WaveCtx<NP>& w, const double* vec) {
-    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
+    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = 16;
     const double* row = w.M2 + w.c * S + w.h;
     const double* v = vec + w.h;
-    double acc = 0.0;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
 #pragma unroll
-    for (int kk = 0; kk < NP / HV; ++kk) acc += row[kk * HV] * v[kk * HV];
-    return halfsum<NP>(acc);
+    for (int k0 = 0; k0 < NP / HV; k0 += CH) {
+        double a[CH], b[CH];
+#pragma unroll
+        for (int t = 0; t < CH; ++t) a[t] = row[(k0 + t) * HV];
+#pragma unroll
+        for (int t = 0; t < CH; ++t) b[t] = v[(k0 + t) * HV];
+#pragma unroll
+        for (int t = 0; t < CH; t += 4) {
+            acc0 = fma(a[t], b[t], acc0); acc1 = fma(a[t + 1], b[t + 1], acc1);
+            acc2 = fma(a[t + 2], b[t + 2], acc2); acc3 = fma(a[t + 3], b[t + 3], acc3);
+        }
+    }
+    return halfsum<NP>((acc0 + acc1) + (acc2 + acc3));
 }
 // z_c = sum_j JT[j][c] * vec[j]   (column walk, j split over the halves)
 template <int NP>
 __device__ __forceinline__ double jt_cols_dot(const WaveCtx<NP>& w, const double* vec) {
-    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
+    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = 16;
     const double* col = w.M2 + w.h * S + w.c;
     const double* v = vec + w.h;
-    double acc = 0.0;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
 #pragma unroll
-    for (int jj = 0; jj < NP / HV; ++jj) acc += col[jj * HV * S] * v[jj * HV];
-    return halfsum<NP>(acc);
+    for (int j0 = 0; j0 < NP / HV; j0 += CH) {
+        double a[CH], b[CH];
+#pragma unroll
+        for (int t = 0; t < CH; ++t) a[t] = col[(j0 + t) * HV * S];
+#pragma unroll
+        for (int t = 0; t < CH; ++t) b[t] = v[(j0 + t) * HV];
+#pragma unroll
+        for (int t = 0; t < CH; t += 4) {
+            acc0 = fma(a[t], b[t], acc0); acc1 = fma(a[t + 1], b[t + 1], acc1);
+            acc2 = fma(a[t + 2], b[t + 2], acc2); acc3 = fma(a[t + 3], b[t + 3], acc3);
+        }
+    }
+    return halfsum<NP>((acc0 + acc1) + (acc2 + acc3));
 }
 
 // One Householder reflection that maps d2 = d[iq:] onto alpha*e_iq, applied to the columns iq.. of J
 // (rows iq.. of JT); appends (d1; alpha) as column iq of R.  z = J2 d2 is an input.
-template <int NP>
+template <int NP, bool WRITE_R>
 __device__ __forceinline__ void householder_add(const WaveCtx<NP>& w, double d, double d2, double z,
                                                 double nd2, int iq) {
     constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
@@ -93,11 +129,22 @@ __device__ __forceinline__ void householder_add(const WaveCtx<NP>& w, double d, 
     wave_sync();
     const double wv = z - alpha * w.M2[iq * S + c];   // w = J2 v
     wave_sync();   // both halves have read row iq before half 0 rewrites it
-    for (int jj = iq; jj < n; jj += HV) {
-        const int j = jj + h;
-        if (j < n) w.M2[j * S + c] -= V2[j] * wv;
+    // rows j >= iq of JT, split over the halves, four rows per half and trip.  The start is rounded DOWN to
+    // a multiple of the trip size: the extra rows j < iq have V2[j] = 0 (exact no-op) and every access stays
+    // inside the NP rows of M2, so the loop needs no predicates and its LDS reads overlap.
+    constexpr int TRIP = 4 * HV;
+    for (int jj = iq & ~(TRIP - 1); jj < NP; jj += TRIP) {
+        double* mrow = w.M2 + (jj + h) * S + c;
+        const double* vrow = V2 + jj + h;
+        double m[4], vb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) m[t] = mrow[t * HV * S];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) vb[t] = vrow[t * HV];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) mrow[t * HV * S] = fma(-vb[t], wv, m[t]);
     }
-    if (h == 0) {
+    if (WRITE_R && h == 0) {
         if (c < iq) w.M1[c * S + iq] = d;
         else if (c == iq) w.M1[iq * S + iq] = alpha;
     }
@@ -143,30 +190,127 @@ __device__ __forceinline__ void drop_constraint(const WaveCtx<NP>& w, int qq, in
     }
 }
 
-// RowSrc: double elem(int r, int col) (a_r[col], 0 for col >= n), double lo(int r), double up(int r)
+// The general rows come from the LDS row table in WaveCtx (rlo/rup/rptr, nrows entries).
 // Pre:  general H: M1 holds H + eps I (lower triangle used);  diagonal H (diag_h = true): hdiag is the
 //       lane's diagonal entry h_cc + eps and M1/M2 contents are ignored.
 // Post: returns status, x is lane-distributed (replicated over the halves).
+// Fused right-looking Cholesky + inverse + forward substitution for NP = 32, matrix held in REGISTERS.
+// In : Hc[ii] = (H + eps I)[2ii+h][c]  (lane (c,h) owns column c, rows of its parity), g.
+// Out: M1 = L (lower triangular, zeros above), M2 = JT = L^-1, x = -(H + eps I)^-1 g, all by lane c.
+// The trailing matrix of a right-looking Cholesky stays symmetric, so the normalised column j
+// (l_ij over i) IS the lane-distributed vector Hc[j>>1] of half (j&1): no transposition is needed; one
+// LDS column write + immediate-offset reads broadcast it.  L^-1 is built in the same sweep
+// (Linv[i][:] -= l_ij * Linv[j][:]) and so is the forward substitution L y = -g; only the backward
+// substitution L'x = y runs afterwards.  Every register index is a compile-time constant.
+// FULL = (n == 32): no per-step guards.
+template <bool FULL>
+__device__ inline int factor32(const WaveCtx<32>& w, double (&Hc)[16], double g, double& x_out) {
+    constexpr int S = WaveCtx<32>::S;
+    const int c = w.c, h = w.h, n = w.n;
+    const bool valid = FULL || (c < n);
+    double* M1 = w.M1;
+    double* M2 = w.M2;
+    double Lc[16];
+#pragma unroll
+    for (int ii = 0; ii < 16; ++ii) Lc[ii] = (2 * ii + h == c) ? 1.0 : 0.0;
+    double rhs = valid ? -g : 0.0;
+    double invd = 0.0;
+    bool bad = false;
+    const double* colbase = M1 + h * S;   // + (2ii*S + j) immediates
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        if (FULL || j < n) {
+            const int hj = j & 1, rj = j >> 1;
+            const double piv = bcast(Hc[rj], j + 32 * hj);
+            if (!(piv > 0.0)) { x_out = 0.0; return QP_NOT_PD; }
+            double sq, rs;
+            fast_sqrt_rsqrt(piv, sq, rs);
+            const double hjc = from_half<32>(Hc[rj], hj);              // H[j][c] = H[c][j]
+            const double lcj = (valid && c >= j) ? ((c == j) ? sq : hjc * rs) : 0.0;
+            if (h == 0) M1[c * S + j] = lcj;
+            if (c == j) invd = rs;
+            const double yj = bcast(rhs, j) * rs;                       // forward substitution
+            rhs = (c == j) ? yj : fma(-lcj, yj, rhs);
+            const double linv_jc = from_half<32>(Lc[rj], hj) * rs;      // row j of L^-1 is final
+            if (h == hj) Lc[rj] = linv_jc;
+            wave_sync();
+            // trailing update: all column-j values this lane needs are read first (one LDS round trip)
+            double li[16];
+#pragma unroll
+            for (int ii = rj; ii < 16; ++ii) li[ii] = colbase[2 * ii * S + j];
+            if ((j & 1) == 0) {   // i = j + 1 lives in half 1 only (i = j itself is finished)
+                const double l0 = (h == 1) ? li[rj] : 0.0;
+                Hc[rj] = fma(-l0, lcj, Hc[rj]);
+                Lc[rj] = fma(-l0, linv_jc, Lc[rj]);
+            }
+#pragma unroll
+            for (int ii = rj + 1; ii < 16; ++ii) {
+                Hc[ii] = fma(-li[ii], lcj, Hc[ii]);
+                Lc[ii] = fma(-li[ii], linv_jc, Lc[ii]);
+            }
+        }
+    }
+    // JT = L^-1
+#pragma unroll
+    for (int ii = 0; ii < 16; ++ii) M2[(2 * ii + h) * S + c] = Lc[ii];
+    // backward substitution L'x = y (rhs holds y); rows of L are fetched eight at a time ahead of the chain
+    double x = 0.0;
+    const double yinv0 = invd;
+#pragma unroll
+    for (int i0 = 24; i0 >= 0; i0 -= 8) {
+        double lrow[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) lrow[t] = M1[(i0 + t) * S + c];   // zero for c > i; lane i itself is done
+#pragma unroll
+        for (int t = 7; t >= 0; --t) {
+            const int i = i0 + t;
+            if (FULL || i < n) {
+                const double xi = bcast(rhs * yinv0, i);
+                if (c == i) x = xi;
+                rhs = fma(-lrow[t], xi, rhs);
+            }
+        }
+    }
+    wave_sync();
+    x_out = (valid && !bad) ? x : 0.0;
+    return bad ? QP_NOT_PD : QP_SOLVED;
+}
+
 // phase cycle counters of the profiling instantiation (PROF = true): indices into prof[]
-enum { PH_HBUILD = 0, PH_CHOL = 1, PH_INV = 2, PH_SUBST = 3, PH_EQ = 4, PH_INEQ = 5, PH_OPT = 6, PH_TOTAL = 7, PH_COUNT = 8 };
+enum { PH_HBUILD = 0, PH_CHOL = 1, PH_INV = 2, PH_SUBST = 3, PH_EQ = 4, PH_INEQ = 5, PH_OPT = 6, PH_TOTAL = 7,
+       PH_EQ_D = 8, PH_EQ_RED = 9, PH_EQ_Z = 10, PH_EQ_HH = 11, PH_COUNT = 12 };
+#define OSOT_SUB_BEGIN() long long sub_t0_ = PROF ? (long long)clock64() : 0
+#define OSOT_SUB_END(idx) do { if (PROF) { const long long t_ = (long long)clock64(); prof[idx] += t_ - sub_t0_; sub_t0_ = t_; } } while (0)
 #define OSOT_PH_BEGIN() long long ph_t0_ = PROF ? (long long)clock64() : 0
 #define OSOT_PH_END(idx) do { if (PROF) { const long long t_ = (long long)clock64(); prof[idx] += t_ - ph_t0_; ph_t0_ = t_; } } while (0)
 
-template <int NP, bool PROF, class RowSrc>
-__device__ int gi_solve(const WaveCtx<NP>& w, const RowSrc& rows, int nrows, double g, bool diag_h,
-                        double hdiag, bool has_box, double lb, double ub, int max_iter, double& x_out,
-                        int& iters_out, long long* prof) {
+template <int NP, bool PROF>
+__device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq, const int me, int Aq, double uq,
+                               int iters, bool has_box, double lb, double ub, int max_iter, double& x_out,
+                               int& iters_out, long long* prof);
+
+// Pre (general H):  NP = 64: M1 holds H + eps I (lower triangle used);
+//                    NP = 32: Hc[ii] = (H + eps I)[2ii+h][c] in registers (see factor32), M1 is scratch.
+template <int NP, bool PROF>
+__device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_h,
+                        double hdiag, double (&Hc)[16], bool has_box, double lb, double ub, int max_iter,
+                        double& x_out, int& iters_out, long long* prof) {
     constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
-    const int c = w.c, h = w.h, n = w.n;
-    double* M1 = w.M1;
-    double* M2 = w.M2;
-    double* V0 = w.V;
-    double* V1 = w.V + NP;
-    const bool valid = c < n;
+    const int n = w_in.n;
+    double* M1 = w_in.M1;
+    double* M2 = w_in.M2;
+    double* V0 = w_in.V;
+    double* V1 = w_in.V + NP;
     lb = clamp_inf(lb);
     ub = clamp_inf(ub);
     double x;
     OSOT_PH_BEGIN();
+    {   // ---------------- factorisation phase (own scope: see the launder_i note below) ----------------
+    WaveCtx<NP> w1 = w_in;
+    { const int l1 = launder_i(w_in.c + NP * w_in.h); w1.c = l1 % NP; w1.h = l1 / NP; }
+    const WaveCtx<NP>& w = w1;
+    const int c = w.c, h = w.h;
+    const bool valid = c < n;
 
     if (diag_h) {
         // H + eps I diagonal (a level made of a Postural block only): L = sqrt(diag), JT = diag(1/L)
@@ -179,6 +323,11 @@ __device__ int gi_solve(const WaveCtx<NP>& w, const RowSrc& rows, int nrows, dou
         if (h == 0 && valid) M2[c * S + c] = rs;
         x = valid ? -g * rs * rs : 0.0;
         wave_sync();
+        OSOT_PH_END(PH_CHOL);
+    } else if (NP == 32) {
+        const WaveCtx<32>& w32 = reinterpret_cast<const WaveCtx<32>&>(w);
+        const int st32 = (n == 32) ? factor32<true>(w32, Hc, g, x) : factor32<false>(w32, Hc, g, x);
+        if (st32 != QP_SOLVED) { x_out = 0.0; iters_out = 0; return st32; }
         OSOT_PH_END(PH_CHOL);
     } else {
         // ---- Cholesky H + eps I = L L' in place (lane c = row c, k split over the halves) ----------
@@ -238,26 +387,51 @@ __device__ int gi_solve(const WaveCtx<NP>& w, const RowSrc& rows, int nrows, dou
         OSOT_PH_END(PH_SUBST);
     }
 
+    }   // end of the factorisation phase
+    // (the lane coordinates are re-derived here so that nothing computed for the factorisation stays live)
+    WaveCtx<NP> w2 = w_in;
+    { const int l2 = launder_i(w_in.c + NP * w_in.h); w2.c = l2 % NP; w2.h = l2 / NP; }
+    const WaveCtx<NP>& w = w2;
+    const int c = w.c, h = w.h;
+    const bool valid = c < n;
     int iq = 0;          // size of the working set (wave-uniform)
     int Aq = -1;         // lane q < iq: code of the constraint at working-set position q
     double uq = 0.0;     // lane q < iq: its multiplier (inequalities only)
-    int box_state = 0;   // lane c: 0 free, 1 lower bound active, 2 upper bound active
     int iters = 0;
 
     // ---- equalities first --------------------------------------------------------------------------
-    for (int r = 0; r < nrows; ++r) {
-        const double lo = clamp_inf(rows.lo(r)), up = clamp_inf(rows.up(r));
-        const bool is_eq = (lo == up) && (lo > -kInfty) && (lo < kInfty);
-        if (c == 0 && h == 0) w.rowstate[r] = is_eq ? 3 : 0;
-        if (!is_eq) continue;
-        const double a = rows.elem(r, c);
+    // classify all rows in parallel (lane = row), then walk the equality rows with the next row's
+    // elements already in flight (one HBM/L2 round trip per row would otherwise sit on the critical path)
+    int n_eq = 0;
+    for (int r0 = 0; r0 < nrows; r0 += 64) {
+        const int r = r0 + c + NP * h;
+        bool is_eq = false;
+        if (r < nrows) {
+            const double lo = w.rlo[r], up = w.rup[r];
+            is_eq = (lo == up) && (lo > -kInfty) && (lo < kInfty);
+            w.rowstate[r] = is_eq ? 3 : 0;
+        }
+        const unsigned long long mask = wave_ballot(is_eq);
+        if (is_eq) w.eqlist[n_eq + lanes_below(mask)] = r;
+        n_eq += __builtin_popcountll(mask);
+    }
+    wave_sync();
+    double a_next = (n_eq > 0) ? row_elem<NP>(w, w.eqlist[0], c) : 0.0;
+    for (int e = 0; e < n_eq; ++e) {
+        const int r = w.eqlist[e];
+        const double a = a_next;
+        const double lo = w.rlo[r];
+        if (e + 1 < n_eq) a_next = row_elem<NP>(w, w.eqlist[e + 1], c);   // prefetch
+        OSOT_SUB_BEGIN();
         if (h == 0) V0[c] = a;
         wave_sync();
         const double d = jt_rows_dot<NP>(w, V0);
+        OSOT_SUB_END(PH_EQ_D);
         const double d2 = (c >= iq) ? d : 0.0;
-        const double dd = colsum<NP>(d * d);
-        const double nd2 = colsum<NP>(d2 * d2);
+        double dd, nd2;
+        colsum2<NP>(d * d, d2 * d2, dd, nd2);
         const double resid = lo - colsum<NP>(a * x);
+        OSOT_SUB_END(PH_EQ_RED);
         if (!(nd2 > kDepTol2 * dd)) {   // row is (numerically) a combination of the rows already in
             if (fabs(resid) <= kEqTol * fmax(1.0, fabs(lo))) continue;   // redundant and consistent
             x_out = x; iters_out = iters; return QP_INFEASIBLE;
@@ -266,7 +440,9 @@ __device__ int gi_solve(const WaveCtx<NP>& w, const RowSrc& rows, int nrows, dou
         wave_sync();
         const double z = jt_cols_dot<NP>(w, V1);
         x += (resid * fast_rcp(nd2)) * z;
-        householder_add<NP>(w, d, d2, z, nd2, iq);
+        OSOT_SUB_END(PH_EQ_Z);
+        householder_add<NP, false>(w, d, d2, z, nd2, iq);   // equality columns of R are never read
+        OSOT_SUB_END(PH_EQ_HH);
         if (c == iq) Aq = -2 - r;
         iq++;
         iters++;
@@ -276,6 +452,24 @@ __device__ int gi_solve(const WaveCtx<NP>& w, const RowSrc& rows, int nrows, dou
     OSOT_PH_END(PH_EQ);
 
     // ---- inequality loop -----------------------------------------------------------------------------
+    WaveCtx<NP> w3 = w_in;
+    { const int l3 = launder_i(w_in.c + NP * w_in.h); w3.c = l3 % NP; w3.h = l3 / NP; }
+    return gi_inequalities<NP, PROF>(w3, nrows, x, iq, me, Aq, uq, iters, has_box, lb, ub, max_iter, x_out, iters_out, prof);
+}
+
+template <int NP, bool PROF>
+__device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq, const int me, int Aq, double uq,
+                               int iters, bool has_box, double lb, double ub, int max_iter, double& x_out,
+                               int& iters_out, long long* prof) {
+    constexpr int S = WaveCtx<NP>::S;
+    const int c = w.c, h = w.h, n = w.n;
+    const bool valid = c < n;
+    double* M1 = w.M1;
+    double* M2 = w.M2;
+    double* V0 = w.V;
+    double* V1 = w.V + NP;
+    int box_state = 0;   // lane c: 0 free, 1 lower bound active, 2 upper bound active
+    OSOT_PH_BEGIN();
     int status = QP_SOLVED;
     const int kNone = 0x7fffffff;
     for (;;) {
@@ -295,10 +489,10 @@ __device__ int gi_solve(const WaveCtx<NP>& w, const RowSrc& rows, int nrows, dou
         for (int r = 0; r < nrows; ++r) {
             const int st = w.rowstate[r];
             if (st == 3) continue;
-            const double lo = clamp_inf(rows.lo(r)), up = clamp_inf(rows.up(r));
+            const double lo = w.rlo[r], up = w.rup[r];
             const bool has_lo = lo > -kInfty, has_up = up < kInfty;
             if (!has_lo && !has_up) continue;
-            const double ax = colsum<NP>(rows.elem(r, c) * x);
+            const double ax = colsum<NP>(row_elem<NP>(w, r, c) * x);
             if (st != 1 && has_lo) {
                 const double s = ax - lo;
                 if (s < -kViolTol * fmax(1.0, fabs(lo)) && s < cand) { cand = s; code = 2 * n + 2 * r; }
@@ -321,7 +515,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w, const RowSrc& rows, int nrows, dou
         const int ip_row = ip_box ? 0 : (ip - 2 * n) >> 1;
         const double ip_sgn = ip_box ? (ip < n ? 1.0 : -1.0) : ((ip & 1) ? -1.0 : 1.0);
         double np = 0.0;   // lane-distributed normal (general rows only)
-        if (!ip_box) np = ip_sgn * rows.elem(ip_row, c);
+        if (!ip_box) np = ip_sgn * row_elem<NP>(w, ip_row, c);
 
         bool failed = false;
         for (;;) {
@@ -365,7 +559,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w, const RowSrc& rows, int nrows, dou
                 x += t2 * z;
                 if (c >= me && c < iq) uq -= t2 * rr;
                 u_new += t2;
-                householder_add<NP>(w, d, d2, z, nd2, iq);
+                householder_add<NP, true>(w, d, d2, z, nd2, iq);
                 if (c == iq) { Aq = ip; uq = u_new; }
                 if (ip_box) { if (c == ip_var) box_state = (ip < n) ? 1 : 2; }
                 else { if (c == 0 && h == 0) w.rowstate[ip_row] = (ip & 1) ? 2 : 1; }
@@ -385,7 +579,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w, const RowSrc& rows, int nrows, dou
                 if (ip_box) s_ip = bcast((ip < n) ? (x - lb) : (ub - x), ip_var);
                 else {
                     const double ax = colsum<NP>(np * x);   // = sgn * a'x
-                    s_ip = (ip & 1) ? (clamp_inf(rows.up(ip_row)) + ax) : (ax - clamp_inf(rows.lo(ip_row)));
+                    s_ip = (ip & 1) ? (w.rup[ip_row] + ax) : (ax - w.rlo[ip_row]);
                     s_ip = bcast(s_ip, 0);
                 }
             }

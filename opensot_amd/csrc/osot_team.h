@@ -27,7 +27,22 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// forbid the instruction scheduler from moving anything across this point (keeps the register pressure of
+// fully unrolled step sequences local to one step)
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
+// returns v, but opaque to the optimiser: values derived from the result cannot be hoisted out of the
+// enclosing loop / kept live across phases (used on the lane index to stop loop-invariant code motion
+// from parking hundreds of per-lane addresses and masks in registers for the whole kernel)
+__device__ __forceinline__ int launder_i(int v) { asm volatile("" : "+v"(v)); return v; }
+
 __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// 64-bit mask of the lanes whose predicate is true, and the number of true lanes below this one
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __ballot(p ? 1 : 0); }
+__device__ __forceinline__ int lanes_below(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
 
 // ---- DPP helpers on doubles (two 32-bit halves) ------------------------------------------------------
 template <int CTRL>
@@ -87,6 +102,18 @@ __device__ __forceinline__ double colsum(double v) {
     if (NP == 64) { swap32_pair(v, a, b); v = a + b; }
     return v;
 }
+// two column sums for the price of one reduction network: half 0 reduces va, half 1 reduces vb, then the
+// halves exchange their totals (NP = 32; plain two reductions for NP = 64)
+template <int NP>
+__device__ __forceinline__ void colsum2(double va, double vb, double& ra, double& rb) {
+    if (NP == 64) { ra = colsum<64>(va); rb = colsum<64>(vb); return; }
+    double v = (threadIdx.x >= 32) ? vb : va;
+    v = row16_sum(v);
+    double a, b;
+    swap16_pair(v, a, b);
+    v = a + b;
+    swap32_pair(v, ra, rb);
+}
 // v(c,0) + v(c,1): combines the partial results of the two halves (identity for NP = 64)
 template <int NP>
 __device__ __forceinline__ double halfsum(double v) {
@@ -94,6 +121,15 @@ __device__ __forceinline__ double halfsum(double v) {
     double a, b;
     swap32_pair(v, a, b);
     return a + b;
+}
+
+// value held by lane (c, hsel) delivered to both halves (hsel is wave-uniform; identity for NP = 64)
+template <int NP>
+__device__ __forceinline__ double from_half(double v, int hsel) {
+    if (NP == 64) return v;
+    double a, b;
+    swap32_pair(v, a, b);
+    return hsel ? b : a;
 }
 
 // minimum over the columns with the payload of the minimiser (ties: smaller payload); every lane gets both

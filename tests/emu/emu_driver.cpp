@@ -35,8 +35,7 @@ extern "C" __attribute__((visibility("default"))) int emu_qp_solve_batch(int B, 
     Q.eps_abs = eps_abs;
     Q.H = H; Q.g = g; Q.A = A; Q.lA = lA; Q.uA = uA; Q.l = l; Q.u = u; Q.x = x; Q.status = status; Q.iterations = iterations;
     const int T = n <= 32 ? 32 : 64;
-    int opt_off;
-    const size_t lds = (size_t)lds_layout(T, 0, nc, &opt_off, &Q.lds_rowstate_off) * sizeof(double);
+    const size_t lds = (size_t)lds_layout(T, nc, &Q.lds_rows_off, &Q.lds_rows_cap) * sizeof(double);
     const unsigned grid = (unsigned)B;
     if (T == 32) emu::launch(osot_qp_kernel<32>, grid, lds, 64, Q);
     else emu::launch(osot_qp_kernel<64>, grid, lds, 64, Q);

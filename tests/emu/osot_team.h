@@ -13,8 +13,19 @@
 namespace osot {
 inline int emu_lane() { return emu::S().cur; }
 inline void wave_sync() { int z = 0, out[64]; emu::allgather(&z, out, sizeof(int)); }
+inline void sched_fence() {}
+inline int launder_i(int v) { return v; }
 inline int uniform_i(int v) { int out[64]; emu::allgather(&v, out, sizeof(int)); return out[0]; }
 
+inline unsigned long long wave_ballot(bool p) {
+    int v = p ? 1 : 0, all[64]; emu::allgather(&v, all, sizeof(int));
+    unsigned long long m = 0; for (int i = 0; i < 64; ++i) if (all[i]) m |= (1ull << i);
+    return m;
+}
+inline int lanes_below(unsigned long long mask) {
+    const int l = emu_lane();
+    return __builtin_popcountll(l ? (mask & ((~0ull) >> (64 - l))) : 0ull);
+}
 template <int NP> inline double colsum(double v) {
     double all[64]; emu::allgather(&v, all, sizeof(double));
     const int h0 = (emu_lane() / NP) * NP;
@@ -22,11 +33,19 @@ template <int NP> inline double colsum(double v) {
     for (int i = 0; i < NP; ++i) s += all[h0 + i];
     return s;
 }
+template <int NP> inline void colsum2(double va, double vb, double& ra, double& rb) {
+    ra = colsum<NP>(va); rb = colsum<NP>(vb);
+}
 template <int NP> inline double halfsum(double v) {
     double all[64]; emu::allgather(&v, all, sizeof(double));
     if (NP == 64) return v;
     const int c = emu_lane() % NP;
     return all[c] + all[c + NP];
+}
+template <int NP> inline double from_half(double v, int hsel) {
+    double all[64]; emu::allgather(&v, all, sizeof(double));
+    if (NP == 64) return v;
+    return all[emu_lane() % NP + NP * hsel];
 }
 template <int NP> inline void colargmin(double& v, int& p) {
     double av[64]; int ap[64];

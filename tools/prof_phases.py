@@ -8,5 +8,5 @@ st = BatchedStack(plan, B, device=0, want_levels=False)
 st.update(st.load_leaf(leaf)); st.solve(B); torch.cuda.synchronize()
 cyc = st.profile_phases(B)
 m = cyc.mean(axis=0)
-for name, v in zip(st.PHASES, m): print(f"{name:14s} {v:10.0f} cycles  {100*v/m[-1]:5.1f}%")
+for name, v in zip(st.PHASES, m): print(f"{name:16s} {v:10.0f} cycles  {100*v/m[7]:5.1f}%")
 print("iters mean", st.iterations[:B].float().mean().item())
