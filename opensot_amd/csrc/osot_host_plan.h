@@ -69,7 +69,7 @@ inline int plan_validate(const osot_plan_desc* p, const char** why) {
 }
 
 // LDS carve-up (doubles) of one wave's slice for padded size NP: M1, M2, V, then the row table
-// (rlo, rup, rptr: 8 B per row each; rowstate, eqlist: 4 B per row each).  Returns the total in doubles.
+// (rlo, rup, rptr: 8 B per row each; rowstate, eqlist: 4 B per row each; rsrc: 1 B per row).  Returns the total in doubles.
 inline int lds_layout(int NP, int n_rows, int* rows_off, int* rows_cap) {
     const int S = NP + 1;
     int d = 2 * NP * S + 4 * NP;
@@ -77,7 +77,7 @@ inline int lds_layout(int NP, int n_rows, int* rows_off, int* rows_cap) {
     *rows_off = d;
     const int cap = ((n_rows > 0 ? n_rows : 1) + 1) & ~1;
     *rows_cap = cap;
-    d += 3 * cap + cap;   // rlo, rup, rptr + (rowstate, eqlist as ints)
+    d += 3 * cap + cap + (cap + 7) / 8;   // rlo, rup, rptr + (rowstate, eqlist as ints) + rsrc bytes
     d = (d + 1) & ~1;
     return d;
 }
@@ -100,7 +100,16 @@ inline int make_dev_plan(const osot_plan_desc& p, const unsigned char* level_act
     P.max_iter = p.max_iter > 0 ? p.max_iter : 20 * (p.n + nrows_max) + 100;
     P.eps_abs = p.eps_abs;
     NP = (p.n <= 32) ? 32 : 64;
-    const int total = lds_layout(NP, nrows_max, &P.lds_rows_off, &P.lds_rows_cap);
+    // cascade layout: M1, M2, V | rlo, rup, rptr | rowstate, eqlist | xlev[L-1][NP] | rsrc bytes
+    const int S = NP + 1;
+    const int cap = ((nrows_max > 0 ? nrows_max : 1) + 1) & ~1;
+    int total = ((2 * NP * S + 4 * NP) + 1) & ~1;
+    P.lds_rows_off = total;
+    P.lds_rows_cap = cap;
+    total += 3 * cap + cap;
+    P.lds_xlev_off = total;
+    total += (p.n_levels > 1 ? p.n_levels - 1 : 1) * NP;
+    total += (cap + 7) / 8;
     lds_bytes = (size_t)total * sizeof(double);
     return OSOT_OK;
 }

@@ -33,8 +33,9 @@ struct DevPlan {
     unsigned active_mask;           // bit k: level k active (iHQP::setActiveStack)
     double eps_abs;
     // LDS carve-up of the wave's slice (doubles): M1, M2, V first (sizes fixed by NP), then
-    int lds_rows_off;               // the row table: rlo, rup, rptr (8 B per row), rowstate, eqlist (4 B per row)
+    int lds_rows_off;               // the row table: rlo, rup, rptr (8 B per row), rowstate, eqlist, rsrc (4 B per row)
     int lds_rows_cap;               // capacity (rows), even
+    int lds_xlev_off;               // [L][NP] doubles: x of the levels solved so far
 };
 
 struct DevBatch {
@@ -76,6 +77,8 @@ __global__ void __launch_bounds__(64, 2) osot_cascade_kernel(const DevPlan P, co
     w.rptr = reinterpret_cast<unsigned long long*>(w.rup + P.lds_rows_cap);
     w.rowstate = reinterpret_cast<int*>(w.rptr + P.lds_rows_cap);
     w.eqlist = w.rowstate + P.lds_rows_cap;
+    w.xlev = base + P.lds_xlev_off;
+    w.rsrc = reinterpret_cast<signed char*>(w.xlev + (P.L > 1 ? P.L - 1 : 1) * NP);
     const int c = w.c, h = w.h;
     const bool valid = c < n;
     // zero the matrices once: the padding beyond n stays zero for the whole kernel
@@ -91,6 +94,7 @@ __global__ void __launch_bounds__(64, 2) osot_cascade_kernel(const DevPlan P, co
         w.rlo[r] = clamp_inf(D.lo[inst * P.nc + r]);
         w.rup[r] = clamp_inf(D.up[inst * P.nc + r]);
         w.rptr[r] = reinterpret_cast<unsigned long long>(D.C + (inst * P.nc + r) * n);
+        w.rsrc[r] = -1;
     }
     wave_sync();
 
@@ -108,6 +112,7 @@ __global__ void __launch_bounds__(64, 2) osot_cascade_kernel(const DevPlan P, co
                 const int off = P.nc + P.optoff[k];
                 for (int q = lane; q < P.m[k]; q += 64) {
                     w.rlo[off + q] = -kInfty; w.rup[off + q] = kInfty; w.rptr[off + q] = (0x7fffffffull << 1) | 1ull;
+                    w.rsrc[off + q] = -1;
                 }
                 wave_sync();
             }
@@ -159,7 +164,6 @@ __global__ void __launch_bounds__(64, 2) osot_cascade_kernel(const DevPlan P, co
                         for (int t = 0; t < 16; ++t) vv[t] = Vu[(i0 + t) * HV];
 #pragma unroll
                         for (int t = 0; t < 16; ++t) hacc[i0 + t] = fma(wa[u], vv[t], hacc[i0 + t]);
-                        sched_fence();   // at most 16 staged values live: keeps the kernel at 2 waves/SIMD
                     }
                 }
             }
@@ -194,34 +198,19 @@ __global__ void __launch_bounds__(64, 2) osot_cascade_kernel(const DevPlan P, co
         if (st != QP_SOLVED) { status = st; break; }
         any = true;
         if (D.x_levels && valid && h == 0) D.x_levels[(inst * P.L + k) * n + c] = x;
-        // optimality rows A_k x = A_k x_k for the lower levels (iHQP.cpp:164-170) -> row table
+        // optimality rows A_k x = A_k x_k for the lower levels (iHQP.cpp:164-170) -> row table.  Only the
+        // row addresses and x_k are recorded: the right-hand side is taken relative to the current iterate,
+        // a'(x_k - x), when the row is added, so A_k is not re-read and no reduction pass is needed here.
         if (k + 1 < P.L) {
             const int off = P.nc + P.optoff[k];
-            for (int q0 = 0; q0 < ma; q0 += 4) {
-                double v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int q = q0 + u;
-                    const double a = (valid && q < ma) ? Ak[q * n + c] : 0.0;
-                    v[u] = a * x;
-                }
-                double s01a, s01b, s23a, s23b;
-                colsum2<NP>(v[0], v[1], s01a, s01b);
-                colsum2<NP>(v[2], v[3], s23a, s23b);
-                const double vs[4] = {s01a, s01b, s23a, s23b};
-                if (lane < 4 && q0 + lane < ma) {
-                    const int q = q0 + lane;
-                    const double val = lane == 0 ? vs[0] : (lane == 1 ? vs[1] : (lane == 2 ? vs[2] : vs[3]));
-                    w.rlo[off + q] = val;
-                    w.rup[off + q] = val;
-                    w.rptr[off + q] = reinterpret_cast<unsigned long long>(Ak + q * n);
-                }
+            for (int q = lane; q < m; q += 64) {
+                w.rlo[off + q] = 0.0;
+                w.rup[off + q] = 0.0;
+                w.rsrc[off + q] = (signed char)k;
+                w.rptr[off + q] = (q < ma) ? reinterpret_cast<unsigned long long>(Ak + q * n)
+                                           : (((unsigned long long)(q - ma) << 1) | 1ull);   // Postural: e_(q-ma)
             }
-            if (m > ma && valid && h == 0) {   // identity rows: e_c' x
-                w.rlo[off + ma + c] = x;
-                w.rup[off + ma + c] = x;
-                w.rptr[off + ma + c] = ((unsigned long long)c << 1) | 1ull;
-            }
+            if (h == 0) w.xlev[k * NP + c] = x;
             wave_sync();
         }
         OSOT_PH_END(PH_OPT);
@@ -273,6 +262,8 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
     w.rptr = reinterpret_cast<unsigned long long*>(w.rup + Q.lds_rows_cap);
     w.rowstate = reinterpret_cast<int*>(w.rptr + Q.lds_rows_cap);
     w.eqlist = w.rowstate + Q.lds_rows_cap;
+    w.xlev = nullptr;
+    w.rsrc = reinterpret_cast<signed char*>(w.eqlist + Q.lds_rows_cap);
     const int c = w.c, h = w.h;
     const bool valid = c < n;
     for (int e = lane; e < 2 * NP * S + 4 * NP; e += 64) base[e] = 0.0;
@@ -297,6 +288,7 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
         w.rlo[r] = clamp_inf(Q.lA[inst * Q.nc + r]);
         w.rup[r] = clamp_inf(Q.uA[inst * Q.nc + r]);
         w.rptr[r] = reinterpret_cast<unsigned long long>(Q.A + (inst * Q.nc + r) * n);
+        w.rsrc[r] = -1;
     }
     wave_sync();
     double x = 0.0;

@@ -51,6 +51,9 @@ struct WaveCtx {
     unsigned long long* rptr;     // address of the row's n doubles in HBM, or (index << 1) | 1 for the unit row e_index
     int* rowstate;                // 0 free, 1 lower active, 2 upper active, 3 equality
     int* eqlist;                  // indices of the equality rows, in row order
+    signed char* rsrc;            // -1: bounds are rlo/rup;  j >= 0: optimality row of level j, i.e. the
+                                  // equality a'x = a'x_j with x_j = xlev[j] (iHQP.cpp:164-170); rlo = rup = 0
+    double* xlev;                 // [levels][NP] solutions of the levels solved so far (cascade only)
 };
 
 // a_r[col] for lane-column col (0 beyond n)
@@ -421,6 +424,9 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
         const int r = w.eqlist[e];
         const double a = a_next;
         const double lo = w.rlo[r];
+        const int src = w.rsrc[r];
+        // right-hand side relative to x: lo - a'x, or a'(x_j - x) for an optimality row of level j
+        const double xref = (src >= 0) ? w.xlev[src * NP + c] : 0.0;
         if (e + 1 < n_eq) a_next = row_elem<NP>(w, w.eqlist[e + 1], c);   // prefetch
         OSOT_SUB_BEGIN();
         if (h == 0) V0[c] = a;
@@ -430,7 +436,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
         const double d2 = (c >= iq) ? d : 0.0;
         double dd, nd2;
         colsum2<NP>(d * d, d2 * d2, dd, nd2);
-        const double resid = lo - colsum<NP>(a * x);
+        const double resid = lo + colsum<NP>(a * (xref - x));
         OSOT_SUB_END(PH_EQ_RED);
         if (!(nd2 > kDepTol2 * dd)) {   // row is (numerically) a combination of the rows already in
             if (fabs(resid) <= kEqTol * fmax(1.0, fabs(lo))) continue;   // redundant and consistent
