@@ -45,7 +45,7 @@ def algo_flops_per_solve(plan):
     return total
 
 
-def cpu_baseline(plan, leaf_sample, seconds_target=12.0):
+def cpu_baseline(plan, leaf_sample, seconds_target=6.0):
     """CPU path timed on this host: the reference's own qpOASES (oracle/_ref, kind 'reference') when the
     prebuilt library is present, otherwise the plain-C port (kind 'port'); restated cascade around it."""
     from oracle import pyoracle as po
@@ -58,7 +58,7 @@ def cpu_baseline(plan, leaf_sample, seconds_target=12.0):
         kind, be = "port", po.BE_EIQP_EQ
         r = po.ihqp_solve_batch(asm, be, nthreads=cores, cycles=1)
     per_cycle = max(r["seconds"], 1e-6)
-    cycles = int(max(1, min(200, seconds_target / per_cycle)))
+    cycles = int(max(1, min(5000, seconds_target / per_cycle)))
     r = po.ihqp_solve_batch(asm, be, nthreads=cores, cycles=cycles)
     B = asm["B"]
     return {"value": B * cycles / r["seconds"], "unit": "solves/s", "cores": cores, "kind": kind,
@@ -152,10 +152,17 @@ def main():
                        "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
             "solved_ok_rank0": f"{ok}/{Bl}",
         }
+        traffic = None
+        try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), same workload only
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_v3_pmc_cascade.json")))
+            if args.config == "C3" and Bl == 4096:
+                traffic = pm["hbm_bytes_per_launch_corrected"]
+        except Exception:
+            traffic = None
         if launches > 0 and kern_s > 0:
             tf = Bl * flops / kern_s / 1e12
             out["roofline"] = {
-                "bound": "mfma", "kernel": "osot_cascade_kernel<32>", "achieved": tf, "peak": FP64_PEAK_TFLOPS,
+                "bound": "mfma", "kernel": "osot_cascade_kernel<32,false>", "achieved": tf, "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": None,
                 "avg_launch_ms": kern_ms, "launches": launches,
                 "algorithmic_flops_per_solve": flops,
@@ -164,10 +171,11 @@ def main():
             if bytes_per:
                 gbs = Bl * bytes_per / kern_s / 1e9
                 out["roofline_hbm"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                                       "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+                                       "traffic_source": "profiles/r01_v3_pmc_cascade.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 per MI355X_MICROARCH.md)" if traffic else None,
                                        "algorithmic_bytes_per_solve": bytes_per}
         if not args.no_cpu_baseline and world == 1:
-            ns = min(Bl, 512)
+            ns = min(Bl, 4096)
             sample = {"B": ns, "A": [a[:ns] if a is not None else None for a in leaf["A"]],
                       "task": [[tuple(None if x is None else x[:ns] for x in t) for t in lev] for lev in leaf["task"]],
                       "bound": [tuple(None if x is None else x[:ns] for x in t) for t in leaf["bound"]],
