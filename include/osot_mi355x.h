@@ -64,8 +64,17 @@ typedef enum {
     OSOT_TASK_GENERIC = 0,   /* tasks::GenericTask (src/tasks/GenericTask.cpp:5-56): A and b supplied   */
     OSOT_TASK_CARTESIAN = 1, /* velocity::Cartesian (src/tasks/velocity/Cartesian.cpp:68-105, 279-285)  */
     OSOT_TASK_COM = 2,       /* velocity::CoM (src/tasks/velocity/CoM.cpp:59-74, 145-149)               */
-    OSOT_TASK_POSTURAL = 3   /* velocity::Postural (src/tasks/velocity/Postural.cpp:50-62, 97-100);
-                                A = I is implicit (never stored); must be the last block of its level */
+    OSOT_TASK_POSTURAL = 3,  /* velocity::Postural (src/tasks/velocity/Postural.cpp:50-62, 97-100);
+                                A = [I_rows 0] is implicit (never stored), rows <= n; must be the last block of
+                                its level */
+    /* inverse-dynamics formulation, x = [qddot; contact forces] (src/utils/InverseDynamics.cpp:12-28).  The
+     * producer writes the task matrix ([J 0] ...) into A_k; the update computes b from the supplied errors. */
+    OSOT_TASK_ACC_CARTESIAN = 4, /* acceleration::Cartesian (src/tasks/acceleration/Cartesian.cpp:127-180):
+                                    b = a_ref + lambda2*vel_err + lambda*pose_err - Jdot*qdot (Kp = Kd = I) */
+    OSOT_TASK_ACC_COM = 5,       /* acceleration::CoM (src/tasks/acceleration/CoM.cpp:74-97), 3 rows */
+    OSOT_TASK_ACC_POSTURAL = 6   /* acceleration::Postural (src/tasks/acceleration/Postural.cpp:135-163):
+                                    A = [I_rows 0] implicit like OSOT_TASK_POSTURAL,
+                                    b = qddot_ref + lambda2*(qdot_ref - qdot) + lambda*(q_ref - q) */
 } osot_task_kind;
 
 typedef struct {
@@ -74,6 +83,7 @@ typedef struct {
     double weight;           /* scalar on this block's W: `0.1*l_wrist` (AutoStack.cpp:16-47) */
     double lambda;           /* Task::setLambda; enters b only (Cartesian.cpp:284, CoM.cpp:148) */
     double orientation_gain; /* Cartesian::setOrientationErrorGain (Cartesian.cpp:283) */
+    double lambda2;          /* velocity gain of the acceleration tasks (acceleration/Cartesian.cpp:158) */
 } osot_task_desc;
 
 typedef struct {
@@ -95,14 +105,29 @@ typedef struct {
 
 typedef enum {
     OSOT_ROWS_GENERIC = 0,  /* constraints::GenericConstraint / TaskToConstraint rows: C, lo, up supplied */
-    OSOT_ROWS_COLLISION = 1 /* velocity::CollisionAvoidance rows (…/CollisionAvoidance.cpp:96-152):
+    OSOT_ROWS_COLLISION = 1,/* velocity::CollisionAvoidance rows (…/CollisionAvoidance.cpp:96-152):
                                -J_d dq <= max(0, s (d - d_min)) for pairs within the detection threshold */
+    /* inverse-dynamics constraint rows on x = [qddot; forces] */
+    OSOT_ROWS_DYN_FEASIBILITY = 2, /* acceleration::DynamicFeasibility as an equality (DynamicFeasibility.cpp:22-46):
+                                      producer writes [B_u, -J_f'] (6 rows); lo = up = -h_u */
+    OSOT_ROWS_TORQUE_LIMITS = 3,   /* acceleration::TorqueLimits (src/constraints/acceleration/TorqueLimits.cpp:25-46):
+                                      producer writes [B, -Jc'] ; lo = -tau_max - h, up = tau_max - h */
+    OSOT_ROWS_FRICTION_CONE = 4,   /* force::FrictionCone (src/constraints/force/FrictionCone.cpp:35-56): 5 rows per
+                                      contact = pyramid(mu/sqrt2) * wRl' on the contact's 3 force columns,
+                                      lo = -1e20, up = 0; rows = 5 * contacts, first_col = first force column */
+    OSOT_ROWS_ACC_JOINT_LIMITS = 5,/* acceleration::JointLimits (src/constraints/acceleration/JointLimits.cpp:58-176):
+                                      unit rows e_(first_col+i) (NOT stored), bounds from q, qdot, limits */
+    OSOT_ROWS_ACC_VELOCITY_LIMITS = 6 /* acceleration::VelocityLimits (…/VelocityLimits.cpp:50-63): unit rows
+                                      (NOT stored), (qdot_lim - qdot)/(dT*p) */
 } osot_rows_kind;
 
 typedef struct {
     int kind;  /* osot_rows_kind */
     int rows;  /* for COLLISION: max_pairs */
     double d_threshold, detection_threshold, bound_scaling;
+    int first_col;   /* unit-row / friction-cone blocks: column of the block's first variable */
+    double dT, p;    /* acceleration limits: time step and horizon factor (dt = dT*p) */
+    double mu;       /* friction coefficient */
 } osot_rows_desc;
 
 typedef struct {
@@ -126,8 +151,9 @@ typedef struct {
     const double* b[OSOT_MAX_LEVELS];   /* [B][m_k] */
     const double* w[OSOT_MAX_LEVELS];   /* [B][m_k] diagonal of W_k; NULL = identity */
     const double* c[OSOT_MAX_LEVELS];   /* [B][n] Task::getc(); NULL = 0 */
-    const double* C;                    /* [B][nc][n] global rows (all row blocks stacked) */
-    const double* lo;                   /* [B][nc] */
+    const double* C;                    /* [B][nc_stored][n] global rows: the STORED row blocks stacked in plan
+                                           order (unit-row blocks have no storage, see osot_plan_constraint_rows) */
+    const double* lo;                   /* [B][nc] (all rows, stored or not) */
     const double* up;                   /* [B][nc] */
     const double* l;                    /* [B][n] merged box; NULL iff plan.n_bounds == 0 */
     const double* u;                    /* [B][n] */
@@ -151,6 +177,14 @@ typedef struct {
  *   BOUND_GENERIC         : p0 = l [B][n], p1 = u [B][n]
  *   ROWS_COLLISION : p0 = distance Jacobians J_d [B][rows][n] (ordered by distance), p1 = distances [B][rows]
  *   ROWS_GENERIC   : p0 = C [B][rows][n], p1 = lo [B][rows], p2 = up [B][rows]
+ *   TASK_ACC_CARTESIAN / TASK_ACC_COM : p0 = [pose_err ; vel_err] [B][2*rows], p1 = Jdot*qdot [B][rows],
+ *                    p2 = a_ref [B][rows] (NULL = 0)
+ *   TASK_ACC_POSTURAL : p0 = [q_ref - q ; qdot_ref - qdot] [B][2*rows], p2 = qddot_ref [B][rows] (NULL = 0)
+ *   ROWS_DYN_FEASIBILITY : p0 = h_u [B][6]            (the 6 x n rows are written by the producer into C)
+ *   ROWS_TORQUE_LIMITS   : p0 = h [B][rows], p1 = tau_max [B][rows]   (rows written by the producer into C)
+ *   ROWS_FRICTION_CONE   : p0 = contact rotations wRl [B][contacts][9] (row-major)
+ *   ROWS_ACC_JOINT_LIMITS    : p0 = [q ; qdot] [B][2*rows], p1 = [q_min ; q_max] [B][2*rows], p2 = qddot_max [B][rows]
+ *   ROWS_ACC_VELOCITY_LIMITS : p0 = qdot [B][rows], p1 = qdot_max [B][rows]
  * Task Jacobians are NOT passed here: the producer writes them straight into their row range of
  * osot_qp_batch.A[k] (zero-copy stacking; the reference copies them twice through MatrixPiler,
  * src/tasks/Aggregated.cpp:113-132). */
@@ -185,6 +219,7 @@ int osot_device_count(int* count);
 int osot_plan_validate(const osot_plan_desc* plan);
 int osot_plan_level_rows(const osot_plan_desc* plan, int level, int* m_total, int* m_stored);
 int osot_plan_constraint_rows(const osot_plan_desc* plan, int* nc);
+int osot_plan_stored_constraint_rows(const osot_plan_desc* plan, int* nc_stored);
 
 /* solver object: owns the per-plan device workspace for up to max_batch instances on `device` */
 int osot_solver_create(const osot_plan_desc* plan, int max_batch, int device, osot_solver** out);

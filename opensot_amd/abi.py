@@ -9,9 +9,10 @@ MAX_LEVELS, MAX_TASKS, MAX_BOUNDS, MAX_ROWBLOCKS, MAX_VARS = 8, 8, 4, 4, 64
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NOT_SOLVED, ERR_COMM = range(6)
 STATUS_SOLVED, STATUS_INFEASIBLE, STATUS_MAX_ITER, STATUS_NOT_PD = range(4)
-TASK_GENERIC, TASK_CARTESIAN, TASK_COM, TASK_POSTURAL = range(4)
+TASK_GENERIC, TASK_CARTESIAN, TASK_COM, TASK_POSTURAL, TASK_ACC_CARTESIAN, TASK_ACC_COM, TASK_ACC_POSTURAL = range(7)
 BOUND_GENERIC, BOUND_JOINT_LIMITS, BOUND_VELOCITY_LIMITS = range(3)
-ROWS_GENERIC, ROWS_COLLISION = range(2)
+(ROWS_GENERIC, ROWS_COLLISION, ROWS_DYN_FEASIBILITY, ROWS_TORQUE_LIMITS, ROWS_FRICTION_CONE,
+ ROWS_ACC_JOINT_LIMITS, ROWS_ACC_VELOCITY_LIMITS) = range(7)
 # OpenSoT::HessianType (include/OpenSoT/Task.h:33-41)
 HST_UNDEFINED, HST_ZERO, HST_IDENTITY, HST_POSDEF, HST_POSDEF_NULLSPACE, HST_SEMIDEF, HST_UNKNOWN = range(7)
 
@@ -21,7 +22,7 @@ ip = C.POINTER(C.c_int)
 
 class TaskDesc(C.Structure):
     _fields_ = [("kind", C.c_int), ("rows", C.c_int), ("weight", C.c_double),
-                ("lambda_", C.c_double), ("orientation_gain", C.c_double)]
+                ("lambda_", C.c_double), ("orientation_gain", C.c_double), ("lambda2", C.c_double)]
 
 
 class LevelDesc(C.Structure):
@@ -34,7 +35,8 @@ class BoundDesc(C.Structure):
 
 class RowsDesc(C.Structure):
     _fields_ = [("kind", C.c_int), ("rows", C.c_int), ("d_threshold", C.c_double),
-                ("detection_threshold", C.c_double), ("bound_scaling", C.c_double)]
+                ("detection_threshold", C.c_double), ("bound_scaling", C.c_double),
+                ("first_col", C.c_int), ("dT", C.c_double), ("p", C.c_double), ("mu", C.c_double)]
 
 
 class PlanDesc(C.Structure):
@@ -76,6 +78,7 @@ class AssembledOut(C.Structure):
 SYMBOLS = [
     "osot_version", "osot_last_error", "osot_device_count",
     "osot_plan_validate", "osot_plan_level_rows", "osot_plan_constraint_rows",
+    "osot_plan_stored_constraint_rows",
     "osot_solver_create", "osot_solver_destroy", "osot_stack_update", "osot_ihqp_solve",
     "osot_solver_kernel_time_ms", "osot_solver_set_timing", "osot_solver_profile_phases",
     "osot_backend_create", "osot_backend_destroy", "osot_backend_init_problem",
@@ -116,6 +119,7 @@ def lib():
     L.osot_plan_validate.argtypes = [C.POINTER(PlanDesc)]
     L.osot_plan_level_rows.argtypes = [C.POINTER(PlanDesc), C.c_int, ip, ip]
     L.osot_plan_constraint_rows.argtypes = [C.POINTER(PlanDesc), ip]
+    L.osot_plan_stored_constraint_rows.argtypes = [C.POINTER(PlanDesc), ip]
     L.osot_solver_create.argtypes = [C.POINTER(PlanDesc), C.c_int, C.c_int, C.POINTER(vp)]
     L.osot_solver_destroy.argtypes = [vp]
     L.osot_stack_update.argtypes = [vp, C.POINTER(LeafBatch), C.POINTER(AssembledOut), vp]

@@ -13,7 +13,7 @@ inline int plan_level_rows(const osot_plan_desc* p, int k, int* m_total, int* m_
     const osot_level_desc& lv = p->level[k];
     for (int j = 0; j < lv.n_tasks; ++j) {
         m += lv.task[j].rows;
-        if (lv.task[j].kind != OSOT_TASK_POSTURAL) ma += lv.task[j].rows;
+        if (lv.task[j].kind != OSOT_TASK_POSTURAL && lv.task[j].kind != OSOT_TASK_ACC_POSTURAL) ma += lv.task[j].rows;
     }
     if (m_total) *m_total = m;
     if (m_stored) *m_stored = ma;
@@ -25,6 +25,17 @@ inline int plan_constraint_rows(const osot_plan_desc* p, int* nc) {
     int s = 0;
     for (int j = 0; j < p->n_rowblocks; ++j) s += p->rowblock[j].rows;
     if (nc) *nc = s;
+    return OSOT_OK;
+}
+
+inline bool rows_are_implicit(int kind) {
+    return kind == OSOT_ROWS_ACC_JOINT_LIMITS || kind == OSOT_ROWS_ACC_VELOCITY_LIMITS;
+}
+inline int plan_stored_constraint_rows(const osot_plan_desc* p, int* nc_stored) {
+    if (!p) return OSOT_ERR_INVALID;
+    int s = 0;
+    for (int j = 0; j < p->n_rowblocks; ++j) if (!rows_are_implicit(p->rowblock[j].kind)) s += p->rowblock[j].rows;
+    if (nc_stored) *nc_stored = s;
     return OSOT_OK;
 }
 
@@ -47,10 +58,12 @@ inline int plan_validate(const osot_plan_desc* p, const char** why) {
             if (t.rows < 1) { *why = "task with no rows"; return OSOT_ERR_INVALID; }
             switch (t.kind) {
                 case OSOT_TASK_GENERIC: break;
-                case OSOT_TASK_CARTESIAN: if (t.rows != 6) { *why = "Cartesian task must have 6 rows"; return OSOT_ERR_INVALID; } break;
-                case OSOT_TASK_COM: if (t.rows != 3) { *why = "CoM task must have 3 rows"; return OSOT_ERR_INVALID; } break;
-                case OSOT_TASK_POSTURAL:
-                    if (t.rows != p->n) { *why = "Postural task must have n rows"; return OSOT_ERR_INVALID; }
+                case OSOT_TASK_CARTESIAN: case OSOT_TASK_ACC_CARTESIAN:
+                    if (t.rows != 6) { *why = "Cartesian task must have 6 rows"; return OSOT_ERR_INVALID; } break;
+                case OSOT_TASK_COM: case OSOT_TASK_ACC_COM:
+                    if (t.rows != 3) { *why = "CoM task must have 3 rows"; return OSOT_ERR_INVALID; } break;
+                case OSOT_TASK_POSTURAL: case OSOT_TASK_ACC_POSTURAL:
+                    if (t.rows > p->n) { *why = "Postural task cannot have more than n rows"; return OSOT_ERR_INVALID; }
                     if (j != lv.n_tasks - 1) { *why = "Postural must be the last block of its level"; return OSOT_ERR_UNSUPPORTED; }
                     break;
                 default: *why = "unknown task kind"; return OSOT_ERR_UNSUPPORTED;
@@ -62,8 +75,15 @@ inline int plan_validate(const osot_plan_desc* p, const char** why) {
     for (int j = 0; j < p->n_bounds; ++j)
         if (p->bound[j].kind < 0 || p->bound[j].kind > OSOT_BOUND_VELOCITY_LIMITS) { *why = "unknown bound kind"; return OSOT_ERR_UNSUPPORTED; }
     for (int j = 0; j < p->n_rowblocks; ++j) {
-        if (p->rowblock[j].kind < 0 || p->rowblock[j].kind > OSOT_ROWS_COLLISION) { *why = "unknown row-block kind"; return OSOT_ERR_UNSUPPORTED; }
-        if (p->rowblock[j].rows < 1 || p->rowblock[j].rows > 256) { *why = "row block size out of range (1..256)"; return OSOT_ERR_INVALID; }
+        const osot_rows_desc& rb = p->rowblock[j];
+        if (rb.kind < 0 || rb.kind > OSOT_ROWS_ACC_VELOCITY_LIMITS) { *why = "unknown row-block kind"; return OSOT_ERR_UNSUPPORTED; }
+        if (rb.rows < 1 || rb.rows > 256) { *why = "row block size out of range (1..256)"; return OSOT_ERR_INVALID; }
+        if (rb.kind == OSOT_ROWS_DYN_FEASIBILITY && rb.rows != 6) { *why = "DynamicFeasibility has 6 rows"; return OSOT_ERR_INVALID; }
+        if (rb.kind == OSOT_ROWS_FRICTION_CONE && (rb.rows % 5 != 0 || rb.first_col < 0 || rb.first_col + 3 * (rb.rows / 5) > p->n)) {
+            *why = "friction cone block: rows = 5*contacts and 3 force columns per contact inside x"; return OSOT_ERR_INVALID; }
+        if (rows_are_implicit(rb.kind) && (rb.first_col < 0 || rb.first_col + rb.rows > p->n)) {
+            *why = "unit-row block exceeds the variables"; return OSOT_ERR_INVALID; }
+        if (rows_are_implicit(rb.kind) && !(rb.dT * rb.p > 0.0)) { *why = "acceleration limits need dT*p > 0"; return OSOT_ERR_INVALID; }
     }
     return OSOT_OK;
 }
@@ -96,6 +116,21 @@ inline int make_dev_plan(const osot_plan_desc& p, const unsigned char* level_act
         P.optoff[k + 1] = P.optoff[k] + P.m[k];
         if (!level_active || level_active[k]) P.active_mask |= (1u << k);
     }
+    P.nblocks = p.n_rowblocks;
+    {
+        int off = 0, soff = 0;
+        for (int j = 0; j < p.n_rowblocks; ++j) {
+            P.blk_rows[j] = p.rowblock[j].rows;
+            P.blk_off[j] = off;
+            P.blk_implicit[j] = rows_are_implicit(p.rowblock[j].kind) ? 1 : 0;
+            P.blk_first_col[j] = p.rowblock[j].first_col;
+            P.blk_stored_off[j] = soff;
+            off += p.rowblock[j].rows;
+            if (!P.blk_implicit[j]) soff += p.rowblock[j].rows;
+        }
+        P.nc_stored = soff;
+    }
+    for (int k = 0; k < p.n_levels; ++k) P.ident_rows[k] = P.m[k] - P.ma[k];
     const int nrows_max = P.nc + P.optoff[p.n_levels];
     P.max_iter = p.max_iter > 0 ? p.max_iter : 20 * (p.n + nrows_max) + 100;
     P.eps_abs = p.eps_abs;

@@ -29,6 +29,10 @@ struct DevPlan {
     int m[OSOT_KMAX_LEVELS];        // rows per level
     int ma[OSOT_KMAX_LEVELS];       // rows stored in A_k (the rest is Postural's implicit identity)
     int optoff[OSOT_KMAX_LEVELS + 1];  // prefix sums of m[]
+    int ident_rows[OSOT_KMAX_LEVELS];  // rows of the implicit [I 0] block (Postural) of each level
+    int nblocks, nc_stored;            // global row blocks; rows of C that are stored
+    int blk_rows[OSOT_KMAX_ROWBLOCKS], blk_off[OSOT_KMAX_ROWBLOCKS], blk_stored_off[OSOT_KMAX_ROWBLOCKS];
+    int blk_implicit[OSOT_KMAX_ROWBLOCKS], blk_first_col[OSOT_KMAX_ROWBLOCKS];
     int max_iter;
     unsigned active_mask;           // bit k: level k active (iHQP::setActiveStack)
     double eps_abs;
@@ -90,11 +94,16 @@ __global__ void __launch_bounds__(64, 2) osot_cascade_kernel(const DevPlan P, co
     const double ub = (has_box && valid) ? D.u[inst * n + c] : INFINITY;
 
     // global rows: bounds and row addresses, lane = row
-    for (int r = lane; r < P.nc; r += 64) {
-        w.rlo[r] = clamp_inf(D.lo[inst * P.nc + r]);
-        w.rup[r] = clamp_inf(D.up[inst * P.nc + r]);
-        w.rptr[r] = reinterpret_cast<unsigned long long>(D.C + (inst * P.nc + r) * n);
-        w.rsrc[r] = -1;
+    for (int j = 0; j < P.nblocks; ++j) {
+        for (int q = lane; q < P.blk_rows[j]; q += 64) {
+            const int r = P.blk_off[j] + q;
+            w.rlo[r] = clamp_inf(D.lo[inst * P.nc + r]);
+            w.rup[r] = clamp_inf(D.up[inst * P.nc + r]);
+            w.rptr[r] = P.blk_implicit[j]
+                ? ((((unsigned long long)(P.blk_first_col[j] + q)) << 1) | 1ull)   // unit row, not stored
+                : reinterpret_cast<unsigned long long>(D.C + (inst * P.nc_stored + P.blk_stored_off[j] + q) * n);
+            w.rsrc[r] = -1;
+        }
     }
     wave_sync();
 
@@ -167,7 +176,7 @@ __global__ void __launch_bounds__(64, 2) osot_cascade_kernel(const DevPlan P, co
                     }
                 }
             }
-            if (m > ma && valid) {   // Postural block appended to the level: A = I (Postural.cpp:37)
+            if (m > ma && c < m - ma) {   // Postural block appended to the level: A = [I 0] (Postural.cpp:37)
                 const double wi = wk ? wk[ma + c] : 1.0;
                 g -= wi * bk[ma + c];
 #pragma unroll
@@ -181,10 +190,11 @@ __global__ void __launch_bounds__(64, 2) osot_cascade_kernel(const DevPlan P, co
                 if (NP == 64) w.M1[i * S + c] = hacc[ii];   // NP = 32 factorises straight from registers
             }
             wave_sync();
-        } else if (valid) {   // level = one Postural block: H = W + eps I is diagonal
-            const double wi = wk ? wk[c] : 1.0;
+        } else if (valid) {   // level = one Postural block [I_m 0]: H = blockdiag(W, 0) + eps I is diagonal
+            const bool inb = c < m;
+            const double wi = inb ? (wk ? wk[c] : 1.0) : 0.0;
             hdiag = wi + P.eps_abs;
-            g = -wi * bk[c];
+            g = inb ? -wi * bk[c] : 0.0;
         }
         if (D.c[k] && valid) g += D.c[k][inst * n + c];
 
@@ -304,12 +314,12 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
 // ---------------------------------------------------------------------------------------------------
 // AutoStack::update(): leaf inputs -> b, W diagonal, merged box, constraint rows
 // ---------------------------------------------------------------------------------------------------
-struct DevTask { int level, kind, rows, off; double weight, lambda, ogain; const double *p0, *p1, *p2; };
+struct DevTask { int level, kind, rows, off; double weight, lambda, ogain, lambda2; const double *p0, *p1, *p2; };
 struct DevBound { int kind; double scaling, dT; const double *p0, *p1, *p2; };
-struct DevRowBlock { int kind, rows, off; double d_threshold, detection_threshold, bound_scaling; const double *p0, *p1, *p2; };
+struct DevRowBlock { int kind, rows, off, stored_off, first_col; double d_threshold, detection_threshold, bound_scaling, dT, p, mu; const double *p0, *p1, *p2; };
 
 struct DevUpdate {
-    int B, n, L, nc;
+    int B, n, L, nc, nc_stored;
     int m[OSOT_KMAX_LEVELS];
     int ntasks;                      // all levels, flat (kernel arguments are limited to 4 KB)
     DevTask task[OSOT_KMAX_FLAT_TASKS];
@@ -396,9 +406,22 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
                 if (t < 3) bk[tk.off + t] = (tk.p2 ? tk.p2[inst * 3 + t] : 0.0) +
                                             tk.lambda * (tk.p1[inst * 3 + t] - tk.p0[inst * 3 + t]);
             } else if (tk.kind == 3) {    // Postural (Postural.cpp:97-100)
-                for (int r = t; r < n; r += 64)
-                    bk[tk.off + r] = (tk.p2 ? tk.p2[inst * n + r] : 0.0) +
-                                     tk.lambda * (tk.p1[inst * n + r] - tk.p0[inst * n + r]);
+                for (int r = t; r < tk.rows; r += 64)
+                    bk[tk.off + r] = (tk.p2 ? tk.p2[inst * tk.rows + r] : 0.0) +
+                                     tk.lambda * (tk.p1[inst * tk.rows + r] - tk.p0[inst * tk.rows + r]);
+            } else if (tk.kind == 4 || tk.kind == 5) {
+                // acceleration::Cartesian / CoM (acceleration/Cartesian.cpp:152-160, acceleration/CoM.cpp:86-92):
+                // J qddot + Jdot qdot - a_ref - lambda2 Kd vel_err - lambda Kp pose_err = 0, Kp = Kd = I
+                for (int r = t; r < tk.rows; r += 64) {
+                    const double pe = tk.p0[inst * 2 * tk.rows + r], ve = tk.p0[inst * 2 * tk.rows + tk.rows + r];
+                    bk[tk.off + r] = (tk.p2 ? tk.p2[inst * tk.rows + r] : 0.0) + tk.lambda2 * ve + tk.lambda * pe -
+                                     tk.p1[inst * tk.rows + r];
+                }
+            } else if (tk.kind == 6) {    // acceleration::Postural (acceleration/Postural.cpp:145-158)
+                for (int r = t; r < tk.rows; r += 64) {
+                    const double pe = tk.p0[inst * 2 * tk.rows + r], ve = tk.p0[inst * 2 * tk.rows + tk.rows + r];
+                    bk[tk.off + r] = (tk.p2 ? tk.p2[inst * tk.rows + r] : 0.0) + tk.lambda2 * ve + tk.lambda * pe;
+                }
             } else {                      // Generic: b supplied
                 for (int r = t; r < tk.rows; r += 64) bk[tk.off + r] = tk.p0[inst * tk.rows + r];
             }
@@ -428,7 +451,7 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
     // ---- global rows
     for (int j = 0; j < U.nrowblocks; ++j) {
         const DevRowBlock& rb = U.rowblock[j];
-        double* Cb = U.C + (inst * U.nc + rb.off) * n;
+        double* Cb = U.C ? U.C + (inst * U.nc_stored + rb.stored_off) * n : nullptr;
         double* lob = U.lo + inst * U.nc + rb.off;
         double* upb = U.up + inst * U.nc + rb.off;
         if (rb.kind == 1) {   // CollisionAvoidance.cpp:96-152
@@ -460,6 +483,56 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
                 }
             }
             __syncthreads();
+        } else if (rb.kind == 2) {   // DynamicFeasibility.cpp:22-46 as equality: rows [B_u, -J_f'] are in C already
+            if (t < 6) { const double v = -rb.p0[inst * 6 + t]; lob[t] = v; upb[t] = v; }
+        } else if (rb.kind == 3) {   // TorqueLimits.cpp:25-46: rows [B, -Jc'] are in C already
+            for (int r = t; r < rb.rows; r += 64) {
+                const double hh = rb.p0[inst * rb.rows + r], tm = rb.p1[inst * rb.rows + r];
+                lob[r] = -tm - hh; upb[r] = tm - hh;
+            }
+        } else if (rb.kind == 4) {   // FrictionCone.cpp:35-56: Ci * wRl', mu/sqrt(2) pyramid, 5 rows per contact
+            const int nct = rb.rows / 5;
+            const double mu = rb.mu / sqrt(2.0);
+            for (int e = t; e < rb.rows * n; e += 64) Cb[e] = 0.0;
+            __syncthreads();
+            for (int e = t; e < nct * 15; e += 64) {
+                const int ct = e / 15, rr = (e % 15) / 3, col = e % 3;
+                const double* R = rb.p0 + (inst * nct + ct) * 9;   // wRl row-major; Ci*wRl' (rr,col) = sum_k Ci[rr][k] R[col][k]
+                const double ci0 = (rr == 0) ? 1.0 : (rr == 1 ? -1.0 : 0.0);
+                const double ci1 = (rr == 2) ? 1.0 : (rr == 3 ? -1.0 : 0.0);
+                const double ci2 = (rr == 4) ? -1.0 : -mu;
+                Cb[(ct * 5 + rr) * n + rb.first_col + ct * 3 + col] = ci0 * R[col * 3 + 0] + ci1 * R[col * 3 + 1] + ci2 * R[col * 3 + 2];
+            }
+            for (int r = t; r < rb.rows; r += 64) { lob[r] = -1.0e20; upb[r] = 0.0; }
+        } else if (rb.kind == 5) {   // acceleration::JointLimits (constraints/acceleration/JointLimits.cpp:58-176)
+            const int nr = rb.rows;
+            const double dt = rb.dT * rb.p;
+            for (int i = t; i < nr; i += 64) {
+                const double q = rb.p0[inst * 2 * nr + i], qd = rb.p0[inst * 2 * nr + nr + i];
+                const double qmin = rb.p1[inst * 2 * nr + i], qmax = rb.p1[inst * 2 * nr + nr + i];
+                const double am = rb.p2[inst * nr + i];
+                const double a = .5 * dt * dt / am;
+                const double b_sup = dt * qd / am + .5 * dt * dt;
+                const double c_sup = q + dt * qd - qmax + .5 * qd * qd / am;
+                double delta_sup = b_sup * b_sup - 4 * a * c_sup;
+                const double b_inf = dt * qd / am - .5 * dt * dt;
+                const double c_inf = -q - dt * qd + qmin + .5 * qd * qd / am;
+                double delta_inf = b_inf * b_inf - 4 * a * c_inf;
+                if (delta_sup < 0) delta_sup = 0;
+                if (delta_inf < 0) delta_inf = 0;
+                const double ub_sup = .5 / a * (-b_sup + sqrt(delta_sup)), lb_sup = .5 / a * (-b_sup - sqrt(delta_sup));
+                const double ub_inf = .5 / a * (-b_inf + sqrt(delta_inf)), lb_inf = .5 / a * (-b_inf - sqrt(delta_inf));
+                double ub = fmin(ub_sup, ub_inf);
+                const double lb = fmax(lb_sup, lb_inf);
+                if (ub < lb) ub = lb;
+                lob[i] = lb; upb[i] = ub;
+            }
+        } else if (rb.kind == 6) {   // acceleration::VelocityLimits (constraints/acceleration/VelocityLimits.cpp:50-63)
+            for (int i = t; i < rb.rows; i += 64) {
+                const double qd = rb.p0[inst * rb.rows + i], lim = rb.p1[inst * rb.rows + i];
+                upb[i] = (lim - qd) / (rb.dT * rb.p);
+                lob[i] = (-lim - qd) / (rb.dT * rb.p);
+            }
         } else {
             for (int e = t; e < rb.rows * n; e += 64) Cb[e] = rb.p0[inst * rb.rows * n + e];
             for (int r = t; r < rb.rows; r += 64) { lob[r] = rb.p1[inst * rb.rows + r]; upb[r] = rb.p2[inst * rb.rows + r]; }

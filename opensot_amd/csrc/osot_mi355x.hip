@@ -80,6 +80,10 @@ int osot_plan_constraint_rows(const osot_plan_desc* plan, int* nc) {
     int rc = plan_constraint_rows(plan, nc);
     return rc == OSOT_OK ? rc : fail(rc, "bad plan");
 }
+int osot_plan_stored_constraint_rows(const osot_plan_desc* plan, int* nc_stored) {
+    int rc = plan_stored_constraint_rows(plan, nc_stored);
+    return rc == OSOT_OK ? rc : fail(rc, "bad plan");
+}
 
 int osot_solver_create(const osot_plan_desc* plan, int max_batch, int device, osot_solver** out) {
     if (!out) return fail(OSOT_ERR_INVALID, "null out");
@@ -162,10 +166,11 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
         if (!b->b[k]) return fail(OSOT_ERR_INVALID, "b[k] is null");
         D.A[k] = b->A[k]; D.b[k] = b->b[k]; D.w[k] = b->w[k]; D.c[k] = b->c[k];
     }
-    if (P.nc > 0 && (!b->C || !b->lo || !b->up)) return fail(OSOT_ERR_INVALID, "plan has constraint rows but C/lo/up is null");
+    if (P.nc > 0 && (!b->lo || !b->up)) return fail(OSOT_ERR_INVALID, "plan has constraint rows but lo/up is null");
+    if (P.nc_stored > 0 && !b->C) return fail(OSOT_ERR_INVALID, "plan has stored constraint rows but C is null");
     if (pl.n_bounds > 0 && (!b->l || !b->u)) return fail(OSOT_ERR_INVALID, "plan has bounds but l/u is null");
     if (!b->dq || !b->status) return fail(OSOT_ERR_INVALID, "dq/status output is null");
-    D.C = P.nc ? b->C : nullptr; D.lo = b->lo; D.up = b->up;
+    D.C = P.nc_stored ? b->C : nullptr; D.lo = b->lo; D.up = b->up;
     D.l = pl.n_bounds ? b->l : nullptr; D.u = pl.n_bounds ? b->u : nullptr;
     D.dq = b->dq; D.x_levels = b->x_levels; D.status = b->status; D.iterations = b->iterations;
     D.prof = prof;
@@ -201,6 +206,7 @@ int osot_stack_update(osot_solver* s, const osot_leaf_batch* leaf, const osot_as
     std::memset(&U, 0, sizeof(U));
     U.B = leaf->B; U.n = pl.n; U.L = pl.n_levels;
     plan_constraint_rows(&pl, &U.nc);
+    plan_stored_constraint_rows(&pl, &U.nc_stored);
     int flat = 0;
     for (int k = 0; k < pl.n_levels; ++k) {
         plan_level_rows(&pl, k, &U.m[k], nullptr);
@@ -211,10 +217,11 @@ int osot_stack_update(osot_solver* s, const osot_leaf_batch* leaf, const osot_as
             const osot_task_desc& t = pl.level[k].task[j];
             DevTask& d = U.task[flat++];
             d.level = k; d.kind = t.kind; d.rows = t.rows; d.off = off;
-            d.weight = t.weight; d.lambda = t.lambda; d.ogain = t.orientation_gain;
+            d.weight = t.weight; d.lambda = t.lambda; d.ogain = t.orientation_gain; d.lambda2 = t.lambda2;
             d.p0 = leaf->task[k][j].p0; d.p1 = leaf->task[k][j].p1; d.p2 = leaf->task[k][j].p2;
             if (!d.p0) return fail(OSOT_ERR_INVALID, "leaf input p0 of a task is null");
-            if (t.kind != OSOT_TASK_GENERIC && !d.p1) return fail(OSOT_ERR_INVALID, "leaf input p1 of a task is null");
+            if (t.kind != OSOT_TASK_GENERIC && t.kind != OSOT_TASK_ACC_POSTURAL && !d.p1)
+                return fail(OSOT_ERR_INVALID, "leaf input p1 of a task is null");
             off += t.rows;
         }
     }
@@ -231,19 +238,27 @@ int osot_stack_update(osot_solver* s, const osot_leaf_batch* leaf, const osot_as
     if (pl.n_bounds > 0 && (!out->l || !out->u)) return fail(OSOT_ERR_INVALID, "out.l/out.u is null");
     U.l = out->l; U.u = out->u;
     U.nrowblocks = pl.n_rowblocks;
-    int roff = 0;
+    int roff = 0, soff = 0;
     for (int j = 0; j < pl.n_rowblocks; ++j) {
         DevRowBlock& d = U.rowblock[j];
         d.kind = pl.rowblock[j].kind; d.rows = pl.rowblock[j].rows; d.off = roff;
+        d.stored_off = soff; d.first_col = pl.rowblock[j].first_col;
+        d.dT = pl.rowblock[j].dT; d.p = pl.rowblock[j].p; d.mu = pl.rowblock[j].mu;
+        if (!rows_are_implicit(d.kind)) soff += d.rows;
         d.d_threshold = pl.rowblock[j].d_threshold;
         d.detection_threshold = pl.rowblock[j].detection_threshold;
         d.bound_scaling = pl.rowblock[j].bound_scaling;
         d.p0 = leaf->rows[j].p0; d.p1 = leaf->rows[j].p1; d.p2 = leaf->rows[j].p2;
-        if (!d.p0 || !d.p1) return fail(OSOT_ERR_INVALID, "leaf inputs of a row block are null");
+        if (!d.p0) return fail(OSOT_ERR_INVALID, "leaf input p0 of a row block is null");
+        if ((d.kind == OSOT_ROWS_GENERIC || d.kind == OSOT_ROWS_COLLISION || d.kind == OSOT_ROWS_TORQUE_LIMITS ||
+             d.kind == OSOT_ROWS_ACC_JOINT_LIMITS || d.kind == OSOT_ROWS_ACC_VELOCITY_LIMITS) && !d.p1)
+            return fail(OSOT_ERR_INVALID, "leaf input p1 of a row block is null");
+        if (d.kind == OSOT_ROWS_ACC_JOINT_LIMITS && !d.p2) return fail(OSOT_ERR_INVALID, "acceleration joint limits need qddot_max");
         if (d.kind == OSOT_ROWS_GENERIC && !d.p2) return fail(OSOT_ERR_INVALID, "generic rows need C, lo, up");
         roff += d.rows;
     }
-    if (U.nc > 0 && (!out->C || !out->lo || !out->up)) return fail(OSOT_ERR_INVALID, "out.C/lo/up is null");
+    if (U.nc > 0 && (!out->lo || !out->up)) return fail(OSOT_ERR_INVALID, "out.lo/up is null");
+    if (U.nc_stored > 0 && !out->C) return fail(OSOT_ERR_INVALID, "out.C is null");
     U.C = out->C; U.lo = out->lo; U.up = out->up;
     hipLaunchKernelGGL(osot_update_kernel, dim3((unsigned)leaf->B), dim3(64), 0, (hipStream_t)hip_stream, U);
     HIP_TRY(hipGetLastError());

@@ -25,6 +25,11 @@ class Task:
     lam: float = 1.0
     orientation_gain: float = 1.0
     name: str = ""
+    lam2: float = 1.0
+
+
+IMPLICIT_IDENTITY_TASKS = (abi.TASK_POSTURAL, abi.TASK_ACC_POSTURAL)
+UNIT_ROW_BLOCKS = (abi.ROWS_ACC_JOINT_LIMITS, abi.ROWS_ACC_VELOCITY_LIMITS)
 
 
 @dataclass
@@ -43,6 +48,10 @@ class Rows:
     detection_threshold: float = 0.0
     bound_scaling: float = 1.0
     name: str = ""
+    first_col: int = 0
+    dT: float = 0.0
+    p: float = 1.0
+    mu: float = 0.0
 
 
 @dataclass
@@ -64,11 +73,19 @@ class StackPlan:
 
     def ma(self, k):
         """rows of level k stored explicitly (Postural's identity block is implicit)."""
-        return sum(t.rows for t in self.levels[k] if t.kind != abi.TASK_POSTURAL)
+        return sum(t.rows for t in self.levels[k] if t.kind not in IMPLICIT_IDENTITY_TASKS)
 
     @property
     def nc(self):
         return sum(r.rows for r in self.rowblocks)
+
+    @property
+    def nc_stored(self):
+        """rows of the constraint matrix C that are stored (unit-row blocks are implicit)."""
+        return sum(r.rows for r in self.rowblocks if r.kind not in UNIT_ROW_BLOCKS)
+
+    def rows_stored_offset(self, j):
+        return sum(r.rows for r in self.rowblocks[:j] if r.kind not in UNIT_ROW_BLOCKS)
 
     def task_row_offset(self, k, j):
         return sum(t.rows for t in self.levels[k][:j])
@@ -82,11 +99,11 @@ class StackPlan:
         for lev in self.levels:
             assert 1 <= len(lev) <= abi.MAX_TASKS
             for j, t in enumerate(lev):
-                if t.kind == abi.TASK_POSTURAL:
-                    assert j == len(lev) - 1 and t.rows == self.n
-                if t.kind == abi.TASK_CARTESIAN:
+                if t.kind in IMPLICIT_IDENTITY_TASKS:
+                    assert j == len(lev) - 1 and 1 <= t.rows <= self.n
+                if t.kind in (abi.TASK_CARTESIAN, abi.TASK_ACC_CARTESIAN):
                     assert t.rows == 6
-                if t.kind == abi.TASK_COM:
+                if t.kind in (abi.TASK_COM, abi.TASK_ACC_COM):
                     assert t.rows == 3
         assert len(self.bounds) <= abi.MAX_BOUNDS and len(self.rowblocks) <= abi.MAX_ROWBLOCKS
 
@@ -99,8 +116,8 @@ class StackPlan:
             p.level[k].n_tasks = len(lev)
             for j, t in enumerate(lev):
                 d = p.level[k].task[j]
-                d.kind, d.rows, d.weight, d.lambda_, d.orientation_gain = (
-                    t.kind, t.rows, t.weight, t.lam, t.orientation_gain)
+                d.kind, d.rows, d.weight, d.lambda_, d.orientation_gain, d.lambda2 = (
+                    t.kind, t.rows, t.weight, t.lam, t.orientation_gain, t.lam2)
         p.n_bounds = len(self.bounds)
         for j, b in enumerate(self.bounds):
             p.bound[j].kind, p.bound[j].scaling, p.bound[j].dT = b.kind, b.scaling, b.dT
@@ -109,6 +126,7 @@ class StackPlan:
             d = p.rowblock[j]
             d.kind, d.rows, d.d_threshold, d.detection_threshold, d.bound_scaling = (
                 r.kind, r.rows, r.d_threshold, r.detection_threshold, r.bound_scaling)
+            d.first_col, d.dT, d.p, d.mu = r.first_col, r.dT, r.p, r.mu
         p.eps_abs = self.eps_abs
         p.max_iter = self.max_iter
         return p

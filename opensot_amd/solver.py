@@ -25,6 +25,17 @@ def _stream_ptr(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def stored_rows(plan, C_dense):
+    """[B][nc][n] dense constraint matrix -> [B][nc_stored][n] (unit-row blocks have no storage)."""
+    from .plan import UNIT_ROW_BLOCKS
+    keep, off = [], 0
+    for r in plan.rowblocks:
+        if r.kind not in UNIT_ROW_BLOCKS:
+            keep.extend(range(off, off + r.rows))
+        off += r.rows
+    return np.ascontiguousarray(C_dense[:, keep, :])
+
+
 class BatchedStack:
     """B independent instances of one static stack (same topology, different numbers)."""
 
@@ -45,7 +56,7 @@ class BatchedStack:
         self.w = [torch.ones((B, plan.m(k)), **f64) for k in range(L)]
         self.c = [None] * L
         nc = plan.nc
-        self.C = torch.zeros((B, nc, n), **f64) if nc else None
+        self.C = torch.zeros((B, plan.nc_stored, n), **f64) if plan.nc_stored else None
         self.lo = torch.zeros((B, nc), **f64) if nc else None
         self.up = torch.zeros((B, nc), **f64) if nc else None
         self.l = torch.zeros((B, n), **f64) if plan.bounds else None
@@ -73,6 +84,10 @@ class BatchedStack:
         for k in range(self.plan.L):
             if self.A[k] is not None:
                 self.A[k][:B].copy_(to(leaf["A"][k]))
+        for j, Cj in enumerate(leaf.get("C", [])):   # constraint rows the producer writes in place
+            if Cj is not None:
+                o = self.plan.rows_stored_offset(j)
+                self.C[:B, o:o + Cj.shape[1]].copy_(to(Cj))
         dev = {"B": B,
                "task": [[tuple(to(x) for x in t) for t in lev] for lev in leaf["task"]],
                "bound": [tuple(to(x) for x in t) for t in leaf["bound"]],
@@ -88,8 +103,10 @@ class BatchedStack:
             self.b[k][:B].copy_(torch.as_tensor(asm["b"][k]))
             if asm["w"][k] is not None:
                 self.w[k][:B].copy_(torch.as_tensor(asm["w"][k]))
-        if self.C is not None:
-            self.C[:B].copy_(torch.as_tensor(asm["C"])); self.lo[:B].copy_(torch.as_tensor(asm["lo"]))
+        if self.lo is not None:
+            if self.C is not None:
+                self.C[:B].copy_(torch.as_tensor(stored_rows(self.plan, asm["C"])))
+            self.lo[:B].copy_(torch.as_tensor(asm["lo"]))
             self.up[:B].copy_(torch.as_tensor(asm["up"]))
         if self.l is not None:
             self.l[:B].copy_(torch.as_tensor(asm["l"])); self.u[:B].copy_(torch.as_tensor(asm["u"]))

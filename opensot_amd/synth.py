@@ -149,3 +149,90 @@ def perturb(leaf, rng, scale=0.01):
            "bound": [tuple(j(x) for x in t) for t in leaf["bound"]],
            "rows": [tuple(j(x) for x in t) for t in leaf["rows"]]}
     return out
+
+
+def make_id_stack(B, seed=None, nv=38, n_contacts=4, eps_factor=1e6, torque_limits=True):
+    """BASELINE config 5: floating-base inverse dynamics in torque mode, x = [qddot (nv); F (3 per point contact)]
+    (src/utils/InverseDynamics.cpp:12-28; bindings/python/examples/LittleDog_id.py:60-106).
+
+    levels : 0 = acceleration::CoM (3) + two acceleration::Cartesian (6 each)      [J 0] written by the producer
+             1 = acceleration::Postural on qddot ([I_nv 0], implicit)
+    rows   : DynamicFeasibility (6 eq) [B_u, -J_f'], FrictionCone (5 per contact), TorqueLimits (nv) [B, -Jc'],
+             acceleration::JointLimits (nv unit rows), acceleration::VelocityLimits (nv unit rows)
+    Model quantities (B, h, J, Jdot*qdot) are synthetic: B = L L' + I, h ~ N(0, 5^2), J ~ N(0, 0.3^2).
+    The stack is feasible by construction around qddot = 0 with supporting contact forces.
+    """
+    rng = np.random.default_rng(5000 if seed is None else seed)
+    nf = 3 * n_contacts
+    n = nv + nf
+    assert n <= abi.MAX_VARS
+    # dynamics
+    Lm = rng.normal(0.0, 0.3, size=(B, nv, nv))
+    Bm = Lm @ np.transpose(Lm, (0, 2, 1)) + np.eye(nv)
+    Jc = np.zeros((B, n_contacts, 3, nv))                      # point-contact linear Jacobians
+    Jc[:, :, :, :6] = rng.normal(0.0, 0.5, size=(B, n_contacts, 3, 6))
+    for ct in range(n_contacts):
+        cols = 6 + ct * 6 + np.arange(6)
+        Jc[:, ct][:, :, cols] = rng.normal(0.0, 0.3, size=(B, 3, 6))
+    # contact frames and a nominal force inside every cone; h chosen so that (qddot = 0, F = F0) is dynamically
+    # consistent on the floating base and well inside the torque limits
+    wRl = _rot_exp(rng.normal(0.0, 0.15, size=(B, n_contacts, 3)))
+    F0_local = np.concatenate([rng.uniform(-3, 3, size=(B, n_contacts, 2)), rng.uniform(40, 80, size=(B, n_contacts, 1))], axis=2)
+    F0 = np.einsum("bcij,bcj->bci", wRl, F0_local)                # world frame
+    JcT_F0 = np.einsum("bcij,bci->bj", Jc, F0)                    # sum_c Jc' F0
+    h = JcT_F0 + np.concatenate([np.zeros((B, 6)), rng.normal(0.0, 5.0, size=(B, nv - 6))], axis=1)
+    tau_max = np.full((B, nv), 30.0)                              # tight enough that some torque limits bind
+    tau_max[:, :6] = 1.0e3                                        # floating-base rows: loose (equality handles them)
+    # tasks
+    Jcom = rng.normal(0.0, 0.3, size=(B, 3, nv))
+    Jh = [_limb_jacobian(rng, B, 6, nv, list(range(0, 6)) + list(range(30 + 4 * k, 34 + 4 * k))) for k in range(2)]
+    A0 = np.zeros((B, 15, n))
+    A0[:, 0:3, :nv] = Jcom
+    A0[:, 3:9, :nv] = Jh[0]
+    A0[:, 9:15, :nv] = Jh[1]
+
+    def acc_leaf(rows):
+        pe = rng.normal(0.0, 0.02, size=(B, rows)); ve = rng.normal(0.0, 0.05, size=(B, rows))
+        return np.concatenate([pe, ve], axis=1), rng.normal(0.0, 0.1, size=(B, rows)), None
+    q = rng.uniform(-1.0, 1.0, size=(B, nv)); qd = rng.normal(0.0, 0.2, size=(B, nv))
+    half = rng.uniform(1.5, 2.5, size=(B, nv))
+    levels = [[Task(abi.TASK_ACC_COM, 3, lam=10.0, lam2=5.0, name="com"),
+               Task(abi.TASK_ACC_CARTESIAN, 6, lam=10.0, lam2=5.0, name="l_hand"),
+               Task(abi.TASK_ACC_CARTESIAN, 6, lam=10.0, lam2=5.0, name="r_hand")],
+              [Task(abi.TASK_ACC_POSTURAL, nv, lam=10.0, lam2=5.0, name="postural")]]
+    tleaf = [[acc_leaf(3), acc_leaf(6), acc_leaf(6)],
+             [(np.concatenate([rng.normal(0.0, 0.1, size=(B, nv)), -qd], axis=1), None, None)]]
+    # constraint rows written by the producer (zero-copy into C): dynamic feasibility and torque limits
+    Cdyn = np.zeros((B, 6, n)); Ctau = np.zeros((B, nv, n))
+    Cdyn[:, :, :nv] = Bm[:, :6, :]
+    Ctau[:, :, :nv] = Bm
+    for ct in range(n_contacts):
+        # DynamicFeasibility.cpp:38-41: -(J[0:k, 0:6])' ; TorqueLimits.cpp:39-40: -(J[0:k, :])'
+        Cdyn[:, :, nv + 3 * ct: nv + 3 * ct + 3] = -np.transpose(Jc[:, ct][:, :, :6], (0, 2, 1))
+        Ctau[:, :, nv + 3 * ct: nv + 3 * ct + 3] = -np.transpose(Jc[:, ct], (0, 2, 1))
+    rowblocks = [Rows(abi.ROWS_DYN_FEASIBILITY, 6, name="dynamic_feasibility"),
+                 Rows(abi.ROWS_FRICTION_CONE, 5 * n_contacts, first_col=nv, mu=0.8, name="friction_cones")]
+    rleaf = [(h[:, :6].copy(), None, None), (wRl.reshape(B, n_contacts, 9), None, None)]
+    Cleaf = [Cdyn, None]
+    if torque_limits:
+        rowblocks.append(Rows(abi.ROWS_TORQUE_LIMITS, nv, name="torque_limits"))
+        rleaf.append((h, tau_max, None)); Cleaf.append(Ctau)
+    rowblocks.append(Rows(abi.ROWS_ACC_JOINT_LIMITS, nv, first_col=0, dT=0.001, p=20.0, name="joint_limits"))
+    rleaf.append((np.concatenate([q, qd], axis=1), np.concatenate([-half, half], axis=1), np.full((B, nv), 500.0)))
+    Cleaf.append(None)
+    # four row blocks at most (OSOT_MAX_ROWBLOCKS): velocity limits only when torque limits are left out
+    if not torque_limits:
+        rowblocks.append(Rows(abi.ROWS_ACC_VELOCITY_LIMITS, nv, first_col=0, dT=0.001, p=20.0, name="velocity_limits"))
+        rleaf.append((qd, np.full((B, nv), 20.0), None)); Cleaf.append(None)
+    plan = StackPlan(n=n, levels=levels, bounds=[], rowblocks=rowblocks, eps_abs=eps_abs_from_factor(eps_factor))
+    leaf = {"B": B, "A": [A0, None], "task": tleaf, "bound": [], "rows": rleaf, "C": Cleaf,
+            "model": {"B": Bm, "h": h, "Jc": Jc, "nv": nv}}
+    return plan, leaf
+
+
+def computed_torque(leaf, x):
+    """InverseDynamics::computedTorque (src/utils/InverseDynamics.cpp:57-96): tau = B qddot + h - sum_c Jc' F_c;
+    the six floating-base rows must vanish."""
+    md = leaf["model"]; nv = md["nv"]
+    qdd = x[:, :nv]; F = x[:, nv:].reshape(x.shape[0], -1, 3)
+    return np.einsum("bij,bj->bi", md["B"], qdd) + md["h"] - np.einsum("bcij,bci->bj", md["Jc"], F)

@@ -125,6 +125,27 @@ void orc_collision_rows(int n, int P, int max_pairs, const double* Jd, const dou
                         double d_threshold, double detection_threshold, double bound_scaling,
                         double* Aineq, double* lo, double* up);
 
+
+/* ---------- inverse-dynamics row producers (x = [qddot; forces]) ---------- */
+/* acceleration::Cartesian / CoM, src/tasks/acceleration/Cartesian.cpp:152-160, CoM.cpp:86-92 with Kp = Kd = I:
+ * b = a_ref + lambda2*vel_err + lambda*pose_err - Jdot*qdot (rows = 6 or 3; a_ref may be NULL) */
+void orc_acc_task_b(int rows, const double* pose_err, const double* vel_err, const double* jdotqdot,
+                    const double* a_ref, double lambda, double lambda2, double* b);
+/* acceleration::Postural, src/tasks/acceleration/Postural.cpp:145-158 (Acceleration gain type) */
+void orc_acc_postural_b(int rows, const double* q_err, const double* qdot_err, const double* qddot_ref,
+                        double lambda, double lambda2, double* b);
+/* acceleration::TorqueLimits bounds, src/constraints/acceleration/TorqueLimits.cpp:44-45 */
+void orc_torque_limit_bounds(int rows, const double* h, const double* tau_max, double* lo, double* up);
+/* force::FrictionCone rows for one contact, src/constraints/force/FrictionCone.cpp:35-56:
+ * A53 (5x3 row-major) = Ci(mu/sqrt2) * wRl' */
+void orc_friction_cone_rows(const double* wRl, double mu, double* A53);
+/* acceleration::JointLimits bounds, src/constraints/acceleration/JointLimits.cpp:58-131 */
+void orc_acc_joint_limits(int rows, const double* q, const double* qdot, const double* qmin, const double* qmax,
+                          const double* qddot_max, double dt, double* lo, double* up);
+/* acceleration::VelocityLimits bounds, src/constraints/acceleration/VelocityLimits.cpp:50-63 */
+void orc_acc_velocity_limits(int rows, const double* qdot, const double* qdot_max, double dT, double p,
+                             double* lo, double* up);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,9 +20,11 @@ dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)
 
 # kinds, duplicated from include/osot_mi355x.h on purpose (the oracle must not import the product)
-TASK_GENERIC, TASK_CARTESIAN, TASK_COM, TASK_POSTURAL = range(4)
+TASK_GENERIC, TASK_CARTESIAN, TASK_COM, TASK_POSTURAL, TASK_ACC_CARTESIAN, TASK_ACC_COM, TASK_ACC_POSTURAL = range(7)
 BOUND_GENERIC, BOUND_JOINT_LIMITS, BOUND_VELOCITY_LIMITS = range(3)
-ROWS_GENERIC, ROWS_COLLISION = range(2)
+(ROWS_GENERIC, ROWS_COLLISION, ROWS_DYN_FEASIBILITY, ROWS_TORQUE_LIMITS, ROWS_FRICTION_CONE,
+ ROWS_ACC_JOINT_LIMITS, ROWS_ACC_VELOCITY_LIMITS) = range(7)
+IMPLICIT_IDENTITY_TASKS = (TASK_POSTURAL, TASK_ACC_POSTURAL)
 
 
 class OrcBatch(C.Structure):
@@ -73,6 +75,12 @@ def lib():
         L.orc_merge_box.argtypes = [C.c_int, dp, dp, dp, dp]
         L.orc_collision_rows.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp, C.c_double, C.c_double,
                                          C.c_double, dp, dp, dp]
+        L.orc_acc_task_b.argtypes = [C.c_int, dp, dp, dp, dp, C.c_double, C.c_double, dp]
+        L.orc_acc_postural_b.argtypes = [C.c_int, dp, dp, dp, C.c_double, C.c_double, dp]
+        L.orc_torque_limit_bounds.argtypes = [C.c_int, dp, dp, dp, dp]
+        L.orc_friction_cone_rows.argtypes = [dp, C.c_double, dp]
+        L.orc_acc_joint_limits.argtypes = [C.c_int, dp, dp, dp, dp, dp, C.c_double, dp, dp]
+        L.orc_acc_velocity_limits.argtypes = [C.c_int, dp, dp, C.c_double, C.c_double, dp, dp]
         _lib = L
     return _lib
 
@@ -99,7 +107,7 @@ def assemble(plan, leaf):
     zerosn = np.zeros(n)
     for k, lev in enumerate(plan.levels):
         m = sum(t.rows for t in lev)
-        ma = sum(t.rows for t in lev if t.kind != TASK_POSTURAL)
+        ma = sum(t.rows for t in lev if t.kind not in IMPLICIT_IDENTITY_TASKS)
         b = np.zeros((B, m))
         w = np.ones((B, m))
         off = 0
@@ -116,8 +124,16 @@ def assemble(plan, leaf):
                     L.orc_com_b(_p(p0[i]), _p(p1[i]), _p(p2[i] if p2 is not None else zeros6[:3]),
                                 t.lam, _p(bi))
                 elif t.kind == TASK_POSTURAL:
-                    L.orc_postural_b(n, _p(p0[i]), _p(p1[i]), _p(p2[i] if p2 is not None else zerosn),
+                    L.orc_postural_b(t.rows, _p(p0[i]), _p(p1[i]), _p(p2[i] if p2 is not None else zerosn),
                                      t.lam, _p(bi))
+                elif t.kind in (TASK_ACC_CARTESIAN, TASK_ACC_COM):
+                    pe = np.ascontiguousarray(p0[i, :t.rows]); ve = np.ascontiguousarray(p0[i, t.rows:])
+                    L.orc_acc_task_b(t.rows, _p(pe), _p(ve), _p(p1[i]), _p(p2[i]) if p2 is not None else None,
+                                     t.lam, t.lam2, _p(bi))
+                elif t.kind == TASK_ACC_POSTURAL:
+                    pe = np.ascontiguousarray(p0[i, :t.rows]); ve = np.ascontiguousarray(p0[i, t.rows:])
+                    L.orc_acc_postural_b(t.rows, _p(pe), _p(ve), _p(p2[i]) if p2 is not None else None,
+                                         t.lam, t.lam2, _p(bi))
                 else:  # GENERIC: b supplied (GenericTask.cpp:5-56)
                     bi[:] = p0[i]
             off += t.rows
@@ -154,11 +170,34 @@ def assemble(plan, leaf):
         for j, rb in enumerate(plan.rowblocks):
             p0, p1, p2 = (_c(x) for x in leaf["rows"][j])
             for i in range(B):
+                sl = slice(off, off + rb.rows)
+                loi = np.zeros(rb.rows); upi = np.zeros(rb.rows)
                 if rb.kind == ROWS_COLLISION:
-                    Ci = np.zeros((rb.rows, n)); loi = np.zeros(rb.rows); upi = np.zeros(rb.rows)
+                    Ci = np.zeros((rb.rows, n))
                     L.orc_collision_rows(n, rb.rows, rb.rows, _p(p0[i]), _p(p1[i]), rb.d_threshold,
                                          rb.detection_threshold, rb.bound_scaling, _p(Ci), _p(loi), _p(upi))
-                    Cm[i, off:off + rb.rows] = Ci; lo[i, off:off + rb.rows] = loi; up[i, off:off + rb.rows] = upi
+                    Cm[i, sl] = Ci; lo[i, sl] = loi; up[i, sl] = upi
+                elif rb.kind == ROWS_DYN_FEASIBILITY:      # rows [B_u, -J_f'] come from the producer (leaf "C")
+                    Cm[i, sl] = leaf["C"][j][i]; lo[i, sl] = -p0[i]; up[i, sl] = -p0[i]
+                elif rb.kind == ROWS_TORQUE_LIMITS:
+                    L.orc_torque_limit_bounds(rb.rows, _p(p0[i]), _p(p1[i]), _p(loi), _p(upi))
+                    Cm[i, sl] = leaf["C"][j][i]; lo[i, sl] = loi; up[i, sl] = upi
+                elif rb.kind == ROWS_FRICTION_CONE:
+                    A53 = np.zeros(15)
+                    for ct in range(rb.rows // 5):
+                        L.orc_friction_cone_rows(_p(np.ascontiguousarray(p0[i, ct])), rb.mu, _p(A53))
+                        Cm[i, off + 5 * ct: off + 5 * ct + 5, rb.first_col + 3 * ct: rb.first_col + 3 * ct + 3] = A53.reshape(5, 3)
+                    lo[i, sl] = -1.0e20; up[i, sl] = 0.0
+                elif rb.kind == ROWS_ACC_JOINT_LIMITS:
+                    nr = rb.rows
+                    L.orc_acc_joint_limits(nr, _p(np.ascontiguousarray(p0[i, :nr])), _p(np.ascontiguousarray(p0[i, nr:])),
+                                           _p(np.ascontiguousarray(p1[i, :nr])), _p(np.ascontiguousarray(p1[i, nr:])),
+                                           _p(p2[i]), rb.dT * rb.p, _p(loi), _p(upi))
+                    Cm[i, sl, rb.first_col:rb.first_col + nr] = np.eye(nr); lo[i, sl] = loi; up[i, sl] = upi
+                elif rb.kind == ROWS_ACC_VELOCITY_LIMITS:
+                    nr = rb.rows
+                    L.orc_acc_velocity_limits(nr, _p(p0[i]), _p(p1[i]), rb.dT, rb.p, _p(loi), _p(upi))
+                    Cm[i, sl, rb.first_col:rb.first_col + nr] = np.eye(nr); lo[i, sl] = loi; up[i, sl] = upi
                 else:
                     Cm[i, off:off + rb.rows] = p0[i]; lo[i, off:off + rb.rows] = p1[i]; up[i, off:off + rb.rows] = p2[i]
             off += rb.rows

@@ -6,7 +6,7 @@ in place into oracle/_ref (oracle/Makefile) and driven with OpenSoT's convention
 diag(H), +-1e20 clamp, cold initProblem then hot-started solve -- oracle/ref_qpoases_shim.cpp) by the
 restated iHQP cascade (oracle/osot_oracle.c).  Only data is written: inputs and expected outputs.
 
-Per config (C2, C3, C4; 32 seeded instances each) one .npz with
+Per config (C2, C3, C4: 32 seeded instances each; C5 = 38-DoF floating-base inverse dynamics: 16) one .npz with
   leaf inputs .............. what XBot::ModelInterface would supply (synthetic, opensot_amd/synth.py)
   asm_* ..................... AutoStack::update() outputs from the oracle's leaf restatement
   x_ref [B][L][n] ........... per-level x of qpOASES with OpenSoT's option set (terminationTolerance 2.2e-7)
@@ -44,6 +44,9 @@ def flatten_leaf(leaf):
         for i, x in enumerate(t):
             if x is not None:
                 out[f"leaf_rows{j}_p{i}"] = x
+    for j, x in enumerate(leaf.get("C", [])):
+        if x is not None:
+            out[f"leaf_C{j}"] = x
     return out
 
 
@@ -51,9 +54,13 @@ def main():
     po.build()
     assert po.ref_available(), "oracle/_ref/libqpoases_ref.so missing: run `make -C oracle ref` where /root/reference exists"
     B = 32
-    for cfg in ("C2", "C3", "C4"):
-        seed = {"C2": 20260, "C3": 30260, "C4": 40260}[cfg]
-        plan, leaf = synth.make_velocity_stack(cfg, B, seed=seed)
+    for cfg in ("C2", "C3", "C4", "C5"):
+        seed = {"C2": 20260, "C3": 30260, "C4": 40260, "C5": 50260}[cfg]
+        if cfg == "C5":
+            B = 16
+            plan, leaf = synth.make_id_stack(B, seed=seed)
+        else:
+            plan, leaf = synth.make_velocity_stack(cfg, B, seed=seed)
         asm = po.assemble(plan, leaf)
         ref = po.ihqp_solve_batch(asm, po.BE_QPOASES_REF, nthreads=1)
         exact = po.ihqp_solve_batch(asm, po.BE_QPOASES_REF, nthreads=1, termination_tolerance=10 * 2.221e-16)

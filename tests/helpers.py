@@ -13,9 +13,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def load_golden(cfg):
     """-> (plan, leaf, golden dict) from tests/golden/<cfg>_b32.npz (see tests/golden/make_golden.py)."""
-    z = np.load(os.path.join(GOLDEN, f"{cfg}_b32.npz"), allow_pickle=False)
+    z = np.load(os.path.join(GOLDEN, f"{cfg}_b{16 if cfg == 'C5' else 32}.npz"), allow_pickle=False)
     B = int(z["B"])
-    plan, tmpl = synth.make_velocity_stack(cfg, 1, seed=0)
+    plan, tmpl = synth.make_id_stack(1, seed=0) if cfg == "C5" else synth.make_velocity_stack(cfg, 1, seed=0)
     plan.eps_abs = float(z["eps_abs"])
 
     def get(name):
@@ -26,7 +26,8 @@ def load_golden(cfg):
             "task": [[tuple(get(f"leaf_task{k}_{j}_p{i}") for i in range(3)) for j in range(len(plan.levels[k]))]
                      for k in range(plan.L)],
             "bound": [tuple(get(f"leaf_bound{j}_p{i}") for i in range(3)) for j in range(len(plan.bounds))],
-            "rows": [tuple(get(f"leaf_rows{j}_p{i}") for i in range(3)) for j in range(len(plan.rowblocks))]}
+            "rows": [tuple(get(f"leaf_rows{j}_p{i}") for i in range(3)) for j in range(len(plan.rowblocks))],
+            "C": [get(f"leaf_C{j}") for j in range(len(plan.rowblocks))]}
     return plan, leaf, z
 
 
@@ -66,9 +67,14 @@ def emu_cascade(plan, asm, active=None):
                 a = np.ascontiguousarray(a, dtype=np.float64)
                 keep.append(a)
                 getattr(qb, name)[k] = a.ctypes.data
+    from opensot_amd.solver import stored_rows
     for name in ("C", "lo", "up", "l", "u"):
         a = asm[name]
         if a is not None:
+            if name == "C":
+                a = stored_rows(plan, a)
+                if a.shape[1] == 0:
+                    continue
             a = np.ascontiguousarray(a, dtype=np.float64)
             keep.append(a)
             setattr(qb, name, a.ctypes.data)

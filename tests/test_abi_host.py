@@ -61,7 +61,7 @@ def test_plan_validation_errors(lib):
     assert code(p) == abi.ERR_UNSUPPORTED
     p = good.to_c(); p.level[0].task[0].rows = 0
     assert code(p) == abi.ERR_INVALID
-    p = good.to_c(); p.level[1].task[0].rows = 7          # Postural must span n rows
+    p = good.to_c(); p.level[1].task[0].rows = 9          # Postural [I_rows 0] cannot exceed n rows
     assert code(p) == abi.ERR_INVALID
     p = good.to_c(); p.eps_abs = -1.0
     assert code(p) == abi.ERR_INVALID

@@ -6,7 +6,7 @@ import pytest
 from helpers import load_golden
 
 
-@pytest.mark.parametrize("cfg", ["C2", "C3", "C4"])
+@pytest.mark.parametrize("cfg", ["C2", "C3", "C4", "C5"])
 def test_leaf_update_matches_golden(cfg, oracle):
     plan, leaf, z = load_golden(cfg)
     asm = oracle.assemble(plan, leaf)
@@ -18,7 +18,7 @@ def test_leaf_update_matches_golden(cfg, oracle):
             np.testing.assert_array_equal(asm[name], z[f"asm_{name}"])
 
 
-@pytest.mark.parametrize("cfg", ["C2", "C3", "C4"])
+@pytest.mark.parametrize("cfg", ["C2", "C3", "C4", "C5"])
 @pytest.mark.parametrize("backend", ["eq", "refform"])
 def test_cascade_matches_qpoases_golden(cfg, backend, oracle):
     plan, leaf, z = load_golden(cfg)
@@ -100,3 +100,34 @@ def test_joint_limits_and_collision_rows(oracle):
     np.testing.assert_array_equal(A[2], -Jd[3]); np.testing.assert_array_equal(A[3], 0 * Jd[0])
     np.testing.assert_array_equal(up, [0.0, 0.04, 0.06, np.finfo(float).max])
     assert (lo == -np.finfo(float).max).all()
+
+
+def test_id_row_producers(oracle):
+    """friction-cone pyramid (FrictionCone.cpp:35-56), torque-limit bounds (TorqueLimits.cpp:44-45) and the
+    acceleration joint-limit bounds (constraints/acceleration/JointLimits.cpp:58-131) on hand-checkable inputs"""
+    import ctypes as C
+    L = oracle.lib(); dp = C.POINTER(C.c_double)
+    p = lambda a: a.ctypes.data_as(dp)
+    A = np.zeros(15)
+    L.orc_friction_cone_rows(p(np.eye(3).ravel().copy()), 0.8, p(A))
+    m = 0.8 / np.sqrt(2.0)
+    np.testing.assert_allclose(A.reshape(5, 3), [[1, 0, -m], [-1, 0, -m], [0, 1, -m], [0, -1, -m], [0, 0, -1]])
+    # a force along the contact normal satisfies A f <= 0; a tangential one beyond the cone does not
+    Rz = np.array([[0.0, -1, 0], [1, 0, 0], [0, 0, 1]])
+    L.orc_friction_cone_rows(p(Rz.ravel().copy()), 0.8, p(A))
+    assert (A.reshape(5, 3) @ (Rz @ np.array([0, 0, 10.0])) <= 1e-12).all()
+    assert (A.reshape(5, 3) @ (Rz @ np.array([9.0, 0, 10.0])) > 0).any()
+    lo = np.zeros(2); up = np.zeros(2)
+    L.orc_torque_limit_bounds(2, p(np.array([3.0, -4.0])), p(np.array([10.0, 10.0])), p(lo), p(up))
+    np.testing.assert_array_equal(lo, [-13, -6]); np.testing.assert_array_equal(up, [7, 14])
+    # joint in the middle of its range at rest: the admissible accelerations are symmetric
+    lo = np.zeros(1); up = np.zeros(1)
+    L.orc_acc_joint_limits(1, p(np.array([0.0])), p(np.array([0.0])), p(np.array([-1.0])), p(np.array([1.0])),
+                           p(np.array([100.0])), 0.02, p(lo), p(up))
+    assert up[0] > 0 and lo[0] == pytest.approx(-up[0])
+    # joint at its upper limit moving towards it: no positive acceleration allowed
+    L.orc_acc_joint_limits(1, p(np.array([1.0])), p(np.array([0.5])), p(np.array([-1.0])), p(np.array([1.0])),
+                           p(np.array([100.0])), 0.02, p(lo), p(up))
+    assert up[0] < 0
+    L.orc_acc_velocity_limits(1, p(np.array([1.0])), p(np.array([3.0])), 0.001, 20.0, p(lo), p(up))
+    assert up[0] == pytest.approx(100.0) and lo[0] == pytest.approx(-200.0)
