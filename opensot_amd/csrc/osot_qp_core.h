@@ -476,6 +476,22 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
     double* V1 = w.V + NP;
     int box_state = 0;   // lane c: 0 free, 1 lower bound active, 2 upper bound active
     OSOT_PH_BEGIN();
+    // the stored rows that can ever be violated (not equalities, at least one finite bound), in row order;
+    // the equality list is dead by now, its LDS array is reused
+    int n_gen = 0;
+    for (int r0 = 0; r0 < nrows; r0 += 64) {
+        const int r = r0 + c + NP * h;
+        bool is_gen = false;
+        if (r < nrows) {
+            const double lo = w.rlo[r], up = w.rup[r];
+            is_gen = (w.rowstate[r] != 3) && !(w.rptr[r] & 1ull) && ((lo > -kInfty) || (up < kInfty));
+        }
+        wave_sync();
+        const unsigned long long mask = wave_ballot(is_gen);
+        if (is_gen) w.eqlist[n_gen + lanes_below(mask)] = r;
+        n_gen += __builtin_popcountll(mask);
+    }
+    wave_sync();
     int status = QP_SOLVED;
     const int kNone = 0x7fffffff;
     for (;;) {
@@ -492,23 +508,60 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                 if (s < -kViolTol * fmax(1.0, fabs(ub)) && s < cand) { cand = s; code = n + c; }
             }
         }
-        for (int r = 0; r < nrows; ++r) {
-            const int st = w.rowstate[r];
-            if (st == 3) continue;
-            const double lo = w.rlo[r], up = w.rup[r];
-            const bool has_lo = lo > -kInfty, has_up = up < kInfty;
-            if (!has_lo && !has_up) continue;
-            const double ax = colsum<NP>(row_elem<NP>(w, r, c) * x);
-            if (st != 1 && has_lo) {
-                const double s = ax - lo;
-                if (s < -kViolTol * fmax(1.0, fabs(lo)) && s < cand) { cand = s; code = 2 * n + 2 * r; }
-            }
-            if (st != 2 && has_up) {
-                const double s = up - ax;
-                if (s < -kViolTol * fmax(1.0, fabs(up)) && s < cand) { cand = s; code = 2 * n + 2 * r + 1; }
+        // unit rows (implicit e_i rows: acceleration joint/velocity limits) are checked 64 rows at a time,
+        // lane = row, against a staged copy of x: they cost no reduction at all
+        if (nrows > 0) {
+            if (h == 0) V0[c] = x;
+            wave_sync();
+            const int lane = c + NP * h;
+            for (int r0 = 0; r0 < nrows; r0 += 64) {
+                const int r = r0 + lane;
+                if (r < nrows) {
+                    const unsigned long long pr = w.rptr[r];
+                    const int st = w.rowstate[r];
+                    const int idx = (int)(pr >> 1);
+                    if ((pr & 1ull) && st != 3 && idx < n) {
+                        const double lo = w.rlo[r], up = w.rup[r];
+                        const double ax = V0[idx];
+                        if (st != 1 && lo > -kInfty) {
+                            const double s = ax - lo;
+                            if (s < -kViolTol * fmax(1.0, fabs(lo)) && s < cand) { cand = s; code = 2 * n + 2 * r; }
+                        }
+                        if (st != 2 && up < kInfty) {
+                            const double s = up - ax;
+                            if (s < -kViolTol * fmax(1.0, fabs(up)) && s < cand) { cand = s; code = 2 * n + 2 * r + 1; }
+                        }
+                    }
+                }
             }
         }
-        colargmin<NP>(cand, code);
+        // stored inequality rows, two at a time: both HBM/L2 row reads are in flight together and one paired
+        // reduction network serves the two a'x
+        for (int g0 = 0; g0 < n_gen; g0 += 2) {
+            const int r0_ = w.eqlist[g0];
+            const int r1_ = (g0 + 1 < n_gen) ? w.eqlist[g0 + 1] : -1;
+            const double p0_ = row_elem<NP>(w, r0_, c) * x;
+            const double p1_ = (r1_ >= 0) ? row_elem<NP>(w, r1_, c) * x : 0.0;
+            double ax0, ax1;
+            colsum2<NP>(p0_, p1_, ax0, ax1);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = u ? r1_ : r0_;
+                if (r < 0) continue;
+                const double ax = u ? ax1 : ax0;
+                const int st = w.rowstate[r];
+                const double lo = w.rlo[r], up = w.rup[r];
+                if (st != 1 && lo > -kInfty) {
+                    const double s = ax - lo;
+                    if (s < -kViolTol * fmax(1.0, fabs(lo)) && s < cand) { cand = s; code = 2 * n + 2 * r; }
+                }
+                if (st != 2 && up < kInfty) {
+                    const double s = up - ax;
+                    if (s < -kViolTol * fmax(1.0, fabs(up)) && s < cand) { cand = s; code = 2 * n + 2 * r + 1; }
+                }
+            }
+        }
+        colargmin<64>(cand, code);   // all 64 lanes: the unit-row pass holds different rows in the two halves
         code = uniform_i(code);
         if (code == kNone) break;   // primal feasible: optimal
         if (++iters > max_iter) { status = QP_MAX_ITER; break; }
@@ -522,6 +575,9 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
         const double ip_sgn = ip_box ? (ip < n ? 1.0 : -1.0) : ((ip & 1) ? -1.0 : 1.0);
         double np = 0.0;   // lane-distributed normal (general rows only)
         if (!ip_box) np = ip_sgn * row_elem<NP>(w, ip_row, c);
+        const unsigned long long ip_ptr = ip_box ? 0ull : w.rptr[ip_row];
+        const bool ip_unit = !ip_box && (ip_ptr & 1ull);      // unit row e_i: d = J'n is a row read, like a bound
+        const int ip_uidx = ip_unit ? (int)(ip_ptr >> 1) : 0;
 
         bool failed = false;
         for (;;) {
@@ -529,6 +585,8 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
             double d;
             if (ip_box) {
                 d = ip_sgn * M2[c * S + ip_var];
+            } else if (ip_unit) {
+                d = ip_sgn * M2[c * S + ip_uidx];
             } else {
                 if (h == 0) V0[c] = np;
                 wave_sync();
