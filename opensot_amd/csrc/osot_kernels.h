@@ -82,6 +82,7 @@ __global__ void __launch_bounds__(64, 2) osot_cascade_kernel(const DevPlan P, co
     w.rowstate = reinterpret_cast<int*>(w.rptr + P.lds_rows_cap);
     w.eqlist = w.rowstate + P.lds_rows_cap;
     w.xlev = base + P.lds_xlev_off;
+    w.safe_row = reinterpret_cast<unsigned long long>(D.dq + inst * n);   // n readable doubles (value is discarded)
     w.rsrc = reinterpret_cast<signed char*>(w.xlev + (P.L > 1 ? P.L - 1 : 1) * NP);
     const int c = w.c, h = w.h;
     const bool valid = c < n;
@@ -273,6 +274,7 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
     w.rowstate = reinterpret_cast<int*>(w.rptr + Q.lds_rows_cap);
     w.eqlist = w.rowstate + Q.lds_rows_cap;
     w.xlev = nullptr;
+    w.safe_row = reinterpret_cast<unsigned long long>(Q.x + inst * n);
     w.rsrc = reinterpret_cast<signed char*>(w.eqlist + Q.lds_rows_cap);
     const int c = w.c, h = w.h;
     const bool valid = c < n;

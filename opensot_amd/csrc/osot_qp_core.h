@@ -54,14 +54,20 @@ struct WaveCtx {
     signed char* rsrc;            // -1: bounds are rlo/rup;  j >= 0: optimality row of level j, i.e. the
                                   // equality a'x = a'x_j with x_j = xlev[j] (iHQP.cpp:164-170); rlo = rup = 0
     double* xlev;                 // [levels][NP] solutions of the levels solved so far (cascade only)
+    unsigned long long safe_row;  // address of n readable doubles in HBM (dummy target of unit-row loads)
 };
 
-// a_r[col] for lane-column col (0 beyond n)
+// a_r[col] for lane-column col (0 beyond n).  Branch-free: a unit row reads a harmless valid address
+// (safe_row) and discards the value; the load is a global_load (address space 1), not a flat one.
 template <int NP>
 __device__ __forceinline__ double row_elem(const WaveCtx<NP>& w, int r, int col) {
     const unsigned long long p = w.rptr[r];
-    if (p & 1ull) return (col == (int)(p >> 1)) ? 1.0 : 0.0;
-    return (col < w.n) ? reinterpret_cast<const double*>(p)[col] : 0.0;
+    const bool unit = (p & 1ull) != 0ull;
+    const unsigned long long addr = unit ? w.safe_row : p;
+    const int cc = (col < w.n) ? col : 0;
+    const double v = OSOT_GLOBAL_F64(addr)[cc];
+    const double uv = (col == (int)(p >> 1)) ? 1.0 : 0.0;
+    return unit ? uv : ((col < w.n) ? v : 0.0);
 }
 
 __device__ __forceinline__ double clamp_inf(double v) {
