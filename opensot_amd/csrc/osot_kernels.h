@@ -63,7 +63,8 @@ struct DevBatch {
 // Row table of level k (LDS): [ global C rows ; A_0 ; ... ; A_{k-1} ]  (iHQP.cpp:282-333).  The C entries are
 // filled once per instance, the optimality entries of level j are appended when level j has been solved
 // (lo = up = A_j x_j, iHQP.cpp:164-170; an inactive level contributes 0*x in [-1,1], iHQP.cpp:301-309).
-template <int NP, bool PROF>
+// FULLN: n == NP (no per-step guards in the factorisation)
+template <int NP, bool PROF, bool FULLN>
 __global__ void __launch_bounds__(64, 2) osot_cascade_kernel(const DevPlan P, const DevBatch D) {
     OSOT_DYNAMIC_LDS(osot_smem);
     constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
@@ -202,7 +203,7 @@ __global__ void __launch_bounds__(64, 2) osot_cascade_kernel(const DevPlan P, co
         const int nrows = P.nc + P.optoff[k];
         int iters = 0;
         OSOT_PH_END(PH_HBUILD);
-        const int st = gi_solve<NP, PROF>(w, nrows, g, diag_h, hdiag, reinterpret_cast<double(&)[16]>(hacc),
+        const int st = gi_solve<NP, PROF, FULLN>(w, nrows, g, diag_h, hdiag, reinterpret_cast<double(&)[16]>(hacc),
                                           has_box, lb, ub, P.max_iter, x, iters, prof);
         if (PROF) ph_t0_ = (long long)clock64();
         iters_total += iters;
@@ -305,7 +306,7 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
     wave_sync();
     double x = 0.0;
     int iters = 0;
-    const int st = gi_solve<NP, false>(w, Q.nc, g, false, 0.0, Hc, has_box, lb, ub, Q.max_iter, x, iters, nullptr);
+    const int st = gi_solve<NP, false, false>(w, Q.nc, g, false, 0.0, Hc, has_box, lb, ub, Q.max_iter, x, iters, nullptr);
     if (valid && h == 0) Q.x[inst * n + c] = (st == QP_SOLVED) ? x : 0.0;
     if (lane == 0) {
         Q.status[inst] = st;

@@ -300,7 +300,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
 
 // Pre (general H):  NP = 64: M1 holds H + eps I (lower triangle used);
 //                    NP = 32: Hc[ii] = (H + eps I)[2ii+h][c] in registers (see factor32), M1 is scratch.
-template <int NP, bool PROF>
+template <int NP, bool PROF, bool FULLN>
 __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_h,
                         double hdiag, double (&Hc)[16], bool has_box, double lb, double ub, int max_iter,
                         double& x_out, int& iters_out, long long* prof) {
@@ -335,7 +335,9 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
         OSOT_PH_END(PH_CHOL);
     } else if (NP == 32) {
         const WaveCtx<32>& w32 = reinterpret_cast<const WaveCtx<32>&>(w);
-        const int st32 = (n == 32) ? factor32<true>(w32, Hc, g, x) : factor32<false>(w32, Hc, g, x);
+        // exactly ONE factor32 instantiation per kernel (FULLN is a kernel template parameter): both variants
+        // in one kernel push it past 256 VGPRs; each alone fits (249 / 243) without scratch
+        const int st32 = factor32<FULLN>(w32, Hc, g, x);
         if (st32 != QP_SOLVED) { x_out = 0.0; iters_out = 0; return st32; }
         OSOT_PH_END(PH_CHOL);
     } else {
