@@ -2,8 +2,9 @@ import sys; sys.path.insert(0,'/root/repo')
 import numpy as np, torch
 from opensot_amd import synth
 from opensot_amd.solver import BatchedStack
-B=4096
-plan, leaf = synth.make_velocity_stack("C3", B, seed=3000)
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+plan, leaf = synth.make_id_stack(B, seed=3000) if cfg == "C5" else synth.make_velocity_stack(cfg, B, seed=3000)
 st = BatchedStack(plan, B, device=0, want_levels=False)
 st.update(st.load_leaf(leaf)); st.solve(B); torch.cuda.synchronize()
 cyc = st.profile_phases(B)
