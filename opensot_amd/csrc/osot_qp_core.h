@@ -33,6 +33,7 @@ constexpr double kInfty = 1.0e20;      // QPOasesBackEnd::checkINFTY clamp (QPOa
 constexpr double kDepTol2 = 1.0e-18;   // |d2|^2 <= kDepTol2 |d|^2  -> normal is in the span of the working set
 constexpr double kViolTol = 1.0e-11;   // a slack below -kViolTol*max(1,|bound|) counts as violated
 constexpr double kEqTol = 1.0e-9;      // consistency of a linearly dependent equality row
+constexpr double kSlackTol = 1.0e-8;   // a violation below this (relative) with no direction left is round-off
 
 enum { QP_SOLVED = 0, QP_INFEASIBLE = 1, QP_MAX_ITER = 2, QP_NOT_PD = 3 };
 
@@ -587,7 +588,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
         const bool ip_unit = !ip_box && (ip_ptr & 1ull);      // unit row e_i: d = J'n is a row read, like a bound
         const int ip_uidx = ip_unit ? (int)(ip_ptr >> 1) : 0;
 
-        bool failed = false;
+        bool failed = false, degenerate_done = false;
         for (;;) {
             // d = J' n
             double d;
@@ -625,7 +626,16 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
             lpos = uniform_i(lpos);
             t1 = bcast(t1, 0);
             const double t2 = z_ok ? (-s_ip * fast_rcp(nd2)) : INFINITY;
-            if (!(t1 < INFINITY) && !(t2 < INFINITY)) { failed = true; break; }   // infeasible
+            if (!(t1 < INFINITY) && !(t2 < INFINITY)) {
+                // no primal direction left and no inequality to trade.  If the most violated constraint is
+                // violated only at round-off level (an active inequality of an upper level re-appearing when the
+                // optimality rows leave no freedom: slack = O(eps * cond)), the point is optimal; otherwise the
+                // QP is infeasible (eiquadprog.hpp:376-382).
+                const double bmag = ip_box ? fabs(bcast((ip < n) ? lb : ub, ip_var))
+                                           : fabs((ip & 1) ? w.rup[ip_row] : w.rlo[ip_row]);
+                if (-s_ip <= kSlackTol * fmax(1.0, bmag)) { degenerate_done = true; break; }
+                failed = true; break;
+            }
             if (t2 <= t1) {
                 // full step: constraint ip becomes active
                 x += t2 * z;
@@ -658,6 +668,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
             if (++iters > max_iter) { status = QP_MAX_ITER; failed = true; break; }
         }
         if (failed) { if (status == QP_SOLVED) status = QP_INFEASIBLE; break; }
+        if (degenerate_done) break;
     }
     OSOT_PH_END(PH_INEQ);
     x_out = x;

@@ -236,3 +236,38 @@ def computed_torque(leaf, x):
     md = leaf["model"]; nv = md["nv"]
     qdd = x[:, :nv]; F = x[:, nv:].reshape(x.shape[0], -1, 3)
     return np.einsum("bij,bj->bi", md["B"], qdd) + md["h"] - np.einsum("bcij,bci->bj", md["Jc"], F)
+
+
+def make_generic_stack(B, n, level_rows, n_eq=0, n_ineq=0, seed=0, box=0.5, duplicate_eq_in_level=None,
+                       postural_last=True, eps_factor=1e6):
+    """small generic stacks (tasks::GenericTask blocks, GenericConstraint rows, generic box) for robot-free tests:
+    e.g. a Panda-like 7-variable 2-level stack, or stacks whose optimality rows duplicate global equality rows
+    (the `<< (l_sole + r_sole)` situation of examples/cpp/coman_ik.cpp:442 where 39 equality rows meet 35
+    variables).  duplicate_eq_in_level = k copies the global equality rows into level k's task (consistent b)."""
+    rng = np.random.default_rng(seed)
+    levels, A, tleaf = [], [], []
+    Ceq = rng.normal(0.0, 0.5, size=(B, n_eq, n)) if n_eq else None
+    beq = rng.uniform(-0.02, 0.02, size=(B, n_eq)) if n_eq else None
+    for k, m in enumerate(level_rows):
+        Ak = rng.normal(0.0, 0.4, size=(B, m, n))
+        bk = rng.normal(0.0, 0.05, size=(B, m))
+        if duplicate_eq_in_level == k and n_eq:
+            Ak = np.concatenate([Ceq, Ak], axis=1); bk = np.concatenate([beq, bk], axis=1)
+        levels.append([Task(abi.TASK_GENERIC, Ak.shape[1], name=f"generic{k}")])
+        A.append(np.ascontiguousarray(Ak)); tleaf.append([(bk, None, None)])
+    if postural_last:
+        q = rng.uniform(-1, 1, size=(B, n))
+        levels.append([Task(abi.TASK_POSTURAL, n, lam=0.1, name="postural")])
+        A.append(None); tleaf.append([(q, q + rng.normal(0, 0.1, size=(B, n)), None)])
+    rowblocks, rleaf = [], []
+    if n_eq:
+        rowblocks.append(Rows(abi.ROWS_GENERIC, n_eq, name="equalities")); rleaf.append((Ceq, beq, beq.copy()))
+    if n_ineq:
+        Ci = rng.normal(0.0, 0.5, size=(B, n_ineq, n))
+        rowblocks.append(Rows(abi.ROWS_GENERIC, n_ineq, name="inequalities"))
+        rleaf.append((Ci, -rng.uniform(0.01, 0.2, size=(B, n_ineq)), rng.uniform(0.01, 0.2, size=(B, n_ineq))))
+    bounds, bleaf = [], []
+    if box:
+        bounds.append(Bound(abi.BOUND_GENERIC, name="box")); bleaf.append((np.full((B, n), -box), np.full((B, n), box), None))
+    plan = StackPlan(n=n, levels=levels, bounds=bounds, rowblocks=rowblocks, eps_abs=eps_abs_from_factor(eps_factor))
+    return plan, {"B": B, "A": A, "task": tleaf, "bound": bleaf, "rows": rleaf}

@@ -146,3 +146,51 @@ def test_inverse_dynamics_stack_properties(oracle):
     assert (Cx <= np.minimum(asm["up"], 1e20) + 1e-9).all() and (Cx >= np.maximum(asm["lo"], -1e20) - 1e-9).all()
     ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
     assert np.abs(dq - ref["dq"]).max() < 1e-8
+
+
+@pytest.mark.parametrize("n,rows,n_eq,n_ineq", [(7, [6], 0, 0), (7, [3, 3], 1, 2), (20, [5, 6], 4, 6), (31, [10, 12], 3, 0)])
+def test_small_generic_cascades(n, rows, n_eq, n_ineq, oracle):
+    """n < 32 goes through the guarded (FULLN = false) instantiation: Panda-like 7-variable stacks
+    (examples/cpp/panda_ik.cpp shape) and mid-size generic stacks with equality and inequality rows"""
+    plan, leaf = synth.make_generic_stack(5, n, rows, n_eq=n_eq, n_ineq=n_ineq, seed=n)
+    asm = oracle.assemble(plan, leaf)
+    dq, xl, st, it = emu_cascade(plan, asm)
+    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+    assert (st == 0).all() and (ref["status"] == 1).all()
+    assert np.abs(dq - ref["dq"]).max() < 1e-9
+    if oracle.ref_available():
+        rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
+        assert (rq["status"] == 1).all() and np.abs(dq - rq["dq"]).max() < 1e-6
+
+
+def test_roundoff_violation_with_no_freedom_left(oracle):
+    """an inequality active at an upper level re-appears at a level whose optimality rows leave no free direction:
+    its slack is O(eps*cond) and must not be reported as infeasibility (instance 54 of this seeded family did)"""
+    plan, leaf = synth.make_generic_stack(64, 7, [3, 3], n_eq=1, n_ineq=2, seed=7)
+    asm = oracle.assemble(plan, leaf)
+    dq, xl, st, it = emu_cascade(plan, asm)
+    assert (st == 0).all()
+    if oracle.ref_available():
+        rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
+        ok = rq["status"] == 1
+        assert np.abs(dq[ok] - rq["dq"][ok]).max() < 1e-6
+
+
+def test_optimality_rows_duplicating_global_equalities(oracle):
+    """coman_ik.cpp:442 situation: the stack's global equality rows re-appear as optimality rows of a task level
+    (more equality rows than could be independent).  Consistent duplicates are skipped; the answer equals the
+    reference's (qpOASES drops them through its linear-independence test, QProblem.cpp:2847)"""
+    plan, leaf = synth.make_generic_stack(6, 16, [4, 5], n_eq=6, seed=3, duplicate_eq_in_level=0)
+    asm = oracle.assemble(plan, leaf)
+    dq, xl, st, it = emu_cascade(plan, asm)
+    assert (st == 0).all()
+    # (the restated eiQuadProg routine, like the reference's own eiQuadProg back-end, gives up on linearly
+    #  dependent equalities -- eiquadprog.hpp:246-251 "FIXME" -- so the comparison is with qpOASES only)
+    if oracle.ref_available():
+        rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
+        assert (rq["status"] == 1).all() and np.abs(dq - rq["dq"]).max() < 1e-6
+    Ceq = asm["C"][:, :6]; e = asm["lo"][:, :6]
+    assert np.abs(np.einsum("brn,bn->br", Ceq, dq) - e).max() < 1e-10
+    for k in (1, 2):   # hierarchy: A_j x_k = A_j x_j
+        for j in range(k):
+            assert np.abs(np.einsum("brn,bn->br", asm["A"][j], xl[:, k] - xl[:, j])).max() < 1e-9

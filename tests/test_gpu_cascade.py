@@ -51,3 +51,22 @@ def test_update_kernel_matches_oracle_assembly(oracle, gpu_device):
     np.testing.assert_array_equal(st.C.cpu().numpy(), asm["C"])
     np.testing.assert_array_equal(st.lo.cpu().numpy(), asm["lo"])
     np.testing.assert_array_equal(st.up.cpu().numpy(), asm["up"])
+
+
+@pytest.mark.parametrize("n,rows,n_eq,n_ineq,dup", [(7, [6], 0, 0, None), (7, [3, 3], 1, 2, None), (20, [5, 6], 4, 6, None),
+                                                     (16, [4, 5], 6, 0, 0)])
+def test_small_generic_cascades_gpu(n, rows, n_eq, n_ineq, dup, oracle, gpu_device):
+    """n < 32 (guarded factor instantiation), Panda-like 7-variable stacks, and a stack whose optimality rows
+    duplicate its global equality rows (coman_ik.cpp:442); vs the oracle, and vs qpOASES when oracle/_ref is there"""
+    plan, leaf = synth.make_generic_stack(64, n, rows, n_eq=n_eq, n_ineq=n_ineq, seed=n, duplicate_eq_in_level=dup)
+    asm = oracle.assemble(plan, leaf)
+    dq, xl, status, it, _ = _run(plan, leaf)
+    assert (status == 0).all()
+    if dup is None:
+        ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+        okr = ref["status"] == 1   # the restated eiQuadProg routine gives up on a few degenerate instances
+        assert okr.mean() > 0.9 and np.abs(dq[okr] - ref["dq"][okr]).max() < 1e-9
+    if oracle.ref_available():
+        rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
+        ok = rq["status"] == 1
+        assert ok.mean() > 0.9 and np.abs(dq[ok] - rq["dq"][ok]).max() < 1e-6
