@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(64, 2) osot_cascade_kernel(const DevPlan P, co
         int iters = 0;
         OSOT_PH_END(PH_HBUILD);
         const int st = gi_solve<NP, PROF, FULLN>(w, nrows, g, diag_h, hdiag, reinterpret_cast<double(&)[16]>(hacc),
-                                          has_box, lb, ub, P.max_iter, x, iters, prof);
+                                                 has_box, lb, ub, P.max_iter, any, x, x, iters, prof);
         if (PROF) ph_t0_ = (long long)clock64();
         iters_total += iters;
         if (st != QP_SOLVED) { status = st; break; }
@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
     wave_sync();
     double x = 0.0;
     int iters = 0;
-    const int st = gi_solve<NP, false, false>(w, Q.nc, g, false, 0.0, Hc, has_box, lb, ub, Q.max_iter, x, iters, nullptr);
+    const int st = gi_solve<NP, false, false>(w, Q.nc, g, false, 0.0, Hc, has_box, lb, ub, Q.max_iter, false, 0.0, x, iters, nullptr);
     if (valid && h == 0) Q.x[inst * n + c] = (st == QP_SOLVED) ? x : 0.0;
     if (lane == 0) {
         Q.status[inst] = st;

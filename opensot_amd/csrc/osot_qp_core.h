@@ -286,6 +286,133 @@ __device__ inline int factor32(const WaveCtx<32>& w, double (&Hc)[16], double g,
     return bad ? QP_NOT_PD : QP_SOLVED;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Null-space elimination of MANY equalities under a DIAGONAL Hessian (NP = 32).
+//
+// The last level of a velocity stack is a Postural task: H = diag(h) and its equalities are the optimality
+// rows of every level above, E x = E x_prev (27 rows in 32 variables at BASELINE config 3), all satisfied by
+// the previous level's solution x_prev.  Adding them one by one costs a rank-1 update of the full 32x32 J
+// each.  Here instead:  (1) Gauss-Jordan with column pivoting brings E (held in registers, lane = column,
+// rows split over the halves) to reduced echelon form -> basic / free columns and Z = [-E_B^-1 E_N ; I];
+// (2) modified Gram-Schmidt in the H metric turns the nf = n - rank columns of Z into J2 (J2' H J2 = I);
+// (3) x = x_prev - J2 J2'(H x_prev + g).  Any H-orthonormal basis of null(E) is a valid J2 for the dual
+// active-set loop that follows, and the equality part of J is never read again.  Work ~ me^2 n / 2 instead of
+// me n^2; linearly dependent (necessarily consistent) rows simply produce no pivot.
+// Returns the rank (= number of equality positions in the working set), or -1 if nf > kNullMax (caller then
+// takes the generic path; nothing has been modified in that case).
+constexpr int kNullMax = 8;
+__device__ inline int nullspace_equalities32(const WaveCtx<32>& w, int n_eq, double hdiag, double g, double xprev,
+                                             double& x_out) {
+    constexpr int S = WaveCtx<32>::S;
+    const int c = w.c, h = w.h, n = w.n;
+    const int lane = c + 32 * h;
+    const bool valid = c < n;
+    double* M2 = w.M2;
+    int* pivcol = reinterpret_cast<int*>(w.V + 3 * 32);   // idle staging vector: pivot column of each row (32 ints)
+    // ---- E -> registers: Er[ii] = E[2ii+h][c] (lane = column, rows split over the halves) ------------------------
+    double Er[16];
+#pragma unroll
+    for (int ii = 0; ii < 16; ++ii) {
+        const int r = 2 * ii + h;
+        Er[ii] = (r < n_eq) ? row_elem<32>(w, w.eqlist[r], c) : 0.0;
+    }
+    double emax = 0.0;
+#pragma unroll
+    for (int ii = 0; ii < 16; ++ii) emax = fmax(emax, fabs(Er[ii]));
+    { double m = -emax; int dummy = lane; colargmin<64>(m, dummy); emax = -bcast(m, 0); }
+    const double tol = 1.0e-9 * emax;
+    // ---- Gauss-Jordan with column pivoting, all in registers.  The pivot column (the 16 values of lane
+    // (pcol, h)) reaches every lane of its half through ds_bpermute (per-lane source index, result in a VGPR:
+    // no SGPR traffic); every register index is a compile-time constant.
+    bool basic = false;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        if (k < n_eq) {
+            const int hk = k & 1, rk = k >> 1;
+            const double v = from_half<32>(Er[rk], hk);           // row k at my column, in both halves
+            double cand = (valid && !basic) ? -fabs(v) : 1.0;
+            int pc = c;
+            colargmin<32>(cand, pc);
+            const int pcol = uniform_i(pc);
+            const double pmax = -bcast(cand, 0);
+            int pk = -1;
+            if (pmax > tol) {
+                pk = pcol;
+                const double rowk = v * fast_rcp(bcast(v, pcol));
+                const int src = pcol + 32 * h;
+                double f[16];
+#pragma unroll
+                for (int ii = 0; ii < 16; ++ii) f[ii] = __shfl(Er[ii], src, 64);
+#pragma unroll
+                for (int ii = 0; ii < 16; ++ii) {
+                    const bool is_k = (ii == rk) && (h == hk);
+                    Er[ii] = is_k ? rowk : fma(-f[ii], rowk, Er[ii]);
+                }
+                if (c == pcol) basic = true;
+            } else {
+                if (h == hk) Er[rk] = 0.0;   // dependent row (consistent: x_prev satisfies every row)
+            }
+            if (lane == 0) pivcol[k] = pk;
+            sched_fence();
+        }
+    }
+    wave_sync();
+    const unsigned long long fmask = wave_ballot(valid && !basic && h == 0);
+    const int nf = __builtin_popcountll(fmask);
+    if (nf > kNullMax) return -1;
+    const bool is_free = valid && !basic;
+    const int t = __builtin_popcountll(fmask & ((1ull << c) - 1ull));   // index of my column among the free ones
+    const int me = n - nf;
+    // ---- Z' rows into M2[me + t][:] ------------------------------------------------------------------------
+    for (int e = lane; e < 32 * S; e += 64) M2[e] = 0.0;
+    wave_sync();
+#pragma unroll
+    for (int ii = 0; ii < 16; ++ii) {
+        const int r = 2 * ii + h;
+        if (r < n_eq) {
+            const int pk = pivcol[r];
+            if (is_free && pk >= 0) M2[(me + t) * S + pk] = -Er[ii];
+        }
+    }
+    if (is_free && h == 0) M2[(me + t) * S + c] = 1.0;
+    wave_sync();
+    // ---- modified Gram-Schmidt in the H metric: rows me.. of M2 become J2' -------------------------------
+    const double hc = valid ? hdiag : 0.0;
+    double zr[kNullMax];
+#pragma unroll
+    for (int s = 0; s < kNullMax; ++s) zr[s] = (s < nf) ? M2[(me + s) * S + c] : 0.0;
+#pragma unroll
+    for (int s = 0; s < kNullMax; ++s) {
+        if (s < nf) {
+#pragma unroll
+            for (int q = 0; q < s; ++q) {
+                const double rq = colsum<32>(hc * zr[q] * zr[s]);
+                zr[s] = fma(-rq, zr[q], zr[s]);
+            }
+            const double nn = colsum<32>(hc * zr[s] * zr[s]);
+            double sq, rs;
+            fast_sqrt_rsqrt(nn, sq, rs);
+            zr[s] *= rs;
+            if (h == 0) M2[(me + s) * S + c] = zr[s];
+        }
+    }
+    // ---- x = x_prev - J2 J2' (H x_prev + g) -----------------------------------------------------------------
+    const double grad = valid ? fma(hc, xprev, g) : 0.0;
+    double x = valid ? xprev : 0.0;
+#pragma unroll
+    for (int s = 0; s < kNullMax; s += 2) {
+        if (s < nf) {
+            double d0, d1;
+            colsum2<32>(zr[s] * grad, (s + 1 < kNullMax) ? zr[s + 1] * grad : 0.0, d0, d1);
+            x = fma(-d0, zr[s], x);
+            if (s + 1 < kNullMax) x = fma(-d1, zr[s + 1], x);
+        }
+    }
+    wave_sync();
+    x_out = x;
+    return me;
+}
+
 // phase cycle counters of the profiling instantiation (PROF = true): indices into prof[]
 enum { PH_HBUILD = 0, PH_CHOL = 1, PH_INV = 2, PH_SUBST = 3, PH_EQ = 4, PH_INEQ = 5, PH_OPT = 6, PH_TOTAL = 7,
        PH_EQ_D = 8, PH_EQ_RED = 9, PH_EQ_Z = 10, PH_EQ_HH = 11, PH_COUNT = 12 };
@@ -296,15 +423,15 @@ enum { PH_HBUILD = 0, PH_CHOL = 1, PH_INV = 2, PH_SUBST = 3, PH_EQ = 4, PH_INEQ 
 
 template <int NP, bool PROF>
 __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq, const int me, int Aq, double uq,
-                               int iters, bool has_box, double lb, double ub, int max_iter, double& x_out,
-                               int& iters_out, long long* prof);
+                               int iters, bool has_box, double lb, double ub, int max_iter, bool diag_dd, double hinv,
+                               double& x_out, int& iters_out, long long* prof);
 
 // Pre (general H):  NP = 64: M1 holds H + eps I (lower triangle used);
 //                    NP = 32: Hc[ii] = (H + eps I)[2ii+h][c] in registers (see factor32), M1 is scratch.
 template <int NP, bool PROF, bool FULLN>
 __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_h,
                         double hdiag, double (&Hc)[16], bool has_box, double lb, double ub, int max_iter,
-                        double& x_out, int& iters_out, long long* prof) {
+                        bool have_prev, double xprev, double& x_out, int& iters_out, long long* prof) {
     constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
     const int n = w_in.n;
     double* M1 = w_in.M1;
@@ -428,6 +555,13 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
         n_eq += __builtin_popcountll(mask);
     }
     wave_sync();
+    // many equalities under a diagonal Hessian, all satisfied by the previous level's solution: null-space
+    // elimination instead of n_eq Householder updates of the full J (see nullspace_equalities32)
+    bool used_nullspace = false;
+    if (NP == 32 && diag_h && have_prev && n_eq >= 8 && n_eq <= 32 && n - n_eq <= kNullMax) {
+        const int r_ns = nullspace_equalities32(reinterpret_cast<const WaveCtx<32>&>(w), n_eq, hdiag, g, xprev, x);
+        if (r_ns >= 0) { iq = r_ns; iters += n_eq; used_nullspace = true; n_eq = 0; }
+    }
     double a_next = (n_eq > 0) ? row_elem<NP>(w, w.eqlist[0], c) : 0.0;
     for (int e = 0; e < n_eq; ++e) {
         const int r = w.eqlist[e];
@@ -469,13 +603,17 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
     // ---- inequality loop -----------------------------------------------------------------------------
     WaveCtx<NP> w3 = w_in;
     { const int l3 = launder_i(w_in.c + NP * w_in.h); w3.c = l3 % NP; w3.h = l3 / NP; }
-    return gi_inequalities<NP, PROF>(w3, nrows, x, iq, me, Aq, uq, iters, has_box, lb, ub, max_iter, x_out, iters_out, prof);
+    // after the null-space path the equality rows of J are zero, so |J'n|^2 no longer measures n'H^-1 n;
+    // the diagonal of H^-1 does (hinv > 0 selects that in the dependency test)
+    const double hinv = (used_nullspace && valid) ? fast_rcp(hdiag) : 0.0;
+    return gi_inequalities<NP, PROF>(w3, nrows, x, iq, me, Aq, uq, iters, has_box, lb, ub, max_iter, used_nullspace, hinv,
+                                     x_out, iters_out, prof);
 }
 
 template <int NP, bool PROF>
 __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq, const int me, int Aq, double uq,
-                               int iters, bool has_box, double lb, double ub, int max_iter, double& x_out,
-                               int& iters_out, long long* prof) {
+                               int iters, bool has_box, double lb, double ub, int max_iter, bool diag_dd, double hinv,
+                               double& x_out, int& iters_out, long long* prof) {
     constexpr int S = WaveCtx<NP>::S;
     const int c = w.c, h = w.h, n = w.n;
     const bool valid = c < n;
@@ -602,8 +740,13 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                 d = jt_rows_dot<NP>(w, V0);
             }
             const double d2 = (c >= iq) ? d : 0.0;
-            const double dd = colsum<NP>(d * d);
-            const double nd2 = colsum<NP>(d2 * d2);
+            double dd, nd2;
+            if (diag_dd) {   // n' H^-1 n from the diagonal of H^-1
+                nd2 = colsum<NP>(d2 * d2);
+                dd = ip_box ? bcast(hinv, ip_var) : (ip_unit ? bcast(hinv, ip_uidx) : colsum<NP>(np * np * hinv));
+            } else {
+                colsum2<NP>(d * d, d2 * d2, dd, nd2);
+            }
             const bool z_ok = nd2 > kDepTol2 * dd;
             // z = J2 d2 : primal step direction
             if (h == 0) V1[c] = d2;
