@@ -65,7 +65,7 @@ struct DevBatch {
 // (lo = up = A_j x_j, iHQP.cpp:164-170; an inactive level contributes 0*x in [-1,1], iHQP.cpp:301-309).
 // FULLN: n == NP (no per-step guards in the factorisation)
 template <int NP, bool PROF, bool FULLN>
-__global__ void __launch_bounds__(64, 2) osot_cascade_kernel(const DevPlan P, const DevBatch D) {
+__global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(const DevPlan P, const DevBatch D) {
     OSOT_DYNAMIC_LDS(osot_smem);
     constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
     const int lane = threadIdx.x;

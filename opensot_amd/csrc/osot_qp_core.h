@@ -682,20 +682,23 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                 }
             }
         }
-        // stored inequality rows, two at a time: both HBM/L2 row reads are in flight together and one paired
-        // reduction network serves the two a'x
-        for (int g0 = 0; g0 < n_gen; g0 += 2) {
-            const int r0_ = w.eqlist[g0];
-            const int r1_ = (g0 + 1 < n_gen) ? w.eqlist[g0 + 1] : -1;
-            const double p0_ = row_elem<NP>(w, r0_, c) * x;
-            const double p1_ = (r1_ >= 0) ? row_elem<NP>(w, r1_, c) * x : 0.0;
-            double ax0, ax1;
-            colsum2<NP>(p0_, p1_, ax0, ax1);
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int r = u ? r1_ : r0_;
-                if (r < 0) continue;
-                const double ax = u ? ax1 : ax0;
+        // stored inequality rows, lane = row, 64 rows at a time: each lane walks its own row against the staged
+        // x (no cross-lane reduction at all).  Consecutive elements of a row share a cache line, so after the
+        // first touch the walk is served from the CU's vector L1.
+        for (int g0 = 0; g0 < n_gen; g0 += 64) {
+            const int gi = g0 + c + NP * h;
+            if (gi < n_gen) {
+                const int r = w.eqlist[gi];
+                const auto* row = OSOT_GLOBAL_F64(w.rptr[r]);
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                int cc = 0;
+                for (; cc + 4 <= n; cc += 4) {
+                    const double e0 = row[cc], e1 = row[cc + 1], e2 = row[cc + 2], e3 = row[cc + 3];
+                    a0 = fma(e0, V0[cc], a0); a1 = fma(e1, V0[cc + 1], a1);
+                    a2 = fma(e2, V0[cc + 2], a2); a3 = fma(e3, V0[cc + 3], a3);
+                }
+                for (; cc < n; ++cc) a0 = fma(row[cc], V0[cc], a0);
+                const double ax = (a0 + a1) + (a2 + a3);
                 const int st = w.rowstate[r];
                 const double lo = w.rlo[r], up = w.rup[r];
                 if (st != 1 && lo > -kInfty) {
