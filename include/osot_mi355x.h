@@ -240,8 +240,10 @@ int osot_solver_set_timing(osot_solver* s, int enabled);
 /* diagnostic: run the cascade once through the instrumented instantiation of the kernel and write, per
  * instance, OSOT_N_PHASES shader-clock cycle counts (H/g build, Cholesky, L^-1, substitution, equality
  * phase, inequality loop, optimality rhs, total, then four sub-phases of the equality adds: J'a,
- * reductions, step direction, Householder update) to cycles[B][OSOT_N_PHASES] (device, int64). */
-#define OSOT_N_PHASES 12
+ * reductions, step direction, Householder update; and six of the inequality loop: violation scan, d = J'n,
+ * step direction z, dual direction r + step lengths, Householder add, drop) to cycles[B][OSOT_N_PHASES]
+ * (device, int64). */
+#define OSOT_N_PHASES 18
 int osot_solver_profile_phases(osot_solver* s, const osot_qp_batch* batch, long long* cycles, void* hip_stream);
 
 /* ---- batch-of-one BackEnd surface (host pointers; mirrors BackEnd.h) ------------------------ */

@@ -188,8 +188,8 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
 #pragma unroll
             for (int ii = 0; ii < NP / HV; ++ii) {
                 const int i = ii * HV + h;
-                hacc[ii] += ((i == c && valid) ? P.eps_abs : 0.0);
-                if (NP == 64) w.M1[i * S + c] = hacc[ii];   // NP = 32 factorises straight from registers
+                // factorised straight from these registers; unit diagonal beyond n (see factor_rows64)
+                hacc[ii] += (i == c) ? (valid ? P.eps_abs : 1.0) : 0.0;
             }
             wave_sync();
         } else if (valid) {   // level = one Postural block [I_m 0]: H = blockdiag(W, 0) + eps I is diagonal
@@ -203,8 +203,14 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
         const int nrows = P.nc + P.optoff[k];
         int iters = 0;
         OSOT_PH_END(PH_HBUILD);
-        const int st = gi_solve<NP, PROF, FULLN>(w, nrows, g, diag_h, hdiag, reinterpret_cast<double(&)[16]>(hacc),
-                                                 has_box, lb, ub, P.max_iter, any, x, x, iters, prof);
+        int st;
+        if (NP == 64) {   // must be inlined: hacc would otherwise be passed through scratch memory
+            OSOT_ALWAYS_INLINE_CALL st = gi_solve<NP, PROF, FULLN>(w, nrows, g, diag_h, hdiag, hacc,
+                                                                   has_box, lb, ub, P.max_iter, any, x, x, iters, prof);
+        } else {          // NP = 32: the inliner's own order keeps the kernel free of vector spills
+            st = gi_solve<NP, PROF, FULLN>(w, nrows, g, diag_h, hdiag, hacc,
+                                           has_box, lb, ub, P.max_iter, any, x, x, iters, prof);
+        }
         if (PROF) ph_t0_ = (long long)clock64();
         iters_total += iters;
         if (st != QP_SOLVED) { status = st; break; }
@@ -281,16 +287,13 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
     const bool valid = c < n;
     for (int e = lane; e < 2 * NP * S + 4 * NP; e += 64) base[e] = 0.0;
     wave_sync();
-    double Hc[16];
-    if (NP == 32) {
+    constexpr int HV = WaveCtx<NP>::HV;
+    double Hc[NP / HV];
 #pragma unroll
-        for (int ii = 0; ii < 16; ++ii) {
-            const int i = 2 * ii + h;
-            Hc[ii] = (valid && i < n) ? Q.H[(inst * n + i) * n + c] + ((i == c) ? Q.eps_abs : 0.0) : 0.0;
-        }
-    } else if (valid && h == 0) {
-        const double* H = Q.H + inst * n * n;
-        for (int i = 0; i < n; ++i) w.M1[i * S + c] = H[i * n + c] + ((i == c) ? Q.eps_abs : 0.0);
+    for (int ii = 0; ii < NP / HV; ++ii) {
+        const int i = HV * ii + h;
+        Hc[ii] = (valid && i < n) ? Q.H[(inst * n + i) * n + c] + ((i == c) ? Q.eps_abs : 0.0)
+                                  : ((i == c) ? 1.0 : 0.0);   // unit diagonal beyond n (see factor_rows64)
     }
     wave_sync();
     const double g = valid ? Q.g[inst * n + c] : 0.0;
@@ -306,7 +309,12 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
     wave_sync();
     double x = 0.0;
     int iters = 0;
-    const int st = gi_solve<NP, false, false>(w, Q.nc, g, false, 0.0, Hc, has_box, lb, ub, Q.max_iter, false, 0.0, x, iters, nullptr);
+    int st;
+    if (NP == 64) {
+        OSOT_ALWAYS_INLINE_CALL st = gi_solve<NP, false, false>(w, Q.nc, g, false, 0.0, Hc, has_box, lb, ub, Q.max_iter, false, 0.0, x, iters, nullptr);
+    } else {
+        st = gi_solve<NP, false, false>(w, Q.nc, g, false, 0.0, Hc, has_box, lb, ub, Q.max_iter, false, 0.0, x, iters, nullptr);
+    }
     if (valid && h == 0) Q.x[inst * n + c] = (st == QP_SOLVED) ? x : 0.0;
     if (lane == 0) {
         Q.status[inst] = st;

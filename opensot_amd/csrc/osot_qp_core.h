@@ -139,20 +139,22 @@ __device__ __forceinline__ void householder_add(const WaveCtx<NP>& w, double d, 
     wave_sync();
     const double wv = z - alpha * w.M2[iq * S + c];   // w = J2 v
     wave_sync();   // both halves have read row iq before half 0 rewrites it
-    // rows j >= iq of JT, split over the halves, four rows per half and trip.  The start is rounded DOWN to
-    // a multiple of the trip size: the extra rows j < iq have V2[j] = 0 (exact no-op) and every access stays
-    // inside the NP rows of M2, so the loop needs no predicates and its LDS reads overlap.
-    constexpr int TRIP = 4 * HV;
-    for (int jj = iq & ~(TRIP - 1); jj < NP; jj += TRIP) {
+    // rows j >= iq of JT, split over the halves, RT rows per half and trip (NP = 64 runs one wave per SIMD:
+    // only loads in flight hide the LDS latency there, and it has the registers for 16).  The start is rounded
+    // DOWN to a multiple of the trip size: the extra rows j < iq have V2[j] = 0 (exact no-op) and every access
+    // stays inside the NP rows of M2, so the loop needs no predicates and its LDS reads overlap.
+    constexpr int RT = (NP == 64) ? 16 : 4;
+    constexpr int TRIP = RT * HV;
+    for (int jj = iq & ~(TRIP - 1); jj < n; jj += TRIP) {
         double* mrow = w.M2 + (jj + h) * S + c;
         const double* vrow = V2 + jj + h;
-        double m[4], vb[4];
+        double m[RT], vb[RT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) m[t] = mrow[t * HV * S];
+        for (int t = 0; t < RT; ++t) m[t] = mrow[t * HV * S];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) vb[t] = vrow[t * HV];
+        for (int t = 0; t < RT; ++t) vb[t] = vrow[t * HV];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) mrow[t * HV * S] = fma(-vb[t], wv, m[t]);
+        for (int t = 0; t < RT; ++t) mrow[t * HV * S] = fma(-vb[t], wv, m[t]);
     }
     if (WRITE_R && h == 0) {
         if (c < iq) w.M1[c * S + iq] = d;
@@ -201,73 +203,80 @@ __device__ __forceinline__ void drop_constraint(const WaveCtx<NP>& w, int qq, in
 }
 
 // The general rows come from the LDS row table in WaveCtx (rlo/rup/rptr, nrows entries).
-// Pre:  general H: M1 holds H + eps I (lower triangle used);  diagonal H (diag_h = true): hdiag is the
-//       lane's diagonal entry h_cc + eps and M1/M2 contents are ignored.
-// Post: returns status, x is lane-distributed (replicated over the halves).
-// Fused right-looking Cholesky + inverse + forward substitution for NP = 32, matrix held in REGISTERS.
-// In : Hc[ii] = (H + eps I)[2ii+h][c]  (lane (c,h) owns column c, rows of its parity), g.
+// Fused right-looking Cholesky + inverse + forward substitution, matrix held in REGISTERS.
+// In : Hc[ii] = (H + eps I)[HV*ii+h][c]  (lane (c,h) owns column c, rows i = h mod HV), g.
 // Out: M1 = L (lower triangular, zeros above), M2 = JT = L^-1, x = -(H + eps I)^-1 g, all by lane c.
 // The trailing matrix of a right-looking Cholesky stays symmetric, so the normalised column j
 // (l_ij over i) IS the lane-distributed vector Hc[j>>1] of half (j&1): no transposition is needed; one
 // LDS column write + immediate-offset reads broadcast it.  L^-1 is built in the same sweep
 // (Linv[i][:] -= l_ij * Linv[j][:]) and so is the forward substitution L y = -g; only the backward
 // substitution L'x = y runs afterwards.  Every register index is a compile-time constant.
-// FULL = (n == 32): no per-step guards.
-template <bool FULL>
-__device__ inline int factor32(const WaveCtx<32>& w, double (&Hc)[16], double g, double& x_out) {
-    constexpr int S = WaveCtx<32>::S;
+// FULL = (n == NP): no per-step guards.  NP = 32: two lanes per column (rows of each parity), 16 registers per
+// array; NP = 64: one lane per column, 64 registers per array (that kernel is LDS-limited to one wave per SIMD,
+// so the 512-register budget is there to be used).
+template <int NP, bool FULL>
+__device__ inline int factor_regs(const WaveCtx<NP>& w, double (&Hc)[NP / (64 / NP)], double g, double& x_out) {
+    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, NR = NP / HV;
     const int c = w.c, h = w.h, n = w.n;
     const bool valid = FULL || (c < n);
     double* M1 = w.M1;
     double* M2 = w.M2;
-    double Lc[16];
+    double Lc[NR];
 #pragma unroll
-    for (int ii = 0; ii < 16; ++ii) Lc[ii] = (2 * ii + h == c) ? 1.0 : 0.0;
+    for (int ii = 0; ii < NR; ++ii) Lc[ii] = (HV * ii + h == c) ? 1.0 : 0.0;
     double rhs = valid ? -g : 0.0;
     double invd = 0.0;
-    bool bad = false;
-    const double* colbase = M1 + h * S;   // + (2ii*S + j) immediates
+    const double* colbase = M1 + h * S;   // + (HV*ii*S + j) immediates
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
+    for (int j = 0; j < NP; ++j) {
         if (FULL || j < n) {
-            const int hj = j & 1, rj = j >> 1;
-            const double piv = bcast(Hc[rj], j + 32 * hj);
+            const int hj = j % HV, rj = j / HV;
+            const double piv = bcast(Hc[rj], j + (HV == 2 ? 32 * hj : 0));   // lane (c = j, h = hj)
             if (!(piv > 0.0)) { x_out = 0.0; return QP_NOT_PD; }
             double sq, rs;
             fast_sqrt_rsqrt(piv, sq, rs);
-            const double hjc = from_half<32>(Hc[rj], hj);              // H[j][c] = H[c][j]
+            const double hjc = from_half<NP>(Hc[rj], hj);              // H[j][c] = H[c][j]
             const double lcj = (valid && c >= j) ? ((c == j) ? sq : hjc * rs) : 0.0;
             if (h == 0) M1[c * S + j] = lcj;
             if (c == j) invd = rs;
             const double yj = bcast(rhs, j) * rs;                       // forward substitution
             rhs = (c == j) ? yj : fma(-lcj, yj, rhs);
-            const double linv_jc = from_half<32>(Lc[rj], hj) * rs;      // row j of L^-1 is final
+            const double linv_jc = from_half<NP>(Lc[rj], hj) * rs;      // row j of L^-1 is final
             if (h == hj) Lc[rj] = linv_jc;
             wave_sync();
-            // trailing update: all column-j values this lane needs are read first (one LDS round trip)
-            double li[16];
+            // trailing update: the column-j values this lane needs are read in chunks of 16 (one LDS round trip each)
 #pragma unroll
-            for (int ii = rj; ii < 16; ++ii) li[ii] = colbase[2 * ii * S + j];
-            if ((j & 1) == 0) {   // i = j + 1 lives in half 1 only (i = j itself is finished)
-                const double l0 = (h == 1) ? li[rj] : 0.0;
-                Hc[rj] = fma(-l0, lcj, Hc[rj]);
-                Lc[rj] = fma(-l0, linv_jc, Lc[rj]);
-            }
+            for (int q = 0; q < (NR + 15) / 16; ++q) {   // constant bounds: every predicate folds after unrolling
+                if (16 * q + 15 >= rj) {
+                    double li[16];
 #pragma unroll
-            for (int ii = rj + 1; ii < 16; ++ii) {
-                Hc[ii] = fma(-li[ii], lcj, Hc[ii]);
-                Lc[ii] = fma(-li[ii], linv_jc, Lc[ii]);
+                    for (int t = 0; t < 16; ++t) if (16 * q + t >= rj && 16 * q + t < NR) li[t] = colbase[HV * (16 * q + t) * S + j];
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const int ii = 16 * q + t;
+                        if (ii == rj) {
+                            if (HV == 2 && hj == 0) {   // row j + 1 lives in half 1 only (row j itself is finished)
+                                const double l0 = (h == 1) ? li[t] : 0.0;
+                                Hc[rj] = fma(-l0, lcj, Hc[rj]);
+                                Lc[rj] = fma(-l0, linv_jc, Lc[rj]);
+                            }
+                        } else if (ii > rj && ii < NR) {
+                            Hc[ii] = fma(-li[t], lcj, Hc[ii]);
+                            Lc[ii] = fma(-li[t], linv_jc, Lc[ii]);
+                        }
+                    }
+                }
             }
         }
     }
     // JT = L^-1
 #pragma unroll
-    for (int ii = 0; ii < 16; ++ii) M2[(2 * ii + h) * S + c] = Lc[ii];
+    for (int ii = 0; ii < NR; ++ii) M2[(HV * ii + h) * S + c] = Lc[ii];
     // backward substitution L'x = y (rhs holds y); rows of L are fetched eight at a time ahead of the chain
     double x = 0.0;
     const double yinv0 = invd;
 #pragma unroll
-    for (int i0 = 24; i0 >= 0; i0 -= 8) {
+    for (int i0 = NP - 8; i0 >= 0; i0 -= 8) {
         double lrow[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) lrow[t] = M1[(i0 + t) * S + c];   // zero for c > i; lane i itself is done
@@ -282,10 +291,124 @@ __device__ inline int factor32(const WaveCtx<32>& w, double (&Hc)[16], double g,
         }
     }
     wave_sync();
-    x_out = (valid && !bad) ? x : 0.0;
-    return bad ? QP_NOT_PD : QP_SOLVED;
+    x_out = valid ? x : 0.0;
+    return QP_SOLVED;
 }
 
+// NP = 64 (one lane per column, 64 registers per array): a LEFT-looking, row-oriented variant in two passes so
+// that only ONE 64-register array is live at a time (the right-looking sweep above needs H and L^-1 together:
+// 256 VGPRs before any temporaries).  By symmetry lane c's column of H is its ROW c, so
+//   pass 1 (Cholesky, in place):  L[c][j] = (H[c][j] - sum_{k<j} L[c][k] L[j][k]) / L[j][j]
+//     lane c's own row L[c][k] sits in the registers Hc[k] it has already overwritten (static index); row j of
+//     L is complete in LDS after step j-1 and is read with UNIFORM addresses (LDS broadcast, ds_read2_b64);
+//     no reduction: only the pivot is broadcast with v_readlane.  The forward substitution rides along.
+//   pass 2 (inverse by rows):  Linv[i][c] = (delta_ic - sum_{k<i} L[i][k] Linv[k][c]) / L[i][i]
+//     the same shape, no cross-lane step at all (pure ILP, four accumulators per dot product).
+// The row bases are laundered: ds_read2_b64 only has an 8-bit offset field, so without it every pair of reads
+// gets its own constant address, and loop-invariant code motion parks ~900 of them in (spilled) SGPRs.
+// In/Out as factor_regs.  MUST be inlined (Hc would otherwise travel through scratch by reference).
+template <bool FULL>
+__device__ __forceinline__ int factor_rows64(const WaveCtx<64>& w, double (&Hc)[64], double g, double& x_out) {
+    constexpr int NP = 64, S = WaveCtx<64>::S;
+    const int c = w.c, n = w.n;
+    const bool valid = FULL || (c < n);
+    double* M1 = w.M1;
+    double* M2 = w.M2;
+    double rhs = valid ? -g : 0.0;
+    double invd = 0.0;
+    bool bad = false;
+    // Control flow is kept to ONE uniform guard per block of eight columns and no early exit (a guard or an
+    // exit per column gives the register allocator 64 join points and ~3000 spills): the caller pads H with
+    // a unit diagonal beyond n, so the columns n .. roundup8(n)-1 factorise to the identity.
+#pragma unroll
+    for (int j0 = 0; j0 < NP; j0 += 8) {
+        if (FULL || j0 < n) {
+#pragma unroll
+            for (int j = j0; j < j0 + 8; ++j) {
+                double acc[4] = {Hc[j], 0.0, 0.0, 0.0};
+                const double* rowj = M1 + launder_i(j * S);   // opaque base: see the note on LDS addresses
+#pragma unroll
+                for (int q = 0; q < NP / 16; ++q) {
+                    if (16 * q < j) {
+                        double lj[16];
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) if (16 * q + t < j) lj[t] = rowj[16 * q + t];
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) if (16 * q + t < j) acc[t & 3] = fma(-Hc[16 * q + t], lj[t], acc[t & 3]);
+                    }
+                }
+                const double sres = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                double piv = bcast(sres, j);
+                if (!(piv > 0.0)) { bad = true; piv = 1.0; }
+                double sq, rs;
+                fast_sqrt_rsqrt(piv, sq, rs);
+                const double lcj = (c == j) ? sq : ((c > j) ? sres * rs : 0.0);
+                Hc[j] = lcj;
+                M1[c * S + j] = lcj;            // zeros above the diagonal included
+                if (c == j) invd = rs;
+                const double yj = bcast(rhs, j) * rs;                       // forward substitution
+                rhs = (c == j) ? yj : fma(-lcj, yj, rhs);
+                wave_sync();
+            }
+        }
+    }
+    if (bad) { x_out = 0.0; return QP_NOT_PD; }
+    // pass 2: JT = L^-1, row by row; Hc is dead from here on.  1/L[i][i] goes through LDS (64 v_readlane
+    // results would all be hoisted to the top and spill the scalar file); a scheduling fence per row keeps
+    // the row reads from being hoisted wholesale (the rows are independent of everything but Lc).
+    w.V[c] = invd;
+    wave_sync();
+    {
+        double Lc[NP];
+#pragma unroll
+        for (int i0 = 0; i0 < NP; i0 += 8) {
+            if (FULL || i0 < n) {
+#pragma unroll
+                for (int i = i0; i < i0 + 8; ++i) {
+                    double acc[4] = {(i == c) ? 1.0 : 0.0, 0.0, 0.0, 0.0};
+                    const double* rowi = M1 + launder_i(i * S);
+#pragma unroll
+                    for (int q = 0; q < NP / 16; ++q) {
+                        if (16 * q < i) {
+                            double li[16];
+#pragma unroll
+                            for (int t = 0; t < 16; ++t) if (16 * q + t < i) li[t] = rowi[16 * q + t];
+#pragma unroll
+                            for (int t = 0; t < 16; ++t) if (16 * q + t < i) acc[t & 3] = fma(-Lc[16 * q + t], li[t], acc[t & 3]);
+                        }
+                    }
+                    Lc[i] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) * w.V[i];
+                    M2[i * S + c] = Lc[i];
+                    sched_fence();
+                }
+            } else {
+#pragma unroll
+                for (int i = i0; i < i0 + 8; ++i) { Lc[i] = (i == c) ? 1.0 : 0.0; M2[i * S + c] = Lc[i]; }
+            }
+        }
+    }
+    // backward substitution L'x = y (rhs holds y); rows of L are fetched eight at a time ahead of the chain
+    double x = 0.0;
+    const double yinv0 = invd;
+#pragma unroll
+    for (int i0 = NP - 8; i0 >= 0; i0 -= 8) {
+        if (FULL || i0 < n) {   // same block guard as above (the padded rows are identity rows)
+            double lrow[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) lrow[t] = M1[(i0 + t) * S + c];   // zero for c > i; lane i itself is done
+#pragma unroll
+            for (int t = 7; t >= 0; --t) {
+                const int i = i0 + t;
+                const double xi = bcast(rhs * yinv0, i);
+                if (c == i) x = xi;
+                rhs = fma(-lrow[t], xi, rhs);
+            }
+        }
+    }
+    wave_sync();
+    x_out = valid ? x : 0.0;
+    return QP_SOLVED;
+}
 // ---------------------------------------------------------------------------------------------------------
 // Null-space elimination of MANY equalities under a DIAGONAL Hessian (NP = 32).
 //
@@ -415,7 +538,8 @@ __device__ inline int nullspace_equalities32(const WaveCtx<32>& w, int n_eq, dou
 
 // phase cycle counters of the profiling instantiation (PROF = true): indices into prof[]
 enum { PH_HBUILD = 0, PH_CHOL = 1, PH_INV = 2, PH_SUBST = 3, PH_EQ = 4, PH_INEQ = 5, PH_OPT = 6, PH_TOTAL = 7,
-       PH_EQ_D = 8, PH_EQ_RED = 9, PH_EQ_Z = 10, PH_EQ_HH = 11, PH_COUNT = 12 };
+       PH_EQ_D = 8, PH_EQ_RED = 9, PH_EQ_Z = 10, PH_EQ_HH = 11,
+       PH_IN_SCAN = 12, PH_IN_D = 13, PH_IN_Z = 14, PH_IN_R = 15, PH_IN_HH = 16, PH_IN_DROP = 17, PH_COUNT = 18 };
 #define OSOT_SUB_BEGIN() long long sub_t0_ = PROF ? (long long)clock64() : 0
 #define OSOT_SUB_END(idx) do { if (PROF) { const long long t_ = (long long)clock64(); prof[idx] += t_ - sub_t0_; sub_t0_ = t_; } } while (0)
 #define OSOT_PH_BEGIN() long long ph_t0_ = PROF ? (long long)clock64() : 0
@@ -426,11 +550,10 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                                int iters, bool has_box, double lb, double ub, int max_iter, bool diag_dd, double hinv,
                                double& x_out, int& iters_out, long long* prof);
 
-// Pre (general H):  NP = 64: M1 holds H + eps I (lower triangle used);
-//                    NP = 32: Hc[ii] = (H + eps I)[2ii+h][c] in registers (see factor32), M1 is scratch.
+// Pre (general H):  Hc[ii] = (H + eps I)[HV*ii+h][c] in registers (see factor_regs), M1 is scratch.
 template <int NP, bool PROF, bool FULLN>
 __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_h,
-                        double hdiag, double (&Hc)[16], bool has_box, double lb, double ub, int max_iter,
+                        double hdiag, double (&Hc)[NP / (64 / NP)], bool has_box, double lb, double ub, int max_iter,
                         bool have_prev, double xprev, double& x_out, int& iters_out, long long* prof) {
     constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
     const int n = w_in.n;
@@ -461,69 +584,17 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
         x = valid ? -g * rs * rs : 0.0;
         wave_sync();
         OSOT_PH_END(PH_CHOL);
-    } else if (NP == 32) {
-        const WaveCtx<32>& w32 = reinterpret_cast<const WaveCtx<32>&>(w);
-        // exactly ONE factor32 instantiation per kernel (FULLN is a kernel template parameter): both variants
-        // in one kernel push it past 256 VGPRs; each alone fits (249 / 243) without scratch
-        const int st32 = factor32<FULLN>(w32, Hc, g, x);
-        if (st32 != QP_SOLVED) { x_out = 0.0; iters_out = 0; return st32; }
-        OSOT_PH_END(PH_CHOL);
     } else {
-        // ---- Cholesky H + eps I = L L' in place (lane c = row c, k split over the halves) ----------
-        double invd = 0.0;   // lane c: 1 / L[c][c]
-        const double* rowi = M1 + c * S;
-        for (int j = 0; j < n; ++j) {
-            const double* rowj = M1 + j * S;
-            double s = 0.0;
-            const int kk_end = (j + HV - 1) / HV;
-            for (int kk = 0; kk < kk_end; ++kk) {
-                const int k = kk * HV + h;
-                const double a = rowi[k], b = rowj[k];
-                s += (k < j) ? a * b : 0.0;
-            }
-            s = rowi[j] - halfsum<NP>(s);
-            const double piv = bcast(s, j);
-            if (!(piv > 0.0)) { x_out = 0.0; iters_out = 0; return QP_NOT_PD; }
-            double sq, rs;
-            fast_sqrt_rsqrt(piv, sq, rs);
-            if (h == 0 && valid && c >= j) M1[c * S + j] = (c == j) ? sq : s * rs;
-            if (c == j) invd = rs;
-            wave_sync();
-        }
+        // exactly ONE instantiation per kernel (FULLN is a kernel template parameter): both variants in one
+        // kernel push the NP = 32 kernel past 256 VGPRs; each alone fits without scratch
+        int stf;
+        if constexpr (NP == 64) stf = factor_rows64<FULLN>(w, Hc, g, x);
+        else stf = factor_regs<NP, FULLN>(w, Hc, g, x);
+        if (stf != QP_SOLVED) { x_out = 0.0; iters_out = 0; return stf; }
         OSOT_PH_END(PH_CHOL);
-        // ---- JT = L^-1 into M2 (lane c = column c, k split over the halves) -------------------------
-        for (int i = 0; i < n; ++i) {
-            const double* Li = M1 + i * S;
-            double s = 0.0;
-            const int kk_end = (i + HV - 1) / HV;
-            for (int kk = 0; kk < kk_end; ++kk) {
-                const int k = kk * HV + h;
-                const double a = Li[k], b = M2[k * S + c];
-                s += (k < i) ? a * b : 0.0;
-            }
-            s = halfsum<NP>(s);
-            const double y = (((i == c) ? 1.0 : 0.0) - s) * bcast(invd, i);
-            if (h == 0 && valid) M2[i * S + c] = y;
-            wave_sync();
-        }
-        OSOT_PH_END(PH_INV);
-        // ---- unconstrained minimiser: L y = -g, L' x = y by substitution ---------------------------
-        // (NOT x = -J J'g: with H = A'A + eps I rank deficient, g lies in range(A') and the substitution
-        //  keeps the exact cancellation in the eps-pivots that the explicit inverse loses -- the
+        // (the substitution, NOT x = -J J'g: with H = A'A + eps I rank deficient, g lies in range(A') and the
+        //  substitution keeps the exact cancellation in the eps-pivots that the explicit inverse loses -- the
         //  reference's own known-answer test TestQPOases.cpp:274-340 needs it at 1e-6)
-        x = valid ? -g : 0.0;
-        for (int j = 0; j < n; ++j) {
-            const double yj = bcast(x * invd, j);
-            if (c == j) x = yj;
-            else if (valid && c > j) x -= M1[c * S + j] * yj;
-        }
-        for (int j = n - 1; j >= 0; --j) {
-            const double xj = bcast(x * invd, j);
-            if (c == j) x = xj;
-            else if (c < j) x -= M1[j * S + c] * xj;
-        }
-        wave_sync();
-        OSOT_PH_END(PH_SUBST);
     }
 
     }   // end of the factorisation phase
@@ -642,6 +713,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
     int status = QP_SOLVED;
     const int kNone = 0x7fffffff;
     for (;;) {
+        OSOT_SUB_BEGIN();
         // most violated constraint outside the working set (eiquadprog.hpp:300-315 picks the same)
         double cand = 0.0;
         int code = kNone;
@@ -692,12 +764,30 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                 const auto* row = OSOT_GLOBAL_F64(w.rptr[r]);
                 double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
                 int cc = 0;
-                for (; cc + 4 <= n; cc += 4) {
-                    const double e0 = row[cc], e1 = row[cc + 1], e2 = row[cc + 2], e3 = row[cc + 3];
-                    a0 = fma(e0, V0[cc], a0); a1 = fma(e1, V0[cc + 1], a1);
-                    a2 = fma(e2, V0[cc + 2], a2); a3 = fma(e3, V0[cc + 3], a3);
+                // SC loads per trip: the walk is a chain of L1/L2 round trips, only loads in flight shorten it
+                constexpr int SC = (NP == 64) ? 16 : 8;
+                for (; cc + SC <= n; cc += SC) {
+                    double e[SC];
+#pragma unroll
+                    for (int t = 0; t < SC; ++t) e[t] = row[cc + t];
+#pragma unroll
+                    for (int t = 0; t < SC; t += 4) {
+                        a0 = fma(e[t], V0[cc + t], a0); a1 = fma(e[t + 1], V0[cc + t + 1], a1);
+                        a2 = fma(e[t + 2], V0[cc + t + 2], a2); a3 = fma(e[t + 3], V0[cc + t + 3], a3);
+                    }
                 }
-                for (; cc < n; ++cc) a0 = fma(row[cc], V0[cc], a0);
+                if (cc < n) {   // the ragged tail in one more round trip (clamped addresses, masked terms)
+                    double e[SC];
+#pragma unroll
+                    for (int t = 0; t < SC; ++t) e[t] = row[(cc + t < n) ? cc + t : n - 1];
+#pragma unroll
+                    for (int t = 0; t < SC; t += 4) {
+                        a0 = fma((cc + t < n) ? e[t] : 0.0, V0[cc + t], a0);
+                        a1 = fma((cc + t + 1 < n) ? e[t + 1] : 0.0, V0[cc + t + 1], a1);
+                        a2 = fma((cc + t + 2 < n) ? e[t + 2] : 0.0, V0[cc + t + 2], a2);
+                        a3 = fma((cc + t + 3 < n) ? e[t + 3] : 0.0, V0[cc + t + 3], a3);
+                    }
+                }
                 const double ax = (a0 + a1) + (a2 + a3);
                 const int st = w.rowstate[r];
                 const double lo = w.rlo[r], up = w.rup[r];
@@ -713,6 +803,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
         }
         colargmin<64>(cand, code);   // all 64 lanes: the unit-row pass holds different rows in the two halves
         code = uniform_i(code);
+        OSOT_SUB_END(PH_IN_SCAN);
         if (code == kNone) break;   // primal feasible: optimal
         if (++iters > max_iter) { status = QP_MAX_ITER; break; }
 
@@ -751,18 +842,33 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                 colsum2<NP>(d * d, d2 * d2, dd, nd2);
             }
             const bool z_ok = nd2 > kDepTol2 * dd;
+            OSOT_SUB_END(PH_IN_D);
             // z = J2 d2 : primal step direction
             if (h == 0) V1[c] = d2;
             wave_sync();
             const double z = jt_cols_dot<NP>(w, V1);
-            // r = R^-1 d1 restricted to the inequality part [me, iq): dual step direction
+            OSOT_SUB_END(PH_IN_Z);
+            // r = R^-1 d1 restricted to the inequality part [me, iq): dual step direction.  The reciprocals of
+            // the diagonal are formed lane-parallel up front and the columns of R are fetched four steps
+            // ahead, so that a step of the serial chain is readlane -> mul -> fma only.
             double rr = 0.0;
             {
                 double d1 = (c < iq) ? d : 0.0;
-                for (int j = iq - 1; j >= me; --j) {
-                    const double rj = bcast(d1, j) * fast_rcp(M1[j * S + j]);
-                    if (c == j) rr = rj;
-                    if (c >= me && c < j) d1 -= M1[c * S + j] * rj;
+                const double rinv = (c >= me && c < iq) ? fast_rcp(M1[c * S + c]) : 0.0;
+                const double* rcol = M1 + ((c >= me && c < iq) ? c : 0) * S;   // in-range row for idle lanes
+                for (int j0 = iq - 1; j0 >= me; j0 -= 4) {
+                    double rc[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) rc[t] = rcol[(j0 - t >= 0) ? j0 - t : 0];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int j = j0 - t;
+                        if (j >= me) {
+                            const double rj = bcast(d1, j) * bcast(rinv, j);
+                            if (c == j) rr = rj;
+                            if (c >= me && c < j) d1 = fma(-rc[t], rj, d1);
+                        }
+                    }
                 }
             }
             // step lengths (eiquadprog.hpp:343-366)
@@ -772,6 +878,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
             lpos = uniform_i(lpos);
             t1 = bcast(t1, 0);
             const double t2 = z_ok ? (-s_ip * fast_rcp(nd2)) : INFINITY;
+            OSOT_SUB_END(PH_IN_R);
             if (!(t1 < INFINITY) && !(t2 < INFINITY)) {
                 // no primal direction left and no inequality to trade.  If the most violated constraint is
                 // violated only at round-off level (an active inequality of an upper level re-appearing when the
@@ -793,6 +900,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                 else { if (c == 0 && h == 0) w.rowstate[ip_row] = (ip & 1) ? 2 : 1; }
                 iq++;
                 wave_sync();
+                OSOT_SUB_END(PH_IN_HH);
                 break;
             }
             // partial step (or pure dual step when z == 0): drop the blocking constraint
@@ -811,6 +919,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                     s_ip = bcast(s_ip, 0);
                 }
             }
+            OSOT_SUB_END(PH_IN_DROP);
             if (++iters > max_iter) { status = QP_MAX_ITER; failed = true; break; }
         }
         if (failed) { if (status == QP_SOLVED) status = QP_INFEASIBLE; break; }

@@ -17,6 +17,8 @@
 // LDS declarations (the emulation in tests/emu maps these onto host memory)
 #define OSOT_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define OSOT_STATIC_LDS(type, name, count) __shared__ type name[count]
+// call-site inlining (statement attribute): used where ONE instantiation of a template must be inlined
+#define OSOT_ALWAYS_INLINE_CALL [[clang::always_inline]]
 // a 64-bit integer that holds an HBM address -> pointer in the global address space (global_load, not flat_load)
 #define OSOT_GLOBAL_F64(addr) (reinterpret_cast<const __attribute__((address_space(1))) double*>(addr))
 

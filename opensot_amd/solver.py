@@ -156,10 +156,11 @@ class BatchedStack:
         abi.check(self._lib.osot_ihqp_solve(self._h, C.byref(qb), _stream_ptr(self.device)), "osot_ihqp_solve")
 
     PHASES = ("hbuild", "chol", "inverse", "subst", "equalities", "inequalities", "opt_rhs", "total",
-              "eq:J'a", "eq:reductions", "eq:z", "eq:householder")
+              "eq:J'a", "eq:reductions", "eq:z", "eq:householder",
+              "in:scan", "in:d=J'n", "in:z", "in:r,steps", "in:householder", "in:drop")
 
     def profile_phases(self, B):
-        """diagnostic: per-instance shader-clock cycles per phase, [B][8] (see PHASES)."""
+        """diagnostic: per-instance shader-clock cycles per phase, [B][OSOT_N_PHASES] (see PHASES)."""
         cyc = torch.zeros((B, len(self.PHASES)), dtype=torch.int64, device=self.device)
         qb = self._qp_batch(B)
         abi.check(self._lib.osot_solver_profile_phases(self._h, C.byref(qb), _dev_ptr(cyc), _stream_ptr(self.device)),
