@@ -144,11 +144,69 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
         const bool diag_h = (ma == 0);
         double hacc[NP / HV];
         if (!diag_h) {
+          if constexpr (NP == 32) {
+            // ---- H = A'WA + eps I on the fp64 MATRIX CORE, g = -A'Wb + c.  Four rows of A per step: lane
+            // l = (a, q) = (l & 15, l >> 4) loads A[r0 + q][a] and A[r0 + q][16 + a] (two coalesced loads cover the
+            // four rows); those two registers ARE the MFMA operands of every 16 x 16 tile of the outer product
+            // (A-operand m = column-in-tile, k = row; B-operand likewise), so no LDS broadcast and no VALU FMA
+            // is spent on the 32 x 32 x m product.  Tile (I, C) element r of lane l is H[16 I + q + 4 r][16 C + a].
+            const int ta = lane & 15, tq = lane >> 4;
+            v4f64 Ht[2][2];
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int C2 = 0; C2 < 2; ++C2) Ht[I][C2] = v4f64{0.0, 0.0, 0.0, 0.0};
+            double gp0 = 0.0, gp1 = 0.0;
+            for (int r0 = 0; r0 < ma; r0 += 4) {
+                const int r = r0 + tq;
+                const bool in = r < ma;
+                const int rr = in ? r : ma - 1;
+                const double a0 = (in && ta < n) ? Ak[rr * n + ta] : 0.0;
+                const double a1 = (in && 16 + ta < n) ? Ak[rr * n + ((16 + ta < n) ? 16 + ta : 0)] : 0.0;
+                const double wr = in ? (wk ? wk[rr] : 1.0) : 0.0;
+                const double br = bk[rr];
+                const double wa0 = wr * a0, wa1 = wr * a1;
+                gp0 = fma(-wa0, br, gp0);
+                gp1 = fma(-wa1, br, gp1);
+                Ht[0][0] = mfma_f64_16x16x4(wa0, a0, Ht[0][0]);
+                Ht[0][1] = mfma_f64_16x16x4(wa0, a1, Ht[0][1]);
+                Ht[1][0] = mfma_f64_16x16x4(wa1, a0, Ht[1][0]);
+                Ht[1][1] = mfma_f64_16x16x4(wa1, a1, Ht[1][1]);
+            }
+            // g: the partial sums of a column sit in the four rows of 16 lanes
+            gp0 = rowgroup_sum(gp0);
+            gp1 = rowgroup_sum(gp1);
+            g = valid ? ((tq & 1) ? gp1 : gp0) : 0.0;
+            const int npost = m - ma;   // Postural block appended to the level: A = [I 0] (Postural.cpp:37)
+            if (npost > 0 && c < npost) g -= (wk ? wk[ma + c] : 1.0) * bk[ma + c];
+            // diagonal: Postural weights, eps I, unit diagonal beyond n (see factor_rows64 for the padding)
+#pragma unroll
+            for (int I = 0; I < 2; ++I) {
+                const int i = 16 * I + ta;    // diagonal element (i, i) lives in tile (I, I) where a == q + 4 r
+                double dv = (i < n) ? P.eps_abs : 1.0;
+                if (i < npost) dv += wk ? wk[ma + i] : 1.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ht[I][I][r] += (ta == tq + 4 * r) ? dv : 0.0;
+            }
+            // (stage 1) hand the tiles to the register layout of the factorisation through LDS
+            wave_sync();
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int C2 = 0; C2 < 2; ++C2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) w.M1[(16 * I + tq + 4 * r) * S + 16 * C2 + ta] = Ht[I][C2][r];
+            wave_sync();
+#pragma unroll
+            for (int ii = 0; ii < NP / HV; ++ii) hacc[ii] = w.M1[(ii * HV + h) * S + c];
+            wave_sync();
+          } else {
             // ---- H = A'WA + eps I, g = -A'Wb + c.  Lane (c,h) accumulates H[i][c] for i = ii*HV + h in
             // registers; stored rows are staged four at a time through LDS for the broadcasts.
 #pragma unroll
             for (int ii = 0; ii < NP / HV; ++ii) hacc[ii] = 0.0;
             for (int r0 = 0; r0 < ma; r0 += 4) {
+                OSOT_SUB_BEGIN();
                 double a[4], wa[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -160,6 +218,7 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
                     g -= wa[u] * (in ? bk[r] : 0.0);
                 }
                 wave_sync();   // the previous group's broadcasts are done
+                OSOT_SUB_END(PH_INV);     // (profiling slot reused: wait for the rows)
                 if (h == 0) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) w.V[u * NP + c] = a[u];
@@ -177,6 +236,7 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
                         for (int t = 0; t < 16; ++t) hacc[i0 + t] = fma(wa[u], vv[t], hacc[i0 + t]);
                     }
                 }
+                OSOT_SUB_END(PH_SUBST);   // (profiling slot reused: LDS broadcast + outer product)
             }
             if (m > ma && c < m - ma) {   // Postural block appended to the level: A = [I 0] (Postural.cpp:37)
                 const double wi = wk ? wk[ma + c] : 1.0;
@@ -192,6 +252,7 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
                 hacc[ii] += (i == c) ? (valid ? P.eps_abs : 1.0) : 0.0;
             }
             wave_sync();
+          }
         } else if (valid) {   // level = one Postural block [I_m 0]: H = blockdiag(W, 0) + eps I is diagonal
             const bool inb = c < m;
             const double wi = inb ? (wk ? wk[c] : 1.0) : 0.0;

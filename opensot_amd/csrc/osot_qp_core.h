@@ -211,71 +211,103 @@ __device__ __forceinline__ void drop_constraint(const WaveCtx<NP>& w, int qq, in
 // LDS column write + immediate-offset reads broadcast it.  L^-1 is built in the same sweep
 // (Linv[i][:] -= l_ij * Linv[j][:]) and so is the forward substitution L y = -g; only the backward
 // substitution L'x = y runs afterwards.  Every register index is a compile-time constant.
-// FULL = (n == NP): no per-step guards.  NP = 32: two lanes per column (rows of each parity), 16 registers per
-// array; NP = 64: one lane per column, 64 registers per array (that kernel is LDS-limited to one wave per SIMD,
-// so the 512-register budget is there to be used).
-template <int NP, bool FULL>
-__device__ inline int factor_regs(const WaveCtx<NP>& w, double (&Hc)[NP / (64 / NP)], double g, double& x_out) {
-    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, NR = NP / HV;
+// The sweep is a LOOP over pairs of columns with ROTATING registers: after the steps j = 2r and 2r+1 the
+// sixteen registers of Hc and Lc shift down by one, so the current pair of rows always sits in register 0 and
+// every register index in the body is a compile-time constant.  A fully unrolled sweep is ~32 KB of
+// straight-line code per instantiation; together with the rest of the kernel that overflows the 64 KB
+// instruction cache two CUs share, and a wave streaming cold code runs at ~1 instruction per 6 cycles
+// (tools/ubench_latency.hip: 480 -> 720 cycles per step).  The loop body is ~2 KB.  The price: the trailing
+// update runs over all sixteen registers at every step (no triangular saving) plus 30 v_mov_b64 per pair.
+// Registers shifted in at the top are zero; they stand for rows >= 32, read whatever lies behind M1 in LDS
+// and are never used.  Non-positive pivots set a sticky flag (no exit inside the sweep).
+__device__ inline int factor_loop32(const WaveCtx<32>& w, double (&Hc)[16], double g, double& x_out) {
+    constexpr int NP = 32, S = WaveCtx<32>::S, NR = 16;
     const int c = w.c, h = w.h, n = w.n;
-    const bool valid = FULL || (c < n);
+    const bool valid = c < n;
     double* M1 = w.M1;
     double* M2 = w.M2;
     double Lc[NR];
 #pragma unroll
-    for (int ii = 0; ii < NR; ++ii) Lc[ii] = (HV * ii + h == c) ? 1.0 : 0.0;
+    for (int ii = 0; ii < NR; ++ii) Lc[ii] = (2 * ii + h == c) ? 1.0 : 0.0;
     double rhs = valid ? -g : 0.0;
     double invd = 0.0;
-    const double* colbase = M1 + h * S;   // + (HV*ii*S + j) immediates
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        if (FULL || j < n) {
-            const int hj = j % HV, rj = j / HV;
-            const double piv = bcast(Hc[rj], j + (HV == 2 ? 32 * hj : 0));   // lane (c = j, h = hj)
-            if (!(piv > 0.0)) { x_out = 0.0; return QP_NOT_PD; }
+    bool bad = false;
+    const int npairs = (n + 1) >> 1;
+    const double* colp = M1 + h * S;      // slot k at pair r reads colp[2 (k + r) S + j]: row 2 (k + r) + h of column j
+    double* wr = M1 + c * S;              // lane c writes its element of columns 2 r, 2 r + 1 to wr[0], wr[1]
+    double* m2p = M2 + h * S + c;         // finished row 2 r + h of L^-1 goes to m2p[2 r S]
+    for (int r = 0; r < npairs; ++r) {
+        // ---------------- even step j = 2 r: row j is register 0 of half 0, row j + 1 register 0 of half 1
+        {
+            const int j = 2 * r;
+            double piv = bcast(Hc[0], j);   // lane (c = j, h = 0)
+            if (!(piv > 0.0)) { bad = true; piv = 1.0; }
             double sq, rs;
             fast_sqrt_rsqrt(piv, sq, rs);
-            const double hjc = from_half<NP>(Hc[rj], hj);              // H[j][c] = H[c][j]
+            const double hjc = from_half<NP>(Hc[0], 0);               // H[j][c] = H[c][j]
             const double lcj = (valid && c >= j) ? ((c == j) ? sq : hjc * rs) : 0.0;
-            if (h == 0) M1[c * S + j] = lcj;
+            if (h == 0) wr[0] = lcj;
             if (c == j) invd = rs;
-            const double yj = bcast(rhs, j) * rs;                       // forward substitution
+            const double yj = bcast(rhs, j) * rs;                      // forward substitution
             rhs = (c == j) ? yj : fma(-lcj, yj, rhs);
-            const double linv_jc = from_half<NP>(Lc[rj], hj) * rs;      // row j of L^-1 is final
-            if (h == hj) Lc[rj] = linv_jc;
+            const double linv_jc = from_half<NP>(Lc[0], 0) * rs;       // row j of L^-1 is final
+            if (h == 0) Lc[0] = linv_jc;
             wave_sync();
-            // trailing update: the column-j values this lane needs are read in chunks of 16 (one LDS round trip each)
+            double li[NR];
 #pragma unroll
-            for (int q = 0; q < (NR + 15) / 16; ++q) {   // constant bounds: every predicate folds after unrolling
-                if (16 * q + 15 >= rj) {
-                    double li[16];
+            for (int k = 0; k < NR; ++k) li[k] = colp[2 * k * S];
+            {   // row j + 1 lives in half 1 of register 0 (row j itself is finished)
+                const double l0 = (h == 1) ? li[0] : 0.0;
+                Hc[0] = fma(-l0, lcj, Hc[0]);
+                Lc[0] = fma(-l0, linv_jc, Lc[0]);
+            }
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) if (16 * q + t >= rj && 16 * q + t < NR) li[t] = colbase[HV * (16 * q + t) * S + j];
-#pragma unroll
-                    for (int t = 0; t < 16; ++t) {
-                        const int ii = 16 * q + t;
-                        if (ii == rj) {
-                            if (HV == 2 && hj == 0) {   // row j + 1 lives in half 1 only (row j itself is finished)
-                                const double l0 = (h == 1) ? li[t] : 0.0;
-                                Hc[rj] = fma(-l0, lcj, Hc[rj]);
-                                Lc[rj] = fma(-l0, linv_jc, Lc[rj]);
-                            }
-                        } else if (ii > rj && ii < NR) {
-                            Hc[ii] = fma(-li[t], lcj, Hc[ii]);
-                            Lc[ii] = fma(-li[t], linv_jc, Lc[ii]);
-                        }
-                    }
-                }
+            for (int k = 1; k < NR; ++k) {
+                Hc[k] = fma(-li[k], lcj, Hc[k]);
+                Lc[k] = fma(-li[k], linv_jc, Lc[k]);
             }
         }
-    }
-    // JT = L^-1
+        // ---------------- odd step j = 2 r + 1: row j is register 0 of half 1
+        if (2 * r + 1 < n) {
+            const int j = 2 * r + 1;
+            double piv = bcast(Hc[0], j + 32);   // lane (c = j, h = 1)
+            if (!(piv > 0.0)) { bad = true; piv = 1.0; }
+            double sq, rs;
+            fast_sqrt_rsqrt(piv, sq, rs);
+            const double hjc = from_half<NP>(Hc[0], 1);
+            const double lcj = (valid && c >= j) ? ((c == j) ? sq : hjc * rs) : 0.0;
+            if (h == 0) wr[1] = lcj;
+            if (c == j) invd = rs;
+            const double yj = bcast(rhs, j) * rs;
+            rhs = (c == j) ? yj : fma(-lcj, yj, rhs);
+            const double linv_jc = from_half<NP>(Lc[0], 1) * rs;
+            if (h == 1) Lc[0] = linv_jc;
+            wave_sync();
+            double li[NR];
 #pragma unroll
-    for (int ii = 0; ii < NR; ++ii) M2[(HV * ii + h) * S + c] = Lc[ii];
+            for (int k = 1; k < NR; ++k) li[k] = colp[2 * k * S + 1];
+#pragma unroll
+            for (int k = 1; k < NR; ++k) {
+                Hc[k] = fma(-li[k], lcj, Hc[k]);
+                Lc[k] = fma(-li[k], linv_jc, Lc[k]);
+            }
+        }
+        m2p[0] = Lc[0];   // rows 2 r (half 0) and 2 r + 1 (half 1) of L^-1 are final
+        // rotate: register k <- k + 1, zero shifted in
+#pragma unroll
+        for (int k = 0; k + 1 < NR; ++k) { Hc[k] = Hc[k + 1]; Lc[k] = Lc[k + 1]; }
+        Hc[NR - 1] = 0.0;
+        Lc[NR - 1] = 0.0;
+        colp += 2 * S + 2;
+        wr += 2;
+        m2p += 2 * S;
+    }
+    // rows of JT beyond the pairs that were swept: identity (they are read, against zeros, by the J products)
+    for (int i = 2 * npairs + h; i < NP; i += 2) M2[i * S + c] = (i == c) ? 1.0 : 0.0;
+    if (bad) { x_out = 0.0; return QP_NOT_PD; }
     // backward substitution L'x = y (rhs holds y); rows of L are fetched eight at a time ahead of the chain
     double x = 0.0;
     const double yinv0 = invd;
-#pragma unroll
     for (int i0 = NP - 8; i0 >= 0; i0 -= 8) {
         double lrow[8];
 #pragma unroll
@@ -283,7 +315,7 @@ __device__ inline int factor_regs(const WaveCtx<NP>& w, double (&Hc)[NP / (64 / 
 #pragma unroll
         for (int t = 7; t >= 0; --t) {
             const int i = i0 + t;
-            if (FULL || i < n) {
+            if (i < n) {
                 const double xi = bcast(rhs * yinv0, i);
                 if (c == i) x = xi;
                 rhs = fma(-lrow[t], xi, rhs);
@@ -306,7 +338,7 @@ __device__ inline int factor_regs(const WaveCtx<NP>& w, double (&Hc)[NP / (64 / 
 //     the same shape, no cross-lane step at all (pure ILP, four accumulators per dot product).
 // The row bases are laundered: ds_read2_b64 only has an 8-bit offset field, so without it every pair of reads
 // gets its own constant address, and loop-invariant code motion parks ~900 of them in (spilled) SGPRs.
-// In/Out as factor_regs.  MUST be inlined (Hc would otherwise travel through scratch by reference).
+// In/Out as factor_loop32.  MUST be inlined (Hc would otherwise travel through scratch by reference).
 template <bool FULL>
 __device__ __forceinline__ int factor_rows64(const WaveCtx<64>& w, double (&Hc)[64], double g, double& x_out) {
     constexpr int NP = 64, S = WaveCtx<64>::S;
@@ -409,6 +441,15 @@ __device__ __forceinline__ int factor_rows64(const WaveCtx<64>& w, double (&Hc)[
     x_out = valid ? x : 0.0;
     return QP_SOLVED;
 }
+// phase cycle counters of the profiling instantiation (PROF = true): indices into prof[]
+enum { PH_HBUILD = 0, PH_CHOL = 1, PH_INV = 2, PH_SUBST = 3, PH_EQ = 4, PH_INEQ = 5, PH_OPT = 6, PH_TOTAL = 7,
+       PH_EQ_D = 8, PH_EQ_RED = 9, PH_EQ_Z = 10, PH_EQ_HH = 11,
+       PH_IN_SCAN = 12, PH_IN_D = 13, PH_IN_Z = 14, PH_IN_R = 15, PH_IN_HH = 16, PH_IN_DROP = 17, PH_COUNT = 18 };
+#define OSOT_SUB_BEGIN() long long sub_t0_ = PROF ? (long long)clock64() : 0
+#define OSOT_SUB_END(idx) do { if (PROF) { const long long t_ = (long long)clock64(); prof[idx] += t_ - sub_t0_; sub_t0_ = t_; } } while (0)
+#define OSOT_PH_BEGIN() long long ph_t0_ = PROF ? (long long)clock64() : 0
+#define OSOT_PH_END(idx) do { if (PROF) { const long long t_ = (long long)clock64(); prof[idx] += t_ - ph_t0_; ph_t0_ = t_; } } while (0)
+
 // ---------------------------------------------------------------------------------------------------------
 // Null-space elimination of MANY equalities under a DIAGONAL Hessian (NP = 32).
 //
@@ -424,8 +465,10 @@ __device__ __forceinline__ int factor_rows64(const WaveCtx<64>& w, double (&Hc)[
 // Returns the rank (= number of equality positions in the working set), or -1 if nf > kNullMax (caller then
 // takes the generic path; nothing has been modified in that case).
 constexpr int kNullMax = 8;
+template <bool PROF>
 __device__ inline int nullspace_equalities32(const WaveCtx<32>& w, int n_eq, double hdiag, double g, double xprev,
-                                             double& x_out) {
+                                             double& x_out, long long* prof) {
+    OSOT_SUB_BEGIN();
     constexpr int S = WaveCtx<32>::S;
     const int c = w.c, h = w.h, n = w.n;
     const int lane = c + 32 * h;
@@ -433,53 +476,65 @@ __device__ inline int nullspace_equalities32(const WaveCtx<32>& w, int n_eq, dou
     double* M2 = w.M2;
     int* pivcol = reinterpret_cast<int*>(w.V + 3 * 32);   // idle staging vector: pivot column of each row (32 ints)
     // ---- E -> registers: Er[ii] = E[2ii+h][c] (lane = column, rows split over the halves) ------------------------
+    // (branch-free: rows beyond n_eq re-read row 0 and are zeroed afterwards, so the sixteen
+    //  eqlist -> row pointer -> HBM/L2 chains are all in flight together instead of one after the other)
     double Er[16];
 #pragma unroll
     for (int ii = 0; ii < 16; ++ii) {
         const int r = 2 * ii + h;
-        Er[ii] = (r < n_eq) ? row_elem<32>(w, w.eqlist[r], c) : 0.0;
+        Er[ii] = row_elem<32>(w, w.eqlist[(r < n_eq) ? r : 0], c);
     }
+#pragma unroll
+    for (int ii = 0; ii < 16; ++ii) Er[ii] = (2 * ii + h < n_eq) ? Er[ii] : 0.0;
     double emax = 0.0;
 #pragma unroll
     for (int ii = 0; ii < 16; ++ii) emax = fmax(emax, fabs(Er[ii]));
-    { double m = -emax; int dummy = lane; colargmin<64>(m, dummy); emax = -bcast(m, 0); }
+    emax = colmax<64>(emax);
     const double tol = 1.0e-9 * emax;
-    // ---- Gauss-Jordan with column pivoting, all in registers.  The pivot column (the 16 values of lane
-    // (pcol, h)) reaches every lane of its half through ds_bpermute (per-lane source index, result in a VGPR:
-    // no SGPR traffic); every register index is a compile-time constant.
+    OSOT_SUB_END(PH_EQ_D);      // (profiling slots reused: load + scale)
+    // ---- Gauss-Jordan with column pivoting, all in registers, as a LOOP over pairs of rows with ROTATING
+    // registers (cyclic: register 0 always holds the current pair; see factor_loop32 for why the sweep is not
+    // unrolled: the unrolled function was 55 KB of straight-line code).  The pivot is the largest |entry| of the
+    // row among the non-basic columns: one max-reduction, then a ballot picks the lowest such column (the
+    // value/payload argmin network costs ~760 cycles, this ~170).  The pivot column (the 16 values of lane
+    // (pcol, h)) reaches every lane of its half through ds_bpermute (per-lane source index, result in a VGPR).
     bool basic = false;
+    const int npairs = (n_eq + 1) >> 1;
+    for (int r = 0; r < npairs; ++r) {
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
-        if (k < n_eq) {
-            const int hk = k & 1, rk = k >> 1;
-            const double v = from_half<32>(Er[rk], hk);           // row k at my column, in both halves
-            double cand = (valid && !basic) ? -fabs(v) : 1.0;
-            int pc = c;
-            colargmin<32>(cand, pc);
-            const int pcol = uniform_i(pc);
-            const double pmax = -bcast(cand, 0);
-            int pk = -1;
-            if (pmax > tol) {
-                pk = pcol;
-                const double rowk = v * fast_rcp(bcast(v, pcol));
-                const int src = pcol + 32 * h;
-                double f[16];
+        for (int hk = 0; hk < 2; ++hk) {
+            const int k = 2 * r + hk;
+            if (k < n_eq) {
+                const double v = from_half<32>(Er[0], hk);            // row k at my column, in both halves
+                const double cand = (valid && !basic) ? fabs(v) : -1.0;
+                const double pmax = colmax<32>(cand);
+                int pk = -1;
+                if (pmax > tol) {
+                    const int pcol = first_lane_equal(cand, pmax) & 31;
+                    pk = pcol;
+                    const double rowk = v * fast_rcp(bcast(v, pcol));
+                    const int src = pcol + 32 * h;
+                    double f[16];
 #pragma unroll
-                for (int ii = 0; ii < 16; ++ii) f[ii] = __shfl(Er[ii], src, 64);
+                    for (int ii = 0; ii < 16; ++ii) f[ii] = __shfl(Er[ii], src, 64);
+                    Er[0] = (h == hk) ? rowk : fma(-f[0], rowk, Er[0]);
 #pragma unroll
-                for (int ii = 0; ii < 16; ++ii) {
-                    const bool is_k = (ii == rk) && (h == hk);
-                    Er[ii] = is_k ? rowk : fma(-f[ii], rowk, Er[ii]);
+                    for (int ii = 1; ii < 16; ++ii) Er[ii] = fma(-f[ii], rowk, Er[ii]);
+                    if (c == pcol) basic = true;
+                } else {
+                    if (h == hk) Er[0] = 0.0;   // dependent row (consistent: x_prev satisfies every row)
                 }
-                if (c == pcol) basic = true;
-            } else {
-                if (h == hk) Er[rk] = 0.0;   // dependent row (consistent: x_prev satisfies every row)
+                if (lane == 0) pivcol[k] = pk;
             }
-            if (lane == 0) pivcol[k] = pk;
-            sched_fence();
         }
+        // rotate (cyclic): register k <- k + 1, register 15 <- the pair just finished
+        const double e0 = Er[0];
+#pragma unroll
+        for (int ii = 0; ii + 1 < 16; ++ii) Er[ii] = Er[ii + 1];
+        Er[15] = e0;
     }
     wave_sync();
+    OSOT_SUB_END(PH_EQ_RED);    // Gauss-Jordan
     const unsigned long long fmask = wave_ballot(valid && !basic && h == 0);
     const int nf = __builtin_popcountll(fmask);
     if (nf > kNullMax) return -1;
@@ -491,7 +546,7 @@ __device__ inline int nullspace_equalities32(const WaveCtx<32>& w, int n_eq, dou
     wave_sync();
 #pragma unroll
     for (int ii = 0; ii < 16; ++ii) {
-        const int r = 2 * ii + h;
+        const int r = 2 * ((ii + npairs) & 15) + h;   // register ii holds this row after npairs rotations
         if (r < n_eq) {
             const int pk = pivcol[r];
             if (is_free && pk >= 0) M2[(me + t) * S + pk] = -Er[ii];
@@ -519,6 +574,7 @@ __device__ inline int nullspace_equalities32(const WaveCtx<32>& w, int n_eq, dou
             if (h == 0) M2[(me + s) * S + c] = zr[s];
         }
     }
+    OSOT_SUB_END(PH_EQ_Z);      // Z extraction + Gram-Schmidt
     // ---- x = x_prev - J2 J2' (H x_prev + g) -----------------------------------------------------------------
     const double grad = valid ? fma(hc, xprev, g) : 0.0;
     double x = valid ? xprev : 0.0;
@@ -532,25 +588,17 @@ __device__ inline int nullspace_equalities32(const WaveCtx<32>& w, int n_eq, dou
         }
     }
     wave_sync();
+    OSOT_SUB_END(PH_EQ_HH);     // projection
     x_out = x;
     return me;
 }
-
-// phase cycle counters of the profiling instantiation (PROF = true): indices into prof[]
-enum { PH_HBUILD = 0, PH_CHOL = 1, PH_INV = 2, PH_SUBST = 3, PH_EQ = 4, PH_INEQ = 5, PH_OPT = 6, PH_TOTAL = 7,
-       PH_EQ_D = 8, PH_EQ_RED = 9, PH_EQ_Z = 10, PH_EQ_HH = 11,
-       PH_IN_SCAN = 12, PH_IN_D = 13, PH_IN_Z = 14, PH_IN_R = 15, PH_IN_HH = 16, PH_IN_DROP = 17, PH_COUNT = 18 };
-#define OSOT_SUB_BEGIN() long long sub_t0_ = PROF ? (long long)clock64() : 0
-#define OSOT_SUB_END(idx) do { if (PROF) { const long long t_ = (long long)clock64(); prof[idx] += t_ - sub_t0_; sub_t0_ = t_; } } while (0)
-#define OSOT_PH_BEGIN() long long ph_t0_ = PROF ? (long long)clock64() : 0
-#define OSOT_PH_END(idx) do { if (PROF) { const long long t_ = (long long)clock64(); prof[idx] += t_ - ph_t0_; ph_t0_ = t_; } } while (0)
 
 template <int NP, bool PROF>
 __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq, const int me, int Aq, double uq,
                                int iters, bool has_box, double lb, double ub, int max_iter, bool diag_dd, double hinv,
                                double& x_out, int& iters_out, long long* prof);
 
-// Pre (general H):  Hc[ii] = (H + eps I)[HV*ii+h][c] in registers (see factor_regs), M1 is scratch.
+// Pre (general H):  Hc[ii] = (H + eps I)[HV*ii+h][c] in registers (see factor_loop32 / factor_rows64), M1 is scratch.
 template <int NP, bool PROF, bool FULLN>
 __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_h,
                         double hdiag, double (&Hc)[NP / (64 / NP)], bool has_box, double lb, double ub, int max_iter,
@@ -589,7 +637,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
         // kernel push the NP = 32 kernel past 256 VGPRs; each alone fits without scratch
         int stf;
         if constexpr (NP == 64) stf = factor_rows64<FULLN>(w, Hc, g, x);
-        else stf = factor_regs<NP, FULLN>(w, Hc, g, x);
+        else stf = factor_loop32(w, Hc, g, x);
         if (stf != QP_SOLVED) { x_out = 0.0; iters_out = 0; return stf; }
         OSOT_PH_END(PH_CHOL);
         // (the substitution, NOT x = -J J'g: with H = A'A + eps I rank deficient, g lies in range(A') and the
@@ -630,7 +678,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
     // elimination instead of n_eq Householder updates of the full J (see nullspace_equalities32)
     bool used_nullspace = false;
     if (NP == 32 && diag_h && have_prev && n_eq >= 8 && n_eq <= 32 && n - n_eq <= kNullMax) {
-        const int r_ns = nullspace_equalities32(reinterpret_cast<const WaveCtx<32>&>(w), n_eq, hdiag, g, xprev, x);
+        const int r_ns = nullspace_equalities32<PROF>(reinterpret_cast<const WaveCtx<32>&>(w), n_eq, hdiag, g, xprev, x, prof);
         if (r_ns >= 0) { iq = r_ns; iters += n_eq; used_nullspace = true; n_eq = 0; }
     }
     double a_next = (n_eq > 0) ? row_elem<NP>(w, w.eqlist[0], c) : 0.0;

@@ -39,6 +39,8 @@ __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0
 // enclosing loop / kept live across phases (used on the lane index to stop loop-invariant code motion
 // from parking hundreds of per-lane addresses and masks in registers for the whole kernel)
 __device__ __forceinline__ int launder_i(int v) { asm volatile("" : "+v"(v)); return v; }
+// the same for a wave-uniform value (stays in a scalar register)
+__device__ __forceinline__ int launder_s(int v) { asm volatile("" : "+s"(v)); return v; }
 
 __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -96,6 +98,22 @@ __device__ __forceinline__ void swap32_pair_i(int v, int& a, int& b) {
     a = (int)p[0]; b = (int)p[1];
 }
 
+// ---- fp64 matrix core: D = A(16x4) B(4x16) + C, one wavefront ------------------------------------------
+// v_mfma_f64_16x16x4_f64.  Lane l supplies A[m = l & 15][k = l >> 4] and B[k = l >> 4][n = l & 15]; the
+// accumulator holds four results per lane: D[row = (l >> 4) + 4 r][col = l & 15] in element r.
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f64 mfma_f64_16x16x4(double a, double b, v4f64 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+// sum over the four rows of 16 lanes (lanes l, l^16, l^32, l^48); every lane gets it
+__device__ __forceinline__ double rowgroup_sum(double v) {
+    double a, b;
+    swap16_pair(v, a, b);
+    v = a + b;
+    swap32_pair(v, a, b);
+    return a + b;
+}
+
 // ---- reductions over the NP columns (lanes with equal h); every lane gets the result ------------------
 template <int NP>
 __device__ __forceinline__ double colsum(double v) {
@@ -105,6 +123,24 @@ __device__ __forceinline__ double colsum(double v) {
     v = a + b;                       // 32 lanes of a half
     if (NP == 64) { swap32_pair(v, a, b); v = a + b; }
     return v;
+}
+// maximum over the NP columns (lanes with equal h); every lane gets it
+template <int NP>
+__device__ __forceinline__ double colmax(double v) {
+    v = fmax(v, dpp_f64<DPP_XOR1>(v));
+    v = fmax(v, dpp_f64<DPP_XOR2>(v));
+    v = fmax(v, dpp_f64<DPP_HALF_MIRROR>(v));
+    v = fmax(v, dpp_f64<DPP_MIRROR>(v));
+    double a, b;
+    swap16_pair(v, a, b);
+    v = fmax(a, b);
+    if (NP == 64) { swap32_pair(v, a, b); v = fmax(a, b); }
+    return v;
+}
+// lowest lane whose value equals the (already reduced) extremum m; 64 if none (NaN)
+__device__ __forceinline__ int first_lane_equal(double v, double m) {
+    const unsigned long long mask = wave_ballot(v == m);
+    return mask ? __builtin_ctzll(mask) : 64;
 }
 // two column sums for the price of one reduction network: half 0 reduces va, half 1 reduces vb, then the
 // halves exchange their totals (NP = 32; plain two reductions for NP = 64)
@@ -200,7 +236,11 @@ __device__ __forceinline__ void fast_sqrt_rsqrt(double x, double& s, double& rs)
     const double d = fma(-g, g, x);
     g = fma(d, h, g);
     s = g;
-    rs = fast_rcp(g);
+    // 1/s from the Goldschmidt companion h ~ 1/(2s) with one Newton step against the corrected root (no
+    // v_rcp_f64 + two refinements on the critical path of every factorisation step); exact for exact roots
+    double q = h + h;
+    const double e = fma(-g, q, 1.0);
+    rs = fma(q, e, q);
 }
 
 }  // namespace osot

@@ -17,6 +17,7 @@ inline int emu_lane() { return emu::S().cur; }
 inline void wave_sync() { int z = 0, out[64]; emu::allgather(&z, out, sizeof(int)); }
 inline void sched_fence() {}
 inline int launder_i(int v) { return v; }
+inline int launder_s(int v) { return v; }
 inline int uniform_i(int v) { int out[64]; emu::allgather(&v, out, sizeof(int)); return out[0]; }
 
 inline unsigned long long wave_ballot(bool p) {
@@ -28,12 +29,47 @@ inline int lanes_below(unsigned long long mask) {
     const int l = emu_lane();
     return __builtin_popcountll(l ? (mask & ((~0ull) >> (64 - l))) : 0ull);
 }
+struct v4f64 {
+    double v[4];
+    double& operator[](int i) { return v[i]; }
+    const double& operator[](int i) const { return v[i]; }
+};
+inline v4f64 mfma_f64_16x16x4(double a, double b, v4f64 c) {
+    double aa[64], bb[64];
+    emu::allgather(&a, aa, sizeof(double));
+    emu::allgather(&b, bb, sizeof(double));
+    const int l = emu_lane(), col = l & 15;
+    v4f64 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = (l >> 4) + 4 * r;
+        double acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = std::fma(aa[row + 16 * k], bb[col + 16 * k], acc);
+        d[r] = acc;
+    }
+    return d;
+}
+inline double rowgroup_sum(double v) {
+    double all[64]; emu::allgather(&v, all, sizeof(double));
+    const int a = emu_lane() & 15;
+    return (all[a] + all[a + 16]) + (all[a + 32] + all[a + 48]);
+}
 template <int NP> inline double colsum(double v) {
     double all[64]; emu::allgather(&v, all, sizeof(double));
     const int h0 = (emu_lane() / NP) * NP;
     double s = 0.0;
     for (int i = 0; i < NP; ++i) s += all[h0 + i];
     return s;
+}
+template <int NP> inline double colmax(double v) {
+    double all[64]; emu::allgather(&v, all, sizeof(double));
+    const int h0 = (emu_lane() / NP) * NP;
+    double m = all[h0];
+    for (int i = 1; i < NP; ++i) m = std::fmax(m, all[h0 + i]);
+    return m;
+}
+inline int first_lane_equal(double v, double m) {
+    const unsigned long long mask = wave_ballot(v == m);
+    return mask ? __builtin_ctzll(mask) : 64;
 }
 template <int NP> inline void colsum2(double va, double vb, double& ra, double& rb) {
     ra = colsum<NP>(va); rb = colsum<NP>(vb);

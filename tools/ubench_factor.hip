@@ -1,0 +1,51 @@
+// developer tool: in-situ cycles of the NP = 32 factorisation (factor_loop32), 1..8 waves per CU
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include "osot_qp_core.h"
+using namespace osot;
+
+__global__ void __launch_bounds__(64, 2) factor_bench(long long* out, double* sink, int n, int reps) {
+    OSOT_DYNAMIC_LDS(smem);
+    double* base = reinterpret_cast<double*>(smem);
+    constexpr int S = WaveCtx<32>::S;
+    WaveCtx<32> w;
+    w.c = threadIdx.x & 31; w.h = threadIdx.x >> 5; w.n = n;
+    w.M1 = base; w.M2 = base + 32 * S; w.V = base + 2 * 32 * S;
+    double acc = 0.0;
+    long long total = 0;
+    for (int r = 0; r < reps; ++r) {
+        double Hc[16];
+#pragma unroll
+        for (int ii = 0; ii < 16; ++ii) {
+            const int i = 2 * ii + w.h;
+            Hc[ii] = (i < n && w.c < n) ? ((i == w.c) ? 40.0 + r : 1.0 / (1.0 + (i > w.c ? i - w.c : w.c - i))) : 0.0;
+        }
+        double x;
+        wave_sync();
+        const long long t0 = clock64();
+        const int st = factor_loop32(w, Hc, 1.0 + w.c, x);
+        const long long t1 = clock64();
+        total += t1 - t0;
+        acc += x + st;
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = total / reps;
+    sink[blockIdx.x * 64 + threadIdx.x] = acc;
+}
+
+int main() {
+    long long* out; double* sink;
+    const int maxb = 256 * 8;
+    hipMalloc(&out, maxb * sizeof(long long));
+    hipMalloc(&sink, maxb * 64 * sizeof(double));
+    const size_t lds = (2 * 32 * 33 + 4 * 32) * sizeof(double);
+    for (int wpc : {1, 2, 4, 8}) {
+        const int grid = 256 * wpc;
+        for (int it = 0; it < 2; ++it) factor_bench<<<grid, 64, lds>>>(out, sink, 32, 8);
+        hipDeviceSynchronize();
+        static long long h[maxb];
+        hipMemcpy(h, out, grid * sizeof(long long), hipMemcpyDeviceToHost);
+        double m = 0; for (int i = 0; i < grid; ++i) m += h[i];
+        printf("waves/CU %d: factor_loop32 (n = 32) %.0f cycles = %.0f per step\n", wpc, m / grid, m / grid / 32);
+    }
+    return 0;
+}
