@@ -237,6 +237,15 @@ int osot_ihqp_solve(osot_solver* s, const osot_qp_batch* batch, void* hip_stream
  * with reset != 0; measured with hipEvents on the launch stream. *launches receives the count. */
 int osot_solver_kernel_time_ms(osot_solver* s, int reset, double* avg_ms, int* launches);
 int osot_solver_set_timing(osot_solver* s, int enabled);
+/* Dispatch order of the instances inside osot_ihqp_solve.  One wavefront solves one instance and the chip holds a
+ * fixed number of them, so a batch runs in rounds and its tail is set by the slowest late starter.
+ * OSOT_SCHEDULE_LONGEST_FIRST (default) dispatches in descending order of each instance's active-set iteration
+ * count in the PREVIOUS solve of a batch of the same size on this solver (control loops are temporally coherent);
+ * the first solve runs in order.  Results do not depend on the mode: the reference solves the robots of a batch
+ * independently (one iHQP per robot, coman_ik.cpp:425-470). */
+#define OSOT_SCHEDULE_IN_ORDER 0
+#define OSOT_SCHEDULE_LONGEST_FIRST 1
+int osot_solver_set_schedule(osot_solver* s, int mode);
 /* diagnostic: run the cascade once through the instrumented instantiation of the kernel and write, per
  * instance, OSOT_N_PHASES shader-clock cycle counts (H/g build, Cholesky, L^-1, substitution, equality
  * phase, inequality loop, optimality rhs, total, then four sub-phases of the equality adds: J'a,

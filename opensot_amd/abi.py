@@ -80,7 +80,7 @@ SYMBOLS = [
     "osot_plan_validate", "osot_plan_level_rows", "osot_plan_constraint_rows",
     "osot_plan_stored_constraint_rows",
     "osot_solver_create", "osot_solver_destroy", "osot_stack_update", "osot_ihqp_solve",
-    "osot_solver_kernel_time_ms", "osot_solver_set_timing", "osot_solver_profile_phases",
+    "osot_solver_kernel_time_ms", "osot_solver_set_timing", "osot_solver_set_schedule", "osot_solver_profile_phases",
     "osot_backend_create", "osot_backend_destroy", "osot_backend_init_problem",
     "osot_backend_update_task", "osot_backend_update_constraints", "osot_backend_update_bounds",
     "osot_backend_solve", "osot_backend_get_solution", "osot_backend_get_objective",
@@ -126,6 +126,7 @@ def lib():
     L.osot_ihqp_solve.argtypes = [vp, C.POINTER(QpBatch), vp]
     L.osot_solver_kernel_time_ms.argtypes = [vp, C.c_int, dp, ip]
     L.osot_solver_set_timing.argtypes = [vp, C.c_int]
+    L.osot_solver_set_schedule.argtypes = [vp, C.c_int]
     L.osot_solver_profile_phases.argtypes = [vp, C.POINTER(QpBatch), vp, vp]
     L.osot_backend_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(vp)]
     L.osot_backend_destroy.argtypes = [vp]

@@ -58,6 +58,8 @@ struct DevBatch {
     int* status;
     int* iterations;
     long long* prof;   // [B][PH_COUNT] shader-clock cycles per phase (profiling instantiation only)
+    const int* order;  // dispatch order: workgroup g solves instance order[g] (null: g).  Longest-first, see below
+    int* cost_out;     // [B] active-set iterations of this solve = the cost estimate for the next dispatch
 };
 
 // Row table of level k (LDS): [ global C rows ; A_0 ; ... ; A_{k-1} ]  (iHQP.cpp:282-333).  The C entries are
@@ -69,7 +71,7 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
     OSOT_DYNAMIC_LDS(osot_smem);
     constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
     const int lane = threadIdx.x;
-    const long long inst = blockIdx.x;
+    const long long inst = D.order ? D.order[blockIdx.x] : (int)blockIdx.x;
     const int n = P.n;
     double* base = reinterpret_cast<double*>(osot_smem);
     WaveCtx<NP> w;
@@ -170,7 +172,6 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
                 gp1 = fma(-wa1, br, gp1);
                 Ht[0][0] = mfma_f64_16x16x4(wa0, a0, Ht[0][0]);
                 Ht[0][1] = mfma_f64_16x16x4(wa0, a1, Ht[0][1]);
-                Ht[1][0] = mfma_f64_16x16x4(wa1, a0, Ht[1][0]);
                 Ht[1][1] = mfma_f64_16x16x4(wa1, a1, Ht[1][1]);
             }
             // g: the partial sums of a column sit in the four rows of 16 lanes
@@ -188,18 +189,13 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Ht[I][I][r] += (ta == tq + 4 * r) ? dv : 0.0;
             }
-            // (stage 1) hand the tiles to the register layout of the factorisation through LDS
-            wave_sync();
+            // the factorisation (factor_tiles32) works on the tiles as they are: hacc[4 (2 I + C) + r]
 #pragma unroll
             for (int I = 0; I < 2; ++I)
 #pragma unroll
                 for (int C2 = 0; C2 < 2; ++C2)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) w.M1[(16 * I + tq + 4 * r) * S + 16 * C2 + ta] = Ht[I][C2][r];
-            wave_sync();
-#pragma unroll
-            for (int ii = 0; ii < NP / HV; ++ii) hacc[ii] = w.M1[(ii * HV + h) * S + c];
-            wave_sync();
+                    for (int r = 0; r < 4; ++r) hacc[4 * (2 * I + C2) + r] = Ht[I][C2][r];
           } else {
             // ---- H = A'WA + eps I, g = -A'Wb + c.  Lane (c,h) accumulates H[i][c] for i = ii*HV + h in
             // registers; stored rows are staged four at a time through LDS for the broadcasts.
@@ -303,8 +299,40 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
     if (lane == 0) {
         D.status[inst] = status;
         if (D.iterations) D.iterations[inst] = iters_total;
+        if (D.cost_out) D.cost_out[inst] = iters_total;
     }
 }
+
+// Longest-first dispatch.  One wavefront solves one instance and an MI355X holds 2048 of them at a time, so a
+// batch of 4096 is two rounds: the kernel ends when the slowest LATE starter ends, and with the active-set
+// iteration count varying 2x between instances (mean 32, max 63 at BASELINE config 3) that tail was ~30 % of the
+// launch.  Control loops are temporally coherent: an instance's iteration count changes slowly from one cycle to
+// the next.  So the instances are dispatched in DESCENDING order of the iteration count of the previous solve
+// (classic longest-processing-time list scheduling).  This kernel builds that order: a counting sort of the
+// instance ids by min(cost, 255), one workgroup.  Results do not depend on the order (instances are independent).
+#ifndef OSOT_EMULATION   // (a 1024-thread workgroup with atomics: outside what tests/emu models; covered by the GPU tests)
+__global__ void __launch_bounds__(1024) osot_order_kernel(const int* cost, int* order, int B) {
+    __shared__ int hist[256];
+    __shared__ int start[256];
+    const int t = threadIdx.x;
+    if (t < 256) hist[t] = 0;
+    __syncthreads();
+    for (int i = t; i < B; i += 1024) {
+        int k = cost[i]; k = k < 0 ? 0 : (k > 255 ? 255 : k);
+        atomicAdd(&hist[k], 1);
+    }
+    __syncthreads();
+    if (t == 0) {
+        int acc = 0;
+        for (int k = 255; k >= 0; --k) { start[k] = acc; acc += hist[k]; }
+    }
+    __syncthreads();
+    for (int i = t; i < B; i += 1024) {
+        int k = cost[i]; k = k < 0 ? 0 : (k > 255 ? 255 : k);
+        order[atomicAdd(&start[k], 1)] = i;
+    }
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // generic batched QP in BackEnd convention
@@ -350,11 +378,21 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
     wave_sync();
     constexpr int HV = WaveCtx<NP>::HV;
     double Hc[NP / HV];
+    if constexpr (NP == 32) {   // accumulator-tile layout of factor_tiles32: Hc[4 (2 I + C) + r] = H[16 I + q + 4 r][16 C + a]
+        const int ta = lane & 15, tq = lane >> 4;
 #pragma unroll
-    for (int ii = 0; ii < NP / HV; ++ii) {
-        const int i = HV * ii + h;
-        Hc[ii] = (valid && i < n) ? Q.H[(inst * n + i) * n + c] + ((i == c) ? Q.eps_abs : 0.0)
-                                  : ((i == c) ? 1.0 : 0.0);   // unit diagonal beyond n (see factor_rows64)
+        for (int t = 0; t < 16; ++t) {
+            const int i = 16 * (t >> 3) + tq + 4 * (t & 3), cc = 16 * ((t >> 2) & 1) + ta;
+            Hc[t] = (i < n && cc < n) ? Q.H[(inst * n + i) * n + cc] + ((i == cc) ? Q.eps_abs : 0.0)
+                                      : ((i == cc) ? 1.0 : 0.0);   // unit diagonal beyond n
+        }
+    } else {
+#pragma unroll
+        for (int ii = 0; ii < NP / HV; ++ii) {
+            const int i = HV * ii + h;
+            Hc[ii] = (valid && i < n) ? Q.H[(inst * n + i) * n + c] + ((i == c) ? Q.eps_abs : 0.0)
+                                      : ((i == c) ? 1.0 : 0.0);   // unit diagonal beyond n (see factor_rows64)
+        }
     }
     wave_sync();
     const double g = valid ? Q.g[inst * n + c] : 0.0;

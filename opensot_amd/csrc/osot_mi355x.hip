@@ -50,6 +50,11 @@ struct osot_solver {
     bool timing;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // recorded, not yet accumulated
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    // longest-first dispatch (osot_order_kernel): cost of the previous solve and the order built from it
+    int schedule = 1;        // 0: in order, 1: longest first
+    int* d_cost = nullptr;   // [max_batch]
+    int* d_order = nullptr;  // [max_batch]
+    int order_B = -1;        // batch size d_order is valid for (-1: none yet)
 };
 
 extern "C" {
@@ -110,7 +115,17 @@ int osot_solver_destroy(osot_solver* s) {
     if (!s) return OSOT_OK;
     for (auto& p : s->events) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     for (auto& p : s->pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    if (s->d_cost) hipFree(s->d_cost);
+    if (s->d_order) hipFree(s->d_order);
     delete s;
+    return OSOT_OK;
+}
+
+int osot_solver_set_schedule(osot_solver* s, int mode) {
+    if (!s) return fail(OSOT_ERR_INVALID, "null solver");
+    if (mode != OSOT_SCHEDULE_IN_ORDER && mode != OSOT_SCHEDULE_LONGEST_FIRST) return fail(OSOT_ERR_INVALID, "unknown schedule mode");
+    s->schedule = mode;
+    s->order_B = -1;
     return OSOT_OK;
 }
 
@@ -175,6 +190,14 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
     D.dq = b->dq; D.x_levels = b->x_levels; D.status = b->status; D.iterations = b->iterations;
     D.prof = prof;
     hipStream_t st = (hipStream_t)hip_stream;
+    if (s->schedule == 1) {
+        if (!s->d_cost) {
+            HIP_TRY(hipMalloc(&s->d_cost, sizeof(int) * (size_t)s->max_batch));
+            HIP_TRY(hipMalloc(&s->d_order, sizeof(int) * (size_t)s->max_batch));
+        }
+        D.order = (s->order_B == b->B) ? s->d_order : nullptr;
+        D.cost_out = s->d_cost;
+    }
     const unsigned grid = (unsigned)b->B;
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (s->timing) {
@@ -196,6 +219,11 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
     if (s->timing) {
         HIP_TRY(hipEventRecord(ev.second, st));
         s->events.push_back(ev);
+    }
+    if (s->schedule == 1) {   // the order for the next solve of a batch of this size
+        hipLaunchKernelGGL(osot_order_kernel, dim3(1), dim3(1024), 0, st, (const int*)s->d_cost, s->d_order, b->B);
+        HIP_TRY(hipGetLastError());
+        s->order_B = b->B;
     }
     return OSOT_OK;
 }

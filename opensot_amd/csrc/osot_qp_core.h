@@ -327,6 +327,139 @@ __device__ inline int factor_loop32(const WaveCtx<32>& w, double (&Hc)[16], doub
     return QP_SOLVED;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// NP = 32 production path: BLOCKED right-looking Cholesky + inverse on the fp64 MATRIX CORE, panel width 4.
+//
+// H + eps I and L^-1 live in the accumulator layout of v_mfma_f64_16x16x4_f64: lane l = (a, q) = (l & 15, l >> 4),
+// tile (I, C), element r holds M[16 I + q + 4 r][16 C + a]; as a flat array Ht[4 (2 I + C) + r] (sixteen fp64
+// registers, the same count as the column layout).  Panel p is the four columns 4p .. 4p+3.
+//   * By symmetry of the trailing matrix the panel IS a register: column 4p+q at rows 16 X + a equals row 4p+q at
+//     columns 16 X + a, which is element r = p & 3 of the tiles (I = p >> 2, X) at lane (a, q).  No data movement.
+//   * Inside the panel (VALU): per column one pivot broadcast + sqrt/rsqrt chain; the 3+2+1 rank-1 updates of the
+//     later panel columns take their operands through ds_bpermute (lane (a, q) <- lane (a, qq): LDS crossbar,
+//     no VALU time).  The four rows 4p .. 4p+3 of L^-1 (the same register of the L^-1 tiles) are finalised with the
+//     same multipliers.
+//   * Trailing updates (matrix core):  H(I,C) -= Lp(I) Lp(C)',  Linv(I,C) -= Lp(I) Linv_rows(C): the panel register
+//     is the A operand (m = row-in-tile, k = panel column) AND the B operand of every tile.  13 + 13 MFMAs per
+//     factorisation replace 32 x (16 LDS broadcasts + 32 VALU FMAs).  The (1,0) tile of H is never needed.
+// In : Ht (H + eps I with a unit diagonal beyond n), g by lane c.   Out: M1 = L, M2 = JT = L^-1, x = -(H+eps I)^-1 g.
+__device__ inline int factor_tiles32(const WaveCtx<32>& w, double (&Hf)[16], double g, double& x_out) {
+    constexpr int S = WaveCtx<32>::S;
+    const int c = w.c, n = w.n;
+    const int lane = c + 32 * w.h;
+    const int ta = lane & 15, tq = lane >> 4;
+    const bool valid = c < n;
+    double* M1 = w.M1;
+    double* M2 = w.M2;
+    double* Vd = w.V;   // 1 / L[j][j] by j
+    v4f64 H00 = {Hf[0], Hf[1], Hf[2], Hf[3]}, H01 = {Hf[4], Hf[5], Hf[6], Hf[7]}, H11 = {Hf[12], Hf[13], Hf[14], Hf[15]};
+    v4f64 L00, L10 = {0.0, 0.0, 0.0, 0.0}, L11;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { L00[r] = (ta == tq + 4 * r) ? 1.0 : 0.0; L11[r] = L00[r]; }
+    bool bad = false;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int Ip = p >> 2, rp = p & 3;
+        // panel columns (as rows, by symmetry) and the matching rows of L^-1
+        double Pn[2], Rp[2];
+        Pn[0] = Ip ? 0.0 : H00[rp];            // rows 0..15 of a column >= 16 are zero (above the diagonal)
+        Pn[1] = Ip ? H11[rp] : H01[rp];
+        Rp[0] = Ip ? L10[rp] : L00[rp];
+        Rp[1] = Ip ? L11[rp] : 0.0;            // rows < 16 of L^-1 have no entries in columns >= 16
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int j = 4 * p + qq;
+            const int lj = (4 * rp + qq) + 16 * qq;   // lane (a = j & 15, q = qq) holds H[j][j] in Pn[Ip]
+            double piv = bcast(Pn[Ip], lj);
+            if (!(piv > 0.0)) { bad = true; piv = 1.0; }
+            double sq, rs;
+            fast_sqrt_rsqrt(piv, sq, rs);
+            if (lane == lj) Vd[j] = rs;
+            const bool mine = (tq == qq);
+#pragma unroll
+            for (int X = 0; X < 2; ++X) {
+                const int i = 16 * X + ta;
+                const double scaled = (i > j) ? Pn[X] * rs : ((i == j) ? sq : 0.0);
+                Pn[X] = mine ? scaled : Pn[X];
+                Rp[X] = mine ? Rp[X] * rs : Rp[X];
+            }
+            if (qq < 3) {
+                const int src = ta + 16 * qq;                     // lane (a, qq): same row, column j
+                const double ljj = __shfl(Pn[Ip], (4 * rp + tq) + 16 * qq, 64);   // L[4p + q][j] for my column 4p + q
+                const bool later = (tq > qq);
+#pragma unroll
+                for (int X = 0; X < 2; ++X) {
+                    if (!(Ip == 1 && X == 0)) {
+                        const double colj = __shfl(Pn[X], src, 64);
+                        Pn[X] = later ? fma(-colj, ljj, Pn[X]) : Pn[X];
+                    }
+                    if (!(Ip == 0 && X == 1)) {
+                        const double rowj = __shfl(Rp[X], src, 64);
+                        Rp[X] = later ? fma(-ljj, rowj, Rp[X]) : Rp[X];
+                    }
+                }
+            }
+        }
+        // L panel -> M1 (zeros above the diagonal included); final rows of L^-1 back into their tiles
+        M1[ta * S + 4 * p + tq] = Pn[0];
+        M1[(16 + ta) * S + 4 * p + tq] = Pn[1];
+        if (Ip) { L10[rp] = Rp[0]; L11[rp] = Rp[1]; } else { L00[rp] = Rp[0]; }
+        // trailing updates on the matrix core; the A operand is the panel restricted to the rows below it
+        const double A0 = (ta > 4 * p + 3) ? -Pn[0] : 0.0;          // rows 0..15
+        const double A1 = (16 + ta > 4 * p + 3) ? -Pn[1] : 0.0;     // rows 16..31
+        if (p < 3) {
+            H00 = mfma_f64_16x16x4(A0, -A0, H00);
+            H01 = mfma_f64_16x16x4(A0, -A1, H01);
+            L00 = mfma_f64_16x16x4(A0, Rp[0], L00);
+        }
+        if (p < 7) {
+            H11 = mfma_f64_16x16x4(A1, -A1, H11);
+            L10 = mfma_f64_16x16x4(A1, Rp[0], L10);
+            if (p >= 4) L11 = mfma_f64_16x16x4(A1, Rp[1], L11);
+        }
+    }
+    // JT = L^-1 (the upper right tile is zero)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        M2[(tq + 4 * r) * S + ta] = L00[r];
+        M2[(tq + 4 * r) * S + 16 + ta] = 0.0;
+        M2[(16 + tq + 4 * r) * S + ta] = L10[r];
+        M2[(16 + tq + 4 * r) * S + 16 + ta] = L11[r];
+    }
+    wave_sync();
+    if (bad) { x_out = 0.0; return QP_NOT_PD; }
+    // L y = -g, then L'x = y, by substitution; columns / rows of L are fetched eight at a time ahead of the chain
+    const double invd = Vd[c];
+    double rhs = valid ? -g : 0.0;
+    for (int j0 = 0; j0 < 32; j0 += 8) {
+        double lcol[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) lcol[t] = M1[c * S + j0 + t];   // zero for c < j
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int j = j0 + t;
+            const double yj = bcast(rhs * invd, j);
+            rhs = (c == j) ? yj : fma(-lcol[t], yj, rhs);
+        }
+    }
+    double x = 0.0;
+    for (int i0 = 24; i0 >= 0; i0 -= 8) {
+        double lrow[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) lrow[t] = M1[(i0 + t) * S + c];   // zero for c > i; lane i itself is done
+#pragma unroll
+        for (int t = 7; t >= 0; --t) {
+            const int i = i0 + t;
+            const double xi = bcast(rhs * invd, i);
+            if (c == i) x = xi;
+            rhs = fma(-lrow[t], xi, rhs);
+        }
+    }
+    wave_sync();
+    x_out = valid ? x : 0.0;
+    return QP_SOLVED;
+}
+
 // NP = 64 (one lane per column, 64 registers per array): a LEFT-looking, row-oriented variant in two passes so
 // that only ONE 64-register array is live at a time (the right-looking sweep above needs H and L^-1 together:
 // 256 VGPRs before any temporaries).  By symmetry lane c's column of H is its ROW c, so
@@ -637,7 +770,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
         // kernel push the NP = 32 kernel past 256 VGPRs; each alone fits without scratch
         int stf;
         if constexpr (NP == 64) stf = factor_rows64<FULLN>(w, Hc, g, x);
-        else stf = factor_loop32(w, Hc, g, x);
+        else stf = factor_tiles32(w, Hc, g, x);
         if (stf != QP_SOLVED) { x_out = 0.0; iters_out = 0; return stf; }
         OSOT_PH_END(PH_CHOL);
         // (the substitution, NOT x = -J J'g: with H = A'A + eps I rank deficient, g lies in range(A') and the

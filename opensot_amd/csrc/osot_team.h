@@ -172,25 +172,39 @@ __device__ __forceinline__ double from_half(double v, int hsel) {
     return hsel ? b : a;
 }
 
-// minimum over the columns with the payload of the minimiser (ties: smaller payload); every lane gets both
-__device__ __forceinline__ void argmin_step(double& v, int& p, double ov, int op) {
-    const bool take = (ov < v) || (ov == v && op < p);
-    v = take ? ov : v;
-    p = take ? op : p;
+// minimum over the columns with the payload of the minimiser (ties: smaller payload); every lane gets both.
+// Two plain min networks (the value, then the payload among the lanes that hold the minimum) instead of one
+// network that carries (value, payload) pairs through compare-and-select stages: ~270 cycles instead of ~760
+// (tools/ubench_latency.hip); the selected pair is the same.
+template <int NP>
+__device__ __forceinline__ double colmin(double v) {
+    v = fmin(v, dpp_f64<DPP_XOR1>(v));
+    v = fmin(v, dpp_f64<DPP_XOR2>(v));
+    v = fmin(v, dpp_f64<DPP_HALF_MIRROR>(v));
+    v = fmin(v, dpp_f64<DPP_MIRROR>(v));
+    double a, b;
+    swap16_pair(v, a, b);
+    v = fmin(a, b);
+    if (NP == 64) { swap32_pair(v, a, b); v = fmin(a, b); }
+    return v;
+}
+template <int NP>
+__device__ __forceinline__ int colmin_i(int v) {
+    v = min(v, dpp_i32<DPP_XOR1>(v));
+    v = min(v, dpp_i32<DPP_XOR2>(v));
+    v = min(v, dpp_i32<DPP_HALF_MIRROR>(v));
+    v = min(v, dpp_i32<DPP_MIRROR>(v));
+    int a, b;
+    swap16_pair_i(v, a, b);
+    v = min(a, b);
+    if (NP == 64) { swap32_pair_i(v, a, b); v = min(a, b); }
+    return v;
 }
 template <int NP>
 __device__ __forceinline__ void colargmin(double& v, int& p) {
-    argmin_step(v, p, dpp_f64<DPP_XOR1>(v), dpp_i32<DPP_XOR1>(p));
-    argmin_step(v, p, dpp_f64<DPP_XOR2>(v), dpp_i32<DPP_XOR2>(p));
-    argmin_step(v, p, dpp_f64<DPP_HALF_MIRROR>(v), dpp_i32<DPP_HALF_MIRROR>(p));
-    argmin_step(v, p, dpp_f64<DPP_MIRROR>(v), dpp_i32<DPP_MIRROR>(p));
-    double a, b; int pa, pb;
-    swap16_pair(v, a, b); swap16_pair_i(p, pa, pb);
-    v = a; p = pa; argmin_step(v, p, b, pb);
-    if (NP == 64) {
-        swap32_pair(v, a, b); swap32_pair_i(p, pa, pb);
-        v = a; p = pa; argmin_step(v, p, b, pb);
-    }
+    const double m = colmin<NP>(v);
+    p = colmin_i<NP>((v == m) ? p : 0x7fffffff);
+    v = m;
 }
 
 // value held by lane `lane` (wave-uniform index) -> every lane (v_readlane: the result lives in SGPRs)

@@ -168,6 +168,11 @@ class BatchedStack:
         torch.cuda.synchronize(self.device)
         return cyc.cpu().numpy()
 
+    def set_schedule(self, longest_first=True):
+        """dispatch order inside solve(): longest-first from the previous solve's iteration counts (default)
+        or plain instance order; results are identical either way."""
+        abi.check(self._lib.osot_solver_set_schedule(self._h, 1 if longest_first else 0), "osot_solver_set_schedule")
+
     def set_timing(self, on):
         abi.check(self._lib.osot_solver_set_timing(self._h, 1 if on else 0), "osot_solver_set_timing")
 

@@ -128,6 +128,29 @@ def test_empty_batch_and_timing_api(gpu_device):
         st.solve(9)                   # exceeds max_batch -> OSOT_ERR_INVALID
 
 
+def test_dispatch_order_does_not_change_results(gpu_device):
+    """longest-first dispatch (osot_order_kernel) only permutes which workgroup solves which instance: the
+    second solve (ordered by the first solve's iteration counts) and an in-order solve are bit-identical"""
+    plan, leaf = synth.make_velocity_stack("C4", 4096, seed=23)
+    st = BatchedStack(plan, 4096, device=0)
+    dl = st.load_leaf(leaf)
+    st.update(dl)
+    st.solve(4096)
+    first = st.dq[:4096].clone()
+    it1 = st.iterations[:4096].clone()
+    st.solve(4096)                    # dispatched longest-first from the first solve's counts
+    torch.cuda.synchronize()
+    assert torch.equal(st.dq[:4096], first) and torch.equal(st.iterations[:4096], it1)
+    st.solve(1000)                    # another batch size: falls back to plain order, same answers
+    torch.cuda.synchronize()
+    assert torch.equal(st.dq[:1000], first[:1000])
+    st.set_schedule(longest_first=False)
+    st.solve(4096)
+    torch.cuda.synchronize()
+    assert torch.equal(st.dq[:4096], first)
+    assert (st.status[:4096] == 0).all()
+
+
 def test_inverse_dynamics_full_size(oracle, gpu_device):
     """BASELINE config 5 shard (8192 over 8 GPUs = 1024 per GPU): floating-base rows of the computed torque
     vanish (InverseDynamics.cpp:83-92), torque limits / friction cones hold, oracle spot check"""

@@ -11,3 +11,7 @@ cyc = st.profile_phases(B)
 m = cyc.mean(axis=0)
 for name, v in zip(st.PHASES, m): print(f"{name:16s} {v:10.0f} cycles  {100*v/m[7]:5.1f}%")
 print("iters mean", st.iterations[:B].float().mean().item())
+t = cyc[:, 7]
+print("total cycles per instance: mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f" % (t.mean(), np.percentile(t, 50), np.percentile(t, 90), np.percentile(t, 99), t.max()))
+it = st.iterations[:B].cpu().numpy()
+print("iterations: mean %.1f p50 %d p90 %d p99 %d max %d" % (it.mean(), np.percentile(it, 50), np.percentile(it, 90), np.percentile(it, 99), it.max()))

@@ -1,9 +1,10 @@
-// developer tool: in-situ cycles of the NP = 32 factorisation (factor_loop32), 1..8 waves per CU
+// developer tool: in-situ cycles of the NP = 32 factorisations (factor_loop32: column layout; factor_tiles32: MFMA tiles), 1..8 waves per CU
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include "osot_qp_core.h"
 using namespace osot;
 
+template <int WHICH>
 __global__ void __launch_bounds__(64, 2) factor_bench(long long* out, double* sink, int n, int reps) {
     OSOT_DYNAMIC_LDS(smem);
     double* base = reinterpret_cast<double*>(smem);
@@ -20,10 +21,18 @@ __global__ void __launch_bounds__(64, 2) factor_bench(long long* out, double* si
             const int i = 2 * ii + w.h;
             Hc[ii] = (i < n && w.c < n) ? ((i == w.c) ? 40.0 + r : 1.0 / (1.0 + (i > w.c ? i - w.c : w.c - i))) : 0.0;
         }
+        if (WHICH == 1) {
+            const int ta = threadIdx.x & 15, tq = threadIdx.x >> 4;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int i = 16 * (t >> 3) + tq + 4 * (t & 3), cc = 16 * ((t >> 2) & 1) + ta;
+                Hc[t] = (i == cc) ? 40.0 + r : 1.0 / (1.0 + (i > cc ? i - cc : cc - i));
+            }
+        }
         double x;
         wave_sync();
         const long long t0 = clock64();
-        const int st = factor_loop32(w, Hc, 1.0 + w.c, x);
+        const int st = (WHICH == 1) ? factor_tiles32(w, Hc, 1.0 + w.c, x) : factor_loop32(w, Hc, 1.0 + w.c, x);
         const long long t1 = clock64();
         total += t1 - t0;
         acc += x + st;
@@ -40,12 +49,23 @@ int main() {
     const size_t lds = (2 * 32 * 33 + 4 * 32) * sizeof(double);
     for (int wpc : {1, 2, 4, 8}) {
         const int grid = 256 * wpc;
-        for (int it = 0; it < 2; ++it) factor_bench<<<grid, 64, lds>>>(out, sink, 32, 8);
-        hipDeviceSynchronize();
         static long long h[maxb];
-        hipMemcpy(h, out, grid * sizeof(long long), hipMemcpyDeviceToHost);
-        double m = 0; for (int i = 0; i < grid; ++i) m += h[i];
-        printf("waves/CU %d: factor_loop32 (n = 32) %.0f cycles = %.0f per step\n", wpc, m / grid, m / grid / 32);
+        for (int which = 0; which < 2; ++which) {
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            const int reps = 64;
+            for (int it = 0; it < 2; ++it) {
+                if (it == 1) hipEventRecord(e0);
+                if (which) factor_bench<1><<<grid, 64, lds>>>(out, sink, 32, reps);
+                else factor_bench<0><<<grid, 64, lds>>>(out, sink, 32, reps);
+                if (it == 1) hipEventRecord(e1);
+            }
+            hipDeviceSynchronize();
+            float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+            hipMemcpy(h, out, grid * sizeof(long long), hipMemcpyDeviceToHost);
+            double m = 0; for (int i = 0; i < grid; ++i) m += h[i];
+            printf("waves/CU %d: %s (n = 32) %.0f cycles = %.0f per column; kernel %.1f us for %d factorisations per wave -> >= %.2f G ticks/s\n", wpc,
+                   which ? "factor_tiles32" : "factor_loop32 ", m / grid, m / grid / 32, ms * 1e3, reps, (m / grid) * reps / (ms * 1e-3) / 1e9);
+        }
     }
     return 0;
 }
