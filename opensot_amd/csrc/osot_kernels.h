@@ -322,9 +322,10 @@ __global__ void __launch_bounds__(1024) osot_order_kernel(const int* cost, int* 
         atomicAdd(&hist[k], 1);
     }
     __syncthreads();
-    if (t == 0) {
+    if (t < 256) {   // start[k] = number of instances with a larger key (descending order); 256 short parallel sums
         int acc = 0;
-        for (int k = 255; k >= 0; --k) { start[k] = acc; acc += hist[k]; }
+        for (int k2 = t + 1; k2 < 256; ++k2) acc += hist[k2];
+        start[t] = acc;
     }
     __syncthreads();
     for (int i = t; i < B; i += 1024) {
@@ -505,13 +506,7 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
             double* bk = U.b[k] + inst * U.m[k];
             double* wk = U.w[k] ? U.w[k] + inst * U.m[k] : nullptr;
             if (wk) for (int r = t; r < tk.rows; r += 64) wk[tk.off + r] = tk.weight;
-            if (tk.kind == 1) {           // Cartesian
-                if (t == 0) {
-                    double b6[6];
-                    cartesian_b(tk.p0 + inst * 12, tk.p1 + inst * 12, tk.p2 ? tk.p2 + inst * 6 : nullptr,
-                                tk.lambda, tk.ogain, b6);
-                    for (int i = 0; i < 6; ++i) bk[tk.off + i] = b6[i];
-                }
+            if (tk.kind == 1) {           // Cartesian: handled below, one lane per task
             } else if (tk.kind == 2) {    // CoM (CoM.cpp:145-149)
                 if (t < 3) bk[tk.off + t] = (tk.p2 ? tk.p2[inst * 3 + t] : 0.0) +
                                             tk.lambda * (tk.p1[inst * 3 + t] - tk.p0[inst * 3 + t]);
@@ -535,6 +530,28 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
             } else {                      // Generic: b supplied
                 for (int r = t; r < tk.rows; r += 64) bk[tk.off + r] = tk.p0[inst * tk.rows + r];
             }
+        }
+    }
+    // ---- Cartesian tasks, ONE LANE PER TASK: the pose error (Cartesian.cpp:190-240: position difference +
+    // quaternion orientation error) is a chain of ~200 dependent fp64 operations; run one after the other on lane 0
+    // the four end-effector tasks of BASELINE config 3 made this kernel latency-bound (18 us for 3 MB of traffic).
+    // The task table is walked uniformly (scalar loads) and each lane keeps the parameters of "its" task.
+    {
+        const double *cp0 = nullptr, *cp1 = nullptr, *cp2 = nullptr;
+        double* cb = nullptr;
+        double clam = 0.0, cog = 0.0;
+        for (int j = 0; j < U.ntasks; ++j) {
+            const DevTask& tk = U.task[j];
+            if (tk.kind == 1 && t == j) {
+                cp0 = tk.p0; cp1 = tk.p1; cp2 = tk.p2;
+                cb = U.b[tk.level] + inst * U.m[tk.level] + tk.off;
+                clam = tk.lambda; cog = tk.ogain;
+            }
+        }
+        if (cb) {
+            double b6[6];
+            cartesian_b(cp0 + inst * 12, cp1 + inst * 12, cp2 ? cp2 + inst * 6 : nullptr, clam, cog, b6);
+            for (int i = 0; i < 6; ++i) cb[i] = b6[i];
         }
     }
     // ---- box: min/max merge (constraints::Aggregated, Aggregated.cpp:141-148)
