@@ -159,14 +159,24 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
 #pragma unroll
                 for (int C2 = 0; C2 < 2; ++C2) Ht[I][C2] = v4f64{0.0, 0.0, 0.0, 0.0};
             double gp0 = 0.0, gp1 = 0.0;
-            for (int r0 = 0; r0 < ma; r0 += 4) {
+            // software-pipelined: the loads of rows r0+4 .. r0+7 are issued before the MFMAs of rows r0 .. r0+3
+            auto fetch = [&](int r0, double& a0, double& a1, double& wr, double& br) {
                 const int r = r0 + tq;
                 const bool in = r < ma;
                 const int rr = in ? r : ma - 1;
-                const double a0 = (in && ta < n) ? Ak[rr * n + ta] : 0.0;
-                const double a1 = (in && 16 + ta < n) ? Ak[rr * n + ((16 + ta < n) ? 16 + ta : 0)] : 0.0;
-                const double wr = in ? (wk ? wk[rr] : 1.0) : 0.0;
-                const double br = bk[rr];
+                const double v0 = Ak[rr * n + ((ta < n) ? ta : 0)];
+                const double v1 = Ak[rr * n + ((16 + ta < n) ? 16 + ta : 0)];
+                const double wv = wk ? wk[rr] : 1.0;
+                br = bk[rr];
+                a0 = (in && ta < n) ? v0 : 0.0;
+                a1 = (in && 16 + ta < n) ? v1 : 0.0;
+                wr = in ? wv : 0.0;
+            };
+            double na0, na1, nwr, nbr;
+            fetch(0, na0, na1, nwr, nbr);
+            for (int r0 = 0; r0 < ma; r0 += 4) {
+                const double a0 = na0, a1 = na1, wr = nwr, br = nbr;
+                if (r0 + 4 < ma) fetch(r0 + 4, na0, na1, nwr, nbr);
                 const double wa0 = wr * a0, wa1 = wr * a1;
                 gp0 = fma(-wa0, br, gp0);
                 gp1 = fma(-wa1, br, gp1);

@@ -609,16 +609,31 @@ __device__ inline int nullspace_equalities32(const WaveCtx<32>& w, int n_eq, dou
     double* M2 = w.M2;
     int* pivcol = reinterpret_cast<int*>(w.V + 3 * 32);   // idle staging vector: pivot column of each row (32 ints)
     // ---- E -> registers: Er[ii] = E[2ii+h][c] (lane = column, rows split over the halves) ------------------------
-    // (branch-free: rows beyond n_eq re-read row 0 and are zeroed afterwards, so the sixteen
-    //  eqlist -> row pointer -> HBM/L2 chains are all in flight together instead of one after the other)
+    // Three passes so that the sixteen eqlist -> row pointer -> HBM/L2 chains are in flight TOGETHER: all row
+    // pointers, then all loads (unconditional: a unit row reads the harmless safe_row), then the selects.  Written
+    // as sixteen calls of row_elem the compiler sinks every load into its "not a unit row" branch and waits for
+    // each one in turn (16 round trips, ~10 k cycles).
     double Er[16];
+    {
+        unsigned long long rp[16];
 #pragma unroll
-    for (int ii = 0; ii < 16; ++ii) {
-        const int r = 2 * ii + h;
-        Er[ii] = row_elem<32>(w, w.eqlist[(r < n_eq) ? r : 0], c);
+        for (int ii = 0; ii < 16; ++ii) {
+            const int r = 2 * ii + h;
+            rp[ii] = w.rptr[w.eqlist[(r < n_eq) ? r : 0]];
+        }
+        const int cc = valid ? c : 0;
+#pragma unroll
+        for (int ii = 0; ii < 16; ++ii)
+            Er[ii] = OSOT_GLOBAL_F64((rp[ii] & 1ull) ? w.safe_row : rp[ii])[cc];
+        OSOT_KEEP16(Er);
+#pragma unroll
+        for (int ii = 0; ii < 16; ++ii) {
+            const bool unit = (rp[ii] & 1ull) != 0ull;
+            const double uv = (c == (int)(rp[ii] >> 1)) ? 1.0 : 0.0;
+            const double v = unit ? uv : (valid ? Er[ii] : 0.0);
+            Er[ii] = (2 * ii + h < n_eq) ? v : 0.0;
+        }
     }
-#pragma unroll
-    for (int ii = 0; ii < 16; ++ii) Er[ii] = (2 * ii + h < n_eq) ? Er[ii] : 0.0;
     double emax = 0.0;
 #pragma unroll
     for (int ii = 0; ii < 16; ++ii) emax = fmax(emax, fabs(Er[ii]));

@@ -17,6 +17,11 @@
 // LDS declarations (the emulation in tests/emu maps these onto host memory)
 #define OSOT_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define OSOT_STATIC_LDS(type, name, count) __shared__ type name[count]
+// "these sixteen values are needed now": an empty asm that reads and rewrites them.  Placed after a batch of loads
+// it stops the compiler from sinking each load into the branch that uses it (which would serialise the batch into
+// sixteen round trips) and makes it wait once, for all of them.
+#define OSOT_KEEP16(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), \
+                                         "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]))
 // call-site inlining (statement attribute): used where ONE instantiation of a template must be inlined
 #define OSOT_ALWAYS_INLINE_CALL [[clang::always_inline]]
 // a 64-bit integer that holds an HBM address -> pointer in the global address space (global_load, not flat_load)

@@ -10,6 +10,7 @@
 #define OSOT_DYNAMIC_LDS(name) char* name = emu::dyn_smem_ptr()
 #define OSOT_STATIC_LDS(type, name, count) static type name[count]
 #define OSOT_ALWAYS_INLINE_CALL
+#define OSOT_KEEP16(a) do { } while (0)
 #define OSOT_GLOBAL_F64(addr) (reinterpret_cast<const double*>(addr))
 
 namespace osot {
