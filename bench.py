@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=4096)
     ap.add_argument("--config", default="C3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cycles", type=int, default=4,
+                    help="distinct, temporally coherent control cycles the steps rotate through (SURVEY 8d: cycle t+1 = "
+                         "cycle t + 1 %% perturbation of every input, Jacobians included); 1 = repeat one cycle")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,11 +103,27 @@ def main():
     # every rank generates only its own shard (seed = 1000*config + rank)
     plan, leaf = synth.make_velocity_stack(args.config, Bl, seed=3000 + rank)
     st = BatchedStack(plan, Bl, device=local_rank, want_levels=False)
-    dev_leaf = st.load_leaf(leaf)
+    # K temporally coherent cycles (MPC-rollout-like): each is the previous one with every float input moved by
+    # ~1 %.  The Jacobians change too: every cycle has its own A_k buffers (the kinematics producer's output) and the
+    # stack just points at them -- nothing is copied inside a step.
+    K = max(1, args.cycles)
+    rng = np.random.default_rng(77 + rank)
+    leaves = [leaf]
+    for _ in range(K - 1):
+        leaves.append(synth.perturb(leaves[-1], rng, 0.01))
+    dev_leaves, A_sets = [], []
+    for lf in leaves:
+        st.A = [None if a is None else torch.empty_like(a) for a in st.A]
+        dev_leaves.append(st.load_leaf(lf))
+        A_sets.append(st.A)
     gathered = torch.empty((Bg, plan.n), dtype=torch.float64, device=st.device) if world > 1 else None
+    state = {"i": 0}
 
     def step():
-        st.update(dev_leaf)
+        i = state["i"] % K
+        state["i"] += 1
+        st.A = A_sets[i]
+        st.update(dev_leaves[i])
         st.solve(Bl)
         if world > 1:
             dist.all_gather_into_tensor(gathered, st.dq[:Bl])
@@ -160,7 +179,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[2]: batch={Bl}/GPU x 32-DoF, 3-level iHQP "
                                    "(CoM / l_wrist(0.1)+r_wrist+l_sole+r_sole / Postural), joint-limit & "
-                                   "velocity-limit box, eps factor 1e6; step = AutoStack::update + cascade solve"
+                                   "velocity-limit box, eps factor 1e6; step = AutoStack::update + cascade solve; "
+                                   f"steps rotate through {K} temporally coherent cycles (1 % input drift per cycle)"
                                    + ("; + RCCL all-gather of dq" if world > 1 else ""),
                        "global_batch": Bg, "n_dof": plan.n, "levels": plan.L,
                        "rows_per_level": [plan.m(k) for k in range(plan.L)],

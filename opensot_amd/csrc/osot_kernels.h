@@ -159,7 +159,6 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
 #pragma unroll
                 for (int C2 = 0; C2 < 2; ++C2) Ht[I][C2] = v4f64{0.0, 0.0, 0.0, 0.0};
             double gp0 = 0.0, gp1 = 0.0;
-            // software-pipelined: the loads of rows r0+4 .. r0+7 are issued before the MFMAs of rows r0 .. r0+3
             auto fetch = [&](int r0, double& a0, double& a1, double& wr, double& br) {
                 const int r = r0 + tq;
                 const bool in = r < ma;
@@ -172,18 +171,29 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
                 a1 = (in && 16 + ta < n) ? v1 : 0.0;
                 wr = in ? wv : 0.0;
             };
-            double na0, na1, nwr, nbr;
-            fetch(0, na0, na1, nwr, nbr);
-            for (int r0 = 0; r0 < ma; r0 += 4) {
-                const double a0 = na0, a1 = na1, wr = nwr, br = nbr;
-                if (r0 + 4 < ma) fetch(r0 + 4, na0, na1, nwr, nbr);
-                const double wa0 = wr * a0, wa1 = wr * a1;
-                gp0 = fma(-wa0, br, gp0);
-                gp1 = fma(-wa1, br, gp1);
-                Ht[0][0] = mfma_f64_16x16x4(wa0, a0, Ht[0][0]);
-                Ht[0][1] = mfma_f64_16x16x4(wa0, a1, Ht[0][1]);
-                Ht[1][1] = mfma_f64_16x16x4(wa1, a1, Ht[1][1]);
+            // 32 rows at a time: all eight groups of four rows are requested before the first MFMA (32 fp64
+            // registers in flight): one HBM/L2 round trip per 32 rows instead of one per group
+            for (int rb = 0; rb < ma; rb += 32) {
+                double ca0[8], ca1[8], cwr[8], cbr[8];
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) {
+                    ca0[ch] = 0.0; ca1[ch] = 0.0; cwr[ch] = 0.0; cbr[ch] = 0.0;
+                    if (rb + 4 * ch < ma) fetch(rb + 4 * ch, ca0[ch], ca1[ch], cwr[ch], cbr[ch]);
+                }
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) {
+                    if (rb + 4 * ch < ma) {
+                        const double a0 = ca0[ch], a1 = ca1[ch], wr = cwr[ch], br = cbr[ch];
+                        const double wa0 = wr * a0, wa1 = wr * a1;
+                        gp0 = fma(-wa0, br, gp0);
+                        gp1 = fma(-wa1, br, gp1);
+                        Ht[0][0] = mfma_f64_16x16x4(wa0, a0, Ht[0][0]);
+                        Ht[0][1] = mfma_f64_16x16x4(wa0, a1, Ht[0][1]);
+                        Ht[1][1] = mfma_f64_16x16x4(wa1, a1, Ht[1][1]);
+                    }
+                }
             }
+            OSOT_PH_END(PH_INV);   // (profiling slot reused: MFMA loop of the H build)
             // g: the partial sums of a column sit in the four rows of 16 lanes
             gp0 = rowgroup_sum(gp0);
             gp1 = rowgroup_sum(gp1);
@@ -199,6 +209,7 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Ht[I][I][r] += (ta == tq + 4 * r) ? dv : 0.0;
             }
+            OSOT_PH_END(PH_SUBST);   // (profiling slot reused: g reduction + diagonal of the H build)
             // the factorisation (factor_tiles32) works on the tiles as they are: hacc[4 (2 I + C) + r]
 #pragma unroll
             for (int I = 0; I < 2; ++I)

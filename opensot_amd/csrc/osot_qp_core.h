@@ -343,7 +343,10 @@ __device__ inline int factor_loop32(const WaveCtx<32>& w, double (&Hc)[16], doub
 //     is the A operand (m = row-in-tile, k = panel column) AND the B operand of every tile.  13 + 13 MFMAs per
 //     factorisation replace 32 x (16 LDS broadcasts + 32 VALU FMAs).  The (1,0) tile of H is never needed.
 // In : Ht (H + eps I with a unit diagonal beyond n), g by lane c.   Out: M1 = L, M2 = JT = L^-1, x = -(H+eps I)^-1 g.
-__device__ inline int factor_tiles32(const WaveCtx<32>& w, double (&Hf)[16], double g, double& x_out) {
+template <bool TT = false>
+__device__ inline int factor_tiles32(const WaveCtx<32>& w, double (&Hf)[16], double g, double& x_out, long long* tt = nullptr) {
+    long long tt0 = TT ? (long long)clock64() : 0;
+#define OSOT_TT(i) do { if (TT) { const long long t_ = (long long)clock64(); tt[i] += t_ - tt0; tt0 = t_; } } while (0)
     constexpr int S = WaveCtx<32>::S;
     const int c = w.c, n = w.n;
     const int lane = c + 32 * w.h;
@@ -418,6 +421,7 @@ __device__ inline int factor_tiles32(const WaveCtx<32>& w, double (&Hf)[16], dou
             if (p >= 4) L11 = mfma_f64_16x16x4(A1, Rp[1], L11);
         }
     }
+    OSOT_TT(0);   // panels
     // JT = L^-1 (the upper right tile is zero)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -428,6 +432,7 @@ __device__ inline int factor_tiles32(const WaveCtx<32>& w, double (&Hf)[16], dou
     }
     wave_sync();
     if (bad) { x_out = 0.0; return QP_NOT_PD; }
+    OSOT_TT(1);   // L^-1 store
     // L y = -g, then L'x = y, by substitution; columns / rows of L are fetched eight at a time ahead of the chain
     const double invd = Vd[c];
     double rhs = valid ? -g : 0.0;
@@ -442,6 +447,7 @@ __device__ inline int factor_tiles32(const WaveCtx<32>& w, double (&Hf)[16], dou
             rhs = (c == j) ? yj : fma(-lcol[t], yj, rhs);
         }
     }
+    OSOT_TT(2);   // forward substitution
     double x = 0.0;
     for (int i0 = 24; i0 >= 0; i0 -= 8) {
         double lrow[8];
@@ -456,6 +462,8 @@ __device__ inline int factor_tiles32(const WaveCtx<32>& w, double (&Hf)[16], dou
         }
     }
     wave_sync();
+    OSOT_TT(3);   // backward substitution
+#undef OSOT_TT
     x_out = valid ? x : 0.0;
     return QP_SOLVED;
 }

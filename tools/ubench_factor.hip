@@ -14,6 +14,7 @@ __global__ void __launch_bounds__(64, 2) factor_bench(long long* out, double* si
     w.M1 = base; w.M2 = base + 32 * S; w.V = base + 2 * 32 * S;
     double acc = 0.0;
     long long total = 0;
+    long long tt[4] = {0, 0, 0, 0};
     for (int r = 0; r < reps; ++r) {
         double Hc[16];
 #pragma unroll
@@ -32,19 +33,20 @@ __global__ void __launch_bounds__(64, 2) factor_bench(long long* out, double* si
         double x;
         wave_sync();
         const long long t0 = clock64();
-        const int st = (WHICH == 1) ? factor_tiles32(w, Hc, 1.0 + w.c, x) : factor_loop32(w, Hc, 1.0 + w.c, x);
+        const int st = (WHICH == 1) ? factor_tiles32<true>(w, Hc, 1.0 + w.c, x, tt) : factor_loop32(w, Hc, 1.0 + w.c, x);
         const long long t1 = clock64();
         total += t1 - t0;
         acc += x + st;
     }
     if (threadIdx.x == 0) out[blockIdx.x] = total / reps;
+    if (threadIdx.x == 0 && blockIdx.x == 0 && WHICH == 1) for (int i = 0; i < 4; ++i) out[gridDim.x + i] = tt[i] / reps;
     sink[blockIdx.x * 64 + threadIdx.x] = acc;
 }
 
 int main() {
     long long* out; double* sink;
     const int maxb = 256 * 8;
-    hipMalloc(&out, maxb * sizeof(long long));
+    hipMalloc(&out, (maxb + 8) * sizeof(long long));
     hipMalloc(&sink, maxb * 64 * sizeof(double));
     const size_t lds = (2 * 32 * 33 + 4 * 32) * sizeof(double);
     for (int wpc : {1, 2, 4, 8}) {
@@ -63,6 +65,8 @@ int main() {
             float ms = 0; hipEventElapsedTime(&ms, e0, e1);
             hipMemcpy(h, out, grid * sizeof(long long), hipMemcpyDeviceToHost);
             double m = 0; for (int i = 0; i < grid; ++i) m += h[i];
+            if (which) { long long t4[4]; hipMemcpy(t4, out + grid, sizeof(t4), hipMemcpyDeviceToHost);
+                printf("    panels %lld  L^-1 store %lld  forward %lld  backward %lld\n", t4[0], t4[1], t4[2], t4[3]); }
             printf("waves/CU %d: %s (n = 32) %.0f cycles = %.0f per column; kernel %.1f us for %d factorisations per wave -> >= %.2f G ticks/s\n", wpc,
                    which ? "factor_tiles32" : "factor_loop32 ", m / grid, m / grid / 32, ms * 1e3, reps, (m / grid) * reps / (ms * 1e-3) / 1e9);
         }
