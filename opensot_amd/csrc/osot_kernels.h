@@ -145,7 +145,22 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
         double g = 0.0, hdiag = 0.0;
         const bool diag_h = (ma == 0);
         double hacc[NP / HV];
-        if (!diag_h) {
+        bool lowrank = false;   // few stored rows: J and x in closed form, no H, no factorisation (lowrank_prepare32)
+        double xprep = 0.0;
+        if constexpr (NP == 32) {
+            if (!diag_h && ma <= kLowRankMax) {
+                lowrank = true;
+                const int npost = m - ma;
+                const bool postc = valid && c < npost;
+                const double wpost = postc ? (wk ? wk[ma + c] : 1.0) : 0.0;
+                double cvec = (D.c[k] && valid) ? D.c[k][inst * n + c] : 0.0;
+                if (postc) cvec -= wpost * bk[ma + c];
+                lowrank_prepare32(reinterpret_cast<const WaveCtx<32>&>(w), Ak, bk, wk, ma, P.eps_abs + wpost, cvec,
+                                  D.c[k] != nullptr || npost > 0, xprep);
+            }
+        }
+        if (lowrank) {
+        } else if (!diag_h) {
           if constexpr (NP == 32) {
             // ---- H = A'WA + eps I on the fp64 MATRIX CORE, g = -A'Wb + c.  Four rows of A per step: lane
             // l = (a, q) = (l & 15, l >> 4) loads A[r0 + q][a] and A[r0 + q][16 + a] (two coalesced loads cover the
@@ -276,7 +291,7 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
             hdiag = wi + P.eps_abs;
             g = inb ? -wi * bk[c] : 0.0;
         }
-        if (D.c[k] && valid) g += D.c[k][inst * n + c];
+        if (D.c[k] && valid && !lowrank) g += D.c[k][inst * n + c];
 
         const int nrows = P.nc + P.optoff[k];
         int iters = 0;
@@ -287,7 +302,7 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
                                                                    has_box, lb, ub, P.max_iter, any, x, x, iters, prof);
         } else {          // NP = 32: the inliner's own order keeps the kernel free of vector spills
             st = gi_solve<NP, PROF, FULLN>(w, nrows, g, diag_h, hdiag, hacc,
-                                           has_box, lb, ub, P.max_iter, any, x, x, iters, prof);
+                                           has_box, lb, ub, P.max_iter, any, x, x, iters, prof, lowrank, xprep);
         }
         if (PROF) ph_t0_ = (long long)clock64();
         iters_total += iters;

@@ -754,11 +754,172 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                                int iters, bool has_box, double lb, double ub, int max_iter, bool diag_dd, double hinv,
                                double& x_out, int& iters_out, long long* prof);
 
+// ---------------------------------------------------------------------------------------------------------
+// Low-rank level (NP = 32):  H + eps I = D + A'WA with D diagonal and at most kLowRankMax stored rows
+// (a CoM task: 3 rows in 32 variables; the Postural weights of the level, if any, and eps are D).
+// Goldfarb-Idnani only needs SOME J with J J' = (H + eps I)^-1, not the Cholesky one.  In the scaled variables
+// xh = D^1/2 x the Hessian is I + Ah'Ah, Ah = W^1/2 A D^-1/2 = Rh Qh (modified Gram-Schmidt of the m rows,
+// Qh orthonormal rows, Rh lower triangular m x m), so with M = Rh'Rh and I + M = Lh Lh':
+//     (I + Ah'Ah)^-1 = (I - Qh'Qh) + Qh'(I + M)^-1 Qh      and      Jh = I + Qh'(Lh^-T - I) Qh  satisfies Jh Jh' = that,
+//     J = D^-1/2 Jh,     xh = -(I - Qh'Qh) ch + Qh'(I + M)^-1 (Rh' W^1/2 b - Qh ch),    ch = D^-1/2 c
+// (c collects the level's linear term and the Postural rows' -w_i b_i).  No cancellation: the b part never forms
+// A'Wb.  Cost: m(m+1)/2 reductions, an m x m Cholesky in uniform scalars and a rank-m update of the identity,
+// instead of the n x n x m product and a 32-column factorisation.  A numerically dependent row is dropped.
+// Out: M2 = JT (M2[j][c] = J[c][j]), x; M1 is used as staging.
+constexpr int kLowRankMax = 4;
+__device__ inline void lowrank_prepare32(const WaveCtx<32>& w, const double* Ak, const double* bk, const double* wk,
+                                         int m, double dcol, double cvec, bool has_c, double& x_out) {
+    constexpr int S = WaveCtx<32>::S, MM = kLowRankMax;
+    const int c = w.c, h = w.h, n = w.n;
+    const bool valid = c < n;
+    double* M1 = w.M1;
+    double* M2 = w.M2;
+    double dsq, dis;   // sqrt(d_c), 1 / sqrt(d_c)
+    fast_sqrt_rsqrt(valid ? dcol : 1.0, dsq, dis);
+    double q[MM], bt[MM], Rm[MM][MM];
+#pragma unroll
+    for (int r = 0; r < MM; ++r) {
+        const int rr = (r < m) ? r : 0;
+        const double wr = wk ? wk[rr] : 1.0;
+        double sw, isw;
+        fast_sqrt_rsqrt((wr > 0.0) ? wr : 1.0, sw, isw);
+        sw = (wr > 0.0 && r < m) ? sw : 0.0;
+        q[r] = valid ? sw * Ak[rr * n + c] * dis : 0.0;
+        bt[r] = sw * bk[rr];
+#pragma unroll
+        for (int s2 = 0; s2 < MM; ++s2) Rm[r][s2] = 0.0;
+    }
+    // modified Gram-Schmidt of the rows (lane = column, replicated over the halves)
+#pragma unroll
+    for (int r = 0; r < MM; ++r) {
+        if (r < m) {
+            double v = q[r];
+            const double n0 = colsum<32>(v * v);
+#pragma unroll
+            for (int s2 = 0; s2 < r; ++s2) {
+                const double d = colsum<32>(q[s2] * v);
+                Rm[r][s2] = d;
+                v = fma(-d, q[s2], v);
+            }
+            const double nn = (r == 0) ? n0 : colsum<32>(v * v);
+            if (nn > 1.0e-24 * n0 && nn > 0.0) {
+                double sq, rs;
+                fast_sqrt_rsqrt(nn, sq, rs);
+                Rm[r][r] = sq;
+                q[r] = v * rs;
+            } else {
+                q[r] = 0.0;   // dependent (or zero) row: nothing new in its direction
+            }
+        } else {
+            q[r] = 0.0;
+        }
+    }
+    // I + M = Lh Lh'  (uniform scalars);  Y = Lh^-T;  Dh = Y - I
+    double Lh[MM][MM], Y[MM][MM];
+#pragma unroll
+    for (int i = 0; i < MM; ++i)
+#pragma unroll
+        for (int j = 0; j < MM; ++j) {
+            double acc = (i == j) ? 1.0 : 0.0;
+            if (j <= i) {
+#pragma unroll
+                for (int r = 0; r < MM; ++r) acc = fma(Rm[r][i], Rm[r][j], acc);   // (I + Rh'Rh)[i][j]
+            }
+            Lh[i][j] = (j <= i) ? acc : 0.0;
+        }
+    double ild[MM];   // 1 / Lh[i][i]
+#pragma unroll
+    for (int j = 0; j < MM; ++j) {
+        double sq, rs;
+        fast_sqrt_rsqrt(Lh[j][j], sq, rs);   // >= 1
+        Lh[j][j] = sq;
+        ild[j] = rs;
+#pragma unroll
+        for (int i = j + 1; i < MM; ++i) Lh[i][j] *= rs;
+#pragma unroll
+        for (int i = j + 1; i < MM; ++i)
+#pragma unroll
+            for (int k = j + 1; k <= i; ++k) Lh[i][k] = fma(-Lh[i][j], Lh[k][j], Lh[i][k]);
+    }
+    // Y = Lh^-T (upper triangular): column by column of Lh^-1, transposed
+#pragma unroll
+    for (int i = 0; i < MM; ++i)
+#pragma unroll
+        for (int j = 0; j < MM; ++j) Y[i][j] = 0.0;
+#pragma unroll
+    for (int col = 0; col < MM; ++col) {      // Linv[:, col] by forward substitution; Y[col][i] = Linv[i][col]
+#pragma unroll
+        for (int i = col; i < MM; ++i) {
+            double acc = (i == col) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = col; k < i; ++k) acc = fma(-Lh[i][k], Y[col][k], acc);
+            Y[col][i] = acc * ild[i];
+        }
+    }
+    // t = Rh' bt - Qh ch;  u = (I + M)^-1 t = Y (Y' t)
+    const double ch = valid ? cvec * dis : 0.0;
+    double Qc[MM], t[MM], u[MM];
+#pragma unroll
+    for (int s2 = 0; s2 < MM; ++s2) {
+        Qc[s2] = (has_c && s2 < m) ? colsum<32>(q[s2] * ch) : 0.0;
+        double acc = -Qc[s2];
+#pragma unroll
+        for (int r = 0; r < MM; ++r) acc = fma(Rm[r][s2], bt[r], acc);
+        t[s2] = acc;
+    }
+    {
+        double yt[MM];
+#pragma unroll
+        for (int i = 0; i < MM; ++i) {      // yt = Y' t   (Y' = Lh^-1, lower triangular: Y'[i][k] = Y[k][i])
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k <= i; ++k) acc = fma(Y[k][i], t[k], acc);
+            yt[i] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < MM; ++i) {      // u = Y yt
+            double acc = 0.0;
+#pragma unroll
+            for (int k = i; k < MM; ++k) acc = fma(Y[i][k], yt[k], acc);
+            u[i] = acc;
+        }
+    }
+    double xh = -ch;
+#pragma unroll
+    for (int s2 = 0; s2 < MM; ++s2) xh = fma(q[s2], u[s2] + Qc[s2], xh);
+    x_out = valid ? xh * dis : 0.0;
+    // J: F[s](c) = sum_r q[r](c) (Y - I)[r][s];  JT[j][c] = J[c][j] = dis_c (delta_cj + sum_s F[s](c) q[s](j))
+    double F[MM];
+#pragma unroll
+    for (int s2 = 0; s2 < MM; ++s2) {
+        double acc = 0.0;
+#pragma unroll
+        for (int r = 0; r < MM; ++r) acc = fma(q[r], Y[r][s2] - ((r == s2) ? 1.0 : 0.0), acc);
+        F[s2] = acc * dis;
+    }
+    wave_sync();
+    if (h == 0) {
+#pragma unroll
+        for (int s2 = 0; s2 < MM; ++s2) M1[s2 * S + c] = q[s2];
+    }
+    wave_sync();
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = 2 * jj + h;
+        double acc = (j == c) ? dis : 0.0;
+#pragma unroll
+        for (int s2 = 0; s2 < MM; ++s2) acc = fma(F[s2], M1[s2 * S + j], acc);
+        M2[j * S + c] = acc;
+    }
+    wave_sync();
+}
+
 // Pre (general H):  Hc[ii] = (H + eps I)[HV*ii+h][c] in registers (see factor_loop32 / factor_rows64), M1 is scratch.
 template <int NP, bool PROF, bool FULLN>
 __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_h,
                         double hdiag, double (&Hc)[NP / (64 / NP)], bool has_box, double lb, double ub, int max_iter,
-                        bool have_prev, double xprev, double& x_out, int& iters_out, long long* prof) {
+                        bool have_prev, double xprev, double& x_out, int& iters_out, long long* prof,
+                        bool prepared = false, double xprep = 0.0) {
     constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
     const int n = w_in.n;
     double* M1 = w_in.M1;
@@ -776,7 +937,11 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
     const int c = w.c, h = w.h;
     const bool valid = c < n;
 
-    if (diag_h) {
+    if (prepared) {
+        // JT is in M2 and the unconstrained minimiser is known already (lowrank_prepare32)
+        x = xprep;
+        OSOT_PH_END(PH_CHOL);
+    } else if (diag_h) {
         // H + eps I diagonal (a level made of a Postural block only): L = sqrt(diag), JT = diag(1/L)
         const bool okd = !valid || (hdiag > 0.0);
         if (colsum<NP>(okd ? 0.0 : 1.0) != 0.0) { x_out = 0.0; iters_out = 0; return QP_NOT_PD; }
