@@ -662,11 +662,13 @@ __device__ inline int nullspace_equalities32(const WaveCtx<32>& w, int n_eq, dou
             const int k = 2 * r + hk;
             if (k < n_eq) {
                 const double v = from_half<32>(Er[0], hk);            // row k at my column, in both halves
-                const double cand = (valid && !basic) ? fabs(v) : -1.0;
-                const double pmax = colmax<32>(cand);
+                // the search runs on fp32 keys (one DPP-modified v_max_f32 per stage instead of two DPP moves and
+                // a v_max_f64): a pivot within 1e-7 of the largest is as good as the largest
+                const float cand = (valid && !basic) ? (float)fabs(v) : -1.0f;
+                const float pmax = colmax_f32<32>(cand);
                 int pk = -1;
-                if (pmax > tol) {
-                    const int pcol = first_lane_equal(cand, pmax) & 31;
+                if ((double)pmax > tol && pmax > 0.0f) {
+                    const int pcol = first_lane_equal_f32(cand, pmax) & 31;
                     pk = pcol;
                     const double rowk = v * fast_rcp(bcast(v, pcol));
                     const int src = pcol + 32 * h;
@@ -1022,7 +1024,10 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
         const double resid = lo + colsum<NP>(a * (xref - x));
         OSOT_SUB_END(PH_EQ_RED);
         if (!(nd2 > kDepTol2 * dd)) {   // row is (numerically) a combination of the rows already in
-            if (fabs(resid) <= kEqTol * fmax(1.0, fabs(lo))) continue;   // redundant and consistent
+            // an optimality row of an upper level (src >= 0) is consistent BY CONSTRUCTION (x of that level
+            // satisfies all of them, iHQP.cpp:164-170): a residual there is round-off of an ill-conditioned level
+            // (default eps 4.4e-11: O(1e-16 / eps)), never infeasibility
+            if (src >= 0 || fabs(resid) <= kEqTol * fmax(1.0, fabs(lo))) continue;   // redundant and consistent
             x_out = x; iters_out = iters; return QP_INFEASIBLE;
         }
         if (h == 0) V1[c] = d2;
@@ -1066,17 +1071,22 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
     // the stored rows that can ever be violated (not equalities, at least one finite bound), in row order;
     // the equality list is dead by now, its LDS array is reused
     int n_gen = 0;
+    bool any_unit = false;   // is there a unit row that can ever be violated?  (none: its pass is skipped)
     for (int r0 = 0; r0 < nrows; r0 += 64) {
         const int r = r0 + c + NP * h;
-        bool is_gen = false;
+        bool is_gen = false, is_unit = false;
         if (r < nrows) {
             const double lo = w.rlo[r], up = w.rup[r];
-            is_gen = (w.rowstate[r] != 3) && !(w.rptr[r] & 1ull) && ((lo > -kInfty) || (up < kInfty));
+            const bool live = (w.rowstate[r] != 3) && ((lo > -kInfty) || (up < kInfty));
+            const bool unit = (w.rptr[r] & 1ull) != 0ull;
+            is_gen = live && !unit;
+            is_unit = live && unit;
         }
         wave_sync();
         const unsigned long long mask = wave_ballot(is_gen);
         if (is_gen) w.eqlist[n_gen + lanes_below(mask)] = r;
         n_gen += __builtin_popcountll(mask);
+        any_unit = any_unit || (wave_ballot(is_unit) != 0ull);
     }
     wave_sync();
     int status = QP_SOLVED;
@@ -1098,9 +1108,11 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
         }
         // unit rows (implicit e_i rows: acceleration joint/velocity limits) are checked 64 rows at a time,
         // lane = row, against a staged copy of x: they cost no reduction at all
-        if (nrows > 0) {
+        if (any_unit || n_gen > 0) {
             if (h == 0) V0[c] = x;
             wave_sync();
+        }
+        if (any_unit) {
             const int lane = c + NP * h;
             for (int r0 = 0; r0 < nrows; r0 += 64) {
                 const int r = r0 + lane;

@@ -13,6 +13,7 @@
 // execute the kernel bodies without a GPU; it is test infrastructure, never part of the product build.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 // LDS declarations (the emulation in tests/emu maps these onto host memory)
 #define OSOT_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]
@@ -141,6 +142,25 @@ __device__ __forceinline__ double colmax(double v) {
     v = fmax(a, b);
     if (NP == 64) { swap32_pair(v, a, b); v = fmax(a, b); }
     return v;
+}
+template <int NP>
+__device__ __forceinline__ float colmax_f32(float v) {
+    auto dppf = [](float x, auto ctrl) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), decltype(ctrl)::value, 0xF, 0xF, false));
+    };
+    v = fmaxf(v, dppf(v, std::integral_constant<int, DPP_XOR1>{}));
+    v = fmaxf(v, dppf(v, std::integral_constant<int, DPP_XOR2>{}));
+    v = fmaxf(v, dppf(v, std::integral_constant<int, DPP_HALF_MIRROR>{}));
+    v = fmaxf(v, dppf(v, std::integral_constant<int, DPP_MIRROR>{}));
+    int a, b;
+    swap16_pair_i(__float_as_int(v), a, b);
+    v = fmaxf(__int_as_float(a), __int_as_float(b));
+    if (NP == 64) { swap32_pair_i(__float_as_int(v), a, b); v = fmaxf(__int_as_float(a), __int_as_float(b)); }
+    return v;
+}
+__device__ __forceinline__ int first_lane_equal_f32(float v, float m) {
+    const unsigned long long mask = wave_ballot(v == m);
+    return mask ? __builtin_ctzll(mask) : 64;
 }
 // lowest lane whose value equals the (already reduced) extremum m; 64 if none (NaN)
 __device__ __forceinline__ int first_lane_equal(double v, double m) {

@@ -271,3 +271,32 @@ def make_generic_stack(B, n, level_rows, n_eq=0, n_ineq=0, seed=0, box=0.5, dupl
         bounds.append(Bound(abi.BOUND_GENERIC, name="box")); bleaf.append((np.full((B, n), -box), np.full((B, n), box), None))
     plan = StackPlan(n=n, levels=levels, bounds=bounds, rowblocks=rowblocks, eps_abs=eps_abs_from_factor(eps_factor))
     return plan, {"B": B, "A": A, "task": tleaf, "bound": bleaf, "rows": rleaf}
+
+
+def make_lowrank_stack(B, n, m=3, seed=0, weight=0.3, postural_weight=None, dependent=False, zero_row=False,
+                       second_level_rows=5, box=0.4, eps_factor=1e6):
+    """a level with only a few stored rows (the closed-form low-rank path of the cascade kernel): m <= 4 generic
+    rows with a non-unit weight, optionally sharing the level with a weighted Postural block (soft priority, as in
+    coman_ik.cpp:429), optionally with a linearly dependent or an all-zero row; a second generic level and a box."""
+    rng = np.random.default_rng(seed)
+    A0 = rng.normal(0.0, 0.4, size=(B, m, n))
+    b0 = rng.normal(0.0, 0.05, size=(B, m))
+    if dependent and m >= 2:
+        A0[:, m - 1] = 2.0 * A0[:, 0]          # dependent direction (inconsistent right-hand side: least squares)
+    if zero_row:
+        A0[:, min(1, m - 1)] = 0.0
+    lev0 = [Task(abi.TASK_GENERIC, m, weight=weight, name="few_rows")]
+    leaf0 = [(b0, None, None)]
+    if postural_weight is not None:
+        q = rng.uniform(-1, 1, size=(B, n))
+        lev0.append(Task(abi.TASK_POSTURAL, n, weight=postural_weight, lam=0.1, name="postural_soft"))
+        leaf0.append((q, q + rng.normal(0, 0.1, size=(B, n)), None))
+    levels, A, tleaf = [lev0], [np.ascontiguousarray(A0)], [leaf0]
+    if second_level_rows:
+        A1 = rng.normal(0.0, 0.4, size=(B, second_level_rows, n))
+        levels.append([Task(abi.TASK_GENERIC, second_level_rows, name="second")])
+        A.append(A1); tleaf.append([(rng.normal(0.0, 0.05, size=(B, second_level_rows)), None, None)])
+    bounds = [Bound(abi.BOUND_GENERIC, name="box")]
+    bleaf = [(np.full((B, n), -box), np.full((B, n), box), None)]
+    plan = StackPlan(n=n, levels=levels, bounds=bounds, rowblocks=[], eps_abs=eps_abs_from_factor(eps_factor))
+    return plan, {"B": B, "A": A, "task": tleaf, "bound": bleaf, "rows": []}

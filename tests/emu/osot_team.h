@@ -68,6 +68,17 @@ template <int NP> inline double colmax(double v) {
     for (int i = 1; i < NP; ++i) m = std::fmax(m, all[h0 + i]);
     return m;
 }
+template <int NP> inline float colmax_f32(float v) {
+    float all[64]; emu::allgather(&v, all, sizeof(float));
+    const int h0 = (emu_lane() / NP) * NP;
+    float m = all[h0];
+    for (int i = 1; i < NP; ++i) m = std::fmax(m, all[h0 + i]);
+    return m;
+}
+inline int first_lane_equal_f32(float v, float m) {
+    const unsigned long long mask = wave_ballot(v == m);
+    return mask ? __builtin_ctzll(mask) : 64;
+}
 inline int first_lane_equal(double v, double m) {
     const unsigned long long mask = wave_ballot(v == m);
     return mask ? __builtin_ctzll(mask) : 64;

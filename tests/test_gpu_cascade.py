@@ -70,3 +70,25 @@ def test_small_generic_cascades_gpu(n, rows, n_eq, n_ineq, dup, oracle, gpu_devi
         rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
         ok = rq["status"] == 1
         assert ok.mean() > 0.9 and np.abs(dq[ok] - rq["dq"][ok]).max() < 1e-6
+
+
+@pytest.mark.parametrize("kw", [dict(m=3), dict(m=4, weight=2.5), dict(m=3, postural_weight=1e-3),
+                                dict(m=3, dependent=True), dict(m=4, zero_row=True, postural_weight=0.05),
+                                dict(m=1, second_level_rows=0), dict(m=2, eps_factor=2e2, postural_weight=1e-3)])
+def test_lowrank_levels_gpu(kw, oracle, gpu_device):
+    """levels with <= 4 stored rows (closed-form J and minimiser, lowrank_prepare32) against the oracle and qpOASES:
+    weights, a Postural block in the same level, a dependent row, a zero row, the default eps factor"""
+    n = 12 if kw.get("m", 3) != 4 else 32
+    plan, leaf = synth.make_lowrank_stack(256, n, seed=11, **kw)
+    asm = oracle.assemble(plan, leaf)
+    dq, xl, status, it, _ = _run(plan, leaf)
+    assert (status == 0).all()
+    degenerate = kw.get("dependent") or kw.get("zero_row")
+    if not degenerate:   # (see test_emulated_kernels.test_lowrank_levels: dependent equalities are pinned by qpOASES only)
+        ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+        okr = ref["status"] == 1
+        assert okr.mean() > 0.9 and np.abs(dq[okr] - ref["dq"][okr]).max() < (1e-9 if kw.get("eps_factor", 1e6) == 1e6 else 1e-7)
+    if oracle.ref_available():
+        rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
+        ok = rq["status"] == 1
+        assert ok.mean() > 0.9 and np.abs(dq[ok] - rq["dq"][ok]).max() < 1e-6

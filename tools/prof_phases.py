@@ -15,3 +15,10 @@ t = cyc[:, 7]
 print("total cycles per instance: mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f" % (t.mean(), np.percentile(t, 50), np.percentile(t, 90), np.percentile(t, 99), t.max()))
 it = st.iterations[:B].cpu().numpy()
 print("iterations: mean %.1f p50 %d p90 %d p99 %d max %d" % (it.mean(), np.percentile(it, 50), np.percentile(it, 90), np.percentile(it, 99), it.max()))
+heavy = it >= np.percentile(it, 99)
+if heavy.any():
+    extra = (it[heavy] - 30).mean()
+    print("instances with >= p99 iterations (%d of them, mean %.1f iterations): in:* cycles per inequality iteration" % (heavy.sum(), it[heavy].mean()))
+    for name, v in zip(st.PHASES[12:], cyc[heavy][:, 12:].mean(axis=0)):
+        print(f"   {name:16s} {v / extra:8.0f}")
+    print("   inequalities total per iteration %.0f" % (cyc[heavy][:, 5].mean() / extra))
