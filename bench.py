@@ -87,8 +87,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with nproc-per-node {args.gpus} (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # (OSOT_BENCH_FORCE_DIST=1 runs the collective path with a world of one: a single-GPU check of the RCCL plumbing)
+    use_dist = world > 1 or os.environ.get("OSOT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
@@ -116,34 +120,66 @@ def main():
         st.A = [None if a is None else torch.empty_like(a) for a in st.A]
         dev_leaves.append(st.load_leaf(lf))
         A_sets.append(st.A)
-    gathered = torch.empty((Bg, plan.n), dtype=torch.float64, device=st.device) if world > 1 else None
+    # The all-gather of the solved dq shards runs on a SIDE stream and is double-buffered: the gather of step t
+    # overlaps the update + solve of step t+1 (which write the other dq buffer); a buffer goes back to the solver only
+    # after the gather that read it has finished (stream-side event waits, the host never blocks).
+    # That variant is OPT-IN (OSOT_BENCH_OVERLAP_GATHER=1): measured with a world of one on a MI355X its extra
+    # host-side calls (events, stream switches) cost 22 us per step against 9 us for the plain gather on the solve
+    # stream, which is therefore the default; at 8 GPUs the gather is ~1 MB per rank (~7-50 us).
+    overlap = use_dist and os.environ.get("OSOT_BENCH_OVERLAP_GATHER") == "1"
+    dq_bufs = [st.dq, torch.empty_like(st.dq)] if overlap else [st.dq]
+    gathered = [torch.empty((Bg, plan.n), dtype=torch.float64, device=st.device) for _ in range(2)] if use_dist else None
+    side = torch.cuda.Stream(device=st.device) if overlap else None
+    main = torch.cuda.current_stream(st.device)
+    solved = [torch.cuda.Event(), torch.cuda.Event()] if overlap else None
+    gathered_ev = [None, None]
     state = {"i": 0}
 
+    def drain():
+        if overlap:
+            main.wait_stream(side)
+
     def step():
-        i = state["i"] % K
+        t = state["i"]
+        i = t % K
+        j = t & 1 if overlap else 0
         state["i"] += 1
+        if overlap:
+            if gathered_ev[j] is not None:
+                main.wait_event(gathered_ev[j])      # the gather that read dq_bufs[j] two steps ago
+            st.dq = dq_bufs[j]
         st.A = A_sets[i]
         st.update(dev_leaves[i])
         st.solve(Bl)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, st.dq[:Bl])
+        if overlap:
+            solved[j].record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(solved[j])
+                dist.all_gather_into_tensor(gathered[j], dq_bufs[j][:Bl])
+                ev = torch.cuda.Event()
+                ev.record(side)
+                gathered_ev[j] = ev
+        elif use_dist:
+            dist.all_gather_into_tensor(gathered[0], st.dq[:Bl])
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     st.set_timing(True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()                      # every gather of the timed steps has completed inside the timed region
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=st.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -155,11 +191,13 @@ def main():
     st.set_schedule(longest_first=False)
     for _ in range(3):
         step()
+    drain()
     torch.cuda.synchronize()
     st.kernel_time_ms()
     t1 = time.perf_counter()
     for _ in range(10):
         step()
+    drain()
     torch.cuda.synchronize()
     inorder_elapsed = (time.perf_counter() - t1) / 10
     inorder_kern_ms, _ = st.kernel_time_ms()
@@ -181,7 +219,7 @@ def main():
                                    "(CoM / l_wrist(0.1)+r_wrist+l_sole+r_sole / Postural), joint-limit & "
                                    "velocity-limit box, eps factor 1e6; step = AutoStack::update + cascade solve; "
                                    f"steps rotate through {K} temporally coherent cycles (1 % input drift per cycle)"
-                                   + ("; + RCCL all-gather of dq" if world > 1 else ""),
+                                   + ("; + RCCL all-gather of dq" + (" on a side stream (double-buffered)" if overlap else "") if use_dist else ""),
                        "global_batch": Bg, "n_dof": plan.n, "levels": plan.L,
                        "rows_per_level": [plan.m(k) for k in range(plan.L)],
                        "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
@@ -224,7 +262,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "solves/s", "cores": 0, "kind": "port",
                                        "sample": f"unavailable: {e}"}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
