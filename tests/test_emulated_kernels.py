@@ -219,3 +219,15 @@ def test_lowrank_levels(kw, oracle):
         assert ok.all() and np.abs(dq[ok] - rq["dq"][ok]).max() < 1e-6
     else:
         assert not degenerate, "degenerate cases need oracle/_ref (qpOASES)"
+
+
+@pytest.mark.parametrize("n,rows", [(32, [45]), (32, [33, 7]), (20, [37])])
+def test_more_rows_than_variables(n, rows, oracle):
+    """over-determined levels: more stored rows than the 32 the H build requests per round of loads (and a row
+    count that is not a multiple of the four rows one MFMA step takes)"""
+    plan, leaf = synth.make_generic_stack(4, n, rows, seed=5, postural_last=False)
+    asm = oracle.assemble(plan, leaf)
+    dq, xl, st, it = emu_cascade(plan, asm)
+    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+    assert (st == 0).all() and (ref["status"] == 1).all()
+    assert np.abs(dq - ref["dq"]).max() < 1e-9

@@ -92,3 +92,16 @@ def test_lowrank_levels_gpu(kw, oracle, gpu_device):
         rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
         ok = rq["status"] == 1
         assert ok.mean() > 0.9 and np.abs(dq[ok] - rq["dq"][ok]).max() < 1e-6
+
+
+@pytest.mark.parametrize("n,rows", [(32, [45]), (32, [33, 7]), (20, [37])])
+def test_more_rows_than_variables_gpu(n, rows, oracle, gpu_device):
+    """over-determined levels: more stored rows than one round of H-build loads covers (32), row counts that are
+    not multiples of four"""
+    plan, leaf = synth.make_generic_stack(128, n, rows, seed=5, postural_last=False)
+    asm = oracle.assemble(plan, leaf)
+    dq, xl, status, it, _ = _run(plan, leaf)
+    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+    okr = ref["status"] == 1
+    assert (status == 0).all() and okr.mean() > 0.9
+    assert np.abs(dq[okr] - ref["dq"][okr]).max() < 1e-9
