@@ -83,7 +83,10 @@ def test_lowrank_levels_gpu(kw, oracle, gpu_device):
     asm = oracle.assemble(plan, leaf)
     dq, xl, status, it, _ = _run(plan, leaf)
     assert (status == 0).all()
-    degenerate = kw.get("dependent") or kw.get("zero_row")
+    # dependent equality rows, or more equality rows than variables at the second level (a Postural block in the
+    # first level leaves m + n optimality rows): outside what the restated eiQuadProg routine supports
+    degenerate = (kw.get("dependent") or kw.get("zero_row")
+                  or (kw.get("postural_weight") is not None and kw.get("second_level_rows", 5) != 0))
     if not degenerate:   # (see test_emulated_kernels.test_lowrank_levels: dependent equalities are pinned by qpOASES only)
         ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
         okr = ref["status"] == 1
@@ -101,7 +104,12 @@ def test_more_rows_than_variables_gpu(n, rows, oracle, gpu_device):
     plan, leaf = synth.make_generic_stack(128, n, rows, seed=5, postural_last=False)
     asm = oracle.assemble(plan, leaf)
     dq, xl, status, it, _ = _run(plan, leaf)
-    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
-    okr = ref["status"] == 1
-    assert (status == 0).all() and okr.mean() > 0.9
-    assert np.abs(dq[okr] - ref["dq"][okr]).max() < 1e-9
+    assert (status == 0).all()
+    if rows[0] <= n or len(rows) == 1:
+        ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+        okr = ref["status"] == 1
+        assert okr.mean() > 0.9 and np.abs(dq[okr] - ref["dq"][okr]).max() < 1e-9
+    elif oracle.ref_available():   # (see the emulator test: more equality rows than variables is qpOASES-only)
+        rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
+        ok = rq["status"] == 1
+        assert ok.mean() > 0.9 and np.abs(dq[ok] - rq["dq"][ok]).max() < 1e-6
