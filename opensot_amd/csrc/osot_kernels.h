@@ -358,11 +358,18 @@ __global__ void __launch_bounds__(1024) osot_order_kernel(const int* cost, int* 
         atomicAdd(&hist[k], 1);
     }
     __syncthreads();
-    if (t < 256) {   // start[k] = number of instances with a larger key (descending order); 256 short parallel sums
-        int acc = 0;
-        for (int k2 = t + 1; k2 < 256; ++k2) acc += hist[k2];
-        start[t] = acc;
+    // start[k] = number of instances with a larger key (descending order): exclusive suffix sum of the histogram,
+    // Hillis-Steele over the 256 bins (eight rounds)
+    if (t < 256) start[t] = hist[t];
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        int v = 0;
+        if (t < 256 && t + off < 256) v = start[t + off];
+        __syncthreads();
+        if (t < 256) start[t] += v;
+        __syncthreads();
     }
+    if (t < 256) start[t] -= hist[t];   // inclusive -> exclusive
     __syncthreads();
     for (int i = t; i < B; i += 1024) {
         int k = cost[i]; k = k < 0 ? 0 : (k > 255 ? 255 : k);
@@ -534,38 +541,54 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
     const int t = threadIdx.x;
     const int n = U.n;
     if (inst >= U.B) return;
-    // ---- tasks: b and diag(W) (tasks::Aggregated::generateAll / generateWeight, Aggregated.cpp:113-132, 265-279)
+    // ---- tasks: b and diag(W) (tasks::Aggregated::generateAll / generateWeight, Aggregated.cpp:113-132, 265-279).
+    // ONE LANE PER ROW of the whole stack (all levels, flat): the task table is walked uniformly (scalar loads) and
+    // each lane keeps the parameters of the task its row belongs to; every kind then goes through the SAME four
+    // loads (p0[ia], p0[ib], p1[ic], p2[id], each optional), so that all rows of all tasks cost one memory round
+    // trip instead of one per task (the kernel was a chain of ~9 dependent round trips: 18 us for 3 MB).
     {
-        for (int j = 0; j < U.ntasks; ++j) {
-            const DevTask& tk = U.task[j];
-            const int k = tk.level;
-            double* bk = U.b[k] + inst * U.m[k];
-            double* wk = U.w[k] ? U.w[k] + inst * U.m[k] : nullptr;
-            if (wk) for (int r = t; r < tk.rows; r += 64) wk[tk.off + r] = tk.weight;
-            if (tk.kind == 1) {           // Cartesian: handled below, one lane per task
-            } else if (tk.kind == 2) {    // CoM (CoM.cpp:145-149)
-                if (t < 3) bk[tk.off + t] = (tk.p2 ? tk.p2[inst * 3 + t] : 0.0) +
-                                            tk.lambda * (tk.p1[inst * 3 + t] - tk.p0[inst * 3 + t]);
-            } else if (tk.kind == 3) {    // Postural (Postural.cpp:97-100)
-                for (int r = t; r < tk.rows; r += 64)
-                    bk[tk.off + r] = (tk.p2 ? tk.p2[inst * tk.rows + r] : 0.0) +
-                                     tk.lambda * (tk.p1[inst * tk.rows + r] - tk.p0[inst * tk.rows + r]);
-            } else if (tk.kind == 4 || tk.kind == 5) {
+        int total = 0;
+        for (int j = 0; j < U.ntasks; ++j) total += U.task[j].rows;
+        for (int fr = t; fr < total; fr += 64) {
+            int kind = -1, rows = 0, r = 0, off = 0, level = 0;
+            double weight = 0.0, lam = 0.0, lam2 = 0.0;
+            const double *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
+            int start = 0;
+            for (int j = 0; j < U.ntasks; ++j) {
+                const DevTask& tk = U.task[j];
+                if (fr >= start && fr < start + tk.rows) {
+                    kind = tk.kind; rows = tk.rows; r = fr - start; off = tk.off; level = tk.level;
+                    weight = tk.weight; lam = tk.lambda; lam2 = tk.lambda2;
+                    p0 = tk.p0; p1 = tk.p1; p2 = tk.p2;
+                }
+                start += tk.rows;
+            }
+            double* wl = nullptr;
+            double* bl = nullptr;
+            for (int k = 0; k < U.L; ++k)
+                if (k == level) { bl = U.b[k] + inst * U.m[k] + off + r; wl = U.w[k] ? U.w[k] + inst * U.m[k] + off + r : nullptr; }
+            if (wl) *wl = weight;
+            if (kind == 1) continue;   // Cartesian rows: below, one lane per task
+            // acceleration kinds read (pose error, velocity error) from p0: [2 rows] per instance
+            const bool acc = (kind == 4 || kind == 5 || kind == 6);
+            const long long base = inst * (long long)rows + r;
+            const double x0 = acc ? p0[inst * 2LL * rows + r] : p0[base];
+            const double x1 = acc ? p0[inst * 2LL * rows + rows + r] : 0.0;
+            const double x2 = (p1 && kind != 0 && kind != 6) ? p1[base] : 0.0;
+            const double x3 = (p2 && kind != 0) ? p2[base] : 0.0;
+            double v;
+            if (kind == 2 || kind == 3) {            // CoM (CoM.cpp:145-149), Postural (Postural.cpp:97-100)
+                v = x3 + lam * (x2 - x0);
+            } else if (kind == 4 || kind == 5) {
                 // acceleration::Cartesian / CoM (acceleration/Cartesian.cpp:152-160, acceleration/CoM.cpp:86-92):
                 // J qddot + Jdot qdot - a_ref - lambda2 Kd vel_err - lambda Kp pose_err = 0, Kp = Kd = I
-                for (int r = t; r < tk.rows; r += 64) {
-                    const double pe = tk.p0[inst * 2 * tk.rows + r], ve = tk.p0[inst * 2 * tk.rows + tk.rows + r];
-                    bk[tk.off + r] = (tk.p2 ? tk.p2[inst * tk.rows + r] : 0.0) + tk.lambda2 * ve + tk.lambda * pe -
-                                     tk.p1[inst * tk.rows + r];
-                }
-            } else if (tk.kind == 6) {    // acceleration::Postural (acceleration/Postural.cpp:145-158)
-                for (int r = t; r < tk.rows; r += 64) {
-                    const double pe = tk.p0[inst * 2 * tk.rows + r], ve = tk.p0[inst * 2 * tk.rows + tk.rows + r];
-                    bk[tk.off + r] = (tk.p2 ? tk.p2[inst * tk.rows + r] : 0.0) + tk.lambda2 * ve + tk.lambda * pe;
-                }
-            } else {                      // Generic: b supplied
-                for (int r = t; r < tk.rows; r += 64) bk[tk.off + r] = tk.p0[inst * tk.rows + r];
+                v = x3 + lam2 * x1 + lam * x0 - x2;
+            } else if (kind == 6) {                  // acceleration::Postural (acceleration/Postural.cpp:145-158)
+                v = x3 + lam2 * x1 + lam * x0;
+            } else {                                 // Generic: b supplied
+                v = x0;
             }
+            *bl = v;
         }
     }
     // ---- Cartesian tasks, ONE LANE PER TASK: the pose error (Cartesian.cpp:190-240: position difference +
@@ -585,8 +608,15 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
             }
         }
         if (cb) {
-            double b6[6];
-            cartesian_b(cp0 + inst * 12, cp1 + inst * 12, cp2 ? cp2 + inst * 6 : nullptr, clam, cog, b6);
+            // both poses (and the feed-forward twist) are fetched in ONE batch before any arithmetic: the
+            // rotation-to-quaternion branches would otherwise pull their matrix entries in one dependent round trip
+            // after the other
+            double Ta[12], Td[12], tw[6], b6[6];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { Ta[i] = cp0[inst * 12 + i]; Td[i] = cp1[inst * 12 + i]; }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) tw[i] = cp2 ? cp2[inst * 6 + i] : 0.0;
+            cartesian_b(Ta, Td, tw, clam, cog, b6);
             for (int i = 0; i < 6; ++i) cb[i] = b6[i];
         }
     }
