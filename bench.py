@@ -238,7 +238,7 @@ def main():
         if launches > 0 and kern_s > 0:
             tf = Bl * flops / kern_s / 1e12
             out["roofline"] = {
-                "bound": "mfma", "kernel": "osot_cascade_kernel<32,false,true> (fp64 MFMA H build + blocked Cholesky, VALU/LDS active set)", "achieved": tf, "peak": FP64_PEAK_TFLOPS,
+                "bound": "mfma", "kernel": "osot_cascade_kernel<32,false> (fp64 MFMA H build + blocked Cholesky, VALU/LDS active set)", "achieved": tf, "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": traffic,
                 "avg_launch_ms": kern_ms, "launches": launches,
                 "algorithmic_flops_per_solve": flops,

@@ -65,8 +65,7 @@ struct DevBatch {
 // Row table of level k (LDS): [ global C rows ; A_0 ; ... ; A_{k-1} ]  (iHQP.cpp:282-333).  The C entries are
 // filled once per instance, the optimality entries of level j are appended when level j has been solved
 // (lo = up = A_j x_j, iHQP.cpp:164-170; an inactive level contributes 0*x in [-1,1], iHQP.cpp:301-309).
-// FULLN: n == NP (no per-step guards in the factorisation)
-template <int NP, bool PROF, bool FULLN>
+template <int NP, bool PROF>
 __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(const DevPlan P, const DevBatch D) {
     OSOT_DYNAMIC_LDS(osot_smem);
     constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
@@ -298,10 +297,10 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
         OSOT_PH_END(PH_HBUILD);
         int st;
         if (NP == 64) {   // must be inlined: hacc would otherwise be passed through scratch memory
-            OSOT_ALWAYS_INLINE_CALL st = gi_solve<NP, PROF, FULLN>(w, nrows, g, diag_h, hdiag, hacc,
+            OSOT_ALWAYS_INLINE_CALL st = gi_solve<NP, PROF>(w, nrows, g, diag_h, hdiag, hacc,
                                                                    has_box, lb, ub, P.max_iter, any, x, x, iters, prof);
         } else {          // NP = 32: the inliner's own order keeps the kernel free of vector spills
-            st = gi_solve<NP, PROF, FULLN>(w, nrows, g, diag_h, hdiag, hacc,
+            st = gi_solve<NP, PROF>(w, nrows, g, diag_h, hdiag, hacc,
                                            has_box, lb, ub, P.max_iter, any, x, x, iters, prof, lowrank, xprep);
         }
         if (PROF) ph_t0_ = (long long)clock64();
@@ -454,9 +453,9 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
     int iters = 0;
     int st;
     if (NP == 64) {
-        OSOT_ALWAYS_INLINE_CALL st = gi_solve<NP, false, false>(w, Q.nc, g, false, 0.0, Hc, has_box, lb, ub, Q.max_iter, false, 0.0, x, iters, nullptr);
+        OSOT_ALWAYS_INLINE_CALL st = gi_solve<NP, false>(w, Q.nc, g, false, 0.0, Hc, has_box, lb, ub, Q.max_iter, false, 0.0, x, iters, nullptr);
     } else {
-        st = gi_solve<NP, false, false>(w, Q.nc, g, false, 0.0, Hc, has_box, lb, ub, Q.max_iter, false, 0.0, x, iters, nullptr);
+        st = gi_solve<NP, false>(w, Q.nc, g, false, 0.0, Hc, has_box, lb, ub, Q.max_iter, false, 0.0, x, iters, nullptr);
     }
     if (valid && h == 0) Q.x[inst * n + c] = (st == QP_SOLVED) ? x : 0.0;
     if (lane == 0) {

@@ -99,8 +99,8 @@ int osot_solver_create(const osot_plan_desc* plan, int max_batch, int device, os
     HIP_TRY(hipSetDevice(device));
     DevPlan P; int T; size_t lds;
     make_dev_plan(*plan, nullptr, P, T, lds);
-    rc = (T == 32) ? ensure_lds(osot_cascade_kernel<32, false, false>, lds) : ensure_lds(osot_cascade_kernel<64, false, false>, lds);
-    if (rc == OSOT_OK) rc = (T == 32) ? ensure_lds(osot_cascade_kernel<32, true, false>, lds) : ensure_lds(osot_cascade_kernel<64, true, false>, lds);
+    rc = (T == 32) ? ensure_lds(osot_cascade_kernel<32, false>, lds) : ensure_lds(osot_cascade_kernel<64, false>, lds);
+    if (rc == OSOT_OK) rc = (T == 32) ? ensure_lds(osot_cascade_kernel<32, true>, lds) : ensure_lds(osot_cascade_kernel<64, true>, lds);
     if (rc != OSOT_OK) return rc;
     osot_solver* s = new osot_solver();
     s->plan = *plan;
@@ -205,15 +205,12 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
         else { HIP_TRY(hipEventCreate(&ev.first)); HIP_TRY(hipEventCreate(&ev.second)); }
         HIP_TRY(hipEventRecord(ev.first, st));
     }
-    const bool full = (P.n == 32);
     if (prof) {
-        if (T == 32 && full) hipLaunchKernelGGL((osot_cascade_kernel<32, true, true>), dim3(grid), dim3(64), lds, st, P, D);
-        else if (T == 32) hipLaunchKernelGGL((osot_cascade_kernel<32, true, false>), dim3(grid), dim3(64), lds, st, P, D);
-        else hipLaunchKernelGGL((osot_cascade_kernel<64, true, false>), dim3(grid), dim3(64), lds, st, P, D);
+        if (T == 32) hipLaunchKernelGGL((osot_cascade_kernel<32, true>), dim3(grid), dim3(64), lds, st, P, D);
+        else hipLaunchKernelGGL((osot_cascade_kernel<64, true>), dim3(grid), dim3(64), lds, st, P, D);
     } else {
-        if (T == 32 && full) hipLaunchKernelGGL((osot_cascade_kernel<32, false, true>), dim3(grid), dim3(64), lds, st, P, D);
-        else if (T == 32) hipLaunchKernelGGL((osot_cascade_kernel<32, false, false>), dim3(grid), dim3(64), lds, st, P, D);
-        else hipLaunchKernelGGL((osot_cascade_kernel<64, false, false>), dim3(grid), dim3(64), lds, st, P, D);
+        if (T == 32) hipLaunchKernelGGL((osot_cascade_kernel<32, false>), dim3(grid), dim3(64), lds, st, P, D);
+        else hipLaunchKernelGGL((osot_cascade_kernel<64, false>), dim3(grid), dim3(64), lds, st, P, D);
     }
     HIP_TRY(hipGetLastError());
     if (s->timing) {

@@ -203,129 +203,6 @@ __device__ __forceinline__ void drop_constraint(const WaveCtx<NP>& w, int qq, in
 }
 
 // The general rows come from the LDS row table in WaveCtx (rlo/rup/rptr, nrows entries).
-// Fused right-looking Cholesky + inverse + forward substitution, matrix held in REGISTERS.
-// In : Hc[ii] = (H + eps I)[HV*ii+h][c]  (lane (c,h) owns column c, rows i = h mod HV), g.
-// Out: M1 = L (lower triangular, zeros above), M2 = JT = L^-1, x = -(H + eps I)^-1 g, all by lane c.
-// The trailing matrix of a right-looking Cholesky stays symmetric, so the normalised column j
-// (l_ij over i) IS the lane-distributed vector Hc[j>>1] of half (j&1): no transposition is needed; one
-// LDS column write + immediate-offset reads broadcast it.  L^-1 is built in the same sweep
-// (Linv[i][:] -= l_ij * Linv[j][:]) and so is the forward substitution L y = -g; only the backward
-// substitution L'x = y runs afterwards.  Every register index is a compile-time constant.
-// The sweep is a LOOP over pairs of columns with ROTATING registers: after the steps j = 2r and 2r+1 the
-// sixteen registers of Hc and Lc shift down by one, so the current pair of rows always sits in register 0 and
-// every register index in the body is a compile-time constant.  A fully unrolled sweep is ~32 KB of
-// straight-line code per instantiation; together with the rest of the kernel that overflows the 64 KB
-// instruction cache two CUs share, and a wave streaming cold code runs at ~1 instruction per 6 cycles
-// (tools/ubench_latency.hip: 480 -> 720 cycles per step).  The loop body is ~2 KB.  The price: the trailing
-// update runs over all sixteen registers at every step (no triangular saving) plus 30 v_mov_b64 per pair.
-// Registers shifted in at the top are zero; they stand for rows >= 32, read whatever lies behind M1 in LDS
-// and are never used.  Non-positive pivots set a sticky flag (no exit inside the sweep).
-__device__ inline int factor_loop32(const WaveCtx<32>& w, double (&Hc)[16], double g, double& x_out) {
-    constexpr int NP = 32, S = WaveCtx<32>::S, NR = 16;
-    const int c = w.c, h = w.h, n = w.n;
-    const bool valid = c < n;
-    double* M1 = w.M1;
-    double* M2 = w.M2;
-    double Lc[NR];
-#pragma unroll
-    for (int ii = 0; ii < NR; ++ii) Lc[ii] = (2 * ii + h == c) ? 1.0 : 0.0;
-    double rhs = valid ? -g : 0.0;
-    double invd = 0.0;
-    bool bad = false;
-    const int npairs = (n + 1) >> 1;
-    const double* colp = M1 + h * S;      // slot k at pair r reads colp[2 (k + r) S + j]: row 2 (k + r) + h of column j
-    double* wr = M1 + c * S;              // lane c writes its element of columns 2 r, 2 r + 1 to wr[0], wr[1]
-    double* m2p = M2 + h * S + c;         // finished row 2 r + h of L^-1 goes to m2p[2 r S]
-    for (int r = 0; r < npairs; ++r) {
-        // ---------------- even step j = 2 r: row j is register 0 of half 0, row j + 1 register 0 of half 1
-        {
-            const int j = 2 * r;
-            double piv = bcast(Hc[0], j);   // lane (c = j, h = 0)
-            if (!(piv > 0.0)) { bad = true; piv = 1.0; }
-            double sq, rs;
-            fast_sqrt_rsqrt(piv, sq, rs);
-            const double hjc = from_half<NP>(Hc[0], 0);               // H[j][c] = H[c][j]
-            const double lcj = (valid && c >= j) ? ((c == j) ? sq : hjc * rs) : 0.0;
-            if (h == 0) wr[0] = lcj;
-            if (c == j) invd = rs;
-            const double yj = bcast(rhs, j) * rs;                      // forward substitution
-            rhs = (c == j) ? yj : fma(-lcj, yj, rhs);
-            const double linv_jc = from_half<NP>(Lc[0], 0) * rs;       // row j of L^-1 is final
-            if (h == 0) Lc[0] = linv_jc;
-            wave_sync();
-            double li[NR];
-#pragma unroll
-            for (int k = 0; k < NR; ++k) li[k] = colp[2 * k * S];
-            {   // row j + 1 lives in half 1 of register 0 (row j itself is finished)
-                const double l0 = (h == 1) ? li[0] : 0.0;
-                Hc[0] = fma(-l0, lcj, Hc[0]);
-                Lc[0] = fma(-l0, linv_jc, Lc[0]);
-            }
-#pragma unroll
-            for (int k = 1; k < NR; ++k) {
-                Hc[k] = fma(-li[k], lcj, Hc[k]);
-                Lc[k] = fma(-li[k], linv_jc, Lc[k]);
-            }
-        }
-        // ---------------- odd step j = 2 r + 1: row j is register 0 of half 1
-        if (2 * r + 1 < n) {
-            const int j = 2 * r + 1;
-            double piv = bcast(Hc[0], j + 32);   // lane (c = j, h = 1)
-            if (!(piv > 0.0)) { bad = true; piv = 1.0; }
-            double sq, rs;
-            fast_sqrt_rsqrt(piv, sq, rs);
-            const double hjc = from_half<NP>(Hc[0], 1);
-            const double lcj = (valid && c >= j) ? ((c == j) ? sq : hjc * rs) : 0.0;
-            if (h == 0) wr[1] = lcj;
-            if (c == j) invd = rs;
-            const double yj = bcast(rhs, j) * rs;
-            rhs = (c == j) ? yj : fma(-lcj, yj, rhs);
-            const double linv_jc = from_half<NP>(Lc[0], 1) * rs;
-            if (h == 1) Lc[0] = linv_jc;
-            wave_sync();
-            double li[NR];
-#pragma unroll
-            for (int k = 1; k < NR; ++k) li[k] = colp[2 * k * S + 1];
-#pragma unroll
-            for (int k = 1; k < NR; ++k) {
-                Hc[k] = fma(-li[k], lcj, Hc[k]);
-                Lc[k] = fma(-li[k], linv_jc, Lc[k]);
-            }
-        }
-        m2p[0] = Lc[0];   // rows 2 r (half 0) and 2 r + 1 (half 1) of L^-1 are final
-        // rotate: register k <- k + 1, zero shifted in
-#pragma unroll
-        for (int k = 0; k + 1 < NR; ++k) { Hc[k] = Hc[k + 1]; Lc[k] = Lc[k + 1]; }
-        Hc[NR - 1] = 0.0;
-        Lc[NR - 1] = 0.0;
-        colp += 2 * S + 2;
-        wr += 2;
-        m2p += 2 * S;
-    }
-    // rows of JT beyond the pairs that were swept: identity (they are read, against zeros, by the J products)
-    for (int i = 2 * npairs + h; i < NP; i += 2) M2[i * S + c] = (i == c) ? 1.0 : 0.0;
-    if (bad) { x_out = 0.0; return QP_NOT_PD; }
-    // backward substitution L'x = y (rhs holds y); rows of L are fetched eight at a time ahead of the chain
-    double x = 0.0;
-    const double yinv0 = invd;
-    for (int i0 = NP - 8; i0 >= 0; i0 -= 8) {
-        double lrow[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) lrow[t] = M1[(i0 + t) * S + c];   // zero for c > i; lane i itself is done
-#pragma unroll
-        for (int t = 7; t >= 0; --t) {
-            const int i = i0 + t;
-            if (i < n) {
-                const double xi = bcast(rhs * yinv0, i);
-                if (c == i) x = xi;
-                rhs = fma(-lrow[t], xi, rhs);
-            }
-        }
-    }
-    wave_sync();
-    x_out = valid ? x : 0.0;
-    return QP_SOLVED;
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // NP = 32 production path: BLOCKED right-looking Cholesky + inverse on the fp64 MATRIX CORE, panel width 4.
@@ -479,7 +356,7 @@ __device__ inline int factor_tiles32(const WaveCtx<32>& w, double (&Hf)[16], dou
 //     the same shape, no cross-lane step at all (pure ILP, four accumulators per dot product).
 // The row bases are laundered: ds_read2_b64 only has an 8-bit offset field, so without it every pair of reads
 // gets its own constant address, and loop-invariant code motion parks ~900 of them in (spilled) SGPRs.
-// In/Out as factor_loop32.  MUST be inlined (Hc would otherwise travel through scratch by reference).
+// In : Hc[i] = (H + eps I)[i][c] (lane c owns column c = row c), g.  Out: M1 = L, M2 = JT = L^-1, x = -(H + eps I)^-1 g.  MUST be inlined (Hc would otherwise travel through scratch by reference).
 template <bool FULL>
 __device__ __forceinline__ int factor_rows64(const WaveCtx<64>& w, double (&Hc)[64], double g, double& x_out) {
     constexpr int NP = 64, S = WaveCtx<64>::S;
@@ -649,8 +526,9 @@ __device__ inline int nullspace_equalities32(const WaveCtx<32>& w, int n_eq, dou
     const double tol = 1.0e-9 * emax;
     OSOT_SUB_END(PH_EQ_D);      // (profiling slots reused: load + scale)
     // ---- Gauss-Jordan with column pivoting, all in registers, as a LOOP over pairs of rows with ROTATING
-    // registers (cyclic: register 0 always holds the current pair; see factor_loop32 for why the sweep is not
-    // unrolled: the unrolled function was 55 KB of straight-line code).  The pivot is the largest |entry| of the
+    // registers (cyclic: register 0 always holds the current pair, so every register index is a compile-time
+    // constant).  Not unrolled: the unrolled function was 55 KB of straight-line code against a 64 KB instruction
+    // cache shared by two CUs, and a wave streaming cold code runs at ~1 instruction per 6 cycles.  The pivot is the largest |entry| of the
     // row among the non-basic columns: one max-reduction, then a ballot picks the lowest such column (the
     // value/payload argmin network costs ~760 cycles, this ~170).  The pivot column (the 16 values of lane
     // (pcol, h)) reaches every lane of its half through ds_bpermute (per-lane source index, result in a VGPR).
@@ -916,8 +794,8 @@ __device__ inline void lowrank_prepare32(const WaveCtx<32>& w, const double* Ak,
     wave_sync();
 }
 
-// Pre (general H):  Hc[ii] = (H + eps I)[HV*ii+h][c] in registers (see factor_loop32 / factor_rows64), M1 is scratch.
-template <int NP, bool PROF, bool FULLN>
+// Pre (general H):  Hc[ii] = (H + eps I)[HV*ii+h][c] in registers (NP = 64, factor_rows64) or the accumulator tiles (NP = 32, factor_tiles32), M1 is scratch.
+template <int NP, bool PROF>
 __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_h,
                         double hdiag, double (&Hc)[NP / (64 / NP)], bool has_box, double lb, double ub, int max_iter,
                         bool have_prev, double xprev, double& x_out, int& iters_out, long long* prof,
@@ -956,10 +834,8 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
         wave_sync();
         OSOT_PH_END(PH_CHOL);
     } else {
-        // exactly ONE instantiation per kernel (FULLN is a kernel template parameter): both variants in one
-        // kernel push the NP = 32 kernel past 256 VGPRs; each alone fits without scratch
         int stf;
-        if constexpr (NP == 64) stf = factor_rows64<FULLN>(w, Hc, g, x);
+        if constexpr (NP == 64) stf = factor_rows64<false>(w, Hc, g, x);
         else stf = factor_tiles32(w, Hc, g, x);
         if (stf != QP_SOLVED) { x_out = 0.0; iters_out = 0; return stf; }
         OSOT_PH_END(PH_CHOL);

@@ -20,9 +20,8 @@ extern "C" __attribute__((visibility("default"))) int emu_ihqp_solve(const osot_
     D.C = b->C; D.lo = b->lo; D.up = b->up; D.l = b->l; D.u = b->u;
     D.dq = b->dq; D.x_levels = b->x_levels; D.status = b->status; D.iterations = b->iterations;
     const unsigned grid = (unsigned)b->B;
-    if (T == 32 && P.n == 32) emu::launch(osot_cascade_kernel<32, false, true>, grid, lds, 64, P, D);
-    else if (T == 32) emu::launch(osot_cascade_kernel<32, false, false>, grid, lds, 64, P, D);
-    else emu::launch(osot_cascade_kernel<64, false, false>, grid, lds, 64, P, D);
+    if (T == 32) emu::launch(osot_cascade_kernel<32, false>, grid, lds, 64, P, D);
+    else emu::launch(osot_cascade_kernel<64, false>, grid, lds, 64, P, D);
     return OSOT_OK;
 }
 

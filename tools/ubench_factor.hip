@@ -1,4 +1,4 @@
-// developer tool: in-situ cycles of the NP = 32 factorisations (factor_loop32: column layout; factor_tiles32: MFMA tiles), 1..8 waves per CU
+// developer tool: in-situ cycles of the NP = 32 factorisation (factor_tiles32: fp64 MFMA tiles), 1..8 waves per CU, 1..8 waves per CU
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include "osot_qp_core.h"
@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(64, 2) factor_bench(long long* out, double* si
         double x;
         wave_sync();
         const long long t0 = clock64();
-        const int st = (WHICH == 1) ? factor_tiles32<true>(w, Hc, 1.0 + w.c, x, tt) : factor_loop32(w, Hc, 1.0 + w.c, x);
+        const int st = factor_tiles32<true>(w, Hc, 1.0 + w.c, x, tt);
         const long long t1 = clock64();
         total += t1 - t0;
         acc += x + st;
@@ -52,7 +52,7 @@ int main() {
     for (int wpc : {1, 2, 4, 8}) {
         const int grid = 256 * wpc;
         static long long h[maxb];
-        for (int which = 0; which < 2; ++which) {
+        for (int which = 1; which < 2; ++which) {
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             const int reps = 64;
             for (int it = 0; it < 2; ++it) {
