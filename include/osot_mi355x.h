@@ -20,6 +20,8 @@
  *  osot_backend_* ................ the BackEnd plugin surface     include/OpenSoT/solvers/BackEnd.h:23-171
  *                                  and its C factory `create_instance`
  *                                  (src/solvers/QPOasesBackEnd.cpp:14-24), batch-of-one, host pointers
+ *  osot_kinematics ............... batched frame poses / Jacobians / CoM: what the leaf _update()s fetch from
+ *                                  XBot::ModelInterface (velocity/Cartesian.cpp:73-81, velocity/CoM.cpp:59-74)
  *  osot_allgather_dq ............. new surface (the reference has no multi-instance API): collects the
  *                                  per-rank dq shards; RCCL all-gather on the solve stream
  *
@@ -283,6 +285,48 @@ int osot_qp_solve_batch(int B, int n, int nc, const double* H, const double* g, 
                         const double* lA, const double* uA, const double* l, const double* u,
                         double eps_abs, int max_iter, double* x, int* status, int* iterations,
                         void* hip_stream);
+
+/* ---- batched kinematics producer ------------------------------------------------------
+ * What the leaf tasks ask XBot::ModelInterface for every cycle: frame poses and 6 x n frame Jacobians
+ * (velocity::Cartesian::_update, src/tasks/velocity/Cartesian.cpp:73-81: getJacobian / getPose), the centre
+ * of mass and its 3 x n Jacobian (velocity::CoM::_update, src/tasks/velocity/CoM.cpp:59-74: getCOM /
+ * getCOMJacobian).  xbot2_interface is not vendored in the reference, so this is an own implementation for a
+ * kinematic TREE of revolute / prismatic joints (a floating base is the usual chain of three prismatic and three
+ * revolute virtual joints); parity at this boundary is pinned by the CPU restatement in oracle/pykin.py and by
+ * finite differences, not by the reference.  Convention: Jacobians are expressed in the world
+ * frame, rows [linear; angular] of the frame origin, columns = joints; poses are [R row-major | p] (the Cartesian
+ * leaf layout, osot_leaf_ptrs).  The Jacobians are written STRAIGHT into their row range of the stacked A_k. */
+#define OSOT_KIN_MAX_JOINTS 64
+#define OSOT_KIN_MAX_FRAMES 8
+enum { OSOT_JOINT_REVOLUTE = 0, OSOT_JOINT_PRISMATIC = 1 };
+typedef struct {
+    int n;                                   /* joints = generalised coordinates; tree order: parent[j] < j     */
+    int parent[OSOT_KIN_MAX_JOINTS];         /* -1 = world                                                      */
+    int type[OSOT_KIN_MAX_JOINTS];
+    double axis[OSOT_KIN_MAX_JOINTS][3];     /* joint axis in the joint frame (unit)                            */
+    double R0[OSOT_KIN_MAX_JOINTS][9];       /* fixed transform parent joint frame -> joint frame at q = 0      */
+    double p0[OSOT_KIN_MAX_JOINTS][3];
+    double mass[OSOT_KIN_MAX_JOINTS];        /* of the link the joint moves                                     */
+    double com[OSOT_KIN_MAX_JOINTS][3];      /* its centre of mass in the joint frame                           */
+    int n_frames;
+    int frame_joint[OSOT_KIN_MAX_FRAMES];    /* joint whose link carries frame f                                */
+    double frame_R[OSOT_KIN_MAX_FRAMES][9];  /* frame f in that joint frame                                     */
+    double frame_p[OSOT_KIN_MAX_FRAMES][3];
+} osot_kin_desc;
+typedef struct {
+    int B;
+    const double* q;                               /* [B][n]                                                    */
+    double* frame_pose[OSOT_KIN_MAX_FRAMES];       /* [B][12] or NULL                                           */
+    double* frame_J[OSOT_KIN_MAX_FRAMES];          /* first of the 6 rows of frame f in instance 0, or NULL     */
+    long long frame_J_stride[OSOT_KIN_MAX_FRAMES]; /* doubles from one instance to the next (ma_k * n)          */
+    double* com;                                   /* [B][3] or NULL                                            */
+    double* com_J;                                 /* first of the 3 rows in instance 0, or NULL                */
+    long long com_J_stride;
+} osot_kin_batch;
+typedef struct osot_kin osot_kin;
+int osot_kin_create(const osot_kin_desc* desc, int device, osot_kin** out);
+int osot_kin_destroy(osot_kin* k);
+int osot_kinematics(osot_kin* k, const osot_kin_batch* batch, void* hip_stream);
 
 /* ---- multi-GPU: collect solved dq shards ---------------------------------------------------- */
 typedef struct osot_comm osot_comm;

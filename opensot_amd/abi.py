@@ -75,12 +75,31 @@ class AssembledOut(C.Structure):
 
 
 # every symbol include/osot_mi355x.h declares (tests/test_abi_symbols.py checks the .so exports all)
+KIN_MAX_JOINTS, KIN_MAX_FRAMES = 64, 8
+JOINT_REVOLUTE, JOINT_PRISMATIC = 0, 1
+
+
+class KinDesc(C.Structure):
+    _fields_ = [("n", C.c_int), ("parent", C.c_int * KIN_MAX_JOINTS), ("type", C.c_int * KIN_MAX_JOINTS),
+                ("axis", (C.c_double * 3) * KIN_MAX_JOINTS), ("R0", (C.c_double * 9) * KIN_MAX_JOINTS),
+                ("p0", (C.c_double * 3) * KIN_MAX_JOINTS), ("mass", C.c_double * KIN_MAX_JOINTS),
+                ("com", (C.c_double * 3) * KIN_MAX_JOINTS), ("n_frames", C.c_int),
+                ("frame_joint", C.c_int * KIN_MAX_FRAMES), ("frame_R", (C.c_double * 9) * KIN_MAX_FRAMES),
+                ("frame_p", (C.c_double * 3) * KIN_MAX_FRAMES)]
+
+
+class KinBatch(C.Structure):
+    _fields_ = [("B", C.c_int), ("q", C.c_void_p), ("frame_pose", C.c_void_p * KIN_MAX_FRAMES),
+                ("frame_J", C.c_void_p * KIN_MAX_FRAMES), ("frame_J_stride", C.c_longlong * KIN_MAX_FRAMES),
+                ("com", C.c_void_p), ("com_J", C.c_void_p), ("com_J_stride", C.c_longlong)]
+
+
 SYMBOLS = [
     "osot_version", "osot_last_error", "osot_device_count",
     "osot_plan_validate", "osot_plan_level_rows", "osot_plan_constraint_rows",
     "osot_plan_stored_constraint_rows",
     "osot_solver_create", "osot_solver_destroy", "osot_stack_update", "osot_ihqp_solve",
-    "osot_solver_kernel_time_ms", "osot_solver_set_timing", "osot_solver_set_schedule", "osot_solver_profile_phases",
+    "osot_solver_kernel_time_ms", "osot_solver_set_timing", "osot_solver_set_schedule", "osot_kin_create", "osot_kin_destroy", "osot_kinematics", "osot_solver_profile_phases",
     "osot_backend_create", "osot_backend_destroy", "osot_backend_init_problem",
     "osot_backend_update_task", "osot_backend_update_constraints", "osot_backend_update_bounds",
     "osot_backend_solve", "osot_backend_get_solution", "osot_backend_get_objective",
@@ -127,6 +146,9 @@ def lib():
     L.osot_solver_kernel_time_ms.argtypes = [vp, C.c_int, dp, ip]
     L.osot_solver_set_timing.argtypes = [vp, C.c_int]
     L.osot_solver_set_schedule.argtypes = [vp, C.c_int]
+    L.osot_kin_create.argtypes = [C.POINTER(KinDesc), C.c_int, C.POINTER(vp)]
+    L.osot_kin_destroy.argtypes = [vp]
+    L.osot_kinematics.argtypes = [vp, C.POINTER(KinBatch), vp]
     L.osot_solver_profile_phases.argtypes = [vp, C.POINTER(QpBatch), vp, vp]
     L.osot_backend_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(vp)]
     L.osot_backend_destroy.argtypes = [vp]

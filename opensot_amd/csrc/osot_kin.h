@@ -1,0 +1,215 @@
+// opensot_amd/csrc/osot_kin.h -- batched kinematics producer.
+//
+// One wavefront per instance, LANE = JOINT (n <= 64).  Per instance:
+//   1. lane j: local transform T_j(q_j) = [R0_j Rot(axis_j, q_j) | p0_j] (revolute) or [R0_j | p0_j + R0_j axis_j q_j]
+//      (prismatic) -> LDS
+//   2. lane j: world transform of its joint frame by pointer jumping over the ancestor chain (log2(depth) rounds)
+//      -> LDS, with the world axis z_j and origin p_j
+//   3. frames: pose out; column j of the frame Jacobian = [z_j x (p_f - p_j); z_j] (revolute) / [z_j; 0] (prismatic)
+//      if joint j is an ancestor of the frame's link, else 0.  Row r of the 6 x n block is written by all lanes at
+//      once: one coalesced 8 n-byte store per row, straight into the stacked A_k.
+//   4. centre of mass: c = sum m_l c_l / M (wave reduction); column j of its Jacobian from the subtree aggregates
+//      (mass and first moment of the links joint j moves): z_j x (Sc_j - Sm_j p_j) / M  (prismatic: (Sm_j / M) z_j)
+// HBM-bound by construction: reads 8 n bytes of q, writes (6 F + 3) n 8 + 96 F + 24 bytes per instance.
+#pragma once
+#include "osot_team.h"
+#include "../../include/osot_mi355x.h"
+
+namespace osot {
+
+struct DevKin {            // osot_kin_desc + ancestor masks, in device memory
+    osot_kin_desc d;
+    unsigned long long anc[OSOT_KIN_MAX_JOINTS];   // bit a set: joint a is an ancestor of (or is) joint j
+    unsigned long long sub[OSOT_KIN_MAX_JOINTS];   // bit l set: link l is moved by joint j (j itself included)
+    double total_mass;
+};
+
+__device__ __forceinline__ void mat3_mul(const double* A, const double* B, double* C) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+__device__ __forceinline__ void mat3_vec(const double* A, const double* v, double* o) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = A[3 * i] * v[0] + A[3 * i + 1] * v[1] + A[3 * i + 2] * v[2];
+}
+__device__ __forceinline__ void cross3(const double* a, const double* b, double* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+__global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__ K, const osot_kin_batch Bt) {
+    constexpr int TS = 12;
+    OSOT_STATIC_LDS(double, Tl, 64 * TS);    // local transforms  [R | p]
+    OSOT_STATIC_LDS(double, Tw, 64 * TS);    // world transforms of the joint frames
+    OSOT_STATIC_LDS(double, Zw, 64 * 3);     // world joint axes
+    OSOT_STATIC_LDS(double, Cw, 64 * 4);     // world link centres of mass, mass
+    OSOT_STATIC_LDS(int, Par, 64);           // parent indices (the chain walk must not chase pointers through HBM)
+    OSOT_STATIC_LDS(unsigned long long, Anc, 64);   // ancestor masks
+    const int j = threadIdx.x;
+    const long long inst = blockIdx.x;
+    const int n = K->d.n;
+    const bool valid = j < n;
+    Par[j] = valid ? K->d.parent[j] : -1;
+    Anc[j] = valid ? K->anc[j] : 0ull;
+    // ---- 1. local transforms
+    if (valid) {
+        const double q = Bt.q[inst * n + j];
+        const double* R0 = K->d.R0[j];
+        const double* ax = K->d.axis[j];
+        double R[9], p[3];
+        if (K->d.type[j] == OSOT_JOINT_REVOLUTE) {
+            double s, c;
+            sincos(q, &s, &c);
+            const double v = 1.0 - c, x = ax[0], y = ax[1], z = ax[2];
+            const double Rq[9] = {c + x * x * v,     x * y * v - z * s, x * z * v + y * s,
+                                  y * x * v + z * s, c + y * y * v,     y * z * v - x * s,
+                                  z * x * v - y * s, z * y * v + x * s, c + z * z * v};   // Rodrigues
+            mat3_mul(R0, Rq, R);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) p[i] = K->d.p0[j][i];
+        } else {
+            double t[3];
+            mat3_vec(R0, ax, t);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) R[i] = R0[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) p[i] = K->d.p0[j][i] + q * t[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Tl[j * TS + i] = R[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Tl[j * TS + 9 + i] = p[i];
+    }
+    wave_sync();
+    // ---- 2. world transforms by POINTER JUMPING: every lane keeps T(jp -> j), the transform from the frame of its
+    // jump pointer jp to its own frame, and in each round composes it with T(jp(jp) -> jp) read from LDS and jumps:
+    // ceil(log2(depth + 1)) rounds (4 for a humanoid) instead of a walk of `depth` steps up the chain.
+    double Rw[9], pw[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rw[i] = valid ? Tl[j * TS + i] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pw[i] = valid ? Tl[j * TS + 9 + i] : 0.0;
+    {
+        int jp = Par[j];
+        double* cur = Tl;
+        double* nxt = Tw;
+        while (wave_ballot(jp >= 0) != 0ull) {
+            int njp = jp;
+            if (jp >= 0) {
+                double Ra[9], pa[3], Rn[9], pn[3];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) Ra[i] = cur[jp * TS + i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) pa[i] = cur[jp * TS + 9 + i];
+                mat3_mul(Ra, Rw, Rn);
+                mat3_vec(Ra, pw, pn);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) Rw[i] = Rn[i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) pw[i] = pn[i] + pa[i];
+                njp = Par[jp];
+            }
+            wave_sync();            // everybody has read Par / cur
+#pragma unroll
+            for (int i = 0; i < 9; ++i) nxt[j * TS + i] = Rw[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) nxt[j * TS + 9 + i] = pw[i];
+            Par[j] = njp;
+            jp = njp;
+            wave_sync();
+            double* t = cur; cur = nxt; nxt = t;
+        }
+    }
+    if (valid) {
+        double z[3], cl[3];
+        mat3_vec(Rw, K->d.axis[j], z);
+        mat3_vec(Rw, K->d.com[j], cl);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Tw[j * TS + i] = Rw[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { Tw[j * TS + 9 + i] = pw[i]; Zw[j * 3 + i] = z[i]; Cw[j * 4 + i] = cl[i] + pw[i]; }
+        Cw[j * 4 + 3] = K->d.mass[j];
+    }
+    wave_sync();
+    const double zj[3] = {valid ? Zw[j * 3] : 0.0, valid ? Zw[j * 3 + 1] : 0.0, valid ? Zw[j * 3 + 2] : 0.0};
+    const bool revolute = valid && K->d.type[j] == OSOT_JOINT_REVOLUTE;
+    // ---- 3. frames
+    for (int f = 0; f < K->d.n_frames; ++f) {
+        const int jf = K->d.frame_joint[f];
+        double Rf[9], pf[3];
+        {
+            double Rj[9], pj[3], t[3];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Rj[i] = Tw[jf * TS + i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) pj[i] = Tw[jf * TS + 9 + i];
+            mat3_mul(Rj, K->d.frame_R[f], Rf);
+            mat3_vec(Rj, K->d.frame_p[f], t);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) pf[i] = pj[i] + t[i];
+        }
+        if (Bt.frame_pose[f] && j < 12) {   // lane j stores element j of [R | p] (a select chain: a lane-indexed
+            double v = Rf[0];                //  read of Rf would put the arrays in scratch memory)
+#pragma unroll
+            for (int i = 1; i < 9; ++i) v = (j == i) ? Rf[i] : v;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) v = (j == 9 + i) ? pf[i] : v;
+            Bt.frame_pose[f][inst * 12 + j] = v;
+        }
+        if (Bt.frame_J[f] && valid) {
+            double col[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if ((Anc[jf] >> j) & 1ull) {
+                if (revolute) {
+                    const double dlt[3] = {pf[0] - pw[0], pf[1] - pw[1], pf[2] - pw[2]};
+                    cross3(zj, dlt, col);
+                    col[3] = zj[0]; col[4] = zj[1]; col[5] = zj[2];
+                } else {
+                    col[0] = zj[0]; col[1] = zj[1]; col[2] = zj[2];
+                }
+            }
+            double* J = Bt.frame_J[f] + inst * Bt.frame_J_stride[f];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) J[r * n + j] = col[r];
+        }
+    }
+    // ---- 4. centre of mass and its Jacobian
+    if (Bt.com || Bt.com_J) {
+        const double M = K->total_mass;
+        if (Bt.com) {
+            const double mj = valid ? Cw[j * 4 + 3] : 0.0;
+            double c3[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) c3[i] = colsum<64>(valid ? mj * Cw[j * 4 + i] : 0.0) / M;
+            if (j < 3) Bt.com[inst * 3 + j] = c3[j];
+        }
+        if (Bt.com_J) {
+            // subtree aggregates S_j = sum over the links l that joint j moves of m_l [c_l, 1]: a 0/1 matrix-vector
+            // product with the link values read at UNIFORM addresses (LDS broadcast), no divergence; then
+            // column j = z_j x (Sc_j - Sm_j p_j) / M  (revolute)   or   (Sm_j / M) z_j  (prismatic)
+            const unsigned long long mine = valid ? K->sub[j] : 0ull;
+            double sc[3] = {0.0, 0.0, 0.0}, sm = 0.0;
+            for (int l = 0; l < n; ++l) {
+                const double ml = ((mine >> l) & 1ull) ? Cw[l * 4 + 3] : 0.0;
+                sc[0] = fma(ml, Cw[l * 4], sc[0]); sc[1] = fma(ml, Cw[l * 4 + 1], sc[1]); sc[2] = fma(ml, Cw[l * 4 + 2], sc[2]);
+                sm += ml;
+            }
+            double acc[3];
+            if (revolute) {
+                const double dlt[3] = {sc[0] - sm * pw[0], sc[1] - sm * pw[1], sc[2] - sm * pw[2]};
+                cross3(zj, dlt, acc);
+            } else {
+                acc[0] = sm * zj[0]; acc[1] = sm * zj[1]; acc[2] = sm * zj[2];
+            }
+            if (valid) {
+                double* J = Bt.com_J + inst * Bt.com_J_stride;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) J[r * n + j] = acc[r] / M;
+            }
+        }
+    }
+}
+
+}  // namespace osot

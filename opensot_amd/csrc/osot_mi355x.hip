@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "osot_host_plan.h"
+#include "osot_kin.h"
 
 using namespace osot;
 
@@ -503,6 +504,62 @@ int osot_backend_get_num_variables(osot_backend* be, int* nv) {
 int osot_backend_get_num_constraints(osot_backend* be, int* nc) {
     if (!be || !nc) return fail(OSOT_ERR_INVALID, "null argument");
     *nc = be->nc;
+    return OSOT_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// batched kinematics producer
+// ---------------------------------------------------------------------------------------------------
+struct osot_kin {
+    DevKin* dev;
+    int n, n_frames, device;
+};
+
+extern "C" {
+
+int osot_kin_create(const osot_kin_desc* d, int device, osot_kin** out) {
+    if (!d || !out) return fail(OSOT_ERR_INVALID, "null argument");
+    if (d->n < 1 || d->n > OSOT_KIN_MAX_JOINTS) return fail(OSOT_ERR_INVALID, "joint count out of range");
+    if (d->n_frames < 0 || d->n_frames > OSOT_KIN_MAX_FRAMES) return fail(OSOT_ERR_INVALID, "frame count out of range");
+    DevKin h;
+    std::memset(&h, 0, sizeof(h));
+    h.d = *d;
+    for (int j = 0; j < d->n; ++j) {
+        if (d->parent[j] >= j || d->parent[j] < -1) return fail(OSOT_ERR_INVALID, "joints must be in tree order (parent[j] < j)");
+        if (d->type[j] != OSOT_JOINT_REVOLUTE && d->type[j] != OSOT_JOINT_PRISMATIC) return fail(OSOT_ERR_INVALID, "unknown joint type");
+        h.anc[j] = (1ull << j) | (d->parent[j] >= 0 ? h.anc[d->parent[j]] : 0ull);
+        for (int a = 0; a <= j; ++a) if ((h.anc[j] >> a) & 1ull) h.sub[a] |= (1ull << j);
+        h.total_mass += d->mass[j];
+    }
+    for (int f = 0; f < d->n_frames; ++f)
+        if (d->frame_joint[f] < 0 || d->frame_joint[f] >= d->n) return fail(OSOT_ERR_INVALID, "frame attached to a joint out of range");
+    if (!(h.total_mass > 0.0)) h.total_mass = 1.0;
+    HIP_TRY(hipSetDevice(device));
+    osot_kin* k = new osot_kin();
+    k->n = d->n; k->n_frames = d->n_frames; k->device = device;
+    hipError_t e = hipMalloc(&k->dev, sizeof(DevKin));
+    if (e == hipSuccess) e = hipMemcpy(k->dev, &h, sizeof(DevKin), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { delete k; return fail(OSOT_ERR_HIP, hipGetErrorString(e)); }
+    *out = k;
+    return OSOT_OK;
+}
+
+int osot_kin_destroy(osot_kin* k) {
+    if (!k) return OSOT_OK;
+    if (k->dev) hipFree(k->dev);
+    delete k;
+    return OSOT_OK;
+}
+
+int osot_kinematics(osot_kin* k, const osot_kin_batch* b, void* hip_stream) {
+    if (!k || !b) return fail(OSOT_ERR_INVALID, "null argument");
+    if (b->B < 0) return fail(OSOT_ERR_INVALID, "negative batch");
+    if (b->B == 0) return OSOT_OK;
+    if (!b->q) return fail(OSOT_ERR_INVALID, "q is null");
+    hipLaunchKernelGGL(osot_kin_kernel, dim3((unsigned)b->B), dim3(64), 0, (hipStream_t)hip_stream, (const DevKin*)k->dev, *b);
+    HIP_TRY(hipGetLastError());
     return OSOT_OK;
 }
 

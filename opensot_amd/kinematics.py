@@ -1,0 +1,147 @@
+"""Host side of the batched kinematics producer (include/osot_mi355x.h: osot_kin_*): model description,
+a 32-DoF humanoid tree for the benchmarks/tests, and the ctypes plumbing that points the producer at the row
+ranges of a BatchedStack's A_k buffers.  Plumbing only: the arithmetic is in csrc/osot_kin.h."""
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import abi
+
+
+@dataclass
+class KinModel:
+    parent: list
+    jtype: list
+    axis: np.ndarray            # [n][3]
+    R0: np.ndarray              # [n][3][3]
+    p0: np.ndarray              # [n][3]
+    mass: np.ndarray            # [n]
+    com: np.ndarray             # [n][3]
+    names: list = field(default_factory=list)
+    frames: list = field(default_factory=list)     # (name, joint index, R[3][3], p[3])
+
+    @property
+    def n(self):
+        return len(self.parent)
+
+    def frame_index(self, name):
+        return [f[0] for f in self.frames].index(name)
+
+    def desc(self):
+        d = abi.KinDesc()
+        d.n = self.n
+        for j in range(self.n):
+            d.parent[j] = int(self.parent[j]); d.type[j] = int(self.jtype[j]); d.mass[j] = float(self.mass[j])
+            for i in range(3):
+                d.axis[j][i] = float(self.axis[j][i]); d.p0[j][i] = float(self.p0[j][i]); d.com[j][i] = float(self.com[j][i])
+            for i in range(9):
+                d.R0[j][i] = float(self.R0[j].reshape(9)[i])
+        d.n_frames = len(self.frames)
+        for f, (_, jf, R, p) in enumerate(self.frames):
+            d.frame_joint[f] = int(jf)
+            for i in range(9):
+                d.frame_R[f][i] = float(np.asarray(R).reshape(9)[i])
+            for i in range(3):
+                d.frame_p[f][i] = float(p[i])
+        return d
+
+
+def _rpy(r, p, y):
+    cr, sr, cp, sp, cy, sy = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+    return np.array([[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+                     [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+                     [-sp, cp * sr, cp * cr]])
+
+
+def humanoid32():
+    """a 32-DoF floating-base humanoid tree: 6 virtual joints (x, y, z, roll, pitch, yaw), 3 waist, 2 x 6 leg,
+    2 x 5 arm, 1 neck.  Link lengths / masses are COMAN-like round numbers (the reference robot,
+    tests/robots/coman_floating_base, has 6 + 29 = 35 coordinates; BASELINE's configs are quoted for 32)."""
+    P, R = abi.JOINT_PRISMATIC, abi.JOINT_REVOLUTE
+    X, Y, Z = [1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0]
+    rows = []   # (name, parent name, type, axis, xyz, rpy, mass, com)
+
+    def add(name, parent, t, ax, xyz=(0, 0, 0), rpy=(0, 0, 0), mass=0.0, com=(0, 0, 0)):
+        rows.append((name, parent, t, ax, xyz, rpy, mass, com))
+    add("base_x", None, P, X); add("base_y", "base_x", P, Y); add("base_z", "base_y", P, Z)
+    add("base_roll", "base_z", R, X); add("base_pitch", "base_roll", R, Y)
+    add("base_yaw", "base_pitch", R, Z, mass=4.0, com=(0.0, 0.0, 0.02))            # pelvis
+    add("WaistLat", "base_yaw", R, X, xyz=(0.02, 0, 0.12), mass=0.8, com=(0, 0, 0.02))
+    add("WaistSag", "WaistLat", R, Y, mass=0.8, com=(0, 0, 0.03))
+    add("WaistYaw", "WaistSag", R, Z, xyz=(0, 0, 0.04), mass=6.0, com=(0, 0, 0.12))   # torso
+    for s, sy in (("R", -1.0), ("L", 1.0)):
+        add(s + "HipSag", "base_yaw", R, Y, xyz=(0, sy * 0.07, -0.03), mass=0.9, com=(0, 0, -0.02))
+        add(s + "HipLat", s + "HipSag", R, X, mass=0.9, com=(0, 0, -0.03))
+        add(s + "HipYaw", s + "HipLat", R, Z, xyz=(0, 0, -0.10), mass=1.6, com=(0, 0, -0.06))
+        add(s + "KneeSag", s + "HipYaw", R, Y, xyz=(0, 0, -0.12), mass=1.3, com=(0, 0, -0.09))
+        add(s + "AnkLat", s + "KneeSag", R, X, xyz=(0, 0, -0.20), mass=0.4, com=(0, 0, -0.01))
+        add(s + "AnkSag", s + "AnkLat", R, Y, mass=0.7, com=(0.02, 0, -0.05))
+    for s, sy in (("R", -1.0), ("L", 1.0)):
+        add(s + "ShSag", "WaistYaw", R, Y, xyz=(0.0, sy * 0.15, 0.22), rpy=(sy * 0.17, 0, 0), mass=0.7, com=(0, sy * 0.02, 0))
+        add(s + "ShLat", s + "ShSag", R, X, mass=0.7, com=(0, 0, -0.03))
+        add(s + "ShYaw", s + "ShLat", R, Z, xyz=(0, 0, -0.05), mass=1.0, com=(0, 0, -0.08))
+        add(s + "Elbj", s + "ShYaw", R, Y, xyz=(0.015, 0, -0.13), mass=0.9, com=(0, 0, -0.08))
+        add(s + "Wrj", s + "Elbj", R, Z, xyz=(0, 0, -0.16), mass=0.5, com=(0, 0, -0.04))
+    add("NeckYaw", "WaistYaw", R, Z, xyz=(0, 0, 0.28), mass=1.5, com=(0, 0, 0.08))
+    names = [r[0] for r in rows]
+    n = len(rows)
+    assert n == 32, n
+    m = KinModel(parent=[-1 if r[1] is None else names.index(r[1]) for r in rows], jtype=[r[2] for r in rows],
+                 axis=np.array([r[3] for r in rows], dtype=float), R0=np.array([_rpy(*r[5]) for r in rows]),
+                 p0=np.array([r[4] for r in rows], dtype=float), mass=np.array([r[6] for r in rows], dtype=float),
+                 com=np.array([r[7] for r in rows], dtype=float), names=names)
+    I = np.eye(3)
+    m.frames = [("l_wrist", names.index("LWrj"), I, (0, 0, -0.08)), ("r_wrist", names.index("RWrj"), I, (0, 0, -0.08)),
+                ("l_sole", names.index("LAnkSag"), I, (0.02, 0, -0.10)), ("r_sole", names.index("RAnkSag"), I, (0.02, 0, -0.10))]
+    return m
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Kinematics:
+    """osot_kin handle + the binding of its outputs to device buffers."""
+
+    def __init__(self, model: KinModel, device=0):
+        self.model = model
+        self._lib = abi.lib()
+        self._h = C.c_void_p()
+        d = model.desc()
+        abi.check(self._lib.osot_kin_create(C.byref(d), int(device), C.byref(self._h)), "osot_kin_create")
+        self.device = torch.device("cuda", device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                self._lib.osot_kin_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def forward(self, q, frame_pose=None, frame_J=None, com=None, com_J=None):
+        """q [B][n] (device).  frame_pose: {frame index: tensor [B][12]}; frame_J: {frame index: (A_k tensor [B][ma][n],
+        first row)}; com: tensor [B][3]; com_J: (A_k tensor, first row).  Stream-ordered on torch's current stream."""
+        B, n = q.shape
+        assert n == self.model.n and q.is_contiguous()
+        kb = abi.KinBatch()
+        kb.B = B
+        kb.q = q.data_ptr()
+        for f, t in (frame_pose or {}).items():
+            assert t.shape[0] >= B and t.is_contiguous()
+            kb.frame_pose[f] = t.data_ptr()
+        for f, (A, row) in (frame_J or {}).items():
+            assert A.is_contiguous() and A.shape[2] == n and row + 6 <= A.shape[1]
+            kb.frame_J[f] = A.data_ptr() + 8 * row * n
+            kb.frame_J_stride[f] = A.shape[1] * n
+        if com is not None:
+            kb.com = com.data_ptr()
+        if com_J is not None:
+            A, row = com_J
+            assert A.is_contiguous() and A.shape[2] == n and row + 3 <= A.shape[1]
+            kb.com_J = A.data_ptr() + 8 * row * n
+            kb.com_J_stride = A.shape[1] * n
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        abi.check(self._lib.osot_kinematics(self._h, C.byref(kb), stream), "osot_kinematics")

@@ -1,0 +1,147 @@
+"""Batched kinematics producer: the numpy restatement against finite differences (CPU), the HIP kernel
+against the restatement (GPU), and a closed loop: kinematics -> AutoStack::update -> cascade -> q += dq, all on the
+device, the end effectors converging on their targets like examples/cpp/coman_ik.cpp:174-219."""
+import numpy as np
+import pytest
+
+from opensot_amd import abi, kinematics as kin
+from opensot_amd.plan import StackPlan, Task, Bound, eps_abs_from_factor
+from oracle import pykin
+
+
+def _fd_jacobians(m, q, h=1e-6):
+    o = pykin.forward(m, q)
+    Jf = [np.zeros((6, m.n)) for _ in m.frames]
+    Jc = np.zeros((3, m.n))
+    for j in range(m.n):
+        dq = np.zeros(m.n); dq[j] = h
+        a, b = pykin.forward(m, q + dq), pykin.forward(m, q - dq)
+        Jc[:, j] = (a["com"] - b["com"]) / (2 * h)
+        for f in range(len(m.frames)):
+            Jf[f][:3, j] = (a["frame_p"][f] - b["frame_p"][f]) / (2 * h)
+            S = (a["frame_R"][f] - b["frame_R"][f]) / (2 * h) @ o["frame_R"][f].T     # [w]x
+            Jf[f][3:, j] = [S[2, 1], S[0, 2], S[1, 0]]
+    return o, Jf, Jc
+
+
+def test_restatement_matches_finite_differences():
+    m = kin.humanoid32()
+    assert m.n == 32 and abs(m.mass.sum() - 32.3) < 1e-12
+    rng = np.random.default_rng(3)
+    for _ in range(3):
+        q = rng.uniform(-0.8, 0.8, m.n)
+        o, Jf, Jc = _fd_jacobians(m, q)
+        for f in range(len(m.frames)):
+            assert np.abs(Jf[f] - o["J"][f]).max() < 1e-8
+            assert np.abs(o["frame_R"][f] @ o["frame_R"][f].T - np.eye(3)).max() < 1e-14
+        assert np.abs(Jc - o["Jcom"]).max() < 1e-8
+
+
+def test_kin_desc_checks_without_gpu():
+    L = abi.lib()
+    import ctypes as C
+    d = kin.humanoid32().desc()
+    h = C.c_void_p()
+    d.parent[5] = 7      # not in tree order
+    assert L.osot_kin_create(C.byref(d), 0, C.byref(h)) == abi.ERR_INVALID
+    d = kin.humanoid32().desc(); d.n = 65
+    assert L.osot_kin_create(C.byref(d), 0, C.byref(h)) == abi.ERR_INVALID
+    d = kin.humanoid32().desc(); d.frame_joint[1] = 40
+    assert L.osot_kin_create(C.byref(d), 0, C.byref(h)) == abi.ERR_INVALID
+    assert L.osot_kinematics(None, None, None) == abi.ERR_INVALID
+
+
+@pytest.mark.gpu
+def test_kernel_matches_restatement(gpu_device):
+    import torch
+    m = kin.humanoid32()
+    K = kin.Kinematics(m, device=0)
+    B = 257
+    rng = np.random.default_rng(5)
+    q = rng.uniform(-1.0, 1.0, (B, m.n))
+    dev = torch.device("cuda", 0)
+    tq = torch.as_tensor(q, device=dev)
+    A = torch.full((B, 24 + 3 + 2, m.n), 7.0, dtype=torch.float64, device=dev)    # 4 frames + CoM rows + 2 spare rows
+    poses = {f: torch.zeros((B, 12), dtype=torch.float64, device=dev) for f in range(4)}
+    com = torch.zeros((B, 3), dtype=torch.float64, device=dev)
+    K.forward(tq, frame_pose=poses, frame_J={f: (A, 6 * f) for f in range(4)}, com=com, com_J=(A, 24))
+    torch.cuda.synchronize()
+    Ah = A.cpu().numpy()
+    for i in range(0, B, 16):
+        o = pykin.forward(m, q[i])
+        for f in range(4):
+            assert np.abs(Ah[i, 6 * f:6 * f + 6] - o["J"][f]).max() < 1e-13
+            ph = poses[f][i].cpu().numpy()
+            assert np.abs(ph[:9].reshape(3, 3) - o["frame_R"][f]).max() < 1e-14
+            assert np.abs(ph[9:] - o["frame_p"][f]).max() < 1e-14
+        assert np.abs(Ah[i, 24:27] - o["Jcom"]).max() < 1e-14
+        assert np.abs(com[i].cpu().numpy() - o["com"]).max() < 1e-14
+    assert (Ah[:, 27:] == 7.0).all()          # rows outside the producers' ranges are untouched
+
+
+@pytest.mark.gpu
+def test_closed_loop_ik_on_device(gpu_device):
+    """coman_ik.cpp:174-219 with everything resident: q -> poses/Jacobians (osot_kinematics) -> b, box
+    (osot_stack_update) -> dq (osot_ihqp_solve) -> q += dq.  Stack of BASELINE config 3."""
+    import torch
+    from opensot_amd.solver import BatchedStack
+    m = kin.humanoid32()
+    n, B = m.n, 128
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(9)
+    q0 = np.zeros((B, n))
+    q0[:, [m.names.index(s + "KneeSag") for s in "RL"]] = 0.5
+    q0[:, [m.names.index(s + "HipSag") for s in "RL"]] = -0.25
+    q0[:, [m.names.index(s + "AnkSag") for s in "RL"]] = -0.25
+    q0[:, [m.names.index(s + "Elbj") for s in "RL"]] = -0.6
+    q0 += rng.normal(0.0, 0.02, (B, n))
+    levels = [[Task(abi.TASK_COM, 3, lam=0.1, name="com")],
+              [Task(abi.TASK_CARTESIAN, 6, weight=0.1, lam=0.1, name="l_wrist"), Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="r_wrist"),
+               Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="l_sole"), Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="r_sole")],
+              [Task(abi.TASK_POSTURAL, n, lam=0.01, name="postural")]]
+    bounds = [Bound(abi.BOUND_JOINT_LIMITS, scaling=1.0, name="jl"), Bound(abi.BOUND_VELOCITY_LIMITS, dT=0.01, name="vl")]
+    plan = StackPlan(n=n, levels=levels, bounds=bounds, rowblocks=[], eps_abs=eps_abs_from_factor(1e6))
+    st = BatchedStack(plan, B, device=0, want_levels=False)
+    K = kin.Kinematics(m, device=0)
+    f64 = dict(dtype=torch.float64, device=dev)
+    q = torch.as_tensor(q0, **f64).contiguous()
+    pose = [torch.zeros((B, 12), **f64) for _ in range(4)]
+    com = torch.zeros((B, 3), **f64)
+
+    def fk():
+        K.forward(q, frame_pose={f: pose[f] for f in range(4)}, frame_J={f: (st.A[1], 6 * f) for f in range(4)},
+                  com=com, com_J=(st.A[0], 0))
+    fk()
+    torch.cuda.synchronize()
+    # targets: feet stay, wrists move 6 cm, CoM 2 cm
+    pose_d = [p.clone() for p in pose]
+    pose_d[0][:, 9:] += torch.as_tensor([0.04, 0.03, 0.03], **f64)
+    pose_d[1][:, 9:] += torch.as_tensor([0.04, -0.03, 0.03], **f64)
+    com_d = com.clone(); com_d[:, 0] += 0.02
+    qmin = torch.full((B, n), -2.5, **f64); qmax = torch.full((B, n), 2.5, **f64)
+    qdot_max = torch.full((B, n), 2.0, **f64)
+    q_ref = q.clone()
+    leaf = {"B": B, "task": [[(com, com_d, None)], [(pose[f], pose_d[f], None) for f in range(4)], [(q, q_ref, None)]],
+            "bound": [(q, qmin, qmax), (qdot_max, None, None)], "rows": []}
+    err0 = None
+    for cycle in range(300):
+        fk()
+        st.update(leaf)
+        st.solve(B)
+        q += st.dq[:B]
+        if cycle == 0:
+            torch.cuda.synchronize()
+            assert (st.status[:B] == 0).all()
+            err0 = [float((pose_d[f][:, 9:] - pose[f][:, 9:]).norm(dim=1).max()) for f in range(4)]
+    fk()
+    torch.cuda.synchronize()
+    assert (st.status[:B] == 0).all()
+    err = [float((pose_d[f][:, 9:] - pose[f][:, 9:]).norm(dim=1).max()) for f in range(4)]
+    assert err0[0] > 0.05 and err0[1] > 0.05
+    assert err[1] < 0.05 * err0[1]                 # r_wrist (full weight) converged (shares its level with the feet)
+    assert err[0] < 0.2 * err0[0]                  # l_wrist (weight 0.1, same level) follows
+    assert err[2] < 5e-3 and err[3] < 5e-3         # the feet (same level as the wrists: a least-squares compromise) stayed
+    assert float((com_d - com).norm(dim=1).max()) < 2e-3
+    # the restatement agrees with the device state at the end
+    o = pykin.forward(m, q[3].cpu().numpy())
+    assert np.abs(pose[1][3].cpu().numpy()[9:] - o["frame_p"][1]).max() < 1e-12
