@@ -42,8 +42,9 @@ __device__ __forceinline__ void cross3(const double* a, const double* b, double*
 
 __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__ K, const osot_kin_batch Bt) {
     constexpr int TS = 12;
-    OSOT_STATIC_LDS(double, Tl, 64 * TS);    // local transforms  [R | p]
-    OSOT_STATIC_LDS(double, Tw, 64 * TS);    // world transforms of the joint frames
+    OSOT_STATIC_LDS(double, Tb, 2 * 64 * TS);   // two transform buffers [R | p] per joint (ping-pong of the pointer jumping:
+    double* Tl = Tb;                            //  ONE array indexed by an offset, so that every access stays a DS op --
+    //                                              swapping two pointers made the compiler fall back to flat loads)
     OSOT_STATIC_LDS(double, Zw, 64 * 3);     // world joint axes
     OSOT_STATIC_LDS(double, Cw, 64 * 4);     // world link centres of mass, mass
     OSOT_STATIC_LDS(int, Par, 64);           // parent indices (the chain walk must not chase pointers through HBM)
@@ -94,16 +95,15 @@ __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__
     for (int i = 0; i < 3; ++i) pw[i] = valid ? Tl[j * TS + 9 + i] : 0.0;
     {
         int jp = Par[j];
-        double* cur = Tl;
-        double* nxt = Tw;
+        int cur = 0, nxt = 64 * TS;
         while (wave_ballot(jp >= 0) != 0ull) {
             int njp = jp;
             if (jp >= 0) {
                 double Ra[9], pa[3], Rn[9], pn[3];
 #pragma unroll
-                for (int i = 0; i < 9; ++i) Ra[i] = cur[jp * TS + i];
+                for (int i = 0; i < 9; ++i) Ra[i] = Tb[cur + jp * TS + i];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) pa[i] = cur[jp * TS + 9 + i];
+                for (int i = 0; i < 3; ++i) pa[i] = Tb[cur + jp * TS + 9 + i];
                 mat3_mul(Ra, Rw, Rn);
                 mat3_vec(Ra, pw, pn);
 #pragma unroll
@@ -114,15 +114,16 @@ __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__
             }
             wave_sync();            // everybody has read Par / cur
 #pragma unroll
-            for (int i = 0; i < 9; ++i) nxt[j * TS + i] = Rw[i];
+            for (int i = 0; i < 9; ++i) Tb[nxt + j * TS + i] = Rw[i];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) nxt[j * TS + 9 + i] = pw[i];
+            for (int i = 0; i < 3; ++i) Tb[nxt + j * TS + 9 + i] = pw[i];
             Par[j] = njp;
             jp = njp;
             wave_sync();
-            double* t = cur; cur = nxt; nxt = t;
+            const int t = cur; cur = nxt; nxt = t;
         }
     }
+    double* Tw = Tb + 64 * TS;   // final world transforms (written below, after the last round's barrier)
     if (valid) {
         double z[3], cl[3];
         mat3_vec(Rw, K->d.axis[j], z);
