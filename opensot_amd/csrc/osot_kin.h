@@ -12,8 +12,8 @@
 //      (mass and first moment of the links joint j moves): z_j x (Sc_j - Sm_j p_j) / M  (prismatic: (Sm_j / M) z_j)
 // HBM-bound by construction: reads 8 n bytes of q, writes (6 F + 3) n 8 + 96 F + 24 bytes per instance.
 #pragma once
-#include "osot_team.h"
-#include "../../include/osot_mi355x.h"
+#include <osot_team.h>
+#include <osot_mi355x.h>
 
 namespace osot {
 

@@ -4,6 +4,7 @@
 // Built by tests/emu/build.sh; used by tests/test_emulated_kernels.py (no GPU needed).
 #include <osot_team.h>
 #include "osot_host_plan.h"
+#include "osot_kin.h"
 
 using namespace osot;
 
@@ -39,5 +40,23 @@ extern "C" __attribute__((visibility("default"))) int emu_qp_solve_batch(int B, 
     const unsigned grid = (unsigned)B;
     if (T == 32) emu::launch(osot_qp_kernel<32>, grid, lds, 64, Q);
     else emu::launch(osot_qp_kernel<64>, grid, lds, 64, Q);
+    return OSOT_OK;
+}
+
+// the kinematics producer (opensot_amd/csrc/osot_kin.h) on host pointers; the ancestor / subtree masks are built as in
+// osot_kin_create (opensot_amd/csrc/osot_mi355x.hip)
+extern "C" __attribute__((visibility("default"))) int emu_kinematics(const osot_kin_desc* d, const osot_kin_batch* b) {
+    if (!d || !b || d->n < 1 || d->n > OSOT_KIN_MAX_JOINTS) return OSOT_ERR_INVALID;
+    static DevKin h;
+    memset(&h, 0, sizeof(h));
+    h.d = *d;
+    for (int j = 0; j < d->n; ++j) {
+        if (d->parent[j] >= j) return OSOT_ERR_INVALID;
+        h.anc[j] = (1ull << j) | (d->parent[j] >= 0 ? h.anc[d->parent[j]] : 0ull);
+        for (int a = 0; a <= j; ++a) if ((h.anc[j] >> a) & 1ull) h.sub[a] |= (1ull << j);
+        h.total_mass += d->mass[j];
+    }
+    if (!(h.total_mass > 0.0)) h.total_mass = 1.0;
+    emu::launch(osot_kin_kernel, (unsigned)b->B, 0, 64, (const DevKin*)&h, *b);
     return OSOT_OK;
 }

@@ -42,7 +42,8 @@ def emu_lib():
         srcs = [os.path.join(ROOT, "tests", "emu", "emu_driver.cpp"),
                 os.path.join(ROOT, "opensot_amd", "csrc", "osot_qp_core.h"),
                 os.path.join(ROOT, "opensot_amd", "csrc", "osot_kernels.h"),
-                os.path.join(ROOT, "opensot_amd", "csrc", "osot_host_plan.h")]
+                os.path.join(ROOT, "opensot_amd", "csrc", "osot_host_plan.h"),
+                os.path.join(ROOT, "opensot_amd", "csrc", "osot_kin.h")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["sh", os.path.join(ROOT, "tests", "emu", "build.sh")])
         L = C.CDLL(so)
@@ -157,3 +158,28 @@ def kkt_check(H, g, A, lA, uA, l, u, x, eps_abs, tol=1e-7):
         if s > 0:
             assert v >= -1e-6 * (1 + np.abs(lam).max()), "negative multiplier on an active inequality"
     return resid
+
+
+def emu_kinematics(model, q):
+    """the kinematics kernel body on host arrays through the emulator: q [B][n] -> poses, frame Jacobians, com, Jcom"""
+    L = emu_lib()
+    L.emu_kinematics.argtypes = [C.POINTER(abi.KinDesc), C.POINTER(abi.KinBatch)]
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    B, n = q.shape
+    F = len(model.frames)
+    d = model.desc()
+    kb = abi.KinBatch()
+    kb.B = B
+    kb.q = q.ctypes.data
+    poses = [np.zeros((B, 12)) for _ in range(F)]
+    J = np.full((B, 6 * F + 3, n), 7.0)
+    com = np.zeros((B, 3))
+    for f in range(F):
+        kb.frame_pose[f] = poses[f].ctypes.data
+        kb.frame_J[f] = J.ctypes.data + 8 * 6 * f * n
+        kb.frame_J_stride[f] = (6 * F + 3) * n
+    kb.com = com.ctypes.data
+    kb.com_J = J.ctypes.data + 8 * 6 * F * n
+    kb.com_J_stride = (6 * F + 3) * n
+    assert L.emu_kinematics(C.byref(d), C.byref(kb)) == 0
+    return poses, J, com

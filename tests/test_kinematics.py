@@ -51,6 +51,23 @@ def test_kin_desc_checks_without_gpu():
     assert L.osot_kinematics(None, None, None) == abi.ERR_INVALID
 
 
+def test_emulated_kernel_matches_restatement():
+    """the kernel body (pointer jumping, ancestor masks, subtree aggregates) run lane by lane on the host emulator"""
+    from helpers import emu_kinematics
+    m = kin.humanoid32()
+    rng = np.random.default_rng(6)
+    q = rng.uniform(-1.0, 1.0, (5, m.n))
+    poses, J, com = emu_kinematics(m, q)
+    for i in range(5):
+        o = pykin.forward(m, q[i])
+        for f in range(4):
+            assert np.abs(J[i, 6 * f:6 * f + 6] - o["J"][f]).max() < 1e-13
+            assert np.abs(poses[f][i][:9].reshape(3, 3) - o["frame_R"][f]).max() < 1e-14
+            assert np.abs(poses[f][i][9:] - o["frame_p"][f]).max() < 1e-14
+        assert np.abs(J[i, 24:27] - o["Jcom"]).max() < 1e-14
+        assert np.abs(com[i] - o["com"]).max() < 1e-14
+
+
 @pytest.mark.gpu
 def test_kernel_matches_restatement(gpu_device):
     import torch
