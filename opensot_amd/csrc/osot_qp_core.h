@@ -1058,7 +1058,10 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                 }
             }
         }
-        colargmin<64>(cand, code);   // all 64 lanes: the unit-row pass holds different rows in the two halves
+        // all 64 lanes when the unit-row / stored-row passes ran (they hold different rows in the two halves);
+        // box candidates alone are replicated over the halves, so the 32-lane network does
+        if (any_unit || n_gen > 0 || NP == 64) colargmin<64>(cand, code);
+        else colargmin<NP>(cand, code);
         code = uniform_i(code);
         OSOT_SUB_END(PH_IN_SCAN);
         if (code == kNone) break;   // primal feasible: optimal
@@ -1121,7 +1124,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                     for (int t = 0; t < 4; ++t) {
                         const int j = j0 - t;
                         if (j >= me) {
-                            const double rj = bcast(d1, j) * bcast(rinv, j);
+                            const double rj = bcast(d1 * rinv, j);   // lane j scales its own entry: one broadcast
                             if (c == j) rr = rj;
                             if (c >= me && c < j) d1 = fma(-rc[t], rj, d1);
                         }
