@@ -121,6 +121,26 @@ __device__ __forceinline__ double jt_cols_dot(const WaveCtx<NP>& w, const double
     return halfsum<NP>((acc0 + acc1) + (acc2 + acc3));
 }
 
+// the same product when vec is known to vanish below row j0 (z = J2 d2 with a large working set), NP = 64: only
+// the rows from j0 rounded down to a multiple of sixteen are read (measured: -3 % on the 50-variable stack; for
+// NP = 32 the fixed, fully unrolled walk above is faster)
+__device__ __forceinline__ double jt_cols_dot_tail64(const WaveCtx<64>& w, const double* vec, int j0) {
+    constexpr int S = WaveCtx<64>::S, RT = 16;
+    double acc0 = 0.0, acc1 = 0.0;
+    for (int jj = j0 & ~(RT - 1); jj < 64; jj += RT) {
+        const double* col = w.M2 + jj * S + w.c;
+        const double* v = vec + jj;
+        double a[RT], b[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) a[t] = col[t * S];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) b[t] = v[t];
+#pragma unroll
+        for (int t = 0; t < RT; t += 2) { acc0 = fma(a[t], b[t], acc0); acc1 = fma(a[t + 1], b[t + 1], acc1); }
+    }
+    return acc0 + acc1;
+}
+
 // One Householder reflection that maps d2 = d[iq:] onto alpha*e_iq, applied to the columns iq.. of J
 // (rows iq.. of JT); appends (d1; alpha) as column iq of R.  z = J2 d2 is an input.
 template <int NP, bool WRITE_R>
@@ -1106,7 +1126,9 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
             // z = J2 d2 : primal step direction
             if (h == 0) V1[c] = d2;
             wave_sync();
-            const double z = jt_cols_dot<NP>(w, V1);
+            double z;
+            if constexpr (NP == 64) z = jt_cols_dot_tail64(w, V1, iq);   // d2 vanishes below row iq
+            else z = jt_cols_dot<NP>(w, V1);
             OSOT_SUB_END(PH_IN_Z);
             // r = R^-1 d1 restricted to the inequality part [me, iq): dual step direction.  The reciprocals of
             // the diagonal are formed lane-parallel up front and the columns of R are fetched four steps
