@@ -1127,7 +1127,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
             if (h == 0) V1[c] = d2;
             wave_sync();
             double z;
-            if constexpr (NP == 64) z = jt_cols_dot_tail64(w, V1, iq);   // d2 vanishes below row iq
+            if constexpr (NP == 64) z = (iq >= 16) ? jt_cols_dot_tail64(w, V1, iq) : jt_cols_dot<NP>(w, V1);   // d2 = 0 below iq
             else z = jt_cols_dot<NP>(w, V1);
             OSOT_SUB_END(PH_IN_Z);
             // r = R^-1 d1 restricted to the inequality part [me, iq): dual step direction.  The reciprocals of
