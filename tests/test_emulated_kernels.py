@@ -240,3 +240,22 @@ def test_more_rows_than_variables(n, rows, oracle):
         # routine supports (its working set is sized n, like the reference's); pinned by qpOASES
         rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
         assert (rq["status"] == 1).all() and np.abs(dq - rq["dq"]).max() < 1e-6
+
+
+def test_last_free_direction_is_not_called_dependent(oracle):
+    """found by tools/stress_parity.py: default eps (4.4e-11), 21 of 22 directions taken, a violated inequality whose
+    normal has |d2|^2 = 6e-19 |d|^2 in the last free direction (|d|^2 is dominated by the 1/eps-scaled directions).
+    A dependency threshold of 1e-18 |d|^2 called it dependent and the instance INFEASIBLE; the reference solves it."""
+    kw = {'n_eq': 3, 'n_ineq': 5, 'seed': 201675281, 'box': 0.5, 'postural_last': False, 'eps_factor': 200.0}
+    plan, leaf = synth.make_generic_stack(192, 22, [12, 3, 13], **kw)
+    asm = oracle.assemble(plan, leaf)
+    i = 140
+    sub = {k: (v[i:i + 1] if isinstance(v, np.ndarray) and v.shape[:1] == (192,) else v) for k, v in asm.items()}
+    for name in ("A", "b", "w", "c"):
+        sub[name] = [None if a is None else a[i:i + 1] for a in asm[name]]
+    sub["B"] = 1
+    dq, xl, st, it = emu_cascade(plan, sub)
+    assert (st == 0).all()
+    if oracle.ref_available():
+        rq = oracle.ihqp_solve_batch(sub, oracle.BE_QPOASES_REF, nthreads=1)
+        assert (rq["status"] == 1).all() and np.abs(dq - rq["dq"]).max() < 2e-6
