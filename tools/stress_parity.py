@@ -10,9 +10,10 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 B = 192
 bad = 0
+counted = total = 0
 t0 = time.time()
 for it in range(N):
-    kind = rng.integers(0, 3)
+    kind = rng.integers(0, 5)
     n = int(rng.integers(5, 33))
     if kind == 0:
         L = int(rng.integers(1, 4))
@@ -29,6 +30,17 @@ for it in range(N):
                   dependent=bool(rng.integers(0, 4) == 0), zero_row=bool(rng.integers(0, 6) == 0),
                   second_level_rows=int(rng.integers(0, 8)), box=float(rng.choice([0.05, 0.4])), eps_factor=float(rng.choice([1e6, 2e2])))
         plan, leaf = synth.make_lowrank_stack(B, n, **kw); desc = ("lowrank", n, kw)
+    elif kind == 3:     # the 64-lane instantiation: 33 .. 64 variables
+        n = int(rng.integers(33, 65))
+        L = int(rng.integers(1, 3))
+        rows = [int(rng.integers(2, n - 4)) for _ in range(L)]
+        while sum(rows) > n + 4: rows[int(np.argmax(rows))] -= 1
+        kw = dict(n=n, level_rows=rows, n_eq=int(rng.integers(0, 8)), n_ineq=int(rng.integers(0, 10)), seed=int(rng.integers(1 << 30)),
+                  box=float(rng.choice([0.1, 0.5])), postural_last=bool(rng.integers(0, 2)), eps_factor=1e6)
+        plan, leaf = synth.make_generic_stack(B, kw.pop("n"), kw.pop("level_rows"), **kw); desc = ("generic64", n, rows, kw)
+    elif kind == 4:     # inverse-dynamics stack (config 5 shape)
+        seed = int(rng.integers(1 << 30))
+        plan, leaf = synth.make_id_stack(B, seed=seed); desc = ("C5", seed, 1e6)
     else:
         cfg = str(rng.choice(["C2", "C3", "C4"]))
         seed = int(rng.integers(1 << 30)); eps = float(rng.choice([1e6, 2e2]))
@@ -39,13 +51,21 @@ for it in range(N):
     dq = st.dq[:B].cpu().numpy(); status = st.status[:B].cpu().numpy()
     rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=0, termination_tolerance=10 * 2.221e-16)
     rd = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=0)       # the reference's own option set
-    # instances on which qpOASES at its default options and qpOASES run to the exact optimum agree: elsewhere the
-    # reference's early termination (terminationTolerance 2.2e-7), or a failure of the tight run, is the difference
-    ok = (rq["status"] == 1) & (rd["status"] == 1) & (np.abs(rq["dq"] - rd["dq"]).max(axis=1) < 1e-7)
-    err = np.abs(dq[ok] - rq["dq"][ok]).max() if ok.any() else 0.0
+    # per instance: the distance to the CLOSER of qpOASES at its own options (early termination: up to 3e-3 off on a few
+    # instances per thousand) and qpOASES run to the exact optimum (which itself fails on some ill-conditioned instances)
+    e_def = np.where(rd["status"] == 1, np.abs(dq - rd["dq"]).max(axis=1), np.inf)
+    e_ex = np.where(rq["status"] == 1, np.abs(dq - rq["dq"]).max(axis=1), np.inf)
+    # third witness: the line-by-line restatement of the reference's eiQuadProg (exact active-set method, independent
+    # of qpOASES' homotopy); it refuses stacks with more equality rows than variables
+    re_ = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=0)
+    e_ei = np.where(re_["status"] == 1, np.abs(dq - re_["dq"]).max(axis=1), np.inf)
+    e = np.minimum(np.minimum(e_def, e_ex), e_ei)
+    ok = np.isfinite(e)
+    counted += int(ok.sum()); total += B
+    err = e[ok].max() if ok.any() else 0.0
     nfail = int((status[ok] != 0).sum())
     tol = 1e-6 if (len(desc) < 3 or desc[-1] == 1e6 or (isinstance(desc[-1], dict) and desc[-1].get("eps_factor", 1e6) == 1e6)) else 2e-5
     if (nfail or err > tol) and not (desc[0] == "generic" and desc[-1].get("box") == 0.0 and desc[-1].get("eps_factor") == 200.0):
         bad += 1
-        print("MISMATCH", desc, "failed", nfail, "of", int(ok.sum()), "max err %.3e" % err, "worst instance", int(np.argmax(np.abs(dq - rq["dq"]).max(axis=1) * ok)), flush=True)
-print(f"{N} configurations x {B} instances in {time.time() - t0:.0f} s: {bad} with a mismatch")
+        print("MISMATCH", desc, "failed", nfail, "of", int(ok.sum()), "max err %.3e" % err, "worst instance", int(np.argmax(np.where(ok, e, 0.0))), flush=True)
+print(f"{N} configurations x {B} instances in {time.time() - t0:.0f} s: {bad} with a mismatch ({counted} of {total} instances compared: distance to the closest of qpOASES at its own options, qpOASES run to the exact optimum, the eiQuadProg restatement)")
