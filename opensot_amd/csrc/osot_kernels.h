@@ -154,8 +154,10 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
                 const double wpost = postc ? (wk ? wk[ma + c] : 1.0) : 0.0;
                 double cvec = (D.c[k] && valid) ? D.c[k][inst * n + c] : 0.0;
                 if (postc) cvec -= wpost * bk[ma + c];
-                lowrank_prepare32(reinterpret_cast<const WaveCtx<32>&>(w), Ak, bk, wk, ma, P.eps_abs + wpost, cvec,
-                                  D.c[k] != nullptr || npost > 0, xprep);
+                const WaveCtx<32>& w32 = reinterpret_cast<const WaveCtx<32>&>(w);
+                const bool has_c = D.c[k] != nullptr || npost > 0;
+                if (ma <= 3) lowrank_prepare32<3>(w32, Ak, bk, wk, ma, P.eps_abs + wpost, cvec, has_c, xprep);
+                else lowrank_prepare32<kLowRankMax>(w32, Ak, bk, wk, ma, P.eps_abs + wpost, cvec, has_c, xprep);
             }
         }
         if (lowrank) {

@@ -673,9 +673,11 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
 // instead of the n x n x m product and a 32-column factorisation.  A numerically dependent row is dropped.
 // Out: M2 = JT (M2[j][c] = J[c][j]), x; M1 is used as staging.
 constexpr int kLowRankMax = 4;
+// MM = compile-time bound on the rows (3 for a CoM task, else kLowRankMax): the m x m algebra is fully unrolled
+template <int MM>
 __device__ inline void lowrank_prepare32(const WaveCtx<32>& w, const double* Ak, const double* bk, const double* wk,
                                          int m, double dcol, double cvec, bool has_c, double& x_out) {
-    constexpr int S = WaveCtx<32>::S, MM = kLowRankMax;
+    constexpr int S = WaveCtx<32>::S;
     const int c = w.c, h = w.h, n = w.n;
     const bool valid = c < n;
     double* M1 = w.M1;
