@@ -98,6 +98,22 @@ def humanoid32():
     return m
 
 
+def from_json(path):
+    """a tree fixture as written by tests/golden/make_coman_tree.py (the reference's COMAN, 6 virtual + 29 revolute
+    joints): returns (KinModel, lower[n], upper[n]) -- the limits are +-inf for the virtual joints."""
+    import json
+    d = json.load(open(path))
+    J = d["joints"]
+    m = KinModel(parent=[j["parent"] for j in J], jtype=[j["type"] for j in J],
+                 axis=np.array([j["axis"] for j in J], dtype=float), R0=np.array([j["R0"] for j in J], dtype=float).reshape(-1, 3, 3),
+                 p0=np.array([j["p0"] for j in J], dtype=float), mass=np.array([j["mass"] for j in J], dtype=float),
+                 com=np.array([j["com"] for j in J], dtype=float), names=[j["name"] for j in J])
+    m.frames = [(f["name"], f["joint"], np.array(f["R"], dtype=float).reshape(3, 3), tuple(f["p"])) for f in d["frames"]]
+    lo = np.array([-np.inf if j["lower"] is None else j["lower"] for j in J])
+    up = np.array([np.inf if j["upper"] is None else j["upper"] for j in J])
+    return m, lo, up
+
+
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 

@@ -37,6 +37,37 @@ def test_restatement_matches_finite_differences():
         assert np.abs(Jc - o["Jcom"]).max() < 1e-8
 
 
+def _coman():
+    import os
+    return kin.from_json(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "coman_tree.json"))
+
+
+def test_coman_tree_fixture():
+    """the reference's robot (tests/robots/coman_floating_base, reduced to a tree fixture by
+    tests/golden/make_coman_tree.py): 6 virtual + 29 revolute joints, 31.46 kg; restatement vs finite differences and
+    the emulated kernel vs the restatement on it (35 joints: more than half of the 64 lanes busy)"""
+    from helpers import emu_kinematics
+    m, lo, up = _coman()
+    assert m.n == 35 and abs(m.mass.sum() - 31.463860196) < 1e-9 and [f[0] for f in m.frames] == ["l_wrist", "r_wrist", "l_sole", "r_sole"]
+    assert np.isinf(lo[:6]).all() and np.isfinite(lo[6:]).all() and (up[6:] > lo[6:]).all()
+    rng = np.random.default_rng(8)
+    q = np.clip(rng.uniform(-0.6, 0.6, (3, m.n)), np.maximum(lo, -3.0), np.minimum(up, 3.0))
+    o, Jf, Jc = _fd_jacobians(m, q[0])
+    for f in range(4):
+        assert np.abs(Jf[f] - o["J"][f]).max() < 1e-8
+    assert np.abs(Jc - o["Jcom"]).max() < 1e-8
+    # standing at q = 0 the soles are level and 0.5168 m (the URDF's reference-joint offset) plus the leg below the waist
+    z0 = pykin.forward(m, np.zeros(m.n))
+    assert abs(z0["frame_p"][2][2] - z0["frame_p"][3][2]) < 1e-12 and abs(z0["frame_p"][2][1] + z0["frame_p"][3][1]) < 1e-9
+    poses, J, com = emu_kinematics(m, q)
+    for i in range(3):
+        oi = pykin.forward(m, q[i])
+        for f in range(4):
+            assert np.abs(J[i, 6 * f:6 * f + 6] - oi["J"][f]).max() < 1e-13
+            assert np.abs(poses[f][i][9:] - oi["frame_p"][f]).max() < 1e-14
+        assert np.abs(J[i, 24:27] - oi["Jcom"]).max() < 1e-14 and np.abs(com[i] - oi["com"]).max() < 1e-14
+
+
 def test_kin_desc_checks_without_gpu():
     L = abi.lib()
     import ctypes as C
@@ -162,3 +193,65 @@ def test_closed_loop_ik_on_device(gpu_device):
     # the restatement agrees with the device state at the end
     o = pykin.forward(m, q[3].cpu().numpy())
     assert np.abs(pose[1][3].cpu().numpy()[9:] - o["frame_p"][1]).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_closed_loop_ik_coman35(gpu_device):
+    """the reference's own robot and stack -- examples/cpp/coman_ik.cpp:425-449: 35 coordinates,
+    (com / 0.1*l_wrist + r_wrist + l_sole + r_sole / postural) << joint limits << velocity limits -- with kinematics,
+    update and the (64-lane) cascade all on the device; joint limits from the URDF"""
+    import torch
+    from opensot_amd.solver import BatchedStack
+    m, lo, up = _coman()
+    n, B = m.n, 96
+    dev = torch.device("cuda", 0)
+    f64 = dict(dtype=torch.float64, device=dev)
+    rng = np.random.default_rng(4)
+    q0 = np.zeros((B, n))
+    for s_ in "RL":                                   # a slightly crouched, arms-bent posture inside the limits
+        q0[:, m.names.index(s_ + "HipSag")] = -0.3; q0[:, m.names.index(s_ + "KneeSag")] = 0.6
+        q0[:, m.names.index(s_ + "AnkSag")] = -0.3; q0[:, m.names.index(s_ + "Elbj")] = -0.8
+        q0[:, m.names.index(s_ + "ShSag")] = 0.2
+    q0[:, m.names.index("LShLat")] = 0.3; q0[:, m.names.index("RShLat")] = -0.3
+    q0[:, 6:] += rng.normal(0.0, 0.01, (B, n - 6))
+    q0 = np.clip(q0, np.maximum(lo, -10.0) + 1e-3, np.minimum(up, 10.0) - 1e-3)
+    levels = [[Task(abi.TASK_COM, 3, lam=0.1, name="com")],
+              [Task(abi.TASK_CARTESIAN, 6, weight=0.1, lam=0.1, name="l_wrist"), Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="r_wrist"),
+               Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="l_sole"), Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="r_sole")],
+              [Task(abi.TASK_POSTURAL, n, lam=0.01, name="postural")]]
+    bounds = [Bound(abi.BOUND_JOINT_LIMITS, scaling=1.0, name="jl"), Bound(abi.BOUND_VELOCITY_LIMITS, dT=0.01, name="vl")]
+    plan = StackPlan(n=n, levels=levels, bounds=bounds, rowblocks=[], eps_abs=eps_abs_from_factor(1e6))
+    st = BatchedStack(plan, B, device=0, want_levels=False)
+    K = kin.Kinematics(m, device=0)
+    q = torch.as_tensor(q0, **f64).contiguous()
+    pose = [torch.zeros((B, 12), **f64) for _ in range(4)]
+    com = torch.zeros((B, 3), **f64)
+
+    def fk():
+        K.forward(q, frame_pose={f: pose[f] for f in range(4)}, frame_J={f: (st.A[1], 6 * f) for f in range(4)},
+                  com=com, com_J=(st.A[0], 0))
+    fk(); torch.cuda.synchronize()
+    pose_d = [p.clone() for p in pose]
+    pose_d[1][:, 9:] += torch.as_tensor([0.05, -0.02, 0.04], **f64)          # r_wrist target
+    com_d = com.clone()
+    big = 1.0e3                                                              # "no limit" for the virtual joints
+    qmin = torch.as_tensor(np.tile(np.maximum(lo, -big), (B, 1)), **f64); qmax = torch.as_tensor(np.tile(np.minimum(up, big), (B, 1)), **f64)
+    qdot_max = torch.full((B, n), 2.0, **f64)
+    q_ref = q.clone()
+    leaf = {"B": B, "task": [[(com, com_d, None)], [(pose[f], pose_d[f], None) for f in range(4)], [(q, q_ref, None)]],
+            "bound": [(q, qmin, qmax), (qdot_max, None, None)], "rows": []}
+    e0 = float((pose_d[1][:, 9:] - pose[1][:, 9:]).norm(dim=1).max())
+    for cycle in range(200):
+        fk(); st.update(leaf); st.solve(B); q += st.dq[:B]
+        if cycle in (0, 199):
+            torch.cuda.synchronize()
+            assert (st.status[:B] == 0).all()
+    fk(); torch.cuda.synchronize()
+    qh = q.cpu().numpy()
+    assert (qh[:, 6:] >= lo[6:] - 1e-9).all() and (qh[:, 6:] <= up[6:] + 1e-9).all()        # the URDF's limits held
+    assert float((pose_d[1][:, 9:] - pose[1][:, 9:]).norm(dim=1).max()) < 0.05 * e0          # r_wrist reached its target
+    for f in (2, 3):
+        assert float((pose_d[f][:, 9:] - pose[f][:, 9:]).norm(dim=1).max()) < 5e-3           # the feet stayed
+    assert float((com_d - com).norm(dim=1).max()) < 2e-3                                      # and so did the CoM
+    o = pykin.forward(m, qh[5])
+    assert np.abs(pose[1][5].cpu().numpy()[9:] - o["frame_p"][1]).max() < 1e-12
