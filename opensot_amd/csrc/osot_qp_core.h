@@ -33,13 +33,13 @@ constexpr double kInfty = 1.0e20;      // QPOasesBackEnd::checkINFTY clamp (QPOa
 constexpr double kDepTol2 = 1.0e-24;   // |d2|^2 <= kDepTol2 |d|^2  -> normal is in the span of the working set.
                                        // |d|^2 is dominated by the 1/eps-scaled directions (6e10 at the default eps), the
                                        // round-off floor of |d2|^2 is ~1e-29 |d|^2, and a genuine last free direction was seen
-                                       // at 6e-19 |d|^2 (tools/stress_parity.py): 1e-18 called it dependent -> false INFEASIBLE
+                                       // at 6e-19 |d|^2 (tests/stress_parity.py): 1e-18 called it dependent -> false INFEASIBLE
 constexpr double kViolTol = 1.0e-11;   // a slack below -kViolTol*max(1,|bound|) counts as violated
 constexpr double kEqTol = 1.0e-9;      // consistency of a linearly dependent equality row
 constexpr double kSlackTol = 1.0e-6;   // a violation below this (relative) with no direction left is round-off: with the
                                        // default eps (4.4e-11) an upper level's x carries O(1e-16 / eps) = 1e-6 of noise and
                                        // its active bound re-appears violated by that much where no freedom is left
-                                       // (found by tools/stress_parity.py; qpOASES accepts the same point)
+                                       // (found by tests/stress_parity.py; qpOASES accepts the same point)
 
 enum { QP_SOLVED = 0, QP_INFEASIBLE = 1, QP_MAX_ITER = 2, QP_NOT_PD = 3 };
 

@@ -1,6 +1,8 @@
-"""developer helper (GPU box): randomised parity sweep of the cascade against the reference's qpOASES (oracle/_ref)
+"""TEST INFRASTRUCTURE (run on the GPU box by tests/test_gpu_golden_and_scale.py, or by hand): randomised parity sweep of the cascade against the reference's qpOASES (oracle/_ref)
 over many small stack shapes; prints every configuration with a failed instance or a disagreement above 1e-6."""
-import sys, time; sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os, sys, time
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, 'tests'))
 import numpy as np, torch
 from opensot_amd import synth
 from opensot_amd.solver import BatchedStack

@@ -1,7 +1,9 @@
-"""developer helper (GPU box): randomised sweep of osot_qp_solve_batch (the BackEnd-convention kernel: explicit H, g,
+"""TEST INFRASTRUCTURE (run on the GPU box by tests/test_gpu_backend.py, or by hand): randomised sweep of osot_qp_solve_batch (the BackEnd-convention kernel: explicit H, g,
 rows, box) over shapes n = 2..64 with full-rank and rank-deficient Hessians; every instance is checked by KKT and a
 sample against the oracle's single-QP solve (eiQuadProg restatement; qpOASES where oracle/_ref exists)."""
-import sys, time, ctypes as C; sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os, sys, time, ctypes as C
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, 'tests'))
 import numpy as np, torch
 from opensot_amd import abi
 from oracle import pyoracle as oracle

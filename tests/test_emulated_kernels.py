@@ -243,7 +243,7 @@ def test_more_rows_than_variables(n, rows, oracle):
 
 
 def test_last_free_direction_is_not_called_dependent(oracle):
-    """found by tools/stress_parity.py: default eps (4.4e-11), 21 of 22 directions taken, a violated inequality whose
+    """found by tests/stress_parity.py: default eps (4.4e-11), 21 of 22 directions taken, a violated inequality whose
     normal has |d2|^2 = 6e-19 |d|^2 in the last free direction (|d|^2 is dominated by the 1/eps-scaled directions).
     A dependency threshold of 1e-18 |d|^2 called it dependent and the instance INFEASIBLE; the reference solves it."""
     kw = {'n_eq': 3, 'n_ineq': 5, 'seed': 201675281, 'box': 0.5, 'postural_last': False, 'eps_factor': 200.0}

@@ -130,10 +130,10 @@ def test_randomised_qp_sweep(oracle, gpu_device):
     """40 random QP shapes (n = 2..64, up to 39 rows, equalities, one-sided rows, boxes, full-rank and rank-deficient
     Hessians with g in range(H), three eps values) x 64 instances through osot_qp_solve_batch: KKT on every solved
     instance, a sample against the oracle's single-QP solve, and every unsolved instance must be one the oracles
-    cannot solve either (tools/stress_qp.py)"""
+    cannot solve either (tests/stress_qp.py)"""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_qp.py"), "5", "40"],
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "stress_qp.py"), "5", "40"],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "40 QP shapes x 64 instances" in out.stdout and ": 0 with a mismatch" in out.stdout, out.stdout[-2000:]

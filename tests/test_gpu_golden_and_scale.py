@@ -154,12 +154,12 @@ def test_dispatch_order_does_not_change_results(gpu_device):
 def test_randomised_parity_sweep(oracle, gpu_device):
     """40 random stack shapes x 192 instances (generic multi-level stacks with equality / inequality rows and boxes,
     low-rank levels, the humanoid configurations, eps 1e6 and the default 2e2) against the reference's qpOASES, on the
-    instances where qpOASES at its own options and qpOASES run to the exact optimum agree (tools/stress_parity.py)"""
+    instances where qpOASES at its own options and qpOASES run to the exact optimum agree (tests/stress_parity.py)"""
     if not oracle.ref_available():
         pytest.skip("needs oracle/_ref (qpOASES)")
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_parity.py"), "11", "40"],
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "stress_parity.py"), "11", "40"],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "40 configurations x 192 instances" in out.stdout and ": 0 with a mismatch" in out.stdout, out.stdout[-2000:]
