@@ -6,7 +6,10 @@ import torch
 from opensot_amd import synth
 from opensot_amd.solver import BatchedStack
 
-for cfg, B in (("C2", 1024), ("C3", 4096), ("C4", 4096), ("C5", 1024)):
+CASES = (("C2", 1024), ("C3", 4096), ("C4", 4096), ("C5", 1024))
+if len(sys.argv) > 1 and sys.argv[1] == "--batch-sweep":      # throughput of config 3 against the batch size
+    CASES = tuple(("C3", b) for b in (1024, 2048, 4096, 8192, 16384, 32768))
+for cfg, B in CASES:
     plan, leaf = synth.make_id_stack(B, seed=1) if cfg == "C5" else synth.make_velocity_stack(cfg, B, seed=1)
     st = BatchedStack(plan, B, device=0, want_levels=False)
     dev = st.load_leaf(leaf)
