@@ -1050,7 +1050,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                 double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
                 int cc = 0;
                 // SC loads per trip: the walk is a chain of L1/L2 round trips, only loads in flight shorten it
-                constexpr int SC = (NP == 64) ? 16 : 8;
+                constexpr int SC = 16;
                 for (; cc + SC <= n; cc += SC) {
                     double e[SC];
 #pragma unroll
