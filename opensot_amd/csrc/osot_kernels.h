@@ -5,10 +5,17 @@
 //                              constraints = global rows + optimality rows of the higher levels
 //                              (iHQP.cpp:282-333), one strictly convex QP (QPOasesBackEnd.cpp:248-307),
 //                              x of the last active level is the answer (iHQP.cpp:349).  All levels
-//                              run in ONE launch; H, its factor, J and the working set never leave LDS.
+//                              run in ONE launch; H, its factor, J and the working set never leave the
+//                              CU (registers / LDS).  NP = 32: H = A'WA and the blocked Cholesky +
+//                              inverse run on the fp64 matrix core (v_mfma_f64_16x16x4_f64), levels with
+//                              <= 4 stored rows take a closed-form path, the optimality rows of a
+//                              Postural last level are eliminated by a register-resident Gauss-Jordan.
 //   osot_qp_kernel<NP> ....... B generic QPs in BackEnd convention (BackEnd.h:125-150).
 //   osot_update_kernel ....... AutoStack::update() (src/utils/AutoStack.cpp:385-393): leaf -> b, W,
-//                              merged box, collision rows.  HBM-bound, one 64-lane block per instance.
+//                              merged box, collision / friction-cone rows, inverse-dynamics bounds.
+//                              One 64-lane block per instance, one lane per stack row.
+//   osot_order_kernel ........ dispatch order of the next solve (longest first).
+// (osot_kin.h holds the batched kinematics producer.)
 //
 // Mapping: ONE WAVEFRONT PER INSTANCE (one wavefront per workgroup).  NP = 32 for n <= 32 (two lanes per
 // column: the halves split every inner product), NP = 64 for n <= 64.  Instance-major fp64 arrays, so a
