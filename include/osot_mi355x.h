@@ -86,6 +86,14 @@ typedef struct {
     double lambda;           /* Task::setLambda; enters b only (Cartesian.cpp:284, CoM.cpp:148) */
     double orientation_gain; /* Cartesian::setOrientationErrorGain (Cartesian.cpp:283) */
     double lambda2;          /* velocity gain of the acceleration tasks (acceleration/Cartesian.cpp:158) */
+    /* SubTask (src/tasks/SubTask.cpp:22-112, `task % {indices}`): this block keeps only some rows of a parent task.
+     * row_mask bit i = row i of the parent is kept (0: not a sub-task); rows = popcount(row_mask); parent_rows = rows
+     * of the parent (0: the kind's own size: 6 / 3 / n); b = sub_lambda * b_parent[kept rows] (SubTask.cpp:56-57);
+     * the weight is the parent's scalar.  The producer writes the kept Jacobian rows; a Postural sub-task is NOT
+     * implicit: its unit rows are stored like any other block's. */
+    unsigned long long row_mask;
+    int parent_rows;
+    double sub_lambda;
 } osot_task_desc;
 
 typedef struct {

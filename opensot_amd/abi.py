@@ -22,7 +22,8 @@ ip = C.POINTER(C.c_int)
 
 class TaskDesc(C.Structure):
     _fields_ = [("kind", C.c_int), ("rows", C.c_int), ("weight", C.c_double),
-                ("lambda_", C.c_double), ("orientation_gain", C.c_double), ("lambda2", C.c_double)]
+                ("lambda_", C.c_double), ("orientation_gain", C.c_double), ("lambda2", C.c_double),
+                ("row_mask", C.c_ulonglong), ("parent_rows", C.c_int), ("sub_lambda", C.c_double)]
 
 
 class LevelDesc(C.Structure):

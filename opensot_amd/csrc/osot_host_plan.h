@@ -7,13 +7,29 @@
 
 namespace osot {
 
+// a Postural block has A = [I 0] (Postural.cpp:37): implicit, never stored -- unless it is a SubTask of one
+inline bool task_is_implicit(const osot_task_desc& t) {
+    return (t.kind == OSOT_TASK_POSTURAL || t.kind == OSOT_TASK_ACC_POSTURAL) && t.row_mask == 0ull;
+}
+// rows of the parent of a sub-task (the kind's own size unless given)
+inline int task_parent_rows(const osot_task_desc& t, int n) {
+    if (t.row_mask == 0ull) return t.rows;
+    if (t.parent_rows > 0) return t.parent_rows;
+    switch (t.kind) {
+        case OSOT_TASK_CARTESIAN: case OSOT_TASK_ACC_CARTESIAN: return 6;
+        case OSOT_TASK_COM: case OSOT_TASK_ACC_COM: return 3;
+        case OSOT_TASK_POSTURAL: case OSOT_TASK_ACC_POSTURAL: return n;
+        default: return 0;
+    }
+}
+
 inline int plan_level_rows(const osot_plan_desc* p, int k, int* m_total, int* m_stored) {
     if (!p || k < 0 || k >= p->n_levels) return OSOT_ERR_INVALID;
     int m = 0, ma = 0;
     const osot_level_desc& lv = p->level[k];
     for (int j = 0; j < lv.n_tasks; ++j) {
         m += lv.task[j].rows;
-        if (lv.task[j].kind != OSOT_TASK_POSTURAL && lv.task[j].kind != OSOT_TASK_ACC_POSTURAL) ma += lv.task[j].rows;
+        if (!task_is_implicit(lv.task[j])) ma += lv.task[j].rows;
     }
     if (m_total) *m_total = m;
     if (m_stored) *m_stored = ma;
@@ -56,6 +72,17 @@ inline int plan_validate(const osot_plan_desc* p, const char** why) {
         for (int j = 0; j < lv.n_tasks; ++j) {
             const osot_task_desc& t = lv.task[j];
             if (t.rows < 1) { *why = "task with no rows"; return OSOT_ERR_INVALID; }
+            if (t.row_mask != 0ull) {   // SubTask: rows = kept rows, all inside the parent
+                const int pr = task_parent_rows(t, p->n);
+                if (pr < 1 || pr > 64) { *why = "sub-task: parent rows out of range (1..64)"; return OSOT_ERR_INVALID; }
+                if (__builtin_popcountll(t.row_mask) != t.rows) { *why = "sub-task: rows != popcount(row_mask)"; return OSOT_ERR_INVALID; }
+                if (pr < 64 && (t.row_mask >> pr) != 0ull) { *why = "sub-task: row_mask selects rows beyond the parent"; return OSOT_ERR_INVALID; }
+                if ((t.kind == OSOT_TASK_CARTESIAN || t.kind == OSOT_TASK_ACC_CARTESIAN) && pr != 6) { *why = "Cartesian parent has 6 rows"; return OSOT_ERR_INVALID; }
+                if ((t.kind == OSOT_TASK_COM || t.kind == OSOT_TASK_ACC_COM) && pr != 3) { *why = "CoM parent has 3 rows"; return OSOT_ERR_INVALID; }
+                if (t.kind < OSOT_TASK_GENERIC || t.kind > OSOT_TASK_ACC_POSTURAL) { *why = "unknown task kind"; return OSOT_ERR_UNSUPPORTED; }
+                if (!(t.weight >= 0.0)) { *why = "negative task weight"; return OSOT_ERR_INVALID; }
+                continue;
+            }
             switch (t.kind) {
                 case OSOT_TASK_GENERIC: break;
                 case OSOT_TASK_CARTESIAN: case OSOT_TASK_ACC_CARTESIAN:

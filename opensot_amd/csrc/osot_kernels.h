@@ -476,7 +476,12 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
 // ---------------------------------------------------------------------------------------------------
 // AutoStack::update(): leaf inputs -> b, W diagonal, merged box, constraint rows
 // ---------------------------------------------------------------------------------------------------
-struct DevTask { int level, kind, rows, off; double weight, lambda, ogain, lambda2; const double *p0, *p1, *p2; };
+struct DevTask {
+    int level, kind, rows, off; double weight, lambda, ogain, lambda2; const double *p0, *p1, *p2;
+    unsigned long long mask;   // SubTask: kept rows of the parent (0: whole task)
+    int prow;                  // rows of the parent (= rows when not a sub-task): the leaf inputs have this size
+    double sublam;             // SubTask lambda on b (1 when not a sub-task)
+};
 struct DevBound { int kind; double scaling, dT; const double *p0, *p1, *p2; };
 struct DevRowBlock { int kind, rows, off, stored_off, first_col; double d_threshold, detection_threshold, bound_scaling, dT, p, mu; const double *p0, *p1, *p2; };
 
@@ -558,8 +563,9 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
         int total = 0;
         for (int j = 0; j < U.ntasks; ++j) total += U.task[j].rows;
         for (int fr = t; fr < total; fr += 64) {
-            int kind = -1, rows = 0, r = 0, off = 0, level = 0;
-            double weight = 0.0, lam = 0.0, lam2 = 0.0;
+            int kind = -1, rows = 0, r = 0, off = 0, level = 0, prow = 0;
+            unsigned long long mask = 0ull;
+            double weight = 0.0, lam = 0.0, lam2 = 0.0, sublam = 1.0;
             const double *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
             int start = 0;
             for (int j = 0; j < U.ntasks; ++j) {
@@ -568,6 +574,7 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
                     kind = tk.kind; rows = tk.rows; r = fr - start; off = tk.off; level = tk.level;
                     weight = tk.weight; lam = tk.lambda; lam2 = tk.lambda2;
                     p0 = tk.p0; p1 = tk.p1; p2 = tk.p2;
+                    mask = tk.mask; prow = tk.prow; sublam = tk.sublam;
                 }
                 start += tk.rows;
             }
@@ -579,9 +586,17 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
             if (kind == 1) continue;   // Cartesian rows: below, one lane per task
             // acceleration kinds read (pose error, velocity error) from p0: [2 rows] per instance
             const bool acc = (kind == 4 || kind == 5 || kind == 6);
-            const long long base = inst * (long long)rows + r;
-            const double x0 = acc ? p0[inst * 2LL * rows + r] : p0[base];
-            const double x1 = acc ? p0[inst * 2LL * rows + rows + r] : 0.0;
+            // SubTask (SubTask.cpp:22-112): row r of this block is row pr of the parent, whose size the leaf inputs have
+            int pr = r;
+            if (mask != 0ull) {
+                unsigned long long mm = mask;
+                for (int q = 0; q < r; ++q) mm &= mm - 1ull;      // drop the r lowest set bits
+                pr = __builtin_ctzll(mm);
+            }
+            (void)rows;
+            const long long base = inst * (long long)prow + pr;
+            const double x0 = acc ? p0[inst * 2LL * prow + pr] : p0[base];
+            const double x1 = acc ? p0[inst * 2LL * prow + prow + pr] : 0.0;
             const double x2 = (p1 && kind != 0 && kind != 6) ? p1[base] : 0.0;
             const double x3 = (p2 && kind != 0) ? p2[base] : 0.0;
             double v;
@@ -596,7 +611,7 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
             } else {                                 // Generic: b supplied
                 v = x0;
             }
-            *bl = v;
+            *bl = (mask != 0ull) ? v * sublam : v;
         }
     }
     // ---- Cartesian tasks, ONE LANE PER TASK: the pose error (Cartesian.cpp:190-240: position difference +
@@ -606,13 +621,15 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
     {
         const double *cp0 = nullptr, *cp1 = nullptr, *cp2 = nullptr;
         double* cb = nullptr;
-        double clam = 0.0, cog = 0.0;
+        double clam = 0.0, cog = 0.0, csub = 1.0;
+        unsigned cmask = 0x3fu;
         for (int j = 0; j < U.ntasks; ++j) {
             const DevTask& tk = U.task[j];
             if (tk.kind == 1 && t == j) {
                 cp0 = tk.p0; cp1 = tk.p1; cp2 = tk.p2;
                 cb = U.b[tk.level] + inst * U.m[tk.level] + tk.off;
                 clam = tk.lambda; cog = tk.ogain;
+                if (tk.mask != 0ull) { cmask = (unsigned)tk.mask & 0x3fu; csub = tk.sublam; }   // e.g. position only
             }
         }
         if (cb) {
@@ -625,7 +642,8 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) tw[i] = cp2 ? cp2[inst * 6 + i] : 0.0;
             cartesian_b(Ta, Td, tw, clam, cog, b6);
-            for (int i = 0; i < 6; ++i) cb[i] = b6[i];
+            int kq = 0;
+            for (int i = 0; i < 6; ++i) if ((cmask >> i) & 1u) cb[kq++] = b6[i] * csub;
         }
     }
     // ---- box: min/max merge (constraints::Aggregated, Aggregated.cpp:141-148)

@@ -247,6 +247,7 @@ int osot_stack_update(osot_solver* s, const osot_leaf_batch* leaf, const osot_as
             DevTask& d = U.task[flat++];
             d.level = k; d.kind = t.kind; d.rows = t.rows; d.off = off;
             d.weight = t.weight; d.lambda = t.lambda; d.ogain = t.orientation_gain; d.lambda2 = t.lambda2;
+            d.mask = t.row_mask; d.prow = task_parent_rows(t, pl.n); d.sublam = t.row_mask ? t.sub_lambda : 1.0;
             d.p0 = leaf->task[k][j].p0; d.p1 = leaf->task[k][j].p1; d.p2 = leaf->task[k][j].p2;
             if (!d.p0) return fail(OSOT_ERR_INVALID, "leaf input p0 of a task is null");
             if (t.kind != OSOT_TASK_GENERIC && t.kind != OSOT_TASK_ACC_POSTURAL && !d.p1)

@@ -26,6 +26,37 @@ class Task:
     orientation_gain: float = 1.0
     name: str = ""
     lam2: float = 1.0
+    # SubTask (src/tasks/SubTask.cpp:22-112): keep only the parent's rows whose bit is set; rows = popcount(row_mask);
+    # b = sub_lam * b_parent[rows]; parent_rows 0 = the kind's own size (6 / 3 / n)
+    row_mask: int = 0
+    parent_rows: int = 0
+    sub_lam: float = 1.0
+
+    @property
+    def implicit(self):
+        """A = [I 0], never stored: a whole Postural block (a Postural sub-task stores its unit rows)"""
+        return self.kind in IMPLICIT_IDENTITY_TASKS and self.row_mask == 0
+
+    def parent_size(self, n):
+        if not self.row_mask:
+            return self.rows
+        if self.parent_rows:
+            return self.parent_rows
+        return {abi.TASK_CARTESIAN: 6, abi.TASK_ACC_CARTESIAN: 6, abi.TASK_COM: 3, abi.TASK_ACC_COM: 3,
+                abi.TASK_POSTURAL: n, abi.TASK_ACC_POSTURAL: n}.get(self.kind, self.rows)
+
+    def kept_rows(self):
+        return [i for i in range(64) if (self.row_mask >> i) & 1]
+
+
+def subtask(parent: "Task", indices, lam=1.0, n=None) -> "Task":
+    """`parent % indices` (SubTask): same kind / weight / gains, only the listed rows of the parent"""
+    mask = 0
+    for i in indices:
+        mask |= 1 << int(i)
+    return Task(parent.kind, len(set(indices)), weight=parent.weight, lam=parent.lam, orientation_gain=parent.orientation_gain,
+                name=parent.name + "%" + ",".join(str(i) for i in sorted(set(indices))), lam2=parent.lam2, row_mask=mask,
+                parent_rows=parent.rows, sub_lam=lam)
 
 
 IMPLICIT_IDENTITY_TASKS = (abi.TASK_POSTURAL, abi.TASK_ACC_POSTURAL)
@@ -73,7 +104,7 @@ class StackPlan:
 
     def ma(self, k):
         """rows of level k stored explicitly (Postural's identity block is implicit)."""
-        return sum(t.rows for t in self.levels[k] if t.kind not in IMPLICIT_IDENTITY_TASKS)
+        return sum(t.rows for t in self.levels[k] if not t.implicit)
 
     @property
     def nc(self):
@@ -99,7 +130,10 @@ class StackPlan:
         for lev in self.levels:
             assert 1 <= len(lev) <= abi.MAX_TASKS
             for j, t in enumerate(lev):
-                if t.kind in IMPLICIT_IDENTITY_TASKS:
+                if t.row_mask:
+                    assert bin(t.row_mask).count("1") == t.rows and (t.row_mask >> t.parent_size(self.n)) == 0
+                    continue
+                if t.implicit:
                     assert j == len(lev) - 1 and 1 <= t.rows <= self.n
                 if t.kind in (abi.TASK_CARTESIAN, abi.TASK_ACC_CARTESIAN):
                     assert t.rows == 6
@@ -118,6 +152,7 @@ class StackPlan:
                 d = p.level[k].task[j]
                 d.kind, d.rows, d.weight, d.lambda_, d.orientation_gain, d.lambda2 = (
                     t.kind, t.rows, t.weight, t.lam, t.orientation_gain, t.lam2)
+                d.row_mask, d.parent_rows, d.sub_lambda = t.row_mask, t.parent_rows, t.sub_lam
         p.n_bounds = len(self.bounds)
         for j, b in enumerate(self.bounds):
             p.bound[j].kind, p.bound[j].scaling, p.bound[j].dT = b.kind, b.scaling, b.dT

@@ -300,3 +300,35 @@ def make_lowrank_stack(B, n, m=3, seed=0, weight=0.3, postural_weight=None, depe
     bleaf = [(np.full((B, n), -box), np.full((B, n), box), None)]
     plan = StackPlan(n=n, levels=levels, bounds=bounds, rowblocks=[], eps_abs=eps_abs_from_factor(eps_factor))
     return plan, {"B": B, "A": A, "task": tleaf, "bound": bleaf, "rows": []}
+
+
+def make_subtask_stack(B, seed=0, n=32, eps_factor=1e6):
+    """config-3-like stack built from SubTasks (`task % {rows}`, src/tasks/SubTask.cpp): CoM restricted to x, y with
+    its own lambda; position-only wrists (rows 0..2 of the Cartesian tasks, one with a sub-task lambda of 0.5), full
+    feet; a Postural sub-task on the actuated joints 6..n-1 (its unit rows are stored, not implicit)."""
+    from .plan import subtask
+    rng = np.random.default_rng(seed)
+    com = Task(abi.TASK_COM, 3, lam=0.1, name="com")
+    carts = {nm: Task(abi.TASK_CARTESIAN, 6, weight=(0.1 if nm == "l_wrist" else 1.0), lam=0.1, name=nm)
+             for nm in ("l_wrist", "r_wrist", "l_sole", "r_sole")}
+    post = Task(abi.TASK_POSTURAL, n, lam=0.01, name="postural")
+    lev0 = [subtask(com, [0, 1], lam=0.7)]
+    lev1 = [subtask(carts["l_wrist"], [0, 1, 2], lam=0.5), subtask(carts["r_wrist"], [0, 1, 2]), carts["l_sole"], carts["r_sole"]]
+    act = list(range(6, n))
+    lev2 = [subtask(post, act, n=n)]
+    bounds, bleaf = _box_leaf(rng, B, n, jl=True, vl=True)
+    q = bleaf[0][0]
+    A0 = rng.normal(0.0, 0.3, size=(B, 3, n))[:, [0, 1]]
+    limb = {"l_wrist": "l_arm", "r_wrist": "r_arm", "l_sole": "l_leg", "r_sole": "r_leg"}
+    J = {nm: _limb_jacobian(rng, B, 6, n, _BASE + _LIMBS[limb[nm]]) for nm in carts}
+    A1 = np.concatenate([J["l_wrist"][:, :3], J["r_wrist"][:, :3], J["l_sole"], J["r_sole"]], axis=1)
+    A2 = np.zeros((B, len(act), n))
+    for r, jn in enumerate(act):
+        A2[:, r, jn] = 1.0
+    p = rng.uniform(-0.2, 0.2, size=(B, 3))
+    tleaf = [[(p, p + rng.uniform(-0.05, 0.05, size=(B, 3)), None)],
+             [_cartesian_leaf(rng, B) for _ in range(4)],
+             [(q, q + rng.normal(0.0, 0.1, size=(B, n)), None)]]
+    plan = StackPlan(n=n, levels=[lev0, lev1, lev2], bounds=bounds, rowblocks=[], eps_abs=eps_abs_from_factor(eps_factor))
+    leaf = {"B": B, "A": [np.ascontiguousarray(A0), np.ascontiguousarray(A1), A2], "task": tleaf, "bound": bleaf, "rows": []}
+    return plan, leaf

@@ -107,15 +107,22 @@ def assemble(plan, leaf):
     zerosn = np.zeros(n)
     for k, lev in enumerate(plan.levels):
         m = sum(t.rows for t in lev)
-        ma = sum(t.rows for t in lev if t.kind not in IMPLICIT_IDENTITY_TASKS)
+        # a whole Postural block is implicit (A = [I 0]); a Postural SubTask stores its unit rows like any block
+        ma = sum(t.rows for t in lev if not (t.kind in IMPLICIT_IDENTITY_TASKS and not getattr(t, "row_mask", 0)))
         b = np.zeros((B, m))
         w = np.ones((B, m))
         off = 0
         for j, t in enumerate(lev):
             p0, p1, p2 = (_c(x) for x in leaf["task"][k][j])
             w[:, off:off + t.rows] = t.weight   # scalar * W (AutoStack.cpp:16-47), W = I by default
+            # SubTask (src/tasks/SubTask.cpp:22-112): the parent's b is formed in full (size pr), then the kept rows are
+            # gathered in index order and scaled by the sub-task's own lambda (SubTask.cpp:44-58)
+            mask = getattr(t, "row_mask", 0)
+            pr = t.parent_size(n) if mask else t.rows
+            kept = [q for q in range(64) if (mask >> q) & 1]
             for i in range(B):
-                bi = b[i, off:off + t.rows]
+                bi = np.zeros(pr) if mask else b[i, off:off + t.rows]
+                rows_ = pr
                 if t.kind == TASK_CARTESIAN:
                     tw = p2[i] if p2 is not None else zeros6
                     L.orc_cartesian_b(_p(p0[i, :9]), _p(p0[i, 9:]), _p(p1[i, :9]), _p(p1[i, 9:]),
@@ -124,18 +131,20 @@ def assemble(plan, leaf):
                     L.orc_com_b(_p(p0[i]), _p(p1[i]), _p(p2[i] if p2 is not None else zeros6[:3]),
                                 t.lam, _p(bi))
                 elif t.kind == TASK_POSTURAL:
-                    L.orc_postural_b(t.rows, _p(p0[i]), _p(p1[i]), _p(p2[i] if p2 is not None else zerosn),
+                    L.orc_postural_b(rows_, _p(p0[i]), _p(p1[i]), _p(p2[i] if p2 is not None else zerosn),
                                      t.lam, _p(bi))
                 elif t.kind in (TASK_ACC_CARTESIAN, TASK_ACC_COM):
-                    pe = np.ascontiguousarray(p0[i, :t.rows]); ve = np.ascontiguousarray(p0[i, t.rows:])
-                    L.orc_acc_task_b(t.rows, _p(pe), _p(ve), _p(p1[i]), _p(p2[i]) if p2 is not None else None,
+                    pe = np.ascontiguousarray(p0[i, :rows_]); ve = np.ascontiguousarray(p0[i, rows_:])
+                    L.orc_acc_task_b(rows_, _p(pe), _p(ve), _p(p1[i]), _p(p2[i]) if p2 is not None else None,
                                      t.lam, t.lam2, _p(bi))
                 elif t.kind == TASK_ACC_POSTURAL:
-                    pe = np.ascontiguousarray(p0[i, :t.rows]); ve = np.ascontiguousarray(p0[i, t.rows:])
-                    L.orc_acc_postural_b(t.rows, _p(pe), _p(ve), _p(p2[i]) if p2 is not None else None,
+                    pe = np.ascontiguousarray(p0[i, :rows_]); ve = np.ascontiguousarray(p0[i, rows_:])
+                    L.orc_acc_postural_b(rows_, _p(pe), _p(ve), _p(p2[i]) if p2 is not None else None,
                                          t.lam, t.lam2, _p(bi))
                 else:  # GENERIC: b supplied (GenericTask.cpp:5-56)
                     bi[:] = p0[i]
+                if mask:
+                    b[i, off:off + t.rows] = bi[kept] * t.sub_lam
             off += t.rows
         out["m"].append(m); out["ma"].append(ma)
         out["A"].append(_c(leaf["A"][k]) if ma else None)

@@ -96,3 +96,26 @@ def test_eps_factor_convention():
     assert eps_abs_from_factor(1.0) == pytest.approx(2.221e-13)
     assert eps_abs_from_factor(2e2) == pytest.approx(4.442e-11)   # iHQP default (iHQP.h:32)
     assert eps_abs_from_factor(1e6) == pytest.approx(2.221e-7)    # benchmark value (coman_ik.cpp:453)
+
+
+def test_subtask_plan_validation(lib):
+    """SubTask blocks (SubTask.cpp:22-112): rows must equal popcount(row_mask), the mask must stay inside the parent,
+    and a Postural sub-task counts as stored rows (a whole Postural block is implicit)"""
+    from opensot_amd.plan import StackPlan, Task, subtask, eps_abs_from_factor
+    import ctypes as C
+    n = 12
+    cart = Task(abi.TASK_CARTESIAN, 6, name="c")
+    post = Task(abi.TASK_POSTURAL, n, name="p")
+    plan = StackPlan(n=n, levels=[[subtask(cart, [0, 1, 2], lam=0.5)], [subtask(post, range(6, n))]], bounds=[], rowblocks=[],
+                     eps_abs=eps_abs_from_factor(1e6))
+    d = plan.to_c()
+    assert lib.osot_plan_validate(C.byref(d)) == abi.OK
+    m, ma = C.c_int(), C.c_int()
+    assert lib.osot_plan_level_rows(C.byref(d), 1, C.byref(m), C.byref(ma)) == abi.OK and (m.value, ma.value) == (6, 6)
+    whole = StackPlan(n=n, levels=[[cart], [post]], bounds=[], rowblocks=[], eps_abs=eps_abs_from_factor(1e6)).to_c()
+    assert lib.osot_plan_level_rows(C.byref(whole), 1, C.byref(m), C.byref(ma)) == abi.OK and (m.value, ma.value) == (n, 0)
+    d.level[0].task[0].rows = 2                       # popcount(row_mask) = 3
+    assert lib.osot_plan_validate(C.byref(d)) == abi.ERR_INVALID
+    d.level[0].task[0].rows = 3
+    d.level[0].task[0].row_mask = 0b1000011           # bit 6 is beyond a Cartesian task's 6 rows
+    assert lib.osot_plan_validate(C.byref(d)) == abi.ERR_INVALID

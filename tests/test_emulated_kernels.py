@@ -259,3 +259,21 @@ def test_last_free_direction_is_not_called_dependent(oracle):
     if oracle.ref_available():
         rq = oracle.ihqp_solve_batch(sub, oracle.BE_QPOASES_REF, nthreads=1)
         assert (rq["status"] == 1).all() and np.abs(dq - rq["dq"]).max() < 2e-6
+
+
+def test_subtasks(oracle):
+    """SubTask (src/tasks/SubTask.cpp:22-112): CoM x,y with its own lambda, position-only wrists, a Postural sub-task on
+    the actuated joints (stored unit rows): assembly by the oracle, cascade on the emulator, against both oracles"""
+    plan, leaf = synth.make_subtask_stack(6, seed=2)
+    assert [plan.m(k) for k in range(3)] == [2, 18, 26] and [plan.ma(k) for k in range(3)] == [2, 18, 26]
+    asm = oracle.assemble(plan, leaf)
+    # the CoM sub-task: rows 0, 1 of lambda (p_d - p), times the sub-task lambda
+    p, pd, _ = leaf["task"][0][0]
+    assert np.abs(asm["b"][0] - 0.7 * 0.1 * (pd - p)[:, :2]).max() < 1e-16
+    dq, xl, st, it = emu_cascade(plan, asm)
+    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+    assert (st == 0).all() and (ref["status"] == 1).all() and np.abs(dq - ref["dq"]).max() < 1e-9
+    if oracle.ref_available():
+        rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
+        ok = rq["status"] == 1
+        assert ok.all() and np.abs(dq[ok] - rq["dq"][ok]).max() < 1e-6

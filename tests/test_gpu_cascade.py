@@ -113,3 +113,26 @@ def test_more_rows_than_variables_gpu(n, rows, oracle, gpu_device):
         rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
         ok = rq["status"] == 1
         assert ok.mean() > 0.9 and np.abs(dq[ok] - rq["dq"][ok]).max() < 1e-6
+
+
+def test_subtasks_gpu(oracle, gpu_device):
+    """SubTask blocks through the update kernel (bit-exact against the oracle's assembly) and the cascade"""
+    plan, leaf = synth.make_subtask_stack(192, seed=2)
+    asm = oracle.assemble(plan, leaf)
+    st = BatchedStack(plan, 192, device=0)
+    st.update(st.load_leaf(leaf)); st.solve(192)
+    torch.cuda.synchronize()
+    for k in range(plan.L):
+        np.testing.assert_allclose(st.b[k].cpu().numpy(), asm["b"][k], rtol=0, atol=1e-15)
+        np.testing.assert_array_equal(st.w[k].cpu().numpy(), asm["w"][k])
+    dq = st.dq[:192].cpu().numpy()
+    assert (st.status[:192].cpu().numpy() == 0).all()
+    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+    okr = ref["status"] == 1
+    assert okr.mean() > 0.95 and np.abs(dq[okr] - ref["dq"][okr]).max() < 1e-9
+    if oracle.ref_available():
+        rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
+        rx = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1, termination_tolerance=10 * 2.221e-16)
+        e = np.minimum(np.where(rq["status"] == 1, np.abs(dq - rq["dq"]).max(axis=1), np.inf),
+                       np.where(rx["status"] == 1, np.abs(dq - rx["dq"]).max(axis=1), np.inf))
+        assert np.isfinite(e).mean() > 0.95 and e[np.isfinite(e)].max() < 1e-6
