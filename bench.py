@@ -45,9 +45,11 @@ def algo_flops_per_solve(plan):
     return total
 
 
-def cpu_baseline(plan, leaf_sample, seconds_target=6.0):
+def cpu_baseline(plan, leaf_sample, seconds_target=6.0, dq_device=None):
     """CPU path timed on this host: the reference's own qpOASES (oracle/_ref, kind 'reference') when the
-    prebuilt library is present, otherwise the plain-C port (kind 'port'); restated cascade around it."""
+    prebuilt library is present, otherwise the plain-C port (kind 'port'); restated cascade around it.
+    dq_device: the GPU's answer for the same sample; the second half of BASELINE's metric (max |dq - dq_ref|) is then
+    reported against the CPU answers of this leg."""
     from oracle import pyoracle as po
     asm = po.assemble(plan, leaf_sample)
     cores = os.cpu_count() or 1
@@ -57,11 +59,31 @@ def cpu_baseline(plan, leaf_sample, seconds_target=6.0):
     except Exception:
         kind, be = "port", po.BE_EIQP_EQ
         r = po.ihqp_solve_batch(asm, be, nthreads=cores, cycles=1)
+    parity = None
+    if dq_device is not None:
+        # per instance the distance to the CLOSEST witness: qpOASES at OpenSoT's options (its early termination at
+        # 2.2e-7 leaves a few instances per thousand 1e-5..3e-3 from the optimum), qpOASES run to the exact optimum
+        # (which fails on some instances) and the line-by-line restatement of the reference's eiQuadProg
+        e_ref = np.where(r["status"] == 1, np.abs(dq_device - r["dq"]).max(axis=1), np.inf)
+        e = e_ref.copy()
+        witness = "qpOASES 3.1 at OpenSoT's options" if kind == "reference" else "C Goldfarb-Idnani port"
+        if kind == "reference":
+            rx = po.ihqp_solve_batch(asm, be, nthreads=cores, cycles=1, termination_tolerance=10 * 2.221e-16)
+            e = np.minimum(e, np.where(rx["status"] == 1, np.abs(dq_device - rx["dq"]).max(axis=1), np.inf))
+            re_ = po.ihqp_solve_batch(asm, po.BE_EIQP_EQ, nthreads=cores, cycles=1)
+            e = np.minimum(e, np.where(re_["status"] == 1, np.abs(dq_device - re_["dq"]).max(axis=1), np.inf))
+            witness = ("closest of: qpOASES 3.1 at OpenSoT's options, qpOASES run to the exact optimum, the restated "
+                       "eiQuadProg (DESIGN.md 2)")
+        fin = np.isfinite(e)
+        parity = {"max_abs_dq_diff": float(e[fin].max()) if fin.any() else None, "tolerance": 1e-6,
+                  "instances_compared": int(fin.sum()), "instances": int(e.size), "witness": witness,
+                  "within_tolerance_of_qpOASES_at_reference_options": int((e_ref <= 1e-6).sum()),
+                  "max_abs_dq_diff_vs_qpOASES_at_reference_options": float(e_ref[np.isfinite(e_ref)].max())}
     per_cycle = max(r["seconds"], 1e-6)
     cycles = int(max(1, min(5000, seconds_target / per_cycle)))
     r = po.ihqp_solve_batch(asm, be, nthreads=cores, cycles=cycles)
     B = asm["B"]
-    return {"value": B * cycles / r["seconds"], "unit": "solves/s", "cores": cores, "kind": kind,
+    return parity, {"value": B * cycles / r["seconds"], "unit": "solves/s", "cores": cores, "kind": kind,
             "sample": f"{B} instances of the same C3 stack x {cycles} cycles, {cores} host threads "
                       f"({'qpOASES 3.1 hot-started across cycles' if kind == 'reference' else 'C Goldfarb-Idnani port'}), "
                       f"{r['seconds']:.1f} s, ok={int(r['status'].sum())}/{B}"}
@@ -203,6 +225,14 @@ def main():
     inorder_kern_ms, _ = st.kernel_time_ms()
     st.set_schedule(longest_first=True)
     st.set_timing(False)
+    # the AutoStack::update equivalent on its own (SURVEY 8d asks for it beside the whole-step figure)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(20):
+        st.update(dev_leaves[i % K])
+    e1.record()
+    torch.cuda.synchronize()
+    update_ms = e0.elapsed_time(e1) / 20
 
     if rank == 0:
         solves = Bg * args.steps
@@ -224,6 +254,7 @@ def main():
                        "rows_per_level": [plan.m(k) for k in range(plan.L)],
                        "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
             "solved_ok_rank0": f"{ok}/{Bl}",
+            "update_avg_ms_rank0": update_ms,
             "dispatch": {"mode": "longest-first by the previous cycle's active-set iteration counts "
                                  "(osot_solver_set_schedule default; results are order-independent)",
                          "in_order_value_rank0": Bl / inorder_elapsed, "in_order_avg_launch_ms": inorder_kern_ms},
@@ -257,7 +288,11 @@ def main():
                       "bound": [tuple(None if x is None else x[:ns] for x in t) for t in leaf["bound"]],
                       "rows": [tuple(None if x is None else x[:ns] for x in t) for t in leaf["rows"]]}
             try:
-                out["cpu_baseline"] = cpu_baseline(plan, sample)
+                # the GPU's answer for the same sample (cycle 0 of the rotation)
+                st.A = A_sets[0]; st.update(dev_leaves[0]); st.solve(Bl); torch.cuda.synchronize()
+                par, out["cpu_baseline"] = cpu_baseline(plan, sample, dq_device=st.dq[:ns].cpu().numpy())
+                if par is not None:
+                    out["parity"] = par
             except Exception as e:  # the oracle is a checker; its absence must not kill the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "solves/s", "cores": 0, "kind": "port",
                                        "sample": f"unavailable: {e}"}
