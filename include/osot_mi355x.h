@@ -152,6 +152,15 @@ typedef struct {
                         (QPOasesBackEnd.cpp:57,67; qpOASES Options.cpp:147) */
     int max_iter;    /* active-set iteration cap per level; 0 = default (the reference's nWSR is 13200,
                         QPOasesBackEnd.cpp:30) */
+    /* user regularisation task (AutoStack::setRegularisationTask, include/OpenSoT/utils/AutoStack.h:78-92): iHQP adds
+     * its cost to the cost of EVERY level, H += Hr, g += gr (iHQP.cpp:265-266, 274-278); it never becomes an
+     * optimality row.  Supported: identity-Jacobian tasks A_r = [I_rows 0] with W_r = weight * I, i.e.
+     * OSOT_TASK_GENERIC (b supplied: GenericTask(I, b) as in tests/solvers/TestiHQP.cpp:118-120, MinimumVelocity
+     * with b = 0), OSOT_TASK_POSTURAL and OSOT_TASK_ACC_POSTURAL; row_mask must be 0.  Then Hr = weight * [I_rows 0;
+     * 0 0] is folded into the diagonal and gr = -weight * b_r.  A regularisation task with a dense Jacobian is
+     * rejected (OSOT_ERR_UNSUPPORTED). */
+    int has_regularisation;
+    osot_task_desc regularisation;
 } osot_plan_desc;
 
 /* ---- assembled, batched QP data (device pointers) ------------------------------------------ */
@@ -173,6 +182,8 @@ typedef struct {
     double* x_levels;                   /* out [B][n_levels][n], may be NULL */
     int* status;                        /* out [B] OSOT_STATUS_* */
     int* iterations;                    /* out [B] active-set iterations summed over levels; may be NULL */
+    const double* b_reg;                /* [B][regularisation.rows] b of the regularisation task; NULL iff the plan
+                                           has none */
 } osot_qp_batch;
 
 /* ---- leaf inputs of AutoStack::update (device pointers) ------------------------------------ */
@@ -205,6 +216,7 @@ typedef struct {
     osot_leaf_ptrs task[OSOT_MAX_LEVELS][OSOT_MAX_TASKS];
     osot_leaf_ptrs bound[OSOT_MAX_BOUNDS];
     osot_leaf_ptrs rows[OSOT_MAX_ROWBLOCKS];
+    osot_leaf_ptrs regularisation;      /* leaf inputs of the regularisation task (same meaning as for its kind) */
 } osot_leaf_batch;
 
 /* writable view of the assembled arrays that osot_stack_update fills (same shapes as osot_qp_batch) */
@@ -216,6 +228,7 @@ typedef struct {
     double* up;
     double* l;
     double* u;
+    double* b_reg;                      /* [B][regularisation.rows]; NULL iff the plan has no regularisation task */
 } osot_assembled_out;
 
 typedef struct osot_solver osot_solver;

@@ -44,7 +44,8 @@ class PlanDesc(C.Structure):
     _fields_ = [("n", C.c_int), ("n_levels", C.c_int), ("level", LevelDesc * MAX_LEVELS),
                 ("n_bounds", C.c_int), ("bound", BoundDesc * MAX_BOUNDS),
                 ("n_rowblocks", C.c_int), ("rowblock", RowsDesc * MAX_ROWBLOCKS),
-                ("eps_abs", C.c_double), ("max_iter", C.c_int)]
+                ("eps_abs", C.c_double), ("max_iter", C.c_int),
+                ("has_regularisation", C.c_int), ("regularisation", TaskDesc)]
 
 
 class QpBatch(C.Structure):
@@ -55,7 +56,7 @@ class QpBatch(C.Structure):
                 ("l", C.c_void_p), ("u", C.c_void_p),
                 ("level_active", C.c_void_p),
                 ("dq", C.c_void_p), ("x_levels", C.c_void_p),
-                ("status", C.c_void_p), ("iterations", C.c_void_p)]
+                ("status", C.c_void_p), ("iterations", C.c_void_p), ("b_reg", C.c_void_p)]
 
 
 class LeafPtrs(C.Structure):
@@ -66,13 +67,13 @@ class LeafBatch(C.Structure):
     _fields_ = [("B", C.c_int),
                 ("task", (LeafPtrs * MAX_TASKS) * MAX_LEVELS),
                 ("bound", LeafPtrs * MAX_BOUNDS),
-                ("rows", LeafPtrs * MAX_ROWBLOCKS)]
+                ("rows", LeafPtrs * MAX_ROWBLOCKS), ("regularisation", LeafPtrs)]
 
 
 class AssembledOut(C.Structure):
     _fields_ = [("b", C.c_void_p * MAX_LEVELS), ("w", C.c_void_p * MAX_LEVELS),
                 ("C", C.c_void_p), ("lo", C.c_void_p), ("up", C.c_void_p),
-                ("l", C.c_void_p), ("u", C.c_void_p)]
+                ("l", C.c_void_p), ("u", C.c_void_p), ("b_reg", C.c_void_p)]
 
 
 # every symbol include/osot_mi355x.h declares (tests/test_abi_symbols.py checks the .so exports all)

@@ -98,6 +98,15 @@ inline int plan_validate(const osot_plan_desc* p, const char** why) {
             if (!(t.weight >= 0.0)) { *why = "negative task weight"; return OSOT_ERR_INVALID; }
         }
     }
+    if (p->has_regularisation) {   // identity-Jacobian regularisation only: Hr is folded into the diagonal
+        const osot_task_desc& t = p->regularisation;
+        if (t.kind != OSOT_TASK_GENERIC && t.kind != OSOT_TASK_POSTURAL && t.kind != OSOT_TASK_ACC_POSTURAL) {
+            *why = "regularisation task: only identity-Jacobian kinds (generic b with A = [I 0], Postural) are supported"; return OSOT_ERR_UNSUPPORTED; }
+        if (t.row_mask != 0ull) { *why = "regularisation task cannot be a sub-task"; return OSOT_ERR_UNSUPPORTED; }
+        if (t.rows < 1 || t.rows > p->n) { *why = "regularisation task: rows out of range (1..n)"; return OSOT_ERR_INVALID; }
+        if (!(t.weight >= 0.0)) { *why = "negative task weight"; return OSOT_ERR_INVALID; }
+        flat += 1;
+    }
     if (flat > OSOT_KMAX_FLAT_TASKS) { *why = "too many leaf tasks in total"; return OSOT_ERR_UNSUPPORTED; }
     for (int j = 0; j < p->n_bounds; ++j)
         if (p->bound[j].kind < 0 || p->bound[j].kind > OSOT_BOUND_VELOCITY_LIMITS) { *why = "unknown bound kind"; return OSOT_ERR_UNSUPPORTED; }
@@ -161,6 +170,8 @@ inline int make_dev_plan(const osot_plan_desc& p, const unsigned char* level_act
     const int nrows_max = P.nc + P.optoff[p.n_levels];
     P.max_iter = p.max_iter > 0 ? p.max_iter : 20 * (p.n + nrows_max) + 100;
     P.eps_abs = p.eps_abs;
+    P.reg_rows = p.has_regularisation ? p.regularisation.rows : 0;
+    P.reg_w = p.has_regularisation ? p.regularisation.weight : 0.0;
     NP = (p.n <= 32) ? 32 : 64;
     // cascade layout: M1, M2, V | rlo, rup, rptr | rowstate, eqlist | xlev[L-1][NP] | rsrc bytes
     const int S = NP + 1;

@@ -43,6 +43,10 @@ struct DevPlan {
     int max_iter;
     unsigned active_mask;           // bit k: level k active (iHQP::setActiveStack)
     double eps_abs;
+    // user regularisation task A_r = [I_rows 0], W_r = w I (iHQP.cpp:274-278): Hr = w on the first reg_rows diagonal
+    // entries of every level's H, gr = -w b_r
+    int reg_rows;
+    double reg_w;
     // LDS carve-up of the wave's slice (doubles): M1, M2, V first (sizes fixed by NP), then
     int lds_rows_off;               // the row table: rlo, rup, rptr (8 B per row), rowstate, eqlist, rsrc (4 B per row)
     int lds_rows_cap;               // capacity (rows), even
@@ -67,6 +71,7 @@ struct DevBatch {
     long long* prof;   // [B][PH_COUNT] shader-clock cycles per phase (profiling instantiation only)
     const int* order;  // dispatch order: workgroup g solves instance order[g] (null: g).  Longest-first, see below
     int* cost_out;     // [B] active-set iterations of this solve = the cost estimate for the next dispatch
+    const double* b_reg;   // [B][reg_rows] b of the regularisation task (null: none)
 };
 
 // Row table of level k (LDS): [ global C rows ; A_0 ; ... ; A_{k-1} ]  (iHQP.cpp:282-333).  The C entries are
@@ -117,6 +122,11 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
     }
     wave_sync();
 
+    // regularisation task (same for every level): its diagonal joins eps, its linear term joins g
+    const bool regc = D.b_reg != nullptr && c < P.reg_rows;
+    const double greg = regc ? -P.reg_w * D.b_reg[inst * P.reg_rows + c] : 0.0;
+    const double dreg = regc ? P.reg_w : 0.0;
+
     double x = 0.0;
     int status = QP_SOLVED;
     int iters_total = 0;
@@ -159,12 +169,12 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
                 const int npost = m - ma;
                 const bool postc = valid && c < npost;
                 const double wpost = postc ? (wk ? wk[ma + c] : 1.0) : 0.0;
-                double cvec = (D.c[k] && valid) ? D.c[k][inst * n + c] : 0.0;
+                double cvec = ((D.c[k] && valid) ? D.c[k][inst * n + c] : 0.0) + greg;
                 if (postc) cvec -= wpost * bk[ma + c];
                 const WaveCtx<32>& w32 = reinterpret_cast<const WaveCtx<32>&>(w);
-                const bool has_c = D.c[k] != nullptr || npost > 0;
-                if (ma <= 3) lowrank_prepare32<3>(w32, Ak, bk, wk, ma, P.eps_abs + wpost, cvec, has_c, xprep);
-                else lowrank_prepare32<kLowRankMax>(w32, Ak, bk, wk, ma, P.eps_abs + wpost, cvec, has_c, xprep);
+                const bool has_c = D.c[k] != nullptr || npost > 0 || D.b_reg != nullptr;
+                if (ma <= 3) lowrank_prepare32<3>(w32, Ak, bk, wk, ma, P.eps_abs + wpost + dreg, cvec, has_c, xprep);
+                else lowrank_prepare32<kLowRankMax>(w32, Ak, bk, wk, ma, P.eps_abs + wpost + dreg, cvec, has_c, xprep);
             }
         }
         if (lowrank) {
@@ -229,6 +239,7 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
                 const int i = 16 * I + ta;    // diagonal element (i, i) lives in tile (I, I) where a == q + 4 r
                 double dv = (i < n) ? P.eps_abs : 1.0;
                 if (i < npost) dv += wk ? wk[ma + i] : 1.0;
+                if (D.b_reg && i < P.reg_rows) dv += P.reg_w;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Ht[I][I][r] += (ta == tq + 4 * r) ? dv : 0.0;
             }
@@ -289,17 +300,18 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
             for (int ii = 0; ii < NP / HV; ++ii) {
                 const int i = ii * HV + h;
                 // factorised straight from these registers; unit diagonal beyond n (see factor_rows64)
-                hacc[ii] += (i == c) ? (valid ? P.eps_abs : 1.0) : 0.0;
+                hacc[ii] += (i == c) ? (valid ? P.eps_abs + dreg : 1.0) : 0.0;
             }
             wave_sync();
           }
         } else if (valid) {   // level = one Postural block [I_m 0]: H = blockdiag(W, 0) + eps I is diagonal
             const bool inb = c < m;
             const double wi = inb ? (wk ? wk[c] : 1.0) : 0.0;
-            hdiag = wi + P.eps_abs;
+            hdiag = wi + P.eps_abs + dreg;
             g = inb ? -wi * bk[c] : 0.0;
         }
         if (D.c[k] && valid && !lowrank) g += D.c[k][inst * n + c];
+        if (!lowrank) g += greg;
 
         const int nrows = P.nc + P.optoff[k];
         int iters = 0;
@@ -501,6 +513,7 @@ struct DevUpdate {
     double* up;
     double* l;
     double* u;
+    double* b_reg;                   // b of the regularisation task (flat task entry with level = -1), [B][rows]
 };
 
 // Eigen's Quaterniond(Matrix3d) as invoked by cartesian_utils::computeCartesianError
@@ -582,6 +595,7 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
             double* bl = nullptr;
             for (int k = 0; k < U.L; ++k)
                 if (k == level) { bl = U.b[k] + inst * U.m[k] + off + r; wl = U.w[k] ? U.w[k] + inst * U.m[k] + off + r : nullptr; }
+            if (level < 0) bl = U.b_reg + inst * rows + r;   // regularisation task: own output, weight stays in the plan
             if (wl) *wl = weight;
             if (kind == 1) continue;   // Cartesian rows: below, one lane per task
             // acceleration kinds read (pose error, velocity error) from p0: [2 rows] per instance

@@ -189,6 +189,8 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
     D.C = P.nc_stored ? b->C : nullptr; D.lo = b->lo; D.up = b->up;
     D.l = pl.n_bounds ? b->l : nullptr; D.u = pl.n_bounds ? b->u : nullptr;
     D.dq = b->dq; D.x_levels = b->x_levels; D.status = b->status; D.iterations = b->iterations;
+    if (pl.has_regularisation && !b->b_reg) return fail(OSOT_ERR_INVALID, "plan has a regularisation task but b_reg is null");
+    D.b_reg = pl.has_regularisation ? b->b_reg : nullptr;
     D.prof = prof;
     hipStream_t st = (hipStream_t)hip_stream;
     if (s->schedule == 1) {
@@ -254,6 +256,18 @@ int osot_stack_update(osot_solver* s, const osot_leaf_batch* leaf, const osot_as
                 return fail(OSOT_ERR_INVALID, "leaf input p1 of a task is null");
             off += t.rows;
         }
+    }
+    if (pl.has_regularisation) {   // one more flat entry; its b goes to out->b_reg (level = -1)
+        const osot_task_desc& t = pl.regularisation;
+        if (!out->b_reg) return fail(OSOT_ERR_INVALID, "out.b_reg is null");
+        DevTask& d = U.task[flat++];
+        d.level = -1; d.kind = t.kind; d.rows = t.rows; d.off = 0;
+        d.weight = t.weight; d.lambda = t.lambda; d.ogain = t.orientation_gain; d.lambda2 = t.lambda2;
+        d.mask = 0ull; d.prow = t.rows; d.sublam = 1.0;
+        d.p0 = leaf->regularisation.p0; d.p1 = leaf->regularisation.p1; d.p2 = leaf->regularisation.p2;
+        if (!d.p0) return fail(OSOT_ERR_INVALID, "leaf input p0 of the regularisation task is null");
+        if (t.kind == OSOT_TASK_POSTURAL && !d.p1) return fail(OSOT_ERR_INVALID, "leaf input p1 of the regularisation task is null");
+        U.b_reg = out->b_reg;
     }
     U.ntasks = flat;
     U.nbounds = pl.n_bounds;

@@ -5,7 +5,7 @@ Mirrors what `(com/(0.1*l_wrist + r_wrist)/postural) << jl << vl` builds in the 
 box-bound producers and global constraint-row producers.  Pure description, no arithmetic.
 """
 from dataclasses import dataclass, field
-from typing import List
+from typing import List, Optional
 
 from . import abi
 
@@ -93,6 +93,9 @@ class StackPlan:
     rowblocks: List[Rows] = field(default_factory=list)
     eps_abs: float = eps_abs_from_factor(2e2)  # iHQP default eps_regularisation (iHQP.h:32)
     max_iter: int = 0
+    # AutoStack::setRegularisationTask (AutoStack.h:78-92): an identity-Jacobian task (TASK_GENERIC with b supplied,
+    # TASK_POSTURAL, TASK_ACC_POSTURAL; rows <= n) whose cost iHQP adds to every level (iHQP.cpp:274-278)
+    regularisation: Optional[Task] = None
 
     # ---- derived sizes -------------------------------------------------------------------
     @property
@@ -140,6 +143,10 @@ class StackPlan:
                 if t.kind in (abi.TASK_COM, abi.TASK_ACC_COM):
                     assert t.rows == 3
         assert len(self.bounds) <= abi.MAX_BOUNDS and len(self.rowblocks) <= abi.MAX_ROWBLOCKS
+        if self.regularisation is not None:
+            r = self.regularisation
+            assert r.kind in (abi.TASK_GENERIC, abi.TASK_POSTURAL, abi.TASK_ACC_POSTURAL) and not r.row_mask
+            assert 1 <= r.rows <= self.n
 
     def to_c(self) -> abi.PlanDesc:
         self.validate()
@@ -164,4 +171,11 @@ class StackPlan:
             d.first_col, d.dT, d.p, d.mu = r.first_col, r.dT, r.p, r.mu
         p.eps_abs = self.eps_abs
         p.max_iter = self.max_iter
+        if self.regularisation is not None:
+            t = self.regularisation
+            p.has_regularisation = 1
+            d = p.regularisation
+            d.kind, d.rows, d.weight, d.lambda_, d.orientation_gain, d.lambda2 = (
+                t.kind, t.rows, t.weight, t.lam, t.orientation_gain, t.lam2)
+            d.row_mask, d.parent_rows, d.sub_lambda = 0, 0, 1.0
         return p

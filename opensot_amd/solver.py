@@ -61,6 +61,7 @@ class BatchedStack:
         self.up = torch.zeros((B, nc), **f64) if nc else None
         self.l = torch.zeros((B, n), **f64) if plan.bounds else None
         self.u = torch.zeros((B, n), **f64) if plan.bounds else None
+        self.b_reg = torch.zeros((B, plan.regularisation.rows), **f64) if plan.regularisation is not None else None
         self.dq = torch.zeros((B, n), **f64)
         self.x_levels = torch.zeros((B, L, n), **f64) if want_levels else None
         self.status = torch.zeros((B,), dtype=torch.int32, device=self.device)
@@ -92,6 +93,8 @@ class BatchedStack:
                "task": [[tuple(to(x) for x in t) for t in lev] for lev in leaf["task"]],
                "bound": [tuple(to(x) for x in t) for t in leaf["bound"]],
                "rows": [tuple(to(x) for x in t) for t in leaf["rows"]]}
+        if self.plan.regularisation is not None:
+            dev["reg"] = tuple(to(x) for x in leaf["reg"])
         return dev
 
     def load_assembled(self, asm):
@@ -110,6 +113,8 @@ class BatchedStack:
             self.up[:B].copy_(torch.as_tensor(asm["up"]))
         if self.l is not None:
             self.l[:B].copy_(torch.as_tensor(asm["l"])); self.u[:B].copy_(torch.as_tensor(asm["u"]))
+        if self.b_reg is not None:
+            self.b_reg[:B].copy_(torch.as_tensor(asm["reg"]["b"]))
         return B
 
     # ---- AutoStack::update ------------------------------------------------------------------------
@@ -129,6 +134,10 @@ class BatchedStack:
             out.b[k] = _dev_ptr(self.b[k]); out.w[k] = _dev_ptr(self.w[k])
         out.C, out.lo, out.up = _dev_ptr(self.C), _dev_ptr(self.lo), _dev_ptr(self.up)
         out.l, out.u = _dev_ptr(self.l), _dev_ptr(self.u)
+        if self.b_reg is not None:
+            p0, p1, p2 = dev_leaf["reg"]
+            lb.regularisation.p0, lb.regularisation.p1, lb.regularisation.p2 = _dev_ptr(p0), _dev_ptr(p1), _dev_ptr(p2)
+            out.b_reg = _dev_ptr(self.b_reg)
         self._leaf_keep = dev_leaf
         abi.check(self._lib.osot_stack_update(self._h, C.byref(lb), C.byref(out), _stream_ptr(self.device)),
                   "osot_stack_update")
@@ -145,6 +154,7 @@ class BatchedStack:
         qb.l, qb.u = _dev_ptr(self.l), _dev_ptr(self.u)
         qb.dq, qb.x_levels = _dev_ptr(self.dq), _dev_ptr(self.x_levels)
         qb.status, qb.iterations = _dev_ptr(self.status), _dev_ptr(self.iterations)
+        qb.b_reg = _dev_ptr(self.b_reg)
         if self.level_active is not None:
             self._act = (C.c_ubyte * self.plan.L)(*[1 if a else 0 for a in self.level_active])
             qb.level_active = C.cast(self._act, C.c_void_p)

@@ -148,7 +148,26 @@ def perturb(leaf, rng, scale=0.01):
            "task": [[tuple(j(x) for x in t) for t in lev] for lev in leaf["task"]],
            "bound": [tuple(j(x) for x in t) for t in leaf["bound"]],
            "rows": [tuple(j(x) for x in t) for t in leaf["rows"]]}
+    if "reg" in leaf:
+        out["reg"] = tuple(j(x) for x in leaf["reg"])
     return out
+
+
+def add_regularisation(plan, leaf, kind=abi.TASK_GENERIC, rows=None, weight=1e-3, lam=0.1, seed=0):
+    """attach a user regularisation task (AutoStack::setRegularisationTask) to a synthetic stack: the reference's own
+    use (tests/solvers/TestiHQP.cpp:112-120) is a minimum-velocity GenericTask(I, -qdot/dt); a Postural works alike."""
+    rng = np.random.default_rng(seed + 977)
+    n, B = plan.n, leaf["B"]
+    rows = n if rows is None else rows
+    plan.regularisation = Task(kind, rows, weight=weight, lam=lam, lam2=2.0 * np.sqrt(lam), name="regularisation")
+    if kind == abi.TASK_GENERIC:
+        leaf["reg"] = (rng.normal(0.0, 0.1, size=(B, rows)), None, None)
+    elif kind == abi.TASK_POSTURAL:
+        q = rng.uniform(-1, 1, size=(B, rows))
+        leaf["reg"] = (q, q + rng.normal(0, 0.1, size=(B, rows)), None)
+    else:   # ACC_POSTURAL: [q_ref - q ; qdot_ref - qdot], qddot_ref
+        leaf["reg"] = (rng.normal(0, 0.1, size=(B, 2 * rows)), None, rng.normal(0, 0.1, size=(B, rows)))
+    return plan, leaf
 
 
 def make_id_stack(B, seed=None, nv=38, n_contacts=4, eps_factor=1e6, torque_limits=True):

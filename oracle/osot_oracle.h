@@ -45,6 +45,12 @@ typedef struct {
     const double* u;             /* [B][n]                                                 */
     double eps_abs;              /* absolute epsilon added to diag(H) by the back-end      */
     const unsigned char* active; /* [L] iHQP::setActiveStack flags, NULL = all active      */
+    /* user regularisation task (AutoStack::setRegularisationTask, AutoStack.h:78-92): its cost is ADDED to the
+     * cost of every level, H += Hr, g += gr (iHQP.cpp:265-266, 274-278); it never becomes an optimality row */
+    int mr;                      /* rows of the regularisation task, 0 = none              */
+    const double* Ar;            /* [B][mr][n]; NULL = [I_mr 0]                            */
+    const double* br;            /* [B][mr]                                                */
+    double wr;                   /* scalar weight: W_r = wr * I                            */
 } orc_batch;
 
 /* back-end selection for the cascade */
@@ -75,6 +81,8 @@ int orc_backend_solve(int form, int n, const double* H, const double* g, int nc,
 /* ---------- iHQP cascade (src/solvers/iHQP.cpp:129-170, 263-358) ---------- */
 /* H = A'WA, g = -A'Wb + c for one instance of level k */
 void orc_cost_function(const orc_batch* P, int inst, int k, double* H, double* g);
+/* H += Hr, g += gr of the regularisation task (no-op when mr == 0) */
+void orc_add_regularisation(const orc_batch* P, int inst, double* H, double* g);
 
 /* Solve the cascade for instance `inst`. x_levels: [L][n] (may be NULL), dq: [n].
  * `be_state`: NULL, or persistent per-instance state created by orc_ref_state_create (qpOASES

@@ -33,7 +33,8 @@ class OrcBatch(C.Structure):
                 ("A", dp * ORC_MAX_LEVELS), ("b", dp * ORC_MAX_LEVELS),
                 ("w", dp * ORC_MAX_LEVELS), ("c", dp * ORC_MAX_LEVELS),
                 ("nc", C.c_int), ("C", dp), ("lo", dp), ("up", dp), ("l", dp), ("u", dp),
-                ("eps_abs", C.c_double), ("active", C.POINTER(C.c_ubyte))]
+                ("eps_abs", C.c_double), ("active", C.POINTER(C.c_ubyte)),
+                ("mr", C.c_int), ("Ar", dp), ("br", dp), ("wr", C.c_double)]
 
 
 _lib = None
@@ -59,6 +60,7 @@ def lib():
         L.orc_eiquadprog.argtypes = [C.c_int, dp, dp, C.c_int, dp, dp, C.c_int, dp, dp, dp, C.c_double, ip, ip, ip]
         L.orc_backend_solve.argtypes = [C.c_int, C.c_int, dp, dp, C.c_int, dp, dp, dp, dp, dp, C.c_double, dp, ip]
         L.orc_cost_function.argtypes = [C.POINTER(OrcBatch), C.c_int, C.c_int, dp, dp]
+        L.orc_add_regularisation.argtypes = [C.POINTER(OrcBatch), C.c_int, dp, dp]
         L.orc_ihqp_solve.argtypes = [C.POINTER(OrcBatch), C.c_int, C.c_int, C.c_void_p, dp, dp, ip]
         L.orc_ihqp_solve_batch.restype = C.c_double
         L.orc_ihqp_solve_batch.argtypes = [C.POINTER(OrcBatch), C.c_int, C.c_int, C.c_int, dp, dp, ip,
@@ -149,6 +151,22 @@ def assemble(plan, leaf):
         out["m"].append(m); out["ma"].append(ma)
         out["A"].append(_c(leaf["A"][k]) if ma else None)
         out["b"].append(b); out["w"].append(w); out["c"].append(None)
+    # user regularisation task (AutoStack::setRegularisationTask, AutoStack.h:78-92): an identity-Jacobian task
+    # ([I_rows 0]: GenericTask(I, b) as in TestiHQP.cpp:118-120, Postural, MinimumVelocity) whose cost iHQP adds to
+    # every level (iHQP.cpp:265-266, 274-278)
+    t = getattr(plan, "regularisation", None)
+    if t is not None:
+        p0, p1, p2 = (_c(x) for x in leaf["reg"])
+        br = np.zeros((B, t.rows))
+        for i in range(B):
+            if t.kind == TASK_POSTURAL:
+                L.orc_postural_b(t.rows, _p(p0[i]), _p(p1[i]), _p(p2[i] if p2 is not None else zerosn), t.lam, _p(br[i]))
+            elif t.kind == TASK_ACC_POSTURAL:
+                pe = np.ascontiguousarray(p0[i, :t.rows]); ve = np.ascontiguousarray(p0[i, t.rows:])
+                L.orc_acc_postural_b(t.rows, _p(pe), _p(ve), _p(p2[i]) if p2 is not None else None, t.lam, t.lam2, _p(br[i]))
+            else:
+                br[i] = p0[i]
+        out["reg"] = {"A": None, "b": br, "w": t.weight}
     # box (constraints::Aggregated, Aggregated.cpp:141-148)
     if plan.bounds:
         l = np.full((B, n), -np.inf)
@@ -240,6 +258,10 @@ def _orc_batch(asm, active=None, sl=None):
     P.C, P.lo, P.up = take(asm["C"]), take(asm["lo"]), take(asm["up"])
     P.l, P.u = take(asm["l"]), take(asm["u"])
     P.eps_abs = asm["eps_abs"]
+    reg = asm.get("reg")   # user regularisation task: dict(A [B][mr][n] or None = [I 0], b [B][mr], w scalar)
+    if reg is not None:
+        P.mr = reg["b"].shape[1]
+        P.Ar, P.br, P.wr = take(reg.get("A")), take(reg["b"]), float(reg.get("w", 1.0))
     if active is not None:
         act = (C.c_ubyte * asm["L"])(*[1 if a else 0 for a in active])
         keep.append(act)
@@ -247,11 +269,14 @@ def _orc_batch(asm, active=None, sl=None):
     return P, keep
 
 
-def cost_function(asm, inst, k):
+def cost_function(asm, inst, k, regularised=False):
+    """iHQP::getCostFunction / getCostFunctionRegularized of level k"""
     P, keep = _orc_batch(asm)
     n = asm["n"]
     H = np.zeros((n, n)); g = np.zeros(n)
     lib().orc_cost_function(C.byref(P), inst, k, _p(H), _p(g))
+    if regularised:
+        lib().orc_add_regularisation(C.byref(P), inst, _p(H), _p(g))
     return H, g
 
 

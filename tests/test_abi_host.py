@@ -119,3 +119,29 @@ def test_subtask_plan_validation(lib):
     d.level[0].task[0].rows = 3
     d.level[0].task[0].row_mask = 0b1000011           # bit 6 is beyond a Cartesian task's 6 rows
     assert lib.osot_plan_validate(C.byref(d)) == abi.ERR_INVALID
+
+
+def test_regularisation_task_plan_validation(lib):
+    """AutoStack::setRegularisationTask: identity-Jacobian kinds only (the cost joins the diagonal of every level's H),
+    rows in 1..n, no sub-task; anything else is refused, not approximated"""
+    from opensot_amd.plan import StackPlan, Task, eps_abs_from_factor
+    import ctypes as C
+    n = 12
+    plan = StackPlan(n=n, levels=[[Task(abi.TASK_GENERIC, 5, name="g")]], bounds=[], rowblocks=[],
+                     eps_abs=eps_abs_from_factor(1e6), regularisation=Task(abi.TASK_GENERIC, n, weight=1e-2, name="minvel"))
+    d = plan.to_c()
+    assert d.has_regularisation == 1 and d.regularisation.rows == n
+    assert lib.osot_plan_validate(C.byref(d)) == abi.OK
+    d.regularisation.kind = abi.TASK_CARTESIAN                # dense Jacobian: not expressible
+    assert lib.osot_plan_validate(C.byref(d)) == abi.ERR_UNSUPPORTED
+    d.regularisation.kind = abi.TASK_POSTURAL
+    d.regularisation.rows = n + 1
+    assert lib.osot_plan_validate(C.byref(d)) == abi.ERR_INVALID
+    d.regularisation.rows = n
+    d.regularisation.row_mask = 0b11
+    assert lib.osot_plan_validate(C.byref(d)) == abi.ERR_UNSUPPORTED
+    d.regularisation.row_mask = 0
+    d.regularisation.weight = -1.0
+    assert lib.osot_plan_validate(C.byref(d)) == abi.ERR_INVALID
+    d.has_regularisation = 0                                   # ignored when absent
+    assert lib.osot_plan_validate(C.byref(d)) == abi.OK

@@ -277,3 +277,51 @@ def test_subtasks(oracle):
         rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
         ok = rq["status"] == 1
         assert ok.all() and np.abs(dq[ok] - rq["dq"][ok]).max() < 1e-6
+
+
+def _reg_cases():
+    from opensot_amd import abi
+    return [("C3", abi.TASK_GENERIC, None, 1e-2), ("C3", abi.TASK_POSTURAL, None, 0.5), ("C2", abi.TASK_GENERIC, 20, 1e-3),
+            ("generic40", abi.TASK_POSTURAL, None, 1e-2), ("lowrank", abi.TASK_GENERIC, None, 0.2), ("lowrank_plain", abi.TASK_POSTURAL, 20, 0.05), ("generic", abi.TASK_POSTURAL, 5, 1.0),
+            ("id", abi.TASK_ACC_POSTURAL, 32, 1e-2)]
+
+
+def _reg_stack(name, B, seed):
+    if name == "generic40":     # 40 variables: the NP = 64 instantiation
+        return synth.make_generic_stack(B, 40, [10, 12], n_eq=2, n_ineq=3, seed=seed)
+    if name in ("C2", "C3"):
+        return synth.make_velocity_stack(name, B, seed=seed)
+    if name == "lowrank":
+        return synth.make_lowrank_stack(B, 32, m=3, seed=seed, postural_weight=1e-3, second_level_rows=5)
+    if name == "lowrank_plain":
+        return synth.make_lowrank_stack(B, 32, m=4, seed=seed, second_level_rows=5)
+    if name == "generic":
+        return synth.make_generic_stack(B, 7, [3, 3], n_eq=1, n_ineq=2, seed=seed, postural_last=False)
+    return synth.make_id_stack(B, seed=seed)
+
+
+@pytest.mark.parametrize("name,kind,rows,weight", _reg_cases())
+def test_user_regularisation_task(name, kind, rows, weight, oracle):
+    """AutoStack::setRegularisationTask (AutoStack.h:78-92): the cost of an identity-Jacobian task is added to every
+    level (iHQP.cpp:265-266, 274-278) and never becomes an optimality row; all H-build paths of the kernel (matrix
+    core, closed-form low-rank, diagonal, NP = 64) on the emulator against the oracle's general H += Hr, g += gr"""
+    plan, leaf = _reg_stack(name, 4, seed=5)
+    # (dependent equality rows / more equality rows than variables: outside the restated eiQuadProg routine, qpOASES only)
+    qpoases_only = name in ("id", "lowrank")
+    base = None if qpoases_only else oracle.ihqp_solve_batch(oracle.assemble(plan, leaf), oracle.BE_EIQP_EQ, nthreads=1)["dq"]
+    synth.add_regularisation(plan, leaf, kind=kind, rows=rows, weight=weight, seed=3)
+    asm = oracle.assemble(plan, leaf)
+    assert asm["reg"]["b"].shape == (4, plan.regularisation.rows)
+    dq, xl, st, it = emu_cascade(plan, asm)
+    assert (st == 0).all()
+    if not qpoases_only:
+        ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+        assert (ref["status"] == 1).all()
+        assert np.abs(dq - ref["dq"]).max() < 1e-9 * max(1.0, np.abs(ref["dq"]).max())
+        assert np.abs(ref["dq"] - base).max() > 1e-6      # the task does change the answer
+    if oracle.ref_available():
+        rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
+        ok = rq["status"] == 1
+        assert ok.all() and np.abs(dq[ok] - rq["dq"][ok]).max() < 1e-6 * max(1.0, np.abs(rq["dq"]).max())
+    else:
+        assert not qpoases_only, "this case needs oracle/_ref (qpOASES)"

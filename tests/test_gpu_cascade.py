@@ -136,3 +136,39 @@ def test_subtasks_gpu(oracle, gpu_device):
         e = np.minimum(np.where(rq["status"] == 1, np.abs(dq - rq["dq"]).max(axis=1), np.inf),
                        np.where(rx["status"] == 1, np.abs(dq - rx["dq"]).max(axis=1), np.inf))
         assert np.isfinite(e).mean() > 0.95 and e[np.isfinite(e)].max() < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kind,rows,weight", [("C3", 0, None, 1e-2), ("C3", 3, None, 0.5), ("C2", 0, 20, 1e-3),
+                                                   ("generic40", 3, None, 1e-2), ("lowrank", 0, None, 0.2),
+                                                   ("lowrank_plain", 3, 20, 0.05), ("id", 6, 32, 1e-2)])
+def test_user_regularisation_task_gpu(name, kind, rows, weight, oracle, gpu_device):
+    """AutoStack::setRegularisationTask (iHQP.cpp:265-266, 274-278): b_r through the update kernel (bit-exact against
+    the oracle's assembly), H += Hr, g += gr inside the cascade kernel, against qpOASES (and the restated eiQuadProg
+    where it applies)"""
+    from test_emulated_kernels import _reg_stack
+    B = 256
+    plan, leaf = _reg_stack(name, B, seed=5)
+    synth.add_regularisation(plan, leaf, kind=kind, rows=rows, weight=weight, seed=3)
+    asm = oracle.assemble(plan, leaf)
+    st = BatchedStack(plan, B, device=0)
+    st.update(st.load_leaf(leaf)); st.solve(B)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(st.b_reg.cpu().numpy(), asm["reg"]["b"], rtol=0, atol=1e-15)
+    for k in range(plan.L):
+        np.testing.assert_allclose(st.b[k].cpu().numpy(), asm["b"][k], rtol=0, atol=1e-14)
+    dq = st.dq[:B].cpu().numpy()
+    assert (st.status[:B].cpu().numpy() == 0).all()
+    scale = max(1.0, np.abs(dq).max())
+    if name not in ("id", "lowrank"):
+        ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+        okr = ref["status"] == 1
+        assert okr.mean() > 0.95 and np.abs(dq[okr] - ref["dq"][okr]).max() < 1e-9 * scale
+    if oracle.ref_available():
+        rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
+        rx = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1, termination_tolerance=10 * 2.221e-16)
+        e = np.minimum(np.where(rq["status"] == 1, np.abs(dq - rq["dq"]).max(axis=1), np.inf),
+                       np.where(rx["status"] == 1, np.abs(dq - rx["dq"]).max(axis=1), np.inf))
+        assert np.isfinite(e).mean() > 0.95 and e[np.isfinite(e)].max() < 1e-6 * scale
+    else:
+        assert name not in ("id", "lowrank"), "this case needs oracle/_ref (qpOASES)"

@@ -96,12 +96,20 @@ def test_ihqp_cost_function_and_regularisation(oracle):
     assert (H == I.T @ I).all() and (g == -(I.T @ b)).all()
     r = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
     np.testing.assert_allclose(r["dq"][0], b, atol=1e-12)
-    # regularisation task (iHQP.cpp:274-278): H += Hr, g += gr with Hr = I'I, gr = -I' b_r
+    # regularisation task (TestiHQP.cpp:112-139; iHQP.cpp:265-266, 274-278): H += Hr, g += gr with Hr = I'I, gr = -I' b_r
     rng = np.random.default_rng(0)
     br = -(1.0 / 0.001) * 1e-4 * rng.uniform(-1, 1, n)
-    Hreg = 2 * I; greg = -(b + br)
-    ok, x, _ = oracle.backend_solve(Hreg, greg, None, None, None, None, None, EPS_BASE * 2e2)
-    np.testing.assert_allclose(x, -np.linalg.solve(Hreg, greg), atol=1e-12)
+    asm["reg"] = {"A": I[None], "b": br[None], "w": 1.0}
+    Hreg, greg = oracle.cost_function(asm, 0, 0, regularised=True)
+    assert (Hreg == 2 * I.T @ I).all() and (greg == -(I.T @ b + I.T @ br)).all()      # TestiHQP.cpp:130-131
+    r = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+    np.testing.assert_allclose(r["dq"][0], -np.linalg.solve(Hreg, greg), atol=1e-12)   # TestiHQP.cpp:134-138
+    asm["reg"] = {"A": None, "b": br[None], "w": 1.0}      # the implicit [I 0] form the product supports
+    r2 = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+    assert (r2["dq"] == r["dq"]).all()
+    if oracle.ref_available():
+        rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
+        np.testing.assert_allclose(rq["dq"][0], r["dq"][0], atol=1e-9)
 
 
 def test_cross_backend_parity(oracle):
