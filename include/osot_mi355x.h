@@ -138,6 +138,9 @@ typedef struct {
     int first_col;   /* unit-row / friction-cone blocks: column of the block's first variable */
     double dT, p;    /* acceleration limits: time step and horizon factor (dt = dT*p) */
     double mu;       /* friction coefficient */
+    int only_level;  /* 0 = global rows: constrain every level (AutoStack `<<`, iHQP.cpp:191-193).  k + 1 = TASK-LOCAL
+                        rows of level k (`task << constraint`, Task::getConstraints(), iHQP.cpp:190, 282-287): they
+                        constrain the QP of level k only; at every other level they are absent */
 } osot_rows_desc;
 
 typedef struct {

@@ -37,7 +37,8 @@ class BoundDesc(C.Structure):
 class RowsDesc(C.Structure):
     _fields_ = [("kind", C.c_int), ("rows", C.c_int), ("d_threshold", C.c_double),
                 ("detection_threshold", C.c_double), ("bound_scaling", C.c_double),
-                ("first_col", C.c_int), ("dT", C.c_double), ("p", C.c_double), ("mu", C.c_double)]
+                ("first_col", C.c_int), ("dT", C.c_double), ("p", C.c_double), ("mu", C.c_double),
+                ("only_level", C.c_int)]
 
 
 class PlanDesc(C.Structure):

@@ -120,6 +120,7 @@ inline int plan_validate(const osot_plan_desc* p, const char** why) {
         if (rows_are_implicit(rb.kind) && (rb.first_col < 0 || rb.first_col + rb.rows > p->n)) {
             *why = "unit-row block exceeds the variables"; return OSOT_ERR_INVALID; }
         if (rows_are_implicit(rb.kind) && !(rb.dT * rb.p > 0.0)) { *why = "acceleration limits need dT*p > 0"; return OSOT_ERR_INVALID; }
+        if (rb.only_level < 0 || rb.only_level > p->n_levels) { *why = "row block: only_level out of range (0..n_levels)"; return OSOT_ERR_INVALID; }
     }
     return OSOT_OK;
 }
@@ -160,6 +161,7 @@ inline int make_dev_plan(const osot_plan_desc& p, const unsigned char* level_act
             P.blk_off[j] = off;
             P.blk_implicit[j] = rows_are_implicit(p.rowblock[j].kind) ? 1 : 0;
             P.blk_first_col[j] = p.rowblock[j].first_col;
+            P.blk_level[j] = p.rowblock[j].only_level;
             P.blk_stored_off[j] = soff;
             off += p.rowblock[j].rows;
             if (!P.blk_implicit[j]) soff += p.rowblock[j].rows;

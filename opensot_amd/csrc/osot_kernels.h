@@ -40,6 +40,7 @@ struct DevPlan {
     int nblocks, nc_stored;            // global row blocks; rows of C that are stored
     int blk_rows[OSOT_KMAX_ROWBLOCKS], blk_off[OSOT_KMAX_ROWBLOCKS], blk_stored_off[OSOT_KMAX_ROWBLOCKS];
     int blk_implicit[OSOT_KMAX_ROWBLOCKS], blk_first_col[OSOT_KMAX_ROWBLOCKS];
+    int blk_level[OSOT_KMAX_ROWBLOCKS];   // 0: global rows; k + 1: task-local rows of level k (absent at the other levels)
     int max_iter;
     unsigned active_mask;           // bit k: level k active (iHQP::setActiveStack)
     double eps_abs;
@@ -146,6 +147,18 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
                 wave_sync();
             }
             continue;
+        }
+        // task-local row blocks (Task::getConstraints(), iHQP.cpp:190, 282-287): real bounds at their own level,
+        // "absent" (infinite bounds: never scanned as violated, never an equality) at every other level
+        for (int j = 0; j < P.nblocks; ++j) {
+            if (P.blk_level[j] == 0) continue;
+            const bool on = P.blk_level[j] - 1 == k;
+            for (int q = lane; q < P.blk_rows[j]; q += 64) {
+                const int r = P.blk_off[j] + q;
+                w.rlo[r] = on ? clamp_inf(D.lo[inst * P.nc + r]) : -kInfty;
+                w.rup[r] = on ? clamp_inf(D.up[inst * P.nc + r]) : kInfty;
+            }
+            wave_sync();
         }
         OSOT_PH_BEGIN();
         {   // re-derive the lane coordinates per level (see launder_i)

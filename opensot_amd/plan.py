@@ -83,6 +83,9 @@ class Rows:
     dT: float = 0.0
     p: float = 1.0
     mu: float = 0.0
+    # None: global rows (every level).  k: task-local rows of level k (`task << constraint`, Task::getConstraints(),
+    # iHQP.cpp:190, 282-287): they constrain level k's QP only
+    level: Optional[int] = None
 
 
 @dataclass
@@ -169,6 +172,7 @@ class StackPlan:
             d.kind, d.rows, d.d_threshold, d.detection_threshold, d.bound_scaling = (
                 r.kind, r.rows, r.d_threshold, r.detection_threshold, r.bound_scaling)
             d.first_col, d.dT, d.p, d.mu = r.first_col, r.dT, r.p, r.mu
+            d.only_level = 0 if r.level is None else r.level + 1
         p.eps_abs = self.eps_abs
         p.max_iter = self.max_iter
         if self.regularisation is not None:

@@ -51,6 +51,9 @@ typedef struct {
     const double* Ar;            /* [B][mr][n]; NULL = [I_mr 0]                            */
     const double* br;            /* [B][mr]                                                */
     double wr;                   /* scalar weight: W_r = wr * I                            */
+    /* task-local constraint rows (Task::getConstraints(), iHQP.cpp:190, 282-287): row r of C belongs to every level
+     * when row_level[r] == 0 and to level k only when row_level[r] == k + 1 */
+    const int* row_level;        /* [nc], NULL = all rows global                           */
 } orc_batch;
 
 /* back-end selection for the cascade */

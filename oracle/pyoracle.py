@@ -34,7 +34,7 @@ class OrcBatch(C.Structure):
                 ("w", dp * ORC_MAX_LEVELS), ("c", dp * ORC_MAX_LEVELS),
                 ("nc", C.c_int), ("C", dp), ("lo", dp), ("up", dp), ("l", dp), ("u", dp),
                 ("eps_abs", C.c_double), ("active", C.POINTER(C.c_ubyte)),
-                ("mr", C.c_int), ("Ar", dp), ("br", dp), ("wr", C.c_double)]
+                ("mr", C.c_int), ("Ar", dp), ("br", dp), ("wr", C.c_double), ("row_level", ip)]
 
 
 _lib = None
@@ -229,6 +229,13 @@ def assemble(plan, leaf):
                     Cm[i, off:off + rb.rows] = p0[i]; lo[i, off:off + rb.rows] = p1[i]; up[i, off:off + rb.rows] = p2[i]
             off += rb.rows
         out["C"], out["lo"], out["up"] = Cm, lo, up
+        # task-local row blocks (Task::getConstraints(), iHQP.cpp:190): 0 = global, k + 1 = rows of level k only
+        rl = []
+        for rb in plan.rowblocks:
+            lv = getattr(rb, "level", None)
+            rl += [0 if lv is None else lv + 1] * rb.rows
+        if any(rl):
+            out["row_level"] = np.asarray(rl, dtype=np.int32)
     else:
         out["C"] = out["lo"] = out["up"] = None
     return out
@@ -258,6 +265,10 @@ def _orc_batch(asm, active=None, sl=None):
     P.C, P.lo, P.up = take(asm["C"]), take(asm["lo"]), take(asm["up"])
     P.l, P.u = take(asm["l"]), take(asm["u"])
     P.eps_abs = asm["eps_abs"]
+    if asm.get("row_level") is not None:
+        rl = np.ascontiguousarray(asm["row_level"], dtype=np.int32)
+        keep.append(rl)
+        P.row_level = rl.ctypes.data_as(ip)
     reg = asm.get("reg")   # user regularisation task: dict(A [B][mr][n] or None = [I 0], b [B][mr], w scalar)
     if reg is not None:
         P.mr = reg["b"].shape[1]

@@ -145,3 +145,19 @@ def test_regularisation_task_plan_validation(lib):
     assert lib.osot_plan_validate(C.byref(d)) == abi.ERR_INVALID
     d.has_regularisation = 0                                   # ignored when absent
     assert lib.osot_plan_validate(C.byref(d)) == abi.OK
+
+
+def test_task_local_rows_plan_validation(lib):
+    """row blocks tagged with a level (`task << constraint`): only_level = level + 1, within the plan's levels"""
+    from opensot_amd.plan import StackPlan, Task, Rows, eps_abs_from_factor
+    import ctypes as C
+    plan = StackPlan(n=8, levels=[[Task(abi.TASK_GENERIC, 3, name="a")], [Task(abi.TASK_GENERIC, 2, name="b")]], bounds=[],
+                     rowblocks=[Rows(abi.ROWS_GENERIC, 2, name="global"), Rows(abi.ROWS_GENERIC, 3, name="local", level=1)],
+                     eps_abs=eps_abs_from_factor(1e6))
+    d = plan.to_c()
+    assert (d.rowblock[0].only_level, d.rowblock[1].only_level) == (0, 2)
+    assert lib.osot_plan_validate(C.byref(d)) == abi.OK
+    d.rowblock[1].only_level = 3          # there is no level 2
+    assert lib.osot_plan_validate(C.byref(d)) == abi.ERR_INVALID
+    d.rowblock[1].only_level = -1
+    assert lib.osot_plan_validate(C.byref(d)) == abi.ERR_INVALID

@@ -325,3 +325,29 @@ def test_user_regularisation_task(name, kind, rows, weight, oracle):
         assert ok.all() and np.abs(dq[ok] - rq["dq"][ok]).max() < 1e-6 * max(1.0, np.abs(rq["dq"]).max())
     else:
         assert not qpoases_only, "this case needs oracle/_ref (qpOASES)"
+
+
+@pytest.mark.parametrize("n,rows,local_level,n_local", [(7, [3, 3], 0, 2), (20, [5, 6], 1, 4), (31, [10, 12], 2, 3), (40, [10, 12], 0, 5)])
+def test_task_local_constraint_rows(n, rows, local_level, n_local, oracle):
+    """`task << constraint` (Task::getConstraints(), iHQP.cpp:190, 282-287): the rows constrain the QP of THEIR level
+    only; the lower levels see that level's optimality rows, not its local constraints"""
+    mk = lambda lvl: synth.make_generic_stack(5, n, rows, n_eq=1, n_ineq=2, seed=9, n_local=n_local, local_level=lvl)
+    plan, leaf = mk(local_level)
+    asm = oracle.assemble(plan, leaf)
+    assert (asm["row_level"] == [0] * 3 + [local_level + 1] * n_local).all()
+    dq, xl, st, it = emu_cascade(plan, asm)
+    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+    assert (st == 0).all() and (ref["status"] == 1).all()
+    assert np.abs(dq - ref["dq"]).max() < 1e-9 and np.abs(xl - ref["x_levels"]).max() < 1e-9
+    if oracle.ref_available():
+        rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
+        ok = rq["status"] == 1
+        assert ok.all() and np.abs(dq[ok] - rq["dq"][ok]).max() < 1e-6
+    # the local rows hold at their own level ...
+    Cl, lo, up = leaf["rows"][-1]
+    v = np.einsum("bri,bi->br", Cl, xl[:, local_level])
+    assert (v >= lo - 1e-9).all() and (v <= up + 1e-9).all()
+    # ... and the tag matters: the same rows as GLOBAL rows give a different cascade
+    plan_g, leaf_g = mk(None)
+    glob = oracle.ihqp_solve_batch(oracle.assemble(plan_g, leaf_g), oracle.BE_EIQP_EQ, nthreads=1)
+    assert np.abs(glob["x_levels"] - ref["x_levels"]).max() > 1e-6
