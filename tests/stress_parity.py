@@ -25,6 +25,8 @@ for it in range(N):
         n_ineq = int(rng.integers(0, 8))
         kw = dict(n=n, level_rows=rows, n_eq=n_eq, n_ineq=n_ineq, seed=int(rng.integers(1 << 30)), box=float(rng.choice([0.0, 0.1, 0.5])),
                   postural_last=bool(rng.integers(0, 2)), eps_factor=float(rng.choice([1e6, 1e6, 2e2])))
+        if rng.integers(0, 3) == 0:   # task-local rows (`task << constraint`) at a random level
+            kw.update(n_local=int(rng.integers(1, 5)), local_level=int(rng.integers(0, L)))
         plan, leaf = synth.make_generic_stack(B, kw.pop("n"), kw.pop("level_rows"), **kw); desc = ("generic", n, rows, kw)
     elif kind == 1:
         kw = dict(m=int(rng.integers(1, 5)), seed=int(rng.integers(1 << 30)), weight=float(rng.choice([0.1, 1.0, 3.0])),
@@ -47,6 +49,12 @@ for it in range(N):
         cfg = str(rng.choice(["C2", "C3", "C4"]))
         seed = int(rng.integers(1 << 30)); eps = float(rng.choice([1e6, 2e2]))
         plan, leaf = synth.make_velocity_stack(cfg, B, seed=seed, eps_factor=eps); desc = (cfg, seed, eps)
+    if rng.integers(0, 3) == 0:       # a user regularisation task (AutoStack::setRegularisationTask)
+        rk = int(rng.choice([0, 6] if desc[0] == "C5" else [0, 3]))
+        rr = plan.n if rng.integers(0, 2) else int(rng.integers(1, plan.n + 1))
+        rw = float(rng.choice([1e-4, 1e-2, 1.0]))
+        synth.add_regularisation(plan, leaf, kind=rk, rows=rr, weight=rw, seed=int(rng.integers(1 << 30)))
+        desc = ("reg", rk, rr, rw) + desc
     asm = oracle.assemble(plan, leaf)
     st = BatchedStack(plan, B, device=0)
     st.update(st.load_leaf(leaf)); st.solve(B); torch.cuda.synchronize()
@@ -63,11 +71,16 @@ for it in range(N):
     e_ei = np.where(re_["status"] == 1, np.abs(dq - re_["dq"]).max(axis=1), np.inf)
     e = np.minimum(np.minimum(e_def, e_ex), e_ei)
     ok = np.isfinite(e)
+    # instances that ONLY qpOASES at its own (early-terminating, terminationTolerance 2.2e-7) options solves have no exact
+    # witness: it stops up to 3e-3 from the optimum with its constraints violated by ~1e-7 (checked on ('C4', 148545842,
+    # 200.0) instance 32: the product's point is feasible to 1e-15 there, qpOASES' is not); they are held to 3e-3
+    early_only = ok & ~np.isfinite(e_ex) & ~np.isfinite(e_ei)
+    e = np.where(early_only & (e < 3e-3), 0.0, e)
     counted += int(ok.sum()); total += B
     err = e[ok].max() if ok.any() else 0.0
     nfail = int((status[ok] != 0).sum())
     tol = 1e-6 if (len(desc) < 3 or desc[-1] == 1e6 or (isinstance(desc[-1], dict) and desc[-1].get("eps_factor", 1e6) == 1e6)) else 2e-5
-    if (nfail or err > tol) and not (desc[0] == "generic" and desc[-1].get("box") == 0.0 and desc[-1].get("eps_factor") == 200.0):
+    if (nfail or err > tol) and not ("generic" in desc[:5] and desc[-1].get("box") == 0.0 and desc[-1].get("eps_factor") == 200.0):
         bad += 1
         print("MISMATCH", desc, "failed", nfail, "of", int(ok.sum()), "max err %.3e" % err, "worst instance", int(np.argmax(np.where(ok, e, 0.0))), flush=True)
 print(f"{N} configurations x {B} instances in {time.time() - t0:.0f} s: {bad} with a mismatch ({counted} of {total} instances compared: distance to the closest of qpOASES at its own options, qpOASES run to the exact optimum, the eiQuadProg restatement)")
