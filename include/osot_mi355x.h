@@ -225,7 +225,8 @@ typedef struct {
 /* writable view of the assembled arrays that osot_stack_update fills (same shapes as osot_qp_batch) */
 typedef struct {
     double* b[OSOT_MAX_LEVELS];
-    double* w[OSOT_MAX_LEVELS];
+    double* w[OSOT_MAX_LEVELS];         /* NULL = leave the weights alone: for a DIAGONAL W_k with per-row entries
+                                           (Task::setWeight(W), Aggregated.cpp:265-279) fill osot_qp_batch.w[k] once */
     double* C;
     double* lo;
     double* up;

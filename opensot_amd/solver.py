@@ -118,7 +118,9 @@ class BatchedStack:
         return B
 
     # ---- AutoStack::update ------------------------------------------------------------------------
-    def update(self, dev_leaf):
+    def update(self, dev_leaf, write_weights=True):
+        """write_weights=False: the update leaves self.w alone (out.w[k] = NULL), for per-row DIAGONAL weight matrices
+        (Task::setWeight(W) with a diagonal W, Aggregated.cpp:265-279) that the caller filled once"""
         lb = abi.LeafBatch()
         lb.B = dev_leaf["B"]
         for k, lev in enumerate(dev_leaf["task"]):
@@ -131,7 +133,7 @@ class BatchedStack:
             lb.rows[j].p0, lb.rows[j].p1, lb.rows[j].p2 = _dev_ptr(p0), _dev_ptr(p1), _dev_ptr(p2)
         out = abi.AssembledOut()
         for k in range(self.plan.L):
-            out.b[k] = _dev_ptr(self.b[k]); out.w[k] = _dev_ptr(self.w[k])
+            out.b[k] = _dev_ptr(self.b[k]); out.w[k] = _dev_ptr(self.w[k]) if write_weights else None
         out.C, out.lo, out.up = _dev_ptr(self.C), _dev_ptr(self.lo), _dev_ptr(self.up)
         out.l, out.u = _dev_ptr(self.l), _dev_ptr(self.u)
         if self.b_reg is not None:

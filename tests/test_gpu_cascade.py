@@ -204,3 +204,34 @@ def test_task_local_constraint_rows_gpu(n, rows, local_level, n_local, oracle, g
         e = np.minimum(np.where(rq["status"] == 1, np.abs(dq - rq["dq"]).max(axis=1), np.inf),
                        np.where(rx["status"] == 1, np.abs(dq - rx["dq"]).max(axis=1), np.inf))[solvable]
         assert e.max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_diagonal_weight_matrices_gpu(oracle, gpu_device):
+    """Task::setWeight(W) with a diagonal W (per-row weights; tasks::Aggregated::generateWeight, Aggregated.cpp:265-279):
+    the caller fills w_k once and the update is told to leave it alone (out.w[k] = NULL)"""
+    B = 256
+    plan, leaf = synth.make_velocity_stack("C3", B, seed=21)
+    asm = oracle.assemble(plan, leaf)
+    rng = np.random.default_rng(4)
+    for k in range(plan.L):
+        asm["w"][k] = np.ascontiguousarray(np.broadcast_to(rng.uniform(0.2, 3.0, size=(1, plan.m(k))), (B, plan.m(k))))
+    st = BatchedStack(plan, B, device=0)
+    for k in range(plan.L):
+        st.w[k][:B].copy_(torch.as_tensor(asm["w"][k]))
+    st.update(st.load_leaf(leaf), write_weights=False); st.solve(B)
+    torch.cuda.synchronize()
+    for k in range(plan.L):
+        np.testing.assert_array_equal(st.w[k].cpu().numpy(), asm["w"][k])
+        np.testing.assert_allclose(st.b[k].cpu().numpy(), asm["b"][k], rtol=0, atol=1e-15)
+    dq = st.dq[:B].cpu().numpy()
+    assert (st.status[:B].cpu().numpy() == 0).all()
+    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+    okr = ref["status"] == 1
+    assert okr.mean() > 0.95 and np.abs(dq[okr] - ref["dq"][okr]).max() < 1e-9
+    if oracle.ref_available():
+        rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
+        rx = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1, termination_tolerance=10 * 2.221e-16)
+        e = np.minimum(np.where(rq["status"] == 1, np.abs(dq - rq["dq"]).max(axis=1), np.inf),
+                       np.where(rx["status"] == 1, np.abs(dq - rx["dq"]).max(axis=1), np.inf))
+        assert np.isfinite(e).mean() > 0.95 and e[np.isfinite(e)].max() < 1e-6
