@@ -323,6 +323,7 @@ int osot_qp_solve_batch(int B, int n, int nc, const double* H, const double* g, 
  * leaf layout, osot_leaf_ptrs).  The Jacobians are written STRAIGHT into their row range of the stacked A_k. */
 #define OSOT_KIN_MAX_JOINTS 64
 #define OSOT_KIN_MAX_FRAMES 8
+#define OSOT_KIN_MAX_PAIRS 32
 enum { OSOT_JOINT_REVOLUTE = 0, OSOT_JOINT_PRISMATIC = 1 };
 typedef struct {
     int n;                                   /* joints = generalised coordinates; tree order: parent[j] < j     */
@@ -337,6 +338,15 @@ typedef struct {
     int frame_joint[OSOT_KIN_MAX_FRAMES];    /* joint whose link carries frame f                                */
     double frame_R[OSOT_KIN_MAX_FRAMES][9];  /* frame f in that joint frame                                     */
     double frame_p[OSOT_KIN_MAX_FRAMES][3];
+    /* self-collision pairs: what velocity::CollisionAvoidance::update asks the (un-vendored) xbot2
+     * collision module for every cycle, computeDistance / getDistanceJacobian
+     * (src/constraints/velocity/CollisionAvoidance.cpp:96-118).  Each pair is two CAPSULES (segment + radius; a
+     * segment of zero length is a sphere), each rigidly attached to a link.  Output per pair: the distance d between
+     * the two surfaces and the row J_d with delta d = J_d dq, in the layout the OSOT_ROWS_COLLISION leaf expects. */
+    int n_pairs;
+    int pair_joint[OSOT_KIN_MAX_PAIRS][2];       /* joints whose links carry the two shapes                      */
+    double pair_seg[OSOT_KIN_MAX_PAIRS][2][6];   /* capsule axis end points (a0, a1) in that joint's frame       */
+    double pair_radius[OSOT_KIN_MAX_PAIRS][2];
 } osot_kin_desc;
 typedef struct {
     int B;
@@ -347,6 +357,10 @@ typedef struct {
     double* com;                                   /* [B][3] or NULL                                            */
     double* com_J;                                 /* first of the 3 rows in instance 0, or NULL                */
     long long com_J_stride;
+    double* pair_dist;                             /* [B][n_pairs] surface distances (negative: penetration), or NULL */
+    double* pair_J;                                /* first of the n_pairs rows J_d in instance 0, or NULL (the
+                                                      OSOT_ROWS_COLLISION leaf p0: [B][rows][n])                */
+    long long pair_J_stride;                       /* doubles from one instance to the next (rows * n)          */
 } osot_kin_batch;
 typedef struct osot_kin osot_kin;
 int osot_kin_create(const osot_kin_desc* desc, int device, osot_kin** out);

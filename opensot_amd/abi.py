@@ -78,7 +78,7 @@ class AssembledOut(C.Structure):
 
 
 # every symbol include/osot_mi355x.h declares (tests/test_abi_symbols.py checks the .so exports all)
-KIN_MAX_JOINTS, KIN_MAX_FRAMES = 64, 8
+KIN_MAX_JOINTS, KIN_MAX_FRAMES, KIN_MAX_PAIRS = 64, 8, 32
 JOINT_REVOLUTE, JOINT_PRISMATIC = 0, 1
 
 
@@ -88,13 +88,16 @@ class KinDesc(C.Structure):
                 ("p0", (C.c_double * 3) * KIN_MAX_JOINTS), ("mass", C.c_double * KIN_MAX_JOINTS),
                 ("com", (C.c_double * 3) * KIN_MAX_JOINTS), ("n_frames", C.c_int),
                 ("frame_joint", C.c_int * KIN_MAX_FRAMES), ("frame_R", (C.c_double * 9) * KIN_MAX_FRAMES),
-                ("frame_p", (C.c_double * 3) * KIN_MAX_FRAMES)]
+                ("frame_p", (C.c_double * 3) * KIN_MAX_FRAMES), ("n_pairs", C.c_int),
+                ("pair_joint", (C.c_int * 2) * KIN_MAX_PAIRS), ("pair_seg", ((C.c_double * 6) * 2) * KIN_MAX_PAIRS),
+                ("pair_radius", (C.c_double * 2) * KIN_MAX_PAIRS)]
 
 
 class KinBatch(C.Structure):
     _fields_ = [("B", C.c_int), ("q", C.c_void_p), ("frame_pose", C.c_void_p * KIN_MAX_FRAMES),
                 ("frame_J", C.c_void_p * KIN_MAX_FRAMES), ("frame_J_stride", C.c_longlong * KIN_MAX_FRAMES),
-                ("com", C.c_void_p), ("com_J", C.c_void_p), ("com_J_stride", C.c_longlong)]
+                ("com", C.c_void_p), ("com_J", C.c_void_p), ("com_J_stride", C.c_longlong),
+                ("pair_dist", C.c_void_p), ("pair_J", C.c_void_p), ("pair_J_stride", C.c_longlong)]
 
 
 SYMBOLS = [

@@ -10,6 +10,10 @@
 //      once: one coalesced 8 n-byte store per row, straight into the stacked A_k.
 //   4. centre of mass: c = sum m_l c_l / M (wave reduction); column j of its Jacobian from the subtree aggregates
 //      (mass and first moment of the links joint j moves): z_j x (Sc_j - Sm_j p_j) / M  (prismatic: (Sm_j / M) z_j)
+//   5. self-collision pairs (capsule / sphere pairs): lane p = pair for the closest points of the two axis segments
+//      (world frame) -> distance d = |c_a - c_b| - r_a - r_b and unit normal n -> LDS; then one coalesced row per
+//      pair, lane j = joint: J_d[j] = n . (v_j(c_a) [j moves a] - v_j(c_b) [j moves b]),  v_j(c) = z_j x (c - p_j)
+//      (revolute) or z_j (prismatic).  (A point of the capsule SURFACE, c - r n, has the same velocity along n.)
 // HBM-bound by construction: reads 8 n bytes of q, writes (6 F + 3) n 8 + 96 F + 24 bytes per instance.
 #pragma once
 #include <osot_team.h>
@@ -38,6 +42,36 @@ __device__ __forceinline__ void cross3(const double* a, const double* b, double*
     o[0] = a[1] * b[2] - a[2] * b[1];
     o[1] = a[2] * b[0] - a[0] * b[2];
     o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+__device__ __forceinline__ double clamp01(double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }
+// closest points of the segments [p1, q1] and [p2, q2] (either may have zero length): parameters s, t in [0, 1]
+__device__ inline void closest_segment_points(const double* p1, const double* q1, const double* p2, const double* q2,
+                                              double* c1, double* c2) {
+    const double tiny = 1.0e-18;
+    double d1[3], d2[3], r[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { d1[i] = q1[i] - p1[i]; d2[i] = q2[i] - p2[i]; r[i] = p1[i] - p2[i]; }
+    const double a = d1[0] * d1[0] + d1[1] * d1[1] + d1[2] * d1[2];
+    const double e = d2[0] * d2[0] + d2[1] * d2[1] + d2[2] * d2[2];
+    const double f = d2[0] * r[0] + d2[1] * r[1] + d2[2] * r[2];
+    const double c = d1[0] * r[0] + d1[1] * r[1] + d1[2] * r[2];
+    double s = 0.0, t = 0.0;
+    if (a <= tiny && e <= tiny) {
+    } else if (a <= tiny) {
+        t = clamp01(f / e);
+    } else if (e <= tiny) {
+        s = clamp01(-c / a);
+    } else {
+        const double b = d1[0] * d2[0] + d1[1] * d2[1] + d1[2] * d2[2];
+        const double den = a * e - b * b;            // >= 0; 0 for parallel axes: any s, take 0
+        s = (den > tiny * a * e) ? clamp01((b * f - c * e) / den) : 0.0;
+        t = (b * s + f) / e;
+        if (t < 0.0) { t = 0.0; s = clamp01(-c / a); }
+        else if (t > 1.0) { t = 1.0; s = clamp01((b - c) / a); }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { c1[i] = p1[i] + s * d1[i]; c2[i] = p2[i] + t * d2[i]; }
 }
 
 __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__ K, const osot_kin_batch Bt) {
@@ -208,6 +242,59 @@ __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__
                 double* J = Bt.com_J + inst * Bt.com_J_stride;
 #pragma unroll
                 for (int r = 0; r < 3; ++r) J[r * n + j] = acc[r] / M;
+            }
+        }
+    }
+    // ---- 5. self-collision pairs
+    const int np = K->d.n_pairs;
+    if (np > 0 && (Bt.pair_dist || Bt.pair_J)) {
+        OSOT_STATIC_LDS(double, Pw, OSOT_KIN_MAX_PAIRS * 9);   // per pair: normal n, axis points c_a, c_b (world)
+        if (j < np) {
+            double e[2][6];
+#pragma unroll
+            for (int sd = 0; sd < 2; ++sd) {
+                const int js = K->d.pair_joint[j][sd];
+                double Rj[9], pj[3];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) Rj[i] = Tw[js * TS + i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) pj[i] = Tw[js * TS + 9 + i];
+                double t0[3], t1[3];
+                mat3_vec(Rj, &K->d.pair_seg[j][sd][0], t0);
+                mat3_vec(Rj, &K->d.pair_seg[j][sd][3], t1);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { e[sd][i] = t0[i] + pj[i]; e[sd][3 + i] = t1[i] + pj[i]; }
+            }
+            double ca[3], cb[3];
+            closest_segment_points(&e[0][0], &e[0][3], &e[1][0], &e[1][3], ca, cb);
+            const double dv[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
+            const double len = sqrt(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+            const bool deg = !(len > 1.0e-12);      // coincident axis points: no direction; the row is zero
+            const double il = deg ? 0.0 : 1.0 / len;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { Pw[j * 9 + i] = dv[i] * il; Pw[j * 9 + 3 + i] = ca[i]; Pw[j * 9 + 6 + i] = cb[i]; }
+            if (Bt.pair_dist) Bt.pair_dist[inst * np + j] = len - K->d.pair_radius[j][0] - K->d.pair_radius[j][1];
+        }
+        wave_sync();
+        if (Bt.pair_J) {
+            double* J = Bt.pair_J + inst * Bt.pair_J_stride;
+            for (int p = 0; p < np; ++p) {
+                const int ja = K->d.pair_joint[p][0], jb = K->d.pair_joint[p][1];
+                const double sa = ((Anc[ja] >> j) & 1ull) ? 1.0 : 0.0, sb = ((Anc[jb] >> j) & 1ull) ? 1.0 : 0.0;
+                const double nn[3] = {Pw[p * 9], Pw[p * 9 + 1], Pw[p * 9 + 2]};
+                double val;
+                if (revolute) {
+                    // n . (z x (c_a - p_j)) sa - n . (z x (c_b - p_j)) sb = n . (z x (sa (c_a - p_j) - sb (c_b - p_j)))
+                    const double dl[3] = {sa * (Pw[p * 9 + 3] - pw[0]) - sb * (Pw[p * 9 + 6] - pw[0]),
+                                          sa * (Pw[p * 9 + 4] - pw[1]) - sb * (Pw[p * 9 + 7] - pw[1]),
+                                          sa * (Pw[p * 9 + 5] - pw[2]) - sb * (Pw[p * 9 + 8] - pw[2])};
+                    double cr[3];
+                    cross3(zj, dl, cr);
+                    val = nn[0] * cr[0] + nn[1] * cr[1] + nn[2] * cr[2];
+                } else {
+                    val = (sa - sb) * (nn[0] * zj[0] + nn[1] * zj[1] + nn[2] * zj[2]);
+                }
+                if (valid) J[p * n + j] = val;
             }
         }
     }

@@ -550,6 +550,12 @@ int osot_kin_create(const osot_kin_desc* d, int device, osot_kin** out) {
     }
     for (int f = 0; f < d->n_frames; ++f)
         if (d->frame_joint[f] < 0 || d->frame_joint[f] >= d->n) return fail(OSOT_ERR_INVALID, "frame attached to a joint out of range");
+    if (d->n_pairs < 0 || d->n_pairs > OSOT_KIN_MAX_PAIRS) return fail(OSOT_ERR_INVALID, "collision pair count out of range");
+    for (int p = 0; p < d->n_pairs; ++p) {
+        for (int sd = 0; sd < 2; ++sd)
+            if (d->pair_joint[p][sd] < 0 || d->pair_joint[p][sd] >= d->n) return fail(OSOT_ERR_INVALID, "collision shape attached to a joint out of range");
+        if (!(d->pair_radius[p][0] >= 0.0) || !(d->pair_radius[p][1] >= 0.0)) return fail(OSOT_ERR_INVALID, "negative capsule radius");
+    }
     if (!(h.total_mass > 0.0)) h.total_mass = 1.0;
     HIP_TRY(hipSetDevice(device));
     osot_kin* k = new osot_kin();

@@ -37,6 +37,12 @@ constexpr double kDepTol2 = 1.0e-24;   // |d2|^2 <= kDepTol2 |d|^2  -> normal is
                                        // |d|^2 is dominated by the 1/eps-scaled directions (6e10 at the default eps), the
                                        // round-off floor of |d2|^2 is ~1e-29 |d|^2, and a genuine last free direction was seen
                                        // at 6e-19 |d|^2 (tests/stress_parity.py): 1e-18 called it dependent -> false INFEASIBLE
+constexpr double kDepFloor2 = 1.0e-19; // second test, only when |d2|^2 <= 1e-16 |d|^2: |d2|^2 <= kDepFloor2 |n|^2 |J2|_F^2 -> dependent.
+                                       // d2 = J2'n is computed from a J that has been through up to n Householder updates: its
+                                       // round-off floor is relative to |n| |J2|, not to |d|.  Seen on hardware (closed-loop
+                                       // self-collision test, 31 of 32 directions taken, a bound violated by 4e-11): |d2|^2 =
+                                       // 9e-23 |d|^2 = 3e-23 |n|^2 |J2|^2, pure noise, accepted as a direction -> x jumped by 26
+                                       // -> false INFEASIBLE; the genuine direction quoted above sits at ~1e-8 on this scale
 constexpr double kViolTol = 1.0e-11;   // a slack below -kViolTol*max(1,|bound|) counts as violated
 constexpr double kEqTol = 1.0e-9;      // consistency of a linearly dependent equality row
 constexpr double kSlackTol = 1.0e-6;   // a violation below this (relative) with no direction left is round-off: with the
@@ -658,6 +664,22 @@ __device__ inline int nullspace_equalities32(const WaveCtx<32>& w, int n_eq, dou
     return me;
 }
 
+// Is the part d2 = J2'n of a constraint normal outside the span of the working set a DIRECTION or round-off?
+// nd2 = |d2|^2, dd = |d|^2 (both uniform); nv = this lane's entry of the normal n.  See kDepTol2 / kDepFloor2.
+template <int NP>
+__device__ inline bool direction_is_independent(const WaveCtx<NP>& w, double nd2, double dd, double nv, int iq) {
+    if (nd2 > 1.0e-16 * dd) return true;           // the usual case: one compare
+    if (!(nd2 > kDepTol2 * dd)) return false;
+    constexpr int S = WaveCtx<NP>::S;
+    const int c = w.c, n = w.n;
+    double cn = 0.0;                                // |J[:, c]|^2 of my column, if it is a free one
+    if (c >= iq && c < n)
+        for (int i = 0; i < n; ++i) { const double v = w.M2[c * S + i]; cn = fma(v, v, cn); }
+    double nn;
+    colsum2<NP>(cn, nv * nv, cn, nn);
+    return nd2 > kDepFloor2 * nn * cn;
+}
+
 template <int NP, bool PROF>
 __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq, const int me, int Aq, double uq,
                                int iters, bool has_box, double lb, double ub, int max_iter, bool diag_dd, double hinv,
@@ -930,7 +952,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
         colsum2<NP>(d * d, d2 * d2, dd, nd2);
         const double resid = lo + colsum<NP>(a * (xref - x));
         OSOT_SUB_END(PH_EQ_RED);
-        if (!(nd2 > kDepTol2 * dd)) {   // row is (numerically) a combination of the rows already in
+        if (!direction_is_independent<NP>(w, nd2, dd, a, iq)) {   // row is (numerically) a combination of the rows already in
             // an optimality row of an upper level (src >= 0) is consistent BY CONSTRUCTION (x of that level
             // satisfies all of them, iHQP.cpp:164-170): a residual there is round-off of an ill-conditioned level
             // (default eps 4.4e-11: O(1e-16 / eps)), never infeasibility
@@ -1132,7 +1154,8 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
             } else {
                 colsum2<NP>(d * d, d2 * d2, dd, nd2);
             }
-            const bool z_ok = nd2 > kDepTol2 * dd;
+            const bool z_ok = direction_is_independent<NP>(w, nd2, dd,
+                                                           ip_box ? ((c == ip_var) ? 1.0 : 0.0) : (ip_unit ? ((c == ip_uidx) ? 1.0 : 0.0) : np), iq);
             OSOT_SUB_END(PH_IN_D);
             // z = J2 d2 : primal step direction
             if (h == 0) V1[c] = d2;

@@ -21,6 +21,9 @@ class KinModel:
     com: np.ndarray             # [n][3]
     names: list = field(default_factory=list)
     frames: list = field(default_factory=list)     # (name, joint index, R[3][3], p[3])
+    # self-collision pairs: (joint a, a0[3], a1[3], radius a, joint b, b0[3], b1[3], radius b): two capsules (axis end
+    # points in the joint frames; a0 == a1: a sphere)
+    pairs: list = field(default_factory=list)
 
     @property
     def n(self):
@@ -45,6 +48,13 @@ class KinModel:
                 d.frame_R[f][i] = float(np.asarray(R).reshape(9)[i])
             for i in range(3):
                 d.frame_p[f][i] = float(p[i])
+        d.n_pairs = len(self.pairs)
+        for k, (ja, a0, a1, ra, jb, b0, b1, rb) in enumerate(self.pairs):
+            d.pair_joint[k][0], d.pair_joint[k][1] = int(ja), int(jb)
+            d.pair_radius[k][0], d.pair_radius[k][1] = float(ra), float(rb)
+            for i in range(3):
+                d.pair_seg[k][0][i], d.pair_seg[k][0][3 + i] = float(a0[i]), float(a1[i])
+                d.pair_seg[k][1][i], d.pair_seg[k][1][3 + i] = float(b0[i]), float(b1[i])
         return d
 
 
@@ -98,6 +108,25 @@ def humanoid32():
     return m
 
 
+def humanoid32_pairs(m):
+    """capsules on the forearms, hands, torso, pelvis and thighs of humanoid32() and the pairs a self-collision
+    constraint would watch (hands / forearms against torso, pelvis, thighs and each other)"""
+    nm = m.names.index
+    shape = {"torso": (nm("WaistYaw"), (0, 0, 0.05), (0, 0, 0.22), 0.10), "pelvis": (nm("base_yaw"), (0, -0.05, 0.0), (0, 0.05, 0.0), 0.09),
+             "head": (nm("NeckYaw"), (0, 0, 0.10), (0, 0, 0.10), 0.09)}
+    for s in "LR":
+        shape[s + "forearm"] = (nm(s + "Elbj"), (0, 0, -0.02), (0, 0, -0.15), 0.035)
+        shape[s + "hand"] = (nm(s + "Wrj"), (0, 0, -0.06), (0, 0, -0.06), 0.045)
+        shape[s + "thigh"] = (nm(s + "HipYaw"), (0, 0, 0.0), (0, 0, -0.12), 0.055)
+        shape[s + "shin"] = (nm(s + "KneeSag"), (0, 0, -0.02), (0, 0, -0.19), 0.045)
+    names = [("Lhand", "torso"), ("Rhand", "torso"), ("Lforearm", "torso"), ("Rforearm", "torso"), ("Lhand", "pelvis"),
+             ("Rhand", "pelvis"), ("Lhand", "Lthigh"), ("Rhand", "Rthigh"), ("Lhand", "Rhand"), ("Lforearm", "Rforearm"),
+             ("Lhand", "Rforearm"), ("Rhand", "Lforearm"), ("Lhand", "head"), ("Rhand", "head"), ("Lshin", "Rshin"), ("Lthigh", "Rthigh")]
+    m.pairs = [shape[a] + shape[b] for a, b in names]
+    m.pair_names = names
+    return m
+
+
 def from_json(path):
     """a tree fixture as written by tests/golden/make_coman_tree.py (the reference's COMAN, 6 virtual + 29 revolute
     joints): returns (KinModel, lower[n], upper[n]) -- the limits are +-inf for the virtual joints."""
@@ -137,7 +166,7 @@ class Kinematics:
         except Exception:
             pass
 
-    def forward(self, q, frame_pose=None, frame_J=None, com=None, com_J=None):
+    def forward(self, q, frame_pose=None, frame_J=None, com=None, com_J=None, pair_dist=None, pair_J=None):
         """q [B][n] (device).  frame_pose: {frame index: tensor [B][12]}; frame_J: {frame index: (A_k tensor [B][ma][n],
         first row)}; com: tensor [B][3]; com_J: (A_k tensor, first row).  Stream-ordered on torch's current stream."""
         B, n = q.shape
@@ -159,5 +188,13 @@ class Kinematics:
             assert A.is_contiguous() and A.shape[2] == n and row + 3 <= A.shape[1]
             kb.com_J = A.data_ptr() + 8 * row * n
             kb.com_J_stride = A.shape[1] * n
+        if pair_dist is not None:      # [B][n_pairs]: the OSOT_ROWS_COLLISION leaf p1
+            assert pair_dist.is_contiguous() and pair_dist.shape[1] == len(self.model.pairs)
+            kb.pair_dist = pair_dist.data_ptr()
+        if pair_J is not None:         # (tensor [B][rows][n], first row): the OSOT_ROWS_COLLISION leaf p0
+            A, row = pair_J
+            assert A.is_contiguous() and A.shape[2] == n and row + len(self.model.pairs) <= A.shape[1]
+            kb.pair_J = A.data_ptr() + 8 * row * n
+            kb.pair_J_stride = A.shape[1] * n
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         abi.check(self._lib.osot_kinematics(self._h, C.byref(kb), stream), "osot_kinematics")

@@ -56,3 +56,56 @@ def forward(model, q):
                 Jc[:, j] += model.mass[l] * z[j]
     out["Jcom"] = Jc / M
     return out
+
+
+def closest_segment_points(p1, q1, p2, q2):
+    """closest points of two segments (either may be a point): the standard clamped two-parameter minimisation"""
+    d1, d2, r = q1 - p1, q2 - p2, p1 - p2
+    a, e, f, c = d1 @ d1, d2 @ d2, d2 @ r, d1 @ r
+    tiny = 1e-18
+    cl = lambda v: min(1.0, max(0.0, v))
+    s = t = 0.0
+    if a <= tiny and e <= tiny:
+        pass
+    elif a <= tiny:
+        t = cl(f / e)
+    elif e <= tiny:
+        s = cl(-c / a)
+    else:
+        b = d1 @ d2
+        den = a * e - b * b
+        s = cl((b * f - c * e) / den) if den > tiny * a * e else 0.0
+        t = (b * s + f) / e
+        if t < 0.0:
+            t, s = 0.0, cl(-c / a)
+        elif t > 1.0:
+            t, s = 1.0, cl((b - c) / a)
+    return p1 + s * d1, p2 + t * d2
+
+
+def pair_distances(model, q, fk=None):
+    """self-collision pairs (what CollisionAvoidance.cpp:96-118 obtains from the collision module): surface distances
+    d[P] of the capsule pairs and the rows J_d[P][n] with delta d = J_d dq"""
+    fk = forward(model, q) if fk is None else fk
+    n = model.n
+    Rw, pw = fk["Rw"], fk["pw"]
+    z = np.einsum("jab,jb->ja", Rw, model.axis)
+    anc = []
+    for j in range(n):
+        anc.append({j} | (anc[model.parent[j]] if model.parent[j] >= 0 else set()))
+    d = np.zeros(len(model.pairs)); J = np.zeros((len(model.pairs), n))
+    for k, (ja, a0, a1, ra, jb, b0, b1, rb) in enumerate(model.pairs):
+        wa0, wa1 = Rw[ja] @ np.asarray(a0, float) + pw[ja], Rw[ja] @ np.asarray(a1, float) + pw[ja]
+        wb0, wb1 = Rw[jb] @ np.asarray(b0, float) + pw[jb], Rw[jb] @ np.asarray(b1, float) + pw[jb]
+        ca, cb = closest_segment_points(wa0, wa1, wb0, wb1)
+        dv = ca - cb
+        ln = np.linalg.norm(dv)
+        d[k] = ln - ra - rb
+        if not ln > 1e-12:
+            continue
+        nn = dv / ln
+        for j in range(n):
+            va = (np.cross(z[j], ca - pw[j]) if model.jtype[j] == 0 else z[j]) if j in anc[ja] else np.zeros(3)
+            vb = (np.cross(z[j], cb - pw[j]) if model.jtype[j] == 0 else z[j]) if j in anc[jb] else np.zeros(3)
+            J[k, j] = nn @ (va - vb)
+    return d, J

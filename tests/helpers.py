@@ -185,5 +185,11 @@ def emu_kinematics(model, q):
     kb.com = com.ctypes.data
     kb.com_J = J.ctypes.data + 8 * 6 * F * n
     kb.com_J_stride = (6 * F + 3) * n
+    P = len(getattr(model, "pairs", []))
+    if P:
+        pd = np.zeros((B, P)); pJ = np.full((B, P + 1, n), 7.0)
+        kb.pair_dist = pd.ctypes.data; kb.pair_J = pJ.ctypes.data; kb.pair_J_stride = (P + 1) * n
     assert L.emu_kinematics(C.byref(d), C.byref(kb)) == 0
+    if P:
+        return poses, J, com, pd, pJ
     return poses, J, com

@@ -37,6 +37,45 @@ def test_restatement_matches_finite_differences():
         assert np.abs(Jc - o["Jcom"]).max() < 1e-8
 
 
+def test_pair_distances_match_finite_differences():
+    """self-collision pairs (what CollisionAvoidance.cpp:96-118 obtains from the collision module): the
+    distance rows J_d of the restatement against central differences of its own distances; capsule-capsule,
+    capsule-sphere and sphere-sphere pairs of the 32-DoF humanoid"""
+    m = kin.humanoid32_pairs(kin.humanoid32())
+    assert len(m.pairs) == 16
+    rng = np.random.default_rng(12)
+    h = 1e-6
+    for _ in range(4):
+        q = rng.uniform(-0.7, 0.7, m.n)
+        d, J = pykin.pair_distances(m, q)
+        Jfd = np.zeros_like(J)
+        for j in range(m.n):
+            e = np.zeros(m.n); e[j] = h
+            Jfd[:, j] = (pykin.pair_distances(m, q + e)[0] - pykin.pair_distances(m, q - e)[0]) / (2 * h)
+        assert np.abs(J - Jfd).max() < 5e-8
+        assert np.abs(J[:, :3]).max() < 1e-12          # a rigid translation of the base changes no distance
+    # known answers: two spheres, and two parallel capsules (degenerate closest pair: any point of the overlap)
+    ca, cb = pykin.closest_segment_points(np.array([0.0, 0, 0]), np.array([0.0, 0, 0]), np.array([3.0, 4, 0]), np.array([3.0, 4, 0]))
+    assert np.linalg.norm(ca - cb) == 5.0
+    ca, cb = pykin.closest_segment_points(np.array([0.0, 0, 0]), np.array([1.0, 0, 0]), np.array([0.5, 2, 0]), np.array([3.0, 2, 0]))
+    assert abs(np.linalg.norm(ca - cb) - 2.0) < 1e-15
+    ca, cb = pykin.closest_segment_points(np.array([0.0, 0, 0]), np.array([1.0, 0, 0]), np.array([2.0, 1, 0]), np.array([2.0, 3, 0]))
+    assert np.allclose(ca, [1, 0, 0]) and np.allclose(cb, [2, 1, 0])
+
+
+def test_emulated_pair_distances_match_restatement():
+    from helpers import emu_kinematics
+    m = kin.humanoid32_pairs(kin.humanoid32())
+    rng = np.random.default_rng(8)
+    q = rng.uniform(-1.0, 1.0, (6, m.n))
+    poses, J, com, pd, pJ = emu_kinematics(m, q)
+    P = len(m.pairs)
+    for i in range(6):
+        d, Jd = pykin.pair_distances(m, q[i])
+        assert np.abs(pd[i] - d).max() < 1e-14 and np.abs(pJ[i, :P] - Jd).max() < 1e-13
+    assert (pJ[:, P] == 7.0).all()
+
+
 def _coman():
     import os
     return kin.from_json(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "coman_tree.json"))
@@ -255,3 +294,93 @@ def test_closed_loop_ik_coman35(gpu_device):
     assert float((com_d - com).norm(dim=1).max()) < 2e-3                                      # and so did the CoM
     o = pykin.forward(m, qh[5])
     assert np.abs(pose[1][5].cpu().numpy()[9:] - o["frame_p"][1]).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_pair_distances_kernel_matches_restatement(gpu_device):
+    import torch
+    m = kin.humanoid32_pairs(kin.humanoid32())
+    K = kin.Kinematics(m, device=0)
+    B, P = 300, len(m.pairs)
+    rng = np.random.default_rng(15)
+    q = rng.uniform(-1.0, 1.0, (B, m.n))
+    dev = torch.device("cuda", 0)
+    tq = torch.as_tensor(q, device=dev)
+    Jd = torch.full((B, P + 2, m.n), 7.0, dtype=torch.float64, device=dev)
+    dist = torch.zeros((B, P), dtype=torch.float64, device=dev)
+    K.forward(tq, pair_dist=dist, pair_J=(Jd, 1))
+    torch.cuda.synchronize()
+    Jh, dh = Jd.cpu().numpy(), dist.cpu().numpy()
+    for i in range(0, B, 13):
+        d, J = pykin.pair_distances(m, q[i])
+        assert np.abs(dh[i] - d).max() < 1e-14 and np.abs(Jh[i, 1:P + 1] - J).max() < 1e-13
+    assert (Jh[:, 0] == 7.0).all() and (Jh[:, P + 1] == 7.0).all()
+
+
+@pytest.mark.gpu
+def test_closed_loop_self_collision_avoidance_on_device(gpu_device):
+    """SURVEY 8f-3 end to end: q -> capsule-pair distances and rows J_d (osot_kinematics) -> CollisionAvoidance rows
+    (osot_stack_update, CollisionAvoidance.cpp:119-147) -> dq (osot_ihqp_solve) -> q += dq.  Both hands are sent to the
+    SAME point: without the constraint they end up inside each other, with it every pair stops at the threshold."""
+    import torch
+    from opensot_amd.plan import Rows, subtask
+    from opensot_amd.solver import BatchedStack
+    m = kin.humanoid32_pairs(kin.humanoid32())
+    n, B, P = m.n, 64, len(m.pairs)
+    dev = torch.device("cuda", 0)
+    f64 = dict(dtype=torch.float64, device=dev)
+    rng = np.random.default_rng(2)
+    q0 = np.zeros((B, n))
+    q0[:, [m.names.index(s + "Elbj") for s in "RL"]] = -0.9
+    q0[:, m.names.index("RShLat")] = -0.35; q0[:, m.names.index("LShLat")] = 0.35
+    q0 += rng.normal(0.0, 0.01, (B, n))
+    d_min = 0.02
+
+    def run(with_constraint):
+        wrist = lambda nm: subtask(Task(abi.TASK_CARTESIAN, 6, lam=0.1, name=nm), [0, 1, 2])      # position only
+        levels = [[Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="l_sole"), Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="r_sole")],
+                  [wrist("l_wrist"), wrist("r_wrist")],
+                  [Task(abi.TASK_POSTURAL, n, lam=0.01, name="postural")]]
+        bounds = [Bound(abi.BOUND_VELOCITY_LIMITS, dT=0.01, name="vl")]
+        rows = [Rows(abi.ROWS_COLLISION, P, d_threshold=d_min, detection_threshold=0.0, bound_scaling=0.2, name="self_collision")] if with_constraint else []
+        plan = StackPlan(n=n, levels=levels, bounds=bounds, rowblocks=rows, eps_abs=eps_abs_from_factor(1e6))
+        st = BatchedStack(plan, B, device=0, want_levels=False)
+        K = kin.Kinematics(m, device=0)
+        q = torch.as_tensor(q0, **f64).contiguous()
+        pose = [torch.zeros((B, 12), **f64) for _ in range(4)]
+        Jd = torch.zeros((B, P, n), **f64); dist = torch.zeros((B, P), **f64)
+        Jw = torch.zeros((B, 12, n), **f64)
+
+        def fk():
+            K.forward(q, frame_pose={f: pose[f] for f in range(4)}, frame_J={2: (st.A[0], 0), 3: (st.A[0], 6), 0: (Jw, 0), 1: (Jw, 6)},
+                      pair_dist=dist, pair_J=(Jd, 0))
+            st.A[1][:B, 0:3].copy_(Jw[:, 0:3]); st.A[1][:B, 3:6].copy_(Jw[:, 6:9])    # the sub-tasks keep the linear rows
+        fk(); torch.cuda.synchronize()
+        pose_d = [p.clone() for p in pose]
+        mid = 0.5 * (pose[0][:, 9:] + pose[1][:, 9:])
+        pose_d[0][:, 9:] = mid; pose_d[1][:, 9:] = mid
+        q_ref = q.clone()
+        qdot_max = torch.full((B, n), 2.0, **f64)
+        leaf = {"B": B, "task": [[(pose[2], pose_d[2], None), (pose[3], pose_d[3], None)],
+                                 [(pose[0], pose_d[0], None), (pose[1], pose_d[1], None)], [(q, q_ref, None)]],
+                "bound": [(qdot_max, None, None)], "rows": [(Jd, dist, None)] if with_constraint else []}
+        dmin_seen = np.inf
+        for cycle in range(400):
+            fk()
+            st.update(leaf); st.solve(B)
+            q += st.dq[:B]
+            if cycle % 20 == 0:
+                torch.cuda.synchronize()
+                assert (st.status[:B] == 0).all()
+                dmin_seen = min(dmin_seen, float(dist.min()))
+        fk(); torch.cuda.synchronize()
+        gap = float((pose[0][:, 9:] - pose[1][:, 9:]).norm(dim=1).max())
+        return float(dist.min()), dmin_seen, dist.cpu().numpy(), q.cpu().numpy(), gap
+
+    free_end, free_seen, _, _, free_gap = run(False)
+    safe_end, safe_seen, dist, q, safe_gap = run(True)
+    assert free_gap < 5e-3 and free_end < -0.05           # unconstrained: the wrists meet, the hand spheres overlap
+    assert safe_end > d_min - 2e-3 and safe_seen > d_min - 2e-3     # constrained: every pair stays at the threshold (first-order rows)
+    assert safe_gap > 0.05                                # ... so the wrists cannot meet
+    d, _ = pykin.pair_distances(m, q[5])
+    assert np.abs(d - dist[5]).max() < 1e-12
