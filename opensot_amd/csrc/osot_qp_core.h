@@ -37,12 +37,16 @@ constexpr double kDepTol2 = 1.0e-24;   // |d2|^2 <= kDepTol2 |d|^2  -> normal is
                                        // |d|^2 is dominated by the 1/eps-scaled directions (6e10 at the default eps), the
                                        // round-off floor of |d2|^2 is ~1e-29 |d|^2, and a genuine last free direction was seen
                                        // at 6e-19 |d|^2 (tests/stress_parity.py): 1e-18 called it dependent -> false INFEASIBLE
-constexpr double kDepFloor2 = 1.0e-19; // second test, only when |d2|^2 <= 1e-16 |d|^2: |d2|^2 <= kDepFloor2 |n|^2 |J2|_F^2 -> dependent.
-                                       // d2 = J2'n is computed from a J that has been through up to n Householder updates: its
-                                       // round-off floor is relative to |n| |J2|, not to |d|.  Seen on hardware (closed-loop
-                                       // self-collision test, 31 of 32 directions taken, a bound violated by 4e-11): |d2|^2 =
-                                       // 9e-23 |d|^2 = 3e-23 |n|^2 |J2|^2, pure noise, accepted as a direction -> x jumped by 26
-                                       // -> false INFEASIBLE; the genuine direction quoted above sits at ~1e-8 on this scale
+constexpr double kDepFloor2 = 1.0e-13; // second test, only when |d2|^2 <= 1e-12 |d|^2: |d2|^2 <= kDepFloor2 |n|^2 |J2|_F^2 -> dependent.
+                                       // |d2| / (|n| |J2|) is (about) the sine of the angle between the normal and the span of
+                                       // the working set.  A row at 1e-8 .. 1e-12 of that span is a direction on paper, but
+                                       // taking it puts |d2| on the diagonal of R (condition 1e8+: the dual directions r lose
+                                       // their signs) and moves x by violation / |d2|.  Seen on hardware (closed-loop
+                                       // self-collision tests, H ~ I): sine^2 = 3e-23 with a bound violated by 4e-11 -> x jumped
+                                       // by 26; sine^2 = 1.5e-17 with 1e-7 -> by 14; both ended as false INFEASIBLE.  The genuine
+                                       // last direction quoted above sits at 9.4e-9 on this scale.  tests/stress_closed_loop.py,
+                                       // product-only failures in 921 k closed-loop solves at eps factor 1e6: 346 with 1e-19,
+                                       // 0 with 1e-16, 0 with 1e-13; at the default eps (307 k solves): 671 / 846 / 318
 constexpr double kViolTol = 1.0e-11;   // a slack below -kViolTol*max(1,|bound|) counts as violated
 constexpr double kEqTol = 1.0e-9;      // consistency of a linearly dependent equality row
 constexpr double kSlackTol = 1.0e-6;   // a violation below this (relative) with no direction left is round-off: with the
@@ -668,7 +672,7 @@ __device__ inline int nullspace_equalities32(const WaveCtx<32>& w, int n_eq, dou
 // nd2 = |d2|^2, dd = |d|^2 (both uniform); nv = this lane's entry of the normal n.  See kDepTol2 / kDepFloor2.
 template <int NP>
 __device__ inline bool direction_is_independent(const WaveCtx<NP>& w, double nd2, double dd, double nv, int iq) {
-    if (nd2 > 1.0e-16 * dd) return true;           // the usual case: one compare
+    if (nd2 > 1.0e-12 * dd) return true;           // the usual case: one compare
     if (!(nd2 > kDepTol2 * dd)) return false;
     constexpr int S = WaveCtx<NP>::S;
     const int c = w.c, n = w.n;

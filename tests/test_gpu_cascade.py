@@ -262,7 +262,7 @@ def test_noise_is_not_a_direction_gpu(oracle, gpu_device):
     """found by the closed-loop self-collision test on hardware: at the Postural level, 29 of 32 directions taken, a
     bound violated by 4e-11 whose normal had |d2|^2 = 9e-23 |d|^2 left outside the working set -- round-off of a J that
     had been through 29 updates, not a direction.  Taken as one, x jumped by 26 and the level ended INFEASIBLE while
-    qpOASES and the eiQuadProg restatement solve it (kDepFloor2 in osot_qp_core.h)."""
+    qpOASES and the eiQuadProg restatement solve it (kDepFloor2 in osot_qp_core.h; tests/stress_closed_loop.py is the sweep that chose its value)."""
     plan, asm = _collision_last_direction_instance()
     st = BatchedStack(plan, 1, device=0)
     st.load_assembled(asm); st.solve(1)
