@@ -106,8 +106,8 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
     wave_sync();
 
     const bool has_box = D.l != nullptr;
-    const double lb = (has_box && valid) ? D.l[inst * n + c] : -INFINITY;
-    const double ub = (has_box && valid) ? D.u[inst * n + c] : INFINITY;
+    double lb = (has_box && valid) ? D.l[inst * n + c] : -INFINITY;   // (a level may relax a bound it accepted as satisfied)
+    double ub = (has_box && valid) ? D.u[inst * n + c] : INFINITY;
 
     // global rows: bounds and row addresses, lane = row
     for (int j = 0; j < P.nblocks; ++j) {
@@ -474,8 +474,8 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
     wave_sync();
     const double g = valid ? Q.g[inst * n + c] : 0.0;
     const bool has_box = Q.l != nullptr;
-    const double lb = (has_box && valid) ? Q.l[inst * n + c] : -INFINITY;
-    const double ub = (has_box && valid) ? Q.u[inst * n + c] : INFINITY;
+    double lb = (has_box && valid) ? Q.l[inst * n + c] : -INFINITY;
+    double ub = (has_box && valid) ? Q.u[inst * n + c] : INFINITY;
     for (int r = lane; r < Q.nc; r += 64) {
         w.rlo[r] = clamp_inf(Q.lA[inst * Q.nc + r]);
         w.rup[r] = clamp_inf(Q.uA[inst * Q.nc + r]);

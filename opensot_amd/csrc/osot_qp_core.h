@@ -37,16 +37,17 @@ constexpr double kDepTol2 = 1.0e-24;   // |d2|^2 <= kDepTol2 |d|^2  -> normal is
                                        // |d|^2 is dominated by the 1/eps-scaled directions (6e10 at the default eps), the
                                        // round-off floor of |d2|^2 is ~1e-29 |d|^2, and a genuine last free direction was seen
                                        // at 6e-19 |d|^2 (tests/stress_parity.py): 1e-18 called it dependent -> false INFEASIBLE
-constexpr double kDepFloor2 = 1.0e-13; // second test, only when |d2|^2 <= 1e-12 |d|^2: |d2|^2 <= kDepFloor2 |n|^2 |J2|_F^2 -> dependent.
-                                       // |d2| / (|n| |J2|) is (about) the sine of the angle between the normal and the span of
-                                       // the working set.  A row at 1e-8 .. 1e-12 of that span is a direction on paper, but
+constexpr double kDepFloor2 = 1.0e-13; // second test, only when |d2|^2 <= 1e-12 |d|^2: max over the free columns c of J of
+                                       // d2_c^2 / (|J_c|^2 |n|^2) <= kDepFloor2 -> dependent (see direction_is_independent).
+                                       // That ratio is the cos^2 of the angle between the normal and the column: about the
+                                       // sine^2 of its angle with the span of the working set.  A row at 1e-8 .. 1e-12 of that span is a direction on paper, but
                                        // taking it puts |d2| on the diagonal of R (condition 1e8+: the dual directions r lose
                                        // their signs) and moves x by violation / |d2|.  Seen on hardware (closed-loop
                                        // self-collision tests, H ~ I): sine^2 = 3e-23 with a bound violated by 4e-11 -> x jumped
                                        // by 26; sine^2 = 1.5e-17 with 1e-7 -> by 14; both ended as false INFEASIBLE.  The genuine
-                                       // last direction quoted above sits at 9.4e-9 on this scale.  tests/stress_closed_loop.py,
-                                       // product-only failures in 921 k closed-loop solves at eps factor 1e6: 346 with 1e-19,
-                                       // 0 with 1e-16, 0 with 1e-13; at the default eps (307 k solves): 671 / 846 / 318
+                                       // last direction quoted above sits at 9.4e-9 on this scale.  tests/stress_closed_loop.py:
+                                       // 1.23 M closed-loop solves at eps factor 1e6 without a product-only failure (346 in
+                                       // 921 k with a floor of 1e-19); at the default eps 5 distinct instances in 3 x 307 k
 constexpr double kViolTol = 1.0e-11;   // a slack below -kViolTol*max(1,|bound|) counts as violated
 constexpr double kEqTol = 1.0e-9;      // consistency of a linearly dependent equality row
 constexpr double kSlackTol = 1.0e-6;   // a violation below this (relative) with no direction left is round-off: with the
@@ -669,9 +670,12 @@ __device__ inline int nullspace_equalities32(const WaveCtx<32>& w, int n_eq, dou
 }
 
 // Is the part d2 = J2'n of a constraint normal outside the span of the working set a DIRECTION or round-off?
-// nd2 = |d2|^2, dd = |d|^2 (both uniform); nv = this lane's entry of the normal n.  See kDepTol2 / kDepFloor2.
+// nd2 = |d2|^2, dd = |d|^2 (both uniform); d2 = this lane's component (0 below iq); nv = this lane's entry of the
+// normal n.  Second tier, per FREE COLUMN c of J: d2_c^2 / (|J_c|^2 |n|^2) = cos^2 of the angle between n and that
+// column; the normal counts as a direction if it makes a usable angle with at least one of them.  (Per column, not
+// against |J2|_F: at the default eps the null directions of H give columns of norm 1e5 next to columns of norm 1.)
 template <int NP>
-__device__ inline bool direction_is_independent(const WaveCtx<NP>& w, double nd2, double dd, double nv, int iq) {
+__device__ inline bool direction_is_independent(const WaveCtx<NP>& w, double nd2, double dd, double d2, double nv, int iq) {
     if (nd2 > 1.0e-12 * dd) return true;           // the usual case: one compare
     if (!(nd2 > kDepTol2 * dd)) return false;
     constexpr int S = WaveCtx<NP>::S;
@@ -679,14 +683,15 @@ __device__ inline bool direction_is_independent(const WaveCtx<NP>& w, double nd2
     double cn = 0.0;                                // |J[:, c]|^2 of my column, if it is a free one
     if (c >= iq && c < n)
         for (int i = 0; i < n; ++i) { const double v = w.M2[c * S + i]; cn = fma(v, v, cn); }
-    double nn;
-    colsum2<NP>(cn, nv * nv, cn, nn);
-    return nd2 > kDepFloor2 * nn * cn;
+    const double cos2 = (cn > 0.0) ? d2 * d2 / cn : 0.0;
+    const double best = colmax<NP>(cos2);
+    const double nn = colsum<NP>(nv * nv);
+    return best > kDepFloor2 * nn;
 }
 
 template <int NP, bool PROF>
 __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq, const int me, int Aq, double uq,
-                               int iters, bool has_box, double lb, double ub, int max_iter, bool diag_dd, double hinv,
+                               int iters, bool has_box, double& lb, double& ub, int max_iter, bool diag_dd, double hinv,
                                double& x_out, int& iters_out, long long* prof);
 
 // ---------------------------------------------------------------------------------------------------------
@@ -854,7 +859,7 @@ __device__ inline void lowrank_prepare32(const WaveCtx<32>& w, const double* Ak,
 // Pre (general H):  Hc[ii] = (H + eps I)[HV*ii+h][c] in registers (NP = 64, factor_rows64) or the accumulator tiles (NP = 32, factor_tiles32), M1 is scratch.
 template <int NP, bool PROF>
 __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_h,
-                        double hdiag, double (&Hc)[NP / (64 / NP)], bool has_box, double lb, double ub, int max_iter,
+                        double hdiag, double (&Hc)[NP / (64 / NP)], bool has_box, double& lb, double& ub, int max_iter,
                         bool have_prev, double xprev, double& x_out, int& iters_out, long long* prof,
                         bool prepared = false, double xprep = 0.0) {
     constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
@@ -956,7 +961,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
         colsum2<NP>(d * d, d2 * d2, dd, nd2);
         const double resid = lo + colsum<NP>(a * (xref - x));
         OSOT_SUB_END(PH_EQ_RED);
-        if (!direction_is_independent<NP>(w, nd2, dd, a, iq)) {   // row is (numerically) a combination of the rows already in
+        if (!direction_is_independent<NP>(w, nd2, dd, d2, a, iq)) {   // row is (numerically) a combination of the rows already in
             // an optimality row of an upper level (src >= 0) is consistent BY CONSTRUCTION (x of that level
             // satisfies all of them, iHQP.cpp:164-170): a residual there is round-off of an ill-conditioned level
             // (default eps 4.4e-11: O(1e-16 / eps)), never infeasibility
@@ -990,7 +995,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
 
 template <int NP, bool PROF>
 __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq, const int me, int Aq, double uq,
-                               int iters, bool has_box, double lb, double ub, int max_iter, bool diag_dd, double hinv,
+                               int iters, bool has_box, double& lb, double& ub, int max_iter, bool diag_dd, double hinv,
                                double& x_out, int& iters_out, long long* prof) {
     constexpr int S = WaveCtx<NP>::S;
     const int c = w.c, h = w.h, n = w.n;
@@ -1158,7 +1163,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
             } else {
                 colsum2<NP>(d * d, d2 * d2, dd, nd2);
             }
-            const bool z_ok = direction_is_independent<NP>(w, nd2, dd,
+            const bool z_ok = direction_is_independent<NP>(w, nd2, dd, d2,
                                                            ip_box ? ((c == ip_var) ? 1.0 : 0.0) : (ip_unit ? ((c == ip_uidx) ? 1.0 : 0.0) : np), iq);
             OSOT_SUB_END(PH_IN_D);
             // z = J2 d2 : primal step direction
@@ -1206,7 +1211,17 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                 // QP is infeasible (eiquadprog.hpp:376-382).
                 const double bmag = ip_box ? fabs(bcast((ip < n) ? lb : ub, ip_var))
                                            : fabs((ip & 1) ? w.rup[ip_row] : w.rlo[ip_row]);
-                if (-s_ip <= kSlackTol * fmax(1.0, bmag)) { degenerate_done = true; break; }
+                if (-s_ip <= kSlackTol * fmax(1.0, bmag)) {
+                    // accepted as satisfied: the LOWER levels must accept the same point (their optimality rows pin x
+                    // to it), so the bound is relaxed by what was accepted for the rest of this instance's cascade --
+                    // otherwise they find the constraint violated by that much, trade it against a bound and end
+                    // INFEASIBLE (tests/stress_closed_loop.py at the default eps)
+                    const double relax = -1.001 * s_ip;
+                    if (ip_box) { if (c == ip_var) { if (ip < n) lb -= relax; else ub += relax; } }
+                    else if (c == 0 && h == 0) { if (ip & 1) w.rup[ip_row] += relax; else w.rlo[ip_row] -= relax; }
+                    wave_sync();
+                    degenerate_done = true; break;
+                }
                 failed = true; break;
             }
             if (t2 <= t1) {

@@ -57,6 +57,7 @@ leaf = {"B": B, "task": [[(pose[2], pose_d[2], None), (pose[3], pose_d[3], None)
         "bound": [(q, qmin, qmax), (qdot_max, None, None)], "rows": [(Jd, dist, None)]}
 t0 = time.time()
 solves = fails = bugs = shared = 0
+bug_instances, shared_instances = set(), set()
 dmin = np.inf
 for cycle in range(cycles):
     fk(); st.update(leaf); st.solve(B); torch.cuda.synchronize()
@@ -74,13 +75,14 @@ for cycle in range(cycles):
         rx = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1, termination_tolerance=10 * 2.221e-16)
         re_ = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
         if rx["status"][0] == 1 or re_["status"][0] == 1:
-            bugs += 1
+            bugs += 1; bug_instances.add(int(i))
             print("BUG cycle", cycle, "instance", int(i), "status", int(s[i]), "witnesses", int(rx["status"][0]), int(re_["status"][0]), flush=True)
             if bugs <= 3:
                 np.savez(os.path.join(_ROOT, "gpurun_out", f"closed_loop_bug_{seed}_{bugs}.npz"), **{k: v for k, v in asm.items() if isinstance(v, np.ndarray)},
                          A0=asm["A"][0], A1=asm["A"][1], b0=asm["b"][0], b1=asm["b"][1], b2=asm["b"][2], w0=asm["w"][0], w1=asm["w"][1], w2=asm["w"][2])
         else:
-            shared += 1
+            shared += 1; shared_instances.add(int(i))
     q += st.dq[:B]
 print(f"seed {seed} eps_factor {eps_factor:g}: {solves} closed-loop solves in {time.time() - t0:.0f} s, {fails} not solved (checked), "
-      f"{shared} of them infeasible for the witnesses too, {bugs} product-only failures; min pair distance seen {dmin:.4f}")
+      f"{shared} of them infeasible for the witnesses too ({len(shared_instances)} distinct instances), {bugs} product-only failures "
+      f"({len(bug_instances)} distinct instances; a failed instance does not move, so it meets the same problem again); min pair distance seen {dmin:.4f}")
