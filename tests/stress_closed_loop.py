@@ -75,10 +75,11 @@ for cycle in range(cycles):
         rx = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1, termination_tolerance=10 * 2.221e-16)
         re_ = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
         if rx["status"][0] == 1 or re_["status"][0] == 1:
+            first = int(i) not in bug_instances
             bugs += 1; bug_instances.add(int(i))
             print("BUG cycle", cycle, "instance", int(i), "status", int(s[i]), "witnesses", int(rx["status"][0]), int(re_["status"][0]), flush=True)
-            if bugs <= 3:
-                np.savez(os.path.join(_ROOT, "gpurun_out", f"closed_loop_bug_{seed}_{bugs}.npz"), **{k: v for k, v in asm.items() if isinstance(v, np.ndarray)},
+            if first and len(bug_instances) <= 6:
+                np.savez(os.path.join(_ROOT, "gpurun_out", f"closed_loop_bug_{seed}_{len(bug_instances)}.npz"), **{k: v for k, v in asm.items() if isinstance(v, np.ndarray)},
                          A0=asm["A"][0], A1=asm["A"][1], b0=asm["b"][0], b1=asm["b"][1], b2=asm["b"][2], w0=asm["w"][0], w1=asm["w"][1], w2=asm["w"][2])
         else:
             shared += 1; shared_instances.add(int(i))
