@@ -74,6 +74,8 @@ __device__ inline void closest_segment_points(const double* p1, const double* q1
     for (int i = 0; i < 3; ++i) { c1[i] = p1[i] + s * d1[i]; c2[i] = p2[i] + t * d2[i]; }
 }
 
+// PAIRS: the instantiation with the self-collision stage (step 5); the other one keeps the leaner register / LDS budget
+template <bool PAIRS>
 __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__ K, const osot_kin_batch Bt) {
     constexpr int TS = 12;
     OSOT_STATIC_LDS(double, Tb, 2 * 64 * TS);   // two transform buffers [R | p] per joint (ping-pong of the pointer jumping:
@@ -246,6 +248,7 @@ __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__
         }
     }
     // ---- 5. self-collision pairs
+    if constexpr (PAIRS) {
     const int np = K->d.n_pairs;
     if (np > 0 && (Bt.pair_dist || Bt.pair_J)) {
         OSOT_STATIC_LDS(double, Pw, OSOT_KIN_MAX_PAIRS * 9);   // per pair: normal n, axis points c_a, c_b (world)
@@ -297,6 +300,7 @@ __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__
                 if (valid) J[p * n + j] = val;
             }
         }
+    }
     }
 }
 

@@ -529,7 +529,7 @@ int osot_backend_get_num_constraints(osot_backend* be, int* nc) {
 // ---------------------------------------------------------------------------------------------------
 struct osot_kin {
     DevKin* dev;
-    int n, n_frames, device;
+    int n, n_frames, n_pairs, device;
 };
 
 extern "C" {
@@ -559,7 +559,7 @@ int osot_kin_create(const osot_kin_desc* d, int device, osot_kin** out) {
     if (!(h.total_mass > 0.0)) h.total_mass = 1.0;
     HIP_TRY(hipSetDevice(device));
     osot_kin* k = new osot_kin();
-    k->n = d->n; k->n_frames = d->n_frames; k->device = device;
+    k->n = d->n; k->n_frames = d->n_frames; k->n_pairs = d->n_pairs; k->device = device;
     hipError_t e = hipMalloc(&k->dev, sizeof(DevKin));
     if (e == hipSuccess) e = hipMemcpy(k->dev, &h, sizeof(DevKin), hipMemcpyHostToDevice);
     if (e != hipSuccess) { delete k; return fail(OSOT_ERR_HIP, hipGetErrorString(e)); }
@@ -579,7 +579,10 @@ int osot_kinematics(osot_kin* k, const osot_kin_batch* b, void* hip_stream) {
     if (b->B < 0) return fail(OSOT_ERR_INVALID, "negative batch");
     if (b->B == 0) return OSOT_OK;
     if (!b->q) return fail(OSOT_ERR_INVALID, "q is null");
-    hipLaunchKernelGGL(osot_kin_kernel, dim3((unsigned)b->B), dim3(64), 0, (hipStream_t)hip_stream, (const DevKin*)k->dev, *b);
+    if (k->n_pairs > 0 && (b->pair_dist || b->pair_J))
+        hipLaunchKernelGGL(osot_kin_kernel<true>, dim3((unsigned)b->B), dim3(64), 0, (hipStream_t)hip_stream, (const DevKin*)k->dev, *b);
+    else
+        hipLaunchKernelGGL(osot_kin_kernel<false>, dim3((unsigned)b->B), dim3(64), 0, (hipStream_t)hip_stream, (const DevKin*)k->dev, *b);
     HIP_TRY(hipGetLastError());
     return OSOT_OK;
 }

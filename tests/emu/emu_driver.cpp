@@ -58,6 +58,7 @@ extern "C" __attribute__((visibility("default"))) int emu_kinematics(const osot_
         h.total_mass += d->mass[j];
     }
     if (!(h.total_mass > 0.0)) h.total_mass = 1.0;
-    emu::launch(osot_kin_kernel, (unsigned)b->B, 0, 64, (const DevKin*)&h, *b);
+    if (d->n_pairs > 0 && (b->pair_dist || b->pair_J)) emu::launch(osot_kin_kernel<true>, (unsigned)b->B, 0, 64, (const DevKin*)&h, *b);
+    else emu::launch(osot_kin_kernel<false>, (unsigned)b->B, 0, 64, (const DevKin*)&h, *b);
     return OSOT_OK;
 }
