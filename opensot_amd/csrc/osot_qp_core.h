@@ -46,7 +46,7 @@ constexpr double kDepFloor2 = 1.0e-13; // second test, only when |d2|^2 <= 1e-12
                                        // self-collision tests, H ~ I): sine^2 = 3e-23 with a bound violated by 4e-11 -> x jumped
                                        // by 26; sine^2 = 1.5e-17 with 1e-7 -> by 14; both ended as false INFEASIBLE.  The genuine
                                        // last direction quoted above sits at 9.4e-9 on this scale.  tests/stress_closed_loop.py:
-                                       // 1.23 M closed-loop solves at eps factor 1e6 without a product-only failure (346 in
+                                       // 5.3 M closed-loop solves at eps factor 1e6 without an unsolved instance (346 in
                                        // 921 k with a floor of 1e-19); at the default eps 5 distinct instances in 3 x 307 k
 constexpr double kViolTol = 1.0e-11;   // a slack below -kViolTol*max(1,|bound|) counts as violated
 constexpr double kEqTol = 1.0e-9;      // consistency of a linearly dependent equality row
