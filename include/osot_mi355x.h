@@ -127,8 +127,15 @@ typedef enum {
                                       lo = -1e20, up = 0; rows = 5 * contacts, first_col = first force column */
     OSOT_ROWS_ACC_JOINT_LIMITS = 5,/* acceleration::JointLimits (src/constraints/acceleration/JointLimits.cpp:58-176):
                                       unit rows e_(first_col+i) (NOT stored), bounds from q, qdot, limits */
-    OSOT_ROWS_ACC_VELOCITY_LIMITS = 6 /* acceleration::VelocityLimits (…/VelocityLimits.cpp:50-63): unit rows
+    OSOT_ROWS_ACC_VELOCITY_LIMITS = 6,/* acceleration::VelocityLimits (…/VelocityLimits.cpp:50-63): unit rows
                                       (NOT stored), (qdot_lim - qdot)/(dT*p) */
+    /* constraints::TaskToConstraint (src/constraints/TaskToConstraint.cpp:25-68; `stack << l_sole` in
+     * examples/cpp/coman_ik.cpp:430-449): the rows are the task's A (written by the producer into C, like the task's
+     * Jacobian into A_k), the bounds are the task's b computed HERE from the task's leaf inputs, widened by the block's
+     * error band: lo = b + err_lb, up = b + err_ub (0, 0: the task as an equality).  task_lambda /
+     * task_orientation_gain are the task's gains. */
+    OSOT_ROWS_TASK_CARTESIAN = 7,     /* velocity::Cartesian as a constraint: 6 rows; leaf as for OSOT_TASK_CARTESIAN */
+    OSOT_ROWS_TASK_COM = 8            /* velocity::CoM as a constraint: 3 rows; leaf as for OSOT_TASK_COM */
 } osot_rows_kind;
 
 typedef struct {
@@ -138,6 +145,8 @@ typedef struct {
     int first_col;   /* unit-row / friction-cone blocks: column of the block's first variable */
     double dT, p;    /* acceleration limits: time step and horizon factor (dt = dT*p) */
     double mu;       /* friction coefficient */
+    double task_lambda, task_orientation_gain;   /* OSOT_ROWS_TASK_*: gains of the underlying task */
+    double err_lb, err_ub;                       /* OSOT_ROWS_TASK_*: TaskToConstraint's error band (scalars) */
     int only_level;  /* 0 = global rows: constrain every level (AutoStack `<<`, iHQP.cpp:191-193).  k + 1 = TASK-LOCAL
                         rows of level k (`task << constraint`, Task::getConstraints(), iHQP.cpp:190, 282-287): they
                         constrain the QP of level k only; at every other level they are absent */
@@ -209,6 +218,7 @@ typedef struct {
  *   ROWS_FRICTION_CONE   : p0 = contact rotations wRl [B][contacts][9] (row-major)
  *   ROWS_ACC_JOINT_LIMITS    : p0 = [q ; qdot] [B][2*rows], p1 = [q_min ; q_max] [B][2*rows], p2 = qddot_max [B][rows]
  *   ROWS_ACC_VELOCITY_LIMITS : p0 = qdot [B][rows], p1 = qdot_max [B][rows]
+ *   ROWS_TASK_CARTESIAN / ROWS_TASK_COM : as TASK_CARTESIAN / TASK_COM (the 6 / 3 rows are written by the producer into C)
  * Task Jacobians are NOT passed here: the producer writes them straight into their row range of
  * osot_qp_batch.A[k] (zero-copy stacking; the reference copies them twice through MatrixPiler,
  * src/tasks/Aggregated.cpp:113-132). */

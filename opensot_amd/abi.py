@@ -12,7 +12,7 @@ STATUS_SOLVED, STATUS_INFEASIBLE, STATUS_MAX_ITER, STATUS_NOT_PD = range(4)
 TASK_GENERIC, TASK_CARTESIAN, TASK_COM, TASK_POSTURAL, TASK_ACC_CARTESIAN, TASK_ACC_COM, TASK_ACC_POSTURAL = range(7)
 BOUND_GENERIC, BOUND_JOINT_LIMITS, BOUND_VELOCITY_LIMITS = range(3)
 (ROWS_GENERIC, ROWS_COLLISION, ROWS_DYN_FEASIBILITY, ROWS_TORQUE_LIMITS, ROWS_FRICTION_CONE,
- ROWS_ACC_JOINT_LIMITS, ROWS_ACC_VELOCITY_LIMITS) = range(7)
+ ROWS_ACC_JOINT_LIMITS, ROWS_ACC_VELOCITY_LIMITS, ROWS_TASK_CARTESIAN, ROWS_TASK_COM) = range(9)
 # OpenSoT::HessianType (include/OpenSoT/Task.h:33-41)
 HST_UNDEFINED, HST_ZERO, HST_IDENTITY, HST_POSDEF, HST_POSDEF_NULLSPACE, HST_SEMIDEF, HST_UNKNOWN = range(7)
 
@@ -38,6 +38,7 @@ class RowsDesc(C.Structure):
     _fields_ = [("kind", C.c_int), ("rows", C.c_int), ("d_threshold", C.c_double),
                 ("detection_threshold", C.c_double), ("bound_scaling", C.c_double),
                 ("first_col", C.c_int), ("dT", C.c_double), ("p", C.c_double), ("mu", C.c_double),
+                ("task_lambda", C.c_double), ("task_orientation_gain", C.c_double), ("err_lb", C.c_double), ("err_ub", C.c_double),
                 ("only_level", C.c_int)]
 
 

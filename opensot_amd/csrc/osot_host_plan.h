@@ -112,7 +112,11 @@ inline int plan_validate(const osot_plan_desc* p, const char** why) {
         if (p->bound[j].kind < 0 || p->bound[j].kind > OSOT_BOUND_VELOCITY_LIMITS) { *why = "unknown bound kind"; return OSOT_ERR_UNSUPPORTED; }
     for (int j = 0; j < p->n_rowblocks; ++j) {
         const osot_rows_desc& rb = p->rowblock[j];
-        if (rb.kind < 0 || rb.kind > OSOT_ROWS_ACC_VELOCITY_LIMITS) { *why = "unknown row-block kind"; return OSOT_ERR_UNSUPPORTED; }
+        if (rb.kind < 0 || rb.kind > OSOT_ROWS_TASK_COM) { *why = "unknown row-block kind"; return OSOT_ERR_UNSUPPORTED; }
+        if (rb.kind == OSOT_ROWS_TASK_CARTESIAN && rb.rows != 6) { *why = "a Cartesian task as a constraint has 6 rows"; return OSOT_ERR_INVALID; }
+        if (rb.kind == OSOT_ROWS_TASK_COM && rb.rows != 3) { *why = "a CoM task as a constraint has 3 rows"; return OSOT_ERR_INVALID; }
+        if ((rb.kind == OSOT_ROWS_TASK_CARTESIAN || rb.kind == OSOT_ROWS_TASK_COM) && !(rb.err_ub >= rb.err_lb)) {
+            *why = "Some components of err_ub are smaller than err_lb!!!"; return OSOT_ERR_INVALID; }   // TaskToConstraint.cpp:43
         if (rb.rows < 1 || rb.rows > 256) { *why = "row block size out of range (1..256)"; return OSOT_ERR_INVALID; }
         if (rb.kind == OSOT_ROWS_DYN_FEASIBILITY && rb.rows != 6) { *why = "DynamicFeasibility has 6 rows"; return OSOT_ERR_INVALID; }
         if (rb.kind == OSOT_ROWS_FRICTION_CONE && (rb.rows % 5 != 0 || rb.first_col < 0 || rb.first_col + 3 * (rb.rows / 5) > p->n)) {

@@ -508,7 +508,8 @@ struct DevTask {
     double sublam;             // SubTask lambda on b (1 when not a sub-task)
 };
 struct DevBound { int kind; double scaling, dT; const double *p0, *p1, *p2; };
-struct DevRowBlock { int kind, rows, off, stored_off, first_col; double d_threshold, detection_threshold, bound_scaling, dT, p, mu; const double *p0, *p1, *p2; };
+struct DevRowBlock { int kind, rows, off, stored_off, first_col; double d_threshold, detection_threshold, bound_scaling, dT, p, mu;
+                     double lambda, ogain, err_lb, err_ub; const double *p0, *p1, *p2; };
 
 struct DevUpdate {
     int B, n, L, nc, nc_stored;
@@ -729,6 +730,21 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
                 }
             }
             __syncthreads();
+        } else if (rb.kind == 7) {   // TaskToConstraint(velocity::Cartesian) (TaskToConstraint.cpp:59-68): rows J are in C already
+            if (t == 0) {
+                double Ta[12], Td[12], tw[6], b6[6];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) { Ta[i] = rb.p0[inst * 12 + i]; Td[i] = rb.p1[inst * 12 + i]; }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) tw[i] = rb.p2 ? rb.p2[inst * 6 + i] : 0.0;
+                cartesian_b(Ta, Td, tw, rb.lambda, rb.ogain, b6);
+                for (int i = 0; i < 6; ++i) { lob[i] = b6[i] + rb.err_lb; upb[i] = b6[i] + rb.err_ub; }
+            }
+        } else if (rb.kind == 8) {   // TaskToConstraint(velocity::CoM): b = v_des + lambda (p_d - p) (CoM.cpp:145-149)
+            if (t < 3) {
+                const double b = (rb.p2 ? rb.p2[inst * 3 + t] : 0.0) + rb.lambda * (rb.p1[inst * 3 + t] - rb.p0[inst * 3 + t]);
+                lob[t] = b + rb.err_lb; upb[t] = b + rb.err_ub;
+            }
         } else if (rb.kind == 2) {   // DynamicFeasibility.cpp:22-46 as equality: rows [B_u, -J_f'] are in C already
             if (t < 6) { const double v = -rb.p0[inst * 6 + t]; lob[t] = v; upb[t] = v; }
         } else if (rb.kind == 3) {   // TorqueLimits.cpp:25-46: rows [B, -Jc'] are in C already

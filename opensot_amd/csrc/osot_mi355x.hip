@@ -288,6 +288,8 @@ int osot_stack_update(osot_solver* s, const osot_leaf_batch* leaf, const osot_as
         d.kind = pl.rowblock[j].kind; d.rows = pl.rowblock[j].rows; d.off = roff;
         d.stored_off = soff; d.first_col = pl.rowblock[j].first_col;
         d.dT = pl.rowblock[j].dT; d.p = pl.rowblock[j].p; d.mu = pl.rowblock[j].mu;
+        d.lambda = pl.rowblock[j].task_lambda; d.ogain = pl.rowblock[j].task_orientation_gain;
+        d.err_lb = pl.rowblock[j].err_lb; d.err_ub = pl.rowblock[j].err_ub;
         if (!rows_are_implicit(d.kind)) soff += d.rows;
         d.d_threshold = pl.rowblock[j].d_threshold;
         d.detection_threshold = pl.rowblock[j].detection_threshold;
@@ -295,7 +297,8 @@ int osot_stack_update(osot_solver* s, const osot_leaf_batch* leaf, const osot_as
         d.p0 = leaf->rows[j].p0; d.p1 = leaf->rows[j].p1; d.p2 = leaf->rows[j].p2;
         if (!d.p0) return fail(OSOT_ERR_INVALID, "leaf input p0 of a row block is null");
         if ((d.kind == OSOT_ROWS_GENERIC || d.kind == OSOT_ROWS_COLLISION || d.kind == OSOT_ROWS_TORQUE_LIMITS ||
-             d.kind == OSOT_ROWS_ACC_JOINT_LIMITS || d.kind == OSOT_ROWS_ACC_VELOCITY_LIMITS) && !d.p1)
+             d.kind == OSOT_ROWS_ACC_JOINT_LIMITS || d.kind == OSOT_ROWS_ACC_VELOCITY_LIMITS ||
+             d.kind == OSOT_ROWS_TASK_CARTESIAN || d.kind == OSOT_ROWS_TASK_COM) && !d.p1)
             return fail(OSOT_ERR_INVALID, "leaf input p1 of a row block is null");
         if (d.kind == OSOT_ROWS_ACC_JOINT_LIMITS && !d.p2) return fail(OSOT_ERR_INVALID, "acceleration joint limits need qddot_max");
         if (d.kind == OSOT_ROWS_GENERIC && !d.p2) return fail(OSOT_ERR_INVALID, "generic rows need C, lo, up");

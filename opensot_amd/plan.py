@@ -86,6 +86,11 @@ class Rows:
     # None: global rows (every level).  k: task-local rows of level k (`task << constraint`, Task::getConstraints(),
     # iHQP.cpp:190, 282-287): they constrain level k's QP only
     level: Optional[int] = None
+    # ROWS_TASK_*: constraints::TaskToConstraint (`stack << l_sole`): the underlying task's gains and the error band
+    lam: float = 1.0
+    orientation_gain: float = 1.0
+    err_lb: float = 0.0
+    err_ub: float = 0.0
 
 
 @dataclass
@@ -172,6 +177,7 @@ class StackPlan:
             d.kind, d.rows, d.d_threshold, d.detection_threshold, d.bound_scaling = (
                 r.kind, r.rows, r.d_threshold, r.detection_threshold, r.bound_scaling)
             d.first_col, d.dT, d.p, d.mu = r.first_col, r.dT, r.p, r.mu
+            d.task_lambda, d.task_orientation_gain, d.err_lb, d.err_ub = r.lam, r.orientation_gain, r.err_lb, r.err_ub
             d.only_level = 0 if r.level is None else r.level + 1
         p.eps_abs = self.eps_abs
         p.max_iter = self.max_iter

@@ -23,7 +23,7 @@ ip = C.POINTER(C.c_int)
 TASK_GENERIC, TASK_CARTESIAN, TASK_COM, TASK_POSTURAL, TASK_ACC_CARTESIAN, TASK_ACC_COM, TASK_ACC_POSTURAL = range(7)
 BOUND_GENERIC, BOUND_JOINT_LIMITS, BOUND_VELOCITY_LIMITS = range(3)
 (ROWS_GENERIC, ROWS_COLLISION, ROWS_DYN_FEASIBILITY, ROWS_TORQUE_LIMITS, ROWS_FRICTION_CONE,
- ROWS_ACC_JOINT_LIMITS, ROWS_ACC_VELOCITY_LIMITS) = range(7)
+ ROWS_ACC_JOINT_LIMITS, ROWS_ACC_VELOCITY_LIMITS, ROWS_TASK_CARTESIAN, ROWS_TASK_COM) = range(9)
 IMPLICIT_IDENTITY_TASKS = (TASK_POSTURAL, TASK_ACC_POSTURAL)
 
 
@@ -206,6 +206,16 @@ def assemble(plan, leaf):
                     Cm[i, sl] = Ci; lo[i, sl] = loi; up[i, sl] = upi
                 elif rb.kind == ROWS_DYN_FEASIBILITY:      # rows [B_u, -J_f'] come from the producer (leaf "C")
                     Cm[i, sl] = leaf["C"][j][i]; lo[i, sl] = -p0[i]; up[i, sl] = -p0[i]
+                elif rb.kind in (ROWS_TASK_CARTESIAN, ROWS_TASK_COM):
+                    # constraints::TaskToConstraint::generateAll (TaskToConstraint.cpp:59-68): Aineq = task A (from the
+                    # producer), bLower/bUpper = task b + err_lb / err_ub
+                    bt = np.zeros(rb.rows)
+                    if rb.kind == ROWS_TASK_CARTESIAN:
+                        tw = p2[i] if p2 is not None else zeros6
+                        L.orc_cartesian_b(_p(p0[i, :9]), _p(p0[i, 9:]), _p(p1[i, :9]), _p(p1[i, 9:]), _p(tw), rb.lam, rb.orientation_gain, _p(bt))
+                    else:
+                        L.orc_com_b(_p(p0[i]), _p(p1[i]), _p(p2[i] if p2 is not None else zeros6[:3]), rb.lam, _p(bt))
+                    Cm[i, sl] = leaf["C"][j][i]; lo[i, sl] = bt + rb.err_lb; up[i, sl] = bt + rb.err_ub
                 elif rb.kind == ROWS_TORQUE_LIMITS:
                     L.orc_torque_limit_bounds(rb.rows, _p(p0[i]), _p(p1[i]), _p(loi), _p(upi))
                     Cm[i, sl] = leaf["C"][j][i]; lo[i, sl] = loi; up[i, sl] = upi

@@ -161,3 +161,23 @@ def test_task_local_rows_plan_validation(lib):
     assert lib.osot_plan_validate(C.byref(d)) == abi.ERR_INVALID
     d.rowblock[1].only_level = -1
     assert lib.osot_plan_validate(C.byref(d)) == abi.ERR_INVALID
+
+
+def test_task_to_constraint_rows_plan_validation(lib):
+    """constraints::TaskToConstraint (`stack << l_sole`, TaskToConstraint.cpp:25-68) as row kinds: sizes of the
+    underlying task, err_ub >= err_lb (the reference throws otherwise, :43)"""
+    from opensot_amd.plan import StackPlan, Task, Rows, eps_abs_from_factor
+    import ctypes as C
+    plan = StackPlan(n=12, levels=[[Task(abi.TASK_GENERIC, 3, name="a")]], bounds=[],
+                     rowblocks=[Rows(abi.ROWS_TASK_CARTESIAN, 6, lam=0.1, name="l_sole"), Rows(abi.ROWS_TASK_COM, 3, lam=0.2, err_lb=-0.01, err_ub=0.02, name="com_band")],
+                     eps_abs=eps_abs_from_factor(1e6))
+    d = plan.to_c()
+    assert lib.osot_plan_validate(C.byref(d)) == abi.OK
+    nc, ns = C.c_int(), C.c_int()
+    assert lib.osot_plan_constraint_rows(C.byref(d), C.byref(nc)) == abi.OK and lib.osot_plan_stored_constraint_rows(C.byref(d), C.byref(ns)) == abi.OK
+    assert (nc.value, ns.value) == (9, 9)
+    d.rowblock[0].rows = 5
+    assert lib.osot_plan_validate(C.byref(d)) == abi.ERR_INVALID
+    d.rowblock[0].rows = 6
+    d.rowblock[1].err_ub = -0.02
+    assert lib.osot_plan_validate(C.byref(d)) == abi.ERR_INVALID

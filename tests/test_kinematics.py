@@ -384,3 +384,87 @@ def test_closed_loop_self_collision_avoidance_on_device(gpu_device):
     assert safe_gap > 0.05                                # ... so the wrists cannot meet
     d, _ = pykin.pair_distances(m, q[5])
     assert np.abs(d - dist[5]).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_closed_loop_coman_ik_stack_with_contact_constraints(oracle, gpu_device):
+    """examples/cpp/coman_ik.cpp:437-442, the reference example's own three-level stack,
+        (com / (0.1*l_wrist + r_wrist) / postural) << joint_limits << vel_limits << (l_sole + r_sole),
+    with the feet as constraints::TaskToConstraint rows (TaskToConstraint.cpp:59-68): their Jacobians go from the
+    kinematics kernel straight into C, their bounds b +- 0 come out of the update kernel; first cycle against the
+    oracle's assembly and the witnesses, then the closed loop."""
+    import torch
+    from opensot_amd.plan import Rows
+    from opensot_amd.solver import BatchedStack
+    m = kin.humanoid32()
+    n, B = m.n, 96
+    dev = torch.device("cuda", 0)
+    f64 = dict(dtype=torch.float64, device=dev)
+    rng = np.random.default_rng(19)
+    q0 = np.zeros((B, n))
+    q0[:, [m.names.index(s + "KneeSag") for s in "RL"]] = 0.5
+    q0[:, [m.names.index(s + "HipSag") for s in "RL"]] = -0.25
+    q0[:, [m.names.index(s + "AnkSag") for s in "RL"]] = -0.25
+    q0[:, [m.names.index(s + "Elbj") for s in "RL"]] = -0.6
+    q0 += rng.normal(0.0, 0.02, (B, n))
+    levels = [[Task(abi.TASK_COM, 3, lam=0.1, name="com")],
+              [Task(abi.TASK_CARTESIAN, 6, weight=0.1, lam=0.1, name="l_wrist"), Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="r_wrist")],
+              [Task(abi.TASK_POSTURAL, n, lam=0.01, name="postural")]]
+    bounds = [Bound(abi.BOUND_JOINT_LIMITS, scaling=1.0, name="jl"), Bound(abi.BOUND_VELOCITY_LIMITS, dT=0.01, name="vl")]
+    rows = [Rows(abi.ROWS_TASK_CARTESIAN, 6, lam=0.1, name="l_sole"), Rows(abi.ROWS_TASK_CARTESIAN, 6, lam=0.1, name="r_sole")]
+    plan = StackPlan(n=n, levels=levels, bounds=bounds, rowblocks=rows, eps_abs=eps_abs_from_factor(1e6))
+    st = BatchedStack(plan, B, device=0)
+    K = kin.Kinematics(m, device=0)
+    q = torch.as_tensor(q0, **f64).contiguous()
+    pose = [torch.zeros((B, 12), **f64) for _ in range(4)]
+    com = torch.zeros((B, 3), **f64)
+
+    def fk():
+        K.forward(q, frame_pose={f: pose[f] for f in range(4)},
+                  frame_J={0: (st.A[1], 0), 1: (st.A[1], 6), 2: (st.C, 0), 3: (st.C, 6)}, com=com, com_J=(st.A[0], 0))
+    fk(); torch.cuda.synchronize()
+    pose_d = [p.clone() for p in pose]
+    pose_d[0][:, 9:] += torch.as_tensor([0.04, 0.03, 0.03], **f64)
+    pose_d[1][:, 9:] += torch.as_tensor([0.04, -0.03, 0.03], **f64)
+    pose_d[2][:, 9:] += torch.as_tensor(rng.normal(0, 2e-4, (B, 3)), **f64)      # the soles start a fraction of a mm off
+    com_d = com.clone(); com_d[:, 0] += 0.02
+    qmin = torch.full((B, n), -2.5, **f64); qmax = torch.full((B, n), 2.5, **f64)
+    qdot_max = torch.full((B, n), 2.0, **f64)
+    q_ref = q.clone()
+    leaf = {"B": B, "task": [[(com, com_d, None)], [(pose[0], pose_d[0], None), (pose[1], pose_d[1], None)], [(q, q_ref, None)]],
+            "bound": [(q, qmin, qmax), (qdot_max, None, None)], "rows": [(pose[2], pose_d[2], None), (pose[3], pose_d[3], None)]}
+    st.update(leaf); st.solve(B); torch.cuda.synchronize()
+    # first cycle: the update kernel's rows against the oracle's assembly, the cascade against the witnesses
+    h = lambda t: None if t is None else t.cpu().numpy()
+    np_leaf = {"B": B, "A": [h(st.A[0]), h(st.A[1]), None],
+               "task": [[tuple(h(x) for x in t) for t in lev] for lev in leaf["task"]],
+               "bound": [tuple(h(x) for x in t) for t in leaf["bound"]], "rows": [tuple(h(x) for x in t) for t in leaf["rows"]],
+               "C": [h(st.C[:, 0:6]), h(st.C[:, 6:12])]}
+    asm = oracle.assemble(plan, np_leaf)
+    np.testing.assert_allclose(h(st.lo), asm["lo"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(h(st.up), asm["up"], rtol=0, atol=1e-15)
+    assert (asm["lo"] == asm["up"]).all() and np.abs(asm["lo"]).max() > 1e-6       # equalities with a non-trivial right-hand side
+    dq = h(st.dq[:B])
+    assert (h(st.status[:B]) == 0).all()
+    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+    okr = ref["status"] == 1
+    assert okr.mean() > 0.9 and np.abs(dq[okr] - ref["dq"][okr]).max() < 1e-9
+    if oracle.ref_available():
+        rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
+        rx = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1, termination_tolerance=10 * 2.221e-16)
+        e = np.minimum(np.where(rq["status"] == 1, np.abs(dq - rq["dq"]).max(axis=1), np.inf),
+                       np.where(rx["status"] == 1, np.abs(dq - rx["dq"]).max(axis=1), np.inf))
+        assert np.isfinite(e).mean() > 0.9 and e[np.isfinite(e)].max() < 1e-6
+    # the feet rows hold exactly: J_sole dq = b_sole
+    Cs = h(st.C[:B]); los = h(st.lo[:B])
+    assert np.abs(np.einsum("bri,bi->br", Cs, dq) - los).max() < 1e-10
+    q += st.dq[:B]
+    for cycle in range(299):
+        fk(); st.update(leaf); st.solve(B)
+        q += st.dq[:B]
+    fk(); torch.cuda.synchronize()
+    assert (st.status[:B] == 0).all()
+    err = [float((pose_d[f][:, 9:] - pose[f][:, 9:]).norm(dim=1).max()) for f in range(4)]
+    assert err[1] < 3e-3 and err[0] < 2e-2           # r_wrist converged, l_wrist (weight 0.1, same level) follows
+    assert err[2] < 5e-3 and err[3] < 5e-3           # the feet are CONSTRAINTS here: velocity-level rows, lambda = 0.1 on the drift
+    assert float((com_d - com).norm(dim=1).max()) < 1e-3
