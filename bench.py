@@ -261,7 +261,7 @@ def main():
         }
         traffic = None
         try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), same workload only
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_v10_pmc_cascade.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_v11_pmc_cascade.json")))
             if args.config == "C3" and Bl == 4096:
                 traffic = pm["hbm_bytes_per_launch_corrected"]
         except Exception:
@@ -279,7 +279,7 @@ def main():
                 gbs = Bl * bytes_per / kern_s / 1e9
                 out["roofline_hbm"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
-                                       "traffic_source": "profiles/r01_v10_pmc_cascade.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 per MI355X_MICROARCH.md)" if traffic else None,
+                                       "traffic_source": "profiles/r01_v11_pmc_cascade.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 per MI355X_MICROARCH.md)" if traffic else None,
                                        "algorithmic_bytes_per_solve": bytes_per}
         if not args.no_cpu_baseline and world == 1:
             ns = min(Bl, 4096)
