@@ -135,7 +135,11 @@ typedef enum {
      * error band: lo = b + err_lb, up = b + err_ub (0, 0: the task as an equality).  task_lambda /
      * task_orientation_gain are the task's gains. */
     OSOT_ROWS_TASK_CARTESIAN = 7,     /* velocity::Cartesian as a constraint: 6 rows; leaf as for OSOT_TASK_CARTESIAN */
-    OSOT_ROWS_TASK_COM = 8            /* velocity::CoM as a constraint: 3 rows; leaf as for OSOT_TASK_COM */
+    OSOT_ROWS_TASK_COM = 8,           /* velocity::CoM as a constraint: 3 rows; leaf as for OSOT_TASK_COM */
+    OSOT_ROWS_UNIT_GENERIC = 9        /* unit rows e_(first_col+i) (NOT stored), lo / up supplied: a box on a range of
+                                         variables as rows.  With only_level = k + 1 this is a TASK-LOCAL BOUND
+                                         (`task << joint_limits`: iHQP merges a level's own bounds into that level's
+                                         box only, iHQP.cpp:190, 336-340) */
 } osot_rows_kind;
 
 typedef struct {
@@ -218,6 +222,7 @@ typedef struct {
  *   ROWS_FRICTION_CONE   : p0 = contact rotations wRl [B][contacts][9] (row-major)
  *   ROWS_ACC_JOINT_LIMITS    : p0 = [q ; qdot] [B][2*rows], p1 = [q_min ; q_max] [B][2*rows], p2 = qddot_max [B][rows]
  *   ROWS_ACC_VELOCITY_LIMITS : p0 = qdot [B][rows], p1 = qdot_max [B][rows]
+ *   ROWS_UNIT_GENERIC : p0 = lo [B][rows], p1 = up [B][rows]
  *   ROWS_TASK_CARTESIAN / ROWS_TASK_COM : as TASK_CARTESIAN / TASK_COM (the 6 / 3 rows are written by the producer into C)
  * Task Jacobians are NOT passed here: the producer writes them straight into their row range of
  * osot_qp_batch.A[k] (zero-copy stacking; the reference copies them twice through MatrixPiler,

@@ -45,7 +45,7 @@ inline int plan_constraint_rows(const osot_plan_desc* p, int* nc) {
 }
 
 inline bool rows_are_implicit(int kind) {
-    return kind == OSOT_ROWS_ACC_JOINT_LIMITS || kind == OSOT_ROWS_ACC_VELOCITY_LIMITS;
+    return kind == OSOT_ROWS_ACC_JOINT_LIMITS || kind == OSOT_ROWS_ACC_VELOCITY_LIMITS || kind == OSOT_ROWS_UNIT_GENERIC;
 }
 inline int plan_stored_constraint_rows(const osot_plan_desc* p, int* nc_stored) {
     if (!p) return OSOT_ERR_INVALID;
@@ -112,7 +112,7 @@ inline int plan_validate(const osot_plan_desc* p, const char** why) {
         if (p->bound[j].kind < 0 || p->bound[j].kind > OSOT_BOUND_VELOCITY_LIMITS) { *why = "unknown bound kind"; return OSOT_ERR_UNSUPPORTED; }
     for (int j = 0; j < p->n_rowblocks; ++j) {
         const osot_rows_desc& rb = p->rowblock[j];
-        if (rb.kind < 0 || rb.kind > OSOT_ROWS_TASK_COM) { *why = "unknown row-block kind"; return OSOT_ERR_UNSUPPORTED; }
+        if (rb.kind < 0 || rb.kind > OSOT_ROWS_UNIT_GENERIC) { *why = "unknown row-block kind"; return OSOT_ERR_UNSUPPORTED; }
         if (rb.kind == OSOT_ROWS_TASK_CARTESIAN && rb.rows != 6) { *why = "a Cartesian task as a constraint has 6 rows"; return OSOT_ERR_INVALID; }
         if (rb.kind == OSOT_ROWS_TASK_COM && rb.rows != 3) { *why = "a CoM task as a constraint has 3 rows"; return OSOT_ERR_INVALID; }
         if ((rb.kind == OSOT_ROWS_TASK_CARTESIAN || rb.kind == OSOT_ROWS_TASK_COM) && !(rb.err_ub >= rb.err_lb)) {
@@ -123,7 +123,7 @@ inline int plan_validate(const osot_plan_desc* p, const char** why) {
             *why = "friction cone block: rows = 5*contacts and 3 force columns per contact inside x"; return OSOT_ERR_INVALID; }
         if (rows_are_implicit(rb.kind) && (rb.first_col < 0 || rb.first_col + rb.rows > p->n)) {
             *why = "unit-row block exceeds the variables"; return OSOT_ERR_INVALID; }
-        if (rows_are_implicit(rb.kind) && !(rb.dT * rb.p > 0.0)) { *why = "acceleration limits need dT*p > 0"; return OSOT_ERR_INVALID; }
+        if (rows_are_implicit(rb.kind) && rb.kind != OSOT_ROWS_UNIT_GENERIC && !(rb.dT * rb.p > 0.0)) { *why = "acceleration limits need dT*p > 0"; return OSOT_ERR_INVALID; }
         if (rb.only_level < 0 || rb.only_level > p->n_levels) { *why = "row block: only_level out of range (0..n_levels)"; return OSOT_ERR_INVALID; }
     }
     return OSOT_OK;

@@ -730,6 +730,8 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
                 }
             }
             __syncthreads();
+        } else if (rb.kind == 9) {   // generic unit rows (a box on a range of variables as rows): bounds supplied
+            for (int r = t; r < rb.rows; r += 64) { lob[r] = rb.p0[inst * rb.rows + r]; upb[r] = rb.p1[inst * rb.rows + r]; }
         } else if (rb.kind == 7) {   // TaskToConstraint(velocity::Cartesian) (TaskToConstraint.cpp:59-68): rows J are in C already
             if (t == 0) {
                 double Ta[12], Td[12], tw[6], b6[6];

@@ -298,7 +298,7 @@ int osot_stack_update(osot_solver* s, const osot_leaf_batch* leaf, const osot_as
         if (!d.p0) return fail(OSOT_ERR_INVALID, "leaf input p0 of a row block is null");
         if ((d.kind == OSOT_ROWS_GENERIC || d.kind == OSOT_ROWS_COLLISION || d.kind == OSOT_ROWS_TORQUE_LIMITS ||
              d.kind == OSOT_ROWS_ACC_JOINT_LIMITS || d.kind == OSOT_ROWS_ACC_VELOCITY_LIMITS ||
-             d.kind == OSOT_ROWS_TASK_CARTESIAN || d.kind == OSOT_ROWS_TASK_COM) && !d.p1)
+             d.kind == OSOT_ROWS_TASK_CARTESIAN || d.kind == OSOT_ROWS_TASK_COM || d.kind == OSOT_ROWS_UNIT_GENERIC) && !d.p1)
             return fail(OSOT_ERR_INVALID, "leaf input p1 of a row block is null");
         if (d.kind == OSOT_ROWS_ACC_JOINT_LIMITS && !d.p2) return fail(OSOT_ERR_INVALID, "acceleration joint limits need qddot_max");
         if (d.kind == OSOT_ROWS_GENERIC && !d.p2) return fail(OSOT_ERR_INVALID, "generic rows need C, lo, up");

@@ -60,7 +60,7 @@ def subtask(parent: "Task", indices, lam=1.0, n=None) -> "Task":
 
 
 IMPLICIT_IDENTITY_TASKS = (abi.TASK_POSTURAL, abi.TASK_ACC_POSTURAL)
-UNIT_ROW_BLOCKS = (abi.ROWS_ACC_JOINT_LIMITS, abi.ROWS_ACC_VELOCITY_LIMITS)
+UNIT_ROW_BLOCKS = (abi.ROWS_ACC_JOINT_LIMITS, abi.ROWS_ACC_VELOCITY_LIMITS, abi.ROWS_UNIT_GENERIC)
 
 
 @dataclass

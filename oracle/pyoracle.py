@@ -23,7 +23,7 @@ ip = C.POINTER(C.c_int)
 TASK_GENERIC, TASK_CARTESIAN, TASK_COM, TASK_POSTURAL, TASK_ACC_CARTESIAN, TASK_ACC_COM, TASK_ACC_POSTURAL = range(7)
 BOUND_GENERIC, BOUND_JOINT_LIMITS, BOUND_VELOCITY_LIMITS = range(3)
 (ROWS_GENERIC, ROWS_COLLISION, ROWS_DYN_FEASIBILITY, ROWS_TORQUE_LIMITS, ROWS_FRICTION_CONE,
- ROWS_ACC_JOINT_LIMITS, ROWS_ACC_VELOCITY_LIMITS, ROWS_TASK_CARTESIAN, ROWS_TASK_COM) = range(9)
+ ROWS_ACC_JOINT_LIMITS, ROWS_ACC_VELOCITY_LIMITS, ROWS_TASK_CARTESIAN, ROWS_TASK_COM, ROWS_UNIT_GENERIC) = range(10)
 IMPLICIT_IDENTITY_TASKS = (TASK_POSTURAL, TASK_ACC_POSTURAL)
 
 
@@ -206,6 +206,8 @@ def assemble(plan, leaf):
                     Cm[i, sl] = Ci; lo[i, sl] = loi; up[i, sl] = upi
                 elif rb.kind == ROWS_DYN_FEASIBILITY:      # rows [B_u, -J_f'] come from the producer (leaf "C")
                     Cm[i, sl] = leaf["C"][j][i]; lo[i, sl] = -p0[i]; up[i, sl] = -p0[i]
+                elif rb.kind == ROWS_UNIT_GENERIC:     # a box on variables first_col .. first_col+rows-1, as rows
+                    Cm[i, sl, rb.first_col:rb.first_col + rb.rows] = np.eye(rb.rows); lo[i, sl] = p0[i]; up[i, sl] = p1[i]
                 elif rb.kind in (ROWS_TASK_CARTESIAN, ROWS_TASK_COM):
                     # constraints::TaskToConstraint::generateAll (TaskToConstraint.cpp:59-68): Aineq = task A (from the
                     # producer), bLower/bUpper = task b + err_lb / err_ub

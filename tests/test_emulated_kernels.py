@@ -366,3 +366,32 @@ def test_collision_instance_from_the_closed_loop(oracle):
         # optimum it agrees)
         rx = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1, termination_tolerance=10 * 2.221e-16)
         assert rx["status"][0] == 1 and np.abs(dq - rx["dq"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("n,rows,level", [(7, [3, 3], 0), (31, [10, 12], 0), (40, [10, 12], 0)])
+def test_task_local_bounds_as_unit_rows(n, rows, level, oracle):
+    """`task << bound` (iHQP merges a level's own bounds into that level's box only, iHQP.cpp:190, 336-340) as a
+    level-tagged block of unit rows (OSOT_ROWS_UNIT_GENERIC, no storage): it holds at its level and only there; the
+    same block without a tag is the global box.  (A tight local box at a LOWER level is infeasible by construction:
+    that level must keep A_0 x = A_0 x_0 with an x_0 that was free to be large -- product and oracle agree on that.)"""
+    hw = 0.01
+    plan_i, leaf_i = synth.make_generic_stack(5, 20, [5, 6], n_eq=1, n_ineq=2, seed=4, box=0.5, unit_box=(1, hw))
+    asm_i = oracle.assemble(plan_i, leaf_i)
+    assert (emu_cascade(plan_i, asm_i)[2] == 1).all() and (oracle.ihqp_solve_batch(asm_i, oracle.BE_EIQP_EQ, nthreads=1)["status"] == 0).all()
+    plan, leaf = synth.make_generic_stack(5, n, rows, n_eq=1, n_ineq=2, seed=4, box=0.5, unit_box=(level, hw))
+    asm = oracle.assemble(plan, leaf)
+    dq, xl, st, it = emu_cascade(plan, asm)
+    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+    assert (st == 0).all() and (ref["status"] == 1).all()
+    assert np.abs(dq - ref["dq"]).max() < 1e-9 and np.abs(xl - ref["x_levels"]).max() < 1e-9
+    if oracle.ref_available():
+        rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
+        assert (rq["status"] == 1).all() and np.abs(dq - rq["dq"]).max() < 1e-6
+    assert np.abs(xl[:, level]).max() <= hw + 1e-9 and np.abs(xl[:, level]).max() > hw - 1e-9     # binding at its level
+    assert np.abs(xl).max() > 2 * hw                                                              # ... and not elsewhere
+    # untagged, the unit rows are a global box: same answer as the plan's own box of that width
+    plan_g, leaf_g = synth.make_generic_stack(5, n, rows, n_eq=1, n_ineq=2, seed=4, box=0.5, unit_box=(None, hw))
+    plan_b, leaf_b = synth.make_generic_stack(5, n, rows, n_eq=1, n_ineq=2, seed=4, box=hw)
+    xg = emu_cascade(plan_g, oracle.assemble(plan_g, leaf_g))[0]
+    xb = emu_cascade(plan_b, oracle.assemble(plan_b, leaf_b))[0]
+    assert np.abs(xg - xb).max() < 1e-9

@@ -276,3 +276,33 @@ def test_noise_is_not_a_direction_gpu(oracle, gpu_device):
         # optimum it agrees)
         rx = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1, termination_tolerance=10 * 2.221e-16)
         assert rx["status"][0] == 1 and np.abs(dq - rx["dq"]).max() < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,rows", [(7, [3, 3]), (31, [10, 12]), (40, [10, 12])])
+def test_task_local_bounds_as_unit_rows_gpu(n, rows, oracle, gpu_device):
+    """`task << bound` as a level-tagged block of unit rows (OSOT_ROWS_UNIT_GENERIC): update + cascade on the GPU"""
+    B, hw = 160, 0.01
+    plan, leaf = synth.make_generic_stack(B, n, rows, n_eq=1, n_ineq=2, seed=4, box=0.5, unit_box=(0, hw))
+    asm = oracle.assemble(plan, leaf)
+    st = BatchedStack(plan, B, device=0)
+    st.update(st.load_leaf(leaf)); st.solve(B)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(st.lo.cpu().numpy(), asm["lo"])
+    np.testing.assert_array_equal(st.up.cpu().numpy(), asm["up"])
+    dq = st.dq[:B].cpu().numpy(); xl = st.x_levels[:B].cpu().numpy()
+    status = st.status[:B].cpu().numpy()
+    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+    okr = ref["status"] == 1
+    solvable = okr.copy()
+    if oracle.ref_available():
+        rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
+        rx = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1, termination_tolerance=10 * 2.221e-16)
+        solvable |= (rq["status"] == 1) | (rx["status"] == 1)
+    assert ((status == 0) == solvable).all() and solvable.mean() > 0.95
+    assert np.abs(dq[okr] - ref["dq"][okr]).max() < 1e-9 and np.abs(xl[okr] - ref["x_levels"][okr]).max() < 1e-9
+    if oracle.ref_available():
+        e = np.minimum(np.where(rq["status"] == 1, np.abs(dq - rq["dq"]).max(axis=1), np.inf),
+                       np.where(rx["status"] == 1, np.abs(dq - rx["dq"]).max(axis=1), np.inf))[solvable]
+        assert e.max() < 1e-6
+    assert np.abs(xl[solvable][:, 0]).max() <= hw + 1e-9
