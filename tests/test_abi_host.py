@@ -181,3 +181,19 @@ def test_task_to_constraint_rows_plan_validation(lib):
     d.rowblock[0].rows = 6
     d.rowblock[1].err_ub = -0.02
     assert lib.osot_plan_validate(C.byref(d)) == abi.ERR_INVALID
+
+
+def test_unit_row_block_plan_validation(lib):
+    """OSOT_ROWS_UNIT_GENERIC: rows e_(first_col + i) without storage; the range must lie inside the variables"""
+    from opensot_amd.plan import StackPlan, Task, Rows, eps_abs_from_factor
+    import ctypes as C
+    plan = StackPlan(n=10, levels=[[Task(abi.TASK_GENERIC, 3, name="a")]], bounds=[],
+                     rowblocks=[Rows(abi.ROWS_UNIT_GENERIC, 4, first_col=6, level=0, name="local_box"), Rows(abi.ROWS_GENERIC, 2, name="rows")],
+                     eps_abs=eps_abs_from_factor(1e6))
+    d = plan.to_c()
+    assert lib.osot_plan_validate(C.byref(d)) == abi.OK
+    nc, ns = C.c_int(), C.c_int()
+    lib.osot_plan_constraint_rows(C.byref(d), C.byref(nc)); lib.osot_plan_stored_constraint_rows(C.byref(d), C.byref(ns))
+    assert (nc.value, ns.value) == (6, 2) and plan.nc_stored == 2
+    d.rowblock[0].first_col = 7           # 7 + 4 > 10
+    assert lib.osot_plan_validate(C.byref(d)) == abi.ERR_INVALID
