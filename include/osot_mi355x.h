@@ -200,6 +200,11 @@ typedef struct {
     int* iterations;                    /* out [B] active-set iterations summed over levels; may be NULL */
     const double* b_reg;                /* [B][regularisation.rows] b of the regularisation task; NULL iff the plan
                                            has none */
+    double* accepted_slack;             /* out [B], may be NULL: the largest constraint violation that a level of the
+                                           instance accepted as round-off of the levels above it (no direction left and
+                                           no multiplier to trade; at most min(1e-6 * max(1, |bound|), 1e-5)); 0 = none.
+                                           The status stays OSOT_STATUS_SOLVED, like the reference's `true` when qpOASES
+                                           stops inside its own tolerances */
 } osot_qp_batch;
 
 /* ---- leaf inputs of AutoStack::update (device pointers) ------------------------------------ */

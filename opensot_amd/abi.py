@@ -58,7 +58,8 @@ class QpBatch(C.Structure):
                 ("l", C.c_void_p), ("u", C.c_void_p),
                 ("level_active", C.c_void_p),
                 ("dq", C.c_void_p), ("x_levels", C.c_void_p),
-                ("status", C.c_void_p), ("iterations", C.c_void_p), ("b_reg", C.c_void_p)]
+                ("status", C.c_void_p), ("iterations", C.c_void_p), ("b_reg", C.c_void_p),
+                ("accepted_slack", C.c_void_p)]
 
 
 class LeafPtrs(C.Structure):

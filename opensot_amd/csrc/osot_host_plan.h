@@ -179,15 +179,13 @@ inline int make_dev_plan(const osot_plan_desc& p, const unsigned char* level_act
     P.reg_rows = p.has_regularisation ? p.regularisation.rows : 0;
     P.reg_w = p.has_regularisation ? p.regularisation.weight : 0.0;
     NP = (p.n <= 32) ? 32 : 64;
-    // cascade layout: M1, M2, V | rlo, rup, rptr | rowstate, eqlist | xlev[L-1][NP] | rsrc bytes
+    // cascade layout: M1, M2, V | rlo, rup, rptr | rowstate, eqlist | rsrc bytes
     const int S = NP + 1;
     const int cap = ((nrows_max > 0 ? nrows_max : 1) + 1) & ~1;
     int total = ((2 * NP * S + 4 * NP) + 1) & ~1;
     P.lds_rows_off = total;
     P.lds_rows_cap = cap;
     total += 3 * cap + cap;
-    P.lds_xlev_off = total;
-    total += (p.n_levels > 1 ? p.n_levels - 1 : 1) * NP;
     total += (cap + 7) / 8;
     lds_bytes = (size_t)total * sizeof(double);
     return OSOT_OK;

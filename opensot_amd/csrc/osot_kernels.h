@@ -51,7 +51,6 @@ struct DevPlan {
     // LDS carve-up of the wave's slice (doubles): M1, M2, V first (sizes fixed by NP), then
     int lds_rows_off;               // the row table: rlo, rup, rptr (8 B per row), rowstate, eqlist, rsrc (4 B per row)
     int lds_rows_cap;               // capacity (rows), even
-    int lds_xlev_off;               // [L][NP] doubles: x of the levels solved so far
 };
 
 struct DevBatch {
@@ -73,6 +72,7 @@ struct DevBatch {
     const int* order;  // dispatch order: workgroup g solves instance order[g] (null: g).  Longest-first, see below
     int* cost_out;     // [B] active-set iterations of this solve = the cost estimate for the next dispatch
     const double* b_reg;   // [B][reg_rows] b of the regularisation task (null: none)
+    double* accepted_slack;   // [B] largest constraint violation accepted as round-off (0: none); may be null
 };
 
 // Row table of level k (LDS): [ global C rows ; A_0 ; ... ; A_{k-1} ]  (iHQP.cpp:282-333).  The C entries are
@@ -96,9 +96,8 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
     w.rptr = reinterpret_cast<unsigned long long*>(w.rup + P.lds_rows_cap);
     w.rowstate = reinterpret_cast<int*>(w.rptr + P.lds_rows_cap);
     w.eqlist = w.rowstate + P.lds_rows_cap;
-    w.xlev = base + P.lds_xlev_off;
     w.safe_row = reinterpret_cast<unsigned long long>(D.dq + inst * n);   // n readable doubles (value is discarded)
-    w.rsrc = reinterpret_cast<signed char*>(w.xlev + (P.L > 1 ? P.L - 1 : 1) * NP);
+    w.rsrc = reinterpret_cast<signed char*>(w.eqlist + P.lds_rows_cap);
     const int c = w.c, h = w.h;
     const bool valid = c < n;
     // zero the matrices once: the padding beyond n stays zero for the whole kernel
@@ -132,6 +131,7 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
     int status = QP_SOLVED;
     int iters_total = 0;
     bool any = false;
+    double slack = 0.0;   // largest violation a level accepted as round-off (kSlackTol), 0 if none
     long long prof[PH_COUNT];
     if (PROF) for (int i = 0; i < PH_COUNT; ++i) prof[i] = 0;
     const long long t_begin = PROF ? (long long)clock64() : 0;
@@ -157,6 +157,7 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
                 const int r = P.blk_off[j] + q;
                 w.rlo[r] = on ? clamp_inf(D.lo[inst * P.nc + r]) : -kInfty;
                 w.rup[r] = on ? clamp_inf(D.up[inst * P.nc + r]) : kInfty;
+                w.rsrc[r] = on ? -2 : -1;   // -2: the previous level's solution owes this row nothing (osot_qp_core.h)
             }
             wave_sync();
         }
@@ -332,10 +333,10 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
         int st;
         if (NP == 64) {   // must be inlined: hacc would otherwise be passed through scratch memory
             OSOT_ALWAYS_INLINE_CALL st = gi_solve<NP, PROF>(w, nrows, g, diag_h, hdiag, hacc,
-                                                                   has_box, lb, ub, P.max_iter, any, x, x, iters, prof);
+                                                                   has_box, lb, ub, P.max_iter, any, x, x, iters, prof, slack);
         } else {          // NP = 32: the inliner's own order keeps the kernel free of vector spills
             st = gi_solve<NP, PROF>(w, nrows, g, diag_h, hdiag, hacc,
-                                           has_box, lb, ub, P.max_iter, any, x, x, iters, prof, lowrank, xprep);
+                                           has_box, lb, ub, P.max_iter, any, x, x, iters, prof, slack, lowrank, xprep);
         }
         if (PROF) ph_t0_ = (long long)clock64();
         iters_total += iters;
@@ -354,7 +355,6 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
                 w.rptr[off + q] = (q < ma) ? reinterpret_cast<unsigned long long>(Ak + q * n)
                                            : (((unsigned long long)(q - ma) << 1) | 1ull);   // Postural: e_(q-ma)
             }
-            if (h == 0) w.xlev[k * NP + c] = x;
             wave_sync();
         }
         OSOT_PH_END(PH_OPT);
@@ -369,6 +369,7 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
         D.status[inst] = status;
         if (D.iterations) D.iterations[inst] = iters_total;
         if (D.cost_out) D.cost_out[inst] = iters_total;
+        if (D.accepted_slack) D.accepted_slack[inst] = slack;
     }
 }
 
@@ -446,7 +447,6 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
     w.rptr = reinterpret_cast<unsigned long long*>(w.rup + Q.lds_rows_cap);
     w.rowstate = reinterpret_cast<int*>(w.rptr + Q.lds_rows_cap);
     w.eqlist = w.rowstate + Q.lds_rows_cap;
-    w.xlev = nullptr;
     w.safe_row = reinterpret_cast<unsigned long long>(Q.x + inst * n);
     w.rsrc = reinterpret_cast<signed char*>(w.eqlist + Q.lds_rows_cap);
     const int c = w.c, h = w.h;
@@ -483,13 +483,13 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
         w.rsrc[r] = -1;
     }
     wave_sync();
-    double x = 0.0;
+    double x = 0.0, slack = 0.0;
     int iters = 0;
     int st;
     if (NP == 64) {
-        OSOT_ALWAYS_INLINE_CALL st = gi_solve<NP, false>(w, Q.nc, g, false, 0.0, Hc, has_box, lb, ub, Q.max_iter, false, 0.0, x, iters, nullptr);
+        OSOT_ALWAYS_INLINE_CALL st = gi_solve<NP, false>(w, Q.nc, g, false, 0.0, Hc, has_box, lb, ub, Q.max_iter, false, 0.0, x, iters, nullptr, slack);
     } else {
-        st = gi_solve<NP, false>(w, Q.nc, g, false, 0.0, Hc, has_box, lb, ub, Q.max_iter, false, 0.0, x, iters, nullptr);
+        st = gi_solve<NP, false>(w, Q.nc, g, false, 0.0, Hc, has_box, lb, ub, Q.max_iter, false, 0.0, x, iters, nullptr, slack);
     }
     if (valid && h == 0) Q.x[inst * n + c] = (st == QP_SOLVED) ? x : 0.0;
     if (lane == 0) {

@@ -192,6 +192,7 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
     if (pl.has_regularisation && !b->b_reg) return fail(OSOT_ERR_INVALID, "plan has a regularisation task but b_reg is null");
     D.b_reg = pl.has_regularisation ? b->b_reg : nullptr;
     D.prof = prof;
+    D.accepted_slack = b->accepted_slack;
     hipStream_t st = (hipStream_t)hip_stream;
     if (s->schedule == 1) {
         if (!s->d_cost) {

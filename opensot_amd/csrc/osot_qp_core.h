@@ -55,6 +55,20 @@ constexpr double kSlackTol = 1.0e-6;   // a violation below this (relative) with
                                        // its active bound re-appears violated by that much where no freedom is left
                                        // (found by tests/stress_parity.py; qpOASES accepts the same point)
 
+constexpr double kSlackCap = 1.0e-5;   // ... but never more than this in absolute terms (torque / acceleration limits of 1e2 .. 1e3)
+#ifndef OSOT_FEAS_MARGIN
+#define OSOT_FEAS_MARGIN 0.0
+#endif
+constexpr double kFeasMargin = OSOT_FEAS_MARGIN;  // cascade levels below the first: every inequality that the previous level's solution
+                                       // x_prev satisfies with less slack than this (or violates at round-off level: a level ends
+                                       // when no violation exceeds kViolTol) has its bound moved to x_prev -+ margin before the
+                                       // level is solved.  With the optimality rows posed relative to x_prev (see gi_solve) x_prev
+                                       // is then a point that satisfies all equalities exactly and all inequalities strictly, so a
+                                       // dual method can only meet its infeasibility certificate (normal in the span of the
+                                       // working set, no multiplier to trade) through round-off, not because the stacked problem
+                                       // is feasible to 1e-13 only.  Same magnitude as qpOASES' boundTolerance under OpenSoT's
+                                       // options (1e6 * EPS, external/qpOASES-ext/src/Options.cpp:191-218).
+
 enum { QP_SOLVED = 0, QP_INFEASIBLE = 1, QP_MAX_ITER = 2, QP_NOT_PD = 3 };
 
 template <int NP>
@@ -72,9 +86,10 @@ struct WaveCtx {
     unsigned long long* rptr;     // address of the row's n doubles in HBM, or (index << 1) | 1 for the unit row e_index
     int* rowstate;                // 0 free, 1 lower active, 2 upper active, 3 equality
     int* eqlist;                  // indices of the equality rows, in row order
-    signed char* rsrc;            // -1: bounds are rlo/rup;  j >= 0: optimality row of level j, i.e. the
-                                  // equality a'x = a'x_j with x_j = xlev[j] (iHQP.cpp:164-170); rlo = rup = 0
-    double* xlev;                 // [levels][NP] solutions of the levels solved so far (cascade only)
+    signed char* rsrc;            // -1: bounds are rlo/rup (global row);  -2: the same, but a TASK-LOCAL row of the level being
+                                  // solved (the previous level's solution need not satisfy it);  j >= 0: optimality row of
+                                  // level j, the equality a'x = a'x_j (iHQP.cpp:164-170), posed as a'x = a'x_prev with x_prev
+                                  // the solution of the last level solved (which satisfies a'x_prev = a'x_j); rlo = rup = 0
     unsigned long long safe_row;  // address of n readable doubles in HBM (dummy target of unit-row loads)
 };
 
@@ -692,7 +707,7 @@ __device__ inline bool direction_is_independent(const WaveCtx<NP>& w, double nd2
 template <int NP, bool PROF>
 __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq, const int me, int Aq, double uq,
                                int iters, bool has_box, double& lb, double& ub, int max_iter, bool diag_dd, double hinv,
-                               double& x_out, int& iters_out, long long* prof);
+                               bool have_prev, double xprev, double& slack_out, double& x_out, int& iters_out, long long* prof);
 
 // ---------------------------------------------------------------------------------------------------------
 // Low-rank level (NP = 32):  H + eps I = D + A'WA with D diagonal and at most kLowRankMax stored rows
@@ -861,7 +876,7 @@ template <int NP, bool PROF>
 __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_h,
                         double hdiag, double (&Hc)[NP / (64 / NP)], bool has_box, double& lb, double& ub, int max_iter,
                         bool have_prev, double xprev, double& x_out, int& iters_out, long long* prof,
-                        bool prepared = false, double xprep = 0.0) {
+                        double& slack_out, bool prepared = false, double xprep = 0.0) {
     constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
     const int n = w_in.n;
     double* M1 = w_in.M1;
@@ -922,23 +937,27 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
     // classify all rows in parallel (lane = row), then walk the equality rows with the next row's
     // elements already in flight (one HBM/L2 round trip per row would otherwise sit on the critical path)
     int n_eq = 0;
+    bool local_eq = false;   // an equality among the level's task-local rows: x_prev does not satisfy it
     for (int r0 = 0; r0 < nrows; r0 += 64) {
         const int r = r0 + c + NP * h;
-        bool is_eq = false;
+        bool is_eq = false, is_loc = false;
         if (r < nrows) {
             const double lo = w.rlo[r], up = w.rup[r];
             is_eq = (lo == up) && (lo > -kInfty) && (lo < kInfty);
+            is_loc = is_eq && (w.rsrc[r] == -2);
             w.rowstate[r] = is_eq ? 3 : 0;
         }
+        local_eq = local_eq || (wave_ballot(is_loc) != 0ull);
         const unsigned long long mask = wave_ballot(is_eq);
         if (is_eq) w.eqlist[n_eq + lanes_below(mask)] = r;
         n_eq += __builtin_popcountll(mask);
     }
     wave_sync();
-    // many equalities under a diagonal Hessian, all satisfied by the previous level's solution: null-space
+    // many equalities under a diagonal Hessian, ALL satisfied by the previous level's solution (optimality rows and
+    // global equality rows are; a task-local equality of this level is not: then the generic path runs): null-space
     // elimination instead of n_eq Householder updates of the full J (see nullspace_equalities32)
     bool used_nullspace = false;
-    if (NP == 32 && diag_h && have_prev && n_eq >= 8 && n_eq <= 32 && n - n_eq <= kNullMax) {
+    if (NP == 32 && diag_h && have_prev && !local_eq && n_eq >= 8 && n_eq <= 32 && n - n_eq <= kNullMax) {
         const int r_ns = nullspace_equalities32<PROF>(reinterpret_cast<const WaveCtx<32>&>(w), n_eq, hdiag, g, xprev, x, prof);
         if (r_ns >= 0) { iq = r_ns; iters += n_eq; used_nullspace = true; n_eq = 0; }
     }
@@ -948,8 +967,9 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
         const double a = a_next;
         const double lo = w.rlo[r];
         const int src = w.rsrc[r];
-        // right-hand side relative to x: lo - a'x, or a'(x_j - x) for an optimality row of level j
-        const double xref = (src >= 0) ? w.xlev[src * NP + c] : 0.0;
+        // right-hand side relative to x: lo - a'x, or a'(x_prev - x) for an optimality row (x_prev, the solution of the
+        // last level solved, satisfies a'x_prev = a'x_j for the rows of every level j above it)
+        const double xref = (src >= 0) ? xprev : 0.0;
         if (e + 1 < n_eq) a_next = row_elem<NP>(w, w.eqlist[e + 1], c);   // prefetch
         OSOT_SUB_BEGIN();
         if (h == 0) V0[c] = a;
@@ -990,13 +1010,13 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
     // the diagonal of H^-1 does (hinv > 0 selects that in the dependency test)
     const double hinv = (used_nullspace && valid) ? fast_rcp(hdiag) : 0.0;
     return gi_inequalities<NP, PROF>(w3, nrows, x, iq, me, Aq, uq, iters, has_box, lb, ub, max_iter, used_nullspace, hinv,
-                                     x_out, iters_out, prof);
+                                     have_prev, xprev, slack_out, x_out, iters_out, prof);
 }
 
 template <int NP, bool PROF>
 __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq, const int me, int Aq, double uq,
                                int iters, bool has_box, double& lb, double& ub, int max_iter, bool diag_dd, double hinv,
-                               double& x_out, int& iters_out, long long* prof) {
+                               bool have_prev, double xprev, double& slack_out, double& x_out, int& iters_out, long long* prof) {
     constexpr int S = WaveCtx<NP>::S;
     const int c = w.c, h = w.h, n = w.n;
     const bool valid = c < n;
@@ -1029,6 +1049,14 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
     wave_sync();
     int status = QP_SOLVED;
     const int kNone = 0x7fffffff;
+    // first trip of a cascade level below the first: the scan below runs once on x_prev and, instead of looking for
+    // violations, gives every inequality the feasibility margin described at kFeasMargin (task-local rows of this level
+    // excepted: x_prev owes them nothing).  The moved bounds stay moved for the lower levels of the instance.
+    bool margin_pass = have_prev;
+    if (margin_pass && has_box && valid) {
+        if (lb > -kInfty) lb = fmin(lb, xprev - kFeasMargin * fmax(1.0, fabs(lb)));
+        if (ub < kInfty) ub = fmax(ub, xprev + kFeasMargin * fmax(1.0, fabs(ub)));
+    }
     for (;;) {
         OSOT_SUB_BEGIN();
         // most violated constraint outside the working set (eiquadprog.hpp:300-315 picks the same)
@@ -1047,7 +1075,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
         // unit rows (implicit e_i rows: acceleration joint/velocity limits) are checked 64 rows at a time,
         // lane = row, against a staged copy of x: they cost no reduction at all
         if (any_unit || n_gen > 0) {
-            if (h == 0) V0[c] = x;
+            if (h == 0) V0[c] = margin_pass ? xprev : x;
             wave_sync();
         }
         if (any_unit) {
@@ -1061,6 +1089,12 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                     if ((pr & 1ull) && st != 3 && idx < n) {
                         const double lo = w.rlo[r], up = w.rup[r];
                         const double ax = V0[idx];
+                        if (margin_pass) {
+                            if (w.rsrc[r] != -2) {
+                                if (lo > -kInfty) w.rlo[r] = fmin(lo, ax - kFeasMargin * fmax(1.0, fabs(lo)));
+                                if (up < kInfty) w.rup[r] = fmax(up, ax + kFeasMargin * fmax(1.0, fabs(up)));
+                            }
+                        } else {
                         if (st != 1 && lo > -kInfty) {
                             const double s = ax - lo;
                             if (s < -kViolTol * fmax(1.0, fabs(lo)) && s < cand) { cand = s; code = 2 * n + 2 * r; }
@@ -1068,6 +1102,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                         if (st != 2 && up < kInfty) {
                             const double s = up - ax;
                             if (s < -kViolTol * fmax(1.0, fabs(up)) && s < cand) { cand = s; code = 2 * n + 2 * r + 1; }
+                        }
                         }
                     }
                 }
@@ -1110,6 +1145,12 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                 const double ax = (a0 + a1) + (a2 + a3);
                 const int st = w.rowstate[r];
                 const double lo = w.rlo[r], up = w.rup[r];
+                if (margin_pass) {
+                    if (w.rsrc[r] != -2) {
+                        if (lo > -kInfty) w.rlo[r] = fmin(lo, ax - kFeasMargin * fmax(1.0, fabs(lo)));
+                        if (up < kInfty) w.rup[r] = fmax(up, ax + kFeasMargin * fmax(1.0, fabs(up)));
+                    }
+                } else {
                 if (st != 1 && lo > -kInfty) {
                     const double s = ax - lo;
                     if (s < -kViolTol * fmax(1.0, fabs(lo)) && s < cand) { cand = s; code = 2 * n + 2 * r; }
@@ -1118,8 +1159,10 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                     const double s = up - ax;
                     if (s < -kViolTol * fmax(1.0, fabs(up)) && s < cand) { cand = s; code = 2 * n + 2 * r + 1; }
                 }
+                }
             }
         }
+        if (margin_pass) { margin_pass = false; wave_sync(); continue; }   // bounds moved: now the real scan
         // all 64 lanes when the unit-row / stored-row passes ran (they hold different rows in the two halves);
         // box candidates alone are replicated over the halves, so the 32-lane network does
         if (any_unit || n_gen > 0 || NP == 64) colargmin<64>(cand, code);
@@ -1211,7 +1254,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                 // QP is infeasible (eiquadprog.hpp:376-382).
                 const double bmag = ip_box ? fabs(bcast((ip < n) ? lb : ub, ip_var))
                                            : fabs((ip & 1) ? w.rup[ip_row] : w.rlo[ip_row]);
-                if (-s_ip <= kSlackTol * fmax(1.0, bmag)) {
+                if (-s_ip <= fmin(kSlackTol * fmax(1.0, bmag), kSlackCap)) {
                     // accepted as satisfied: the LOWER levels must accept the same point (their optimality rows pin x
                     // to it), so the bound is relaxed by what was accepted for the rest of this instance's cascade --
                     // otherwise they find the constraint violated by that much, trade it against a bound and end
@@ -1220,7 +1263,8 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                     if (ip_box) { if (c == ip_var) { if (ip < n) lb -= relax; else ub += relax; } }
                     else if (c == 0 && h == 0) { if (ip & 1) w.rup[ip_row] += relax; else w.rlo[ip_row] -= relax; }
                     wave_sync();
-                    degenerate_done = true; break;
+                    slack_out = fmax(slack_out, -s_ip);
+                    degenerate_done = true; break;   // this constraint now counts as satisfied; the scan goes on
                 }
                 failed = true; break;
             }
@@ -1258,7 +1302,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
             if (++iters > max_iter) { status = QP_MAX_ITER; failed = true; break; }
         }
         if (failed) { if (status == QP_SOLVED) status = QP_INFEASIBLE; break; }
-        if (degenerate_done) break;
+        if (degenerate_done) continue;   // (bounded: every trip of the outer loop counts against max_iter)
     }
     OSOT_PH_END(PH_INEQ);
     x_out = x;

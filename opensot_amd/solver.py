@@ -66,6 +66,7 @@ class BatchedStack:
         self.x_levels = torch.zeros((B, L, n), **f64) if want_levels else None
         self.status = torch.zeros((B,), dtype=torch.int32, device=self.device)
         self.iterations = torch.zeros((B,), dtype=torch.int32, device=self.device)
+        self.accepted_slack = torch.zeros((B,), **f64)   # largest violation accepted as round-off, per instance
         self._leaf_keep = None
         self.level_active = None   # iHQP::setActiveStack (iHQP.cpp:391-395)
 
@@ -157,6 +158,7 @@ class BatchedStack:
         qb.dq, qb.x_levels = _dev_ptr(self.dq), _dev_ptr(self.x_levels)
         qb.status, qb.iterations = _dev_ptr(self.status), _dev_ptr(self.iterations)
         qb.b_reg = _dev_ptr(self.b_reg)
+        qb.accepted_slack = _dev_ptr(self.accepted_slack)
         if self.level_active is not None:
             self._act = (C.c_ubyte * self.plan.L)(*[1 if a else 0 for a in self.level_active])
             qb.level_active = C.cast(self._act, C.c_void_p)

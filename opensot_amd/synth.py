@@ -258,7 +258,7 @@ def computed_torque(leaf, x):
 
 
 def make_generic_stack(B, n, level_rows, n_eq=0, n_ineq=0, seed=0, box=0.5, duplicate_eq_in_level=None,
-                       postural_last=True, eps_factor=1e6, n_local=0, local_level=0, unit_box=None):
+                       postural_last=True, eps_factor=1e6, n_local=0, local_level=0, unit_box=None, local_equality=False):
     """small generic stacks (tasks::GenericTask blocks, GenericConstraint rows, generic box) for robot-free tests:
     e.g. a Panda-like 7-variable 2-level stack, or stacks whose optimality rows duplicate global equality rows
     (the `<< (l_sole + r_sole)` situation of examples/cpp/coman_ik.cpp:442 where 39 equality rows meet 35
@@ -288,7 +288,10 @@ def make_generic_stack(B, n, level_rows, n_eq=0, n_ineq=0, seed=0, box=0.5, dupl
     if n_local:   # task-local rows (`task << constraint`): tight enough to bind at their level
         Cl = rng.normal(0.0, 0.5, size=(B, n_local, n))
         rowblocks.append(Rows(abi.ROWS_GENERIC, n_local, name="task_local", level=local_level))
-        rleaf.append((Cl, -rng.uniform(0.001, 0.02, size=(B, n_local)), rng.uniform(0.001, 0.02, size=(B, n_local))))
+        lol, upl = -rng.uniform(0.001, 0.02, size=(B, n_local)), rng.uniform(0.001, 0.02, size=(B, n_local))
+        if local_equality:   # `task << equality`: a row the solution of the level above does NOT satisfy
+            upl = lol.copy()
+        rleaf.append((Cl, lol, upl))
     if unit_box is not None:   # (level or None, half width): a box as unit rows; with a level: a task-local bound
         lvl, hw = unit_box
         rowblocks.append(Rows(abi.ROWS_UNIT_GENERIC, n, name="unit_box", first_col=0, level=lvl))

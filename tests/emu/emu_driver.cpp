@@ -21,6 +21,7 @@ extern "C" __attribute__((visibility("default"))) int emu_ihqp_solve(const osot_
     D.C = b->C; D.lo = b->lo; D.up = b->up; D.l = b->l; D.u = b->u;
     D.dq = b->dq; D.x_levels = b->x_levels; D.status = b->status; D.iterations = b->iterations;
     D.b_reg = plan->has_regularisation ? b->b_reg : nullptr;
+    D.accepted_slack = b->accepted_slack;
     const unsigned grid = (unsigned)b->B;
     if (T == 32) emu::launch(osot_cascade_kernel<32, false>, grid, lds, 64, P, D);
     else emu::launch(osot_cascade_kernel<64, false>, grid, lds, 64, P, D);

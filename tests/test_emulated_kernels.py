@@ -4,7 +4,7 @@ device algorithm is debugged in the build container; the -m gpu tests repeat the
 import numpy as np
 import pytest
 
-from helpers import emu_cascade, emu_qp, kkt_check, load_golden, random_qp
+from helpers import answer_is_acceptable, default_eps_stuck_instances, emu_cascade, emu_qp, kkt_check, load_golden, random_qp
 from opensot_amd import synth
 
 EPS = 1e3 * 2.221e-16
@@ -351,6 +351,44 @@ def test_task_local_constraint_rows(n, rows, local_level, n_local, oracle):
     plan_g, leaf_g = mk(None)
     glob = oracle.ihqp_solve_batch(oracle.assemble(plan_g, leaf_g), oracle.BE_EIQP_EQ, nthreads=1)
     assert np.abs(glob["x_levels"] - ref["x_levels"]).max() > 1e-6
+
+
+@pytest.mark.parametrize("n,rows", [(12, [9]), (16, [5, 6]), (32, [10, 17]), (32, [3, 24])])
+def test_task_local_equality_on_a_postural_last_level(n, rows, oracle):
+    """a task-local EQUALITY at a Postural last level (diagonal Hessian, many optimality rows): the previous level's
+    solution does not satisfy that row, so the null-space shortcut -- which projects from x_prev and assumes every
+    equality holds there -- must not be taken (it used to return SOLVED with the row violated by 0.1 .. 0.3)"""
+    plan, leaf = synth.make_generic_stack(6, n, rows, n_eq=0, n_ineq=2, seed=21, n_local=1, local_level=len(rows), local_equality=True)
+    asm = oracle.assemble(plan, leaf)
+    dq, xl, st, it = emu_cascade(plan, asm)
+    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+    assert (st == 0).all() and (ref["status"] == 1).all()
+    Cl, lo, up = leaf["rows"][-1]
+    assert np.abs(np.einsum("bri,bi->br", Cl, dq) - lo).max() < 1e-9      # the local equality holds at its level
+    assert np.abs(dq - ref["dq"]).max() < 1e-9
+    if oracle.ref_available():
+        rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1, termination_tolerance=10 * 2.221e-16)
+        ok = rq["status"] == 1
+        assert ok.any() and np.abs(dq[ok] - rq["dq"][ok]).max() < 1e-7
+
+
+def test_default_eps_stuck_instances(oracle):
+    """the five closed-loop instances at iHQP's default eps (factor 2e2) that round 1 reported INFEASIBLE: every level's
+    optimality rows are now posed relative to the previous level's solution, which is therefore an exactly feasible point
+    of the level (osot_qp_core.h: kFeasMargin); all five solve, and each answer is within 1e-6 of a witness or feasible
+    and lexicographically not worse than the witnesses (which disagree with each other by up to 2e-2 here)"""
+    plan, asm = default_eps_stuck_instances()
+    dq, xl, st, it = emu_cascade(plan, asm)
+    assert (st == 0).all()
+    if oracle.ref_available():
+        rx = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1, termination_tolerance=10 * 2.221e-16)
+        rd = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
+        re_ = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+        for i in range(asm["B"]):
+            ok, why = answer_is_acceptable(asm, i, dq[i], [("qpOASES exact", rx["dq"][i], rx["status"][i] == 1),
+                                                            ("qpOASES", rd["dq"][i], rd["status"][i] == 1),
+                                                            ("eiQuadProg", re_["dq"][i], re_["status"][i] == 1)])
+            assert ok, (i, why)
 
 
 def test_collision_instance_from_the_closed_loop(oracle):

@@ -306,3 +306,41 @@ def test_task_local_bounds_as_unit_rows_gpu(n, rows, oracle, gpu_device):
                        np.where(rx["status"] == 1, np.abs(dq - rx["dq"]).max(axis=1), np.inf))[solvable]
         assert e.max() < 1e-6
     assert np.abs(xl[solvable][:, 0]).max() <= hw + 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,rows", [(12, [9]), (16, [5, 6]), (32, [10, 17]), (32, [3, 24])])
+def test_task_local_equality_on_a_postural_last_level_gpu(n, rows, oracle, gpu_device):
+    """a task-local EQUALITY at a Postural last level: the null-space shortcut (which assumes x_prev satisfies every
+    equality) must not be taken -- see the emulator test of the same name"""
+    B = 96
+    plan, leaf = synth.make_generic_stack(B, n, rows, n_eq=0, n_ineq=2, seed=21, n_local=1, local_level=len(rows), local_equality=True)
+    asm = oracle.assemble(plan, leaf)
+    dq, xl, status, it, _ = _run(plan, leaf)
+    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+    okr = ref["status"] == 1   # (a random equality at the last level is infeasible for a few instances: witness and product agree)
+    assert (status[okr] == 0).all() and okr.mean() > 0.5
+    Cl, lo, up = leaf["rows"][-1]
+    assert np.abs(np.einsum("bri,bi->br", Cl, dq) - lo)[status == 0].max() < 1e-9
+    assert np.abs(dq[okr] - ref["dq"][okr]).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_default_eps_stuck_instances_gpu(oracle, gpu_device):
+    """tests/golden/default_eps_stuck_instances.npz on hardware (see the emulator test of the same name)"""
+    from helpers import answer_is_acceptable, default_eps_stuck_instances
+    plan, asm = default_eps_stuck_instances()
+    B = asm["B"]
+    st = BatchedStack(plan, B, device=0)
+    st.load_assembled(asm); st.solve(B)
+    torch.cuda.synchronize()
+    assert (st.status[:B].cpu().numpy() == 0).all()
+    dq = st.dq[:B].cpu().numpy()
+    re_ = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+    wit = [("eiQuadProg", re_)]
+    if oracle.ref_available():
+        wit += [("qpOASES exact", oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1, termination_tolerance=10 * 2.221e-16)),
+                ("qpOASES", oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1))]
+    for i in range(B):
+        ok, why = answer_is_acceptable(asm, i, dq[i], [(nm, r["dq"][i], r["status"][i] == 1) for nm, r in wit])
+        assert ok, (i, why)
