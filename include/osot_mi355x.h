@@ -39,7 +39,8 @@ extern "C" {
 #define OSOT_MAX_LEVELS 8
 #define OSOT_MAX_TASKS 8      /* leaf task blocks per level   */
 #define OSOT_MAX_BOUNDS 4     /* box-bound producers          */
-#define OSOT_MAX_ROWBLOCKS 4  /* global constraint-row blocks */
+#define OSOT_MAX_ROWBLOCKS 8  /* constraint-row blocks (global and task-local) */
+#define OSOT_MAX_BAND_ROWS 6  /* rows of a task used as a constraint (TaskToConstraint error band) */
 #define OSOT_MAX_VARS 64      /* one lane per variable        */
 
 /* error codes (the reference returns bool / throws std::runtime_error) */
@@ -94,6 +95,16 @@ typedef struct {
     unsigned long long row_mask;
     int parent_rows;
     double sub_lambda;
+    /* velocity::Cartesian with a BODY Jacobian (Cartesian::setIsBodyJacobian, src/tasks/velocity/Cartesian.cpp:93-100):
+     * A and b are both rotated by Ad(R') with R the actual orientation.  The producer writes the rotated Jacobian
+     * (osot_kin_desc.frame_body does); the update rotates b.  0 = world frame. */
+    int body_frame;
+    /* non-diagonal weight matrix (Task::setWeight(W) with a full W, include/OpenSoT/Task.h:273-300; in an aggregate the
+     * level's W is blockdiag(weight_i * W_i), src/tasks/Aggregated.cpp:265-279).  1: the block's W_i [B][rows][rows]
+     * comes with the leaf inputs (osot_leaf_ptrs.W); the update then forms W_k A_k and W_k b_k for the whole level
+     * (osot_assembled_out.WA / Wb) and the cascade takes them as the left operand of H = A'(WA), g = -A'(Wb).  A
+     * Postural block with dense_weight is stored like any other block (its unit rows are written by the producer). */
+    int dense_weight;
 } osot_task_desc;
 
 typedef struct {
@@ -150,7 +161,12 @@ typedef struct {
     double dT, p;    /* acceleration limits: time step and horizon factor (dt = dT*p) */
     double mu;       /* friction coefficient */
     double task_lambda, task_orientation_gain;   /* OSOT_ROWS_TASK_*: gains of the underlying task */
-    double err_lb, err_ub;                       /* OSOT_ROWS_TASK_*: TaskToConstraint's error band (scalars) */
+    double err_lb[OSOT_MAX_BAND_ROWS], err_ub[OSOT_MAX_BAND_ROWS];   /* OSOT_ROWS_TASK_*: TaskToConstraint's error band,
+                        one pair per row (err_lb / err_ub are vectors, src/constraints/TaskToConstraint.cpp:34-52, 61-68) */
+    int task_body_frame;   /* OSOT_ROWS_TASK_CARTESIAN: the task has a body Jacobian (see osot_task_desc.body_frame) */
+    int n_candidates;      /* OSOT_ROWS_COLLISION: collision pairs supplied per instance (0 = rows).  With more candidates
+                              than rows the `rows` CLOSEST pairs are taken, in order of distance
+                              (getOrderedCollisionPairIndices, src/constraints/velocity/CollisionAvoidance.cpp:120-131) */
     int only_level;  /* 0 = global rows: constrain every level (AutoStack `<<`, iHQP.cpp:191-193).  k + 1 = TASK-LOCAL
                         rows of level k (`task << constraint`, Task::getConstraints(), iHQP.cpp:190, 282-287): they
                         constrain the QP of level k only; at every other level they are absent */
@@ -200,6 +216,9 @@ typedef struct {
     int* iterations;                    /* out [B] active-set iterations summed over levels; may be NULL */
     const double* b_reg;                /* [B][regularisation.rows] b of the regularisation task; NULL iff the plan
                                            has none */
+    const double* WA[OSOT_MAX_LEVELS];  /* [B][ma_k][n] W_k A_k and                                              */
+    const double* Wb[OSOT_MAX_LEVELS];  /* [B][m_k]     W_k b_k of a level with a non-diagonal W_k (written by
+                                           osot_stack_update); NULL = diagonal W_k (w[k])                          */
     double* accepted_slack;             /* out [B], may be NULL: the largest constraint violation that a level of the
                                            instance accepted as round-off of the levels above it (no direction left and
                                            no multiplier to trade; at most min(1e-6 * max(1, |bound|), 1e-5)); 0 = none.
@@ -231,8 +250,9 @@ typedef struct {
  *   ROWS_TASK_CARTESIAN / ROWS_TASK_COM : as TASK_CARTESIAN / TASK_COM (the 6 / 3 rows are written by the producer into C)
  * Task Jacobians are NOT passed here: the producer writes them straight into their row range of
  * osot_qp_batch.A[k] (zero-copy stacking; the reference copies them twice through MatrixPiler,
- * src/tasks/Aggregated.cpp:113-132). */
-typedef struct { const double *p0, *p1, *p2; } osot_leaf_ptrs;
+ * src/tasks/Aggregated.cpp:113-132).
+ *   any task with dense_weight : W = the block's weight matrix [B][rows][rows] (row-major) */
+typedef struct { const double *p0, *p1, *p2, *W; } osot_leaf_ptrs;
 
 typedef struct {
     int B;
@@ -253,6 +273,10 @@ typedef struct {
     double* l;
     double* u;
     double* b_reg;                      /* [B][regularisation.rows]; NULL iff the plan has no regularisation task */
+    double* WA[OSOT_MAX_LEVELS];        /* [B][ma_k][n], [B][m_k]: required for the levels that hold a dense_weight block  */
+    double* Wb[OSOT_MAX_LEVELS];
+    const double* A[OSOT_MAX_LEVELS];   /* the stacked Jacobians A_k the producer wrote (read to form W_k A_k); required for
+                                           the same levels */
 } osot_assembled_out;
 
 typedef struct osot_solver osot_solver;
@@ -293,6 +317,11 @@ int osot_solver_set_timing(osot_solver* s, int enabled);
 #define OSOT_SCHEDULE_IN_ORDER 0
 #define OSOT_SCHEDULE_LONGEST_FIRST 1
 int osot_solver_set_schedule(osot_solver* s, int mode);
+/* Task::setActive (include/OpenSoT/Task.h:232-239, 375-400): an inactive task's A is zero -- it adds nothing to H and g
+ * of its level and its optimality rows are void for the levels below.  The producer's Jacobian rows stay untouched in
+ * A_k; the cascade ignores them.  Takes effect at the next osot_ihqp_solve.  (Column masks, Task::setActiveJointsMask,
+ * are the producer's: osot_kin_desc.frame_col_mask.) */
+int osot_solver_set_task_active(osot_solver* s, int level, int task, int active);
 /* diagnostic: run the cascade once through the instrumented instantiation of the kernel and write, per
  * instance, OSOT_N_PHASES shader-clock cycle counts (H/g build, Cholesky, L^-1, substitution, equality
  * phase, inequality loop, optimality rhs, total, then four sub-phases of the equality adds: J'a,
@@ -367,6 +396,13 @@ typedef struct {
     int pair_joint[OSOT_KIN_MAX_PAIRS][2];       /* joints whose links carry the two shapes                      */
     double pair_seg[OSOT_KIN_MAX_PAIRS][2][6];   /* capsule axis end points (a0, a1) in that joint's frame       */
     double pair_radius[OSOT_KIN_MAX_PAIRS][2];
+    /* per-frame options of the Jacobian the producer writes (what Task::update applies after _update(), Task.h:375-400,
+     * and Cartesian's own frame choice, Cartesian.cpp:73-100) */
+    int frame_body[OSOT_KIN_MAX_FRAMES];         /* 1: BODY Jacobian Ad(R_f') J (Cartesian::setIsBodyJacobian,
+                                                    Cartesian.cpp:93-100; pair with osot_task_desc.body_frame)       */
+    unsigned long long frame_col_mask[OSOT_KIN_MAX_FRAMES]; /* Task::setActiveJointsMask (Task.h:129-139): bit j CLEAR =
+                                                    column j of the frame's Jacobian is written as zero; 0 = no mask  */
+    unsigned long long com_col_mask;             /* the same for the CoM Jacobian                                    */
 } osot_kin_desc;
 typedef struct {
     int B;
@@ -386,6 +422,34 @@ typedef struct osot_kin osot_kin;
 int osot_kin_create(const osot_kin_desc* desc, int device, osot_kin** out);
 int osot_kin_destroy(osot_kin* k);
 int osot_kinematics(osot_kin* k, const osot_kin_batch* batch, void* hip_stream);
+
+/* ---- inverse-dynamics formulation (BASELINE config 5): x = [qddot (nv); contact forces / wrenches] -------------
+ * (src/utils/InverseDynamics.cpp:12-28).  The matrices that are pure copies of model quantities are written by these
+ * producers straight into their row ranges of the stacked A_k / C (zero-copy, like the kinematics producer's Jacobians);
+ * the model quantities themselves (inertia matrix B, non-linear term h, contact Jacobians) come from the caller's
+ * dynamics library, as they come from XBot::ModelInterface in the reference. */
+#define OSOT_ID_MAX_FORCE_VARS 24
+typedef struct {
+    int B, nv, n_contacts, contact_dim;   /* contact_dim: 3 = point contact (force), 6 = surface contact (wrench)
+                                             (InverseDynamics.cpp:16-27); nv + n_contacts * contact_dim <= OSOT_MAX_VARS */
+    const double* Bm;                     /* [B][nv][nv] inertia matrix (symmetric)                                      */
+    const double* h;                      /* [B][nv] non-linear term                                                     */
+    const double* Jc;                     /* [B][n_contacts][contact_dim][nv] first contact_dim rows of each contact's
+                                             Jacobian                                                                    */
+    int floating_base;                    /* computedTorque checks the first six rows of tau (InverseDynamics.cpp:83-92)  */
+} osot_id_model;
+/* rows [B_u, -J_f'] of acceleration::DynamicFeasibility (DynamicFeasibility.cpp:22-46; 6 rows) and [B, -Jc'] of
+ * TorqueLimits (TorqueLimits.cpp:25-46; nv rows): C_dyn / C_tau point at the block's first row in instance 0 (either may
+ * be NULL), *_stride = doubles from one instance to the next (nc_stored * n).  Plus n_tasks task matrices [J_i 0]
+ * (acceleration::Cartesian / CoM, Cartesian.cpp:152-160): J[i] is [B][J_rows[i]][nv], A_dst[i] the block's first row in
+ * instance 0 of A_k, A_stride[i] = ma_k * n. */
+int osot_id_rows(const osot_id_model* m, double* C_dyn, long long dyn_stride, double* C_tau, long long tau_stride,
+                 int n_tasks, const double* const* J, const int* J_rows, double* const* A_dst, const long long* A_stride,
+                 void* hip_stream);
+/* InverseDynamics::computedTorque (InverseDynamics.cpp:57-96): tau[B][nv] = B qddot + h - sum_c Jc' F_c from the solved
+ * x[B][n]; ok[B] (may be NULL) = 0 where a floating-base row of tau exceeds fb_tol (the reference uses 10e-3 and
+ * returns false). */
+int osot_computed_torque(const osot_id_model* m, const double* x, double* tau, int* ok, double fb_tol, void* hip_stream);
 
 /* ---- multi-GPU: collect solved dq shards ---------------------------------------------------- */
 typedef struct osot_comm osot_comm;

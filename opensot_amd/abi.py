@@ -5,7 +5,8 @@ Host-side plumbing only: the product's arithmetic lives in opensot_amd/csrc (HIP
 import ctypes as C
 import os
 
-MAX_LEVELS, MAX_TASKS, MAX_BOUNDS, MAX_ROWBLOCKS, MAX_VARS = 8, 8, 4, 4, 64
+MAX_LEVELS, MAX_TASKS, MAX_BOUNDS, MAX_ROWBLOCKS, MAX_VARS = 8, 8, 4, 8, 64
+MAX_BAND_ROWS, ID_MAX_FORCE_VARS = 6, 24
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NOT_SOLVED, ERR_COMM = range(6)
 STATUS_SOLVED, STATUS_INFEASIBLE, STATUS_MAX_ITER, STATUS_NOT_PD = range(4)
@@ -23,7 +24,8 @@ ip = C.POINTER(C.c_int)
 class TaskDesc(C.Structure):
     _fields_ = [("kind", C.c_int), ("rows", C.c_int), ("weight", C.c_double),
                 ("lambda_", C.c_double), ("orientation_gain", C.c_double), ("lambda2", C.c_double),
-                ("row_mask", C.c_ulonglong), ("parent_rows", C.c_int), ("sub_lambda", C.c_double)]
+                ("row_mask", C.c_ulonglong), ("parent_rows", C.c_int), ("sub_lambda", C.c_double),
+                ("body_frame", C.c_int), ("dense_weight", C.c_int)]
 
 
 class LevelDesc(C.Structure):
@@ -38,8 +40,9 @@ class RowsDesc(C.Structure):
     _fields_ = [("kind", C.c_int), ("rows", C.c_int), ("d_threshold", C.c_double),
                 ("detection_threshold", C.c_double), ("bound_scaling", C.c_double),
                 ("first_col", C.c_int), ("dT", C.c_double), ("p", C.c_double), ("mu", C.c_double),
-                ("task_lambda", C.c_double), ("task_orientation_gain", C.c_double), ("err_lb", C.c_double), ("err_ub", C.c_double),
-                ("only_level", C.c_int)]
+                ("task_lambda", C.c_double), ("task_orientation_gain", C.c_double),
+                ("err_lb", C.c_double * MAX_BAND_ROWS), ("err_ub", C.c_double * MAX_BAND_ROWS),
+                ("task_body_frame", C.c_int), ("n_candidates", C.c_int), ("only_level", C.c_int)]
 
 
 class PlanDesc(C.Structure):
@@ -59,11 +62,12 @@ class QpBatch(C.Structure):
                 ("level_active", C.c_void_p),
                 ("dq", C.c_void_p), ("x_levels", C.c_void_p),
                 ("status", C.c_void_p), ("iterations", C.c_void_p), ("b_reg", C.c_void_p),
+                ("WA", C.c_void_p * MAX_LEVELS), ("Wb", C.c_void_p * MAX_LEVELS),
                 ("accepted_slack", C.c_void_p)]
 
 
 class LeafPtrs(C.Structure):
-    _fields_ = [("p0", C.c_void_p), ("p1", C.c_void_p), ("p2", C.c_void_p)]
+    _fields_ = [("p0", C.c_void_p), ("p1", C.c_void_p), ("p2", C.c_void_p), ("W", C.c_void_p)]
 
 
 class LeafBatch(C.Structure):
@@ -76,7 +80,13 @@ class LeafBatch(C.Structure):
 class AssembledOut(C.Structure):
     _fields_ = [("b", C.c_void_p * MAX_LEVELS), ("w", C.c_void_p * MAX_LEVELS),
                 ("C", C.c_void_p), ("lo", C.c_void_p), ("up", C.c_void_p),
-                ("l", C.c_void_p), ("u", C.c_void_p), ("b_reg", C.c_void_p)]
+                ("l", C.c_void_p), ("u", C.c_void_p), ("b_reg", C.c_void_p),
+                ("WA", C.c_void_p * MAX_LEVELS), ("Wb", C.c_void_p * MAX_LEVELS), ("A", C.c_void_p * MAX_LEVELS)]
+
+
+class IdModel(C.Structure):
+    _fields_ = [("B", C.c_int), ("nv", C.c_int), ("n_contacts", C.c_int), ("contact_dim", C.c_int),
+                ("Bm", C.c_void_p), ("h", C.c_void_p), ("Jc", C.c_void_p), ("floating_base", C.c_int)]
 
 
 # every symbol include/osot_mi355x.h declares (tests/test_abi_symbols.py checks the .so exports all)
@@ -92,7 +102,9 @@ class KinDesc(C.Structure):
                 ("frame_joint", C.c_int * KIN_MAX_FRAMES), ("frame_R", (C.c_double * 9) * KIN_MAX_FRAMES),
                 ("frame_p", (C.c_double * 3) * KIN_MAX_FRAMES), ("n_pairs", C.c_int),
                 ("pair_joint", (C.c_int * 2) * KIN_MAX_PAIRS), ("pair_seg", ((C.c_double * 6) * 2) * KIN_MAX_PAIRS),
-                ("pair_radius", (C.c_double * 2) * KIN_MAX_PAIRS)]
+                ("pair_radius", (C.c_double * 2) * KIN_MAX_PAIRS),
+                ("frame_body", C.c_int * KIN_MAX_FRAMES), ("frame_col_mask", C.c_ulonglong * KIN_MAX_FRAMES),
+                ("com_col_mask", C.c_ulonglong)]
 
 
 class KinBatch(C.Structure):
@@ -107,7 +119,8 @@ SYMBOLS = [
     "osot_plan_validate", "osot_plan_level_rows", "osot_plan_constraint_rows",
     "osot_plan_stored_constraint_rows",
     "osot_solver_create", "osot_solver_destroy", "osot_stack_update", "osot_ihqp_solve",
-    "osot_solver_kernel_time_ms", "osot_solver_set_timing", "osot_solver_set_schedule", "osot_kin_create", "osot_kin_destroy", "osot_kinematics", "osot_solver_profile_phases",
+    "osot_solver_kernel_time_ms", "osot_solver_set_timing", "osot_solver_set_schedule", "osot_solver_set_task_active",
+    "osot_id_rows", "osot_computed_torque", "osot_kin_create", "osot_kin_destroy", "osot_kinematics", "osot_solver_profile_phases",
     "osot_backend_create", "osot_backend_destroy", "osot_backend_init_problem",
     "osot_backend_update_task", "osot_backend_update_constraints", "osot_backend_update_bounds",
     "osot_backend_solve", "osot_backend_get_solution", "osot_backend_get_objective",
@@ -154,6 +167,9 @@ def lib():
     L.osot_solver_kernel_time_ms.argtypes = [vp, C.c_int, dp, ip]
     L.osot_solver_set_timing.argtypes = [vp, C.c_int]
     L.osot_solver_set_schedule.argtypes = [vp, C.c_int]
+    L.osot_solver_set_task_active.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.osot_id_rows.argtypes = [C.POINTER(IdModel), vp, C.c_longlong, vp, C.c_longlong, C.c_int, vp, vp, vp, vp, vp]
+    L.osot_computed_torque.argtypes = [C.POINTER(IdModel), vp, vp, vp, C.c_double, vp]
     L.osot_kin_create.argtypes = [C.POINTER(KinDesc), C.c_int, C.POINTER(vp)]
     L.osot_kin_destroy.argtypes = [vp]
     L.osot_kinematics.argtypes = [vp, C.POINTER(KinBatch), vp]

@@ -9,7 +9,7 @@ namespace osot {
 
 // a Postural block has A = [I 0] (Postural.cpp:37): implicit, never stored -- unless it is a SubTask of one
 inline bool task_is_implicit(const osot_task_desc& t) {
-    return (t.kind == OSOT_TASK_POSTURAL || t.kind == OSOT_TASK_ACC_POSTURAL) && t.row_mask == 0ull;
+    return (t.kind == OSOT_TASK_POSTURAL || t.kind == OSOT_TASK_ACC_POSTURAL) && t.row_mask == 0ull && !t.dense_weight;
 }
 // rows of the parent of a sub-task (the kind's own size unless given)
 inline int task_parent_rows(const osot_task_desc& t, int n) {
@@ -91,11 +91,13 @@ inline int plan_validate(const osot_plan_desc* p, const char** why) {
                     if (t.rows != 3) { *why = "CoM task must have 3 rows"; return OSOT_ERR_INVALID; } break;
                 case OSOT_TASK_POSTURAL: case OSOT_TASK_ACC_POSTURAL:
                     if (t.rows > p->n) { *why = "Postural task cannot have more than n rows"; return OSOT_ERR_INVALID; }
-                    if (j != lv.n_tasks - 1) { *why = "Postural must be the last block of its level"; return OSOT_ERR_UNSUPPORTED; }
+                    if (task_is_implicit(t) && j != lv.n_tasks - 1) { *why = "an implicit Postural block must be the last block of its level"; return OSOT_ERR_UNSUPPORTED; }
                     break;
                 default: *why = "unknown task kind"; return OSOT_ERR_UNSUPPORTED;
             }
             if (!(t.weight >= 0.0)) { *why = "negative task weight"; return OSOT_ERR_INVALID; }
+            if (t.body_frame && t.kind != OSOT_TASK_CARTESIAN) { *why = "body_frame is an option of velocity::Cartesian"; return OSOT_ERR_INVALID; }
+            if (t.dense_weight && t.rows > 64) { *why = "dense weight: at most 64 rows per block"; return OSOT_ERR_INVALID; }
         }
     }
     if (p->has_regularisation) {   // identity-Jacobian regularisation only: Hr is folded into the diagonal
@@ -103,6 +105,7 @@ inline int plan_validate(const osot_plan_desc* p, const char** why) {
         if (t.kind != OSOT_TASK_GENERIC && t.kind != OSOT_TASK_POSTURAL && t.kind != OSOT_TASK_ACC_POSTURAL) {
             *why = "regularisation task: only identity-Jacobian kinds (generic b with A = [I 0], Postural) are supported"; return OSOT_ERR_UNSUPPORTED; }
         if (t.row_mask != 0ull) { *why = "regularisation task cannot be a sub-task"; return OSOT_ERR_UNSUPPORTED; }
+        if (t.dense_weight || t.body_frame) { *why = "regularisation task: scalar weight, no frame option"; return OSOT_ERR_UNSUPPORTED; }
         if (t.rows < 1 || t.rows > p->n) { *why = "regularisation task: rows out of range (1..n)"; return OSOT_ERR_INVALID; }
         if (!(t.weight >= 0.0)) { *why = "negative task weight"; return OSOT_ERR_INVALID; }
         flat += 1;
@@ -115,8 +118,11 @@ inline int plan_validate(const osot_plan_desc* p, const char** why) {
         if (rb.kind < 0 || rb.kind > OSOT_ROWS_UNIT_GENERIC) { *why = "unknown row-block kind"; return OSOT_ERR_UNSUPPORTED; }
         if (rb.kind == OSOT_ROWS_TASK_CARTESIAN && rb.rows != 6) { *why = "a Cartesian task as a constraint has 6 rows"; return OSOT_ERR_INVALID; }
         if (rb.kind == OSOT_ROWS_TASK_COM && rb.rows != 3) { *why = "a CoM task as a constraint has 3 rows"; return OSOT_ERR_INVALID; }
-        if ((rb.kind == OSOT_ROWS_TASK_CARTESIAN || rb.kind == OSOT_ROWS_TASK_COM) && !(rb.err_ub >= rb.err_lb)) {
-            *why = "Some components of err_ub are smaller than err_lb!!!"; return OSOT_ERR_INVALID; }   // TaskToConstraint.cpp:43
+        if (rb.kind == OSOT_ROWS_TASK_CARTESIAN || rb.kind == OSOT_ROWS_TASK_COM)
+            for (int i = 0; i < rb.rows; ++i) if (!(rb.err_ub[i] >= rb.err_lb[i])) {
+                *why = "Some components of err_ub are smaller than err_lb!!!"; return OSOT_ERR_INVALID; }   // TaskToConstraint.cpp:43
+        if (rb.kind == OSOT_ROWS_COLLISION && (rb.n_candidates < 0 || rb.n_candidates > 256 || (rb.n_candidates > 0 && rb.n_candidates < rb.rows))) {
+            *why = "collision block: n_candidates must be 0 or in rows..256"; return OSOT_ERR_INVALID; }
         if (rb.rows < 1 || rb.rows > 256) { *why = "row block size out of range (1..256)"; return OSOT_ERR_INVALID; }
         if (rb.kind == OSOT_ROWS_DYN_FEASIBILITY && rb.rows != 6) { *why = "DynamicFeasibility has 6 rows"; return OSOT_ERR_INVALID; }
         if (rb.kind == OSOT_ROWS_FRICTION_CONE && (rb.rows % 5 != 0 || rb.first_col < 0 || rb.first_col + 3 * (rb.rows / 5) > p->n)) {
@@ -144,8 +150,9 @@ inline int lds_layout(int NP, int n_rows, int* rows_off, int* rows_cap) {
 }
 
 // returns OSOT_OK and fills P, the padded size NP (32/64) and the dynamic LDS bytes per workgroup (= wave)
+// task_active: [OSOT_MAX_LEVELS][OSOT_MAX_TASKS] flags (Task::setActive), null = all active
 inline int make_dev_plan(const osot_plan_desc& p, const unsigned char* level_active, DevPlan& P, int& NP,
-                         size_t& lds_bytes) {
+                         size_t& lds_bytes, const unsigned char* task_active = nullptr) {
     std::memset(&P, 0, sizeof(P));
     P.n = p.n;
     P.L = p.n_levels;
@@ -173,6 +180,16 @@ inline int make_dev_plan(const osot_plan_desc& p, const unsigned char* level_act
         P.nc_stored = soff;
     }
     for (int k = 0; k < p.n_levels; ++k) P.ident_rows[k] = P.m[k] - P.ma[k];
+    for (int k = 0; k < p.n_levels; ++k) {
+        P.ntask[k] = p.level[k].n_tasks;
+        int off = 0;
+        for (int j = 0; j < p.level[k].n_tasks; ++j) {
+            P.task_off[k][j] = off;
+            off += p.level[k].task[j].rows;
+            if (task_active && !task_active[k * OSOT_MAX_TASKS + j]) P.inactive[k] |= (1u << j);
+        }
+        P.task_off[k][p.level[k].n_tasks] = off;
+    }
     const int nrows_max = P.nc + P.optoff[p.n_levels];
     P.max_iter = p.max_iter > 0 ? p.max_iter : 20 * (p.n + nrows_max) + 100;
     P.eps_abs = p.eps_abs;
@@ -188,6 +205,116 @@ inline int make_dev_plan(const osot_plan_desc& p, const unsigned char* level_act
     total += 3 * cap + cap;
     total += (cap + 7) / 8;
     lds_bytes = (size_t)total * sizeof(double);
+    return OSOT_OK;
+}
+
+// the static part of the update kernel's arguments (uploaded once per solver)
+inline void make_update_plan(const osot_plan_desc& pl, DevUpdatePlan& U) {
+    std::memset(&U, 0, sizeof(U));
+    U.n = pl.n; U.L = pl.n_levels;
+    plan_constraint_rows(&pl, &U.nc);
+    plan_stored_constraint_rows(&pl, &U.nc_stored);
+    int flat = 0;
+    for (int k = 0; k < pl.n_levels; ++k) {
+        plan_level_rows(&pl, k, &U.m[k], &U.ma[k]);
+        int off = 0;
+        for (int j = 0; j < pl.level[k].n_tasks; ++j) {
+            const osot_task_desc& t = pl.level[k].task[j];
+            DevTaskS& d = U.task[flat++];
+            d.level = k; d.kind = t.kind; d.rows = t.rows; d.off = off;
+            d.weight = t.weight; d.lambda = t.lambda; d.ogain = t.orientation_gain; d.lambda2 = t.lambda2;
+            d.mask = t.row_mask; d.prow = task_parent_rows(t, pl.n); d.sublam = t.row_mask ? t.sub_lambda : 1.0;
+            d.body = t.body_frame; d.dense = t.dense_weight;
+            if (t.dense_weight) U.dense_level[k] = 1;
+            off += t.rows;
+        }
+    }
+    if (pl.has_regularisation) {   // one more flat entry; its b goes to out->b_reg (level = -1)
+        const osot_task_desc& t = pl.regularisation;
+        DevTaskS& d = U.task[flat++];
+        d.level = -1; d.kind = t.kind; d.rows = t.rows; d.off = 0;
+        d.weight = t.weight; d.lambda = t.lambda; d.ogain = t.orientation_gain; d.lambda2 = t.lambda2;
+        d.mask = 0ull; d.prow = t.rows; d.sublam = 1.0;
+    }
+    U.ntasks = flat;
+    U.nbounds = pl.n_bounds;
+    for (int j = 0; j < pl.n_bounds; ++j) {
+        U.bound[j].kind = pl.bound[j].kind; U.bound[j].scaling = pl.bound[j].scaling; U.bound[j].dT = pl.bound[j].dT;
+    }
+    U.nrowblocks = pl.n_rowblocks;
+    int roff = 0, soff = 0;
+    for (int j = 0; j < pl.n_rowblocks; ++j) {
+        const osot_rows_desc& r = pl.rowblock[j];
+        DevRowBlockS& d = U.rowblock[j];
+        d.kind = r.kind; d.rows = r.rows; d.off = roff; d.stored_off = soff; d.first_col = r.first_col;
+        d.body = r.task_body_frame; d.ncand = r.n_candidates;
+        d.dT = r.dT; d.p = r.p; d.mu = r.mu; d.lambda = r.task_lambda; d.ogain = r.task_orientation_gain;
+        for (int i = 0; i < OSOT_MAX_BAND_ROWS; ++i) { d.err_lb[i] = r.err_lb[i]; d.err_ub[i] = r.err_ub[i]; }
+        d.d_threshold = r.d_threshold; d.detection_threshold = r.detection_threshold; d.bound_scaling = r.bound_scaling;
+        if (!rows_are_implicit(d.kind)) soff += d.rows;
+        roff += d.rows;
+    }
+}
+
+// the per-call part of the update kernel's arguments: leaf / output pointers, checked against the plan
+inline int make_update_args(const osot_plan_desc& pl, const DevUpdatePlan& PL, const osot_leaf_batch* leaf,
+                            const osot_assembled_out* out, const DevUpdatePlan* dev_plan, DevUpdate& U, const char** why) {
+    std::memset(&U, 0, sizeof(U));
+    U.B = leaf->B;
+    U.plan = dev_plan;
+    int flat = 0;
+    for (int k = 0; k < pl.n_levels; ++k) {
+        if (!out->b[k]) { *why = "out.b[k] is null"; return OSOT_ERR_INVALID; }
+        U.b[k] = out->b[k]; U.w[k] = out->w[k];
+        if (PL.dense_level[k]) {
+            if (!out->WA[k] || !out->Wb[k] || (PL.ma[k] > 0 && !out->A[k]))
+                { *why = "level has a non-diagonal weight: out.WA[k], out.Wb[k] and out.A[k] are required"; return OSOT_ERR_INVALID; }
+            U.WA[k] = out->WA[k]; U.Wb[k] = out->Wb[k]; U.A[k] = out->A[k];
+        }
+        for (int j = 0; j < pl.level[k].n_tasks; ++j) {
+            const osot_task_desc& t = pl.level[k].task[j];
+            DevPtr4& d = U.task[flat++];
+            d.p0 = leaf->task[k][j].p0; d.p1 = leaf->task[k][j].p1; d.p2 = leaf->task[k][j].p2; d.W = leaf->task[k][j].W;
+            if (!d.p0) { *why = "leaf input p0 of a task is null"; return OSOT_ERR_INVALID; }
+            if (t.kind != OSOT_TASK_GENERIC && t.kind != OSOT_TASK_ACC_POSTURAL && !d.p1)
+                { *why = "leaf input p1 of a task is null"; return OSOT_ERR_INVALID; }
+            if (t.dense_weight && !d.W) { *why = "task has dense_weight but its leaf W is null"; return OSOT_ERR_INVALID; }
+        }
+    }
+    if (pl.has_regularisation) {   // one more flat entry; its b goes to out->b_reg (level = -1)
+        const osot_task_desc& t = pl.regularisation;
+        if (!out->b_reg) { *why = "out.b_reg is null"; return OSOT_ERR_INVALID; }
+        DevPtr4& d = U.task[flat++];
+        d.p0 = leaf->regularisation.p0; d.p1 = leaf->regularisation.p1; d.p2 = leaf->regularisation.p2; d.W = nullptr;
+        if (!d.p0) { *why = "leaf input p0 of the regularisation task is null"; return OSOT_ERR_INVALID; }
+        if (t.kind == OSOT_TASK_POSTURAL && !d.p1) { *why = "leaf input p1 of the regularisation task is null"; return OSOT_ERR_INVALID; }
+        U.b_reg = out->b_reg;
+    }
+    for (int j = 0; j < pl.n_bounds; ++j) {
+        DevPtr3& d = U.bound[j];
+        const int kind = pl.bound[j].kind;
+        d.p0 = leaf->bound[j].p0; d.p1 = leaf->bound[j].p1; d.p2 = leaf->bound[j].p2;
+        if (!d.p0) { *why = "leaf input p0 of a bound is null"; return OSOT_ERR_INVALID; }
+        if (kind == OSOT_BOUND_JOINT_LIMITS && (!d.p1 || !d.p2)) { *why = "joint limits need q, q_min, q_max"; return OSOT_ERR_INVALID; }
+        if (kind == OSOT_BOUND_GENERIC && !d.p1) { *why = "generic bound needs l and u"; return OSOT_ERR_INVALID; }
+    }
+    if (pl.n_bounds > 0 && (!out->l || !out->u)) { *why = "out.l/out.u is null"; return OSOT_ERR_INVALID; }
+    U.l = out->l; U.u = out->u;
+    for (int j = 0; j < pl.n_rowblocks; ++j) {
+        DevPtr3& d = U.rows[j];
+        const int kind = pl.rowblock[j].kind;
+        d.p0 = leaf->rows[j].p0; d.p1 = leaf->rows[j].p1; d.p2 = leaf->rows[j].p2;
+        if (!d.p0) { *why = "leaf input p0 of a row block is null"; return OSOT_ERR_INVALID; }
+        if ((kind == OSOT_ROWS_GENERIC || kind == OSOT_ROWS_COLLISION || kind == OSOT_ROWS_TORQUE_LIMITS ||
+             kind == OSOT_ROWS_ACC_JOINT_LIMITS || kind == OSOT_ROWS_ACC_VELOCITY_LIMITS ||
+             kind == OSOT_ROWS_TASK_CARTESIAN || kind == OSOT_ROWS_TASK_COM || kind == OSOT_ROWS_UNIT_GENERIC) && !d.p1)
+            { *why = "leaf input p1 of a row block is null"; return OSOT_ERR_INVALID; }
+        if (kind == OSOT_ROWS_ACC_JOINT_LIMITS && !d.p2) { *why = "acceleration joint limits need qddot_max"; return OSOT_ERR_INVALID; }
+        if (kind == OSOT_ROWS_GENERIC && !d.p2) { *why = "generic rows need C, lo, up"; return OSOT_ERR_INVALID; }
+    }
+    if (PL.nc > 0 && (!out->lo || !out->up)) { *why = "out.lo/up is null"; return OSOT_ERR_INVALID; }
+    if (PL.nc_stored > 0 && !out->C) { *why = "out.C is null"; return OSOT_ERR_INVALID; }
+    U.C = out->C; U.lo = out->lo; U.up = out->up;
     return OSOT_OK;
 }
 

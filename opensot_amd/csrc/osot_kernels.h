@@ -21,13 +21,14 @@
 // column: the halves split every inner product), NP = 64 for n <= 64.  Instance-major fp64 arrays, so a
 // wave's reads of its stacked Jacobian rows are contiguous 8n-byte segments.
 #pragma once
+#include <osot_mi355x.h>   // OSOT_MAX_* (the C-ABI's limits are the kernels' limits)
 #include "osot_qp_core.h"
 
 #define OSOT_KMAX_LEVELS 8
 #define OSOT_KMAX_TASKS 8
 #define OSOT_KMAX_FLAT_TASKS 24
 #define OSOT_KMAX_BOUNDS 4
-#define OSOT_KMAX_ROWBLOCKS 4
+#define OSOT_KMAX_ROWBLOCKS 8
 
 namespace osot {
 
@@ -43,6 +44,11 @@ struct DevPlan {
     int blk_level[OSOT_KMAX_ROWBLOCKS];   // 0: global rows; k + 1: task-local rows of level k (absent at the other levels)
     int max_iter;
     unsigned active_mask;           // bit k: level k active (iHQP::setActiveStack)
+    // Task::setActive(false) (Task.h:232-239, 375-400): bit j of inactive[k] = task j of level k is inactive, i.e. its
+    // rows [task_off[k][j], task_off[k][j+1]) count as zero rows: nothing in H and g, void optimality rows
+    int ntask[OSOT_KMAX_LEVELS];
+    int task_off[OSOT_KMAX_LEVELS][OSOT_KMAX_TASKS + 1];
+    unsigned inactive[OSOT_KMAX_LEVELS];
     double eps_abs;
     // user regularisation task A_r = [I_rows 0], W_r = w I (iHQP.cpp:274-278): Hr = w on the first reg_rows diagonal
     // entries of every level's H, gr = -w b_r
@@ -72,6 +78,8 @@ struct DevBatch {
     const int* order;  // dispatch order: workgroup g solves instance order[g] (null: g).  Longest-first, see below
     int* cost_out;     // [B] active-set iterations of this solve = the cost estimate for the next dispatch
     const double* b_reg;   // [B][reg_rows] b of the regularisation task (null: none)
+    const double* WA[OSOT_KMAX_LEVELS];   // [B][ma_k][n] W_k A_k, [B][m_k] W_k b_k of a level with a non-diagonal weight
+    const double* Wb[OSOT_KMAX_LEVELS];   // (osot_update_kernel writes them); null: W_k is diag(w[k])
     double* accepted_slack;   // [B] largest constraint violation accepted as round-off (0: none); may be null
 };
 
@@ -172,13 +180,27 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
         const double* Ak = D.A[k] ? D.A[k] + inst * ma * n : nullptr;
         const double* bk = D.b[k] + inst * m;
         const double* wk = D.w[k] ? D.w[k] + inst * m : nullptr;
+        // non-diagonal W_k: left operand W_k A_k and W_k b_k come from the update kernel (stored rows only: an implicit
+        // Postural block keeps its diagonal weights w)
+        const bool dense = D.WA[k] != nullptr;
+        const double* WAk = dense ? D.WA[k] + inst * ma * n : nullptr;
+        const double* Wbk = dense ? D.Wb[k] + inst * m : nullptr;
+        // Task::setActive(false): rows of an inactive task are zero rows
+        const unsigned inact = P.inactive[k];
+        auto row_off = [&](int r) -> bool {
+            bool off = false;
+            for (int j = 0; j < P.ntask[k]; ++j)
+                off = off || (((inact >> j) & 1u) && r >= P.task_off[k][j] && r < P.task_off[k][j + 1]);
+            return off;
+        };
+        auto wrow = [&](int r) -> double { return (inact && row_off(r)) ? 0.0 : (wk ? wk[r] : 1.0); };
         double g = 0.0, hdiag = 0.0;
         const bool diag_h = (ma == 0);
         double hacc[NP / HV];
         bool lowrank = false;   // few stored rows: J and x in closed form, no H, no factorisation (lowrank_prepare32)
         double xprep = 0.0;
         if constexpr (NP == 32) {
-            if (!diag_h && ma <= kLowRankMax) {
+            if (!diag_h && ma <= kLowRankMax && !dense && !inact) {
                 lowrank = true;
                 const int npost = m - ma;
                 const bool postc = valid && c < npost;
@@ -206,34 +228,43 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
 #pragma unroll
                 for (int C2 = 0; C2 < 2; ++C2) Ht[I][C2] = v4f64{0.0, 0.0, 0.0, 0.0};
             double gp0 = 0.0, gp1 = 0.0;
-            auto fetch = [&](int r0, double& a0, double& a1, double& wr, double& br) {
+            // (a0, a1): the row of A (right operand);  (l0, l1): the row of W A (left operand) -- w_r * a for a diagonal W,
+            // read from WA otherwise;  gb: b_r, or (W b)_r for a non-diagonal W: g = -A'(W b) (iHQP.cpp:153, Task::getWb)
+            auto fetch = [&](int r0, double& a0, double& a1, double& l0, double& l1, double& gb) {
                 const int r = r0 + tq;
-                const bool in = r < ma;
-                const int rr = in ? r : ma - 1;
-                const double v0 = Ak[rr * n + ((ta < n) ? ta : 0)];
-                const double v1 = Ak[rr * n + ((16 + ta < n) ? 16 + ta : 0)];
-                const double wv = wk ? wk[rr] : 1.0;
-                br = bk[rr];
+                const bool in = r < ma && !(inact && row_off(r));
+                const int rr = (r < ma) ? r : ma - 1;
+                const int c0 = (ta < n) ? ta : 0, c1 = (16 + ta < n) ? 16 + ta : 0;
+                const double v0 = Ak[rr * n + c0];
+                const double v1 = Ak[rr * n + c1];
                 a0 = (in && ta < n) ? v0 : 0.0;
                 a1 = (in && 16 + ta < n) ? v1 : 0.0;
-                wr = in ? wv : 0.0;
+                gb = dense ? Wbk[rr] : bk[rr];
+                if (dense) {
+                    const double u0 = WAk[rr * n + c0], u1 = WAk[rr * n + c1];
+                    l0 = (in && ta < n) ? u0 : 0.0;
+                    l1 = (in && 16 + ta < n) ? u1 : 0.0;
+                } else {
+                    const double wv = wk ? wk[rr] : 1.0;
+                    l0 = wv * a0; l1 = wv * a1;
+                }
             };
             // 32 rows at a time: all eight groups of four rows are requested before the first MFMA (32 fp64
             // registers in flight): one HBM/L2 round trip per 32 rows instead of one per group
             for (int rb = 0; rb < ma; rb += 32) {
-                double ca0[8], ca1[8], cwr[8], cbr[8];
+                double ca0[8], ca1[8], cl0[8], cl1[8], cbr[8];
 #pragma unroll
                 for (int ch = 0; ch < 8; ++ch) {
-                    ca0[ch] = 0.0; ca1[ch] = 0.0; cwr[ch] = 0.0; cbr[ch] = 0.0;
-                    if (rb + 4 * ch < ma) fetch(rb + 4 * ch, ca0[ch], ca1[ch], cwr[ch], cbr[ch]);
+                    ca0[ch] = 0.0; ca1[ch] = 0.0; cl0[ch] = 0.0; cl1[ch] = 0.0; cbr[ch] = 0.0;
+                    if (rb + 4 * ch < ma) fetch(rb + 4 * ch, ca0[ch], ca1[ch], cl0[ch], cl1[ch], cbr[ch]);
                 }
 #pragma unroll
                 for (int ch = 0; ch < 8; ++ch) {
                     if (rb + 4 * ch < ma) {
-                        const double a0 = ca0[ch], a1 = ca1[ch], wr = cwr[ch], br = cbr[ch];
-                        const double wa0 = wr * a0, wa1 = wr * a1;
-                        gp0 = fma(-wa0, br, gp0);
-                        gp1 = fma(-wa1, br, gp1);
+                        const double a0 = ca0[ch], a1 = ca1[ch], br = cbr[ch];
+                        const double wa0 = cl0[ch], wa1 = cl1[ch];
+                        gp0 = fma(dense ? -a0 : -wa0, br, gp0);
+                        gp1 = fma(dense ? -a1 : -wa1, br, gp1);
                         Ht[0][0] = mfma_f64_16x16x4(wa0, a0, Ht[0][0]);
                         Ht[0][1] = mfma_f64_16x16x4(wa0, a1, Ht[0][1]);
                         Ht[1][1] = mfma_f64_16x16x4(wa1, a1, Ht[1][1]);
@@ -246,13 +277,13 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
             gp1 = rowgroup_sum(gp1);
             g = valid ? ((tq & 1) ? gp1 : gp0) : 0.0;
             const int npost = m - ma;   // Postural block appended to the level: A = [I 0] (Postural.cpp:37)
-            if (npost > 0 && c < npost) g -= (wk ? wk[ma + c] : 1.0) * bk[ma + c];
+            if (npost > 0 && c < npost) g -= wrow(ma + c) * bk[ma + c];
             // diagonal: Postural weights, eps I, unit diagonal beyond n (see factor_rows64 for the padding)
 #pragma unroll
             for (int I = 0; I < 2; ++I) {
                 const int i = 16 * I + ta;    // diagonal element (i, i) lives in tile (I, I) where a == q + 4 r
                 double dv = (i < n) ? P.eps_abs : 1.0;
-                if (i < npost) dv += wk ? wk[ma + i] : 1.0;
+                if (i < npost) dv += wrow(ma + i);
                 if (D.b_reg && i < P.reg_rows) dv += P.reg_w;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Ht[I][I][r] += (ta == tq + 4 * r) ? dv : 0.0;
@@ -276,11 +307,11 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int r = r0 + u;
-                    const bool in = r < ma;
+                    const bool in = r < ma && !(inact && row_off(r));
                     a[u] = (in && valid) ? Ak[r * n + c] : 0.0;
-                    const double wr = in ? (wk ? wk[r] : 1.0) : 0.0;
-                    wa[u] = wr * a[u];
-                    g -= wa[u] * (in ? bk[r] : 0.0);
+                    if (dense) wa[u] = (in && valid) ? WAk[r * n + c] : 0.0;
+                    else wa[u] = (in ? (wk ? wk[r] : 1.0) : 0.0) * a[u];
+                    g -= dense ? a[u] * (in ? Wbk[r] : 0.0) : wa[u] * (in ? bk[r] : 0.0);
                 }
                 wave_sync();   // the previous group's broadcasts are done
                 OSOT_SUB_END(PH_INV);     // (profiling slot reused: wait for the rows)
@@ -304,7 +335,7 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
                 OSOT_SUB_END(PH_SUBST);   // (profiling slot reused: LDS broadcast + outer product)
             }
             if (m > ma && c < m - ma) {   // Postural block appended to the level: A = [I 0] (Postural.cpp:37)
-                const double wi = wk ? wk[ma + c] : 1.0;
+                const double wi = wrow(ma + c);
                 g -= wi * bk[ma + c];
 #pragma unroll
                 for (int ii = 0; ii < NP / HV; ++ii) if (ii * HV + h == c) hacc[ii] += wi;
@@ -320,7 +351,7 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
           }
         } else if (valid) {   // level = one Postural block [I_m 0]: H = blockdiag(W, 0) + eps I is diagonal
             const bool inb = c < m;
-            const double wi = inb ? (wk ? wk[c] : 1.0) : 0.0;
+            const double wi = inb ? wrow(c) : 0.0;
             hdiag = wi + P.eps_abs + dreg;
             g = inb ? -wi * bk[c] : 0.0;
         }
@@ -349,10 +380,12 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
         if (k + 1 < P.L) {
             const int off = P.nc + P.optoff[k];
             for (int q = lane; q < m; q += 64) {
-                w.rlo[off + q] = 0.0;
-                w.rup[off + q] = 0.0;
-                w.rsrc[off + q] = (signed char)k;
-                w.rptr[off + q] = (q < ma) ? reinterpret_cast<unsigned long long>(Ak + q * n)
+                const bool void_row = inact && row_off(q);   // inactive task: 0 x = 0 (Task.h:383-387), i.e. no row
+                w.rlo[off + q] = void_row ? -kInfty : 0.0;
+                w.rup[off + q] = void_row ? kInfty : 0.0;
+                w.rsrc[off + q] = void_row ? (signed char)-1 : (signed char)k;
+                w.rptr[off + q] = void_row ? ((0x7fffffffull << 1) | 1ull)
+                                : (q < ma) ? reinterpret_cast<unsigned long long>(Ak + q * n)
                                            : (((unsigned long long)(q - ma) << 1) | 1ull);   // Postural: e_(q-ma)
             }
             wave_sync();
@@ -501,34 +534,51 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
 // ---------------------------------------------------------------------------------------------------
 // AutoStack::update(): leaf inputs -> b, W diagonal, merged box, constraint rows
 // ---------------------------------------------------------------------------------------------------
-struct DevTask {
-    int level, kind, rows, off; double weight, lambda, ogain, lambda2; const double *p0, *p1, *p2;
-    unsigned long long mask;   // SubTask: kept rows of the parent (0: whole task)
-    int prow;                  // rows of the parent (= rows when not a sub-task): the leaf inputs have this size
-    double sublam;             // SubTask lambda on b (1 when not a sub-task)
+// The STATIC part of the update (kinds, sizes, gains: from the plan) lives in device memory, uploaded once per solver;
+// the per-call part (leaf and output pointers) travels as the kernel argument (kernel arguments are limited to 4 KB).
+struct DevTaskS {
+    int level, kind, rows, off, prow, body, dense;
+    double weight, lambda, ogain, lambda2, sublam;
+    unsigned long long mask;   // SubTask: kept rows of the parent (0: whole task); prow = rows of the parent
 };
-struct DevBound { int kind; double scaling, dT; const double *p0, *p1, *p2; };
-struct DevRowBlock { int kind, rows, off, stored_off, first_col; double d_threshold, detection_threshold, bound_scaling, dT, p, mu;
-                     double lambda, ogain, err_lb, err_ub; const double *p0, *p1, *p2; };
-
-struct DevUpdate {
-    int B, n, L, nc, nc_stored;
-    int m[OSOT_KMAX_LEVELS];
-    int ntasks;                      // all levels, flat (kernel arguments are limited to 4 KB)
-    DevTask task[OSOT_KMAX_FLAT_TASKS];
+struct DevBoundS { int kind; double scaling, dT; };
+struct DevRowBlockS {
+    int kind, rows, off, stored_off, first_col, body, ncand;
+    double d_threshold, detection_threshold, bound_scaling, dT, p, mu, lambda, ogain;
+    double err_lb[OSOT_MAX_BAND_ROWS], err_ub[OSOT_MAX_BAND_ROWS];
+};
+struct DevUpdatePlan {
+    int n, L, nc, nc_stored;
+    int m[OSOT_KMAX_LEVELS], ma[OSOT_KMAX_LEVELS];
+    int dense_level[OSOT_KMAX_LEVELS];   // level holds a block with a non-diagonal W: W_k A_k and W_k b_k are formed
+    int ntasks;                          // all levels, flat
+    DevTaskS task[OSOT_KMAX_FLAT_TASKS];
     int nbounds;
-    DevBound bound[OSOT_KMAX_BOUNDS];
+    DevBoundS bound[OSOT_KMAX_BOUNDS];
     int nrowblocks;
-    DevRowBlock rowblock[OSOT_KMAX_ROWBLOCKS];
+    DevRowBlockS rowblock[OSOT_KMAX_ROWBLOCKS];
+};
+struct DevPtr4 { const double *p0, *p1, *p2, *W; };
+struct DevPtr3 { const double *p0, *p1, *p2; };
+struct DevUpdate {
+    int B;
+    const DevUpdatePlan* plan;           // device memory (host memory under the emulation)
+    DevPtr4 task[OSOT_KMAX_FLAT_TASKS];
+    DevPtr3 bound[OSOT_KMAX_BOUNDS];
+    DevPtr3 rows[OSOT_KMAX_ROWBLOCKS];
     double* b[OSOT_KMAX_LEVELS];
     double* w[OSOT_KMAX_LEVELS];
+    double* WA[OSOT_KMAX_LEVELS];        // [B][ma_k][n] W_k A_k, [B][m_k] W_k b_k: levels with a dense block only
+    double* Wb[OSOT_KMAX_LEVELS];
+    const double* A[OSOT_KMAX_LEVELS];   // the stacked Jacobians (read for W_k A_k)
     double* C;
     double* lo;
     double* up;
     double* l;
     double* u;
-    double* b_reg;                   // b of the regularisation task (flat task entry with level = -1), [B][rows]
+    double* b_reg;                       // b of the regularisation task (flat task entry with level = -1), [B][rows]
 };
+static_assert(sizeof(DevUpdate) <= 4096, "kernel arguments are limited to 4 KB");
 
 // Eigen's Quaterniond(Matrix3d) as invoked by cartesian_utils::computeCartesianError
 // (src/utils/cartesian_utils.cpp:83-84); R row-major, q = (x, y, z, w)
@@ -557,8 +607,9 @@ __device__ inline void rot_to_quat(const double* R, double* q) {
 
 // velocity::Cartesian::update_b (src/tasks/velocity/Cartesian.cpp:279-285) with the quaternion error
 // of include/OpenSoT/utils/cartesian_utils.h:144-164; one lane computes the 6 entries
+// body: the task has a BODY Jacobian (Cartesian.cpp:93-100): b is rotated by Ad(R') = blockdiag(R', R'), R = actual rotation
 __device__ inline void cartesian_b(const double* Ta, const double* Td, const double* twist,
-                                   double lambda, double ogain, double* b6) {
+                                   double lambda, double ogain, double* b6, bool body = false) {
     double q[4], qd[4];
     rot_to_quat(Ta, q);
     rot_to_quat(Td, qd);
@@ -574,12 +625,21 @@ __device__ inline void cartesian_b(const double* Ta, const double* Td, const dou
         b6[i] = tw_p + lambda * (Td[9 + i] - Ta[9 + i]);
         b6[3 + i] = tw_o + lambda * (-ogain * eo[i]);
     }
+    if (body) {
+        double r6[6];
+        for (int i = 0; i < 3; ++i) {   // (R'v)_i = sum_k R[k][i] v_k, R row-major in Ta[0..8]
+            r6[i] = Ta[i] * b6[0] + Ta[3 + i] * b6[1] + Ta[6 + i] * b6[2];
+            r6[3 + i] = Ta[i] * b6[3] + Ta[3 + i] * b6[4] + Ta[6 + i] * b6[5];
+        }
+        for (int i = 0; i < 6; ++i) b6[i] = r6[i];
+    }
 }
 
 __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
     const long long inst = blockIdx.x;
     const int t = threadIdx.x;
-    const int n = U.n;
+    const DevUpdatePlan& PL = *U.plan;
+    const int n = PL.n;
     if (inst >= U.B) return;
     // ---- tasks: b and diag(W) (tasks::Aggregated::generateAll / generateWeight, Aggregated.cpp:113-132, 265-279).
     // ONE LANE PER ROW of the whole stack (all levels, flat): the task table is walked uniformly (scalar loads) and
@@ -588,27 +648,27 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
     // trip instead of one per task (the kernel was a chain of ~9 dependent round trips: 18 us for 3 MB).
     {
         int total = 0;
-        for (int j = 0; j < U.ntasks; ++j) total += U.task[j].rows;
+        for (int j = 0; j < PL.ntasks; ++j) total += PL.task[j].rows;
         for (int fr = t; fr < total; fr += 64) {
             int kind = -1, rows = 0, r = 0, off = 0, level = 0, prow = 0;
             unsigned long long mask = 0ull;
             double weight = 0.0, lam = 0.0, lam2 = 0.0, sublam = 1.0;
             const double *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
             int start = 0;
-            for (int j = 0; j < U.ntasks; ++j) {
-                const DevTask& tk = U.task[j];
+            for (int j = 0; j < PL.ntasks; ++j) {
+                const DevTaskS& tk = PL.task[j];
                 if (fr >= start && fr < start + tk.rows) {
                     kind = tk.kind; rows = tk.rows; r = fr - start; off = tk.off; level = tk.level;
                     weight = tk.weight; lam = tk.lambda; lam2 = tk.lambda2;
-                    p0 = tk.p0; p1 = tk.p1; p2 = tk.p2;
+                    p0 = U.task[j].p0; p1 = U.task[j].p1; p2 = U.task[j].p2;
                     mask = tk.mask; prow = tk.prow; sublam = tk.sublam;
                 }
                 start += tk.rows;
             }
             double* wl = nullptr;
             double* bl = nullptr;
-            for (int k = 0; k < U.L; ++k)
-                if (k == level) { bl = U.b[k] + inst * U.m[k] + off + r; wl = U.w[k] ? U.w[k] + inst * U.m[k] + off + r : nullptr; }
+            for (int k = 0; k < PL.L; ++k)
+                if (k == level) { bl = U.b[k] + inst * PL.m[k] + off + r; wl = U.w[k] ? U.w[k] + inst * PL.m[k] + off + r : nullptr; }
             if (level < 0) bl = U.b_reg + inst * rows + r;   // regularisation task: own output, weight stays in the plan
             if (wl) *wl = weight;
             if (kind == 1) continue;   // Cartesian rows: below, one lane per task
@@ -651,12 +711,13 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
         double* cb = nullptr;
         double clam = 0.0, cog = 0.0, csub = 1.0;
         unsigned cmask = 0x3fu;
-        for (int j = 0; j < U.ntasks; ++j) {
-            const DevTask& tk = U.task[j];
+        bool cbody = false;
+        for (int j = 0; j < PL.ntasks; ++j) {
+            const DevTaskS& tk = PL.task[j];
             if (tk.kind == 1 && t == j) {
-                cp0 = tk.p0; cp1 = tk.p1; cp2 = tk.p2;
-                cb = U.b[tk.level] + inst * U.m[tk.level] + tk.off;
-                clam = tk.lambda; cog = tk.ogain;
+                cp0 = U.task[j].p0; cp1 = U.task[j].p1; cp2 = U.task[j].p2;
+                cb = U.b[tk.level] + inst * PL.m[tk.level] + tk.off;
+                clam = tk.lambda; cog = tk.ogain; cbody = tk.body != 0;
                 if (tk.mask != 0ull) { cmask = (unsigned)tk.mask & 0x3fu; csub = tk.sublam; }   // e.g. position only
             }
         }
@@ -669,56 +730,114 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
             for (int i = 0; i < 12; ++i) { Ta[i] = cp0[inst * 12 + i]; Td[i] = cp1[inst * 12 + i]; }
 #pragma unroll
             for (int i = 0; i < 6; ++i) tw[i] = cp2 ? cp2[inst * 6 + i] : 0.0;
-            cartesian_b(Ta, Td, tw, clam, cog, b6);
+            cartesian_b(Ta, Td, tw, clam, cog, b6, cbody);
             int kq = 0;
             for (int i = 0; i < 6; ++i) if ((cmask >> i) & 1u) cb[kq++] = b6[i] * csub;
         }
     }
+    // ---- levels with a non-diagonal weight: W_k A_k and W_k b_k with W_k = blockdiag(weight_i W_i) (Task::getWA / getWb,
+    // Task.h:273-300; Aggregated::generateWeight, Aggregated.cpp:265-279).  Blocks without a matrix contribute
+    // weight_i * rows.  b_k was written above by other lanes of this workgroup: one barrier.
+    {
+        bool any_dense = false;
+        for (int k = 0; k < PL.L; ++k) any_dense = any_dense || (PL.dense_level[k] != 0);
+        if (any_dense) {
+            workgroup_fence();     // b_k is in global memory: make this workgroup's stores visible to its loads
+            __syncthreads();
+            for (int j = 0; j < PL.ntasks; ++j) {
+                const DevTaskS& tk = PL.task[j];
+                if (tk.level < 0 || !PL.dense_level[tk.level]) continue;
+                const int k = tk.level, mk = PL.m[k], mak = PL.ma[k];
+                const double* bk = U.b[k] + inst * mk + tk.off;
+                double* wbk = U.Wb[k] + inst * mk + tk.off;
+                const bool stored = tk.off + tk.rows <= mak;          // (an implicit Postural block has no rows in A_k)
+                const double* Ak = stored ? U.A[k] + (inst * mak + tk.off) * n : nullptr;
+                double* WAk = stored ? U.WA[k] + (inst * mak + tk.off) * n : nullptr;
+                const double* Wm = tk.dense ? U.task[j].W + inst * tk.rows * tk.rows : nullptr;
+                for (int r = 0; r < tk.rows; ++r) {
+                    if (Wm) {
+                        double wb = 0.0;
+                        for (int q = 0; q < tk.rows; ++q) wb = fma(Wm[r * tk.rows + q], bk[q], wb);
+                        if (t == 0) wbk[r] = tk.weight * wb;
+                        for (int c0 = t; c0 < n; c0 += 64) {
+                            double acc = 0.0;
+                            for (int q = 0; q < tk.rows; ++q) acc = fma(Wm[r * tk.rows + q], Ak[q * n + c0], acc);
+                            WAk[r * n + c0] = tk.weight * acc;
+                        }
+                    } else {
+                        if (t == 0) wbk[r] = tk.weight * bk[r];
+                        if (stored) for (int c0 = t; c0 < n; c0 += 64) WAk[r * n + c0] = tk.weight * Ak[r * n + c0];
+                    }
+                }
+            }
+        }
+    }
     // ---- box: min/max merge (constraints::Aggregated, Aggregated.cpp:141-148)
-    if (U.nbounds > 0) {
+    if (PL.nbounds > 0) {
         for (int i = t; i < n; i += 64) {
             double l = 0.0, u = 0.0;
-            for (int j = 0; j < U.nbounds; ++j) {
-                const DevBound& bd = U.bound[j];
+            for (int j = 0; j < PL.nbounds; ++j) {
+                const DevBoundS& bd = PL.bound[j];
+                const DevPtr3& bp = U.bound[j];
                 double l2, u2;
                 if (bd.kind == 1) {        // JointLimits.cpp:47-52
-                    const double q = bd.p0[inst * n + i];
-                    u2 = fmax((bd.p2[inst * n + i] - q) * bd.scaling, 0.0);
-                    l2 = fmin((bd.p1[inst * n + i] - q) * bd.scaling, 0.0);
+                    const double q = bp.p0[inst * n + i];
+                    u2 = fmax((bp.p2[inst * n + i] - q) * bd.scaling, 0.0);
+                    l2 = fmin((bp.p1[inst * n + i] - q) * bd.scaling, 0.0);
                 } else if (bd.kind == 2) { // VelocityLimits.cpp:81-89
-                    const double v = fabs(bd.p0[inst * n + i]) * bd.dT;
+                    const double v = fabs(bp.p0[inst * n + i]) * bd.dT;
                     l2 = -1.0 * v; u2 = 1.0 * v;
-                } else { l2 = bd.p0[inst * n + i]; u2 = bd.p1[inst * n + i]; }
+                } else { l2 = bp.p0[inst * n + i]; u2 = bp.p1[inst * n + i]; }
                 if (j == 0) { l = l2; u = u2; } else { u = fmin(u, u2); l = fmax(l, l2); }
             }
             U.l[inst * n + i] = l;
             U.u[inst * n + i] = u;
         }
     }
-    // ---- global rows
-    for (int j = 0; j < U.nrowblocks; ++j) {
-        const DevRowBlock& rb = U.rowblock[j];
-        double* Cb = U.C ? U.C + (inst * U.nc_stored + rb.stored_off) * n : nullptr;
-        double* lob = U.lo + inst * U.nc + rb.off;
-        double* upb = U.up + inst * U.nc + rb.off;
+    // ---- constraint rows
+    for (int j = 0; j < PL.nrowblocks; ++j) {
+        const DevRowBlockS& rb = PL.rowblock[j];
+        const DevPtr3& rp = U.rows[j];
+        double* Cb = U.C ? U.C + (inst * PL.nc_stored + rb.stored_off) * n : nullptr;
+        double* lob = U.lo + inst * PL.nc + rb.off;
+        double* upb = U.up + inst * PL.nc + rb.off;
         if (rb.kind == 1) {   // CollisionAvoidance.cpp:96-152
-            const double* Jd = rb.p0 + inst * rb.rows * n;
-            const double* dist = rb.p1 + inst * rb.rows;
-            // compaction of the pairs within the detection threshold, in order
+            const int ncand = rb.ncand > 0 ? rb.ncand : rb.rows;   // pairs supplied; the `rows` closest become rows
+            const double* Jd = rp.p0 + inst * ncand * n;
+            const double* dist = rp.p1 + inst * ncand;
+            // the pairs within the detection threshold, CLOSEST FIRST (getOrderedCollisionPairIndices,
+            // CollisionAvoidance.cpp:120-131): lane = candidate, rank = number of candidates that come before it (smaller
+            // distance; ties by index), by a walk over the distances staged in LDS.  Up to 256 candidates.
             OSOT_STATIC_LDS(int, src_of_row, 256);
+            OSOT_STATIC_LDS(double, dcand, 256);
             OSOT_STATIC_LDS(int, n_used_s, 1);
             int& n_used = n_used_s[0];
-            if (t == 0) {
-                int row = 0;
-                for (int i = 0; i < rb.rows && row < rb.rows; ++i) {
-                    if (rb.detection_threshold > 0 && dist[i] > rb.detection_threshold) continue;
-                    src_of_row[row++] = i;
+            for (int i = t; i < ncand; i += 64) {
+                const double d = dist[i];
+                dcand[i] = (rb.detection_threshold > 0 && d > rb.detection_threshold) ? INFINITY : d;   // skipped pair
+            }
+            for (int i = t; i < 256; i += 64) src_of_row[i] = -1;
+            __syncthreads();
+            int mine_used = 0;
+            for (int i = t; i < ncand; i += 64) {
+                const double d = dcand[i];
+                if (d < INFINITY) {
+                    int rank = 0;
+                    for (int q = 0; q < ncand; ++q) { const double dq = dcand[q]; rank += (dq < d || (dq == d && q < i)) ? 1 : 0; }
+                    if (rank < rb.rows) src_of_row[rank] = i;
+                    mine_used++;
                 }
-                n_used = row;
+            }
+            (void)mine_used;
+            if (t == 0) {   // (uniform walk; the count of pairs inside the detection threshold)
+                int cnt = 0;
+                for (int q = 0; q < ncand; ++q) cnt += (dcand[q] < INFINITY) ? 1 : 0;
+                n_used = cnt;
             }
             __syncthreads();
+            const int nu = n_used < rb.rows ? n_used : rb.rows;
             for (int r = 0; r < rb.rows; ++r) {
-                const bool used = r < n_used;
+                const bool used = r < nu;
                 const int src = used ? src_of_row[r] : 0;
                 for (int i = t; i < n; i += 64) Cb[r * n + i] = used ? -Jd[src * n + i] : 0.0;
                 if (t == 0) {
@@ -731,27 +850,27 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
             }
             __syncthreads();
         } else if (rb.kind == 9) {   // generic unit rows (a box on a range of variables as rows): bounds supplied
-            for (int r = t; r < rb.rows; r += 64) { lob[r] = rb.p0[inst * rb.rows + r]; upb[r] = rb.p1[inst * rb.rows + r]; }
+            for (int r = t; r < rb.rows; r += 64) { lob[r] = rp.p0[inst * rb.rows + r]; upb[r] = rp.p1[inst * rb.rows + r]; }
         } else if (rb.kind == 7) {   // TaskToConstraint(velocity::Cartesian) (TaskToConstraint.cpp:59-68): rows J are in C already
             if (t == 0) {
                 double Ta[12], Td[12], tw[6], b6[6];
 #pragma unroll
-                for (int i = 0; i < 12; ++i) { Ta[i] = rb.p0[inst * 12 + i]; Td[i] = rb.p1[inst * 12 + i]; }
+                for (int i = 0; i < 12; ++i) { Ta[i] = rp.p0[inst * 12 + i]; Td[i] = rp.p1[inst * 12 + i]; }
 #pragma unroll
-                for (int i = 0; i < 6; ++i) tw[i] = rb.p2 ? rb.p2[inst * 6 + i] : 0.0;
-                cartesian_b(Ta, Td, tw, rb.lambda, rb.ogain, b6);
-                for (int i = 0; i < 6; ++i) { lob[i] = b6[i] + rb.err_lb; upb[i] = b6[i] + rb.err_ub; }
+                for (int i = 0; i < 6; ++i) tw[i] = rp.p2 ? rp.p2[inst * 6 + i] : 0.0;
+                cartesian_b(Ta, Td, tw, rb.lambda, rb.ogain, b6, rb.body != 0);
+                for (int i = 0; i < 6; ++i) { lob[i] = b6[i] + rb.err_lb[i]; upb[i] = b6[i] + rb.err_ub[i]; }
             }
         } else if (rb.kind == 8) {   // TaskToConstraint(velocity::CoM): b = v_des + lambda (p_d - p) (CoM.cpp:145-149)
             if (t < 3) {
-                const double b = (rb.p2 ? rb.p2[inst * 3 + t] : 0.0) + rb.lambda * (rb.p1[inst * 3 + t] - rb.p0[inst * 3 + t]);
-                lob[t] = b + rb.err_lb; upb[t] = b + rb.err_ub;
+                const double b = (rp.p2 ? rp.p2[inst * 3 + t] : 0.0) + rb.lambda * (rp.p1[inst * 3 + t] - rp.p0[inst * 3 + t]);
+                lob[t] = b + rb.err_lb[t]; upb[t] = b + rb.err_ub[t];
             }
         } else if (rb.kind == 2) {   // DynamicFeasibility.cpp:22-46 as equality: rows [B_u, -J_f'] are in C already
-            if (t < 6) { const double v = -rb.p0[inst * 6 + t]; lob[t] = v; upb[t] = v; }
+            if (t < 6) { const double v = -rp.p0[inst * 6 + t]; lob[t] = v; upb[t] = v; }
         } else if (rb.kind == 3) {   // TorqueLimits.cpp:25-46: rows [B, -Jc'] are in C already
             for (int r = t; r < rb.rows; r += 64) {
-                const double hh = rb.p0[inst * rb.rows + r], tm = rb.p1[inst * rb.rows + r];
+                const double hh = rp.p0[inst * rb.rows + r], tm = rp.p1[inst * rb.rows + r];
                 lob[r] = -tm - hh; upb[r] = tm - hh;
             }
         } else if (rb.kind == 4) {   // FrictionCone.cpp:35-56: Ci * wRl', mu/sqrt(2) pyramid, 5 rows per contact
@@ -761,7 +880,7 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
             __syncthreads();
             for (int e = t; e < nct * 15; e += 64) {
                 const int ct = e / 15, rr = (e % 15) / 3, col = e % 3;
-                const double* R = rb.p0 + (inst * nct + ct) * 9;   // wRl row-major; Ci*wRl' (rr,col) = sum_k Ci[rr][k] R[col][k]
+                const double* R = rp.p0 + (inst * nct + ct) * 9;   // wRl row-major; Ci*wRl' (rr,col) = sum_k Ci[rr][k] R[col][k]
                 const double ci0 = (rr == 0) ? 1.0 : (rr == 1 ? -1.0 : 0.0);
                 const double ci1 = (rr == 2) ? 1.0 : (rr == 3 ? -1.0 : 0.0);
                 const double ci2 = (rr == 4) ? -1.0 : -mu;
@@ -772,9 +891,9 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
             const int nr = rb.rows;
             const double dt = rb.dT * rb.p;
             for (int i = t; i < nr; i += 64) {
-                const double q = rb.p0[inst * 2 * nr + i], qd = rb.p0[inst * 2 * nr + nr + i];
-                const double qmin = rb.p1[inst * 2 * nr + i], qmax = rb.p1[inst * 2 * nr + nr + i];
-                const double am = rb.p2[inst * nr + i];
+                const double q = rp.p0[inst * 2 * nr + i], qd = rp.p0[inst * 2 * nr + nr + i];
+                const double qmin = rp.p1[inst * 2 * nr + i], qmax = rp.p1[inst * 2 * nr + nr + i];
+                const double am = rp.p2[inst * nr + i];
                 const double a = .5 * dt * dt / am;
                 const double b_sup = dt * qd / am + .5 * dt * dt;
                 const double c_sup = q + dt * qd - qmax + .5 * qd * qd / am;
@@ -793,13 +912,13 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
             }
         } else if (rb.kind == 6) {   // acceleration::VelocityLimits (constraints/acceleration/VelocityLimits.cpp:50-63)
             for (int i = t; i < rb.rows; i += 64) {
-                const double qd = rb.p0[inst * rb.rows + i], lim = rb.p1[inst * rb.rows + i];
+                const double qd = rp.p0[inst * rb.rows + i], lim = rp.p1[inst * rb.rows + i];
                 upb[i] = (lim - qd) / (rb.dT * rb.p);
                 lob[i] = (-lim - qd) / (rb.dT * rb.p);
             }
         } else {
-            for (int e = t; e < rb.rows * n; e += 64) Cb[e] = rb.p0[inst * rb.rows * n + e];
-            for (int r = t; r < rb.rows; r += 64) { lob[r] = rb.p1[inst * rb.rows + r]; upb[r] = rb.p2[inst * rb.rows + r]; }
+            for (int e = t; e < rb.rows * n; e += 64) Cb[e] = rp.p0[inst * rb.rows * n + e];
+            for (int r = t; r < rb.rows; r += 64) { lob[r] = rp.p1[inst * rb.rows + r]; upb[r] = rp.p2[inst * rb.rows + r]; }
         }
     }
 }

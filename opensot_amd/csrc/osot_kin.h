@@ -207,9 +207,21 @@ __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__
                     col[0] = zj[0]; col[1] = zj[1]; col[2] = zj[2];
                 }
             }
+            if (K->d.frame_body[f]) {   // BODY Jacobian Ad(R_f') J (Cartesian.cpp:93-100): both halves rotated by R_f'
+                double rl[3], ra[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    rl[i] = Rf[i] * col[0] + Rf[3 + i] * col[1] + Rf[6 + i] * col[2];
+                    ra[i] = Rf[i] * col[3] + Rf[3 + i] * col[4] + Rf[6 + i] * col[5];
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { col[i] = rl[i]; col[3 + i] = ra[i]; }
+            }
+            const unsigned long long cm = K->d.frame_col_mask[f];   // Task::applyActiveJointsMask (Task.h:129-139)
+            const bool masked = cm != 0ull && !((cm >> j) & 1ull);
             double* J = Bt.frame_J[f] + inst * Bt.frame_J_stride[f];
 #pragma unroll
-            for (int r = 0; r < 6; ++r) J[r * n + j] = col[r];
+            for (int r = 0; r < 6; ++r) J[r * n + j] = masked ? 0.0 : col[r];
         }
     }
     // ---- 4. centre of mass and its Jacobian
@@ -241,9 +253,11 @@ __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__
                 acc[0] = sm * zj[0]; acc[1] = sm * zj[1]; acc[2] = sm * zj[2];
             }
             if (valid) {
+                const unsigned long long cm = K->d.com_col_mask;
+                const bool masked = cm != 0ull && !((cm >> j) & 1ull);
                 double* J = Bt.com_J + inst * Bt.com_J_stride;
 #pragma unroll
-                for (int r = 0; r < 3; ++r) J[r * n + j] = acc[r] / M;
+                for (int r = 0; r < 3; ++r) J[r * n + j] = masked ? 0.0 : acc[r] / M;
             }
         }
     }

@@ -14,6 +14,7 @@
 
 #include "osot_host_plan.h"
 #include "osot_kin.h"
+#include "osot_id.h"
 
 using namespace osot;
 
@@ -32,6 +33,19 @@ int fail(int code, const std::string& msg) {
         if (e_ != hipSuccess)                                                               \
             return fail(OSOT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
     } while (0)
+
+// Every entry point that touches a device runs under this guard: the calling thread's current device is saved, the
+// object's device made current, and the caller's restored on the way out (several solvers on different GPUs may live
+// in one process; the caller's current device is never changed).
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) ok = (hipSetDevice(device) == hipSuccess);
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 
 template <class K>
 int ensure_lds(K kernel, size_t bytes) {
@@ -56,6 +70,15 @@ struct osot_solver {
     int* d_cost = nullptr;   // [max_batch]
     int* d_order = nullptr;  // [max_batch]
     int order_B = -1;        // batch size d_order is valid for (-1: none yet)
+    // d_cost / d_order are stream-ordered state shared by consecutive solves.  A solver is meant to be driven from one
+    // thread on one stream (like the reference's Solver: no locks, SURVEY 8b "threading"); a solve that arrives on a
+    // DIFFERENT stream than the previous one first waits (host side, rare) for that stream, so that it never reads
+    // d_order while the order kernel is still writing it.  No event traffic on the common path.
+    hipStream_t order_stream = nullptr;
+    DevUpdatePlan* d_uplan = nullptr;   // static part of the update kernel's arguments, uploaded at creation
+    DevUpdatePlan h_uplan;
+    unsigned char task_active[OSOT_MAX_LEVELS * OSOT_MAX_TASKS];   // Task::setActive flags
+    bool any_inactive = false;
 };
 
 extern "C" {
@@ -97,7 +120,8 @@ int osot_solver_create(const osot_plan_desc* plan, int max_batch, int device, os
     int rc = osot_plan_validate(plan);
     if (rc != OSOT_OK) return rc;
     if (max_batch < 1) return fail(OSOT_ERR_INVALID, "max_batch < 1");
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(OSOT_ERR_HIP, "hipSetDevice failed");
     DevPlan P; int T; size_t lds;
     make_dev_plan(*plan, nullptr, P, T, lds);
     rc = (T == 32) ? ensure_lds(osot_cascade_kernel<32, false>, lds) : ensure_lds(osot_cascade_kernel<64, false>, lds);
@@ -108,16 +132,32 @@ int osot_solver_create(const osot_plan_desc* plan, int max_batch, int device, os
     s->max_batch = max_batch;
     s->device = device;
     s->timing = false;
+    std::memset(s->task_active, 1, sizeof(s->task_active));
+    make_update_plan(*plan, s->h_uplan);
+    // dispatch-order state and the static update plan live with the solver from the start (no lazy allocation on
+    // whatever device is current)
+    if (hipMalloc(&s->d_cost, sizeof(int) * (size_t)max_batch) != hipSuccess ||
+        hipMalloc(&s->d_order, sizeof(int) * (size_t)max_batch) != hipSuccess ||
+        hipMalloc(&s->d_uplan, sizeof(DevUpdatePlan)) != hipSuccess ||
+        hipMemcpy(s->d_uplan, &s->h_uplan, sizeof(DevUpdatePlan), hipMemcpyHostToDevice) != hipSuccess) {
+        if (s->d_cost) hipFree(s->d_cost);
+        if (s->d_order) hipFree(s->d_order);
+        if (s->d_uplan) hipFree(s->d_uplan);
+        delete s;
+        return fail(OSOT_ERR_HIP, "device allocation for the solver failed");
+    }
     *out = s;
     return OSOT_OK;
 }
 
 int osot_solver_destroy(osot_solver* s) {
     if (!s) return OSOT_OK;
+    DeviceGuard guard(s->device);
     for (auto& p : s->events) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     for (auto& p : s->pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     if (s->d_cost) hipFree(s->d_cost);
     if (s->d_order) hipFree(s->d_order);
+    if (s->d_uplan) hipFree(s->d_uplan);
     delete s;
     return OSOT_OK;
 }
@@ -127,6 +167,18 @@ int osot_solver_set_schedule(osot_solver* s, int mode) {
     if (mode != OSOT_SCHEDULE_IN_ORDER && mode != OSOT_SCHEDULE_LONGEST_FIRST) return fail(OSOT_ERR_INVALID, "unknown schedule mode");
     s->schedule = mode;
     s->order_B = -1;
+    return OSOT_OK;
+}
+
+int osot_solver_set_task_active(osot_solver* s, int level, int task, int active) {
+    if (!s) return fail(OSOT_ERR_INVALID, "null solver");
+    if (level < 0 || level >= s->plan.n_levels || task < 0 || task >= s->plan.level[level].n_tasks)
+        return fail(OSOT_ERR_INVALID, "no such task");
+    s->task_active[level * OSOT_MAX_TASKS + task] = active ? 1 : 0;
+    s->any_inactive = false;
+    for (int k = 0; k < s->plan.n_levels; ++k)
+        for (int j = 0; j < s->plan.level[k].n_tasks; ++j)
+            if (!s->task_active[k * OSOT_MAX_TASKS + j]) s->any_inactive = true;
     return OSOT_OK;
 }
 
@@ -171,9 +223,11 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
     if (!s || !b) return fail(OSOT_ERR_INVALID, "null solver/batch");
     if (b->B < 0 || b->B > s->max_batch) return fail(OSOT_ERR_INVALID, "batch size exceeds max_batch");
     if (b->B == 0) return OSOT_OK;   // empty batch: nothing to do
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return fail(OSOT_ERR_HIP, "hipSetDevice failed");
     const osot_plan_desc& pl = s->plan;
     DevPlan P; int T; size_t lds;
-    make_dev_plan(pl, b->level_active, P, T, lds);
+    make_dev_plan(pl, b->level_active, P, T, lds, s->any_inactive ? s->task_active : nullptr);
     DevBatch D;
     std::memset(&D, 0, sizeof(D));
     D.B = b->B;
@@ -181,6 +235,10 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
         if (P.ma[k] > 0 && !b->A[k]) return fail(OSOT_ERR_INVALID, "A[k] is null for a level with stored rows");
         if (!b->b[k]) return fail(OSOT_ERR_INVALID, "b[k] is null");
         D.A[k] = b->A[k]; D.b[k] = b->b[k]; D.w[k] = b->w[k]; D.c[k] = b->c[k];
+        if (s->h_uplan.dense_level[k]) {
+            if (!b->WA[k] || !b->Wb[k]) return fail(OSOT_ERR_INVALID, "level has a non-diagonal weight but WA[k] / Wb[k] is null");
+            D.WA[k] = b->WA[k]; D.Wb[k] = b->Wb[k];
+        }
     }
     if (P.nc > 0 && (!b->lo || !b->up)) return fail(OSOT_ERR_INVALID, "plan has constraint rows but lo/up is null");
     if (P.nc_stored > 0 && !b->C) return fail(OSOT_ERR_INVALID, "plan has stored constraint rows but C is null");
@@ -195,10 +253,7 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
     D.accepted_slack = b->accepted_slack;
     hipStream_t st = (hipStream_t)hip_stream;
     if (s->schedule == 1) {
-        if (!s->d_cost) {
-            HIP_TRY(hipMalloc(&s->d_cost, sizeof(int) * (size_t)s->max_batch));
-            HIP_TRY(hipMalloc(&s->d_order, sizeof(int) * (size_t)s->max_batch));
-        }
+        if (s->order_B >= 0 && s->order_stream != st) HIP_TRY(hipStreamSynchronize(s->order_stream));
         D.order = (s->order_B == b->B) ? s->d_order : nullptr;
         D.cost_out = s->d_cost;
     }
@@ -225,6 +280,7 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
         hipLaunchKernelGGL(osot_order_kernel, dim3(1), dim3(1024), 0, st, (const int*)s->d_cost, s->d_order, b->B);
         HIP_TRY(hipGetLastError());
         s->order_B = b->B;
+        s->order_stream = st;
     }
     return OSOT_OK;
 }
@@ -233,81 +289,14 @@ int osot_stack_update(osot_solver* s, const osot_leaf_batch* leaf, const osot_as
     if (!s || !leaf || !out) return fail(OSOT_ERR_INVALID, "null argument");
     if (leaf->B < 0 || leaf->B > s->max_batch) return fail(OSOT_ERR_INVALID, "batch size exceeds max_batch");
     if (leaf->B == 0) return OSOT_OK;
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return fail(OSOT_ERR_HIP, "hipSetDevice failed");
     const osot_plan_desc& pl = s->plan;
+    const DevUpdatePlan& PL = s->h_uplan;
     DevUpdate U;
-    std::memset(&U, 0, sizeof(U));
-    U.B = leaf->B; U.n = pl.n; U.L = pl.n_levels;
-    plan_constraint_rows(&pl, &U.nc);
-    plan_stored_constraint_rows(&pl, &U.nc_stored);
-    int flat = 0;
-    for (int k = 0; k < pl.n_levels; ++k) {
-        plan_level_rows(&pl, k, &U.m[k], nullptr);
-        if (!out->b[k]) return fail(OSOT_ERR_INVALID, "out.b[k] is null");
-        U.b[k] = out->b[k]; U.w[k] = out->w[k];
-        int off = 0;
-        for (int j = 0; j < pl.level[k].n_tasks; ++j) {
-            const osot_task_desc& t = pl.level[k].task[j];
-            DevTask& d = U.task[flat++];
-            d.level = k; d.kind = t.kind; d.rows = t.rows; d.off = off;
-            d.weight = t.weight; d.lambda = t.lambda; d.ogain = t.orientation_gain; d.lambda2 = t.lambda2;
-            d.mask = t.row_mask; d.prow = task_parent_rows(t, pl.n); d.sublam = t.row_mask ? t.sub_lambda : 1.0;
-            d.p0 = leaf->task[k][j].p0; d.p1 = leaf->task[k][j].p1; d.p2 = leaf->task[k][j].p2;
-            if (!d.p0) return fail(OSOT_ERR_INVALID, "leaf input p0 of a task is null");
-            if (t.kind != OSOT_TASK_GENERIC && t.kind != OSOT_TASK_ACC_POSTURAL && !d.p1)
-                return fail(OSOT_ERR_INVALID, "leaf input p1 of a task is null");
-            off += t.rows;
-        }
-    }
-    if (pl.has_regularisation) {   // one more flat entry; its b goes to out->b_reg (level = -1)
-        const osot_task_desc& t = pl.regularisation;
-        if (!out->b_reg) return fail(OSOT_ERR_INVALID, "out.b_reg is null");
-        DevTask& d = U.task[flat++];
-        d.level = -1; d.kind = t.kind; d.rows = t.rows; d.off = 0;
-        d.weight = t.weight; d.lambda = t.lambda; d.ogain = t.orientation_gain; d.lambda2 = t.lambda2;
-        d.mask = 0ull; d.prow = t.rows; d.sublam = 1.0;
-        d.p0 = leaf->regularisation.p0; d.p1 = leaf->regularisation.p1; d.p2 = leaf->regularisation.p2;
-        if (!d.p0) return fail(OSOT_ERR_INVALID, "leaf input p0 of the regularisation task is null");
-        if (t.kind == OSOT_TASK_POSTURAL && !d.p1) return fail(OSOT_ERR_INVALID, "leaf input p1 of the regularisation task is null");
-        U.b_reg = out->b_reg;
-    }
-    U.ntasks = flat;
-    U.nbounds = pl.n_bounds;
-    for (int j = 0; j < pl.n_bounds; ++j) {
-        DevBound& d = U.bound[j];
-        d.kind = pl.bound[j].kind; d.scaling = pl.bound[j].scaling; d.dT = pl.bound[j].dT;
-        d.p0 = leaf->bound[j].p0; d.p1 = leaf->bound[j].p1; d.p2 = leaf->bound[j].p2;
-        if (!d.p0) return fail(OSOT_ERR_INVALID, "leaf input p0 of a bound is null");
-        if (d.kind == OSOT_BOUND_JOINT_LIMITS && (!d.p1 || !d.p2)) return fail(OSOT_ERR_INVALID, "joint limits need q, q_min, q_max");
-        if (d.kind == OSOT_BOUND_GENERIC && !d.p1) return fail(OSOT_ERR_INVALID, "generic bound needs l and u");
-    }
-    if (pl.n_bounds > 0 && (!out->l || !out->u)) return fail(OSOT_ERR_INVALID, "out.l/out.u is null");
-    U.l = out->l; U.u = out->u;
-    U.nrowblocks = pl.n_rowblocks;
-    int roff = 0, soff = 0;
-    for (int j = 0; j < pl.n_rowblocks; ++j) {
-        DevRowBlock& d = U.rowblock[j];
-        d.kind = pl.rowblock[j].kind; d.rows = pl.rowblock[j].rows; d.off = roff;
-        d.stored_off = soff; d.first_col = pl.rowblock[j].first_col;
-        d.dT = pl.rowblock[j].dT; d.p = pl.rowblock[j].p; d.mu = pl.rowblock[j].mu;
-        d.lambda = pl.rowblock[j].task_lambda; d.ogain = pl.rowblock[j].task_orientation_gain;
-        d.err_lb = pl.rowblock[j].err_lb; d.err_ub = pl.rowblock[j].err_ub;
-        if (!rows_are_implicit(d.kind)) soff += d.rows;
-        d.d_threshold = pl.rowblock[j].d_threshold;
-        d.detection_threshold = pl.rowblock[j].detection_threshold;
-        d.bound_scaling = pl.rowblock[j].bound_scaling;
-        d.p0 = leaf->rows[j].p0; d.p1 = leaf->rows[j].p1; d.p2 = leaf->rows[j].p2;
-        if (!d.p0) return fail(OSOT_ERR_INVALID, "leaf input p0 of a row block is null");
-        if ((d.kind == OSOT_ROWS_GENERIC || d.kind == OSOT_ROWS_COLLISION || d.kind == OSOT_ROWS_TORQUE_LIMITS ||
-             d.kind == OSOT_ROWS_ACC_JOINT_LIMITS || d.kind == OSOT_ROWS_ACC_VELOCITY_LIMITS ||
-             d.kind == OSOT_ROWS_TASK_CARTESIAN || d.kind == OSOT_ROWS_TASK_COM || d.kind == OSOT_ROWS_UNIT_GENERIC) && !d.p1)
-            return fail(OSOT_ERR_INVALID, "leaf input p1 of a row block is null");
-        if (d.kind == OSOT_ROWS_ACC_JOINT_LIMITS && !d.p2) return fail(OSOT_ERR_INVALID, "acceleration joint limits need qddot_max");
-        if (d.kind == OSOT_ROWS_GENERIC && !d.p2) return fail(OSOT_ERR_INVALID, "generic rows need C, lo, up");
-        roff += d.rows;
-    }
-    if (U.nc > 0 && (!out->lo || !out->up)) return fail(OSOT_ERR_INVALID, "out.lo/up is null");
-    if (U.nc_stored > 0 && !out->C) return fail(OSOT_ERR_INVALID, "out.C is null");
-    U.C = out->C; U.lo = out->lo; U.up = out->up;
+    const char* why = "";
+    int rc = make_update_args(pl, PL, leaf, out, s->d_uplan, U, &why);
+    if (rc != OSOT_OK) return fail(rc, why);
     hipLaunchKernelGGL(osot_update_kernel, dim3((unsigned)leaf->B), dim3(64), 0, (hipStream_t)hip_stream, U);
     HIP_TRY(hipGetLastError());
     return OSOT_OK;
@@ -352,6 +341,7 @@ struct osot_backend {
     int hessian_type;
     double eps_abs;
     bool inited, has_bounds;
+    int device;         // the device that was current when the back-end was created
     std::vector<double> H, g, A, lA, uA, l, u, x;
     double* d_buf;      // device arena
     size_t d_cap;
@@ -362,6 +352,8 @@ struct osot_backend {
 namespace {
 int backend_run(osot_backend* be) {
     const int n = be->nv, nc = be->nc;
+    DeviceGuard guard(be->device);
+    if (!guard.ok) return fail(OSOT_ERR_HIP, "hipSetDevice failed");
     const size_t need = (size_t)n * n + n + (size_t)nc * n + 2 * (size_t)nc + 2 * (size_t)n + n;
     if (need > be->d_cap) {
         if (be->d_buf) hipFree(be->d_buf);
@@ -419,6 +411,7 @@ int osot_backend_create(int number_of_variables, int number_of_constraints, int 
     be->inited = false; be->has_bounds = false;
     be->d_buf = nullptr; be->d_cap = 0; be->d_status = nullptr;
     be->last_status = 0; be->last_iters = 0;
+    if (hipGetDevice(&be->device) != hipSuccess) be->device = 0;
     be->x.assign(be->nv, 0.0);
     *out = be;
     return OSOT_OK;
@@ -426,6 +419,7 @@ int osot_backend_create(int number_of_variables, int number_of_constraints, int 
 
 int osot_backend_destroy(osot_backend* be) {
     if (!be) return OSOT_OK;
+    DeviceGuard guard(be->device);
     if (be->d_buf) hipFree(be->d_buf);
     if (be->d_status) hipFree(be->d_status);
     delete be;
@@ -443,12 +437,14 @@ int osot_backend_update_constraints(osot_backend* be, const double* A, const dou
                                     int number_of_constraints) {
     if (!be || number_of_constraints < 0) return fail(OSOT_ERR_INVALID, "bad argument");
     if (number_of_constraints > 0 && (!A || !lA || !uA)) return fail(OSOT_ERR_INVALID, "null A/lA/uA");
+    // validate first, commit after: a refused update leaves the previous problem intact (BackEnd::updateConstraints,
+    // BackEnd.cpp:47-71)
+    for (int i = 0; i < number_of_constraints; ++i)
+        if (lA[i] > uA[i]) return fail(OSOT_ERR_INVALID, "lA > uA");
     be->nc = number_of_constraints;   // a changed row count re-allocates (QPOasesBackEnd.cpp:229-244)
     be->A.assign(A, A + (size_t)be->nc * be->nv);
     be->lA.assign(lA, lA + be->nc);
     be->uA.assign(uA, uA + be->nc);
-    for (int i = 0; i < be->nc; ++i)
-        if (be->lA[i] > be->uA[i]) return fail(OSOT_ERR_INVALID, "lA > uA");
     return OSOT_OK;
 }
 
@@ -467,6 +463,14 @@ int osot_backend_update_bounds(osot_backend* be, const double* l, const double* 
 int osot_backend_init_problem(osot_backend* be, const double* H, const double* g, const double* A,
                               const double* lA, const double* uA, const double* l, const double* u) {
     if (!be) return fail(OSOT_ERR_INVALID, "null backend");
+    // every argument is checked before anything is committed: a refused initProblem leaves the object as it was
+    if (!H || !g) return fail(OSOT_ERR_INVALID, "null argument");
+    if (be->nc > 0 && (!A || !lA || !uA)) return fail(OSOT_ERR_INVALID, "null A/lA/uA");
+    for (int i = 0; i < be->nc; ++i)
+        if (lA[i] > uA[i]) return fail(OSOT_ERR_INVALID, "lA > uA");
+    if ((l == nullptr) != (u == nullptr)) return fail(OSOT_ERR_INVALID, "l and u must both be given");
+    if (l) for (int i = 0; i < be->nv; ++i)
+        if (l[i] > u[i]) return fail(OSOT_ERR_INVALID, "l > u");
     int rc = osot_backend_update_task(be, H, g);
     if (rc != OSOT_OK) return rc;
     rc = osot_backend_update_constraints(be, A, lA, uA, be->nc);
@@ -561,7 +565,8 @@ int osot_kin_create(const osot_kin_desc* d, int device, osot_kin** out) {
         if (!(d->pair_radius[p][0] >= 0.0) || !(d->pair_radius[p][1] >= 0.0)) return fail(OSOT_ERR_INVALID, "negative capsule radius");
     }
     if (!(h.total_mass > 0.0)) h.total_mass = 1.0;
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(OSOT_ERR_HIP, "hipSetDevice failed");
     osot_kin* k = new osot_kin();
     k->n = d->n; k->n_frames = d->n_frames; k->n_pairs = d->n_pairs; k->device = device;
     hipError_t e = hipMalloc(&k->dev, sizeof(DevKin));
@@ -573,6 +578,7 @@ int osot_kin_create(const osot_kin_desc* d, int device, osot_kin** out) {
 
 int osot_kin_destroy(osot_kin* k) {
     if (!k) return OSOT_OK;
+    DeviceGuard guard(k->device);
     if (k->dev) hipFree(k->dev);
     delete k;
     return OSOT_OK;
@@ -583,10 +589,72 @@ int osot_kinematics(osot_kin* k, const osot_kin_batch* b, void* hip_stream) {
     if (b->B < 0) return fail(OSOT_ERR_INVALID, "negative batch");
     if (b->B == 0) return OSOT_OK;
     if (!b->q) return fail(OSOT_ERR_INVALID, "q is null");
+    DeviceGuard guard(k->device);
+    if (!guard.ok) return fail(OSOT_ERR_HIP, "hipSetDevice failed");
     if (k->n_pairs > 0 && (b->pair_dist || b->pair_J))
         hipLaunchKernelGGL(osot_kin_kernel<true>, dim3((unsigned)b->B), dim3(64), 0, (hipStream_t)hip_stream, (const DevKin*)k->dev, *b);
     else
         hipLaunchKernelGGL(osot_kin_kernel<false>, dim3((unsigned)b->B), dim3(64), 0, (hipStream_t)hip_stream, (const DevKin*)k->dev, *b);
+    HIP_TRY(hipGetLastError());
+    return OSOT_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// inverse-dynamics producers and computedTorque (osot_id.h)
+// ---------------------------------------------------------------------------------------------------
+namespace {
+int id_model_check(const osot_id_model* m, int* n_out) {
+    if (!m) return fail(OSOT_ERR_INVALID, "null model");
+    if (m->B < 0 || m->nv < 1 || m->n_contacts < 0) return fail(OSOT_ERR_INVALID, "bad sizes");
+    if (m->contact_dim != 3 && m->contact_dim != 6) return fail(OSOT_ERR_INVALID, "Unsupported  contact model");   // InverseDynamics.cpp:27
+    const int nf = m->n_contacts * m->contact_dim;
+    if (nf > OSOT_ID_MAX_FORCE_VARS || m->nv + nf > OSOT_MAX_VARS) return fail(OSOT_ERR_UNSUPPORTED, "nv + force variables exceed 64 (or forces exceed 24)");
+    if (!m->Bm || (nf > 0 && !m->Jc)) return fail(OSOT_ERR_INVALID, "null B / Jc");
+    *n_out = m->nv + nf;
+    return OSOT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int osot_id_rows(const osot_id_model* m, double* C_dyn, long long dyn_stride, double* C_tau, long long tau_stride,
+                 int n_tasks, const double* const* J, const int* J_rows, double* const* A_dst, const long long* A_stride,
+                 void* hip_stream) {
+    int n = 0;
+    int rc = id_model_check(m, &n);
+    if (rc != OSOT_OK) return rc;
+    if (m->B == 0) return OSOT_OK;
+    if (n_tasks < 0 || n_tasks > OSOT_MAX_TASKS) return fail(OSOT_ERR_INVALID, "n_tasks out of range");
+    if (n_tasks > 0 && (!J || !J_rows || !A_dst || !A_stride)) return fail(OSOT_ERR_INVALID, "null task arrays");
+    if (C_dyn && m->nv < 6) return fail(OSOT_ERR_INVALID, "DynamicFeasibility needs a floating base (nv >= 6)");
+    DevIdRows R;
+    std::memset(&R, 0, sizeof(R));
+    R.B = m->B; R.nv = m->nv; R.n_contacts = m->n_contacts; R.cdim = m->contact_dim; R.n = n;
+    R.Bm = m->Bm; R.Jc = m->Jc;
+    R.C_dyn = C_dyn; R.dyn_stride = dyn_stride; R.C_tau = C_tau; R.tau_stride = tau_stride;
+    R.n_tasks = n_tasks;
+    for (int i = 0; i < n_tasks; ++i) {
+        if (!J[i] || !A_dst[i] || J_rows[i] < 1) return fail(OSOT_ERR_INVALID, "bad task block");
+        R.J[i] = J[i]; R.J_rows[i] = J_rows[i]; R.A_dst[i] = A_dst[i]; R.A_stride[i] = A_stride[i];
+    }
+    hipLaunchKernelGGL(osot_id_rows_kernel, dim3((unsigned)m->B), dim3(64), 0, (hipStream_t)hip_stream, R);
+    HIP_TRY(hipGetLastError());
+    return OSOT_OK;
+}
+
+int osot_computed_torque(const osot_id_model* m, const double* x, double* tau, int* ok, double fb_tol, void* hip_stream) {
+    int n = 0;
+    int rc = id_model_check(m, &n);
+    if (rc != OSOT_OK) return rc;
+    if (m->B == 0) return OSOT_OK;
+    if (!m->h || !x || !tau) return fail(OSOT_ERR_INVALID, "null h / x / tau");
+    DevTorque T;
+    std::memset(&T, 0, sizeof(T));
+    T.B = m->B; T.nv = m->nv; T.n_contacts = m->n_contacts; T.cdim = m->contact_dim; T.n = n; T.floating_base = m->floating_base;
+    T.Bm = m->Bm; T.h = m->h; T.Jc = m->Jc; T.x = x; T.tau = tau; T.ok = ok; T.fb_tol = fb_tol;
+    hipLaunchKernelGGL(osot_torque_kernel, dim3((unsigned)m->B), dim3(64), 0, (hipStream_t)hip_stream, T);
     HIP_TRY(hipGetLastError());
     return OSOT_OK;
 }
@@ -616,7 +684,8 @@ int osot_comm_unique_id(void* id128) {
 int osot_comm_create(const void* id128, int rank, int world, int device, osot_comm** out) {
     if (!id128 || !out || world < 1 || rank < 0 || rank >= world) return fail(OSOT_ERR_INVALID, "bad argument");
     *out = nullptr;
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(OSOT_ERR_HIP, "hipSetDevice failed");
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof(id));
     ncclComm_t c;

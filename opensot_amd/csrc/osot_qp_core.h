@@ -55,6 +55,7 @@ constexpr double kSlackTol = 1.0e-6;   // a violation below this (relative) with
                                        // its active bound re-appears violated by that much where no freedom is left
                                        // (found by tests/stress_parity.py; qpOASES accepts the same point)
 
+constexpr double kRatioTol = 1.0e-10;  // dual ratio test: r_k counts as positive only above this fraction of max |r| (see gi_inequalities)
 constexpr double kSlackCap = 1.0e-5;   // ... but never more than this in absolute terms (torque / acceleration limits of 1e2 .. 1e3)
 #ifndef OSOT_FEAS_MARGIN
 #define OSOT_FEAS_MARGIN 0.0
@@ -1239,8 +1240,12 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                     }
                 }
             }
-            // step lengths (eiquadprog.hpp:343-366)
-            double t1 = (c >= me && c < iq && rr > 0.0) ? fast_div(fmax(uq, 0.0), rr) : INFINITY;
+            // step lengths (eiquadprog.hpp:343-366).  An entry of r counts as positive only above round-off of the largest
+            // one (kRatioTol): r = R^-1 d1 carries ~1e-16 cond(R) of noise, and a noise-level "positive" entry that happens to
+            // be the only one gives a dual step of u / r ~ 1e8 that wrecks every multiplier (seen in the closed-loop sweep at
+            // the default eps; qpOASES guards its ratio tests the same way, epsNum / epsDen in Constants.hpp)
+            const float rmax = colmax_f32<NP>((c >= me && c < iq) ? (float)fabs(rr) : 0.0f);
+            double t1 = (c >= me && c < iq && rr > kRatioTol * (double)rmax) ? fast_div(fmax(uq, 0.0), rr) : INFINITY;
             int lpos = c;
             colargmin<NP>(t1, lpos);
             lpos = uniform_i(lpos);

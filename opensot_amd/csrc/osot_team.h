@@ -37,6 +37,12 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// release/acquire fence at workgroup scope: global-memory stores of this workgroup become visible to its later loads
+__device__ __forceinline__ void workgroup_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // forbid the instruction scheduler from moving anything across this point (keeps the register pressure of
 // fully unrolled step sequences local to one step)
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }

@@ -24,6 +24,12 @@ class KinModel:
     # self-collision pairs: (joint a, a0[3], a1[3], radius a, joint b, b0[3], b1[3], radius b): two capsules (axis end
     # points in the joint frames; a0 == a1: a sphere)
     pairs: list = field(default_factory=list)
+    # per-frame options of the Jacobian the producer writes: frame index -> True for a BODY Jacobian Ad(R_f') J
+    # (Cartesian::setIsBodyJacobian, Cartesian.cpp:93-100); frame index -> list of ACTIVE joint columns, the others are
+    # written as zero (Task::setActiveJointsMask, Task.h:129-139); the same for the CoM Jacobian
+    frame_body: dict = field(default_factory=dict)
+    frame_active_joints: dict = field(default_factory=dict)
+    com_active_joints: list = None
 
     @property
     def n(self):
@@ -48,6 +54,11 @@ class KinModel:
                 d.frame_R[f][i] = float(np.asarray(R).reshape(9)[i])
             for i in range(3):
                 d.frame_p[f][i] = float(p[i])
+        mask = lambda cols: sum(1 << int(c) for c in cols)
+        for f in range(len(self.frames)):
+            d.frame_body[f] = 1 if self.frame_body.get(f) else 0
+            d.frame_col_mask[f] = mask(self.frame_active_joints[f]) if f in self.frame_active_joints else 0
+        d.com_col_mask = mask(self.com_active_joints) if self.com_active_joints is not None else 0
         d.n_pairs = len(self.pairs)
         for k, (ja, a0, a1, ra, jb, b0, b1, rb) in enumerate(self.pairs):
             d.pair_joint[k][0], d.pair_joint[k][1] = int(ja), int(jb)

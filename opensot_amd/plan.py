@@ -31,11 +31,16 @@ class Task:
     row_mask: int = 0
     parent_rows: int = 0
     sub_lam: float = 1.0
+    # velocity::Cartesian with a body Jacobian (Cartesian::setIsBodyJacobian, Cartesian.cpp:93-100): b rotated by Ad(R')
+    body_frame: bool = False
+    # non-diagonal weight matrix W_i [rows][rows] (Task::setWeight(W), Task.h:273-300): comes with the leaf inputs
+    dense_weight: bool = False
 
     @property
     def implicit(self):
-        """A = [I 0], never stored: a whole Postural block (a Postural sub-task stores its unit rows)"""
-        return self.kind in IMPLICIT_IDENTITY_TASKS and self.row_mask == 0
+        """A = [I 0], never stored: a whole Postural block with a scalar weight (a Postural sub-task, or one with a
+        dense weight matrix, stores its unit rows)"""
+        return self.kind in IMPLICIT_IDENTITY_TASKS and self.row_mask == 0 and not self.dense_weight
 
     def parent_size(self, n):
         if not self.row_mask:
@@ -89,8 +94,16 @@ class Rows:
     # ROWS_TASK_*: constraints::TaskToConstraint (`stack << l_sole`): the underlying task's gains and the error band
     lam: float = 1.0
     orientation_gain: float = 1.0
-    err_lb: float = 0.0
-    err_ub: float = 0.0
+    err_lb: object = 0.0      # scalar or one value per row (TaskToConstraint.cpp:34-52: err_lb / err_ub are vectors)
+    err_ub: object = 0.0
+    body_frame: bool = False  # ROWS_TASK_CARTESIAN: the task has a body Jacobian
+    n_candidates: int = 0     # ROWS_COLLISION: pairs supplied per instance (0 = rows); the `rows` closest become rows
+
+    def band(self):
+        """(err_lb, err_ub) as per-row lists"""
+        import numpy as np
+        return (np.broadcast_to(np.asarray(self.err_lb, dtype=float), (self.rows,)).tolist(),
+                np.broadcast_to(np.asarray(self.err_ub, dtype=float), (self.rows,)).tolist())
 
 
 @dataclass
@@ -129,6 +142,10 @@ class StackPlan:
     def rows_stored_offset(self, j):
         return sum(r.rows for r in self.rowblocks[:j] if r.kind not in UNIT_ROW_BLOCKS)
 
+    def dense_level(self, k):
+        """level k holds a block with a non-diagonal weight matrix: W_k A_k / W_k b_k are formed by the update"""
+        return any(t.dense_weight for t in self.levels[k])
+
     def task_row_offset(self, k, j):
         return sum(t.rows for t in self.levels[k][:j])
 
@@ -146,6 +163,7 @@ class StackPlan:
                     continue
                 if t.implicit:
                     assert j == len(lev) - 1 and 1 <= t.rows <= self.n
+                assert not t.body_frame or t.kind == abi.TASK_CARTESIAN
                 if t.kind in (abi.TASK_CARTESIAN, abi.TASK_ACC_CARTESIAN):
                     assert t.rows == 6
                 if t.kind in (abi.TASK_COM, abi.TASK_ACC_COM):
@@ -168,6 +186,7 @@ class StackPlan:
                 d.kind, d.rows, d.weight, d.lambda_, d.orientation_gain, d.lambda2 = (
                     t.kind, t.rows, t.weight, t.lam, t.orientation_gain, t.lam2)
                 d.row_mask, d.parent_rows, d.sub_lambda = t.row_mask, t.parent_rows, t.sub_lam
+                d.body_frame, d.dense_weight = int(t.body_frame), int(t.dense_weight)
         p.n_bounds = len(self.bounds)
         for j, b in enumerate(self.bounds):
             p.bound[j].kind, p.bound[j].scaling, p.bound[j].dT = b.kind, b.scaling, b.dT
@@ -177,7 +196,12 @@ class StackPlan:
             d.kind, d.rows, d.d_threshold, d.detection_threshold, d.bound_scaling = (
                 r.kind, r.rows, r.d_threshold, r.detection_threshold, r.bound_scaling)
             d.first_col, d.dT, d.p, d.mu = r.first_col, r.dT, r.p, r.mu
-            d.task_lambda, d.task_orientation_gain, d.err_lb, d.err_ub = r.lam, r.orientation_gain, r.err_lb, r.err_ub
+            d.task_lambda, d.task_orientation_gain = r.lam, r.orientation_gain
+            if r.kind in (abi.ROWS_TASK_CARTESIAN, abi.ROWS_TASK_COM):
+                elb, eub = r.band()
+                for i in range(r.rows):
+                    d.err_lb[i], d.err_ub[i] = elb[i], eub[i]
+            d.task_body_frame, d.n_candidates = int(r.body_frame), int(r.n_candidates)
             d.only_level = 0 if r.level is None else r.level + 1
         p.eps_abs = self.eps_abs
         p.max_iter = self.max_iter

@@ -55,6 +55,9 @@ class BatchedStack:
         self.b = [torch.zeros((B, plan.m(k)), **f64) for k in range(L)]
         self.w = [torch.ones((B, plan.m(k)), **f64) for k in range(L)]
         self.c = [None] * L
+        # levels with a non-diagonal weight: W_k A_k and W_k b_k, written by update()
+        self.WA = [torch.zeros((B, plan.ma(k), n), **f64) if plan.dense_level(k) and plan.ma(k) else None for k in range(L)]
+        self.Wb = [torch.zeros((B, plan.m(k)), **f64) if plan.dense_level(k) else None for k in range(L)]
         nc = plan.nc
         self.C = torch.zeros((B, plan.nc_stored, n), **f64) if plan.nc_stored else None
         self.lo = torch.zeros((B, nc), **f64) if nc else None
@@ -92,6 +95,8 @@ class BatchedStack:
                 self.C[:B, o:o + Cj.shape[1]].copy_(to(Cj))
         dev = {"B": B,
                "task": [[tuple(to(x) for x in t) for t in lev] for lev in leaf["task"]],
+               # dense weight matrices W_i [B][rows][rows] of the blocks that have one (same nesting as "task")
+               "W": [[to(x) for x in lev] for lev in leaf["W"]] if leaf.get("W") is not None else None,
                "bound": [tuple(to(x) for x in t) for t in leaf["bound"]],
                "rows": [tuple(to(x) for x in t) for t in leaf["rows"]]}
         if self.plan.regularisation is not None:
@@ -128,6 +133,8 @@ class BatchedStack:
             for j, (p0, p1, p2) in enumerate(lev):
                 lp = lb.task[k][j]
                 lp.p0, lp.p1, lp.p2 = _dev_ptr(p0), _dev_ptr(p1), _dev_ptr(p2)
+                if dev_leaf.get("W") is not None:
+                    lp.W = _dev_ptr(dev_leaf["W"][k][j])
         for j, (p0, p1, p2) in enumerate(dev_leaf["bound"]):
             lb.bound[j].p0, lb.bound[j].p1, lb.bound[j].p2 = _dev_ptr(p0), _dev_ptr(p1), _dev_ptr(p2)
         for j, (p0, p1, p2) in enumerate(dev_leaf["rows"]):
@@ -135,6 +142,8 @@ class BatchedStack:
         out = abi.AssembledOut()
         for k in range(self.plan.L):
             out.b[k] = _dev_ptr(self.b[k]); out.w[k] = _dev_ptr(self.w[k]) if write_weights else None
+            out.WA[k], out.Wb[k] = _dev_ptr(self.WA[k]), _dev_ptr(self.Wb[k])
+            out.A[k] = _dev_ptr(self.A[k]) if self.Wb[k] is not None else None
         out.C, out.lo, out.up = _dev_ptr(self.C), _dev_ptr(self.lo), _dev_ptr(self.up)
         out.l, out.u = _dev_ptr(self.l), _dev_ptr(self.u)
         if self.b_reg is not None:
@@ -158,6 +167,8 @@ class BatchedStack:
         qb.dq, qb.x_levels = _dev_ptr(self.dq), _dev_ptr(self.x_levels)
         qb.status, qb.iterations = _dev_ptr(self.status), _dev_ptr(self.iterations)
         qb.b_reg = _dev_ptr(self.b_reg)
+        for k in range(self.plan.L):
+            qb.WA[k], qb.Wb[k] = _dev_ptr(self.WA[k]), _dev_ptr(self.Wb[k])
         qb.accepted_slack = _dev_ptr(self.accepted_slack)
         if self.level_active is not None:
             self._act = (C.c_ubyte * self.plan.L)(*[1 if a else 0 for a in self.level_active])
@@ -181,6 +192,10 @@ class BatchedStack:
                   "osot_solver_profile_phases")
         torch.cuda.synchronize(self.device)
         return cyc.cpu().numpy()
+
+    def set_task_active(self, level, task, active):
+        """Task::setActive (Task.h:232-239): an inactive task's rows count as zero rows from the next solve() on"""
+        abi.check(self._lib.osot_solver_set_task_active(self._h, level, task, 1 if active else 0), "osot_solver_set_task_active")
 
     def set_schedule(self, longest_first=True):
         """dispatch order inside solve(): longest-first from the previous solve's iteration counts (default)
@@ -237,7 +252,7 @@ class BackEnd:
 
     def updateTask(self, H, g):
         (H_, hp), (g_, gp) = self._p(H), self._p(g)
-        if H_.shape != (self.nv, self.nv) or g_.shape[0] != self.nv:
+        if H_ is None or g_ is None or H_.shape != (self.nv, self.nv) or g_.shape[0] != self.nv:
             return False   # BackEnd.cpp:23-41
         return self._lib.osot_backend_update_task(self._h, hp, gp) == abi.OK
 

@@ -362,3 +362,60 @@ def make_subtask_stack(B, seed=0, n=32, eps_factor=1e6):
     plan = StackPlan(n=n, levels=[lev0, lev1, lev2], bounds=bounds, rowblocks=[], eps_abs=eps_abs_from_factor(eps_factor))
     leaf = {"B": B, "A": [np.ascontiguousarray(A0), np.ascontiguousarray(A1), A2], "task": tleaf, "bound": bleaf, "rows": []}
     return plan, leaf
+
+
+def make_feature_stack(B, seed=0, n=32, eps_factor=1e6, body_frame=True, dense=True, bands=True, candidates=24, many_blocks=True):
+    """a velocity stack that exercises the options beyond the benchmark configurations (all of them parts of the reference's
+    surface): a Cartesian task with a BODY Jacobian (Cartesian.cpp:93-100), a task with a full weight matrix
+    (Task.h:273-300) next to scalar-weighted ones, TaskToConstraint rows with per-row error bands
+    (TaskToConstraint.cpp:34-68), a collision block that picks its rows among more candidate pairs than rows
+    (CollisionAvoidance.cpp:120-131), and more than four row blocks.  Returns (plan, leaf); leaf["W"] holds the weight
+    matrices."""
+    rng = np.random.default_rng(seed)
+    bounds, bleaf = _box_leaf(rng, B, n, jl=True, vl=True)
+
+    def cart(name, limb, weight=1.0, lam=0.1, **kw):
+        return (Task(abi.TASK_CARTESIAN, 6, weight=weight, lam=lam, name=name, **kw),
+                _limb_jacobian(rng, B, 6, n, _BASE + _LIMBS[limb]), _cartesian_leaf(rng, B))
+
+    def spd(rows):
+        M = rng.normal(0.0, 0.4, size=(B, rows, rows))
+        return M @ np.transpose(M, (0, 2, 1)) + 0.5 * np.eye(rows)
+
+    l0 = [cart("l_sole", "l_leg", body_frame=body_frame), cart("r_sole", "r_leg")]
+    # (two tasks on the SAME limb: they conflict, so the weights -- and the off-diagonal entries of W -- shape the answer)
+    l1 = [cart("l_wrist", "l_arm", weight=0.3, dense_weight=dense), cart("l_elbow", "l_arm", lam=0.2)]
+    q = bleaf[0][0]
+    l2 = [(Task(abi.TASK_POSTURAL, n, lam=0.01, name="postural"), None, (q, q + rng.normal(0.0, 0.1, size=(B, n)), None))]
+    levels, A, tleaf, Wl = [], [], [], []
+    for lev in (l0, l1, l2):
+        levels.append([t for (t, _, _) in lev])
+        Js = [J for (_, J, _) in lev if J is not None]
+        A.append(np.ascontiguousarray(np.concatenate(Js, axis=1)) if Js else None)
+        tleaf.append([lf for (_, _, lf) in lev])
+        Wl.append([spd(t.rows) if t.dense_weight else None for (t, _, _) in lev])
+    rowblocks, rleaf, Cleaf = [], [], []
+    # CoM as a constraint with a per-row band (TaskToConstraint with err_lb / err_ub vectors)
+    p = rng.uniform(-0.2, 0.2, size=(B, 3))
+    elb = [-0.02, -0.01, -0.03] if bands else 0.0
+    eub = [0.01, 0.02, 0.0] if bands else 0.0
+    rowblocks.append(Rows(abi.ROWS_TASK_COM, 3, lam=0.1, err_lb=elb, err_ub=eub, name="com_band"))
+    rleaf.append((p, p + rng.uniform(-0.01, 0.01, size=(B, 3)), None)); Cleaf.append(rng.normal(0.0, 0.3, size=(B, 3, n)))
+    # self-collision: `candidates` pairs supplied in arbitrary order, the 8 closest become rows
+    P = 8
+    Jd = np.zeros((B, candidates, n))
+    for r in range(candidates):
+        cols = rng.choice(np.arange(6, n), size=14, replace=False)
+        Jd[:, r, cols] = rng.normal(0.0, 0.3, size=(B, 14))
+    d = rng.uniform(0.0, 0.09, size=(B, candidates))
+    rowblocks.append(Rows(abi.ROWS_COLLISION, P, d_threshold=0.0, detection_threshold=0.05, bound_scaling=1.0,
+                          n_candidates=(candidates if candidates != P else 0), name="self_collision"))
+    rleaf.append((Jd, d, None)); Cleaf.append(None)
+    if many_blocks:   # four more (small) generic blocks: six row blocks in all
+        for i in range(4):
+            Ci = rng.normal(0.0, 0.5, size=(B, 2, n))
+            rowblocks.append(Rows(abi.ROWS_GENERIC, 2, name=f"generic{i}"))
+            rleaf.append((Ci, -rng.uniform(0.05, 0.3, size=(B, 2)), rng.uniform(0.05, 0.3, size=(B, 2)))); Cleaf.append(None)
+    plan = StackPlan(n=n, levels=levels, bounds=bounds, rowblocks=rowblocks, eps_abs=eps_abs_from_factor(eps_factor))
+    leaf = {"B": B, "A": A, "task": tleaf, "bound": bleaf, "rows": rleaf, "C": Cleaf, "W": Wl}
+    return plan, leaf

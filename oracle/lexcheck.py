@@ -156,13 +156,19 @@ def global_violation(asm, i, x):
     return v
 
 
-def lex_compare(ca, cb, rtol=1e-9, atol=1e-14):
-    """-1: cost vector ca is lexicographically smaller (better), +1: cb is, 0: equal within tolerance at every level"""
+def lex_compare(ca, cb, rtol=1e-9, atol=1e-14, rtol_better=None):
+    """-1: cost vector ca is lexicographically smaller (better), +1: cb is, 0: equal within tolerance at every level.
+    rtol_better (default: rtol) is the tolerance for calling ca BETTER at a level; with rtol_better << rtol the test is
+    the one-sided "ca is not worse than cb": a level where ca is lower by more than round-off decides for ca (a point
+    that is really better at level k owes nothing at the levels below), a level where ca is higher only counts when the
+    excess is beyond what the level's conditioning resolves (rtol)."""
+    if rtol_better is None:
+        rtol_better = rtol
     for a, b in zip(ca, cb):
-        tol = atol + rtol * max(abs(a), abs(b))
-        if a < b - tol:
+        m = max(abs(a), abs(b))
+        if a < b - (atol + rtol_better * m):
             return -1
-        if b < a - tol:
+        if b < a - (atol + rtol * m):
             return 1
     return 0
 

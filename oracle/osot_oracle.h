@@ -54,6 +54,9 @@ typedef struct {
     /* task-local constraint rows (Task::getConstraints(), iHQP.cpp:190, 282-287): row r of C belongs to every level
      * when row_level[r] == 0 and to level k only when row_level[r] == k + 1 */
     const int* row_level;        /* [nc], NULL = all rows global                           */
+    /* non-diagonal weight matrices (Task::setWeight(W), Task.h:273-300; Aggregated::generateWeight builds the level's
+     * blockdiag, Aggregated.cpp:265-279): the FULL m_k x m_k matrix W_k; when given, w[k] is ignored */
+    const double* Wd[ORC_MAX_LEVELS]; /* [B][m_k][m_k], NULL = diagonal (w[k])             */
 } orc_batch;
 
 /* back-end selection for the cascade */
@@ -116,6 +119,9 @@ void orc_cartesian_error(const double* R, const double* p, const double* Rd, con
 /* velocity::Cartesian::update_b, src/tasks/velocity/Cartesian.cpp:279-285 */
 void orc_cartesian_b(const double* R, const double* p, const double* Rd, const double* pd,
                      const double* twist_des, double lambda, double orientation_gain, double* b6);
+/* the same with a body Jacobian: b rotated by Ad(R'), Cartesian.cpp:93-100 */
+void orc_cartesian_b_body(const double* R, const double* p, const double* Rd, const double* pd,
+                          const double* twist_des, double lambda, double orientation_gain, double* b6);
 /* velocity::CoM::update_b, src/tasks/velocity/CoM.cpp:145-149 */
 void orc_com_b(const double* p, const double* pd, const double* v_des, double lambda, double* b3);
 /* velocity::Postural::update_b, src/tasks/velocity/Postural.cpp:97-100 (Euclidean joints) */

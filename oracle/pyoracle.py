@@ -34,7 +34,8 @@ class OrcBatch(C.Structure):
                 ("w", dp * ORC_MAX_LEVELS), ("c", dp * ORC_MAX_LEVELS),
                 ("nc", C.c_int), ("C", dp), ("lo", dp), ("up", dp), ("l", dp), ("u", dp),
                 ("eps_abs", C.c_double), ("active", C.POINTER(C.c_ubyte)),
-                ("mr", C.c_int), ("Ar", dp), ("br", dp), ("wr", C.c_double), ("row_level", ip)]
+                ("mr", C.c_int), ("Ar", dp), ("br", dp), ("wr", C.c_double), ("row_level", ip),
+                ("Wd", dp * ORC_MAX_LEVELS)]
 
 
 _lib = None
@@ -70,6 +71,7 @@ def lib():
         L.orc_rot_to_quat.argtypes = [dp, dp]
         L.orc_cartesian_error.argtypes = [dp, dp, dp, dp, dp, dp]
         L.orc_cartesian_b.argtypes = [dp, dp, dp, dp, dp, C.c_double, C.c_double, dp]
+        L.orc_cartesian_b_body.argtypes = [dp, dp, dp, dp, dp, C.c_double, C.c_double, dp]
         L.orc_com_b.argtypes = [dp, dp, dp, C.c_double, dp]
         L.orc_postural_b.argtypes = [C.c_int, dp, dp, dp, C.c_double, dp]
         L.orc_joint_limits.argtypes = [C.c_int, dp, dp, dp, C.c_double, dp, dp]
@@ -98,11 +100,13 @@ def _c(a):
 # --------------------------------------------------------------------------------------------
 # AutoStack::update restatement: leaf -> assembled arrays
 # --------------------------------------------------------------------------------------------
-def assemble(plan, leaf):
+def assemble(plan, leaf, task_active=None):
     """plan: any object with .n, .levels (lists of tasks with kind/rows/weight/lam/orientation_gain),
-    .bounds, .rowblocks, .eps_abs; leaf: dict from opensot_amd.synth.  Returns the assembled dict."""
+    .bounds, .rowblocks, .eps_abs; leaf: dict from opensot_amd.synth.  Returns the assembled dict.
+    task_active: {(level, task): bool} -- Task::setActive(false) zeroes the task's A (Task.h:232-239, 383-387)"""
     L = lib()
     n, B = plan.n, leaf["B"]
+    task_active = task_active or {}
     out = {"n": n, "B": B, "L": len(plan.levels), "eps_abs": plan.eps_abs,
            "m": [], "ma": [], "A": [], "b": [], "w": [], "c": []}
     zeros6 = np.zeros(6)
@@ -110,13 +114,32 @@ def assemble(plan, leaf):
     for k, lev in enumerate(plan.levels):
         m = sum(t.rows for t in lev)
         # a whole Postural block is implicit (A = [I 0]); a Postural SubTask stores its unit rows like any block
-        ma = sum(t.rows for t in lev if not (t.kind in IMPLICIT_IDENTITY_TASKS and not getattr(t, "row_mask", 0)))
+        is_impl = lambda t: (t.kind in IMPLICIT_IDENTITY_TASKS and not getattr(t, "row_mask", 0)
+                             and not getattr(t, "dense_weight", False))
+        ma = sum(t.rows for t in lev if not is_impl(t))
         b = np.zeros((B, m))
         w = np.ones((B, m))
+        # non-diagonal weights: the level's W = blockdiag(weight_i * W_i) (Aggregated::generateWeight, Aggregated.cpp:265-279)
+        dense = any(getattr(t, "dense_weight", False) for t in lev)
+        Wd = np.zeros((B, m, m)) if dense else None
+        # Task::setActive(false): A = 0 (Task.h:383-387).  An inactive implicit [I 0] block becomes a stored block of zero rows
+        Ak = _c(leaf["A"][k]).copy() if ma else None
+        for j, t in enumerate(lev):
+            if task_active.get((k, j), True):
+                continue
+            o = sum(tt.rows for tt in lev[:j])
+            if is_impl(t):
+                Ak = np.concatenate([Ak, np.zeros((B, t.rows, n))], axis=1) if Ak is not None else np.zeros((B, t.rows, n))
+                ma += t.rows
+            else:
+                Ak[:, o:o + t.rows] = 0.0
         off = 0
         for j, t in enumerate(lev):
             p0, p1, p2 = (_c(x) for x in leaf["task"][k][j])
             w[:, off:off + t.rows] = t.weight   # scalar * W (AutoStack.cpp:16-47), W = I by default
+            if dense:
+                Wi = _c(leaf["W"][k][j]) if getattr(t, "dense_weight", False) else np.broadcast_to(np.eye(t.rows), (B, t.rows, t.rows))
+                Wd[:, off:off + t.rows, off:off + t.rows] = t.weight * Wi
             # SubTask (src/tasks/SubTask.cpp:22-112): the parent's b is formed in full (size pr), then the kept rows are
             # gathered in index order and scaled by the sub-task's own lambda (SubTask.cpp:44-58)
             mask = getattr(t, "row_mask", 0)
@@ -127,8 +150,8 @@ def assemble(plan, leaf):
                 rows_ = pr
                 if t.kind == TASK_CARTESIAN:
                     tw = p2[i] if p2 is not None else zeros6
-                    L.orc_cartesian_b(_p(p0[i, :9]), _p(p0[i, 9:]), _p(p1[i, :9]), _p(p1[i, 9:]),
-                                      _p(tw), t.lam, t.orientation_gain, _p(bi))
+                    fn = L.orc_cartesian_b_body if getattr(t, "body_frame", False) else L.orc_cartesian_b
+                    fn(_p(p0[i, :9]), _p(p0[i, 9:]), _p(p1[i, :9]), _p(p1[i, 9:]), _p(tw), t.lam, t.orientation_gain, _p(bi))
                 elif t.kind == TASK_COM:
                     L.orc_com_b(_p(p0[i]), _p(p1[i]), _p(p2[i] if p2 is not None else zeros6[:3]),
                                 t.lam, _p(bi))
@@ -149,8 +172,9 @@ def assemble(plan, leaf):
                     b[i, off:off + t.rows] = bi[kept] * t.sub_lam
             off += t.rows
         out["m"].append(m); out["ma"].append(ma)
-        out["A"].append(_c(leaf["A"][k]) if ma else None)
+        out["A"].append(Ak if ma else None)
         out["b"].append(b); out["w"].append(w); out["c"].append(None)
+        out.setdefault("Wdense", []).append(Wd)
     # user regularisation task (AutoStack::setRegularisationTask, AutoStack.h:78-92): an identity-Jacobian task
     # ([I_rows 0]: GenericTask(I, b) as in TestiHQP.cpp:118-120, Postural, MinimumVelocity) whose cost iHQP adds to
     # every level (iHQP.cpp:265-266, 274-278)
@@ -201,7 +225,12 @@ def assemble(plan, leaf):
                 loi = np.zeros(rb.rows); upi = np.zeros(rb.rows)
                 if rb.kind == ROWS_COLLISION:
                     Ci = np.zeros((rb.rows, n))
-                    L.orc_collision_rows(n, rb.rows, rb.rows, _p(p0[i]), _p(p1[i]), rb.d_threshold,
+                    ncand = getattr(rb, "n_candidates", 0) or rb.rows
+                    # getOrderedCollisionPairIndices (CollisionAvoidance.cpp:120): the pairs in order of distance
+                    # (xbot2's collision module is not vendored: closest first, ties by index, is this build's reading)
+                    order = np.argsort(p1[i][:ncand], kind="stable")
+                    Jo = np.ascontiguousarray(p0[i][:ncand][order]); do = np.ascontiguousarray(p1[i][:ncand][order])
+                    L.orc_collision_rows(n, ncand, rb.rows, _p(Jo), _p(do), rb.d_threshold,
                                          rb.detection_threshold, rb.bound_scaling, _p(Ci), _p(loi), _p(upi))
                     Cm[i, sl] = Ci; lo[i, sl] = loi; up[i, sl] = upi
                 elif rb.kind == ROWS_DYN_FEASIBILITY:      # rows [B_u, -J_f'] come from the producer (leaf "C")
@@ -214,10 +243,14 @@ def assemble(plan, leaf):
                     bt = np.zeros(rb.rows)
                     if rb.kind == ROWS_TASK_CARTESIAN:
                         tw = p2[i] if p2 is not None else zeros6
-                        L.orc_cartesian_b(_p(p0[i, :9]), _p(p0[i, 9:]), _p(p1[i, :9]), _p(p1[i, 9:]), _p(tw), rb.lam, rb.orientation_gain, _p(bt))
+                        fn = L.orc_cartesian_b_body if getattr(rb, "body_frame", False) else L.orc_cartesian_b
+                        fn(_p(p0[i, :9]), _p(p0[i, 9:]), _p(p1[i, :9]), _p(p1[i, 9:]), _p(tw), rb.lam, rb.orientation_gain, _p(bt))
                     else:
                         L.orc_com_b(_p(p0[i]), _p(p1[i]), _p(p2[i] if p2 is not None else zeros6[:3]), rb.lam, _p(bt))
-                    Cm[i, sl] = leaf["C"][j][i]; lo[i, sl] = bt + rb.err_lb; up[i, sl] = bt + rb.err_ub
+                    # _bLowerBound = b + _err_lb, _bUpperBound = b + _err_ub, vectors (TaskToConstraint.cpp:61-68)
+                    Cm[i, sl] = leaf["C"][j][i]
+                    lo[i, sl] = bt + np.broadcast_to(np.asarray(rb.err_lb, dtype=float), (rb.rows,))
+                    up[i, sl] = bt + np.broadcast_to(np.asarray(rb.err_ub, dtype=float), (rb.rows,))
                 elif rb.kind == ROWS_TORQUE_LIMITS:
                     L.orc_torque_limit_bounds(rb.rows, _p(p0[i]), _p(p1[i]), _p(loi), _p(upi))
                     Cm[i, sl] = leaf["C"][j][i]; lo[i, sl] = loi; up[i, sl] = upi
@@ -277,6 +310,10 @@ def _orc_batch(asm, active=None, sl=None):
     P.C, P.lo, P.up = take(asm["C"]), take(asm["lo"]), take(asm["up"])
     P.l, P.u = take(asm["l"]), take(asm["u"])
     P.eps_abs = asm["eps_abs"]
+    if asm.get("Wdense") is not None:
+        for k in range(asm["L"]):
+            if asm["Wdense"][k] is not None:
+                P.Wd[k] = take(asm["Wdense"][k])
     if asm.get("row_level") is not None:
         rl = np.ascontiguousarray(asm["row_level"], dtype=np.int32)
         keep.append(rl)

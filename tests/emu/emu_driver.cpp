@@ -5,19 +5,23 @@
 #include <osot_team.h>
 #include "osot_host_plan.h"
 #include "osot_kin.h"
+#include "osot_id.h"
 
 using namespace osot;
 
-extern "C" __attribute__((visibility("default"))) int emu_ihqp_solve(const osot_plan_desc* plan, const osot_qp_batch* b) {
+// task_active: [OSOT_MAX_LEVELS * OSOT_MAX_TASKS] Task::setActive flags, or null
+extern "C" __attribute__((visibility("default"))) int emu_ihqp_solve(const osot_plan_desc* plan, const osot_qp_batch* b,
+                                                                     const unsigned char* task_active) {
     const char* why;
     int rc = plan_validate(plan, &why);
     if (rc != OSOT_OK) { fprintf(stderr, "emu: %s\n", why); return rc; }
     DevPlan P; int T; size_t lds;
-    make_dev_plan(*plan, b->level_active, P, T, lds);
+    make_dev_plan(*plan, b->level_active, P, T, lds, task_active);
     DevBatch D;
     memset(&D, 0, sizeof(D));
     D.B = b->B;
-    for (int k = 0; k < plan->n_levels; ++k) { D.A[k] = b->A[k]; D.b[k] = b->b[k]; D.w[k] = b->w[k]; D.c[k] = b->c[k]; }
+    for (int k = 0; k < plan->n_levels; ++k) { D.A[k] = b->A[k]; D.b[k] = b->b[k]; D.w[k] = b->w[k]; D.c[k] = b->c[k];
+                                               D.WA[k] = b->WA[k]; D.Wb[k] = b->Wb[k]; }
     D.C = b->C; D.lo = b->lo; D.up = b->up; D.l = b->l; D.u = b->u;
     D.dq = b->dq; D.x_levels = b->x_levels; D.status = b->status; D.iterations = b->iterations;
     D.b_reg = plan->has_regularisation ? b->b_reg : nullptr;
@@ -42,6 +46,44 @@ extern "C" __attribute__((visibility("default"))) int emu_qp_solve_batch(int B, 
     const unsigned grid = (unsigned)B;
     if (T == 32) emu::launch(osot_qp_kernel<32>, grid, lds, 64, Q);
     else emu::launch(osot_qp_kernel<64>, grid, lds, 64, Q);
+    return OSOT_OK;
+}
+
+// AutoStack::update (osot_update_kernel) on host pointers
+extern "C" __attribute__((visibility("default"))) int emu_stack_update(const osot_plan_desc* plan, const osot_leaf_batch* leaf,
+                                                                       const osot_assembled_out* out) {
+    const char* why;
+    int rc = plan_validate(plan, &why);
+    if (rc != OSOT_OK) { fprintf(stderr, "emu: %s\n", why); return rc; }
+    static DevUpdatePlan PL;
+    make_update_plan(*plan, PL);
+    DevUpdate U;
+    rc = make_update_args(*plan, PL, leaf, out, &PL, U, &why);
+    if (rc != OSOT_OK) { fprintf(stderr, "emu: %s\n", why); return rc; }
+    emu::launch(osot_update_kernel, (unsigned)leaf->B, 0, 64, U);
+    return OSOT_OK;
+}
+
+// the inverse-dynamics producers and computedTorque (opensot_amd/csrc/osot_id.h) on host pointers
+extern "C" __attribute__((visibility("default"))) int emu_id_rows(const osot_id_model* m, double* C_dyn, long long dyn_stride,
+        double* C_tau, long long tau_stride, int n_tasks, const double* const* J, const int* J_rows, double* const* A_dst,
+        const long long* A_stride) {
+    DevIdRows R;
+    memset(&R, 0, sizeof(R));
+    R.B = m->B; R.nv = m->nv; R.n_contacts = m->n_contacts; R.cdim = m->contact_dim; R.n = m->nv + m->n_contacts * m->contact_dim;
+    R.Bm = m->Bm; R.Jc = m->Jc; R.C_dyn = C_dyn; R.dyn_stride = dyn_stride; R.C_tau = C_tau; R.tau_stride = tau_stride;
+    R.n_tasks = n_tasks;
+    for (int i = 0; i < n_tasks; ++i) { R.J[i] = J[i]; R.J_rows[i] = J_rows[i]; R.A_dst[i] = A_dst[i]; R.A_stride[i] = A_stride[i]; }
+    emu::launch(osot_id_rows_kernel, (unsigned)m->B, 0, 64, R);
+    return OSOT_OK;
+}
+extern "C" __attribute__((visibility("default"))) int emu_computed_torque(const osot_id_model* m, const double* x, double* tau,
+                                                                          int* ok, double fb_tol) {
+    DevTorque T;
+    memset(&T, 0, sizeof(T));
+    T.B = m->B; T.nv = m->nv; T.n_contacts = m->n_contacts; T.cdim = m->contact_dim; T.n = m->nv + m->n_contacts * m->contact_dim;
+    T.floating_base = m->floating_base; T.Bm = m->Bm; T.h = m->h; T.Jc = m->Jc; T.x = x; T.tau = tau; T.ok = ok; T.fb_tol = fb_tol;
+    emu::launch(osot_torque_kernel, (unsigned)m->B, 0, 64, T);
     return OSOT_OK;
 }
 

@@ -17,6 +17,7 @@ namespace osot {
 inline int emu_lane() { return emu::S().cur; }
 inline void wave_sync() { int z = 0, out[64]; emu::allgather(&z, out, sizeof(int)); }
 inline void sched_fence() {}
+inline void workgroup_fence() {}
 inline int launder_i(int v) { return v; }
 inline int launder_s(int v) { return v; }
 inline int uniform_i(int v) { int out[64]; emu::allgather(&v, out, sizeof(int)); return out[0]; }

@@ -43,11 +43,14 @@ def emu_lib():
                 os.path.join(ROOT, "opensot_amd", "csrc", "osot_qp_core.h"),
                 os.path.join(ROOT, "opensot_amd", "csrc", "osot_kernels.h"),
                 os.path.join(ROOT, "opensot_amd", "csrc", "osot_host_plan.h"),
-                os.path.join(ROOT, "opensot_amd", "csrc", "osot_kin.h")]
+                os.path.join(ROOT, "opensot_amd", "csrc", "osot_kin.h"),
+                os.path.join(ROOT, "opensot_amd", "csrc", "osot_id.h"),
+                os.path.join(ROOT, "include", "osot_mi355x.h")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["sh", os.path.join(ROOT, "tests", "emu", "build.sh")])
         L = C.CDLL(so)
-        L.emu_ihqp_solve.argtypes = [C.POINTER(abi.PlanDesc), C.POINTER(abi.QpBatch)]
+        L.emu_ihqp_solve.argtypes = [C.POINTER(abi.PlanDesc), C.POINTER(abi.QpBatch), C.c_void_p]
+        L.emu_stack_update.argtypes = [C.POINTER(abi.PlanDesc), C.POINTER(abi.LeafBatch), C.POINTER(abi.AssembledOut)]
         vp = C.c_void_p
         L.emu_qp_solve_batch.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp,
                                          C.c_double, C.c_int, vp, vp, vp]
@@ -55,14 +58,17 @@ def emu_lib():
     return _emu
 
 
-def emu_cascade(plan, asm, active=None):
-    """run the cascade kernel body on host pointers through the emulator."""
+def emu_cascade(plan, asm, active=None, task_active=None):
+    """run the cascade kernel body on host pointers through the emulator.  task_active: {(level, task): bool}
+    (Task::setActive); asm may carry "WA" / "Wb" (levels with a non-diagonal weight, see emu_update)"""
     B, n, L = asm["B"], asm["n"], asm["L"]
     qb = abi.QpBatch()
     qb.B = B
     keep = []
     for k in range(L):
-        for name in ("A", "b", "w", "c"):
+        for name in ("A", "b", "w", "c", "WA", "Wb"):
+            if name not in asm:
+                continue
             a = asm[name][k]
             if a is not None:
                 a = np.ascontiguousarray(a, dtype=np.float64)
@@ -94,9 +100,73 @@ def emu_cascade(plan, asm, active=None):
         keep.append(act)
         qb.level_active = C.addressof(act)
     pd = plan.to_c()
-    rc = emu_lib().emu_ihqp_solve(C.byref(pd), C.byref(qb))
+    ta = None
+    if task_active:
+        ta = (C.c_ubyte * (abi.MAX_LEVELS * abi.MAX_TASKS))(*([1] * (abi.MAX_LEVELS * abi.MAX_TASKS)))
+        for (k, j), on in task_active.items():
+            ta[k * abi.MAX_TASKS + j] = 1 if on else 0
+    rc = emu_lib().emu_ihqp_solve(C.byref(pd), C.byref(qb), C.cast(ta, C.c_void_p) if ta is not None else None)
     assert rc == 0
     return dq, xl, st, it
+
+
+def emu_update(plan, leaf):
+    """AutoStack::update (osot_update_kernel) on host arrays through the emulator: leaf dict (opensot_amd.synth layout) ->
+    assembled dict in the oracle's layout (b, w, l, u, C [stored rows], lo, up, reg b, WA / Wb for dense-weight levels)"""
+    B, n, L = leaf["B"], plan.n, plan.L
+    keep = []
+
+    def p(a):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        keep.append(a)
+        return a.ctypes.data
+
+    lb = abi.LeafBatch(); lb.B = B
+    for k, lev in enumerate(leaf["task"]):
+        for j, (p0, p1, p2) in enumerate(lev):
+            lp = lb.task[k][j]
+            lp.p0, lp.p1, lp.p2 = p(p0), p(p1), p(p2)
+            if leaf.get("W") is not None:
+                lp.W = p(leaf["W"][k][j])
+    for j, (p0, p1, p2) in enumerate(leaf["bound"]):
+        lb.bound[j].p0, lb.bound[j].p1, lb.bound[j].p2 = p(p0), p(p1), p(p2)
+    for j, (p0, p1, p2) in enumerate(leaf["rows"]):
+        lb.rows[j].p0, lb.rows[j].p1, lb.rows[j].p2 = p(p0), p(p1), p(p2)
+    out = abi.AssembledOut()
+    res = {"b": [np.zeros((B, plan.m(k))) for k in range(L)], "w": [np.ones((B, plan.m(k))) for k in range(L)],
+           "WA": [np.zeros((B, plan.ma(k), n)) if plan.dense_level(k) and plan.ma(k) else None for k in range(L)],
+           "Wb": [np.zeros((B, plan.m(k))) if plan.dense_level(k) else None for k in range(L)]}
+    A = [np.ascontiguousarray(a, dtype=np.float64) if a is not None else None for a in leaf["A"]]
+    for k in range(L):
+        out.b[k], out.w[k] = res["b"][k].ctypes.data, res["w"][k].ctypes.data
+        if res["Wb"][k] is not None:
+            out.Wb[k] = res["Wb"][k].ctypes.data
+            out.WA[k] = res["WA"][k].ctypes.data if res["WA"][k] is not None else None
+            out.A[k] = A[k].ctypes.data if A[k] is not None else None
+    nc, ncs = plan.nc, plan.nc_stored
+    res["C"] = np.zeros((B, ncs, n)) if ncs else None
+    for j, Cj in enumerate(leaf.get("C", [])):   # rows the producer writes in place
+        if Cj is not None:
+            o = plan.rows_stored_offset(j)
+            res["C"][:, o:o + Cj.shape[1]] = Cj
+    res["lo"] = np.zeros((B, nc)) if nc else None
+    res["up"] = np.zeros((B, nc)) if nc else None
+    res["l"] = np.zeros((B, n)) if plan.bounds else None
+    res["u"] = np.zeros((B, n)) if plan.bounds else None
+    for name in ("C", "lo", "up", "l", "u"):
+        if res[name] is not None:
+            setattr(out, name, res[name].ctypes.data)
+    if plan.regularisation is not None:
+        p0, p1, p2 = leaf["reg"]
+        lb.regularisation.p0, lb.regularisation.p1, lb.regularisation.p2 = p(p0), p(p1), p(p2)
+        res["b_reg"] = np.zeros((B, plan.regularisation.rows))
+        out.b_reg = res["b_reg"].ctypes.data
+    pd = plan.to_c()
+    rc = emu_lib().emu_stack_update(C.byref(pd), C.byref(lb), C.byref(out))
+    assert rc == 0
+    return res
 
 
 def emu_qp(H, g, A, lA, uA, l, u, eps_abs=0.0, max_iter=0):
@@ -219,14 +289,18 @@ def closed_loop_plan(mode="tasks", eps_factor=1e6):
     return plan, m
 
 
-def default_eps_stuck_instances():
-    """five instances met by tests/stress_closed_loop.py (seeds 4 and 7) at iHQP's DEFAULT eps factor 2e2 (iHQP.h:32) that
-    the round-1 kernel reported INFEASIBLE while qpOASES went on -- kept as data (assembled arrays of the cycle)"""
-    plan, _ = closed_loop_plan("tasks", 2e2)
-    z = np.load(os.path.join(GOLDEN, "default_eps_stuck_instances.npz"))
+def default_eps_stuck_instances(mode="tasks"):
+    """instances met by tests/stress_closed_loop.py at iHQP's DEFAULT eps factor 2e2 (iHQP.h:32) that the kernel reported
+    INFEASIBLE while a witness went on -- kept as data (assembled arrays of the cycle).  mode "tasks": five instances of
+    seeds 4 and 7 (round 1); "ttc": one of seed 21 with the feet as TaskToConstraint rows (a noise-level "positive" entry
+    of the dual direction gave a dual step of 6.6e8: kRatioTol in osot_qp_core.h)"""
+    plan, _ = closed_loop_plan(mode, 2e2)
+    z = np.load(os.path.join(GOLDEN, "default_eps_stuck_instances.npz" if mode == "tasks" else "default_eps_stuck_ttc_instance.npz"))
     B = z["b0"].shape[0]
-    asm = {"n": plan.n, "B": B, "L": 3, "eps_abs": plan.eps_abs, "m": [12, 6, 32], "ma": [12, 6, 0],
-           "A": [z["A0"], z["A1"], None], "b": [z["b0"], z["b1"], z["b2"]], "w": [z["w0"], z["w1"], z["w2"]], "c": [None] * 3,
+    L = plan.L
+    asm = {"n": plan.n, "B": B, "L": L, "eps_abs": plan.eps_abs, "m": [plan.m(k) for k in range(L)], "ma": [plan.ma(k) for k in range(L)],
+           "A": [z[f"A{k}"] if f"A{k}" in z.files else None for k in range(L)], "b": [z[f"b{k}"] for k in range(L)],
+           "w": [z[f"w{k}"] for k in range(L)], "c": [None] * L,
            "nc": plan.nc, "C": z["C"], "lo": z["lo"], "up": z["up"], "l": z["l"], "u": z["u"]}
     return plan, asm
 
@@ -256,6 +330,6 @@ def answer_is_acceptable(asm, i, dq_dev, witnesses, tol=1e-6, feas_tol=1e-8, act
         if gw > max(10 * gv, 1e-12):
             continue      # that witness bought its cost with a constraint violation the device point does not have (at the
                           # default eps a violation of 3e-9 buys 10 % of the Postural level's cost on these instances)
-        if lc.lex_compare(cd, lc.lex_costs(asm, i, x, active), rtol=rtol, atol=1e-13) > 0:
+        if lc.lex_compare(cd, lc.lex_costs(asm, i, x, active), rtol=rtol, atol=1e-13, rtol_better=1e-9) > 0:
             return False, f"{d:.1e} from the closest witness; lexicographically worse than {nm} (device {cd}, violation {gv:.1e})"
     return True, f"{d:.1e} from the closest witness, feasible to {gv:.1e} and lexicographically not worse than any as-feasible witness"

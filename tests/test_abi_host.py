@@ -179,7 +179,7 @@ def test_task_to_constraint_rows_plan_validation(lib):
     d.rowblock[0].rows = 5
     assert lib.osot_plan_validate(C.byref(d)) == abi.ERR_INVALID
     d.rowblock[0].rows = 6
-    d.rowblock[1].err_ub = -0.02
+    d.rowblock[1].err_ub[2] = -0.02      # one component of err_ub below err_lb (the band is per row)
     assert lib.osot_plan_validate(C.byref(d)) == abi.ERR_INVALID
 
 

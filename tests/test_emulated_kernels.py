@@ -372,12 +372,13 @@ def test_task_local_equality_on_a_postural_last_level(n, rows, oracle):
         assert ok.any() and np.abs(dq[ok] - rq["dq"][ok]).max() < 1e-7
 
 
-def test_default_eps_stuck_instances(oracle):
+@pytest.mark.parametrize("mode", ["tasks", "ttc"])
+def test_default_eps_stuck_instances(mode, oracle):
     """the five closed-loop instances at iHQP's default eps (factor 2e2) that round 1 reported INFEASIBLE: every level's
     optimality rows are now posed relative to the previous level's solution, which is therefore an exactly feasible point
     of the level (osot_qp_core.h: kFeasMargin); all five solve, and each answer is within 1e-6 of a witness or feasible
     and lexicographically not worse than the witnesses (which disagree with each other by up to 2e-2 here)"""
-    plan, asm = default_eps_stuck_instances()
+    plan, asm = default_eps_stuck_instances(mode)
     dq, xl, st, it = emu_cascade(plan, asm)
     assert (st == 0).all()
     if oracle.ref_available():

@@ -326,10 +326,11 @@ def test_task_local_equality_on_a_postural_last_level_gpu(n, rows, oracle, gpu_d
 
 
 @pytest.mark.gpu
-def test_default_eps_stuck_instances_gpu(oracle, gpu_device):
+@pytest.mark.parametrize("mode", ["tasks", "ttc"])
+def test_default_eps_stuck_instances_gpu(mode, oracle, gpu_device):
     """tests/golden/default_eps_stuck_instances.npz on hardware (see the emulator test of the same name)"""
     from helpers import answer_is_acceptable, default_eps_stuck_instances
-    plan, asm = default_eps_stuck_instances()
+    plan, asm = default_eps_stuck_instances(mode)
     B = asm["B"]
     st = BatchedStack(plan, B, device=0)
     st.load_assembled(asm); st.solve(B)

@@ -138,6 +138,65 @@ def test_emulated_kernel_matches_restatement():
         assert np.abs(com[i] - o["com"]).max() < 1e-14
 
 
+def _frame_options_model():
+    m = kin.humanoid32()
+    m.frame_body = {1: True, 2: True}
+    m.frame_active_joints = {0: list(range(6, m.n)), 2: [j for j in range(m.n) if j % 3]}    # frame 0: the floating base masked out
+    m.com_active_joints = list(range(0, m.n, 2))
+    return m
+
+
+def _expected_with_options(m, o, f):
+    """the frame's Jacobian with the reference's post-processing restated on the world Jacobian of oracle/pykin.py: body
+    frame = Ad(R') J with Ad(R) = blockdiag(R, R) (Cartesian.cpp:93-100), then the active-joints mask zeroes columns
+    (Task::applyActiveJointsMask, Task.h:129-139)"""
+    J = o["J"][f].copy()
+    if m.frame_body.get(f):
+        Rt = o["frame_R"][f].T
+        J = np.concatenate([Rt @ J[:3], Rt @ J[3:]], axis=0)
+    if f in m.frame_active_joints:
+        keep = np.zeros(m.n, dtype=bool); keep[m.frame_active_joints[f]] = True
+        J[:, ~keep] = 0.0
+    return J
+
+
+def test_emulated_frame_options():
+    """body-frame Jacobians and active-joint masks written by the producer (the emulated kernel body)"""
+    from helpers import emu_kinematics
+    m = _frame_options_model()
+    rng = np.random.default_rng(16)
+    q = rng.uniform(-1.0, 1.0, (4, m.n))
+    poses, J, com = emu_kinematics(m, q)
+    for i in range(4):
+        o = pykin.forward(m, q[i])
+        for f in range(4):
+            assert np.abs(J[i, 6 * f:6 * f + 6] - _expected_with_options(m, o, f)).max() < 1e-13
+        Jc = o["Jcom"].copy(); Jc[:, 1::2] = 0.0
+        assert np.abs(J[i, 24:27] - Jc).max() < 1e-14
+    assert np.abs(J[:, 0:6, :6]).max() == 0.0 and np.abs(J[:, 6:12, :6]).max() > 0.1
+
+
+@pytest.mark.gpu
+def test_frame_options_gpu(gpu_device):
+    import torch
+    m = _frame_options_model()
+    K = kin.Kinematics(m, device=0)
+    B = 130
+    rng = np.random.default_rng(17)
+    q = rng.uniform(-1.0, 1.0, (B, m.n))
+    dev = torch.device("cuda", 0)
+    A = torch.full((B, 27, m.n), 7.0, dtype=torch.float64, device=dev)
+    K.forward(torch.as_tensor(q, device=dev), frame_J={f: (A, 6 * f) for f in range(4)}, com_J=(A, 24))
+    torch.cuda.synchronize()
+    Ah = A.cpu().numpy()
+    for i in range(0, B, 13):
+        o = pykin.forward(m, q[i])
+        for f in range(4):
+            assert np.abs(Ah[i, 6 * f:6 * f + 6] - _expected_with_options(m, o, f)).max() < 1e-13
+        Jc = o["Jcom"].copy(); Jc[:, 1::2] = 0.0
+        assert np.abs(Ah[i, 24:27] - Jc).max() < 1e-14
+
+
 @pytest.mark.gpu
 def test_kernel_matches_restatement(gpu_device):
     import torch
