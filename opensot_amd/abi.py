@@ -131,7 +131,8 @@ SYMBOLS = [
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libosot_mi355x.so")
+# (OSOT_MI355X_LIB: developer override, to A/B two builds of the HIP library on the GPU box)
+LIB_PATH = os.environ.get("OSOT_MI355X_LIB") or os.path.join(_HERE, "csrc", "libosot_mi355x.so")
 _lib = None
 
 

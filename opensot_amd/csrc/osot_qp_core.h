@@ -55,7 +55,10 @@ constexpr double kSlackTol = 1.0e-6;   // a violation below this (relative) with
                                        // its active bound re-appears violated by that much where no freedom is left
                                        // (found by tests/stress_parity.py; qpOASES accepts the same point)
 
-constexpr double kRatioTol = 1.0e-10;  // dual ratio test: r_k counts as positive only above this fraction of max |r| (see gi_inequalities)
+#ifndef OSOT_RATIO_TOL
+#define OSOT_RATIO_TOL 1.0e-14
+#endif
+constexpr double kRatioTol = OSOT_RATIO_TOL;  // (1e-10 cost a genuine trade at the default eps, where the entries of r span ten decades; the noise seen was < 1e-15)  // dual ratio test: r_k counts as positive only above this fraction of max |r| (see gi_inequalities)
 constexpr double kSlackCap = 1.0e-5;   // ... but never more than this in absolute terms (torque / acceleration limits of 1e2 .. 1e3)
 #ifndef OSOT_FEAS_MARGIN
 #define OSOT_FEAS_MARGIN 0.0

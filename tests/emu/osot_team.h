@@ -119,7 +119,27 @@ template <int NP> inline int shift_down_i(int v) {
     const int l = emu_lane(), c = l % NP;
     return (c + 1 < NP) ? all[l + 1] : all[l];
 }
+#ifndef OSOT_EMU_HW_ROUNDING
 inline double fast_rcp(double x) { return 1.0 / x; }
 inline double fast_div(double a, double b) { return a / b; }
 inline void fast_sqrt_rsqrt(double x, double& s, double& rs) { s = std::sqrt(x); rs = 1.0 / s; }
+#else
+// a SECOND round-off pattern for the robustness fixtures: every reciprocal / division / square root is moved one ulp up or
+// down (by a bit of its argument), i.e. results that are faithfully but not correctly rounded -- what the hardware's
+// v_rcp_f64 / v_rsq_f64 seeds + Newton steps deliver.  Instances that fail on the GPU only do not reproduce under exact
+// IEEE division; some do under this one.
+inline double ulp_jitter(double v, double key) {
+    unsigned long long b; std::memcpy(&b, &key, 8);
+    b ^= b >> 17; b *= 0x9E3779B97F4A7C15ull; b ^= b >> 29;
+    const int sel = (int)(b % 3);
+    return sel == 0 ? v : std::nextafter(v, sel == 1 ? INFINITY : -INFINITY);
+}
+inline double fast_rcp(double x) { return ulp_jitter(1.0 / x, x); }
+inline double fast_div(double a, double b) { return ulp_jitter(a / b, a + b); }
+inline void fast_sqrt_rsqrt(double x, double& s, double& rs) {
+    s = std::sqrt(x);
+    rs = (s * s == x) ? 1.0 / s : ulp_jitter(1.0 / s, x);     // exact roots stay exact (see the product's routine)
+    if (s * s != x) s = ulp_jitter(s, x * 3.0);
+}
+#endif
 }  // namespace osot

@@ -292,7 +292,7 @@ def closed_loop_plan(mode="tasks", eps_factor=1e6):
 def default_eps_stuck_instances(mode="tasks"):
     """instances met by tests/stress_closed_loop.py at iHQP's DEFAULT eps factor 2e2 (iHQP.h:32) that the kernel reported
     INFEASIBLE while a witness went on -- kept as data (assembled arrays of the cycle).  mode "tasks": five instances of
-    seeds 4 and 7 (round 1); "ttc": one of seed 21 with the feet as TaskToConstraint rows (a noise-level "positive" entry
+    seeds 4 and 7 (round 1) and a sixth of seed 7 that only the hardware failed with a ratio tolerance of 1e-10; "ttc": one of seed 21 with the feet as TaskToConstraint rows (a noise-level "positive" entry
     of the dual direction gave a dual step of 6.6e8: kRatioTol in osot_qp_core.h)"""
     plan, _ = closed_loop_plan(mode, 2e2)
     z = np.load(os.path.join(GOLDEN, "default_eps_stuck_instances.npz" if mode == "tasks" else "default_eps_stuck_ttc_instance.npz"))
