@@ -305,10 +305,12 @@ def default_eps_stuck_instances(mode="tasks"):
     return plan, asm
 
 
-def answer_is_acceptable(asm, i, dq_dev, witnesses, tol=1e-6, feas_tol=1e-8, active=None):
+def answer_is_acceptable(asm, i, dq_dev, witnesses, tol=1e-6, feas_tol=1e-7, active=None):
     """Is the device's final point for instance i an answer to the reference's problem (iHQP.cpp:263-358)?  Yes if it is
     within `tol` of a witness -- or, where the witnesses themselves disagree (ill-conditioned levels: qpOASES at OpenSoT's
-    options stops up to 2e-2 from the optimum with its constraints violated by 2e-7), if it is FEASIBLE to `feas_tol` and
+    options stops up to 2e-2 from the optimum with its constraints violated by 2e-7), if it is FEASIBLE to `feas_tol` (1e-7:
+    half of qpOASES' own terminationTolerance under OpenSoT's options, 2.2e-7; the kernel reports what it accepted in
+    osot_qp_batch.accepted_slack) and
     its lexicographic cost vector (oracle/lexcheck.py) is not worse than that of any witness that is as feasible as it is.
     witnesses: list of (name, dq, solved).  Returns (ok, why)."""
     from oracle import lexcheck as lc

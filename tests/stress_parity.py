@@ -68,7 +68,7 @@ for it in range(N):
     # fails on some ill-conditioned instances) and the line-by-line restatement of the reference's eiQuadProg (an exact
     # active-set method independent of qpOASES' homotopy; it refuses stacks with more equality rows than variables).
     # ONE criterion for every configuration, no exclusions (tests/helpers.py:answer_is_acceptable): within 1e-6 of a
-    # witness, or -- where the witnesses themselves disagree -- feasible to 1e-8 and lexicographically (oracle/lexcheck.py)
+    # witness, or -- where the witnesses themselves disagree -- feasible to 1e-7 and lexicographically (oracle/lexcheck.py)
     # not worse than any witness that is as feasible.
     wit = [("qpOASES", rd), ("qpOASES exact", rq), ("eiQuadProg", re_)]
     has_wit = (rd["status"] == 1) | (rq["status"] == 1) | (re_["status"] == 1)
