@@ -1,5 +1,6 @@
-"""N>1 path on CPU: world_size-2 gloo processes shard the instances contiguously, each 'solves' its shard
-and the all-gather reassembles the global dq in instance order (the path bench.py --gpus N takes with RCCL)."""
+"""N>1 path on CPU: world_size-2 gloo processes run THE SAME objects bench.py runs with RCCL -- `ShardGather` (one
+all_gather_into_tensor per array, dq and status, padded for uneven shards) and `ShardedCycle` + `timed_steps` (the per-rank
+step loop and its barrier bracket) -- with the solve stubbed at the BatchedStack boundary."""
 import os
 import socket
 
@@ -9,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from opensot_amd.parallel import all_gather_dq, shard_range
+from opensot_amd.parallel import ShardedCycle, ShardGather, all_gather_dq, shard_range, timed_steps
 
 
 def test_shard_range_partitions():
@@ -25,22 +26,51 @@ def test_shard_range_partitions():
         shard_range(10, 2, 2)
 
 
+class _StubStack:
+    """stands in for opensot_amd.solver.BatchedStack on CPU tensors: `solve` writes a dq that depends only on the GLOBAL
+    instance index and on the cycle's inputs, `update` consumes the cycle's leaf"""
+
+    def __init__(self, lo, hi, n):
+        self.lo, self.n = lo, n
+        B = hi - lo
+        self.dq = torch.zeros((B, n), dtype=torch.float64)
+        self.status = torch.full((B,), -1, dtype=torch.int32)
+        self.A = None
+        self.cycle_value = None
+        self.calls = []
+
+    def update(self, dev_leaf):
+        self.cycle_value = float(dev_leaf["bias"])
+        self.calls.append("update")
+
+    def solve(self, B):
+        idx = torch.arange(self.lo, self.lo + B, dtype=torch.float64)
+        self.dq[:B] = idx[:, None] * 10.0 + torch.arange(self.n, dtype=torch.float64)[None, :] + self.cycle_value + self.A
+        self.status[:B] = (idx % 3 == 0).to(torch.int32)      # a few "unsolved" instances: the status must travel too
+        self.calls.append("solve")
+
+
 def _worker(rank, world, port, total, n, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = shard_range(total, rank, world)
-    # stand-in for the per-rank solve: dq[i] depends only on the GLOBAL instance index
-    idx = torch.arange(lo, hi, dtype=torch.float64)
-    local = idx[:, None] * 10.0 + torch.arange(n, dtype=torch.float64)[None, :]
-    full = all_gather_dq(local, total)
-    q.put((rank, full.numpy()))
+    stack = _StubStack(lo, hi, n)
+    gather = ShardGather(total, n, torch.device("cpu"), torch.float64)
+    K = 3
+    cyc = ShardedCycle(stack, [{"bias": 100.0 * k} for k in range(K)], [1000.0 * k for k in range(K)], hi - lo, gather)
+    steps, warmup = 4, 2
+    elapsed = timed_steps(cyc.step, steps, warmup, sync=lambda: None, dist=dist, device=torch.device("cpu"))
+    last = (steps + warmup - 1) % K           # the cycle the last step ran
+    one_shot = all_gather_dq(stack.dq, total)  # the convenience form must agree with the resident buffers
+    q.put((rank, gather.dq.numpy().copy(), gather.status.numpy().copy(), one_shot.numpy().copy(), last, elapsed,
+           stack.calls == ["update", "solve"] * (steps + warmup)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total", [8, 7])
-def test_two_rank_allgather_reassembles_global_order(total):
+@pytest.mark.parametrize("total", [8, 7, 1])
+def test_two_rank_step_loop_and_gather(total):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -48,10 +78,15 @@ def test_two_rank_allgather_reassembles_global_order(total):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, total, n, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in range(2))
+    res = [q.get(timeout=180) for _ in range(2)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    want = np.arange(total)[:, None] * 10.0 + np.arange(n)[None, :]
-    for r in range(2):
-        np.testing.assert_array_equal(res[r], want)
+    idx = np.arange(total)
+    for rank, dq, status, one_shot, last, elapsed, order_ok in res:
+        want = idx[:, None] * 10.0 + np.arange(n)[None, :] + 100.0 * last + 1000.0 * last
+        np.testing.assert_array_equal(dq, want)              # global instance order, uneven shards included
+        np.testing.assert_array_equal(one_shot, want)
+        np.testing.assert_array_equal(status, (idx % 3 == 0).astype(np.int32))
+        assert order_ok and elapsed > 0.0
+    assert res[0][5] == res[1][5]                            # the elapsed time is the MAX over ranks on every rank

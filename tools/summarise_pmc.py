@@ -1,5 +1,7 @@
 """developer helper: per-launch averages of the rocprofv3 --pmc passes for the cascade kernel (see profile_round.sh)"""
-import csv, glob, json, sys
+import csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
 out = sys.argv[1]
 per = {}
 kname = None
@@ -18,7 +20,9 @@ for f in sorted(glob.glob(out + "/pmc*_counters.csv")):
         byc.setdefault(c, []).append(v)
     for c, vs in byc.items():
         per[c] = sum(vs) / len(vs)
-res = {"kernel": kname, "workload": "C3 B=4096 (bench.py --steps 10 --warmup 2, one counter group per pass)", "per_launch": per}
+res = {"kernel": kname, "workload": "C3 B=4096 (bench.py --steps 10 --warmup 2, one counter group per pass)", "per_launch": per,
+       # bench.py reports this traffic figure only while the kernel sources still hash to this value
+       "kernel_source_sha": bench.kernel_source_sha(), "config": "C3", "batch": 4096}
 if "FETCH_SIZE" in per:
     res["hbm_bytes_per_launch_corrected"] = per["FETCH_SIZE"] * 1024 * 2 + per.get("WRITE_SIZE", 0.0) * 1024
     res["correction"] = ("MI355X_MICROARCH.md HBM section: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the "
