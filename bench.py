@@ -184,12 +184,15 @@ def parity_report(plan, leaf_sample, dq_dev, xl_dev, slack_dev, tol=1e-6, max_ev
         asm_f["B"] = int(far.size)
         asm_f.pop("Wdense", None)
         rx = po.ihqp_solve_batch(asm_f, po.BE_QPOASES_REF, nthreads=min(nt, int(far.size)), termination_tolerance=10 * 2.221e-16)
+        re_ = po.ihqp_solve_batch(asm_f, po.BE_EIQP_EQ, nthreads=min(nt, int(far.size)))   # independent exact active-set method
         ev = []
         better = {"device": 0, "qpOASES": 0, "tie": 0}
         for j, i in enumerate(far):
             rec = lc.instance_evidence(asm, int(i), xl_dev[i], rd["x_levels"][i], names=("device", "qpOASES"))
             rec["device_vs_qpOASES_run_to_exact_optimum"] = (float(np.abs(dq_dev[i] - rx["dq"][j]).max())
                                                              if rx["status"][j] == 1 else None)
+            rec["device_vs_eiQuadProg_restatement"] = (float(np.abs(dq_dev[i] - re_["dq"][j]).max())
+                                                       if re_["status"][j] == 1 else None)
             better[rec["lexicographically_better"]] += 1
             if len(ev) < max_evidence:
                 ev.append(rec)

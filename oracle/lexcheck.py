@@ -173,7 +173,7 @@ def lex_compare(ca, cb, rtol=1e-9, atol=1e-14, rtol_better=None):
     return 0
 
 
-def instance_evidence(asm, i, chain_a, chain_b, active=None, names=("device", "qpOASES")):
+def instance_evidence(asm, i, chain_a, chain_b, active=None, names=("device", "qpOASES"), feas_tol=1e-9):
     """per-level KKT / violation / cost of two chains, the lexicographic cost vector of their final points and the
     verdict -- what bench.py prints for every instance whose two answers differ by more than the tolerance"""
     L = asm["L"]
@@ -186,6 +186,18 @@ def instance_evidence(asm, i, chain_a, chain_b, active=None, names=("device", "q
                      "lex_cost_of_dq": lex_costs(asm, i, ch[last], active),
                      "global_violation_of_dq": global_violation(asm, i, ch[last])}
     cmp_ = lex_compare(out[names[0]]["lex_cost_of_dq"], out[names[1]]["lex_cost_of_dq"])
-    out["lexicographically_better"] = names[0] if cmp_ < 0 else (names[1] if cmp_ > 0 else "tie")
+    out["lexicographically_smaller_cost"] = names[0] if cmp_ < 0 else (names[1] if cmp_ > 0 else "tie")
+    # the optimum of the reference's problem is the lexicographically smallest FEASIBLE point: a point that violates the
+    # shared constraints (here: by more than `feas_tol`, and by more than the other one) bought its cost with that violation
+    va, vb = (max(out[nm]["global_violation_of_dq"], max(out[nm]["viol_per_level"])) for nm in names)
+    fa, fb = va <= feas_tol, vb <= feas_tol
+    if fa and not fb:
+        verdict = f"{names[0]} (feasible to {va:.1e}; {names[1]}'s point violates its constraints by {vb:.1e})"
+    elif fb and not fa:
+        verdict = f"{names[1]} (feasible to {vb:.1e}; {names[0]}'s point violates its constraints by {va:.1e})"
+    else:
+        verdict = out["lexicographically_smaller_cost"]
+    out["lexicographically_better"] = verdict.split(" ")[0]
+    out["verdict"] = verdict
     out["max_abs_diff"] = float(np.abs(chain_a[last] - chain_b[last]).max())
     return out
