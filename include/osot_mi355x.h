@@ -304,6 +304,12 @@ int osot_stack_update(osot_solver* s, const osot_leaf_batch* leaf, const osot_as
 /* Solver::solve() for B instances: the whole iHQP cascade in one launch. Stream-ordered. */
 int osot_ihqp_solve(osot_solver* s, const osot_qp_batch* batch, void* hip_stream);
 
+/* One control cycle in ONE launch: osot_stack_update followed by osot_ihqp_solve for the same B instances
+ * (`stack->update(); solver->solve(dq)`, examples/cpp/coman_ik.cpp:186-192) with each instance's update and cascade run by
+ * the same wavefront.  Results are identical to the two calls; the assembled arrays are still written. */
+int osot_cycle(osot_solver* s, const osot_leaf_batch* leaf, const osot_assembled_out* out, const osot_qp_batch* batch,
+               void* hip_stream);
+
 /* average device time (ms) of the cascade kernel over the launches recorded since the last call
  * with reset != 0; measured with hipEvents on the launch stream. *launches receives the count. */
 int osot_solver_kernel_time_ms(osot_solver* s, int reset, double* avg_ms, int* launches);

@@ -87,11 +87,8 @@ struct DevBatch {
 // filled once per instance, the optimality entries of level j are appended when level j has been solved
 // (lo = up = A_j x_j, iHQP.cpp:164-170; an inactive level contributes 0*x in [-1,1], iHQP.cpp:301-309).
 template <int NP, bool PROF>
-__global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(const DevPlan P, const DevBatch D) {
-    OSOT_DYNAMIC_LDS(osot_smem);
+__device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D, const long long inst, const int lane, char* osot_smem) {
     constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
-    const int lane = threadIdx.x;
-    const long long inst = D.order ? D.order[blockIdx.x] : (int)blockIdx.x;
     const int n = P.n;
     double* base = reinterpret_cast<double*>(osot_smem);
     WaveCtx<NP> w;
@@ -406,6 +403,13 @@ __global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(co
     }
 }
 
+template <int NP, bool PROF>
+__global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(const DevPlan P, const DevBatch D) {
+    OSOT_DYNAMIC_LDS(osot_smem);
+    const long long inst = D.order ? D.order[blockIdx.x] : (int)blockIdx.x;
+    cascade_body<NP, PROF>(P, D, inst, (int)threadIdx.x, osot_smem);
+}
+
 // Longest-first dispatch.  One wavefront solves one instance and an MI355X holds 2048 of them at a time, so a
 // batch of 4096 is two rounds: the kernel ends when the slowest LATE starter ends, and with the active-set
 // iteration count varying 2x between instances (mean 32, max 63 at BASELINE config 3) that tail was ~30 % of the
@@ -635,12 +639,12 @@ __device__ inline void cartesian_b(const double* Ta, const double* Td, const dou
     }
 }
 
-__global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
-    const long long inst = blockIdx.x;
-    const int t = threadIdx.x;
+// scratch: 256 ints + 256 doubles + 1 int of LDS for the collision block's candidate ranking (the stand-alone kernel's own
+// static arrays; the fused kernel lends the head of the cascade's slice, which is idle until the cascade starts)
+__device__ __forceinline__ void update_body(const DevUpdate& U, const long long inst, const int t, int* src_of_row, double* dcand,
+                                            int* n_used_s) {
     const DevUpdatePlan& PL = *U.plan;
     const int n = PL.n;
-    if (inst >= U.B) return;
     // ---- tasks: b and diag(W) (tasks::Aggregated::generateAll / generateWeight, Aggregated.cpp:113-132, 265-279).
     // ONE LANE PER ROW of the whole stack (all levels, flat): the task table is walked uniformly (scalar loads) and
     // each lane keeps the parameters of the task its row belongs to; every kind then goes through the SAME four
@@ -808,9 +812,6 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
             // the pairs within the detection threshold, CLOSEST FIRST (getOrderedCollisionPairIndices,
             // CollisionAvoidance.cpp:120-131): lane = candidate, rank = number of candidates that come before it (smaller
             // distance; ties by index), by a walk over the distances staged in LDS.  Up to 256 candidates.
-            OSOT_STATIC_LDS(int, src_of_row, 256);
-            OSOT_STATIC_LDS(double, dcand, 256);
-            OSOT_STATIC_LDS(int, n_used_s, 1);
             int& n_used = n_used_s[0];
             for (int i = t; i < ncand; i += 64) {
                 const double d = dist[i];
@@ -921,6 +922,32 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
             for (int r = t; r < rb.rows; r += 64) { lob[r] = rp.p1[inst * rb.rows + r]; upb[r] = rp.p2[inst * rb.rows + r]; }
         }
     }
+}
+
+__global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
+    OSOT_STATIC_LDS(int, src_of_row, 256);
+    OSOT_STATIC_LDS(double, dcand, 256);
+    OSOT_STATIC_LDS(int, n_used_s, 2);
+    if ((long long)blockIdx.x >= U.B) return;
+    update_body(U, blockIdx.x, threadIdx.x, src_of_row, dcand, n_used_s);
+}
+
+// One control cycle in ONE launch: AutoStack::update() and Solver::solve() of an instance by the same wavefront
+// (coman_ik.cpp:186-192: `stack->update(); solver->solve(dq)`).  The assembled b / W / box / rows still go through their
+// HBM arrays (they are outputs of the update in their own right) but come back from the CU's own L1 / L2 lines; what is
+// saved is a launch, its tail and the gap between the two (18 + ~4 us of a 227 us step at BASELINE config 3).
+template <int NP>
+__global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cycle_kernel(const DevUpdate U, const DevPlan P, const DevBatch D) {
+    OSOT_DYNAMIC_LDS(osot_smem);
+    const long long inst = D.order ? D.order[blockIdx.x] : (int)blockIdx.x;
+    {
+        double* dsc = reinterpret_cast<double*>(osot_smem);
+        int* isc = reinterpret_cast<int*>(dsc + 256);
+        update_body(U, inst, (int)threadIdx.x, isc, dsc, isc + 256);
+    }
+    workgroup_fence();      // the update's global stores are visible to the cascade's loads (same workgroup)
+    __syncthreads();
+    cascade_body<NP, false>(P, D, inst, (int)threadIdx.x, osot_smem);
 }
 
 }  // namespace osot

@@ -8,6 +8,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -126,6 +127,7 @@ int osot_solver_create(const osot_plan_desc* plan, int max_batch, int device, os
     make_dev_plan(*plan, nullptr, P, T, lds);
     rc = (T == 32) ? ensure_lds(osot_cascade_kernel<32, false>, lds) : ensure_lds(osot_cascade_kernel<64, false>, lds);
     if (rc == OSOT_OK) rc = (T == 32) ? ensure_lds(osot_cascade_kernel<32, true>, lds) : ensure_lds(osot_cascade_kernel<64, true>, lds);
+    if (rc == OSOT_OK) rc = (T == 32) ? ensure_lds(osot_cycle_kernel<32>, lds) : ensure_lds(osot_cycle_kernel<64>, lds);
     if (rc != OSOT_OK) return rc;
     osot_solver* s = new osot_solver();
     s->plan = *plan;
@@ -208,10 +210,23 @@ int osot_solver_kernel_time_ms(osot_solver* s, int reset, double* avg_ms, int* l
     return OSOT_OK;
 }
 
-static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream, long long* prof);
+static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream, long long* prof, const DevUpdate* fused = nullptr);
 
 int osot_ihqp_solve(osot_solver* s, const osot_qp_batch* b, void* hip_stream) {
     return ihqp_launch(s, b, hip_stream, nullptr);
+}
+
+int osot_cycle(osot_solver* s, const osot_leaf_batch* leaf, const osot_assembled_out* out, const osot_qp_batch* b,
+               void* hip_stream) {
+    if (!s || !leaf || !out || !b) return fail(OSOT_ERR_INVALID, "null argument");
+    if (leaf->B != b->B) return fail(OSOT_ERR_INVALID, "leaf and batch disagree on B");
+    if (leaf->B < 0 || leaf->B > s->max_batch) return fail(OSOT_ERR_INVALID, "batch size exceeds max_batch");
+    if (leaf->B == 0) return OSOT_OK;
+    DevUpdate U;
+    const char* why = "";
+    int rc = make_update_args(s->plan, s->h_uplan, leaf, out, s->d_uplan, U, &why);
+    if (rc != OSOT_OK) return fail(rc, why);
+    return ihqp_launch(s, b, hip_stream, nullptr, &U);
 }
 
 int osot_solver_profile_phases(osot_solver* s, const osot_qp_batch* b, long long* cycles, void* hip_stream) {
@@ -219,7 +234,7 @@ int osot_solver_profile_phases(osot_solver* s, const osot_qp_batch* b, long long
     return ihqp_launch(s, b, hip_stream, cycles);
 }
 
-static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream, long long* prof) {
+static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream, long long* prof, const DevUpdate* fused) {
     if (!s || !b) return fail(OSOT_ERR_INVALID, "null solver/batch");
     if (b->B < 0 || b->B > s->max_batch) return fail(OSOT_ERR_INVALID, "batch size exceeds max_batch");
     if (b->B == 0) return OSOT_OK;   // empty batch: nothing to do
@@ -228,6 +243,10 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
     const osot_plan_desc& pl = s->plan;
     DevPlan P; int T; size_t lds;
     make_dev_plan(pl, b->level_active, P, T, lds, s->any_inactive ? s->task_active : nullptr);
+    {   // developer knob: extra dynamic LDS per wave (lowers the occupancy; used to measure how the kernel responds to it)
+        static const char* extra = getenv("OSOT_DEBUG_EXTRA_LDS");
+        if (extra) lds += (size_t)atoi(extra);
+    }
     DevBatch D;
     std::memset(&D, 0, sizeof(D));
     D.B = b->B;
@@ -264,7 +283,10 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
         else { HIP_TRY(hipEventCreate(&ev.first)); HIP_TRY(hipEventCreate(&ev.second)); }
         HIP_TRY(hipEventRecord(ev.first, st));
     }
-    if (prof) {
+    if (fused) {
+        if (T == 32) hipLaunchKernelGGL((osot_cycle_kernel<32>), dim3(grid), dim3(64), lds, st, *fused, P, D);
+        else hipLaunchKernelGGL((osot_cycle_kernel<64>), dim3(grid), dim3(64), lds, st, *fused, P, D);
+    } else if (prof) {
         if (T == 32) hipLaunchKernelGGL((osot_cascade_kernel<32, true>), dim3(grid), dim3(64), lds, st, P, D);
         else hipLaunchKernelGGL((osot_cascade_kernel<64, true>), dim3(grid), dim3(64), lds, st, P, D);
     } else {

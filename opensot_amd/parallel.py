@@ -93,8 +93,11 @@ class ShardedCycle:
         self.i += 1
         if self.A_sets is not None:
             self.stack.A = self.A_sets[k]
-        self.stack.update(self.dev_leaves[k])
-        self.stack.solve(self.B)
+        if hasattr(self.stack, "cycle"):     # update + solve in one launch (BatchedStack.cycle), same results
+            self.stack.cycle(self.dev_leaves[k])
+        else:
+            self.stack.update(self.dev_leaves[k])
+            self.stack.solve(self.B)
         if self.gather is not None:
             self.gather(self.stack.dq[:self.B], self.stack.status[:self.B])
 

@@ -124,9 +124,7 @@ class BatchedStack:
         return B
 
     # ---- AutoStack::update ------------------------------------------------------------------------
-    def update(self, dev_leaf, write_weights=True):
-        """write_weights=False: the update leaves self.w alone (out.w[k] = NULL), for per-row DIAGONAL weight matrices
-        (Task::setWeight(W) with a diagonal W, Aggregated.cpp:265-279) that the caller filled once"""
+    def _update_args(self, dev_leaf, write_weights=True):
         lb = abi.LeafBatch()
         lb.B = dev_leaf["B"]
         for k, lev in enumerate(dev_leaf["task"]):
@@ -151,8 +149,23 @@ class BatchedStack:
             lb.regularisation.p0, lb.regularisation.p1, lb.regularisation.p2 = _dev_ptr(p0), _dev_ptr(p1), _dev_ptr(p2)
             out.b_reg = _dev_ptr(self.b_reg)
         self._leaf_keep = dev_leaf
+        return lb, out
+
+    def update(self, dev_leaf, write_weights=True):
+        """AutoStack::update for the B instances of dev_leaf (stream-ordered).  write_weights=False: the update leaves self.w
+        alone (out.w[k] = NULL), for per-row DIAGONAL weight matrices (Task::setWeight(W) with a diagonal W,
+        Aggregated.cpp:265-279) that the caller filled once"""
+        lb, out = self._update_args(dev_leaf, write_weights)
         abi.check(self._lib.osot_stack_update(self._h, C.byref(lb), C.byref(out), _stream_ptr(self.device)),
                   "osot_stack_update")
+        return lb.B
+
+    def cycle(self, dev_leaf, write_weights=True):
+        """one control cycle, `stack->update(); solver->solve(dq)` (coman_ik.cpp:186-192), in ONE launch: same results as
+        update() followed by solve()"""
+        lb, out = self._update_args(dev_leaf, write_weights)
+        qb = self._qp_batch(lb.B)
+        abi.check(self._lib.osot_cycle(self._h, C.byref(lb), C.byref(out), C.byref(qb), _stream_ptr(self.device)), "osot_cycle")
         return lb.B
 
     # ---- Solver::solve ------------------------------------------------------------------------------

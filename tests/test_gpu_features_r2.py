@@ -103,3 +103,28 @@ def test_inverse_dynamics_producers_and_computed_torque_gpu(oracle, gpu_device):
         rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=0)
         okq = rq["status"] == 1
         assert okq.mean() > 0.95 and np.abs(x[okq] - rq["dq"][okq]).max() < 1e-6 * max(1.0, np.abs(x).max())
+
+
+@pytest.mark.parametrize("cfg,B", [("C3", 300), ("C4", 128), ("C5", 64), ("feature", 96)])
+def test_cycle_is_update_then_solve_gpu(cfg, B, gpu_device):
+    """osot_cycle (update + cascade of an instance by the same wavefront, one launch) gives bit-identical assembled arrays
+    and solutions to osot_stack_update followed by osot_ihqp_solve"""
+    if cfg == "feature":
+        plan, leaf = synth.make_feature_stack(B, seed=8)
+    elif cfg == "C5":
+        plan, leaf = synth.make_id_stack(B, seed=8)
+    else:
+        plan, leaf = synth.make_velocity_stack(cfg, B, seed=8)
+    a = BatchedStack(plan, B, device=0); b = BatchedStack(plan, B, device=0)
+    da, db = a.load_leaf(leaf), b.load_leaf(leaf)
+    a.update(da); a.solve(B)
+    b.cycle(db)
+    torch.cuda.synchronize()
+    assert (a.status[:B] == 0).all()
+    for x, y in [(a.dq, b.dq), (a.x_levels, b.x_levels), (a.status, b.status), (a.iterations, b.iterations), (a.lo, b.lo), (a.up, b.up),
+                 (a.l, b.l), (a.u, b.u), (a.C, b.C)] + list(zip(a.b, b.b)) + list(zip(a.w, b.w)):
+        if x is not None:
+            assert torch.equal(x, y)
+    # and a second cycle on the same objects (dispatch order from the first one's iteration counts)
+    b.cycle(db); torch.cuda.synchronize()
+    assert torch.equal(a.dq, b.dq)
