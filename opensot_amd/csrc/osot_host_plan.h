@@ -111,6 +111,11 @@ inline int plan_validate(const osot_plan_desc* p, const char** why) {
         flat += 1;
     }
     if (flat > OSOT_KMAX_FLAT_TASKS) { *why = "too many leaf tasks in total"; return OSOT_ERR_UNSUPPORTED; }
+    {
+        int rows_total = p->has_regularisation ? p->regularisation.rows : 0;
+        for (int k = 0; k < p->n_levels; ++k) for (int j = 0; j < p->level[k].n_tasks; ++j) rows_total += p->level[k].task[j].rows;
+        if (rows_total > OSOT_KMAX_FLAT_ROWS) { *why = "more than 256 task rows in all levels together"; return OSOT_ERR_UNSUPPORTED; }
+    }
     for (int j = 0; j < p->n_bounds; ++j)
         if (p->bound[j].kind < 0 || p->bound[j].kind > OSOT_BOUND_VELOCITY_LIMITS) { *why = "unknown bound kind"; return OSOT_ERR_UNSUPPORTED; }
     for (int j = 0; j < p->n_rowblocks; ++j) {
@@ -237,6 +242,13 @@ inline void make_update_plan(const osot_plan_desc& pl, DevUpdatePlan& U) {
         d.mask = 0ull; d.prow = t.rows; d.sublam = 1.0;
     }
     U.ntasks = flat;
+    {
+        int fr = 0;
+        for (int j = 0; j < flat; ++j)
+            for (int r = 0; r < U.task[j].rows && fr < OSOT_KMAX_FLAT_ROWS; ++r, ++fr) { U.row_task[fr] = (unsigned char)j; U.row_in_task[fr] = (short)r; }
+        U.total_rows = fr;
+        for (int k = 0; k < pl.n_levels; ++k) if (U.dense_level[k]) U.any_dense = 1;
+    }
     U.nbounds = pl.n_bounds;
     for (int j = 0; j < pl.n_bounds; ++j) {
         U.bound[j].kind = pl.bound[j].kind; U.bound[j].scaling = pl.bound[j].scaling; U.bound[j].dT = pl.bound[j].dT;

@@ -24,11 +24,15 @@
 #include <osot_mi355x.h>   // OSOT_MAX_* (the C-ABI's limits are the kernels' limits)
 #include "osot_qp_core.h"
 
+#ifndef OSOT_WAVES32
+#define OSOT_WAVES32 2   // waves per SIMD the NP = 32 cascade is compiled for (register budget 512 / OSOT_WAVES32)
+#endif
 #define OSOT_KMAX_LEVELS 8
 #define OSOT_KMAX_TASKS 8
 #define OSOT_KMAX_FLAT_TASKS 24
 #define OSOT_KMAX_BOUNDS 4
 #define OSOT_KMAX_ROWBLOCKS 8
+#define OSOT_KMAX_FLAT_ROWS 256
 
 namespace osot {
 
@@ -404,7 +408,7 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
 }
 
 template <int NP, bool PROF>
-__global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cascade_kernel(const DevPlan P, const DevBatch D) {
+__global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : 1)) osot_cascade_kernel(const DevPlan P, const DevBatch D) {
     OSOT_DYNAMIC_LDS(osot_smem);
     const long long inst = D.order ? D.order[blockIdx.x] : (int)blockIdx.x;
     cascade_body<NP, PROF>(P, D, inst, (int)threadIdx.x, osot_smem);
@@ -555,6 +559,10 @@ struct DevUpdatePlan {
     int n, L, nc, nc_stored;
     int m[OSOT_KMAX_LEVELS], ma[OSOT_KMAX_LEVELS];
     int dense_level[OSOT_KMAX_LEVELS];   // level holds a block with a non-diagonal W: W_k A_k and W_k b_k are formed
+    int any_dense;                       // some level does
+    int total_rows;                      // task rows of all levels + the regularisation task (<= OSOT_KMAX_FLAT_ROWS)
+    unsigned char row_task[OSOT_KMAX_FLAT_ROWS];   // flat row -> flat task index
+    short row_in_task[OSOT_KMAX_FLAT_ROWS];        // flat row -> row inside its task
     int ntasks;                          // all levels, flat
     DevTaskS task[OSOT_KMAX_FLAT_TASKS];
     int nbounds;
@@ -583,6 +591,10 @@ struct DevUpdate {
     double* b_reg;                       // b of the regularisation task (flat task entry with level = -1), [B][rows]
 };
 static_assert(sizeof(DevUpdate) <= 4096, "kernel arguments are limited to 4 KB");
+static_assert(sizeof(DevUpdate) % 16 == 0 && sizeof(DevUpdatePlan) % 16 == 0, "staged into LDS in 16-byte pieces");
+// LDS the update needs (bytes): copies of the per-call arguments and of the static plan, then the collision block's
+// candidate-ranking scratch (256 doubles, 256 + 2 ints)
+constexpr int kUpdateLdsBytes = (int)sizeof(DevUpdate) + (int)sizeof(DevUpdatePlan) + 256 * 8 + 258 * 4 + 8;
 
 // Eigen's Quaterniond(Matrix3d) as invoked by cartesian_utils::computeCartesianError
 // (src/utils/cartesian_utils.cpp:83-84); R row-major, q = (x, y, z, w)
@@ -596,16 +608,34 @@ __device__ inline void rot_to_quat(const double* R, double* q) {
         q[1] = (R[2] - R[6]) * t;
         q[2] = (R[3] - R[1]) * t;
     } else {
+        // Eigen picks i = argmax of the diagonal (first wins ties), j = (i+1)%3, k = (j+1)%3.  The three cases are written
+        // out with CONSTANT indices: a lane-dependent index into R / q would put both arrays into scratch memory (that was
+        // 208 bytes per lane and a dozen memory round trips on the critical path of every wave)
         int i = 0;
         if (R[4] > R[0]) i = 1;
-        if (R[8] > R[i * 3 + i]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0);
-        q[i] = 0.5 * t;
-        t = 0.5 / t;
-        q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t;
-        q[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
-        q[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+        if (R[8] > ((i == 1) ? R[4] : R[0])) i = 2;
+        if (i == 0) {            // j = 1, k = 2
+            t = sqrt(R[0] - R[4] - R[8] + 1.0);
+            q[0] = 0.5 * t;
+            t = 0.5 / t;
+            q[3] = (R[7] - R[5]) * t;
+            q[1] = (R[3] + R[1]) * t;
+            q[2] = (R[6] + R[2]) * t;
+        } else if (i == 1) {     // j = 2, k = 0
+            t = sqrt(R[4] - R[8] - R[0] + 1.0);
+            q[1] = 0.5 * t;
+            t = 0.5 / t;
+            q[3] = (R[2] - R[6]) * t;
+            q[2] = (R[7] + R[5]) * t;
+            q[0] = (R[1] + R[3]) * t;
+        } else {                 // j = 0, k = 1
+            t = sqrt(R[8] - R[0] - R[4] + 1.0);
+            q[2] = 0.5 * t;
+            t = 0.5 / t;
+            q[3] = (R[3] - R[1]) * t;
+            q[0] = (R[2] + R[6]) * t;
+            q[1] = (R[5] + R[7]) * t;
+        }
     }
 }
 
@@ -639,113 +669,104 @@ __device__ inline void cartesian_b(const double* Ta, const double* Td, const dou
     }
 }
 
-// scratch: 256 ints + 256 doubles + 1 int of LDS for the collision block's candidate ranking (the stand-alone kernel's own
-// static arrays; the fused kernel lends the head of the cascade's slice, which is idle until the cascade starts)
-__device__ __forceinline__ void update_body(const DevUpdate& U, const long long inst, const int t, int* src_of_row, double* dcand,
-                                            int* n_used_s) {
-    const DevUpdatePlan& PL = *U.plan;
+// AutoStack::update() of one instance by one wavefront.  `args_global` = the kernel's DevUpdate as MEMORY (the kernarg
+// segment), `lds` = kUpdateLdsBytes of LDS.  First the per-call pointers and the static plan are staged into LDS by ONE
+// batch of 16-byte vector loads (6 per lane): after that every lane looks up its row's task, gains and pointers with
+// per-lane LDS reads -- no walk over the task table with one dependent scalar load per entry (that walk, three times over,
+// was most of the 14 us a wave spent here), and no lane-indexed access to kernel arguments (which the compiler can only
+// serve from a scratch copy).  Dependent chain: stage -> look up -> leaf loads -> arithmetic -> stores.
+__device__ __forceinline__ void update_body(const DevUpdate* args_global, const long long inst, const int t, char* lds) {
+    DevUpdate* Ul = reinterpret_cast<DevUpdate*>(lds);
+    DevUpdatePlan* Pl = reinterpret_cast<DevUpdatePlan*>(lds + sizeof(DevUpdate));
+    double* dcand = reinterpret_cast<double*>(lds + sizeof(DevUpdate) + sizeof(DevUpdatePlan));
+    int* src_of_row = reinterpret_cast<int*>(dcand + 256);
+    int* n_used_s = src_of_row + 256;
+    {
+        struct alignas(16) v2f64 { double a, b; };     // one 16-byte load / LDS store per piece
+        constexpr int NA = (int)sizeof(DevUpdate) / 16, NP_ = (int)sizeof(DevUpdatePlan) / 16;
+        const v2f64* ga = reinterpret_cast<const v2f64*>(args_global);
+        v2f64* la = reinterpret_cast<v2f64*>(Ul);
+        for (int e = t; e < NA; e += 64) la[e] = ga[e];
+        wave_sync();
+        const v2f64* gp = reinterpret_cast<const v2f64*>(Ul->plan);
+        v2f64* lp = reinterpret_cast<v2f64*>(Pl);
+        for (int e = t; e < NP_; e += 64) lp[e] = gp[e];
+        wave_sync();
+    }
+    const DevUpdate& U = *Ul;
+    const DevUpdatePlan& PL = *Pl;
     const int n = PL.n;
     // ---- tasks: b and diag(W) (tasks::Aggregated::generateAll / generateWeight, Aggregated.cpp:113-132, 265-279).
-    // ONE LANE PER ROW of the whole stack (all levels, flat): the task table is walked uniformly (scalar loads) and
-    // each lane keeps the parameters of the task its row belongs to; every kind then goes through the SAME four
-    // loads (p0[ia], p0[ib], p1[ic], p2[id], each optional), so that all rows of all tasks cost one memory round
-    // trip instead of one per task (the kernel was a chain of ~9 dependent round trips: 18 us for 3 MB).
-    {
-        int total = 0;
-        for (int j = 0; j < PL.ntasks; ++j) total += PL.task[j].rows;
-        for (int fr = t; fr < total; fr += 64) {
-            int kind = -1, rows = 0, r = 0, off = 0, level = 0, prow = 0;
-            unsigned long long mask = 0ull;
-            double weight = 0.0, lam = 0.0, lam2 = 0.0, sublam = 1.0;
-            const double *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
-            int start = 0;
-            for (int j = 0; j < PL.ntasks; ++j) {
-                const DevTaskS& tk = PL.task[j];
-                if (fr >= start && fr < start + tk.rows) {
-                    kind = tk.kind; rows = tk.rows; r = fr - start; off = tk.off; level = tk.level;
-                    weight = tk.weight; lam = tk.lambda; lam2 = tk.lambda2;
-                    p0 = U.task[j].p0; p1 = U.task[j].p1; p2 = U.task[j].p2;
-                    mask = tk.mask; prow = tk.prow; sublam = tk.sublam;
-                }
-                start += tk.rows;
-            }
-            double* wl = nullptr;
-            double* bl = nullptr;
-            for (int k = 0; k < PL.L; ++k)
-                if (k == level) { bl = U.b[k] + inst * PL.m[k] + off + r; wl = U.w[k] ? U.w[k] + inst * PL.m[k] + off + r : nullptr; }
-            if (level < 0) bl = U.b_reg + inst * rows + r;   // regularisation task: own output, weight stays in the plan
-            if (wl) *wl = weight;
-            if (kind == 1) continue;   // Cartesian rows: below, one lane per task
-            // acceleration kinds read (pose error, velocity error) from p0: [2 rows] per instance
-            const bool acc = (kind == 4 || kind == 5 || kind == 6);
-            // SubTask (SubTask.cpp:22-112): row r of this block is row pr of the parent, whose size the leaf inputs have
-            int pr = r;
-            if (mask != 0ull) {
-                unsigned long long mm = mask;
-                for (int q = 0; q < r; ++q) mm &= mm - 1ull;      // drop the r lowest set bits
-                pr = __builtin_ctzll(mm);
-            }
-            (void)rows;
-            const long long base = inst * (long long)prow + pr;
-            const double x0 = acc ? p0[inst * 2LL * prow + pr] : p0[base];
-            const double x1 = acc ? p0[inst * 2LL * prow + prow + pr] : 0.0;
-            const double x2 = (p1 && kind != 0 && kind != 6) ? p1[base] : 0.0;
-            const double x3 = (p2 && kind != 0) ? p2[base] : 0.0;
-            double v;
-            if (kind == 2 || kind == 3) {            // CoM (CoM.cpp:145-149), Postural (Postural.cpp:97-100)
-                v = x3 + lam * (x2 - x0);
-            } else if (kind == 4 || kind == 5) {
-                // acceleration::Cartesian / CoM (acceleration/Cartesian.cpp:152-160, acceleration/CoM.cpp:86-92):
-                // J qddot + Jdot qdot - a_ref - lambda2 Kd vel_err - lambda Kp pose_err = 0, Kp = Kd = I
-                v = x3 + lam2 * x1 + lam * x0 - x2;
-            } else if (kind == 6) {                  // acceleration::Postural (acceleration/Postural.cpp:145-158)
-                v = x3 + lam2 * x1 + lam * x0;
-            } else {                                 // Generic: b supplied
-                v = x0;
-            }
-            *bl = (mask != 0ull) ? v * sublam : v;
+    // ONE LANE PER ROW of the whole stack (all levels, flat); every kind goes through the SAME four loads (p0[ia], p0[ib],
+    // p1[ic], p2[id], each optional), so that all rows of all tasks cost one memory round trip.
+    for (int fr = t; fr < PL.total_rows; fr += 64) {
+        const int j = PL.row_task[fr], r = PL.row_in_task[fr];
+        const DevTaskS& tk = PL.task[j];
+        const int kind = tk.kind, level = tk.level, prow = tk.prow;
+        const unsigned long long mask = tk.mask;
+        const double *p0 = U.task[j].p0, *p1 = U.task[j].p1, *p2 = U.task[j].p2;
+        double* bl;
+        double* wl = nullptr;
+        if (level < 0) bl = U.b_reg + inst * tk.rows + r;   // regularisation task: own output, weight stays in the plan
+        else {
+            bl = U.b[level] + inst * PL.m[level] + tk.off + r;
+            if (U.w[level]) wl = U.w[level] + inst * PL.m[level] + tk.off + r;
         }
+        if (wl) *wl = tk.weight;
+        if (kind == 1) continue;   // Cartesian rows: below, one lane per task
+        // acceleration kinds read (pose error, velocity error) from p0: [2 rows] per instance
+        const bool acc = (kind == 4 || kind == 5 || kind == 6);
+        // SubTask (SubTask.cpp:22-112): row r of this block is row pr of the parent, whose size the leaf inputs have
+        int pr = r;
+        if (mask != 0ull) {
+            unsigned long long mm = mask;
+            for (int q = 0; q < r; ++q) mm &= mm - 1ull;      // drop the r lowest set bits
+            pr = __builtin_ctzll(mm);
+        }
+        const long long base = inst * (long long)prow + pr;
+        const double x0 = acc ? p0[inst * 2LL * prow + pr] : p0[base];
+        const double x1 = acc ? p0[inst * 2LL * prow + prow + pr] : 0.0;
+        const double x2 = (p1 && kind != 0 && kind != 6) ? p1[base] : 0.0;
+        const double x3 = (p2 && kind != 0) ? p2[base] : 0.0;
+        const double lam = tk.lambda, lam2 = tk.lambda2;
+        double v;
+        if (kind == 2 || kind == 3) {            // CoM (CoM.cpp:145-149), Postural (Postural.cpp:97-100)
+            v = x3 + lam * (x2 - x0);
+        } else if (kind == 4 || kind == 5) {
+            // acceleration::Cartesian / CoM (acceleration/Cartesian.cpp:152-160, acceleration/CoM.cpp:86-92):
+            // J qddot + Jdot qdot - a_ref - lambda2 Kd vel_err - lambda Kp pose_err = 0, Kp = Kd = I
+            v = x3 + lam2 * x1 + lam * x0 - x2;
+        } else if (kind == 6) {                  // acceleration::Postural (acceleration/Postural.cpp:145-158)
+            v = x3 + lam2 * x1 + lam * x0;
+        } else {                                 // Generic: b supplied
+            v = x0;
+        }
+        *bl = (mask != 0ull) ? v * tk.sublam : v;
     }
-    // ---- Cartesian tasks, ONE LANE PER TASK: the pose error (Cartesian.cpp:190-240: position difference +
-    // quaternion orientation error) is a chain of ~200 dependent fp64 operations; run one after the other on lane 0
-    // the four end-effector tasks of BASELINE config 3 made this kernel latency-bound (18 us for 3 MB of traffic).
-    // The task table is walked uniformly (scalar loads) and each lane keeps the parameters of "its" task.
-    {
-        const double *cp0 = nullptr, *cp1 = nullptr, *cp2 = nullptr;
-        double* cb = nullptr;
-        double clam = 0.0, cog = 0.0, csub = 1.0;
-        unsigned cmask = 0x3fu;
-        bool cbody = false;
-        for (int j = 0; j < PL.ntasks; ++j) {
-            const DevTaskS& tk = PL.task[j];
-            if (tk.kind == 1 && t == j) {
-                cp0 = U.task[j].p0; cp1 = U.task[j].p1; cp2 = U.task[j].p2;
-                cb = U.b[tk.level] + inst * PL.m[tk.level] + tk.off;
-                clam = tk.lambda; cog = tk.ogain; cbody = tk.body != 0;
-                if (tk.mask != 0ull) { cmask = (unsigned)tk.mask & 0x3fu; csub = tk.sublam; }   // e.g. position only
-            }
-        }
-        if (cb) {
-            // both poses (and the feed-forward twist) are fetched in ONE batch before any arithmetic: the
-            // rotation-to-quaternion branches would otherwise pull their matrix entries in one dependent round trip
-            // after the other
-            double Ta[12], Td[12], tw[6], b6[6];
+    // ---- Cartesian tasks, ONE LANE PER TASK (lane j = flat task j): the pose error (Cartesian.cpp:190-240: position
+    // difference + quaternion orientation error) is a chain of ~200 dependent fp64 operations; both poses (and the
+    // feed-forward twist) are fetched in ONE batch before any arithmetic
+    if (t < PL.ntasks && PL.task[t].kind == 1) {
+        const DevTaskS& tk = PL.task[t];
+        const double *cp0 = U.task[t].p0, *cp1 = U.task[t].p1, *cp2 = U.task[t].p2;
+        double* cb = U.b[tk.level] + inst * PL.m[tk.level] + tk.off;
+        const unsigned cmask = (tk.mask != 0ull) ? ((unsigned)tk.mask & 0x3fu) : 0x3fu;   // e.g. position only
+        const double csub = (tk.mask != 0ull) ? tk.sublam : 1.0;
+        double Ta[12], Td[12], tw[6], b6[6];
 #pragma unroll
-            for (int i = 0; i < 12; ++i) { Ta[i] = cp0[inst * 12 + i]; Td[i] = cp1[inst * 12 + i]; }
+        for (int i = 0; i < 12; ++i) { Ta[i] = cp0[inst * 12 + i]; Td[i] = cp1[inst * 12 + i]; }
 #pragma unroll
-            for (int i = 0; i < 6; ++i) tw[i] = cp2 ? cp2[inst * 6 + i] : 0.0;
-            cartesian_b(Ta, Td, tw, clam, cog, b6, cbody);
-            int kq = 0;
-            for (int i = 0; i < 6; ++i) if ((cmask >> i) & 1u) cb[kq++] = b6[i] * csub;
-        }
+        for (int i = 0; i < 6; ++i) tw[i] = cp2 ? cp2[inst * 6 + i] : 0.0;
+        cartesian_b(Ta, Td, tw, tk.lambda, tk.ogain, b6, tk.body != 0);
+        int kq = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) if ((cmask >> i) & 1u) { cb[kq] = b6[i] * csub; kq++; }
     }
     // ---- levels with a non-diagonal weight: W_k A_k and W_k b_k with W_k = blockdiag(weight_i W_i) (Task::getWA / getWb,
     // Task.h:273-300; Aggregated::generateWeight, Aggregated.cpp:265-279).  Blocks without a matrix contribute
     // weight_i * rows.  b_k was written above by other lanes of this workgroup: one barrier.
     {
-        bool any_dense = false;
-        for (int k = 0; k < PL.L; ++k) any_dense = any_dense || (PL.dense_level[k] != 0);
-        if (any_dense) {
+        if (PL.any_dense) {
             workgroup_fence();     // b_k is in global memory: make this workgroup's stores visible to its loads
             __syncthreads();
             for (int j = 0; j < PL.ntasks; ++j) {
@@ -925,11 +946,9 @@ __device__ __forceinline__ void update_body(const DevUpdate& U, const long long 
 }
 
 __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
-    OSOT_STATIC_LDS(int, src_of_row, 256);
-    OSOT_STATIC_LDS(double, dcand, 256);
-    OSOT_STATIC_LDS(int, n_used_s, 2);
+    OSOT_STATIC_LDS(double, upd_lds, kUpdateLdsBytes / 8);
     if ((long long)blockIdx.x >= U.B) return;
-    update_body(U, blockIdx.x, threadIdx.x, src_of_row, dcand, n_used_s);
+    update_body(OSOT_KERNARG_PTR(DevUpdate, U), blockIdx.x, threadIdx.x, reinterpret_cast<char*>(upd_lds));
 }
 
 // One control cycle in ONE launch: AutoStack::update() and Solver::solve() of an instance by the same wavefront
@@ -937,17 +956,22 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
 // HBM arrays (they are outputs of the update in their own right) but come back from the CU's own L1 / L2 lines; what is
 // saved is a launch, its tail and the gap between the two (18 + ~4 us of a 227 us step at BASELINE config 3).
 template <int NP>
-__global__ void __launch_bounds__(64, (NP == 32 ? 2 : 1)) osot_cycle_kernel(const DevUpdate U, const DevPlan P, const DevBatch D) {
+__global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : 1)) osot_cycle_kernel(const DevUpdate U, const DevPlan P, const DevBatch D) {
     OSOT_DYNAMIC_LDS(osot_smem);
     const long long inst = D.order ? D.order[blockIdx.x] : (int)blockIdx.x;
-    {
-        double* dsc = reinterpret_cast<double*>(osot_smem);
-        int* isc = reinterpret_cast<int*>(dsc + 256);
-        update_body(U, inst, (int)threadIdx.x, isc, dsc, isc + 256);
-    }
+    const long long tc0 = D.prof ? (long long)clock64() : 0;
+    const long long tw0 = D.prof ? (long long)wall_clock64() : 0;
+    update_body(OSOT_KERNARG_PTR(DevUpdate, U), inst, (int)threadIdx.x, osot_smem);   // (the cascade's slice is idle until it starts)
     workgroup_fence();      // the update's global stores are visible to the cascade's loads (same workgroup)
     __syncthreads();
+    const long long tc1 = D.prof ? (long long)clock64() : 0;
     cascade_body<NP, false>(P, D, inst, (int)threadIdx.x, osot_smem);
+    if (D.prof && threadIdx.x == 0) {   // diagnostic (osot_solver_profile_cycle): shader-clock cycles of the two halves
+        D.prof[inst * 4] = tc1 - tc0;
+        D.prof[inst * 4 + 1] = (long long)clock64() - tc1;
+        D.prof[inst * 4 + 2] = tw0;                          // constant-rate (100 MHz) timestamps: the launch's timeline
+        D.prof[inst * 4 + 3] = (long long)wall_clock64();
+    }
 }
 
 }  // namespace osot

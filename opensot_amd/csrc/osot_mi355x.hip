@@ -226,7 +226,9 @@ int osot_cycle(osot_solver* s, const osot_leaf_batch* leaf, const osot_assembled
     const char* why = "";
     int rc = make_update_args(s->plan, s->h_uplan, leaf, out, s->d_uplan, U, &why);
     if (rc != OSOT_OK) return fail(rc, why);
-    return ihqp_launch(s, b, hip_stream, nullptr, &U);
+    // developer knob: OSOT_DEBUG_CYCLE_PROF=<device pointer, hex> receives [B][2] int64 cycle counts (update, cascade)
+    static const char* dbg = getenv("OSOT_DEBUG_CYCLE_PROF");
+    return ihqp_launch(s, b, hip_stream, dbg ? (long long*)strtoull(dbg, nullptr, 16) : nullptr, &U);
 }
 
 int osot_solver_profile_phases(osot_solver* s, const osot_qp_batch* b, long long* cycles, void* hip_stream) {

@@ -23,6 +23,9 @@
 // sixteen round trips) and makes it wait once, for all of them.
 #define OSOT_KEEP16(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), \
                                          "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]))
+// the FIRST kernel parameter as memory: a pointer into the kernarg segment (taking the address of a by-value kernel
+// parameter would make the compiler copy it to scratch)
+#define OSOT_KERNARG_PTR(type, first_param) ((const type*)(__builtin_amdgcn_kernarg_segment_ptr()))
 // call-site inlining (statement attribute): used where ONE instantiation of a template must be inlined
 #define OSOT_ALWAYS_INLINE_CALL [[clang::always_inline]]
 // a 64-bit integer that holds an HBM address -> pointer in the global address space (global_load, not flat_load)

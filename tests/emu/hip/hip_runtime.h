@@ -160,4 +160,5 @@ inline V __shfl_down(V v, int delta, int width) {
     return out;
 }
 inline long long clock64() { return 0; }
+inline long long wall_clock64() { return 0; }
 inline void __syncthreads() { int z = 0; emu::exchange(&z, nullptr, sizeof(int), 0, 64); }

@@ -9,6 +9,7 @@
 
 #define OSOT_DYNAMIC_LDS(name) char* name = emu::dyn_smem_ptr()
 #define OSOT_STATIC_LDS(type, name, count) static type name[count]
+#define OSOT_KERNARG_PTR(type, first_param) (&(first_param))
 #define OSOT_ALWAYS_INLINE_CALL
 #define OSOT_KEEP16(a) do { } while (0)
 #define OSOT_GLOBAL_F64(addr) (reinterpret_cast<const double*>(addr))
