@@ -323,6 +323,10 @@ int osot_solver_set_timing(osot_solver* s, int enabled);
 #define OSOT_SCHEDULE_IN_ORDER 0
 #define OSOT_SCHEDULE_LONGEST_FIRST 1
 int osot_solver_set_schedule(osot_solver* s, int mode);
+/* instances the device works on at once for this solver's plan (one wavefront each: CUs x resident wavefronts per CU, from
+ * the kernel's register and LDS footprint): the dispatch order is planned for it, and batches that are a multiple of it
+ * waste no round */
+int osot_solver_resident_waves(osot_solver* s, int* waves);
 /* Task::setActive (include/OpenSoT/Task.h:232-239, 375-400): an inactive task's A is zero -- it adds nothing to H and g
  * of its level and its optimality rows are void for the levels below.  The producer's Jacobian rows stay untouched in
  * A_k; the cascade ignores them.  Takes effect at the next osot_ihqp_solve.  (Column masks, Task::setActiveJointsMask,

@@ -144,7 +144,7 @@ inline int plan_validate(const osot_plan_desc* p, const char** why) {
 // (rlo, rup, rptr: 8 B per row each; rowstate, eqlist: 4 B per row each; rsrc: 1 B per row).  Returns the total in doubles.
 inline int lds_layout(int NP, int n_rows, int* rows_off, int* rows_cap) {
     const int S = NP + 1;
-    int d = 2 * NP * S + 4 * NP;
+    int d = (NP == 32 ? WaveCtx<32>::M1_DOUBLES : WaveCtx<64>::M1_DOUBLES) + NP * S + 4 * NP;
     d = (d + 1) & ~1;
     *rows_off = d;
     const int cap = ((n_rows > 0 ? n_rows : 1) + 1) & ~1;
@@ -204,7 +204,7 @@ inline int make_dev_plan(const osot_plan_desc& p, const unsigned char* level_act
     // cascade layout: M1, M2, V | rlo, rup, rptr | rowstate, eqlist | rsrc bytes
     const int S = NP + 1;
     const int cap = ((nrows_max > 0 ? nrows_max : 1) + 1) & ~1;
-    int total = ((2 * NP * S + 4 * NP) + 1) & ~1;
+    int total = (((NP == 32 ? WaveCtx<32>::M1_DOUBLES : WaveCtx<64>::M1_DOUBLES) + NP * S + 4 * NP) + 1) & ~1;
     P.lds_rows_off = total;
     P.lds_rows_cap = cap;
     total += 3 * cap + cap;

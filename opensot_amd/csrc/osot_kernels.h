@@ -25,7 +25,10 @@
 #include "osot_qp_core.h"
 
 #ifndef OSOT_WAVES32
-#define OSOT_WAVES32 2   // waves per SIMD the NP = 32 cascade is compiled for (register budget 512 / OSOT_WAVES32)
+#define OSOT_WAVES32 2   // waves per SIMD the NP = 32 cascade is compiled for (register budget 512 / OSOT_WAVES32).  3 (168
+                         // VGPRs; with the 15.9 KB LDS slice of the packed R: 10 waves per CU, 2560 instances in flight) was
+                         // measured: 43 spilled registers make every wave 10 % slower, and a batch of 4096 still needs two
+                         // jobs on 1536 of the slots -- launch 168 us against 166 us, bench step 0.229 ms against 0.218 ms
 #endif
 #define OSOT_KMAX_LEVELS 8
 #define OSOT_KMAX_TASKS 8
@@ -98,8 +101,8 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
     WaveCtx<NP> w;
     w.c = lane % NP; w.h = lane / NP; w.n = n;
     w.M1 = base;
-    w.M2 = base + NP * S;
-    w.V = base + 2 * NP * S;
+    w.M2 = base + WaveCtx<NP>::M1_DOUBLES;
+    w.V = w.M2 + NP * S;
     w.rlo = base + P.lds_rows_off;
     w.rup = w.rlo + P.lds_rows_cap;
     w.rptr = reinterpret_cast<unsigned long long*>(w.rup + P.lds_rows_cap);
@@ -110,7 +113,7 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
     const int c = w.c, h = w.h;
     const bool valid = c < n;
     // zero the matrices once: the padding beyond n stays zero for the whole kernel
-    for (int e = lane; e < 2 * NP * S + 4 * NP; e += 64) base[e] = 0.0;
+    for (int e = lane; e < WaveCtx<NP>::M1_DOUBLES + NP * S + 4 * NP; e += 64) base[e] = 0.0;
     wave_sync();
 
     const bool has_box = D.l != nullptr;
@@ -201,7 +204,11 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
         bool lowrank = false;   // few stored rows: J and x in closed form, no H, no factorisation (lowrank_prepare32)
         double xprep = 0.0;
         if constexpr (NP == 32) {
+#ifndef OSOT_X_NO_LOWRANK
             if (!diag_h && ma <= kLowRankMax && !dense && !inact) {
+#else
+            if (false) {
+#endif
                 lowrank = true;
                 const int npost = m - ma;
                 const bool postc = valid && c < npost;
@@ -252,15 +259,19 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
             };
             // 32 rows at a time: all eight groups of four rows are requested before the first MFMA (32 fp64
             // registers in flight): one HBM/L2 round trip per 32 rows instead of one per group
-            for (int rb = 0; rb < ma; rb += 32) {
-                double ca0[8], ca1[8], cl0[8], cl1[8], cbr[8];
+#ifndef OSOT_HB_DEPTH
+#define OSOT_HB_DEPTH 8
+#endif
+            constexpr int HBD = OSOT_HB_DEPTH;   // groups of four rows requested before the first MFMA
+            for (int rb = 0; rb < ma; rb += 4 * HBD) {
+                double ca0[HBD], ca1[HBD], cl0[HBD], cl1[HBD], cbr[HBD];
 #pragma unroll
-                for (int ch = 0; ch < 8; ++ch) {
+                for (int ch = 0; ch < HBD; ++ch) {
                     ca0[ch] = 0.0; ca1[ch] = 0.0; cl0[ch] = 0.0; cl1[ch] = 0.0; cbr[ch] = 0.0;
                     if (rb + 4 * ch < ma) fetch(rb + 4 * ch, ca0[ch], ca1[ch], cl0[ch], cl1[ch], cbr[ch]);
                 }
 #pragma unroll
-                for (int ch = 0; ch < 8; ++ch) {
+                for (int ch = 0; ch < HBD; ++ch) {
                     if (rb + 4 * ch < ma) {
                         const double a0 = ca0[ch], a1 = ca1[ch], br = cbr[ch];
                         const double wa0 = cl0[ch], wa1 = cl1[ch];
@@ -422,7 +433,17 @@ __global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : 1)) osot_cascad
 // (classic longest-processing-time list scheduling).  This kernel builds that order: a counting sort of the
 // instance ids by min(cost, 255), one workgroup.  Results do not depend on the order (instances are independent).
 #ifndef OSOT_EMULATION   // (a 1024-thread workgroup with atomics: outside what tests/emu models; covered by the GPU tests)
-__global__ void __launch_bounds__(1024) osot_order_kernel(const int* cost, int* order, int B) {
+// `slots` = wavefronts the chip holds at once for this kernel (CUs x resident waves per CU).  The sorted list (descending
+// cost) is mapped to dispatch positions by the number of rounds the batch makes:
+//   B <= slots or B >= 2 slots : longest first (classic LPT list scheduling)
+//   slots < B < 2 slots        : k = B - slots jobs must start late, so 2k jobs share a slot and slots - k run alone.  The
+//                                ones that run alone are the LONGEST (the launch cannot end before its longest job anyway);
+//                                the 2k shortest share: first the k shortest (ascending: they free their slots early, in
+//                                that order), then the k medium ones in DESCENDING order, so that the first slot to free
+//                                takes the longest of them.  With plain LPT the last slot to free (the longest job's)
+//                                would have taken a late job: measured at BASELINE config 3, B = 4096 on 2560 slots, the
+//                                launch ended 20 us after its longest wave (tools/prof_cycle.py).
+__global__ void __launch_bounds__(1024) osot_order_kernel(const int* cost, int* order, int B, int slots) {
     __shared__ int hist[256];
     __shared__ int start[256];
     const int t = threadIdx.x;
@@ -446,9 +467,18 @@ __global__ void __launch_bounds__(1024) osot_order_kernel(const int* cost, int* 
     }
     if (t < 256) start[t] -= hist[t];   // inclusive -> exclusive
     __syncthreads();
+    const int late = B - slots;                       // jobs that cannot be in the first round
+    const bool paired = late > 0 && B < 2 * slots;
     for (int i = t; i < B; i += 1024) {
         int k = cost[i]; k = k < 0 ? 0 : (k > 255 ? 255 : k);
-        order[atomicAdd(&start[k], 1)] = i;
+        const int pos = atomicAdd(&start[k], 1);      // rank in descending order of cost
+        int where = pos;
+        if (paired) {
+            const int alone = slots - late;           // the longest `alone` jobs keep a slot to themselves
+            if (pos >= B - late) where = alone + (B - 1 - pos);          // the `late` shortest: ascending, right after
+            else if (pos >= alone) where = slots + (pos - alone);        // the medium ones: descending, second round
+        }
+        order[where] = i;
     }
 }
 #endif
@@ -482,7 +512,7 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
     double* base = reinterpret_cast<double*>(osot_smem);
     WaveCtx<NP> w;
     w.c = lane % NP; w.h = lane / NP; w.n = n;
-    w.M1 = base; w.M2 = base + NP * S; w.V = base + 2 * NP * S;
+    w.M1 = base; w.M2 = base + WaveCtx<NP>::M1_DOUBLES; w.V = w.M2 + NP * S;
     w.rlo = base + Q.lds_rows_off;
     w.rup = w.rlo + Q.lds_rows_cap;
     w.rptr = reinterpret_cast<unsigned long long*>(w.rup + Q.lds_rows_cap);
@@ -492,7 +522,7 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
     w.rsrc = reinterpret_cast<signed char*>(w.eqlist + Q.lds_rows_cap);
     const int c = w.c, h = w.h;
     const bool valid = c < n;
-    for (int e = lane; e < 2 * NP * S + 4 * NP; e += 64) base[e] = 0.0;
+    for (int e = lane; e < WaveCtx<NP>::M1_DOUBLES + NP * S + 4 * NP; e += 64) base[e] = 0.0;
     wave_sync();
     constexpr int HV = WaveCtx<NP>::HV;
     double Hc[NP / HV];

@@ -80,6 +80,7 @@ struct osot_solver {
     DevUpdatePlan h_uplan;
     unsigned char task_active[OSOT_MAX_LEVELS * OSOT_MAX_TASKS];   // Task::setActive flags
     bool any_inactive = false;
+    int slots = 1;      // wavefronts of the cascade kernel the device holds at once (CUs x resident workgroups per CU)
 };
 
 extern "C" {
@@ -135,6 +136,14 @@ int osot_solver_create(const osot_plan_desc* plan, int max_batch, int device, os
     s->device = device;
     s->timing = false;
     std::memset(s->task_active, 1, sizeof(s->task_active));
+    {   // resident workgroups: what the longest-first dispatch order is planned for (osot_order_kernel)
+        int per_cu = 0, cus = 0;
+        hipError_t e1 = (T == 32)
+            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, osot_cycle_kernel<32>, 64, lds)
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, osot_cycle_kernel<64>, 64, lds);
+        hipError_t e2 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+        s->slots = (e1 == hipSuccess && e2 == hipSuccess && per_cu > 0 && cus > 0) ? per_cu * cus : 2048;
+    }
     make_update_plan(*plan, s->h_uplan);
     // dispatch-order state and the static update plan live with the solver from the start (no lazy allocation on
     // whatever device is current)
@@ -187,6 +196,12 @@ int osot_solver_set_task_active(osot_solver* s, int level, int task, int active)
 int osot_solver_set_timing(osot_solver* s, int enabled) {
     if (!s) return fail(OSOT_ERR_INVALID, "null solver");
     s->timing = enabled != 0;
+    return OSOT_OK;
+}
+
+int osot_solver_resident_waves(osot_solver* s, int* waves) {
+    if (!s || !waves) return fail(OSOT_ERR_INVALID, "null argument");
+    *waves = s->slots;
     return OSOT_OK;
 }
 
@@ -301,7 +316,7 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
         s->events.push_back(ev);
     }
     if (s->schedule == 1) {   // the order for the next solve of a batch of this size
-        hipLaunchKernelGGL(osot_order_kernel, dim3(1), dim3(1024), 0, st, (const int*)s->d_cost, s->d_order, b->B);
+        hipLaunchKernelGGL(osot_order_kernel, dim3(1), dim3(1024), 0, st, (const int*)s->d_cost, s->d_order, b->B, s->slots);
         HIP_TRY(hipGetLastError());
         s->order_B = b->B;
         s->order_stream = st;

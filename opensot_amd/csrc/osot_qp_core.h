@@ -75,10 +75,20 @@ constexpr double kFeasMargin = OSOT_FEAS_MARGIN;  // cascade levels below the fi
 
 enum { QP_SOLVED = 0, QP_INFEASIBLE = 1, QP_MAX_ITER = 2, QP_NOT_PD = 3 };
 
+// R (the triangular factor of the working set; upper Hessenberg for a moment while a constraint is being dropped) lives in
+// M1.  NP = 64: plain [NP][S] storage, shared with the Cholesky factor L that factor_rows64 keeps there.  NP = 32: PACKED
+// by columns, column j holding rows 0 .. j+1 at offset j (j + 3) / 2 -- 560 doubles instead of 1056: the 4 KB that let ten
+// waves (instead of eight) share a CU's 160 KB of LDS, i.e. 2560 instead of 2048 instances in flight.  (At BASELINE
+// config 3 a batch of 4096 then is 1.6 instead of 2 jobs per slot: the long jobs get a slot to themselves and the launch
+// ends with its longest instance instead of with a late-started short one; tools/prof_cycle.py shows the timeline.)  A
+// column's rows are contiguous, so lane-per-row accesses of one column are conflict-free and the column offset is uniform.
+template <int NP>
+__device__ __forceinline__ int ridx(int i, int j) { return NP == 32 ? ((j * (j + 3)) >> 1) + i : i * (NP + 1) + j; }
 template <int NP>
 struct WaveCtx {
     static constexpr int HV = 64 / NP;
     static constexpr int S = NP + 1;
+    static constexpr int M1_DOUBLES = (NP == 32) ? 560 : NP * (NP + 1);   // 32 * 35 / 2 packed, or the full square
     int c, h;       // column index and half of this lane
     int n;
     double* M1;
@@ -118,7 +128,10 @@ __device__ __forceinline__ double clamp_inf(double v) {
 // before the first FMA (one LDS round trip per chunk) and four accumulators break the dependent chain.
 template <int NP>
 __device__ __forceinline__ double jt_rows_dot(const WaveCtx<NP>& w, const double* vec) {
-    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = 16;
+#ifndef OSOT_DOT_CH
+#define OSOT_DOT_CH 16
+#endif
+    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = OSOT_DOT_CH;
     const double* row = w.M2 + w.c * S + w.h;
     const double* v = vec + w.h;
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
@@ -140,7 +153,7 @@ __device__ __forceinline__ double jt_rows_dot(const WaveCtx<NP>& w, const double
 // z_c = sum_j JT[j][c] * vec[j]   (column walk, j split over the halves)
 template <int NP>
 __device__ __forceinline__ double jt_cols_dot(const WaveCtx<NP>& w, const double* vec) {
-    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = 16;
+    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = OSOT_DOT_CH;
     const double* col = w.M2 + w.h * S + w.c;
     const double* v = vec + w.h;
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
@@ -216,8 +229,8 @@ __device__ __forceinline__ void householder_add(const WaveCtx<NP>& w, double d, 
         for (int t = 0; t < RT; ++t) mrow[t * HV * S] = fma(-vb[t], wv, m[t]);
     }
     if (WRITE_R && h == 0) {
-        if (c < iq) w.M1[c * S + iq] = d;
-        else if (c == iq) w.M1[iq * S + iq] = alpha;
+        if (c < iq) w.M1[ridx<NP>(c, iq)] = d;
+        else if (c == iq) w.M1[ridx<NP>(iq, iq)] = alpha;
     }
     wave_sync();
 }
@@ -233,12 +246,12 @@ __device__ __forceinline__ void drop_constraint(const WaveCtx<NP>& w, int qq, in
     if (c >= qq && c < iq - 1) { Aq = An; uq = un; }
     if (h == 0 && c < n) {
         for (int q = qq; q < iq - 1; ++q)
-            if (c <= q + 1) w.M1[c * S + q] = w.M1[c * S + q + 1];
+            if (c <= q + 1) w.M1[ridx<NP>(c, q)] = w.M1[ridx<NP>(c, q + 1)];
     }
     wave_sync();
     iq--;
     for (int j = qq; j < iq; ++j) {
-        const double a = w.M1[j * S + j], b = w.M1[(j + 1) * S + j];
+        const double a = w.M1[ridx<NP>(j, j)], b = w.M1[ridx<NP>(j + 1, j)];
         wave_sync();   // every lane has read the pivot pair before lane j overwrites it
         const double hh = a * a + b * b;
         if (hh == 0.0) continue;
@@ -247,9 +260,11 @@ __device__ __forceinline__ void drop_constraint(const WaveCtx<NP>& w, int qq, in
         const double cg = a * rs_, sg = b * rs_;
         if (h == 0) {
             if (c >= j && c < iq) {
-                const double r1 = w.M1[j * S + c], r2 = w.M1[(j + 1) * S + c];
-                w.M1[j * S + c] = cg * r1 + sg * r2;
-                w.M1[(j + 1) * S + c] = cg * r2 - sg * r1;
+                const int o1 = ridx<NP>(j, c);            // (rows j, j+1 of column c: adjacent in the packed form)
+                const int o2 = ridx<NP>(j + 1, c);
+                const double r1 = w.M1[o1], r2 = w.M1[o2];
+                w.M1[o1] = cg * r1 + sg * r2;
+                w.M1[o2] = cg * r2 - sg * r1;
             }
             if (c < n) {
                 const double j1 = w.M2[j * S + c], j2 = w.M2[(j + 1) * S + c];
@@ -278,7 +293,11 @@ __device__ __forceinline__ void drop_constraint(const WaveCtx<NP>& w, int qq, in
 //   * Trailing updates (matrix core):  H(I,C) -= Lp(I) Lp(C)',  Linv(I,C) -= Lp(I) Linv_rows(C): the panel register
 //     is the A operand (m = row-in-tile, k = panel column) AND the B operand of every tile.  13 + 13 MFMAs per
 //     factorisation replace 32 x (16 LDS broadcasts + 32 VALU FMAs).  The (1,0) tile of H is never needed.
-// In : Ht (H + eps I with a unit diagonal beyond n), g by lane c.   Out: M1 = L, M2 = JT = L^-1, x = -(H+eps I)^-1 g.
+//   * L itself is never stored whole (M1 is the packed R of the working set, 560 doubles): the forward substitution
+//     L y = -g rides along, one panel at a time -- the finished panel goes through a 4 x 32 staging buffer (the head of M1,
+//     idle during the factorisation) so that lane c picks up its row's four entries L[c][4p .. 4p+3]; the backward
+//     substitution L'x = y is the product x = (L^-1)'y with the rows of L^-1 that have just been stored.
+// In : Ht (H + eps I with a unit diagonal beyond n), g by lane c.   Out: M2 = JT = L^-1, x = -(H+eps I)^-1 g; M1 clobbered.
 template <bool TT = false>
 __device__ inline int factor_tiles32(const WaveCtx<32>& w, double (&Hf)[16], double g, double& x_out, long long* tt = nullptr) {
     long long tt0 = TT ? (long long)clock64() : 0;
@@ -288,9 +307,9 @@ __device__ inline int factor_tiles32(const WaveCtx<32>& w, double (&Hf)[16], dou
     const int lane = c + 32 * w.h;
     const int ta = lane & 15, tq = lane >> 4;
     const bool valid = c < n;
-    double* M1 = w.M1;
+    double* PB = w.M1;   // [4][32] staging of the finished panel: PB[q * 32 + i] = L[i][4p + q]
     double* M2 = w.M2;
-    double* Vd = w.V;   // 1 / L[j][j] by j
+    double rhs = valid ? -g : 0.0;   // forward substitution, lane c = row c (replicated over the halves)
     v4f64 H00 = {Hf[0], Hf[1], Hf[2], Hf[3]}, H01 = {Hf[4], Hf[5], Hf[6], Hf[7]}, H11 = {Hf[12], Hf[13], Hf[14], Hf[15]};
     v4f64 L00, L10 = {0.0, 0.0, 0.0, 0.0}, L11;
 #pragma unroll
@@ -301,6 +320,7 @@ __device__ inline int factor_tiles32(const WaveCtx<32>& w, double (&Hf)[16], dou
         const int Ip = p >> 2, rp = p & 3;
         // panel columns (as rows, by symmetry) and the matching rows of L^-1
         double Pn[2], Rp[2];
+        double rsq[4];                         // 1 / L[j][j] of the panel's four columns (uniform)
         Pn[0] = Ip ? 0.0 : H00[rp];            // rows 0..15 of a column >= 16 are zero (above the diagonal)
         Pn[1] = Ip ? H11[rp] : H01[rp];
         Rp[0] = Ip ? L10[rp] : L00[rp];
@@ -313,7 +333,7 @@ __device__ inline int factor_tiles32(const WaveCtx<32>& w, double (&Hf)[16], dou
             if (!(piv > 0.0)) { bad = true; piv = 1.0; }
             double sq, rs;
             fast_sqrt_rsqrt(piv, sq, rs);
-            if (lane == lj) Vd[j] = rs;
+            rsq[qq] = rs;
             const bool mine = (tq == qq);
 #pragma unroll
             for (int X = 0; X < 2; ++X) {
@@ -339,10 +359,23 @@ __device__ inline int factor_tiles32(const WaveCtx<32>& w, double (&Hf)[16], dou
                 }
             }
         }
-        // L panel -> M1 (zeros above the diagonal included); final rows of L^-1 back into their tiles
-        M1[ta * S + 4 * p + tq] = Pn[0];
-        M1[(16 + ta) * S + 4 * p + tq] = Pn[1];
+        // finished panel (zeros above the diagonal included) -> staging; final rows of L^-1 back into their tiles
+        PB[tq * 32 + ta] = Pn[0];
+        PB[tq * 32 + 16 + ta] = Pn[1];
         if (Ip) { L10[rp] = Rp[0]; L11[rp] = Rp[1]; } else { L00[rp] = Rp[0]; }
+        wave_sync();
+        {   // forward substitution through the panel's four columns: y_j = rhs_j / L[j][j], rhs_i -= L[i][j] y_j below it
+            double lrow[4];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) lrow[qq] = PB[qq * 32 + c];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int j = 4 * p + qq;
+                const double yj = bcast(rhs, j) * rsq[qq];
+                rhs = (c == j) ? yj : ((c > j) ? fma(-lrow[qq], yj, rhs) : rhs);
+            }
+        }
+        wave_sync();   // the staging buffer is free for the next panel
         // trailing updates on the matrix core; the A operand is the panel restricted to the rows below it
         const double A0 = (ta > 4 * p + 3) ? -Pn[0] : 0.0;          // rows 0..15
         const double A1 = (16 + ta > 4 * p + 3) ? -Pn[1] : 0.0;     // rows 16..31
@@ -369,34 +402,11 @@ __device__ inline int factor_tiles32(const WaveCtx<32>& w, double (&Hf)[16], dou
     wave_sync();
     if (bad) { x_out = 0.0; return QP_NOT_PD; }
     OSOT_TT(1);   // L^-1 store
-    // L y = -g, then L'x = y, by substitution; columns / rows of L are fetched eight at a time ahead of the chain
-    const double invd = Vd[c];
-    double rhs = valid ? -g : 0.0;
-    for (int j0 = 0; j0 < 32; j0 += 8) {
-        double lcol[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) lcol[t] = M1[c * S + j0 + t];   // zero for c < j
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int j = j0 + t;
-            const double yj = bcast(rhs * invd, j);
-            rhs = (c == j) ? yj : fma(-lcol[t], yj, rhs);
-        }
-    }
-    OSOT_TT(2);   // forward substitution
-    double x = 0.0;
-    for (int i0 = 24; i0 >= 0; i0 -= 8) {
-        double lrow[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) lrow[t] = M1[(i0 + t) * S + c];   // zero for c > i; lane i itself is done
-#pragma unroll
-        for (int t = 7; t >= 0; --t) {
-            const int i = i0 + t;
-            const double xi = bcast(rhs * invd, i);
-            if (c == i) x = xi;
-            rhs = fma(-lrow[t], xi, rhs);
-        }
-    }
+    OSOT_TT(2);   // (forward substitution: done panel by panel above)
+    // L'x = y:  x_c = sum_j (L^-1)[j][c] y_j  (rhs holds y; rows of L^-1 = rows of JT)
+    if (w.h == 0) w.V[c] = valid ? rhs : 0.0;
+    wave_sync();
+    const double x = jt_cols_dot<32>(w, w.V);
     wave_sync();
     OSOT_TT(3);   // backward substitution
 #undef OSOT_TT
@@ -961,7 +971,11 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
     // global equality rows are; a task-local equality of this level is not: then the generic path runs): null-space
     // elimination instead of n_eq Householder updates of the full J (see nullspace_equalities32)
     bool used_nullspace = false;
+#ifdef OSOT_X_NO_NULLSPACE
+    if (false) {
+#else
     if (NP == 32 && diag_h && have_prev && !local_eq && n_eq >= 8 && n_eq <= 32 && n - n_eq <= kNullMax) {
+#endif
         const int r_ns = nullspace_equalities32<PROF>(reinterpret_cast<const WaveCtx<32>&>(w), n_eq, hdiag, g, xprev, x, prof);
         if (r_ns >= 0) { iq = r_ns; iters += n_eq; used_nullspace = true; n_eq = 0; }
     }
@@ -1123,7 +1137,10 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                 double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
                 int cc = 0;
                 // SC loads per trip: the walk is a chain of L1/L2 round trips, only loads in flight shorten it
-                constexpr int SC = 16;
+#ifndef OSOT_SCAN_SC
+#define OSOT_SCAN_SC 16
+#endif
+                constexpr int SC = OSOT_SCAN_SC;
                 for (; cc + SC <= n; cc += SC) {
                     double e[SC];
 #pragma unroll
@@ -1226,12 +1243,16 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
             double rr = 0.0;
             {
                 double d1 = (c < iq) ? d : 0.0;
-                const double rinv = (c >= me && c < iq) ? fast_rcp(M1[c * S + c]) : 0.0;
-                const double* rcol = M1 + ((c >= me && c < iq) ? c : 0) * S;   // in-range row for idle lanes
+                const bool mine = (c >= me && c < iq);
+                const double rinv = mine ? fast_rcp(M1[ridx<NP>(c, c)]) : 0.0;
+                const int rrow = mine ? c : 0;                                  // in-range row for idle lanes
                 for (int j0 = iq - 1; j0 >= me; j0 -= 4) {
                     double rc[4];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) rc[t] = rcol[(j0 - t >= 0) ? j0 - t : 0];
+                    for (int t = 0; t < 4; ++t) {     // R[c][j] is only used for c < j: rows above the diagonal exist in every column
+                        const int jj = (j0 - t >= 0) ? j0 - t : 0;
+                        rc[t] = M1[ridx<NP>((rrow <= jj) ? rrow : 0, jj)];
+                    }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int j = j0 - t;

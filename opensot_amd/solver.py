@@ -210,6 +210,12 @@ class BatchedStack:
         """Task::setActive (Task.h:232-239): an inactive task's rows count as zero rows from the next solve() on"""
         abi.check(self._lib.osot_solver_set_task_active(self._h, level, task, 1 if active else 0), "osot_solver_set_task_active")
 
+    def resident_waves(self):
+        """instances the device holds at once for this plan (one wavefront each)"""
+        v = C.c_int(0)
+        abi.check(self._lib.osot_solver_resident_waves(self._h, C.byref(v)), "osot_solver_resident_waves")
+        return v.value
+
     def set_schedule(self, longest_first=True):
         """dispatch order inside solve(): longest-first from the previous solve's iteration counts (default)
         or plain instance order; results are identical either way."""

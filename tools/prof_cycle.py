@@ -15,6 +15,7 @@ for _ in range(4):
     st.cycle(dev)
 torch.cuda.synchronize()
 c = buf.cpu().numpy()
+print("resident waves:", st.resident_waves())
 print("update half: mean %.0f max %.0f cycles; cascade half: mean %.0f max %.0f" % (c[:, 0].mean(), c[:, 0].max(), c[:, 1].mean(), c[:, 1].max()))
 t0 = c[:, 2].min()
 s = (c[:, 2] - t0) / 100.0; e = (c[:, 3] - t0) / 100.0     # microseconds
