@@ -241,6 +241,28 @@ def time_config(name, B, device, steps=20, warmup=5):
             "roofline": rf, "roofline_hbm": rh}
 
 
+def time_nhqp(B, device, steps=5, warmup=2):
+    """the null-space front-end (OpenSoT::solvers::nHQP, SURVEY 8f-2) on the C3 stack: update + osot_nhqp_solve"""
+    from opensot_amd import synth
+    from opensot_amd.solver import BatchedStack
+    plan, leaf = synth.make_velocity_stack("C3", B, seed=3000)
+    st = BatchedStack(plan, B, device=device, want_levels=False)
+    dev = st.load_leaf(leaf)
+    for _ in range(warmup):
+        st.update(dev); st.solve_nhqp(B)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st.update(dev); st.solve_nhqp(B)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ok = int((st.status[:B] == 0).sum().item())
+    return {"workload": "BASELINE configs[2] stack through the reference's null-space front-end (nHQP.cpp:155-204; defaults: A/b "
+                        "regularisation at 0.05 sv_max, selective null-space regularisation): per level an SVD of A N (parallel Jacobi in "
+                        "LDS), the QP in the nf = 32 / 29 / 5 free coordinates, q += N z, N <- N V2; three launches per level",
+            "batch": B, "value": B * steps / el, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "solved_ok": f"{ok}/{B}"}
+
+
 def time_kinematics(B, device, steps=20, warmup=5):
     from opensot_amd import kinematics as kin
     m = kin.humanoid32()
@@ -400,6 +422,10 @@ def main():
                     oc[name] = time_config(name, B, local_rank)
                 except Exception as e:
                     oc[name] = {"error": str(e)}
+            try:
+                oc["nHQP_C3"] = time_nhqp(4096, local_rank)
+            except Exception as e:
+                oc["nHQP_C3"] = {"error": str(e)}
             try:
                 oc["kinematics"] = time_kinematics(4096, local_rank)
             except Exception as e:

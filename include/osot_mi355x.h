@@ -341,6 +341,23 @@ int osot_solver_set_task_active(osot_solver* s, int level, int task, int active)
 #define OSOT_N_PHASES 18
 int osot_solver_profile_phases(osot_solver* s, const osot_qp_batch* batch, long long* cycles, void* hip_stream);
 
+/* ---- the null-space front-end: OpenSoT::solvers::nHQP (src/solvers/nHQP.cpp:155-204, 236-317, 357-390) ----
+ * Same stack, same assembled arrays as osot_ihqp_solve; per level the task is projected into the cumulated null space N of
+ * the levels above, an SVD of A N drives the reference's A/b regularisation and yields the level's null space, the QP is
+ * solved in the nf free coordinates (bounds become rows N z, compute_contraints :282-317) and q += N z, N <- N V2.  Three
+ * launches per level (prepare, the batched QP kernel, accumulate).  n <= 32, <= 64 rows per level, diagonal weights,
+ * global rows and the box only (the reference refuses task-local constraints, nHQP.cpp:41-44). */
+typedef struct {
+    int free_vars[OSOT_MAX_LEVELS];      /* free variables of each level.  The reference fixes them in its constructor from the
+                                            singular values of A N at construction (>= 1e-6 counts as rank, nHQP.cpp:88-103)
+                                            and never changes them; 0 = default: n, then previous minus the rows of the level
+                                            above (full row rank) */
+    double min_sv_ratio;                 /* setMinSingularValueRatio; 0 = DEFAULT_MIN_SV_RATIO = 0.05 (nHQP.h:66) */
+    int no_ab_regularization;            /* setPerformAbRegularization(false) */
+    int no_selective_ns_regularization;  /* setPerformSelectiveNullSpaceRegularization(false) */
+} osot_nhqp_options;
+int osot_nhqp_solve(osot_solver* s, const osot_qp_batch* batch, const osot_nhqp_options* options, void* hip_stream);
+
 /* ---- batch-of-one BackEnd surface (host pointers; mirrors BackEnd.h) ------------------------ */
 typedef struct osot_backend osot_backend;
 /* create_instance(number_of_variables, number_of_constraints, hessian_type, eps_regularisation)

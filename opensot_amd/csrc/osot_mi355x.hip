@@ -16,6 +16,7 @@
 #include "osot_host_plan.h"
 #include "osot_kin.h"
 #include "osot_id.h"
+#include "osot_nhqp_host.h"
 
 using namespace osot;
 
@@ -81,6 +82,8 @@ struct osot_solver {
     unsigned char task_active[OSOT_MAX_LEVELS * OSOT_MAX_TASKS];   // Task::setActive flags
     bool any_inactive = false;
     int slots = 1;      // wavefronts of the cascade kernel the device holds at once (CUs x resident workgroups per CU)
+    NhqpWorkspace nhqp; // scratch of the null-space front-end, allocated at its first use
+    bool nhqp_ready = false;
 };
 
 extern "C" {
@@ -169,6 +172,11 @@ int osot_solver_destroy(osot_solver* s) {
     if (s->d_cost) hipFree(s->d_cost);
     if (s->d_order) hipFree(s->d_order);
     if (s->d_uplan) hipFree(s->d_uplan);
+    if (s->nhqp_ready) {
+        void* ptrs[] = {s->nhqp.N[0], s->nhqp.N[1], s->nhqp.q0, s->nhqp.H, s->nhqp.g, s->nhqp.R, s->nhqp.rlo, s->nhqp.rup, s->nhqp.z,
+                        s->nhqp.V2, s->nhqp.qp_status, s->nhqp.qp_iters};
+        for (void* q : ptrs) if (q) hipFree(q);
+    }
     delete s;
     return OSOT_OK;
 }
@@ -196,6 +204,53 @@ int osot_solver_set_task_active(osot_solver* s, int level, int task, int active)
 int osot_solver_set_timing(osot_solver* s, int enabled) {
     if (!s) return fail(OSOT_ERR_INVALID, "null solver");
     s->timing = enabled != 0;
+    return OSOT_OK;
+}
+
+int osot_nhqp_solve(osot_solver* s, const osot_qp_batch* b, const osot_nhqp_options* opt, void* hip_stream) {
+    if (!s || !b) return fail(OSOT_ERR_INVALID, "null solver/batch");
+    if (b->B < 0 || b->B > s->max_batch) return fail(OSOT_ERR_INVALID, "batch size exceeds max_batch");
+    if (b->B == 0) return OSOT_OK;
+    if (!b->dq || !b->status) return fail(OSOT_ERR_INVALID, "dq/status output is null");
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return fail(OSOT_ERR_HIP, "hipSetDevice failed");
+    const osot_plan_desc& pl = s->plan;
+    {
+        int fv[OSOT_MAX_LEVELS]; const char* why = "";
+        int rc = nhqp_validate(pl, opt, fv, &why);
+        if (rc != OSOT_OK) return fail(rc, why);
+        for (int k = 0; k < pl.n_levels; ++k) {
+            int m, ma; plan_level_rows(&pl, k, &m, &ma);
+            if (ma > 0 && !b->A[k]) return fail(OSOT_ERR_INVALID, "A[k] is null for a level with stored rows");
+            if (!b->b[k]) return fail(OSOT_ERR_INVALID, "b[k] is null");
+        }
+        int nc = 0; plan_constraint_rows(&pl, &nc);
+        if (nc > 0 && (!b->C || !b->lo || !b->up)) return fail(OSOT_ERR_INVALID, "plan has constraint rows but C/lo/up is null");
+        if (pl.n_bounds > 0 && (!b->l || !b->u)) return fail(OSOT_ERR_INVALID, "plan has bounds but l/u is null");
+    }
+    if (!s->nhqp_ready) {
+        const NhqpSizes z = nhqp_sizes(pl, s->max_batch);
+        NhqpWorkspace& w = s->nhqp;
+        std::memset(&w, 0, sizeof(w));
+        auto dm = [](double** p, size_t cnt) { return hipMalloc((void**)p, sizeof(double) * (cnt ? cnt : 1)) == hipSuccess; };
+        bool ok = dm(&w.N[0], z.N) && dm(&w.N[1], z.N) && dm(&w.q0, z.q0) && dm(&w.H, z.H) && dm(&w.g, z.g) && dm(&w.R, z.R) &&
+                  dm(&w.rlo, z.rl) && dm(&w.rup, z.rl) && dm(&w.z, z.z) && dm(&w.V2, z.V2) &&
+                  hipMalloc((void**)&w.qp_status, sizeof(int) * z.st) == hipSuccess && hipMalloc((void**)&w.qp_iters, sizeof(int) * z.st) == hipSuccess;
+        if (!ok) return fail(OSOT_ERR_HIP, "device allocation for the nHQP workspace failed");
+        s->nhqp_ready = true;
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const unsigned grid = (unsigned)b->B;
+    const char* why = "";
+    int rc = nhqp_run(pl, b, opt, s->nhqp,
+        [&](const DevNhqp& Q) { hipLaunchKernelGGL(osot_nhqp_prepare_kernel, dim3(grid), dim3(64), 0, st, Q); },
+        [&](int B, int n, int nc, const double* H, const double* g, const double* A, const double* lA, const double* uA,
+            const double* l, const double* u, double eps, double* x, int* status, int* iters) {
+            return osot_qp_solve_batch(B, n, nc, H, g, A, lA, uA, l, u, eps, 0, x, status, iters, hip_stream);
+        },
+        [&](const DevNhqpAcc& A) { hipLaunchKernelGGL(osot_nhqp_accumulate_kernel, dim3(grid), dim3(64), 0, st, A); }, &why);
+    if (rc != OSOT_OK) return fail(rc, why);
+    HIP_TRY(hipGetLastError());
     return OSOT_OK;
 }
 

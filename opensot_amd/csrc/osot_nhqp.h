@@ -1,0 +1,383 @@
+// opensot_amd/csrc/osot_nhqp.h -- the NULL-SPACE front-end of the reference, OpenSoT::solvers::nHQP (src/solvers/nHQP.cpp),
+// for B instances: per priority level the task is projected into the cumulated null space of the levels above
+// (AN = A N, b0 = b - A q0), an SVD of AN drives the A/b regularisation and yields the level's own null space, a QP in the
+// nf free coordinates is solved by the batched back-end kernel (osot_qp_kernel), and q0 += N z, N <- N V2.
+//
+//   osot_nhqp_prepare_kernel ..... compute_cost + compute_contraints (nHQP.cpp:357-390, 236-279, 282-317) of one level:
+//                                  H, g, constraint rows / bounds in z-coordinates and V2 -> per-instance scratch in HBM
+//   osot_qp_kernel<32> ........... the level's QP (BackEnd convention)
+//   osot_nhqp_accumulate_kernel .. solution += N z; N <- N V2 (nHQP.cpp:182-196)
+//
+// One wavefront per instance, lane = c + 32 h like the QP core; n <= 32, m <= 64 rows per level.
+// The SVD: AN is m x nf with k = min(m, nf) <= 32.  The SYMMETRIC eigenproblem of the SMALL Gram matrix (AN AN' when
+// m <= nf, AN'AN otherwise) is solved by parallel two-sided Jacobi in LDS -- step s pairs column c with column c ^ s
+// (s = 1 .. kp-1, kp = the power of two above k: every pair exactly once per sweep, sixteen disjoint rotations at a
+// time, each lane updating its own column / row) -- and the other factor follows from one product with AN.  Squaring
+// costs accuracy only in singular values below ~1e-8 sv_max, which the reference's own regularisation overwrites
+// (anything below min_sv_ratio * sv_max = 0.05 sv_max is lifted, nHQP.cpp:262-266).  A level's null-space basis V2 need
+// not be the SVD's: every orthonormal basis gives the same q (the QP is posed in its coordinates and both
+// regularisations are basis-invariant); for m <= nf it is the orthogonal complement of the leading right singular
+// vectors, built with Householder reflections.
+#pragma once
+#include <osot_team.h>
+#include <osot_mi355x.h>
+
+namespace osot {
+
+struct DevNhqp {
+    int B, n, nc, nc_stored_all;     // nc: global constraint rows (all stored: unit-row blocks are refused for nHQP)
+    int level, m, ma;                // this level: task rows, stored rows (the rest: implicit identity rows)
+    int nf, ns;                      // free variables of this level, null-space dimension handed to the next (0: none)
+    int has_box;
+    int ab_reg, sel_reg;             // perform_A_b_regularization, perform_selective_null_space_regularization
+    double thr;                      // min_sv_ratio
+    const double* A; const double* b; const double* w;      // level data [B][ma][n], [B][m], [B][m] (w may be null)
+    const double* C; const double* lo; const double* up; const double* l; const double* u;
+    const double* N;                 // [B][n][n] cumulated null space (n x nf, row stride n); unused at level 0
+    const double* q0;                // [B][n] solution so far; unused at level 0
+    double* H; double* g;            // out [B][nf][nf], [B][nf]
+    double* R; double* rlo; double* rup;   // out (levels > 0) [B][nr][nf], [B][nr], nr = nc + (has_box ? n : 0)
+    double* V2;                      // out [B][n][n] (nf x ns, row stride n)
+    const int* status;               // [B] status so far (instances that failed above are skipped)
+};
+
+constexpr int kNS = 33;              // LDS row stride of the 32-column work matrices
+
+// sum over the 32 lanes of a half AND over the two halves; every lane gets it
+__device__ __forceinline__ double sum64(double v) { return halfsum<32>(colsum<32>(v)); }
+
+// Parallel two-sided Jacobi: K (k x k symmetric, LDS [32][33], zero beyond k) -> diag(lambda), E = eigenvectors (columns)
+__device__ inline void jacobi_eig32(double* K, double* E, int k, int c, int h) {
+    int kp = 1;
+    while (kp < k) kp <<= 1;
+    for (int e = c + 32 * h; e < 32 * kNS; e += 64) E[e] = 0.0;
+    wave_sync();
+    if (h == 0) E[c * kNS + c] = 1.0;
+    wave_sync();
+    for (int sweep = 0; sweep < 14; ++sweep) {
+        // convergence: off-diagonal mass against the diagonal's
+        double off = 0.0, dg = 0.0;
+        for (int t = 0; t < 16; ++t) {
+            const int i = 2 * t + h;
+            const double v = K[i * kNS + c];
+            if (i == c) dg += v * v; else off += v * v;
+        }
+        off = sum64(off); dg = sum64(dg);
+        if (!(off > 1.0e-30 * dg) || kp < 2) break;
+        for (int s = 1; s < kp; ++s) {
+            const int o = c ^ s;                       // partner column (same for both halves)
+            const int p = c < o ? c : o, q = c < o ? o : c;
+            const double app = K[p * kNS + p], aqq = K[q * kNS + q], apq = K[p * kNS + q];
+            double cs = 1.0, sn = 0.0;
+            if (fabs(apq) > 1.0e-300 && fabs(apq) > 1.0e-17 * sqrt(fabs(app * aqq))) {
+                const double tau = (aqq - app) / (2.0 * apq);
+                const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                cs = 1.0 / sqrt(1.0 + t * t);
+                sn = t * cs;
+            }
+            const bool low = c < o;                    // I am the pair's p column
+            // column phase on K and on E:  col_p <- cs col_p - sn col_q,  col_q <- sn col_p + cs col_q
+            double nk[16], ne[16];
+            for (int t = 0; t < 16; ++t) {
+                const int i = 2 * t + h;
+                const double own = K[i * kNS + c], oth = K[i * kNS + o];
+                nk[t] = low ? cs * own - sn * oth : sn * oth + cs * own;
+                const double eo = E[i * kNS + c], et = E[i * kNS + o];
+                ne[t] = low ? cs * eo - sn * et : sn * et + cs * eo;
+            }
+            wave_sync();
+            for (int t = 0; t < 16; ++t) { const int i = 2 * t + h; K[i * kNS + c] = nk[t]; E[i * kNS + c] = ne[t]; }
+            wave_sync();
+            // row phase on K:  row_p <- cs row_p - sn row_q,  row_q <- sn row_p + cs row_q
+            for (int t = 0; t < 16; ++t) {
+                const int j = 2 * t + h;
+                const double own = K[c * kNS + j], oth = K[o * kNS + j];
+                nk[t] = low ? cs * own - sn * oth : sn * oth + cs * own;
+            }
+            wave_sync();
+            for (int t = 0; t < 16; ++t) { const int j = 2 * t + h; K[c * kNS + j] = nk[t]; }
+            wave_sync();
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) {
+    OSOT_STATIC_LDS(double, AN, 64 * kNS);     // A N (m x nf)
+    OSOT_STATIC_LDS(double, Nl, 32 * kNS);     // N (n x nf)
+    OSOT_STATIC_LDS(double, K, 32 * kNS);      // Gram matrix -> diag(lambda)
+    OSOT_STATIC_LDS(double, E, 32 * kNS);      // eigenvectors of K
+    OSOT_STATIC_LDS(double, V2, 32 * kNS);     // null-space basis (nf x ns) / scratch
+    OSOT_STATIC_LDS(double, b0, 64);
+    OSOT_STATIC_LDS(double, vec, 64);          // staging vector
+    OSOT_STATIC_LDS(double, sig, 32);          // singular values, sorted descending
+    OSOT_STATIC_LDS(int, idx, 32);             // idx[pos] = eigen-column holding the pos-th largest
+    const long long inst = blockIdx.x;
+    const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
+    if (inst >= Q.B) return;
+    if (Q.status && Q.status[inst] != 0) return;
+    const int n = Q.n, m = Q.m, ma = Q.ma, nf = Q.nf, ns = Q.ns;
+    const bool first = Q.level == 0;
+    const double* A = Q.A ? Q.A + inst * (long long)ma * n : nullptr;
+    // ---- N -> LDS (identity at the first level)
+    for (int e = lane; e < 32 * kNS; e += 64) { Nl[e] = 0.0; K[e] = 0.0; V2[e] = 0.0; }
+    for (int e = lane; e < 64 * kNS; e += 64) AN[e] = 0.0;
+    wave_sync();
+    if (first) { if (h == 0 && c < n) Nl[c * kNS + c] = 1.0; }
+    else {
+        const double* Ng = Q.N + inst * (long long)n * n;
+        for (int i = h; i < n; i += 2) if (c < nf) Nl[i * kNS + c] = Ng[i * n + c];
+    }
+    if (lane < 64) vec[lane] = (!first && lane < n) ? Q.q0[inst * n + lane] : 0.0;     // q0 staged
+    wave_sync();
+    // ---- AN = A N (stored rows: a row of A against the columns of N, i split over the halves; identity rows: rows of N)
+    for (int r = 0; r < ma; ++r) {
+        double acc = 0.0;
+        for (int i = h; i < n; i += 2) acc = fma(A[r * n + i], Nl[i * kNS + c], acc);
+        acc = halfsum<32>(acc);
+        if (h == 0 && c < nf) AN[r * kNS + c] = acc;
+    }
+    for (int r = ma + h; r < m; r += 2) if (c < nf) AN[r * kNS + c] = Nl[(r - ma) * kNS + c];
+    // ---- b0 = b - A q0 (lane = row)
+    if (lane < m) {
+        double v = Q.b[inst * m + lane];
+        if (!first) {
+            if (lane < ma) { double acc = 0.0; for (int i = 0; i < n; ++i) acc = fma(A[lane * n + i], vec[i], acc); v -= acc; }
+            else v -= vec[lane - ma];
+        }
+        b0[lane] = v;
+    }
+    wave_sync();
+    // ---- Gram matrix of the small side
+    const bool rowside = m <= nf;
+    const int k = rowside ? m : nf;
+    if (rowside) {          // K[a][c] = <row a, row c> of AN
+        for (int a = 0; a < m; ++a) {
+            double acc = 0.0;
+            if (c < m) for (int t = h; t < nf; t += 2) acc = fma(AN[a * kNS + t], AN[c * kNS + t], acc);
+            acc = halfsum<32>(acc);
+            if (h == 0 && c < m) K[a * kNS + c] = acc;
+        }
+    } else {                // K[a][c] = <column a, column c>
+        for (int a = 0; a < nf; ++a) {
+            double acc = 0.0;
+            if (c < nf) for (int r = h; r < m; r += 2) acc = fma(AN[r * kNS + a], AN[r * kNS + c], acc);
+            acc = halfsum<32>(acc);
+            if (h == 0 && c < nf) K[a * kNS + c] = acc;
+        }
+    }
+    wave_sync();
+    jacobi_eig32(K, E, k, c, h);
+    // ---- singular values, sorted descending: pos = number of eigenvalues ahead of mine
+    {
+        const double lam = (c < k) ? K[c * kNS + c] : -1.0;
+        if (h == 0) vec[c] = lam;
+        wave_sync();
+        int pos = 0;
+        for (int d = 0; d < k; ++d) { const double ld = vec[d]; pos += (ld > lam || (ld == lam && d < c)) ? 1 : 0; }
+        if (h == 0 && c < k) { idx[pos] = c; sig[pos] = sqrt(lam > 0.0 ? lam : 0.0); }
+        wave_sync();
+    }
+    const double sv_max = sig[0];
+    // ---- A / b regularisation (regularize_A_b, nHQP.cpp:236-279).  For singular triplet i (sorted): the known factor is a
+    // column of E, the other one is a normalised product with AN.  AN <- AN + sum_i (sv'_i - sv_i) u_i v_i'  over the
+    // lifted ones;  b0 <- sum_i d_i (u_i'b0) u_i  (+ the part of b0 in the complement of range(U_k) only when U_k is all
+    // of U, i.e. never when m > nf: "b0(i) = 0 for i >= sv.size()").
+    if (Q.ab_reg) {
+        double bnew = 0.0;                       // lane = row r (< m): accumulates the new b0 when it is rebuilt (m > nf)
+        const bool rebuild = !rowside;           // m > nf: b0 is the sum over the nf triplets
+        for (int i = 0; i < k; ++i) {
+            const double sv = sig[i];
+            const bool lift = sv < Q.thr * sv_max;
+            if (!lift && !rebuild) continue;
+            const int ec = idx[i];
+            // u (m entries, lane = row via vec) and v (nf entries, lane c)
+            double uu = 0.0, vv = 0.0;
+            if (rowside) {
+                uu = (lane < m) ? E[lane * kNS + ec] : 0.0;                       // u_i = column of E
+                double acc = 0.0;                                                 // v_i ~ AN' u_i
+                if (c < nf) for (int r = h; r < m; r += 2) acc = fma(AN[r * kNS + c], E[r * kNS + ec], acc);
+                vv = halfsum<32>(acc);
+                const double nrm2 = colsum<32>((c < nf) ? vv * vv : 0.0);
+                vv = (nrm2 > 0.0) ? vv / sqrt(nrm2) : 0.0;
+            } else {
+                vv = (c < nf) ? E[c * kNS + ec] : 0.0;                            // v_i = column of E
+                double acc = 0.0;                                                 // u_i ~ AN v_i (lane = row, all 64 lanes)
+                if (lane < m) for (int t = 0; t < nf; ++t) acc = fma(AN[lane * kNS + t], E[t * kNS + ec], acc);
+                const double nrm2 = sum64(acc * acc);
+                uu = (nrm2 > 0.0) ? acc / sqrt(nrm2) : 0.0;
+            }
+            const double ub = sum64((lane < m) ? uu * b0[lane] : 0.0);           // u_i' b0
+            double d = 1.0, svn = sv;
+            if (lift) { d = sv / (Q.thr * sv_max); svn = (Q.thr * sv_max) * (Q.thr * sv_max) / (sv + Q.thr / 100.0); }
+            if (rebuild) bnew = fma(d * ub, uu, bnew);
+            else if (lane < m) b0[lane] -= (1.0 - d) * ub * uu;
+            if (lift) {         // AN += (sv' - sv) u v'
+                if (lane < 64) vec[lane] = (lane < m) ? uu : 0.0;
+                wave_sync();
+                const double dl = svn - sv;
+                for (int r = h; r < m; r += 2) if (c < nf) AN[r * kNS + c] = fma(dl * vec[r], vv, AN[r * kNS + c]);
+                wave_sync();
+            }
+        }
+        if (rebuild && lane < m) b0[lane] = bnew;
+        wave_sync();
+    }
+    // ---- null-space basis V2 (nf x ns) for the next level and for the selective regularisation
+    if (ns > 0) {
+        if (!rowside) {
+            // columns of E for the ns smallest eigenvalues
+            for (int t = 0; t < ns; ++t) { const int ec = idx[k - ns + t]; if (h == 0 && c < nf) V2[c * kNS + t] = E[c * kNS + ec]; }
+            wave_sync();
+        } else {
+            // orthogonal complement of the r = nf - ns leading right singular vectors v_i = AN'u_i / |.|: Householder QR
+            // of V1 = [v_1 .. v_r] kept as reflectors in the columns of V2 (scratch), then Q [0; I_ns]
+            const int r = nf - ns;
+            double* V1 = K;          // K is free now: V1[t][i] = component t of v_i (nf x r)
+            for (int i = 0; i < r; ++i) {
+                const int ec = idx[i];
+                double acc = 0.0;
+                if (c < nf) for (int q = h; q < m; q += 2) acc = fma(AN[q * kNS + c], E[q * kNS + ec], acc);
+                double vv = halfsum<32>(acc);
+                const double nrm2 = colsum<32>((c < nf) ? vv * vv : 0.0);
+                vv = (nrm2 > 0.0) ? vv / sqrt(nrm2) : 0.0;
+                if (h == 0 && c < nf) V1[c * kNS + i] = vv;
+            }
+            wave_sync();
+            // Householder vectors: for column i, reflect x = V1[i:, i] onto alpha e_i; apply to the later columns
+            for (int i = 0; i < r; ++i) {
+                const double x = (c >= i && c < nf) ? V1[c * kNS + i] : 0.0;
+                const double nrm2 = colsum<32>(x * x);
+                const double xi = bcast(x, i);
+                const double alpha = (xi > 0.0) ? -sqrt(nrm2) : sqrt(nrm2);
+                double hv = (c == i) ? x - alpha : x;             // reflector v (zero above i)
+                const double vn2 = colsum<32>(hv * hv);
+                const double beta = (vn2 > 0.0) ? 2.0 / vn2 : 0.0;
+                wave_sync();
+                if (h == 0 && c < nf) V1[c * kNS + i] = hv;        // keep the reflector in place of the column
+                for (int j = i + 1; j < r; ++j) {                  // later columns: y -= beta (v'y) v
+                    const double y = (c < nf) ? V1[c * kNS + j] : 0.0;
+                    const double dot = colsum<32>(hv * y);
+                    wave_sync();
+                    if (h == 0 && c < nf) V1[c * kNS + j] = y - beta * dot * hv;
+                    wave_sync();
+                }
+                if (h == 0 && c == 0) vec[i] = beta;
+                wave_sync();
+            }
+            // V2[:, t] = H_1 .. H_r e_(r + t)
+            for (int t = 0; t < ns; ++t) {
+                double y = (c == r + t) ? 1.0 : 0.0;
+                for (int i = r - 1; i >= 0; --i) {
+                    const double hv = (c >= i && c < nf) ? V1[c * kNS + i] : 0.0;
+                    const double dot = colsum<32>(hv * y);
+                    y -= vec[i] * dot * hv;
+                }
+                if (h == 0 && c < nf) V2[c * kNS + t] = y;
+            }
+            wave_sync();
+        }
+    }
+    // ---- H = AN' W AN (+ sv_max V2 V2'), g = -AN' W b0   ->  HBM, nf x nf row-major
+    {
+        const double* w = Q.w ? Q.w + inst * m : nullptr;
+        if (lane < m) vec[lane] = w ? w[lane] : 1.0;
+        wave_sync();
+        double* Hg = Q.H + inst * (long long)nf * nf;
+        double gacc = 0.0;
+        if (c < nf) for (int r = h; r < m; r += 2) gacc = fma(-vec[r] * AN[r * kNS + c], b0[r], gacc);
+        gacc = halfsum<32>(gacc);
+        if (h == 0 && c < nf) Q.g[inst * nf + c] = gacc;
+        for (int i = 0; i < nf; ++i) {
+            double acc = 0.0;
+            if (c < nf) for (int r = h; r < m; r += 2) acc = fma(vec[r] * AN[r * kNS + i], AN[r * kNS + c], acc);
+            if (ns > 0 && Q.sel_reg && c < nf)
+                for (int t = h; t < ns; t += 2) acc = fma(sv_max * V2[i * kNS + t], V2[c * kNS + t], acc);
+            acc = halfsum<32>(acc);
+            if (h == 0 && c < nf) Hg[i * nf + c] = acc;
+        }
+    }
+    // ---- V2 -> HBM (row stride n)
+    if (ns > 0 && Q.V2) {
+        double* Vg = Q.V2 + inst * (long long)n * n;
+        for (int i = h; i < nf; i += 2) if (c < ns) Vg[i * n + c] = V2[i * kNS + c];
+    }
+    // ---- constraints in z-coordinates (levels below the first): rows [C N; N], bounds shifted by q0
+    if (!first) {
+        const int nr = Q.nc + (Q.has_box ? n : 0);
+        double* Rg = Q.R + inst * (long long)nr * nf;
+        if (lane < 64) vec[lane] = (lane < n) ? Q.q0[inst * n + lane] : 0.0;
+        wave_sync();
+        for (int r = 0; r < Q.nc; ++r) {
+            const double* Cr = Q.C + (inst * (long long)Q.nc + r) * n;
+            double acc = 0.0, cq = 0.0;
+            for (int i = h; i < n; i += 2) { const double ci = Cr[i]; acc = fma(ci, Nl[i * kNS + c], acc); cq = fma(ci, vec[i], cq); }
+            acc = halfsum<32>(acc); cq = halfsum<32>(cq);
+            if (h == 0 && c < nf) Rg[r * nf + c] = acc;
+            if (lane == 0) {
+                const double lo = Q.lo[inst * Q.nc + r], up = Q.up[inst * Q.nc + r];
+                Q.rlo[inst * nr + r] = (lo <= -1.0e20) ? -1.0e20 : lo - cq;
+                Q.rup[inst * nr + r] = (up >= 1.0e20) ? 1.0e20 : up - cq;
+            }
+        }
+        if (Q.has_box) {
+            for (int i = h; i < n; i += 2) if (c < nf) Rg[(Q.nc + i) * nf + c] = Nl[i * kNS + c];
+            if (lane < n) {
+                const double l = Q.l[inst * n + lane], u = Q.u[inst * n + lane];
+                Q.rlo[inst * nr + Q.nc + lane] = (l <= -1.0e20) ? -1.0e20 : l - vec[lane];
+                Q.rup[inst * nr + Q.nc + lane] = (u >= 1.0e20) ? 1.0e20 : u - vec[lane];
+            }
+        }
+    }
+}
+
+struct DevNhqpAcc {
+    int B, n, nf, ns, first, last;
+    const double* z;       // [B][nf] the level's QP solution
+    const int* qp_status;  // [B] status of the level's QP
+    double* q0;            // [B][n] in/out
+    const double* N;       // [B][n][n] (n x nf); identity at the first level
+    const double* V2;      // [B][n][n] (nf x ns)
+    double* Nnext;         // [B][n][n] (n x ns)
+    int* status;           // [B] in/out: OSOT_STATUS_* of the instance (first failure sticks)
+    double* dq;            // [B][n] written at the last level
+};
+
+// solution += N z;  N <- N V2  (nHQP.cpp:182-196).  lane = c + 32 h
+__global__ void __launch_bounds__(64) osot_nhqp_accumulate_kernel(const DevNhqpAcc Q) {
+    const long long inst = blockIdx.x;
+    const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
+    if (inst >= Q.B) return;
+    const int n = Q.n, nf = Q.nf, ns = Q.ns;
+    int st = Q.first ? 0 : Q.status[inst];
+    if (st == 0 && Q.qp_status[inst] != 0) st = Q.qp_status[inst];
+    if (lane == 0) Q.status[inst] = st;
+    if (st != 0) {
+        if (Q.last && h == 0 && c < n) Q.dq[inst * n + c] = 0.0;      // failed instances return 0 (coman_ik.cpp:189-190)
+        return;
+    }
+    const double* Ng = Q.N + inst * (long long)n * n;
+    const double* z = Q.z + inst * nf;
+    double acc = 0.0;
+    if (c < n) {
+        if (Q.first) acc = (h == 0) ? z[c] : 0.0;
+        else for (int j = h; j < nf; j += 2) acc = fma(Ng[c * n + j], z[j], acc);
+    }
+    acc = halfsum<32>(acc);
+    const double qn = (Q.first ? 0.0 : ((c < n) ? Q.q0[inst * n + c] : 0.0)) + acc;
+    if (h == 0 && c < n) { Q.q0[inst * n + c] = qn; if (Q.last) Q.dq[inst * n + c] = qn; }
+    if (!Q.last && ns > 0) {
+        const double* Vg = Q.V2 + inst * (long long)n * n;
+        double* Nn = Q.Nnext + inst * (long long)n * n;
+        for (int i = 0; i < n; ++i) {          // row i of N V2: lane c = column t
+            double a2 = 0.0;
+            if (c < ns) {
+                if (Q.first) a2 = (h == 0 && i < nf) ? Vg[i * n + c] : 0.0;
+                else for (int j = h; j < nf; j += 2) a2 = fma(Ng[i * n + j], Vg[j * n + c], a2);
+            }
+            a2 = halfsum<32>(a2);
+            if (h == 0 && c < ns) Nn[i * n + c] = a2;
+        }
+    }
+}
+
+}  // namespace osot

@@ -193,6 +193,20 @@ class BatchedStack:
         qb = self._qp_batch(B)
         abi.check(self._lib.osot_ihqp_solve(self._h, C.byref(qb), _stream_ptr(self.device)), "osot_ihqp_solve")
 
+    def solve_nhqp(self, B, free_vars=None, min_sv_ratio=0.0, ab_regularization=True, selective_ns_regularization=True):
+        """Solver::solve() with the reference's NULL-SPACE front-end, OpenSoT::solvers::nHQP (nHQP.cpp:155-204), on the same
+        assembled arrays; stream-ordered, results in self.dq[:B] / self.status[:B].  free_vars: free variables per level
+        (the reference fixes them at construction); None = n, then minus the rows of the level above"""
+        opt = abi.NhqpOptions()
+        if free_vars is not None:
+            for k, v in enumerate(free_vars):
+                opt.free_vars[k] = int(v)
+        opt.min_sv_ratio = float(min_sv_ratio)
+        opt.no_ab_regularization = 0 if ab_regularization else 1
+        opt.no_selective_ns_regularization = 0 if selective_ns_regularization else 1
+        qb = self._qp_batch(B)
+        abi.check(self._lib.osot_nhqp_solve(self._h, C.byref(qb), C.byref(opt), _stream_ptr(self.device)), "osot_nhqp_solve")
+
     PHASES = ("hbuild", "chol", "inverse", "subst", "equalities", "inequalities", "opt_rhs", "total",
               "eq:J'a", "eq:reductions", "eq:z", "eq:householder",
               "in:scan", "in:d=J'n", "in:z", "in:r,steps", "in:householder", "in:drop")

@@ -6,6 +6,8 @@
 #include "osot_host_plan.h"
 #include "osot_kin.h"
 #include "osot_id.h"
+#include "osot_nhqp_host.h"
+#include <vector>
 
 using namespace osot;
 
@@ -47,6 +49,28 @@ extern "C" __attribute__((visibility("default"))) int emu_qp_solve_batch(int B, 
     if (T == 32) emu::launch(osot_qp_kernel<32>, grid, lds, 64, Q);
     else emu::launch(osot_qp_kernel<64>, grid, lds, 64, Q);
     return OSOT_OK;
+}
+
+// the null-space front-end (osot_nhqp_host.h: the product's own orchestration) on host pointers
+extern "C" __attribute__((visibility("default"))) int emu_nhqp_solve(const osot_plan_desc* plan, const osot_qp_batch* b,
+                                                                     const osot_nhqp_options* opt) {
+    const char* why = "";
+    int rc = plan_validate(plan, &why);
+    if (rc != OSOT_OK) { fprintf(stderr, "emu: %s\n", why); return rc; }
+    const NhqpSizes z = nhqp_sizes(*plan, b->B);
+    std::vector<double> N0(z.N), N1(z.N), q0(z.q0), H(z.H), g(z.g), R(z.R + 1), rlo(z.rl + 1), rup(z.rl + 1), zz(z.z), V2(z.V2);
+    std::vector<int> st(z.st), it(z.st);
+    NhqpWorkspace ws = {{N0.data(), N1.data()}, q0.data(), H.data(), g.data(), R.data(), rlo.data(), rup.data(), zz.data(), V2.data(), st.data(), it.data()};
+    const unsigned grid = (unsigned)b->B;
+    rc = nhqp_run(*plan, b, opt, ws,
+        [&](const DevNhqp& Q) { emu::launch(osot_nhqp_prepare_kernel, grid, 0, 64, Q); },
+        [&](int B, int n, int nc, const double* Hh, const double* gg, const double* A, const double* lA, const double* uA,
+            const double* l, const double* u, double eps, double* x, int* status, int* iters) {
+            return emu_qp_solve_batch(B, n, nc, Hh, gg, A, lA, uA, l, u, eps, 0, x, status, iters);
+        },
+        [&](const DevNhqpAcc& A) { emu::launch(osot_nhqp_accumulate_kernel, grid, 0, 64, A); }, &why);
+    if (rc != OSOT_OK) fprintf(stderr, "emu: %s\n", why);
+    return rc;
 }
 
 // AutoStack::update (osot_update_kernel) on host pointers

@@ -335,3 +335,37 @@ def answer_is_acceptable(asm, i, dq_dev, witnesses, tol=1e-6, feas_tol=1e-7, act
         if lc.lex_compare(cd, lc.lex_costs(asm, i, x, active), rtol=rtol, atol=1e-13, rtol_better=1e-9) > 0:
             return False, f"{d:.1e} from the closest witness; lexicographically worse than {nm} (device {cd}, violation {gv:.1e})"
     return True, f"{d:.1e} from the closest witness, feasible to {gv:.1e} and lexicographically not worse than any as-feasible witness"
+
+
+def emu_nhqp(plan, asm, free_vars=None, min_sv_ratio=0.0, ab_regularization=True, selective_ns_regularization=True):
+    """the null-space front-end (osot_nhqp_*.h: kernels AND host orchestration) on host pointers through the emulator"""
+    B, n, L = asm["B"], asm["n"], asm["L"]
+    qb = abi.QpBatch()
+    qb.B = B
+    keep = []
+    for k in range(L):
+        for name in ("A", "b", "w"):
+            a = asm[name][k]
+            if a is not None:
+                a = np.ascontiguousarray(a, dtype=np.float64); keep.append(a)
+                getattr(qb, name)[k] = a.ctypes.data
+    for name in ("C", "lo", "up", "l", "u"):
+        a = asm[name]
+        if a is not None and a.size:
+            a = np.ascontiguousarray(a, dtype=np.float64); keep.append(a)
+            setattr(qb, name, a.ctypes.data)
+    dq = np.zeros((B, n)); st = np.full(B, -1, dtype=np.int32)
+    qb.dq, qb.status = dq.ctypes.data, st.ctypes.data
+    opt = abi.NhqpOptions()
+    if free_vars is not None:
+        for k, v in enumerate(free_vars):
+            opt.free_vars[k] = int(v)
+    opt.min_sv_ratio = min_sv_ratio
+    opt.no_ab_regularization = 0 if ab_regularization else 1
+    opt.no_selective_ns_regularization = 0 if selective_ns_regularization else 1
+    L_ = emu_lib()
+    L_.emu_nhqp_solve.argtypes = [C.POINTER(abi.PlanDesc), C.POINTER(abi.QpBatch), C.POINTER(abi.NhqpOptions)]
+    pd = plan.to_c()
+    rc = L_.emu_nhqp_solve(C.byref(pd), C.byref(qb), C.byref(opt))
+    assert rc == 0
+    return dq, st

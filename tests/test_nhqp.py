@@ -1,0 +1,100 @@
+"""The null-space front-end: OpenSoT::solvers::nHQP (src/solvers/nHQP.cpp).
+  * oracle/pynhqp.py (numpy SVD + the reference's qpOASES per level) restates it; PARITY UNPINNED against the reference (its
+    own nHQP test needs a robot model) -- the restatement is pinned to the iHQP path instead: with both regularisations
+    off the two front-ends pose the same lexicographic problem and must agree on full-rank stacks;
+  * the device kernels (Jacobi SVD in LDS, QP in null-space coordinates through the batched back-end kernel) against the
+    restatement, with the reference's default options (A/b regularisation at 0.05, selective null-space regularisation)."""
+import numpy as np
+import pytest
+
+from helpers import emu_nhqp
+from opensot_amd import synth
+
+
+def test_restatement_agrees_with_ihqp_without_regularisations(oracle):
+    if not oracle.ref_available():
+        pytest.skip("needs oracle/_ref (qpOASES)")
+    from oracle import pynhqp
+    plan, leaf = synth.make_velocity_stack("C3", 12, seed=3)
+    asm = oracle.assemble(plan, leaf)
+    assert pynhqp.free_variables(asm) == [32, 29, 5]          # nHQP.cpp:88-103 on full-rank levels: 32 -> 29 -> 5
+    ri = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1, termination_tolerance=10 * 2.221e-16)
+    rn = pynhqp.nhqp_solve(asm, ab_regularization=False, selective_ns_regularization=False, termination_tolerance=10 * 2.221e-16)
+    ok = (ri["status"] == 1) & (rn["status"] == 1)
+    assert ok.mean() > 0.9 and np.abs(ri["dq"][ok] - rn["dq"][ok]).max() < 1e-6
+    # with the reference's default regularisations nHQP is a DIFFERENT answer wherever they bite (a lifted singular value,
+    # a bound active above the last level): that is the reference's own behaviour, not a defect of either path
+    rd = pynhqp.nhqp_solve(asm)
+    assert np.abs(rd["dq"] - ri["dq"]).max() > 1e-4
+
+
+@pytest.mark.parametrize("cfg,opts", [("C3", {}), ("C3", dict(ab_regularization=False, selective_ns_regularization=False)),
+                                      ("C4", {}), ("C2", {}), ("C3", dict(min_sv_ratio=0.2))])
+def test_emulated_kernels_match_restatement(cfg, opts, oracle):
+    from oracle import pynhqp
+    B = 6
+    plan, leaf = synth.make_velocity_stack(cfg, B, seed=17)
+    asm = oracle.assemble(plan, leaf)
+    backend = "qpoases" if oracle.ref_available() else "eiqp"
+    kw = dict(opts)
+    if "min_sv_ratio" not in kw:
+        kw["min_sv_ratio"] = pynhqp.DEFAULT_MIN_SV_RATIO
+    ref = pynhqp.nhqp_solve(asm, backend=backend, termination_tolerance=10 * 2.221e-16, **kw)
+    dq, st = emu_nhqp(plan, asm, **opts)
+    ok = ref["status"] == 1
+    assert ok.mean() > 0.8 and (st[ok] == 0).all()
+    assert np.abs(dq[ok] - ref["dq"][ok]).max() < 1e-7
+
+
+def test_small_generic_stack_and_no_free_variables(oracle):
+    """a 12-variable generic stack (row side and column side of the SVD both occur); a stack that runs out of free
+    variables is refused like the reference's constructor does (nHQP.cpp:32-35)"""
+    from oracle import pynhqp
+    plan, leaf = synth.make_generic_stack(5, 12, [4, 5], n_eq=0, n_ineq=3, seed=2, box=0.4)
+    asm = oracle.assemble(plan, leaf)
+    ref = pynhqp.nhqp_solve(asm, backend="qpoases" if oracle.ref_available() else "eiqp", termination_tolerance=10 * 2.221e-16)
+    dq, st = emu_nhqp(plan, asm)
+    ok = ref["status"] == 1
+    assert ok.all() and (st == 0).all() and np.abs(dq - ref["dq"]).max() < 1e-7
+    import ctypes as C
+    from helpers import emu_lib
+    from opensot_amd import abi
+    plan2, leaf2 = synth.make_generic_stack(2, 8, [5, 4], seed=1, postural_last=True)    # 8 -> 3 -> -1 free variables
+    qb = abi.QpBatch(); qb.B = 2
+    opt = abi.NhqpOptions()
+    L = emu_lib()
+    L.emu_nhqp_solve.argtypes = [C.POINTER(abi.PlanDesc), C.POINTER(abi.QpBatch), C.POINTER(abi.NhqpOptions)]
+    pd = plan2.to_c()
+    assert L.emu_nhqp_solve(C.byref(pd), C.byref(qb), C.byref(opt)) == abi.ERR_INVALID
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,opts", [("C3", {}), ("C4", {}), ("C3", dict(ab_regularization=False, selective_ns_regularization=False))])
+def test_nhqp_gpu(cfg, opts, oracle, gpu_device):
+    """osot_nhqp_solve through the C-ABI: against the restatement (reference qpOASES per level) on a sample of the batch;
+    without the regularisations also against the device's own iHQP cascade (the two front-ends must agree there)"""
+    import torch
+    from oracle import pynhqp
+    from opensot_amd.solver import BatchedStack
+    B = 512
+    plan, leaf = synth.make_velocity_stack(cfg, B, seed=23)
+    st = BatchedStack(plan, B, device=0)
+    st.update(st.load_leaf(leaf))
+    st.solve_nhqp(B, **opts)
+    torch.cuda.synchronize()
+    dq = st.dq[:B].cpu().numpy().copy(); status = st.status[:B].cpu().numpy().copy()
+    sub = slice(0, B, 16)
+    sl = {"B": len(range(*sub.indices(B))), "A": [a[sub] if a is not None else None for a in leaf["A"]],
+          "task": [[tuple(None if x is None else x[sub] for x in t) for t in lev] for lev in leaf["task"]],
+          "bound": [tuple(None if x is None else x[sub] for x in t) for t in leaf["bound"]],
+          "rows": [tuple(None if x is None else x[sub] for x in t) for t in leaf["rows"]]}
+    asm = oracle.assemble(plan, sl)
+    kw = dict(opts); kw.setdefault("min_sv_ratio", pynhqp.DEFAULT_MIN_SV_RATIO)
+    ref = pynhqp.nhqp_solve(asm, backend="qpoases" if oracle.ref_available() else "eiqp", termination_tolerance=10 * 2.221e-16, **kw)
+    ok = ref["status"] == 1
+    assert ok.mean() > 0.8 and (status[sub][ok] == 0).all()
+    assert np.abs(dq[sub][ok] - ref["dq"][ok]).max() < 1e-7
+    if opts:
+        st.solve(B); torch.cuda.synchronize()
+        both = (status == 0) & (st.status[:B].cpu().numpy() == 0)
+        assert both.mean() > 0.9 and np.abs(dq[both] - st.dq[:B].cpu().numpy()[both]).max() < 1e-6
