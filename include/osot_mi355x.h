@@ -387,6 +387,16 @@ int osot_qp_solve_batch(int B, int n, int nc, const double* H, const double* g, 
                         double eps_abs, int max_iter, double* x, int* status, int* iterations,
                         void* hip_stream);
 
+/* The same call through the SECOND back-end: an OSQP-convention ADMM solver -- the problem as
+ * src/solvers/OSQPBackEnd.cpp poses it (P = H + eps I, one constraint matrix [A; I] with piled bounds, eps_abs = eps_rel =
+ * 1e-5, sigma = 1e-6, alpha = 1.6, rho = 0.1 adaptive, 4000 iterations, "solved inaccurate" counts as solved: :25-49,
+ * 198-226); osqp itself is not vendored in the reference, so this restates the published algorithm (parity vs osqp
+ * unpinned) and is cross-checked against the active-set kernel.  eps_reg is the ABSOLUTE epsilon (the factory's factor
+ * times 2.22e-13, OSQPBackEnd.cpp:8, 29).  max_iter 0 = 4000. */
+int osot_qp_solve_batch_admm(int B, int n, int nc, const double* H, const double* g, const double* A,
+                             const double* lA, const double* uA, const double* l, const double* u,
+                             double eps_reg, int max_iter, double* x, int* status, int* iterations, void* hip_stream);
+
 /* ---- batched kinematics producer ------------------------------------------------------
  * What the leaf tasks ask XBot::ModelInterface for every cycle: frame poses and 6 x n frame Jacobians
  * (velocity::Cartesian::_update, src/tasks/velocity/Cartesian.cpp:73-81: getJacobian / getPose), the centre

@@ -131,7 +131,7 @@ SYMBOLS = [
     "osot_backend_solve", "osot_backend_get_solution", "osot_backend_get_objective",
     "osot_backend_set_eps_regularisation", "osot_backend_get_eps_regularisation",
     "osot_backend_get_num_variables", "osot_backend_get_num_constraints",
-    "osot_qp_solve_batch",
+    "osot_qp_solve_batch", "osot_qp_solve_batch_admm",
     "osot_comm_unique_id", "osot_comm_create", "osot_comm_destroy", "osot_allgather_dq",
 ]
 
@@ -198,6 +198,8 @@ def lib():
     L.osot_backend_get_num_constraints.argtypes = [vp, ip]
     L.osot_qp_solve_batch.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp,
                                       C.c_double, C.c_int, vp, vp, vp, vp]
+    L.osot_qp_solve_batch_admm.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp,
+                                           C.c_double, C.c_int, vp, vp, vp, vp]
     L.osot_comm_unique_id.argtypes = [vp]
     L.osot_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.osot_comm_destroy.argtypes = [vp]

@@ -7,6 +7,7 @@
 #include "osot_kin.h"
 #include "osot_id.h"
 #include "osot_nhqp_host.h"
+#include "osot_admm.h"
 #include <vector>
 
 using namespace osot;
@@ -48,6 +49,19 @@ extern "C" __attribute__((visibility("default"))) int emu_qp_solve_batch(int B, 
     const unsigned grid = (unsigned)B;
     if (T == 32) emu::launch(osot_qp_kernel<32>, grid, lds, 64, Q);
     else emu::launch(osot_qp_kernel<64>, grid, lds, 64, Q);
+    return OSOT_OK;
+}
+
+// the OSQP-convention ADMM back-end (osot_admm.h) on host pointers
+extern "C" __attribute__((visibility("default"))) int emu_qp_solve_batch_admm(int B, int n, int nc, const double* H, const double* g,
+        const double* A, const double* lA, const double* uA, const double* l, const double* u, double eps_reg, int max_iter,
+        double* x, int* status, int* iterations) {
+    DevAdmm Q;
+    memset(&Q, 0, sizeof(Q));
+    Q.B = B; Q.n = n; Q.nc = nc; Q.max_iter = max_iter > 0 ? max_iter : 4000; Q.check_every = 25;
+    Q.eps_reg = eps_reg; Q.eps_abs = 1.0e-5; Q.eps_rel = 1.0e-5; Q.rho0 = 0.1; Q.sigma = 1.0e-6; Q.alpha = 1.6;
+    Q.H = H; Q.g = g; Q.A = A; Q.lA = lA; Q.uA = uA; Q.l = l; Q.u = u; Q.x = x; Q.status = status; Q.iterations = iterations;
+    emu::launch(osot_admm_kernel, (unsigned)B, admm_lds_bytes(n, nc, l != nullptr), 64, Q);
     return OSOT_OK;
 }
 

@@ -369,3 +369,18 @@ def emu_nhqp(plan, asm, free_vars=None, min_sv_ratio=0.0, ab_regularization=True
     rc = L_.emu_nhqp_solve(C.byref(pd), C.byref(qb), C.byref(opt))
     assert rc == 0
     return dq, st
+
+
+def emu_qp_admm(H, g, A, lA, uA, l, u, eps_reg=0.0, max_iter=0):
+    """B generic QPs through the emulated OSQP-convention ADMM kernel (osot_admm.h); arrays are [B][...]"""
+    H = np.ascontiguousarray(H, dtype=np.float64)
+    B, n = H.shape[0], H.shape[1]
+    nc = 0 if A is None else A.shape[1]
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) if a is not None else None for a in (g, A, lA, uA, l, u)]
+    x = np.zeros((B, n)); st = np.full(B, -1, dtype=np.int32); it = np.zeros(B, dtype=np.int32)
+    p = lambda a: None if a is None else a.ctypes.data
+    L = emu_lib()
+    vp = C.c_void_p
+    L.emu_qp_solve_batch_admm.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_double, C.c_int, vp, vp, vp]
+    assert L.emu_qp_solve_batch_admm(B, n, nc, p(H), *[p(a) for a in arrs], eps_reg, max_iter, p(x), p(st), p(it)) == 0
+    return x, st, it

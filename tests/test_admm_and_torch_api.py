@@ -1,0 +1,123 @@
+"""Second back-end and tensor entry points.  The OSQP-convention ADMM kernel restates the published
+algorithm (osqp is not vendored in the reference: PARITY UNPINNED against osqp itself) and is checked against the
+active-set kernel / the oracle at 1e-4 -- the accuracy OSQP's own tolerances (eps_abs = eps_rel = 1e-5,
+OSQPBackEnd.cpp:38-39) buy."""
+import numpy as np
+import pytest
+
+from helpers import emu_qp, emu_qp_admm, random_qp
+
+
+@pytest.mark.parametrize("n,nc,n_eq", [(5, 3, 1), (17, 9, 0), (32, 20, 3), (50, 40, 6), (64, 30, 4)])
+def test_admm_matches_active_set_on_random_qps(n, nc, n_eq, oracle):
+    rng = np.random.default_rng(100 + n)
+    B = 4
+    H, g, A, lA, uA, l, u = random_qp(rng, B, n, nc, n_eq)
+    xa, sa, _ = emu_qp(H, g, A, lA, uA, l, u, eps_abs=1e-9)
+    x, st, it = emu_qp_admm(H, g, A, lA, uA, l, u, eps_reg=1e-9)
+    assert (sa == 0).all() and (st == 0).all() and (it <= 4000).all()
+    assert np.abs(x - xa).max() < 1e-4
+    for i in range(B):
+        ok, xo, _ = oracle.backend_solve(H[i], g[i], A[i], lA[i], uA[i], l[i], u[i], 1e-9)
+        assert ok and np.abs(x[i] - xo).max() < 1e-4
+
+
+def test_admm_known_answers_and_infeasibility():
+    """TestQPOases.cpp:208-254 ((10, -10, 10)) through the ADMM kernel; no box; an infeasible problem is not reported solved"""
+    l = -10 * np.ones((1, 3)); u = 10 * np.ones((1, 3))
+    Hm = np.array([[1.0, 1, 1]]); b = np.array([10.0])
+    x, st, _ = emu_qp_admm((Hm.T @ Hm)[None], (-Hm.T @ b)[None], np.array([[[1.0, 0, 1]]]), np.array([[20.0]]), np.array([[20.0]]),
+                           l, u, eps_reg=2.22e-13 * 1e4)
+    assert st[0] == 0
+    np.testing.assert_allclose(x[0], [10, -10, 10], atol=1e-3)
+    H = np.eye(4)[None] * 2.0; g = np.array([[1.0, -2, 3, -4]])
+    x, st, _ = emu_qp_admm(H, g, None, None, None, None, None)
+    assert st[0] == 0
+    np.testing.assert_allclose(x[0], -g[0] / 2.0, atol=1e-5)
+    H = np.eye(2)[None]; g = np.zeros((1, 2))
+    A = np.array([[[1.0, 1.0]]]); lA = np.array([[5.0]]); uA = np.array([[np.inf]])
+    x, st, _ = emu_qp_admm(H, g, A, lA, uA, -np.ones((1, 2)), np.ones((1, 2)))
+    assert st[0] != 0 and (x[0] == 0).all()
+
+
+@pytest.mark.gpu
+def test_torch_qp_solve_both_back_ends_gpu(oracle, gpu_device):
+    """tensors in, tensors out: the caller's device pointers go straight to the C-ABI; the two back-ends agree at 1e-4, the
+    active-set one with the oracle at 1e-8"""
+    import torch
+    from opensot_amd import torch_api as ta
+    rng = np.random.default_rng(5)
+    B, n, nc = 256, 32, 24
+    H, g, A, lA, uA, l, u = random_qp(rng, B, n, nc, 4)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=dev).contiguous()
+    args = [t(a) for a in (H, g, A, lA, uA, l, u)]
+    xa, sa, ia = ta.qp_solve(*args, eps_regularisation=1.0, be_solver=ta.solver_back_ends.qpOASES)
+    xo, so, io = ta.qp_solve(*args, eps_regularisation=1.0, be_solver=ta.solver_back_ends.OSQP)
+    torch.cuda.synchronize()
+    assert xa.is_cuda and xa.shape == (B, n) and (sa == 0).all() and (so == 0).all()
+    assert float((xa - xo).abs().max()) < 1e-4
+    for i in range(0, B, 32):
+        ok, xr, _ = oracle.backend_solve(H[i], g[i], A[i], lA[i], uA[i], l[i], u[i], 1e3 * 2.221e-16)
+        assert ok and np.abs(xa[i].cpu().numpy() - xr).max() < 1e-8
+    with pytest.raises(ValueError):
+        ta.qp_solve(args[0], args[1][:, :5])
+    with pytest.raises(TypeError):
+        ta.qp_solve(args[0].cpu(), args[1])
+
+
+@pytest.mark.gpu
+def test_torch_ihqp_and_nhqp_classes_gpu(oracle, gpu_device):
+    """pyopensot-shaped front-ends: iHQP(...).solve() -> dq tensor, setActiveStack; nHQP with its option setters"""
+    import torch
+    from opensot_amd import synth, torch_api as ta
+    B = 128
+    plan, leaf = synth.make_velocity_stack("C3", B, seed=4)
+    s = ta.iHQP(plan, B, eps_regularisation=1e6)
+    assert s.getNumberOfTasks() == 3
+    dev_leaf = s.stack.load_leaf(leaf)
+    dq = s.solve(dev_leaf)
+    torch.cuda.synchronize()
+    asm = oracle.assemble(plan, leaf)
+    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=0)
+    assert isinstance(dq, torch.Tensor) and dq.is_cuda and (s.status() == 0).all()
+    assert np.abs(dq.cpu().numpy() - ref["dq"]).max() < 1e-9
+    s.setActiveStack(1, False)
+    dq2 = s.solve(dev_leaf).clone(); torch.cuda.synchronize()
+    ref2 = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=0, active=(1, 0, 1))
+    assert np.abs(dq2.cpu().numpy() - ref2["dq"]).max() < 1e-9
+    s.activateAllStacks()
+    with pytest.raises(RuntimeError):
+        ta.iHQP(plan, B, be_solver=ta.solver_back_ends.OSQP)
+    nh = ta.nHQP(plan, B, eps_regularisation=1e6)
+    nh.setPerformAbRegularization(False); nh.setPerformSelectiveNullSpaceRegularization(False)
+    dqn = nh.solve(nh.stack.load_leaf(leaf)); torch.cuda.synchronize()
+    ok = (nh.status() == 0).cpu().numpy()
+    assert ok.mean() > 0.95 and np.abs(dqn.cpu().numpy()[ok] - ref["dq"][ok]).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_admm_cross_checks_config5_qps_gpu(gpu_device):
+    """the use SURVEY 8f-4 names: an independent check of config 5's 102-row QPs -- level 0 of the inverse-dynamics stack as
+    one explicit QP per instance through both back-ends"""
+    import torch
+    from opensot_amd import synth, torch_api as ta
+    from oracle import pyoracle as po
+    B = 64
+    plan, leaf = synth.make_id_stack(B, seed=3)
+    asm = po.assemble(plan, leaf)
+    n = plan.n
+    H = np.zeros((B, n, n)); g = np.zeros((B, n))
+    for i in range(B):
+        H[i], g[i] = po.cost_function(asm, i, 0)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=dev).contiguous()
+    lo = np.clip(np.nan_to_num(asm["lo"], neginf=-1e20, posinf=1e20), -1e20, 1e20); up = np.clip(np.nan_to_num(asm["up"], neginf=-1e20, posinf=1e20), -1e20, 1e20)
+    args = [t(H), t(g), t(asm["C"]), t(lo), t(up)]
+    xa, sa, _ = ta.qp_solve(*args, eps_regularisation=1e6, be_solver=ta.solver_back_ends.qpOASES)
+    xo, so, io = ta.qp_solve(*args, eps_regularisation=1e6 * 1e3 * 2.221e-16 / 2.22e-13, be_solver=ta.solver_back_ends.OSQP)
+    torch.cuda.synchronize()
+    assert (sa == 0).all() and (so == 0).float().mean() > 0.9
+    ok = (so == 0).cpu().numpy()
+    rel = (xa - xo).abs().max(dim=1).values.cpu().numpy()[ok] / max(1.0, float(xa.abs().max()))
+    assert rel.max() < 1e-3       # |x| ~ 1e2 here (forces in N): 1e-5-class residuals on rows of norm ~ 30
