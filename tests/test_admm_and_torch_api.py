@@ -119,5 +119,13 @@ def test_admm_cross_checks_config5_qps_gpu(gpu_device):
     torch.cuda.synchronize()
     assert (sa == 0).all() and (so == 0).float().mean() > 0.9
     ok = (so == 0).cpu().numpy()
-    rel = (xa - xo).abs().max(dim=1).values.cpu().numpy()[ok] / max(1.0, float(xa.abs().max()))
-    assert rel.max() < 1e-3       # |x| ~ 1e2 here (forces in N): 1e-5-class residuals on rows of norm ~ 30
+    # H has rank 15 of 50 here (+ eps 2.2e-7): along its null directions x is decided by eps |x|^2 alone, far below what
+    # eps_abs = eps_rel = 1e-5 resolves -- the two solvers are compared on what the QP is about: the objective value and
+    # the constraints
+    Xa, Xo = xa.cpu().numpy(), xo.cpu().numpy()
+    f = lambda X: 0.5 * np.einsum("bi,bij,bj->b", X, H, X) + np.einsum("bi,bi->b", g, X)
+    fa, fo = f(Xa), f(Xo)
+    assert (np.abs(fa - fo)[ok] <= 1e-3 * (1.0 + np.abs(fa[ok]))).all()
+    ax = np.einsum("brj,bj->br", asm["C"], Xo)
+    viol = np.maximum(np.where(lo > -1e20, lo - ax, 0.0), np.where(up < 1e20, ax - up, 0.0)).max(axis=1)
+    assert viol[ok].max() < 1e-2      # rows of norm ~30 and bounds of 30 .. 1e3: 1e-5-class relative residuals
