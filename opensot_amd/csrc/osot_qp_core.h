@@ -562,101 +562,170 @@ __device__ inline int nullspace_equalities32(const WaveCtx<32>& w, int n_eq, dou
     const bool valid = c < n;
     double* M2 = w.M2;
     int* pivcol = reinterpret_cast<int*>(w.V + 3 * 32);   // idle staging vector: pivot column of each row (32 ints)
-    // ---- E -> registers: Er[ii] = E[2ii+h][c] (lane = column, rows split over the halves) ------------------------
-    // Three passes so that the sixteen eqlist -> row pointer -> HBM/L2 chains are in flight TOGETHER: all row
-    // pointers, then all loads (unconditional: a unit row reads the harmless safe_row), then the selects.  Written
-    // as sixteen calls of row_elem the compiler sinks every load into its "not a unit row" branch and waits for
-    // each one in turn (16 round trips, ~10 k cycles).
-    double Er[16];
-    {
-        unsigned long long rp[16];
-#pragma unroll
-        for (int ii = 0; ii < 16; ++ii) {
-            const int r = 2 * ii + h;
-            rp[ii] = w.rptr[w.eqlist[(r < n_eq) ? r : 0]];
-        }
-        const int cc = valid ? c : 0;
-#pragma unroll
-        for (int ii = 0; ii < 16; ++ii)
-            Er[ii] = OSOT_GLOBAL_F64((rp[ii] & 1ull) ? w.safe_row : rp[ii])[cc];
-        OSOT_KEEP16(Er);
-#pragma unroll
-        for (int ii = 0; ii < 16; ++ii) {
-            const bool unit = (rp[ii] & 1ull) != 0ull;
-            const double uv = (c == (int)(rp[ii] >> 1)) ? 1.0 : 0.0;
-            const double v = unit ? uv : (valid ? Er[ii] : 0.0);
-            Er[ii] = (2 * ii + h < n_eq) ? v : 0.0;
-        }
-    }
+    // ---- E -> registers in the ACCUMULATOR-TILE layout of v_mfma_f64_16x16x4: lane l = (ta, tq) = (l & 15, l >> 4), tile
+    // (I, C) element r holds E[16 I + tq + 4 r][16 C + ta] (the layout of factor_tiles32).  All sixteen row pointers first,
+    // then all loads (unconditional: a unit row reads the harmless safe_row), then the selects: ONE memory round trip.
+    const int ta = lane & 15, tq = lane >> 4;
+    v4f64 Et[4];   // Et[2 I + C]
     double emax = 0.0;
+    {
+        unsigned long long rp[8];
+        double ld[16];
 #pragma unroll
-    for (int ii = 0; ii < 16; ++ii) emax = fmax(emax, fabs(Er[ii]));
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * I + tq + 4 * r;
+                rp[4 * I + r] = w.rptr[w.eqlist[(row < n_eq) ? row : 0]];
+            }
+        const int c0 = (ta < n) ? ta : 0, c1 = (16 + ta < n) ? 16 + ta : 0;
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned long long pr = rp[4 * I + r];
+                const auto* base = OSOT_GLOBAL_F64((pr & 1ull) ? w.safe_row : pr);
+                ld[8 * I + 2 * r] = base[c0];
+                ld[8 * I + 2 * r + 1] = base[c1];
+            }
+        OSOT_KEEP16(ld);
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned long long pr = rp[4 * I + r];
+                const bool unit = (pr & 1ull) != 0ull;
+                const int ucol = (int)(pr >> 1);
+                const bool in = (16 * I + tq + 4 * r) < n_eq;
+#pragma unroll
+                for (int C = 0; C < 2; ++C) {
+                    const int col = 16 * C + ta;
+                    const double v = unit ? ((col == ucol) ? 1.0 : 0.0) : ((col < n) ? ld[8 * I + 2 * r + C] : 0.0);
+                    const double e = in ? v : 0.0;
+                    Et[2 * I + C][r] = e;
+                    emax = fmax(emax, fabs(e));
+                }
+            }
+    }
     emax = colmax<64>(emax);
     const double tol = 1.0e-9 * emax;
     OSOT_SUB_END(PH_EQ_D);      // (profiling slots reused: load + scale)
-    // ---- Gauss-Jordan with column pivoting, all in registers, as a LOOP over pairs of rows with ROTATING
-    // registers (cyclic: register 0 always holds the current pair, so every register index is a compile-time
-    // constant).  Not unrolled: the unrolled function was 55 KB of straight-line code against a 64 KB instruction
-    // cache shared by two CUs, and a wave streaming cold code runs at ~1 instruction per 6 cycles.  The pivot is the largest |entry| of the
-    // row among the non-basic columns: one max-reduction, then a ballot picks the lowest such column (the
-    // value/payload argmin network costs ~760 cycles, this ~170).  The pivot column (the 16 values of lane
-    // (pcol, h)) reaches every lane of its half through ds_bpermute (per-lane source index, result in a VGPR).
-    bool basic = false;
-    const int npairs = (n_eq + 1) >> 1;
-    for (int r = 0; r < npairs; ++r) {
+    // ---- Gauss-Jordan with column pivoting, FOUR ROWS AT A TIME.  Panel p = rows 4p .. 4p+3 = element p & 3 of the tiles
+    // (p >> 2, C) -- one register per tile column, lane (ta, tq) holding row 4p + tq at columns 16 C + ta: no data movement
+    // to take it out.  (a) The four rows are reduced against each other in that form (pivot = largest entry of the row among
+    // the non-basic columns: a 16-lane DPP max + ballot; three ds_bpermute per pivot).  (b) Every other row i then needs
+    // E[i] -= sum_q E[i][p_q] Rhat[q], the Schur form of eliminating the panel's four pivot columns with the ORIGINAL column
+    // entries as multipliers: a rank-4 update, i.e. ONE v_mfma_f64_16x16x4 per tile.  The reduced panel in its quarter-row
+    // form IS the B operand (lane (n, k) = Rhat[k][16 C + n]); the A operand (lane (m, k) = E[16 I + m][p_k]) is gathered
+    // from the tiles with sixteen ds_bpermute per panel -- where the rank-1 form spent sixteen per PIVOT plus 16 VALU FMAs.
+    unsigned basicmask = 0u;     // bit c: column c has become a pivot (basic) column
+    const int npanels = (n_eq + 3) >> 2;
+    for (int p = 0; p < npanels; ++p) {
+        const int Ip = p >> 2, rq = p & 3;
+        double Pr0 = 0.0, Pr1 = 0.0;
 #pragma unroll
-        for (int hk = 0; hk < 2; ++hk) {
-            const int k = 2 * r + hk;
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool hit = (p == 4 * I + r);
+                Pr0 = hit ? Et[2 * I][r] : Pr0;
+                Pr1 = hit ? Et[2 * I + 1][r] : Pr1;
+            }
+        int pc0 = -1, pc1 = -1, pc2 = -1, pc3 = -1;     // pivot columns of the panel's rows (-1: dependent row)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = 4 * p + q;
+            int pk = -1;
             if (k < n_eq) {
-                const double v = from_half<32>(Er[0], hk);            // row k at my column, in both halves
-                // the search runs on fp32 keys (one DPP-modified v_max_f32 per stage instead of two DPP moves and
-                // a v_max_f64): a pivot within 1e-7 of the largest is as good as the largest
-                const float cand = (valid && !basic) ? (float)fabs(v) : -1.0f;
-                const float pmax = colmax_f32<32>(cand);
-                int pk = -1;
+                const bool myrow = (tq == q);
+                const bool nb0 = (ta < n) && !((basicmask >> ta) & 1u), nb1 = (16 + ta < n) && !((basicmask >> (16 + ta)) & 1u);
+                const float cand0 = (myrow && nb0) ? (float)fabs(Pr0) : -1.0f;
+                const float cand1 = (myrow && nb1) ? (float)fabs(Pr1) : -1.0f;
+                const float rmx = row16_max_f32(fmaxf(cand0, cand1));
+                const float pmax = bcast_f32(rmx, 16 * q);
                 if ((double)pmax > tol && pmax > 0.0f) {
-                    const int pcol = first_lane_equal_f32(cand, pmax) & 31;
+                    const unsigned b0 = (unsigned)((wave_ballot(myrow && cand0 == pmax) >> (16 * q)) & 0xffffull);
+                    const unsigned b1 = (unsigned)((wave_ballot(myrow && cand1 == pmax) >> (16 * q)) & 0xffffull);
+                    const int pcol = b0 ? __builtin_ctz(b0) : 16 + __builtin_ctz(b1);
                     pk = pcol;
-                    const double rowk = v * fast_rcp(bcast(v, pcol));
-                    const int src = pcol + 32 * h;
-                    double f[16];
-#pragma unroll
-                    for (int ii = 0; ii < 16; ++ii) f[ii] = __shfl(Er[ii], src, 64);
-                    Er[0] = (h == hk) ? rowk : fma(-f[0], rowk, Er[0]);
-#pragma unroll
-                    for (int ii = 1; ii < 16; ++ii) Er[ii] = fma(-f[ii], rowk, Er[ii]);
-                    if (c == pcol) basic = true;
-                } else {
-                    if (h == hk) Er[0] = 0.0;   // dependent row (consistent: x_prev satisfies every row)
+                    const int ap = pcol & 15;
+                    const double fsel = (pcol >> 4) ? Pr1 : Pr0;              // the register that holds column pcol
+                    const double ipv = fast_rcp(bcast(fsel, ap + 16 * q));
+                    const double f = __shfl(fsel, ap + 16 * tq, 64);          // my panel row's entry at the pivot column
+                    const double r0 = __shfl(Pr0, ta + 16 * q, 64) * ipv;     // the scaled pivot row at my columns
+                    const double r1 = __shfl(Pr1, ta + 16 * q, 64) * ipv;
+                    Pr0 = myrow ? r0 : fma(-f, r0, Pr0);
+                    Pr1 = myrow ? r1 : fma(-f, r1, Pr1);
+                    basicmask |= (1u << pcol);
+                } else if (myrow) {
+                    Pr0 = 0.0; Pr1 = 0.0;      // dependent row (consistent: x_prev satisfies every row)
                 }
                 if (lane == 0) pivcol[k] = pk;
             }
+            if (q == 0) pc0 = pk; else if (q == 1) pc1 = pk; else if (q == 2) pc2 = pk; else pc3 = pk;
         }
-        // rotate (cyclic): register k <- k + 1, register 15 <- the pair just finished
-        const double e0 = Er[0];
+        // A operand of the trailing update: lane (m, k) = (ta, tq) <- E[16 I + m][p_k], which sits in tile (I, p_k >> 4),
+        // element m >> 2, lane (p_k & 15, m & 3).  Zero for the panel's own rows and for a row without a pivot.
+        const int pm = (tq == 0) ? pc0 : ((tq == 1) ? pc1 : ((tq == 2) ? pc2 : pc3));
+        const int srcl = ((pm >= 0 ? pm : 0) & 15) + 16 * (ta & 3);
+        const int wr = ta >> 2, wC = (pm >= 0 ? pm : 0) >> 4;
+        double FA[2] = {0.0, 0.0};
 #pragma unroll
-        for (int ii = 0; ii + 1 < 16; ++ii) Er[ii] = Er[ii + 1];
-        Er[15] = e0;
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int C = 0; C < 2; ++C)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double v = __shfl(Et[2 * I + C][r], srcl, 64);
+                    FA[I] = (r == wr && C == wC) ? v : FA[I];
+                }
+#pragma unroll
+        for (int I = 0; I < 2; ++I) {
+            const bool own = (I == Ip) && (wr == rq);
+            FA[I] = (pm < 0 || own) ? 0.0 : -FA[I];
+        }
+        Et[0] = mfma_f64_16x16x4(FA[0], Pr0, Et[0]);
+        Et[1] = mfma_f64_16x16x4(FA[0], Pr1, Et[1]);
+        Et[2] = mfma_f64_16x16x4(FA[1], Pr0, Et[2]);
+        Et[3] = mfma_f64_16x16x4(FA[1], Pr1, Et[3]);
+        // the reduced panel back into its register
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool hit = (p == 4 * I + r);
+                Et[2 * I][r] = hit ? Pr0 : Et[2 * I][r];
+                Et[2 * I + 1][r] = hit ? Pr1 : Et[2 * I + 1][r];
+            }
     }
     wave_sync();
     OSOT_SUB_END(PH_EQ_RED);    // Gauss-Jordan
+    const bool basic = valid && ((basicmask >> c) & 1u);
     const unsigned long long fmask = wave_ballot(valid && !basic && h == 0);
     const int nf = __builtin_popcountll(fmask);
     if (nf > kNullMax) return -1;
     const bool is_free = valid && !basic;
     const int t = __builtin_popcountll(fmask & ((1ull << c) - 1ull));   // index of my column among the free ones
     const int me = n - nf;
-    // ---- Z' rows into M2[me + t][:] ------------------------------------------------------------------------
+    // ---- Z' rows into M2[me + t][:]:  Z[pivcol(row)][free column] = -E_reduced[row][free column]
     for (int e = lane; e < 32 * S; e += 64) M2[e] = 0.0;
     wave_sync();
 #pragma unroll
-    for (int ii = 0; ii < 16; ++ii) {
-        const int r = 2 * ((ii + npairs) & 15) + h;   // register ii holds this row after npairs rotations
-        if (r < n_eq) {
-            const int pk = pivcol[r];
-            if (is_free && pk >= 0) M2[(me + t) * S + pk] = -Er[ii];
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * I + tq + 4 * r;
+            const int pk = (row < n_eq) ? pivcol[row] : -1;
+#pragma unroll
+            for (int C = 0; C < 2; ++C) {
+                const int col = 16 * C + ta;
+                const bool colfree = (col < n) && !((basicmask >> col) & 1u);
+                if (colfree && pk >= 0) {
+                    const int tc = __builtin_popcountll(fmask & ((1ull << col) - 1ull));
+                    M2[(me + tc) * S + pk] = -Et[2 * I + C][r];
+                }
+            }
         }
-    }
     if (is_free && h == 0) M2[(me + t) * S + c] = 1.0;
     wave_sync();
     // ---- modified Gram-Schmidt in the H metric: rows me.. of M2 become J2' -------------------------------

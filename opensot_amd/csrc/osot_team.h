@@ -167,6 +167,17 @@ __device__ __forceinline__ float colmax_f32(float v) {
     if (NP == 64) { swap32_pair_i(__float_as_int(v), a, b); v = fmaxf(__int_as_float(a), __int_as_float(b)); }
     return v;
 }
+// maximum over the 16 lanes of each DPP row (lanes 16 q .. 16 q + 15); every lane of the row gets its row's maximum
+__device__ __forceinline__ float row16_max_f32(float v) {
+    auto dppf = [](float x, auto ctrl) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), decltype(ctrl)::value, 0xF, 0xF, false));
+    };
+    v = fmaxf(v, dppf(v, std::integral_constant<int, DPP_XOR1>{}));
+    v = fmaxf(v, dppf(v, std::integral_constant<int, DPP_XOR2>{}));
+    v = fmaxf(v, dppf(v, std::integral_constant<int, DPP_HALF_MIRROR>{}));
+    v = fmaxf(v, dppf(v, std::integral_constant<int, DPP_MIRROR>{}));
+    return v;
+}
 __device__ __forceinline__ int first_lane_equal_f32(float v, float m) {
     const unsigned long long mask = wave_ballot(v == m);
     return mask ? __builtin_ctzll(mask) : 64;
@@ -248,6 +259,7 @@ __device__ __forceinline__ double bcast(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int bcast_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float bcast_f32(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 
 // value of lane c+1 of the same half (lane NP-1 keeps its own): used to shift the working-set bookkeeping
 template <int NP>

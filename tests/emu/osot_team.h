@@ -77,6 +77,13 @@ template <int NP> inline float colmax_f32(float v) {
     for (int i = 1; i < NP; ++i) m = std::fmax(m, all[h0 + i]);
     return m;
 }
+inline float row16_max_f32(float v) {
+    float all[64]; emu::allgather(&v, all, sizeof(float));
+    const int r0 = emu_lane() & ~15;
+    float m = all[r0];
+    for (int i = 1; i < 16; ++i) m = std::fmax(m, all[r0 + i]);
+    return m;
+}
 inline int first_lane_equal_f32(float v, float m) {
     const unsigned long long mask = wave_ballot(v == m);
     return mask ? __builtin_ctzll(mask) : 64;
@@ -109,6 +116,7 @@ template <int NP> inline void colargmin(double& v, int& p) {
     v = bv; p = bp;
 }
 inline double bcast(double v, int lane) { double all[64]; emu::allgather(&v, all, sizeof(double)); return all[lane]; }
+inline float bcast_f32(float v, int lane) { float all[64]; emu::allgather(&v, all, sizeof(float)); return all[lane]; }
 inline int bcast_i(int v, int lane) { int all[64]; emu::allgather(&v, all, sizeof(int)); return all[lane]; }
 template <int NP> inline double shift_down(double v) {
     double all[64]; emu::allgather(&v, all, sizeof(double));

@@ -74,10 +74,12 @@ def test_task_set_active(off, oracle):
     asm = oracle.assemble(plan, leaf)
     dq, xl, st, it = emu_cascade(plan, asm, task_active=ta)
     assert (st == 0).all()
-    # the flag is the zeroed Jacobian, bit for bit (stored blocks; the implicit Postural block has no rows to zero)
+    # the flag is the zeroed Jacobian (stored blocks; the implicit Postural block has no rows to zero).  To round-off only:
+    # void rows are absent from the lower levels' equality lists, zero rows are present and skipped as dependent, which
+    # changes how the rows group into the Gauss-Jordan's panels of four
     if all(not plan.levels[k][j].implicit for k, j in off):
         dz, xz, sz, _ = emu_cascade(plan, asm_ref)
-        assert (sz == 0).all() and np.array_equal(dq, dz)
+        assert (sz == 0).all() and np.abs(dq - dz).max() < 1e-12
     assert np.abs(dq - emu_cascade(plan, asm)[0]).max() > 1e-6      # and it is not the all-active answer
     # witness: the real qpOASES (the zero rows are linearly dependent EQUALITY rows at the levels below, which the
     # eiQuadProg restatement -- like the routine it restates, eiquadprog.hpp:246-251 -- does not handle)
