@@ -93,7 +93,10 @@ struct DevBatch {
 // Row table of level k (LDS): [ global C rows ; A_0 ; ... ; A_{k-1} ]  (iHQP.cpp:282-333).  The C entries are
 // filled once per instance, the optimality entries of level j are appended when level j has been solved
 // (lo = up = A_j x_j, iHQP.cpp:164-170; an inactive level contributes 0*x in [-1,1], iHQP.cpp:301-309).
-template <int NP, bool PROF>
+// EXTRA: the instantiation that knows about non-diagonal weights (WA / Wb operands) and Task::setActive(false); the plain
+// one carries none of that code (registers, scalar loads, branches) -- launches pick it whenever the plan has no dense-weight
+// level and every task is active
+template <int NP, bool PROF, bool EXTRA>
 __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D, const long long inst, const int lane, char* osot_smem) {
     constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
     const int n = P.n;
@@ -186,11 +189,11 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
         const double* wk = D.w[k] ? D.w[k] + inst * m : nullptr;
         // non-diagonal W_k: left operand W_k A_k and W_k b_k come from the update kernel (stored rows only: an implicit
         // Postural block keeps its diagonal weights w)
-        const bool dense = D.WA[k] != nullptr;
+        const bool dense = EXTRA && D.WA[k] != nullptr;
         const double* WAk = dense ? D.WA[k] + inst * ma * n : nullptr;
         const double* Wbk = dense ? D.Wb[k] + inst * m : nullptr;
         // Task::setActive(false): rows of an inactive task are zero rows
-        const unsigned inact = P.inactive[k];
+        const unsigned inact = EXTRA ? P.inactive[k] : 0u;
         auto row_off = [&](int r) -> bool {
             bool off = false;
             for (int j = 0; j < P.ntask[k]; ++j)
@@ -418,11 +421,11 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
     }
 }
 
-template <int NP, bool PROF>
+template <int NP, bool PROF, bool EXTRA = false>
 __global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : 1)) osot_cascade_kernel(const DevPlan P, const DevBatch D) {
     OSOT_DYNAMIC_LDS(osot_smem);
     const long long inst = D.order ? D.order[blockIdx.x] : (int)blockIdx.x;
-    cascade_body<NP, PROF>(P, D, inst, (int)threadIdx.x, osot_smem);
+    cascade_body<NP, PROF, EXTRA>(P, D, inst, (int)threadIdx.x, osot_smem);
 }
 
 // Longest-first dispatch.  One wavefront solves one instance and an MI355X holds 2048 of them at a time, so a
@@ -985,7 +988,7 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
 // (coman_ik.cpp:186-192: `stack->update(); solver->solve(dq)`).  The assembled b / W / box / rows still go through their
 // HBM arrays (they are outputs of the update in their own right) but come back from the CU's own L1 / L2 lines; what is
 // saved is a launch, its tail and the gap between the two (18 + ~4 us of a 227 us step at BASELINE config 3).
-template <int NP>
+template <int NP, bool EXTRA = false>
 __global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : 1)) osot_cycle_kernel(const DevUpdate U, const DevPlan P, const DevBatch D) {
     OSOT_DYNAMIC_LDS(osot_smem);
     const long long inst = D.order ? D.order[blockIdx.x] : (int)blockIdx.x;
@@ -995,7 +998,7 @@ __global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : 1)) osot_cycle_
     workgroup_fence();      // the update's global stores are visible to the cascade's loads (same workgroup)
     __syncthreads();
     const long long tc1 = D.prof ? (long long)clock64() : 0;
-    cascade_body<NP, false>(P, D, inst, (int)threadIdx.x, osot_smem);
+    cascade_body<NP, false, EXTRA>(P, D, inst, (int)threadIdx.x, osot_smem);
     if (D.prof && threadIdx.x == 0) {   // diagnostic (osot_solver_profile_cycle): shader-clock cycles of the two halves
         D.prof[inst * 4] = tc1 - tc0;
         D.prof[inst * 4 + 1] = (long long)clock64() - tc1;

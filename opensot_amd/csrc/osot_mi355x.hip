@@ -132,7 +132,9 @@ int osot_solver_create(const osot_plan_desc* plan, int max_batch, int device, os
     make_dev_plan(*plan, nullptr, P, T, lds);
     rc = (T == 32) ? ensure_lds(osot_cascade_kernel<32, false>, lds) : ensure_lds(osot_cascade_kernel<64, false>, lds);
     if (rc == OSOT_OK) rc = (T == 32) ? ensure_lds(osot_cascade_kernel<32, true>, lds) : ensure_lds(osot_cascade_kernel<64, true>, lds);
-    if (rc == OSOT_OK) rc = (T == 32) ? ensure_lds(osot_cycle_kernel<32>, lds) : ensure_lds(osot_cycle_kernel<64>, lds);
+    if (rc == OSOT_OK) rc = (T == 32) ? ensure_lds(osot_cycle_kernel<32, false>, lds) : ensure_lds(osot_cycle_kernel<64, false>, lds);
+    if (rc == OSOT_OK) rc = (T == 32) ? ensure_lds(osot_cycle_kernel<32, true>, lds) : ensure_lds(osot_cycle_kernel<64, true>, lds);
+    if (rc == OSOT_OK) rc = (T == 32) ? ensure_lds(osot_cascade_kernel<32, false, true>, lds) : ensure_lds(osot_cascade_kernel<64, false, true>, lds);
     if (rc != OSOT_OK) return rc;
     osot_solver* s = new osot_solver();
     s->plan = *plan;
@@ -143,8 +145,8 @@ int osot_solver_create(const osot_plan_desc* plan, int max_batch, int device, os
     {   // resident workgroups: what the longest-first dispatch order is planned for (osot_order_kernel)
         int per_cu = 0, cus = 0;
         hipError_t e1 = (T == 32)
-            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, osot_cycle_kernel<32>, 64, lds)
-            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, osot_cycle_kernel<64>, 64, lds);
+            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, osot_cycle_kernel<32, false>, 64, lds)
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, osot_cycle_kernel<64, false>, 64, lds);
         hipError_t e2 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
         s->slots = (e1 == hipSuccess && e2 == hipSuccess && per_cu > 0 && cus > 0) ? per_cu * cus : 2048;
     }
@@ -356,9 +358,20 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
         else { HIP_TRY(hipEventCreate(&ev.first)); HIP_TRY(hipEventCreate(&ev.second)); }
         HIP_TRY(hipEventRecord(ev.first, st));
     }
+    // the instantiation with the dense-weight / inactive-task code only where the plan or the solver state asks for it
+    bool extra = s->any_inactive;
+    for (int k = 0; k < pl.n_levels; ++k) extra = extra || (s->h_uplan.dense_level[k] != 0);
     if (fused) {
-        if (T == 32) hipLaunchKernelGGL((osot_cycle_kernel<32>), dim3(grid), dim3(64), lds, st, *fused, P, D);
-        else hipLaunchKernelGGL((osot_cycle_kernel<64>), dim3(grid), dim3(64), lds, st, *fused, P, D);
+        if (T == 32) {
+            if (extra) hipLaunchKernelGGL((osot_cycle_kernel<32, true>), dim3(grid), dim3(64), lds, st, *fused, P, D);
+            else hipLaunchKernelGGL((osot_cycle_kernel<32, false>), dim3(grid), dim3(64), lds, st, *fused, P, D);
+        } else {
+            if (extra) hipLaunchKernelGGL((osot_cycle_kernel<64, true>), dim3(grid), dim3(64), lds, st, *fused, P, D);
+            else hipLaunchKernelGGL((osot_cycle_kernel<64, false>), dim3(grid), dim3(64), lds, st, *fused, P, D);
+        }
+    } else if (extra && !prof) {
+        if (T == 32) hipLaunchKernelGGL((osot_cascade_kernel<32, false, true>), dim3(grid), dim3(64), lds, st, P, D);
+        else hipLaunchKernelGGL((osot_cascade_kernel<64, false, true>), dim3(grid), dim3(64), lds, st, P, D);
     } else if (prof) {
         if (T == 32) hipLaunchKernelGGL((osot_cascade_kernel<32, true>), dim3(grid), dim3(64), lds, st, P, D);
         else hipLaunchKernelGGL((osot_cascade_kernel<64, true>), dim3(grid), dim3(64), lds, st, P, D);

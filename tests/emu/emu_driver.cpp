@@ -30,8 +30,9 @@ extern "C" __attribute__((visibility("default"))) int emu_ihqp_solve(const osot_
     D.b_reg = plan->has_regularisation ? b->b_reg : nullptr;
     D.accepted_slack = b->accepted_slack;
     const unsigned grid = (unsigned)b->B;
-    if (T == 32) emu::launch(osot_cascade_kernel<32, false>, grid, lds, 64, P, D);
-    else emu::launch(osot_cascade_kernel<64, false>, grid, lds, 64, P, D);
+    // (the emulation always runs the instantiation with the dense-weight / inactive-task code: it is a superset)
+    if (T == 32) emu::launch(osot_cascade_kernel<32, false, true>, grid, lds, 64, P, D);
+    else emu::launch(osot_cascade_kernel<64, false, true>, grid, lds, 64, P, D);
     return OSOT_OK;
 }
 
