@@ -201,21 +201,40 @@ def test_closed_loop_robustness_sweep_default_eps(oracle, gpu_device):
 
 
 def test_inverse_dynamics_full_size(oracle, gpu_device):
-    """BASELINE config 5 shard (8192 over 8 GPUs = 1024 per GPU): floating-base rows of the computed torque
-    vanish (InverseDynamics.cpp:83-92), torque limits / friction cones hold, oracle spot check"""
+    """BASELINE config 5 shard (8192 over 8 GPUs = 1024 per GPU), ALL on the device: [B_u, -J_f'], [B, -Jc'] and the [J 0]
+    task rows written by osot_id_rows from the model quantities, update + cascade, tau from osot_computed_torque
+    (InverseDynamics.cpp:57-96): its floating-base rows vanish and the acceptance flag is set, torque limits / friction
+    cones hold; 256 instances against the eiQuadProg restatement AND the reference's qpOASES"""
+    import torch
+    from opensot_amd.dynamics import IdModel
+    from opensot_amd.solver import BatchedStack
     B = 1024
     plan, leaf = synth.make_id_stack(B, seed=50)
-    st = _solve(plan, leaf)
+    nv = leaf["model"]["nv"]
+    st = BatchedStack(plan, B, device=0)
+    bare = dict(leaf); bare["A"] = [np.zeros_like(leaf["A"][0]), None]; bare["C"] = [None] * len(leaf["C"])
+    dev = st.load_leaf(bare)
+    md = IdModel(leaf["model"]["B"], leaf["model"]["h"], leaf["model"]["Jc"], device=0)
+    J = [np.ascontiguousarray(leaf["A"][0][:, o:o + r, :nv]) for o, r in ((0, 3), (3, 6), (9, 6))]
+    md.write_rows(st, dyn_block=0, tau_block=2, tasks=[(0, 0, J[0]), (0, 3, J[1]), (0, 9, J[2])])
+    st.cycle(dev)
+    tau_d, ok_d = md.computed_torque(st.dq[:B])
+    torch.cuda.synchronize()
     dq = st.dq[:B].cpu().numpy()
     assert (st.status[:B].cpu().numpy() == 0).all()
-    tau = synth.computed_torque(leaf, dq)
-    assert np.abs(tau[:, :6]).max() < 1e-8
+    tau = tau_d.cpu().numpy()
+    np.testing.assert_allclose(tau, synth.computed_torque(leaf, dq), rtol=0, atol=1e-10)
+    assert (ok_d.cpu().numpy() == 1).all() and np.abs(tau[:, :6]).max() < 1e-8
     assert np.abs(tau[:, 6:]).max() <= 30.0 + 1e-8
-    sub = slice(0, B, 32)
+    sub = slice(0, B, 4)      # 256 instances
     sl = {"B": len(range(*sub.indices(B))), "A": [a[sub] if a is not None else None for a in leaf["A"]],
           "task": [[tuple(None if x is None else x[sub] for x in t) for t in lev] for lev in leaf["task"]],
           "bound": [], "rows": [tuple(None if x is None else x[sub] for x in t) for t in leaf["rows"]],
           "C": [None if x is None else x[sub] for x in leaf["C"]]}
     asm = oracle.assemble(plan, sl)
-    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
-    assert np.abs(dq[sub] - ref["dq"]).max() < 1e-8
+    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=0)
+    assert (ref["status"] == 1).all() and np.abs(dq[sub] - ref["dq"]).max() < 1e-8
+    if oracle.ref_available():
+        rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=0)
+        okq = rq["status"] == 1
+        assert okq.mean() > 0.95 and np.abs(dq[sub][okq] - rq["dq"][okq]).max() < 1e-6 * max(1.0, np.abs(dq).max())
