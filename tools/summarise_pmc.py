@@ -9,7 +9,7 @@ for f in sorted(glob.glob(out + "/pmc*_counters.csv")):
     rows = list(csv.DictReader(open(f)))
     acc, cnt = {}, {}
     for r in rows:
-        if "osot_cascade_kernel" not in r.get("Kernel_Name", ""):
+        if "osot_cycle_kernel" not in r.get("Kernel_Name", ""):      # the bench's step: update + cascade in one launch
             continue
         kname = r["Kernel_Name"]
         c, v = r["Counter_Name"], float(r["Counter_Value"])
@@ -28,4 +28,6 @@ if "FETCH_SIZE" in per:
     res["correction"] = ("MI355X_MICROARCH.md HBM section: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the "
                          "bytes of a coalesced stream, so it is doubled; WRITE_SIZE taken as is; separate --pmc passes")
 res["algorithmic_bytes_per_launch"] = 4096 * ((3 + 24) * 32 * 8 + 59 * 8 + 59 * 8 + 2 * 32 * 8 + 32 * 8)
+res["note"] = ("osot_cycle_kernel = AutoStack::update + cascade of an instance by one wavefront: its traffic also holds the leaf inputs "
+               "(poses, q, limits: ~2.3 KB per instance) and the assembled b / w / box it writes and reads back (~1.5 KB)")
 print(json.dumps(res, indent=1))
