@@ -561,7 +561,6 @@ __device__ inline int nullspace_equalities32(const WaveCtx<32>& w, int n_eq, dou
     const int lane = c + 32 * h;
     const bool valid = c < n;
     double* M2 = w.M2;
-    int* pivcol = reinterpret_cast<int*>(w.V + 3 * 32);   // idle staging vector: pivot column of each row (32 ints)
     // ---- E -> registers in the ACCUMULATOR-TILE layout of v_mfma_f64_16x16x4: lane l = (ta, tq) = (l & 15, l >> 4), tile
     // (I, C) element r holds E[16 I + tq + 4 r][16 C + ta] (the layout of factor_tiles32).  All sixteen row pointers first,
     // then all loads (unconditional: a unit row reads the harmless safe_row), then the selects: ONE memory round trip.
@@ -612,92 +611,96 @@ __device__ inline int nullspace_equalities32(const WaveCtx<32>& w, int n_eq, dou
     OSOT_SUB_END(PH_EQ_D);      // (profiling slots reused: load + scale)
     // ---- Gauss-Jordan with column pivoting, FOUR ROWS AT A TIME.  Panel p = rows 4p .. 4p+3 = element p & 3 of the tiles
     // (p >> 2, C) -- one register per tile column, lane (ta, tq) holding row 4p + tq at columns 16 C + ta: no data movement
-    // to take it out.  (a) The four rows are reduced against each other in that form (pivot = largest entry of the row among
-    // the non-basic columns: a 16-lane DPP max + ballot; three ds_bpermute per pivot).  (b) Every other row i then needs
+    // to take it out.  (a) The four rows are reduced against each other in that form.  Pivot of a row = its largest entry among
+    // the non-basic columns: the candidates travel as |value| in fp32 bits with the column packed into the five low bits
+    // (non-negative floats order like unsigned integers), so ONE 16-lane integer DPP max + v_readlane yields value and
+    // column; ties and values within 2^-18 of each other go to the lower column.  (b) Every other row i then needs
     // E[i] -= sum_q E[i][p_q] Rhat[q], the Schur form of eliminating the panel's four pivot columns with the ORIGINAL column
     // entries as multipliers: a rank-4 update, i.e. ONE v_mfma_f64_16x16x4 per tile.  The reduced panel in its quarter-row
-    // form IS the B operand (lane (n, k) = Rhat[k][16 C + n]); the A operand (lane (m, k) = E[16 I + m][p_k]) is gathered
-    // from the tiles with sixteen ds_bpermute per panel -- where the rank-1 form spent sixteen per PIVOT plus 16 VALU FMAs.
+    // form IS the B operand (lane (n, k) = Rhat[k][16 C + n]); the A operand (lane (m, k) = E[16 I + m][p_k]) goes through a
+    // 4 x 32 LDS buffer: the four lanes that own column p_k write their eight entries when the pivot is chosen (off the
+    // critical path), every lane reads its two after the panel.
     unsigned basicmask = 0u;     // bit c: column c has become a pivot (basic) column
-    const int npanels = (n_eq + 3) >> 2;
-    for (int p = 0; p < npanels; ++p) {
-        const int Ip = p >> 2, rq = p & 3;
-        double Pr0 = 0.0, Pr1 = 0.0;
-#pragma unroll
-        for (int I = 0; I < 2; ++I)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool hit = (p == 4 * I + r);
-                Pr0 = hit ? Et[2 * I][r] : Pr0;
-                Pr1 = hit ? Et[2 * I + 1][r] : Pr1;
-            }
-        int pc0 = -1, pc1 = -1, pc2 = -1, pc3 = -1;     // pivot columns of the panel's rows (-1: dependent row)
+    double* colbuf = w.M1;                                      // [4][32]; M1 is idle until the first inequality is added
+    int* pivcol = reinterpret_cast<int*>(w.M1 + 4 * 32);        // pivot column of each row (32 ints)
+    const unsigned tolbits = uniform_u32(f32_bits((float)tol));
+    const int ta4 = ta << 2, rowbase4 = (lane & 48) << 2;       // byte addresses for ds_bpermute
+    bool nb0 = ta < n, nb1 = 16 + ta < n;                       // my columns are (still) non-basic
+    int mypk = -1;                                              // lane k: pivot column of row k
+    auto panel = [&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        constexpr int Ip = p >> 2, rq = p & 3;
+        if (4 * p >= n_eq) return;
+        double Pr0 = Et[2 * Ip][rq], Pr1 = Et[2 * Ip + 1][rq];
+        unsigned okmask = 0u;                                   // bit q: row 4p + q found a pivot
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int k = 4 * p + q;
-            int pk = -1;
             if (k < n_eq) {
-                const bool myrow = (tq == q);
-                const bool nb0 = (ta < n) && !((basicmask >> ta) & 1u), nb1 = (16 + ta < n) && !((basicmask >> (16 + ta)) & 1u);
-                const float cand0 = (myrow && nb0) ? (float)fabs(Pr0) : -1.0f;
-                const float cand1 = (myrow && nb1) ? (float)fabs(Pr1) : -1.0f;
-                const float rmx = row16_max_f32(fmaxf(cand0, cand1));
-                const float pmax = bcast_f32(rmx, 16 * q);
-                if ((double)pmax > tol && pmax > 0.0f) {
-                    const unsigned b0 = (unsigned)((wave_ballot(myrow && cand0 == pmax) >> (16 * q)) & 0xffffull);
-                    const unsigned b1 = (unsigned)((wave_ballot(myrow && cand1 == pmax) >> (16 * q)) & 0xffffull);
-                    const int pcol = b0 ? __builtin_ctz(b0) : 16 + __builtin_ctz(b1);
+                int pk = -1;
+                const double r0raw = permute_f64(Pr0, ta4 + 64 * q), r1raw = permute_f64(Pr1, ta4 + 64 * q);   // row k at my columns
+                const unsigned c0 = nb0 ? ((f32_bits((float)fabs(Pr0)) & ~31u) | (unsigned)(31 - ta)) : 0u;
+                const unsigned c1 = nb1 ? ((f32_bits((float)fabs(Pr1)) & ~31u) | (unsigned)(15 - ta)) : 0u;
+                const unsigned s = bcast_u32(row16_max_u32(umax(c0, c1)), 16 * q);
+                if ((s & ~31u) > tolbits) {
+                    const int pcol = 31 - (int)(s & 31u);
                     pk = pcol;
                     const int ap = pcol & 15;
                     const double fsel = (pcol >> 4) ? Pr1 : Pr0;              // the register that holds column pcol
                     const double ipv = fast_rcp(bcast(fsel, ap + 16 * q));
-                    const double f = __shfl(fsel, ap + 16 * tq, 64);          // my panel row's entry at the pivot column
-                    const double r0 = __shfl(Pr0, ta + 16 * q, 64) * ipv;     // the scaled pivot row at my columns
-                    const double r1 = __shfl(Pr1, ta + 16 * q, 64) * ipv;
+                    const double f = permute_f64(fsel, (ap << 2) + rowbase4);  // my panel row's entry at the pivot column
+                    const double r0 = r0raw * ipv, r1 = r1raw * ipv;           // the scaled pivot row at my columns
+                    const bool myrow = (tq == q);
                     Pr0 = myrow ? r0 : fma(-f, r0, Pr0);
                     Pr1 = myrow ? r1 : fma(-f, r1, Pr1);
                     basicmask |= (1u << pcol);
-                } else if (myrow) {
+                    nb0 = nb0 && (ta != pcol);
+                    nb1 = nb1 && (16 + ta != pcol);
+                    okmask |= (1u << q);
+                    if (ta == ap) {       // four lanes (tq = 0..3): column pcol as it was at the start of the panel
+                        double* cb = colbuf + q * 32 + tq;
+                        if (pcol < 16) {
+#pragma unroll
+                            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) cb[16 * I + 4 * r] = Et[2 * I][r];
+                        } else {
+#pragma unroll
+                            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) cb[16 * I + 4 * r] = Et[2 * I + 1][r];
+                        }
+                    }
+                } else if (tq == q) {
                     Pr0 = 0.0; Pr1 = 0.0;      // dependent row (consistent: x_prev satisfies every row)
                 }
-                if (lane == 0) pivcol[k] = pk;
+                mypk = (lane == k) ? pk : mypk;
             }
-            if (q == 0) pc0 = pk; else if (q == 1) pc1 = pk; else if (q == 2) pc2 = pk; else pc3 = pk;
         }
-        // A operand of the trailing update: lane (m, k) = (ta, tq) <- E[16 I + m][p_k], which sits in tile (I, p_k >> 4),
-        // element m >> 2, lane (p_k & 15, m & 3).  Zero for the panel's own rows and for a row without a pivot.
-        const int pm = (tq == 0) ? pc0 : ((tq == 1) ? pc1 : ((tq == 2) ? pc2 : pc3));
-        const int srcl = ((pm >= 0 ? pm : 0) & 15) + 16 * (ta & 3);
-        const int wr = ta >> 2, wC = (pm >= 0 ? pm : 0) >> 4;
-        double FA[2] = {0.0, 0.0};
-#pragma unroll
-        for (int I = 0; I < 2; ++I)
-#pragma unroll
-            for (int C = 0; C < 2; ++C)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double v = __shfl(Et[2 * I + C][r], srcl, 64);
-                    FA[I] = (r == wr && C == wC) ? v : FA[I];
-                }
+        wave_sync();
+        // A operand of the trailing update: lane (m, k) = (ta, tq) <- -E[16 I + m][p_k]; zero for the panel's own rows and for
+        // a row without a pivot
+        const bool okq = ((okmask >> tq) & 1u) != 0u;
+        double FA[2];
 #pragma unroll
         for (int I = 0; I < 2; ++I) {
-            const bool own = (I == Ip) && (wr == rq);
-            FA[I] = (pm < 0 || own) ? 0.0 : -FA[I];
+            const double v = colbuf[tq * 32 + 16 * I + ta];
+            const bool own = (I == Ip) && ((ta >> 2) == rq);
+            FA[I] = (okq && !own) ? -v : 0.0;
         }
         Et[0] = mfma_f64_16x16x4(FA[0], Pr0, Et[0]);
         Et[1] = mfma_f64_16x16x4(FA[0], Pr1, Et[1]);
         Et[2] = mfma_f64_16x16x4(FA[1], Pr0, Et[2]);
         Et[3] = mfma_f64_16x16x4(FA[1], Pr1, Et[3]);
-        // the reduced panel back into its register
-#pragma unroll
-        for (int I = 0; I < 2; ++I)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool hit = (p == 4 * I + r);
-                Et[2 * I][r] = hit ? Pr0 : Et[2 * I][r];
-                Et[2 * I + 1][r] = hit ? Pr1 : Et[2 * I + 1][r];
-            }
-    }
+        Et[2 * Ip][rq] = Pr0;                 // the reduced panel back into its register
+        Et[2 * Ip + 1][rq] = Pr1;
+        wave_sync();                          // colbuf is free for the next panel
+    };
+    panel(std::integral_constant<int, 0>{}); panel(std::integral_constant<int, 1>{});
+    panel(std::integral_constant<int, 2>{}); panel(std::integral_constant<int, 3>{});
+    panel(std::integral_constant<int, 4>{}); panel(std::integral_constant<int, 5>{});
+    panel(std::integral_constant<int, 6>{}); panel(std::integral_constant<int, 7>{});
+    if (lane < 32) pivcol[lane] = mypk;
     wave_sync();
     OSOT_SUB_END(PH_EQ_RED);    // Gauss-Jordan
     const bool basic = valid && ((basicmask >> c) & 1u);

@@ -129,6 +129,38 @@ __device__ __forceinline__ double rowgroup_sum(double v) {
     return a + b;
 }
 
+// ---- LDS-crossbar permutes with a precomputed BYTE address (4 * source lane): no per-call lane arithmetic ----------
+__device__ __forceinline__ double permute_f64(double v, int byteaddr) {
+    const int lo = __builtin_amdgcn_ds_bpermute(byteaddr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(byteaddr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+// all-gather over the four rows of 16 lanes: the values of lanes (l & 15) + 16 q, q = 0..3, in every lane.  Eight
+// ds_bpermute_b32 (~10 cycles of issue each, one ~80-cycle latency for the lot); the v_permlane16/32_swap form needs twelve
+// instructions at ~16 cycles each (tools/ubench_latency.hip).
+struct Quad { double a, b, c, d; };
+__device__ __forceinline__ Quad rowgroup_gather4(double v) {
+    const int a4 = (int)(threadIdx.x & 15u) << 2;
+    Quad g;
+    g.a = permute_f64(v, a4);
+    g.b = permute_f64(v, a4 + 64);
+    g.c = permute_f64(v, a4 + 128);
+    g.d = permute_f64(v, a4 + 192);
+    return g;
+}
+// maximum of an unsigned over the 16 lanes of each DPP row; every lane of the row gets it
+__device__ __forceinline__ unsigned row16_max_u32(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, DPP_XOR1, 0xF, 0xF, true));
+    v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, DPP_XOR2, 0xF, 0xF, true));
+    v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, DPP_HALF_MIRROR, 0xF, 0xF, true));
+    v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, DPP_MIRROR, 0xF, 0xF, true));
+    return v;
+}
+__device__ __forceinline__ unsigned f32_bits(float v) { return __float_as_uint(v); }
+__device__ __forceinline__ unsigned umax(unsigned a, unsigned b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned bcast_u32(unsigned v, int lane) { return (unsigned)__builtin_amdgcn_readlane((int)v, lane); }
+__device__ __forceinline__ unsigned uniform_u32(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+
 // ---- reductions over the NP columns (lanes with equal h); every lane gets the result ------------------
 template <int NP>
 __device__ __forceinline__ double colsum(double v) {

@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cmath>
+#include <cstring>
 
 #define OSOT_DYNAMIC_LDS(name) char* name = emu::dyn_smem_ptr()
 #define OSOT_STATIC_LDS(type, name, count) static type name[count]
@@ -56,6 +57,27 @@ inline double rowgroup_sum(double v) {
     const int a = emu_lane() & 15;
     return (all[a] + all[a + 16]) + (all[a + 32] + all[a + 48]);
 }
+struct Quad { double a, b, c, d; };
+inline Quad rowgroup_gather4(double v) {
+    double all[64]; emu::allgather(&v, all, sizeof(double));
+    const int a = emu_lane() & 15;
+    return Quad{all[a], all[a + 16], all[a + 32], all[a + 48]};
+}
+inline double permute_f64(double v, int byteaddr) {
+    double all[64]; emu::allgather(&v, all, sizeof(double));
+    return all[(byteaddr >> 2) & 63];
+}
+inline unsigned row16_max_u32(unsigned v) {
+    unsigned all[64]; emu::allgather(&v, all, sizeof(unsigned));
+    const int r0 = emu_lane() & ~15;
+    unsigned m = all[r0];
+    for (int i = 1; i < 16; ++i) m = all[r0 + i] > m ? all[r0 + i] : m;
+    return m;
+}
+inline unsigned f32_bits(float v) { unsigned b; std::memcpy(&b, &v, 4); return b; }
+inline unsigned umax(unsigned a, unsigned b) { return a > b ? a : b; }
+inline unsigned bcast_u32(unsigned v, int lane) { unsigned all[64]; emu::allgather(&v, all, sizeof(unsigned)); return all[lane]; }
+inline unsigned uniform_u32(unsigned v) { return bcast_u32(v, 0); }
 template <int NP> inline double colsum(double v) {
     double all[64]; emu::allgather(&v, all, sizeof(double));
     const int h0 = (emu_lane() / NP) * NP;
