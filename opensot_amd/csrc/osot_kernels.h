@@ -435,6 +435,7 @@ template <int NP, bool PROF, bool EXTRA = false>
 __global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : 1)) osot_cascade_kernel(const DevPlan P, const DevBatch D) {
     OSOT_DYNAMIC_LDS(osot_smem);
     const long long inst = D.order ? D.order[blockIdx.x] : (int)blockIdx.x;
+    if (D.order) wave_priority_by_rank(blockIdx.x, gridDim.x);
     cascade_body<NP, PROF, EXTRA>(P, D, inst, (int)threadIdx.x, osot_smem);
 }
 
@@ -1002,6 +1003,7 @@ template <int NP, bool EXTRA = false>
 __global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : 1)) osot_cycle_kernel(const DevUpdate U, const DevPlan P, const DevBatch D) {
     OSOT_DYNAMIC_LDS(osot_smem);
     const long long inst = D.order ? D.order[blockIdx.x] : (int)blockIdx.x;
+    if (D.order) wave_priority_by_rank(blockIdx.x, gridDim.x);
     const long long tc0 = D.prof ? (long long)clock64() : 0;
     const long long tw0 = D.prof ? (long long)wall_clock64() : 0;
     update_body(OSOT_KERNARG_PTR(DevUpdate, U), inst, (int)threadIdx.x, osot_smem);   // (the cascade's slice is idle until it starts)

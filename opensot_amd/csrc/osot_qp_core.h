@@ -550,7 +550,7 @@ enum { PH_HBUILD = 0, PH_CHOL = 1, PH_INV = 2, PH_SUBST = 3, PH_EQ = 4, PH_INEQ 
 // active-set loop that follows, and the equality part of J is never read again.  Work ~ me^2 n / 2 instead of
 // me n^2; linearly dependent (necessarily consistent) rows simply produce no pivot.
 // Returns the rank (= number of equality positions in the working set), or -1 if nf > kNullMax (caller then
-// takes the generic path; nothing has been modified in that case).
+// takes the generic path; M2 = JT is as it was on entry in that case).
 constexpr int kNullMax = 8;
 template <bool PROF>
 __device__ inline int nullspace_equalities32(const WaveCtx<32>& w, int n_eq, double hdiag, double g, double xprev,
@@ -617,12 +617,12 @@ __device__ inline int nullspace_equalities32(const WaveCtx<32>& w, int n_eq, dou
     // column; ties and values within 2^-18 of each other go to the lower column.  (b) Every other row i then needs
     // E[i] -= sum_q E[i][p_q] Rhat[q], the Schur form of eliminating the panel's four pivot columns with the ORIGINAL column
     // entries as multipliers: a rank-4 update, i.e. ONE v_mfma_f64_16x16x4 per tile.  The reduced panel in its quarter-row
-    // form IS the B operand (lane (n, k) = Rhat[k][16 C + n]); the A operand (lane (m, k) = E[16 I + m][p_k]) goes through a
-    // 4 x 32 LDS buffer: the four lanes that own column p_k write their eight entries when the pivot is chosen (off the
-    // critical path), every lane reads its two after the panel.
+    // form IS the B operand (lane (n, k) = Rhat[k][16 C + n]); the A operand (lane (m, k) = E[16 I + m][p_k]) goes through
+    // LDS: every lane stores its sixteen entries of E by columns when the panel starts (asynchronously) and reads its two
+    // after the panel, at the column its quarter-row's pivot fell on.
     unsigned basicmask = 0u;     // bit c: column c has become a pivot (basic) column
-    double* colbuf = w.M1;                                      // [4][32]; M1 is idle until the first inequality is added
-    int* pivcol = reinterpret_cast<int*>(w.M1 + 4 * 32);        // pivot column of each row (32 ints)
+    double* colstore = M2;                                      // E by columns, stride 33 (M2 is idle: it is zeroed below)
+    int* pivcol = reinterpret_cast<int*>(w.M1);                 // pivot column of each row (32 ints); M1 is idle too
     const unsigned tolbits = uniform_u32(f32_bits((float)tol));
     const int ta4 = ta << 2, rowbase4 = (lane & 48) << 2;       // byte addresses for ds_bpermute
     bool nb0 = ta < n, nb1 = 16 + ta < n;                       // my columns are (still) non-basic
@@ -631,62 +631,56 @@ __device__ inline int nullspace_equalities32(const WaveCtx<32>& w, int n_eq, dou
         constexpr int p = decltype(pc)::value;
         constexpr int Ip = p >> 2, rq = p & 3;
         if (4 * p >= n_eq) return;
+        // E as it is at the start of the panel -> LDS by columns (asynchronous: the stores drain under the first pivot search)
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int C = 0; C < 2; ++C)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) colstore[(16 * C + ta) * 33 + 16 * I + tq + 4 * r] = Et[2 * I + C][r];
         double Pr0 = Et[2 * Ip][rq], Pr1 = Et[2 * Ip + 1][rq];
-        unsigned okmask = 0u;                                   // bit q: row 4p + q found a pivot
+        int pcq = 0;                                            // pivot column of MY panel row (row 4p + tq); -1: none
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int k = 4 * p + q;
             if (k < n_eq) {
-                int pk = -1;
+                // branch-free: a row without a pivot (every candidate below tol: a dependent row, consistent because x_prev
+                // satisfies every row) goes through the same arithmetic with a zero reciprocal, which zeroes the row and
+                // leaves the others as they are
                 const double r0raw = permute_f64(Pr0, ta4 + 64 * q), r1raw = permute_f64(Pr1, ta4 + 64 * q);   // row k at my columns
                 const unsigned c0 = nb0 ? ((f32_bits((float)fabs(Pr0)) & ~31u) | (unsigned)(31 - ta)) : 0u;
                 const unsigned c1 = nb1 ? ((f32_bits((float)fabs(Pr1)) & ~31u) | (unsigned)(15 - ta)) : 0u;
                 const unsigned s = bcast_u32(row16_max_u32(umax(c0, c1)), 16 * q);
-                if ((s & ~31u) > tolbits) {
-                    const int pcol = 31 - (int)(s & 31u);
-                    pk = pcol;
-                    const int ap = pcol & 15;
-                    const double fsel = (pcol >> 4) ? Pr1 : Pr0;              // the register that holds column pcol
-                    const double ipv = fast_rcp(bcast(fsel, ap + 16 * q));
-                    const double f = permute_f64(fsel, (ap << 2) + rowbase4);  // my panel row's entry at the pivot column
-                    const double r0 = r0raw * ipv, r1 = r1raw * ipv;           // the scaled pivot row at my columns
-                    const bool myrow = (tq == q);
-                    Pr0 = myrow ? r0 : fma(-f, r0, Pr0);
-                    Pr1 = myrow ? r1 : fma(-f, r1, Pr1);
-                    basicmask |= (1u << pcol);
-                    nb0 = nb0 && (ta != pcol);
-                    nb1 = nb1 && (16 + ta != pcol);
-                    okmask |= (1u << q);
-                    if (ta == ap) {       // four lanes (tq = 0..3): column pcol as it was at the start of the panel
-                        double* cb = colbuf + q * 32 + tq;
-                        if (pcol < 16) {
-#pragma unroll
-                            for (int I = 0; I < 2; ++I)
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) cb[16 * I + 4 * r] = Et[2 * I][r];
-                        } else {
-#pragma unroll
-                            for (int I = 0; I < 2; ++I)
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) cb[16 * I + 4 * r] = Et[2 * I + 1][r];
-                        }
-                    }
-                } else if (tq == q) {
-                    Pr0 = 0.0; Pr1 = 0.0;      // dependent row (consistent: x_prev satisfies every row)
-                }
+                const bool ok = (s & ~31u) > tolbits;
+                const int pcol = 31 - (int)(s & 31u);
+                const int ap = pcol & 15;
+                const double fsel = (pcol >> 4) ? Pr1 : Pr0;              // the register that holds column pcol
+                const double piv = bcast(fsel, ap + 16 * q);
+                const double ipv = ok ? fast_rcp(piv) : 0.0;
+                const double f = permute_f64(fsel, (ap << 2) + rowbase4);  // my panel row's entry at the pivot column
+                const double r0 = r0raw * ipv, r1 = r1raw * ipv;           // the scaled pivot row at my columns
+                const bool myrow = (tq == q);
+                Pr0 = myrow ? r0 : fma(-f, r0, Pr0);
+                Pr1 = myrow ? r1 : fma(-f, r1, Pr1);
+                const int pk = ok ? pcol : -1;
+                basicmask |= ok ? (1u << pcol) : 0u;
+                nb0 = nb0 && (ta != pk);
+                nb1 = nb1 && (16 + ta != pk);
+                pcq = myrow ? pk : pcq;
                 mypk = (lane == k) ? pk : mypk;
+            } else {
+                pcq = (tq == q) ? -1 : pcq;
             }
         }
         wave_sync();
-        // A operand of the trailing update: lane (m, k) = (ta, tq) <- -E[16 I + m][p_k]; zero for the panel's own rows and for
-        // a row without a pivot
-        const bool okq = ((okmask >> tq) & 1u) != 0u;
+        // A operand of the trailing update: lane (m, k) = (ta, tq) <- -E[16 I + m][p_k] as stored above; zero for the panel's own
+        // rows and for a row without a pivot
         double FA[2];
 #pragma unroll
         for (int I = 0; I < 2; ++I) {
-            const double v = colbuf[tq * 32 + 16 * I + ta];
+            const double v = colstore[(pcq < 0 ? 0 : pcq) * 33 + 16 * I + ta];
             const bool own = (I == Ip) && ((ta >> 2) == rq);
-            FA[I] = (okq && !own) ? -v : 0.0;
+            FA[I] = (pcq >= 0 && !own) ? -v : 0.0;
         }
         Et[0] = mfma_f64_16x16x4(FA[0], Pr0, Et[0]);
         Et[1] = mfma_f64_16x16x4(FA[0], Pr1, Et[1]);
@@ -694,7 +688,7 @@ __device__ inline int nullspace_equalities32(const WaveCtx<32>& w, int n_eq, dou
         Et[3] = mfma_f64_16x16x4(FA[1], Pr1, Et[3]);
         Et[2 * Ip][rq] = Pr0;                 // the reduced panel back into its register
         Et[2 * Ip + 1][rq] = Pr1;
-        wave_sync();                          // colbuf is free for the next panel
+        wave_sync();                          // the column store is free for the next panel
     };
     panel(std::integral_constant<int, 0>{}); panel(std::integral_constant<int, 1>{});
     panel(std::integral_constant<int, 2>{}); panel(std::integral_constant<int, 3>{});
@@ -706,7 +700,13 @@ __device__ inline int nullspace_equalities32(const WaveCtx<32>& w, int n_eq, dou
     const bool basic = valid && ((basicmask >> c) & 1u);
     const unsigned long long fmask = wave_ballot(valid && !basic && h == 0);
     const int nf = __builtin_popcountll(fmask);
-    if (nf > kNullMax) return -1;
+    if (nf > kNullMax) {   // the caller goes on with the generic path: JT = diag(1 / sqrt(h)) back into M2 (it held the column store)
+        for (int e = lane; e < 32 * S; e += 64) M2[e] = 0.0;
+        wave_sync();
+        if (h == 0 && valid) { double sq, rs; fast_sqrt_rsqrt(hdiag, sq, rs); M2[c * S + c] = rs; }
+        wave_sync();
+        return -1;
+    }
     const bool is_free = valid && !basic;
     const int t = __builtin_popcountll(fmask & ((1ull << c) - 1ull));   // index of my column among the free ones
     const int me = n - nf;

@@ -65,21 +65,46 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
+__device__ __forceinline__ unsigned f32_bits(float v) { return __float_as_uint(v); }
+__device__ __forceinline__ unsigned umax(unsigned a, unsigned b) { return a > b ? a : b; }
+
+// Issue priority of this wavefront among the waves of its SIMD (s_setprio, 0..3), by its position in a dispatch list
+// that is sorted by descending expected cost: the launch ends with its longest jobs, so those get the SIMD's issue slots
+// first and their co-resident (shorter) waves absorb the delay.  g = position, total = list length.
+#ifndef OSOT_PRIO_SH3
+#define OSOT_PRIO_SH3 5
+#define OSOT_PRIO_SH2 3
+#define OSOT_PRIO_SH1 2
+#endif
+__device__ __forceinline__ void wave_priority_by_rank(unsigned g, unsigned total) {
+#ifndef OSOT_PRIO_OFF
+    if (g < (total >> OSOT_PRIO_SH3)) __builtin_amdgcn_s_setprio(3);
+    else if (g < (total >> OSOT_PRIO_SH2)) __builtin_amdgcn_s_setprio(2);
+    else if (g < (total >> OSOT_PRIO_SH1)) __builtin_amdgcn_s_setprio(1);
+#endif
+}
+
 // ---- DPP helpers on doubles (two 32-bit halves) ------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);   // (every lane has a source under the controls used here: no
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);   //  "old" operand, hence no register copy in front of the DPP move)
     return __hiloint2double(hi, lo);
 }
 template <int CTRL>
-__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
 
 constexpr int DPP_XOR1 = 0xB1;          // quad_perm [1,0,3,2]
 constexpr int DPP_XOR2 = 0x4E;          // quad_perm [2,3,0,1]
 constexpr int DPP_HALF_MIRROR = 0x141;  // lane i <-> 7-i inside each 8
 constexpr int DPP_MIRROR = 0x140;       // lane i <-> 15-i inside each row of 16
+
+// v_max_f64 / v_min_f64 as they are (IEEE mode: a NaN operand loses, a signalling NaN is quieted by the instruction
+// itself).  fmax()/fmin() on values that went through a DPP move or a permlane swap cost a v_max_f64 x, x, x in front
+// of every operand: the compiler cannot see that they are canonical.
+__device__ __forceinline__ double max_raw(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double min_raw(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 // sum over the 16 lanes of each DPP row; every lane of the row gets it
 __device__ __forceinline__ double row16_sum(double v) {
@@ -156,8 +181,6 @@ __device__ __forceinline__ unsigned row16_max_u32(unsigned v) {
     v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, DPP_MIRROR, 0xF, 0xF, true));
     return v;
 }
-__device__ __forceinline__ unsigned f32_bits(float v) { return __float_as_uint(v); }
-__device__ __forceinline__ unsigned umax(unsigned a, unsigned b) { return a > b ? a : b; }
 __device__ __forceinline__ unsigned bcast_u32(unsigned v, int lane) { return (unsigned)__builtin_amdgcn_readlane((int)v, lane); }
 __device__ __forceinline__ unsigned uniform_u32(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 
@@ -174,41 +197,29 @@ __device__ __forceinline__ double colsum(double v) {
 // maximum over the NP columns (lanes with equal h); every lane gets it
 template <int NP>
 __device__ __forceinline__ double colmax(double v) {
-    v = fmax(v, dpp_f64<DPP_XOR1>(v));
-    v = fmax(v, dpp_f64<DPP_XOR2>(v));
-    v = fmax(v, dpp_f64<DPP_HALF_MIRROR>(v));
-    v = fmax(v, dpp_f64<DPP_MIRROR>(v));
+    v = max_raw(v, dpp_f64<DPP_XOR1>(v));
+    v = max_raw(v, dpp_f64<DPP_XOR2>(v));
+    v = max_raw(v, dpp_f64<DPP_HALF_MIRROR>(v));
+    v = max_raw(v, dpp_f64<DPP_MIRROR>(v));
     double a, b;
     swap16_pair(v, a, b);
-    v = fmax(a, b);
-    if (NP == 64) { swap32_pair(v, a, b); v = fmax(a, b); }
+    v = max_raw(a, b);
+    if (NP == 64) { swap32_pair(v, a, b); v = max_raw(a, b); }
     return v;
 }
+// (inputs >= 0 or -0: non-negative floats order like unsigned integers, and v_max_u32 takes its DPP operand directly)
 template <int NP>
 __device__ __forceinline__ float colmax_f32(float v) {
-    auto dppf = [](float x, auto ctrl) {
-        return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), decltype(ctrl)::value, 0xF, 0xF, false));
-    };
-    v = fmaxf(v, dppf(v, std::integral_constant<int, DPP_XOR1>{}));
-    v = fmaxf(v, dppf(v, std::integral_constant<int, DPP_XOR2>{}));
-    v = fmaxf(v, dppf(v, std::integral_constant<int, DPP_HALF_MIRROR>{}));
-    v = fmaxf(v, dppf(v, std::integral_constant<int, DPP_MIRROR>{}));
+    unsigned u = __float_as_uint(v) & 0x7fffffffu;
+    u = umax(u, (unsigned)__builtin_amdgcn_mov_dpp((int)u, DPP_XOR1, 0xF, 0xF, true));
+    u = umax(u, (unsigned)__builtin_amdgcn_mov_dpp((int)u, DPP_XOR2, 0xF, 0xF, true));
+    u = umax(u, (unsigned)__builtin_amdgcn_mov_dpp((int)u, DPP_HALF_MIRROR, 0xF, 0xF, true));
+    u = umax(u, (unsigned)__builtin_amdgcn_mov_dpp((int)u, DPP_MIRROR, 0xF, 0xF, true));
     int a, b;
-    swap16_pair_i(__float_as_int(v), a, b);
-    v = fmaxf(__int_as_float(a), __int_as_float(b));
-    if (NP == 64) { swap32_pair_i(__float_as_int(v), a, b); v = fmaxf(__int_as_float(a), __int_as_float(b)); }
-    return v;
-}
-// maximum over the 16 lanes of each DPP row (lanes 16 q .. 16 q + 15); every lane of the row gets its row's maximum
-__device__ __forceinline__ float row16_max_f32(float v) {
-    auto dppf = [](float x, auto ctrl) {
-        return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), decltype(ctrl)::value, 0xF, 0xF, false));
-    };
-    v = fmaxf(v, dppf(v, std::integral_constant<int, DPP_XOR1>{}));
-    v = fmaxf(v, dppf(v, std::integral_constant<int, DPP_XOR2>{}));
-    v = fmaxf(v, dppf(v, std::integral_constant<int, DPP_HALF_MIRROR>{}));
-    v = fmaxf(v, dppf(v, std::integral_constant<int, DPP_MIRROR>{}));
-    return v;
+    swap16_pair_i((int)u, a, b);
+    u = umax((unsigned)a, (unsigned)b);
+    if (NP == 64) { swap32_pair_i((int)u, a, b); u = umax((unsigned)a, (unsigned)b); }
+    return __uint_as_float(u);
 }
 __device__ __forceinline__ int first_lane_equal_f32(float v, float m) {
     const unsigned long long mask = wave_ballot(v == m);
@@ -255,14 +266,14 @@ __device__ __forceinline__ double from_half(double v, int hsel) {
 // (tools/ubench_latency.hip); the selected pair is the same.
 template <int NP>
 __device__ __forceinline__ double colmin(double v) {
-    v = fmin(v, dpp_f64<DPP_XOR1>(v));
-    v = fmin(v, dpp_f64<DPP_XOR2>(v));
-    v = fmin(v, dpp_f64<DPP_HALF_MIRROR>(v));
-    v = fmin(v, dpp_f64<DPP_MIRROR>(v));
+    v = min_raw(v, dpp_f64<DPP_XOR1>(v));
+    v = min_raw(v, dpp_f64<DPP_XOR2>(v));
+    v = min_raw(v, dpp_f64<DPP_HALF_MIRROR>(v));
+    v = min_raw(v, dpp_f64<DPP_MIRROR>(v));
     double a, b;
     swap16_pair(v, a, b);
-    v = fmin(a, b);
-    if (NP == 64) { swap32_pair(v, a, b); v = fmin(a, b); }
+    v = min_raw(a, b);
+    if (NP == 64) { swap32_pair(v, a, b); v = min_raw(a, b); }
     return v;
 }
 template <int NP>

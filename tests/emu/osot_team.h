@@ -20,6 +20,7 @@ inline int emu_lane() { return emu::S().cur; }
 inline void wave_sync() { int z = 0, out[64]; emu::allgather(&z, out, sizeof(int)); }
 inline void sched_fence() {}
 inline void workgroup_fence() {}
+inline void wave_priority_by_rank(unsigned, unsigned) {}
 inline int launder_i(int v) { return v; }
 inline int launder_s(int v) { return v; }
 inline int uniform_i(int v) { int out[64]; emu::allgather(&v, out, sizeof(int)); return out[0]; }
@@ -97,13 +98,6 @@ template <int NP> inline float colmax_f32(float v) {
     const int h0 = (emu_lane() / NP) * NP;
     float m = all[h0];
     for (int i = 1; i < NP; ++i) m = std::fmax(m, all[h0 + i]);
-    return m;
-}
-inline float row16_max_f32(float v) {
-    float all[64]; emu::allgather(&v, all, sizeof(float));
-    const int r0 = emu_lane() & ~15;
-    float m = all[r0];
-    for (int i = 1; i < 16; ++i) m = std::fmax(m, all[r0 + i]);
     return m;
 }
 inline int first_lane_equal_f32(float v, float m) {

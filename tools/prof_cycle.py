@@ -25,3 +25,22 @@ ss = np.sort(s)
 print("start times (us): first 2048 waves by %.1f; wave #2049 at %.1f; median of the second half %.1f; last start %.1f" % (ss[min(2047, B - 1)], ss[min(2048, B - 1)], np.median(ss[B // 2:]), ss[-1]))
 i = np.argmax(e)
 print("last wave to end: started %.1f ran %.1f us (%d iterations); the longest wave: started %.1f ran %.1f us" % (s[i], dur[i], int(st.iterations[i]), s[np.argmax(dur)], dur.max()))
+
+
+def list_schedule(order, d, slots):
+    """finish time of list scheduling: jobs taken in `order`, each onto the slot that frees first"""
+    import heapq
+    free = [0.0] * slots
+    heapq.heapify(free)
+    end = 0.0
+    for j in order:
+        t = heapq.heappop(free) + d[j]
+        end = max(end, t)
+        heapq.heappush(free, t)
+    return end
+
+
+slots = st.resident_waves()
+print("packing: sum(dur)/slots %.1f us, longest %.1f us; list schedule in the order the waves started %.1f us, longest-first with the TRUE durations %.1f us, by iteration count %.1f us"
+      % (dur.sum() / slots, dur.max(), list_schedule(np.argsort(s, kind="stable"), dur, slots), list_schedule(np.argsort(-dur, kind="stable"), dur, slots),
+         list_schedule(np.argsort(-st.iterations[:B].cpu().numpy(), kind="stable"), dur, slots)))
