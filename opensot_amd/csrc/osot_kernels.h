@@ -729,12 +729,18 @@ __device__ __forceinline__ void update_body(const DevUpdate* args_global, const 
         struct alignas(16) v2f64 { double a, b; };     // one 16-byte load / LDS store per piece
         constexpr int NA = (int)sizeof(DevUpdate) / 16, NP_ = (int)sizeof(DevUpdatePlan) / 16;
         const v2f64* ga = reinterpret_cast<const v2f64*>(args_global);
+        const v2f64* gp = reinterpret_cast<const v2f64*>(args_global->plan);   // (a scalar kernarg load: both copies are in flight together)
         v2f64* la = reinterpret_cast<v2f64*>(Ul);
-        for (int e = t; e < NA; e += 64) la[e] = ga[e];
-        wave_sync();
-        const v2f64* gp = reinterpret_cast<const v2f64*>(Ul->plan);
         v2f64* lp = reinterpret_cast<v2f64*>(Pl);
-        for (int e = t; e < NP_; e += 64) lp[e] = gp[e];
+        v2f64 va[(NA + 63) / 64], vp[(NP_ + 63) / 64];
+#pragma unroll
+        for (int i = 0; i < (NA + 63) / 64; ++i) { const int e = t + 64 * i; va[i] = ga[e < NA ? e : 0]; }
+#pragma unroll
+        for (int i = 0; i < (NP_ + 63) / 64; ++i) { const int e = t + 64 * i; vp[i] = gp[e < NP_ ? e : 0]; }
+#pragma unroll
+        for (int i = 0; i < (NA + 63) / 64; ++i) { const int e = t + 64 * i; if (e < NA) la[e] = va[i]; }
+#pragma unroll
+        for (int i = 0; i < (NP_ + 63) / 64; ++i) { const int e = t + 64 * i; if (e < NP_) lp[e] = vp[i]; }
         wave_sync();
     }
     const DevUpdate& U = *Ul;

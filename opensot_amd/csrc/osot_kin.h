@@ -75,20 +75,31 @@ __device__ inline void closest_segment_points(const double* p1, const double* q1
 }
 
 // PAIRS: the instantiation with the self-collision stage (step 5); the other one keeps the leaner register / LDS budget
-template <bool PAIRS>
+// JMAX = 32: TWO instances per wavefront (lanes 0..31 and 32..63 each run a robot of <= 32 joints: every instruction, every
+// 64-lane store carries two instances);  JMAX = 64: one instance per wavefront.  LDS per wavefront 16.5 KB either way.
+template <bool PAIRS, int JMAX>
 __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__ K, const osot_kin_batch Bt) {
     constexpr int TS = 12;
-    OSOT_STATIC_LDS(double, Tb, 2 * 64 * TS);   // two transform buffers [R | p] per joint (ping-pong of the pointer jumping:
-    double* Tl = Tb;                            //  ONE array indexed by an offset, so that every access stays a DS op --
+    constexpr int PACK = 64 / JMAX;
+    OSOT_STATIC_LDS(double, Tb_all, PACK * 2 * JMAX * TS);   // two transform buffers [R | p] per joint (ping-pong of the pointer
+    //                                              jumping: ONE array indexed by an offset, so that every access stays a DS op --
     //                                              swapping two pointers made the compiler fall back to flat loads)
-    OSOT_STATIC_LDS(double, Zw, 64 * 3);     // world joint axes
-    OSOT_STATIC_LDS(double, Cw, 64 * 4);     // world link centres of mass, mass
-    OSOT_STATIC_LDS(int, Par, 64);           // parent indices (the chain walk must not chase pointers through HBM)
-    OSOT_STATIC_LDS(unsigned long long, Anc, 64);   // ancestor masks
-    const int j = threadIdx.x;
-    const long long inst = blockIdx.x;
+    OSOT_STATIC_LDS(double, Zw_all, PACK * JMAX * 3);     // world joint axes
+    OSOT_STATIC_LDS(double, Cw_all, PACK * JMAX * 4);     // world link centres of mass, mass
+    OSOT_STATIC_LDS(int, Par_all, PACK * JMAX);           // parent indices (the chain walk must not chase pointers through HBM)
+    OSOT_STATIC_LDS(unsigned long long, Anc_all, PACK * JMAX);   // ancestor masks
+    const int sub = (PACK == 2) ? (int)(threadIdx.x >> 5) : 0;
+    const int j = (PACK == 2) ? (int)(threadIdx.x & 31u) : (int)threadIdx.x;
+    double* Tb = Tb_all + sub * (2 * JMAX * TS);
+    double* Tl = Tb;
+    double* Zw = Zw_all + sub * (JMAX * 3);
+    double* Cw = Cw_all + sub * (JMAX * 4);
+    int* Par = Par_all + sub * JMAX;
+    unsigned long long* Anc = Anc_all + sub * JMAX;
+    const long long inst = (long long)blockIdx.x * PACK + sub;
+    const bool live = inst < Bt.B;            // (an odd batch leaves the last wavefront's second half idle)
     const int n = K->d.n;
-    const bool valid = j < n;
+    const bool valid = j < n && live;
     Par[j] = valid ? K->d.parent[j] : -1;
     Anc[j] = valid ? K->anc[j] : 0ull;
     // ---- 1. local transforms
@@ -131,7 +142,7 @@ __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__
     for (int i = 0; i < 3; ++i) pw[i] = valid ? Tl[j * TS + 9 + i] : 0.0;
     {
         int jp = Par[j];
-        int cur = 0, nxt = 64 * TS;
+        int cur = 0, nxt = JMAX * TS;
         while (wave_ballot(jp >= 0) != 0ull) {
             int njp = jp;
             if (jp >= 0) {
@@ -159,7 +170,7 @@ __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__
             const int t = cur; cur = nxt; nxt = t;
         }
     }
-    double* Tw = Tb + 64 * TS;   // final world transforms (written below, after the last round's barrier)
+    double* Tw = Tb + JMAX * TS;   // final world transforms (written below, after the last round's barrier)
     if (valid) {
         double z[3], cl[3];
         mat3_vec(Rw, K->d.axis[j], z);
@@ -188,7 +199,7 @@ __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__
 #pragma unroll
             for (int i = 0; i < 3; ++i) pf[i] = pj[i] + t[i];
         }
-        if (Bt.frame_pose[f] && j < 12) {   // lane j stores element j of [R | p] (a select chain: a lane-indexed
+        if (Bt.frame_pose[f] && j < 12 && live) {   // lane j stores element j of [R | p] (a select chain: a lane-indexed
             double v = Rf[0];                //  read of Rf would put the arrays in scratch memory)
 #pragma unroll
             for (int i = 1; i < 9; ++i) v = (j == i) ? Rf[i] : v;
@@ -231,8 +242,8 @@ __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__
             const double mj = valid ? Cw[j * 4 + 3] : 0.0;
             double c3[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) c3[i] = colsum<64>(valid ? mj * Cw[j * 4 + i] : 0.0) / M;
-            if (j < 3) Bt.com[inst * 3 + j] = c3[j];
+            for (int i = 0; i < 3; ++i) c3[i] = colsum<JMAX>(valid ? mj * Cw[j * 4 + i] : 0.0) / M;
+            if (j < 3 && live) Bt.com[inst * 3 + j] = c3[(j == 0) ? 0 : ((j == 1) ? 1 : 2)];
         }
         if (Bt.com_J) {
             // subtree aggregates S_j = sum over the links l that joint j moves of m_l [c_l, 1]: a 0/1 matrix-vector
@@ -265,8 +276,9 @@ __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__
     if constexpr (PAIRS) {
     const int np = K->d.n_pairs;
     if (np > 0 && (Bt.pair_dist || Bt.pair_J)) {
-        OSOT_STATIC_LDS(double, Pw, OSOT_KIN_MAX_PAIRS * 9);   // per pair: normal n, axis points c_a, c_b (world)
-        if (j < np) {
+        OSOT_STATIC_LDS(double, Pw_all, PACK * OSOT_KIN_MAX_PAIRS * 9);   // per pair: normal n, axis points c_a, c_b (world)
+        double* Pw = Pw_all + sub * (OSOT_KIN_MAX_PAIRS * 9);
+        if (j < np && live) {
             double e[2][6];
 #pragma unroll
             for (int sd = 0; sd < 2; ++sd) {

@@ -720,10 +720,17 @@ int osot_kinematics(osot_kin* k, const osot_kin_batch* b, void* hip_stream) {
     if (!b->q) return fail(OSOT_ERR_INVALID, "q is null");
     DeviceGuard guard(k->device);
     if (!guard.ok) return fail(OSOT_ERR_HIP, "hipSetDevice failed");
-    if (k->n_pairs > 0 && (b->pair_dist || b->pair_J))
-        hipLaunchKernelGGL(osot_kin_kernel<true>, dim3((unsigned)b->B), dim3(64), 0, (hipStream_t)hip_stream, (const DevKin*)k->dev, *b);
-    else
-        hipLaunchKernelGGL(osot_kin_kernel<false>, dim3((unsigned)b->B), dim3(64), 0, (hipStream_t)hip_stream, (const DevKin*)k->dev, *b);
+    const bool pairs = k->n_pairs > 0 && (b->pair_dist || b->pair_J);
+    const dim3 grid((unsigned)(k->n <= 32 ? (b->B + 1) / 2 : b->B)), block(64);   // <= 32 joints: two instances per wavefront
+    hipStream_t st = (hipStream_t)hip_stream;
+    const DevKin* dk = (const DevKin*)k->dev;
+    if (k->n <= 32) {
+        if (pairs) hipLaunchKernelGGL((osot_kin_kernel<true, 32>), grid, block, 0, st, dk, *b);
+        else hipLaunchKernelGGL((osot_kin_kernel<false, 32>), grid, block, 0, st, dk, *b);
+    } else {
+        if (pairs) hipLaunchKernelGGL((osot_kin_kernel<true, 64>), grid, block, 0, st, dk, *b);
+        else hipLaunchKernelGGL((osot_kin_kernel<false, 64>), grid, block, 0, st, dk, *b);
+    }
     HIP_TRY(hipGetLastError());
     return OSOT_OK;
 }

@@ -140,7 +140,13 @@ extern "C" __attribute__((visibility("default"))) int emu_kinematics(const osot_
         h.total_mass += d->mass[j];
     }
     if (!(h.total_mass > 0.0)) h.total_mass = 1.0;
-    if (d->n_pairs > 0 && (b->pair_dist || b->pair_J)) emu::launch(osot_kin_kernel<true>, (unsigned)b->B, 0, 64, (const DevKin*)&h, *b);
-    else emu::launch(osot_kin_kernel<false>, (unsigned)b->B, 0, 64, (const DevKin*)&h, *b);
+    const bool pairs = d->n_pairs > 0 && (b->pair_dist || b->pair_J);
+    if (d->n <= 32) {
+        if (pairs) emu::launch(osot_kin_kernel<true, 32>, (unsigned)((b->B + 1) / 2), 0, 64, (const DevKin*)&h, *b);
+        else emu::launch(osot_kin_kernel<false, 32>, (unsigned)((b->B + 1) / 2), 0, 64, (const DevKin*)&h, *b);
+    } else {
+        if (pairs) emu::launch(osot_kin_kernel<true, 64>, (unsigned)b->B, 0, 64, (const DevKin*)&h, *b);
+        else emu::launch(osot_kin_kernel<false, 64>, (unsigned)b->B, 0, 64, (const DevKin*)&h, *b);
+    }
     return OSOT_OK;
 }

@@ -44,3 +44,6 @@ slots = st.resident_waves()
 print("packing: sum(dur)/slots %.1f us, longest %.1f us; list schedule in the order the waves started %.1f us, longest-first with the TRUE durations %.1f us, by iteration count %.1f us"
       % (dur.sum() / slots, dur.max(), list_schedule(np.argsort(s, kind="stable"), dur, slots), list_schedule(np.argsort(-dur, kind="stable"), dur, slots),
          list_schedule(np.argsort(-st.iterations[:B].cpu().numpy(), kind="stable"), dur, slots)))
+first = s < 5.0
+print("update half by round: first %d waves mean %.0f cycles, later ones mean %.0f; cascade half: %.0f / %.0f"
+      % (first.sum(), c[first, 0].mean(), c[~first, 0].mean(), c[first, 1].mean(), c[~first, 1].mean()))
