@@ -1313,25 +1313,30 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
             // the diagonal are formed lane-parallel up front and the columns of R are fetched four steps
             // ahead, so that a step of the serial chain is readlane -> mul -> fma only.
             double rr = 0.0;
+            double rmax = 0.0;   // max |r_j| (uniform): picked up on the way, every r_j passes through a broadcast
             {
-                double d1 = (c < iq) ? d : 0.0;
+                // the residual is carried SCALED by the reciprocal diagonal, e_c = d1_c / R_cc, and so are the column entries
+                // (off the chain: the columns are fetched four steps ahead): a step of the serial chain is then
+                // readlane -> fma only (the unscaled form had a multiplication by 1 / R_jj in front of every broadcast)
                 const bool mine = (c >= me && c < iq);
                 const double rinv = mine ? fast_rcp(M1[ridx<NP>(c, c)]) : 0.0;
+                double e = mine ? d * rinv : 0.0;
                 const int rrow = mine ? c : 0;                                  // in-range row for idle lanes
                 for (int j0 = iq - 1; j0 >= me; j0 -= 4) {
                     double rc[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {     // R[c][j] is only used for c < j: rows above the diagonal exist in every column
                         const int jj = (j0 - t >= 0) ? j0 - t : 0;
-                        rc[t] = M1[ridx<NP>((rrow <= jj) ? rrow : 0, jj)];
+                        rc[t] = M1[ridx<NP>((rrow <= jj) ? rrow : 0, jj)] * rinv;
                     }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int j = j0 - t;
                         if (j >= me) {
-                            const double rj = bcast(d1 * rinv, j);   // lane j scales its own entry: one broadcast
+                            const double rj = bcast(e, j);
+                            rmax = fmax(rmax, fabs(rj));
                             if (c == j) rr = rj;
-                            if (c >= me && c < j) d1 = fma(-rc[t], rj, d1);
+                            if (mine && c < j) e = fma(-rc[t], rj, e);
                         }
                     }
                 }
@@ -1340,8 +1345,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
             // one (kRatioTol): r = R^-1 d1 carries ~1e-16 cond(R) of noise, and a noise-level "positive" entry that happens to
             // be the only one gives a dual step of u / r ~ 1e8 that wrecks every multiplier (seen in the closed-loop sweep at
             // the default eps; qpOASES guards its ratio tests the same way, epsNum / epsDen in Constants.hpp)
-            const float rmax = colmax_f32<NP>((c >= me && c < iq) ? (float)fabs(rr) : 0.0f);
-            double t1 = (c >= me && c < iq && rr > kRatioTol * (double)rmax) ? fast_div(fmax(uq, 0.0), rr) : INFINITY;
+            double t1 = (c >= me && c < iq && rr > kRatioTol * rmax) ? fast_div(fmax(uq, 0.0), rr) : INFINITY;
             int lpos = c;
             colargmin<NP>(t1, lpos);
             lpos = uniform_i(lpos);

@@ -288,10 +288,16 @@ __device__ __forceinline__ int colmin_i(int v) {
     if (NP == 64) { swap32_pair_i(v, a, b); v = min(a, b); }
     return v;
 }
+// NP = 32: BOTH HALVES MUST HOLD THE SAME CANDIDATES (they do wherever the solver reduces over 32 columns: vectors are
+// replicated over the halves).  One lane holds the minimum (the usual case): its payload is a v_readlane away; several do
+// (exact ties): the second network picks the smallest payload among them -- the same pair either way.
 template <int NP>
 __device__ __forceinline__ void colargmin(double& v, int& p) {
     const double m = colmin<NP>(v);
-    p = colmin_i<NP>((v == m) ? p : 0x7fffffff);
+    unsigned long long tie = wave_ballot(v == m);
+    if (NP == 32) tie &= 0xffffffffull;
+    if (__builtin_popcountll(tie) == 1) p = __builtin_amdgcn_readlane(p, __builtin_ctzll(tie));
+    else p = colmin_i<NP>((v == m) ? p : 0x7fffffff);
     v = m;
 }
 
