@@ -60,6 +60,30 @@ def algo_bytes_per_solve(plan):
     return 8 * d
 
 
+def leaf_bytes_per_instance(dev_leaf):
+    """bytes of leaf inputs one instance's AutoStack::update reads (poses, q, references, limits ...)"""
+    tot = 0
+
+    def walk(o):
+        nonlocal tot
+        if o is None:
+            return
+        if torch.is_tensor(o):
+            tot += o.element_size() * o[0].numel() if o.dim() > 0 and o.shape[0] > 0 else 0
+        elif isinstance(o, (list, tuple)):
+            for x in o:
+                walk(x)
+
+    for key in ("task", "W", "bound", "rows", "reg"):
+        walk(dev_leaf.get(key))
+    return tot
+
+
+def assembled_bytes_per_solve(plan):
+    """bytes of the assembled arrays the update half writes: b and diag(W) of every level, the merged box"""
+    return 8 * (sum(2 * plan.m(k) for k in range(plan.L)) + (2 * plan.n if plan.bounds else 0) + 2 * plan.nc)
+
+
 def kernel_source_sha():
     """identifies the cascade kernel a PMC traffic figure belongs to (profiles/*.json carry the same hash)"""
     h = hashlib.sha256()
@@ -410,10 +434,20 @@ def main():
         if launches > 0 and kern_ms > 0:
             traffic, src = pmc_traffic(args.config, Bl)
             rf, rh = roofline_of(plan, Bl, kern_ms, launches,
-                                 "osot_cascade_kernel<32,false> (fp64 MFMA H build + blocked Cholesky, VALU/LDS active set)",
+                                 "osot_cycle_kernel<32,false> (AutoStack::update + the whole cascade of an instance by one wavefront: "
+                                 "fp64 MFMA H build + blocked Cholesky + null-space elimination, VALU/LDS active set)",
                                  traffic, (src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 per "
                                            "MI355X_MICROARCH.md; same kernel source hash)") if traffic else
                                  "no PMC passes committed for this kernel source: null rather than a stale figure")
+            # the fused kernel's algorithmic bytes: the cascade's compulsory bytes + the leaf inputs the update
+            # half reads + the assembled arrays it writes (they are outputs in their own right; the cascade half reads them
+            # back from the CU's L1 / L2, which costs no HBM traffic)
+            lb, ab = leaf_bytes_per_instance(dev_leaves[0]), assembled_bytes_per_solve(plan)
+            rh["algorithmic_bytes_per_solve_cascade_only"] = rh["algorithmic_bytes_per_solve"]
+            rh["algorithmic_bytes_per_solve"] = rh["algorithmic_bytes_per_solve"] + lb + ab
+            rh["leaf_input_bytes_per_solve"], rh["assembled_output_bytes_per_solve"] = lb, ab
+            rh["achieved"] = rh["algorithmic_bytes_per_solve"] * Bl / (rf["avg_launch_ms"] * 1e-3) / 1e9
+            rh["frac"] = rh["achieved"] / rh["peak"]
             out["roofline"], out["roofline_hbm"] = rf, rh
         if world == 1 and not args.no_other_configs:
             oc = {}
