@@ -370,7 +370,8 @@ def main():
         A_sets.append(st.A)
     # the gather of the solved shards runs on the solve stream (measured: 9 us per step with a world of one; the
     # double-buffered side-stream variant cost 22 us of host-side event traffic and was dropped)
-    gather = ShardGather(Bg, plan.n, st.device, torch.float64) if use_dist else None
+    ov = os.environ.get("OSOT_GATHER_OVERLAP")      # (developer switch: 0 = collective on the solve stream's critical path)
+    gather = ShardGather(Bg, plan.n, st.device, torch.float64, overlap=None if ov is None else ov == "1") if use_dist else None
     cyc = ShardedCycle(st, dev_leaves, A_sets, Bl, gather)
     sync = torch.cuda.synchronize
 

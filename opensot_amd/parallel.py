@@ -20,61 +20,88 @@ def shard_range(total, rank, world):
 
 class ShardGather:
     """all-gather of the per-rank result shards into global instance order: dq [total][n] fp64 and status [total] int32
-    (`ncclAllGather(dq_shard) (+ status)`).  Shards may be uneven (total % world != 0): every rank contributes a
-    block padded to the largest shard, ONE `all_gather_into_tensor` per array moves them, and `dq` / `status` return
-    views (even shards) or compacted copies (uneven).  Buffers are allocated once; call = enqueue on the current stream."""
+    (`ncclAllGather(dq_shard) (+ status)`) in ONE collective per step: a rank's block is a flat fp64 buffer, its
+    dq rows first and its int32 status words behind them (viewed as int32: the collective moves bytes) -- a small collective
+    over xGMI is latency-bound, two of them cost twice.  `bind(stack)` makes the solver write its dq and status STRAIGHT
+    into that block (the stack's output tensors become views of it), so a step is solve + one collective with no copy
+    kernel in between; shards handed in from other tensors are copied.  Shards may be uneven (total % world != 0): every
+    rank's block is sized for the largest shard; `dq` / `status` return the rows in global instance order.
 
-    def __init__(self, total, n, device, dtype, group=None):
+    `overlap` (default off): issue the collective with async_op so that it runs on the process group's stream while the rank
+    solves the next step (two blocks, alternating; with `bind` the caller re-binds every step, `ShardedCycle` does).
+    Measured with a world of one on an MI355X it is slower than the in-stream form (0.210 against 0.194 ms per step: the
+    extra enqueue work costs more than the 1 MB copy it hides), so it stays an option for worlds where the collective
+    itself is long."""
+
+    def __init__(self, total, n, device, dtype, group=None, overlap=False):
         import torch
         import torch.distributed as dist
+        self.torch = torch
         self.dist, self.group = dist, group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.total, self.n = total, n
         self.sizes = [shard_range(total, r, self.world)[1] - shard_range(total, r, self.world)[0] for r in range(self.world)]
         self.mx = max(self.sizes) if self.sizes else 0
         self.even = all(s == self.mx for s in self.sizes)
-        self.recv_dq = torch.empty((self.world * self.mx, n), dtype=dtype, device=device)
-        self.recv_status = torch.empty((self.world * self.mx,), dtype=torch.int32, device=device)
-        self.pad_dq = None if self.even else torch.zeros((self.mx, n), dtype=dtype, device=device)
-        self.pad_status = None if self.even else torch.zeros((self.mx,), dtype=torch.int32, device=device)
+        self.overlap = bool(overlap) and torch.device(device).type == "cuda"
+        nb = 2 if self.overlap else 1
+        self.ndq = self.mx * n                       # doubles of dq in a block
+        self.blk = self.ndq + (self.mx + 1) // 2     # + the status words, two per double
+        self.send_b = [torch.zeros((self.blk,), dtype=dtype, device=device) for _ in range(nb)]
+        self.recv_b = [torch.empty((self.world * self.blk,), dtype=dtype, device=device) for _ in range(nb)]
+        self.work = [None] * nb
+        self.i = 0
+        self.last = 0
         self.has_status = False
 
-    def _gather(self, recv, send):
+    def _views(self, block):
+        return block[:self.ndq].view(self.mx, self.n), block[self.ndq:].view(self.torch.int32)[:self.mx]
+
+    def bind(self, stack):
+        """the stack's dq / status outputs become views of the NEXT step's send block"""
+        stack.dq, stack.status = self._views(self.send_b[self.i % len(self.send_b)])
+
+    def _gather(self, recv, send, async_op=False):
         if hasattr(self.dist, "all_gather_into_tensor"):
-            self.dist.all_gather_into_tensor(recv, send, group=self.group)
-        else:   # (older torch: the list form on views of the same receive buffer)
-            self.dist.all_gather(list(recv.chunk(self.world)), send, group=self.group)
+            return self.dist.all_gather_into_tensor(recv, send, group=self.group, async_op=async_op)
+        # (older torch: the list form on views of the same receive buffer)
+        return self.dist.all_gather(list(recv.chunk(self.world)), send, group=self.group, async_op=async_op)
+
+    def _wait(self, b):
+        if self.work[b] is not None:
+            self.work[b].wait()   # (stream-level for RCCL: the current stream waits, the host does not)
+            self.work[b] = None
 
     def __call__(self, dq_shard, status_shard=None):
         mine = self.sizes[self.rank]
-        if self.even:
-            send = dq_shard[:mine]
-        else:
-            self.pad_dq[:mine].copy_(dq_shard[:mine])
-            send = self.pad_dq
-        self._gather(self.recv_dq, send)
+        b = self.i % len(self.recv_b)
+        self.i += 1
+        self.last = b
         self.has_status = status_shard is not None
-        if self.has_status:
-            if self.even:
-                sst = status_shard[:mine]
-            else:
-                self.pad_status[:mine].copy_(status_shard[:mine])
-                sst = self.pad_status
-            self._gather(self.recv_status, sst)
+        self._wait(b)             # (overlap: the gather that last used this pair of blocks is over)
+        sdq, sst = self._views(self.send_b[b])
+        if dq_shard.data_ptr() != sdq.data_ptr():
+            sdq[:mine].copy_(dq_shard[:mine])
+        if self.has_status and status_shard.data_ptr() != sst.data_ptr():
+            sst[:mine].copy_(status_shard[:mine])
+        w = self._gather(self.recv_b[b], self.send_b[b], async_op=self.overlap)
+        if self.overlap:
+            self.work[b] = w
 
-    def _compact(self, buf):
-        import torch
-        if self.even:
-            return buf
-        return torch.cat([buf[r * self.mx: r * self.mx + self.sizes[r]] for r in range(self.world)], dim=0)
+    def _collect(self, which):
+        self._wait(self.last)
+        buf = self.recv_b[self.last]
+        parts = [self._views(buf[r * self.blk:(r + 1) * self.blk])[which][:self.sizes[r]] for r in range(self.world)]
+        return parts[0] if self.world == 1 else self.torch.cat(parts, dim=0)
 
     @property
     def dq(self):
-        return self._compact(self.recv_dq)
+        """the gathered dq of the LAST call, [total][n]"""
+        return self._collect(0)
 
     @property
     def status(self):
-        return self._compact(self.recv_status) if self.has_status else None
+        return self._collect(1) if self.has_status else None
 
 
 class ShardedCycle:
@@ -83,9 +110,10 @@ class ShardedCycle:
     the gather of the solved shards.  The steps rotate through K temporally coherent cycles, each with its own leaf
     inputs and stacked Jacobians (nothing is copied inside a step: the stack just points at the cycle's buffers)."""
 
-    def __init__(self, stack, dev_leaves, A_sets, B_local, gather=None):
+    def __init__(self, stack, dev_leaves, A_sets, B_local, gather=None, bind=True):
         self.stack, self.dev_leaves, self.A_sets, self.B = stack, dev_leaves, A_sets, B_local
         self.gather = gather
+        self.bind = bind and gather is not None and hasattr(stack, "cycle")   # (a real BatchedStack: outputs are re-pointable)
         self.i = 0
 
     def step(self):
@@ -93,6 +121,8 @@ class ShardedCycle:
         self.i += 1
         if self.A_sets is not None:
             self.stack.A = self.A_sets[k]
+        if self.gather is not None and self.bind:
+            self.gather.bind(self.stack)     # the solver writes dq / status straight into the collective's send block
         if hasattr(self.stack, "cycle"):     # update + solve in one launch (BatchedStack.cycle), same results
             self.stack.cycle(self.dev_leaves[k])
         else:

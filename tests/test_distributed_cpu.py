@@ -1,6 +1,7 @@
-"""N>1 path on CPU: world_size-2 gloo processes run THE SAME objects bench.py runs with RCCL -- `ShardGather` (one
-all_gather_into_tensor per array, dq and status, padded for uneven shards) and `ShardedCycle` + `timed_steps` (the per-rank
-step loop and its barrier bracket) -- with the solve stubbed at the BatchedStack boundary."""
+"""N>1 path on CPU: world_size-2 gloo processes run THE SAME objects bench.py runs with RCCL -- `ShardGather` (ONE
+all_gather_into_tensor per step: dq rows and status words in one block, sized for the largest shard; the solver's outputs
+bound straight into that block as bench.py does, or copied in) and `ShardedCycle` + `timed_steps` (the per-rank step loop
+and its barrier bracket) -- with the solve stubbed at the BatchedStack boundary."""
 import os
 import socket
 
@@ -50,32 +51,45 @@ class _StubStack:
         self.calls.append("solve")
 
 
-def _worker(rank, world, port, total, n, q):
+class _StubFusedStack(_StubStack):
+    """a stack with BatchedStack.cycle(): ShardedCycle then BINDS its dq / status to the collective's send block before
+    every step (the zero-copy route bench.py takes): whatever tensors `dq` / `status` point at when cycle() runs get written"""
+
+    def cycle(self, dev_leaf):
+        self.update(dev_leaf)
+        self.solve(self.dq.shape[0] if self.B is None else self.B)
+
+    B = None
+
+
+def _worker(rank, world, port, total, n, q, fused=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = shard_range(total, rank, world)
-    stack = _StubStack(lo, hi, n)
+    stack = _StubFusedStack(lo, hi, n) if fused else _StubStack(lo, hi, n)
+    if fused:
+        stack.B = hi - lo                       # (the bound views hold the LARGEST shard's rows: solve only this rank's)
     gather = ShardGather(total, n, torch.device("cpu"), torch.float64)
     K = 3
     cyc = ShardedCycle(stack, [{"bias": 100.0 * k} for k in range(K)], [1000.0 * k for k in range(K)], hi - lo, gather)
     steps, warmup = 4, 2
     elapsed = timed_steps(cyc.step, steps, warmup, sync=lambda: None, dist=dist, device=torch.device("cpu"))
     last = (steps + warmup - 1) % K           # the cycle the last step ran
-    one_shot = all_gather_dq(stack.dq, total)  # the convenience form must agree with the resident buffers
+    one_shot = all_gather_dq(stack.dq[:hi - lo], total)  # the convenience form must agree with the resident buffers
     q.put((rank, gather.dq.numpy().copy(), gather.status.numpy().copy(), one_shot.numpy().copy(), last, elapsed,
            stack.calls == ["update", "solve"] * (steps + warmup)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total", [8, 7, 1])
-def test_two_rank_step_loop_and_gather(total):
+@pytest.mark.parametrize("total,fused", [(8, False), (7, False), (1, False), (8, True), (7, True)])
+def test_two_rank_step_loop_and_gather(total, fused):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     n = 5
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, n, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, n, q, fused)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in range(2)]
