@@ -176,11 +176,15 @@ def test_roundoff_violation_with_no_freedom_left(oracle):
         assert np.abs(dq[ok] - rq["dq"][ok]).max() < 1e-6
 
 
-def test_optimality_rows_duplicating_global_equalities(oracle):
+@pytest.mark.parametrize("n,rows", [(16, [4, 5]), (18, [2])])
+def test_optimality_rows_duplicating_global_equalities(n, rows, oracle):
     """coman_ik.cpp:442 situation: the stack's global equality rows re-appear as optimality rows of a task level
     (more equality rows than could be independent).  Consistent duplicates are skipped; the answer equals the
-    reference's (qpOASES drops them through its linear-independence test, QProblem.cpp:2847)"""
-    plan, leaf = synth.make_generic_stack(6, 16, [4, 5], n_eq=6, seed=3, duplicate_eq_in_level=0)
+    reference's (qpOASES drops them through its linear-independence test, QProblem.cpp:2847).
+    (18, [2]): 14 equality rows of rank 8 at the Postural level: the null-space elimination starts (18 - 14 <= 8), finds ten
+    free columns, more than it carries, and hands the level back to the generic path -- with J' restored in the LDS matrix
+    it used as its column store."""
+    plan, leaf = synth.make_generic_stack(6, n, rows, n_eq=6, seed=3, duplicate_eq_in_level=0)
     asm = oracle.assemble(plan, leaf)
     dq, xl, st, it = emu_cascade(plan, asm)
     assert (st == 0).all()
@@ -191,7 +195,7 @@ def test_optimality_rows_duplicating_global_equalities(oracle):
         assert (rq["status"] == 1).all() and np.abs(dq - rq["dq"]).max() < 1e-6
     Ceq = asm["C"][:, :6]; e = asm["lo"][:, :6]
     assert np.abs(np.einsum("brn,bn->br", Ceq, dq) - e).max() < 1e-10
-    for k in (1, 2):   # hierarchy: A_j x_k = A_j x_j
+    for k in range(1, plan.L):   # hierarchy: A_j x_k = A_j x_j
         for j in range(k):
             assert np.abs(np.einsum("brn,bn->br", asm["A"][j], xl[:, k] - xl[:, j])).max() < 1e-9
 

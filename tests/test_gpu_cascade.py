@@ -54,10 +54,11 @@ def test_update_kernel_matches_oracle_assembly(oracle, gpu_device):
 
 
 @pytest.mark.parametrize("n,rows,n_eq,n_ineq,dup", [(7, [6], 0, 0, None), (7, [3, 3], 1, 2, None), (20, [5, 6], 4, 6, None),
-                                                     (16, [4, 5], 6, 0, 0)])
+                                                     (16, [4, 5], 6, 0, 0), (18, [2], 6, 0, 0)])
 def test_small_generic_cascades_gpu(n, rows, n_eq, n_ineq, dup, oracle, gpu_device):
     """n < 32 (guarded factor instantiation), Panda-like 7-variable stacks, and a stack whose optimality rows
-    duplicate its global equality rows (coman_ik.cpp:442); vs the oracle, and vs qpOASES when oracle/_ref is there"""
+    duplicate its global equality rows (coman_ik.cpp:442; (18, [2]): with so many dependent rows that the null-space
+    elimination of the Postural level hands over to the generic path); vs the oracle, and vs qpOASES when oracle/_ref is there"""
     plan, leaf = synth.make_generic_stack(64, n, rows, n_eq=n_eq, n_ineq=n_ineq, seed=n, duplicate_eq_in_level=dup)
     asm = oracle.assemble(plan, leaf)
     dq, xl, status, it, _ = _run(plan, leaf)
