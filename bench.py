@@ -287,6 +287,28 @@ def time_nhqp(B, device, steps=5, warmup=2):
             "batch": B, "value": B * steps / el, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "solved_ok": f"{ok}/{B}"}
 
 
+def time_ehqp(B, device, steps=10, warmup=3):
+    """the equality-only front-end (OpenSoT::solvers::eHQP, SURVEY 8f-2) on the C3 stack: update + osot_ehqp_solve"""
+    from opensot_amd import synth
+    from opensot_amd.solver import BatchedStack
+    plan, leaf = synth.make_velocity_stack("C3", B, seed=3000)
+    st = BatchedStack(plan, B, device=device, want_levels=False)
+    dev = st.load_leaf(leaf)
+    for _ in range(warmup):
+        st.update(dev); st.solve_ehqp(B)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st.update(dev); st.solve_ehqp(B)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ok = int((st.status[:B] == 0).sum().item())
+    return {"workload": "BASELINE configs[2] stack through the reference's equality-only front-end (eHQP.cpp:64-95: damped pseudo-"
+                        "inverses and projectors, the box is not used): per level an eigen-decomposition of P A'W A P (parallel Jacobi "
+                        "in LDS); all levels of an instance in one launch",
+            "batch": B, "value": B * steps / el, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "solved_ok": f"{ok}/{B}"}
+
+
 def time_kinematics(B, device, steps=20, warmup=5):
     from opensot_amd import kinematics as kin
     m = kin.humanoid32()
@@ -461,6 +483,10 @@ def main():
                 oc["nHQP_C3"] = time_nhqp(4096, local_rank)
             except Exception as e:
                 oc["nHQP_C3"] = {"error": str(e)}
+            try:
+                oc["eHQP_C3"] = time_ehqp(4096, local_rank)
+            except Exception as e:
+                oc["eHQP_C3"] = {"error": str(e)}
             try:
                 oc["kinematics"] = time_kinematics(4096, local_rank)
             except Exception as e:

@@ -358,6 +358,15 @@ typedef struct {
 } osot_nhqp_options;
 int osot_nhqp_solve(osot_solver* s, const osot_qp_batch* batch, const osot_nhqp_options* options, void* hip_stream);
 
+/* ---- the equality-only front-end: OpenSoT::solvers::eHQP (src/solvers/eHQP.cpp:64-95, 124-146) -----------
+ * Same stack, same assembled arrays (A_k, b_k, w_k or WA_k / Wb_k) as osot_ihqp_solve; the constraints and bounds of the
+ * stack are NOT used (the reference's eHQP does not use them either: eHQP.cpp:45-47) and there is no active set: per level
+ * JP = L'A P (W = L L'), x += JP^+ (L'b - L'A x) with the reference's damped pseudo-inverse, P <- P - V V' (thin right
+ * singular vectors).  One launch for all levels.  sigma_min <= 0 = the reference's default 1e-12 (eHQP.cpp:56).
+ * n <= 32; no regularisation task (the reference's eHQP has none); status is OSOT_STATUS_SOLVED for every instance
+ * (eHQP::solve returns true). */
+int osot_ehqp_solve(osot_solver* s, const osot_qp_batch* batch, double sigma_min, void* hip_stream);
+
 /* ---- batch-of-one BackEnd surface (host pointers; mirrors BackEnd.h) ------------------------ */
 typedef struct osot_backend osot_backend;
 /* create_instance(number_of_variables, number_of_constraints, hessian_type, eps_regularisation)

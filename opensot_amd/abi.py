@@ -123,7 +123,7 @@ SYMBOLS = [
     "osot_version", "osot_last_error", "osot_device_count",
     "osot_plan_validate", "osot_plan_level_rows", "osot_plan_constraint_rows",
     "osot_plan_stored_constraint_rows",
-    "osot_solver_create", "osot_solver_destroy", "osot_stack_update", "osot_ihqp_solve", "osot_cycle", "osot_nhqp_solve",
+    "osot_solver_create", "osot_solver_destroy", "osot_stack_update", "osot_ihqp_solve", "osot_cycle", "osot_nhqp_solve", "osot_ehqp_solve",
     "osot_solver_kernel_time_ms", "osot_solver_set_timing", "osot_solver_set_schedule", "osot_solver_set_task_active", "osot_solver_resident_waves",
     "osot_id_rows", "osot_computed_torque", "osot_kin_create", "osot_kin_destroy", "osot_kinematics", "osot_solver_profile_phases",
     "osot_backend_create", "osot_backend_destroy", "osot_backend_init_problem",
@@ -171,6 +171,7 @@ def lib():
     L.osot_stack_update.argtypes = [vp, C.POINTER(LeafBatch), C.POINTER(AssembledOut), vp]
     L.osot_ihqp_solve.argtypes = [vp, C.POINTER(QpBatch), vp]
     L.osot_nhqp_solve.argtypes = [vp, C.POINTER(QpBatch), C.POINTER(NhqpOptions), vp]
+    L.osot_ehqp_solve.argtypes = [vp, C.POINTER(QpBatch), C.c_double, vp]
     L.osot_cycle.argtypes = [vp, C.POINTER(LeafBatch), C.POINTER(AssembledOut), C.POINTER(QpBatch), vp]
     L.osot_solver_kernel_time_ms.argtypes = [vp, C.c_int, dp, ip]
     L.osot_solver_set_timing.argtypes = [vp, C.c_int]

@@ -15,6 +15,7 @@
 
 #include "osot_host_plan.h"
 #include "osot_kin.h"
+#include "osot_ehqp.h"
 #include "osot_id.h"
 #include "osot_nhqp_host.h"
 #include "osot_admm.h"
@@ -207,6 +208,23 @@ int osot_solver_set_task_active(osot_solver* s, int level, int task, int active)
 int osot_solver_set_timing(osot_solver* s, int enabled) {
     if (!s) return fail(OSOT_ERR_INVALID, "null solver");
     s->timing = enabled != 0;
+    return OSOT_OK;
+}
+
+int osot_ehqp_solve(osot_solver* s, const osot_qp_batch* b, double sigma_min, void* hip_stream) {
+    if (!s || !b) return fail(OSOT_ERR_INVALID, "null solver/batch");
+    if (b->B < 0 || b->B > s->max_batch) return fail(OSOT_ERR_INVALID, "batch size exceeds max_batch");
+    if (b->B == 0) return OSOT_OK;
+    if (!b->dq || !b->status) return fail(OSOT_ERR_INVALID, "dq/status output is null");
+    const osot_plan_desc& pl = s->plan;
+    DevEhqp Q;
+    const char* why = "";
+    int rc = ehqp_args(pl, b, sigma_min, s->any_inactive, Q, &why);
+    if (rc != OSOT_OK) return fail(rc, why);
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return fail(OSOT_ERR_HIP, "hipSetDevice failed");
+    hipLaunchKernelGGL(osot_ehqp_kernel, dim3((unsigned)b->B), dim3(64), 0, (hipStream_t)hip_stream, Q);
+    HIP_TRY(hipGetLastError());
     return OSOT_OK;
 }
 

@@ -207,6 +207,13 @@ class BatchedStack:
         qb = self._qp_batch(B)
         abi.check(self._lib.osot_nhqp_solve(self._h, C.byref(qb), C.byref(opt), _stream_ptr(self.device)), "osot_nhqp_solve")
 
+    def solve_ehqp(self, B, sigma_min=0.0):
+        """Solver::solve() with the reference's EQUALITY-ONLY front-end, OpenSoT::solvers::eHQP (eHQP.cpp:64-95): damped
+        pseudo-inverses and projectors on the same assembled arrays; the stack's constraints and bounds are not used (as in
+        the reference).  sigma_min 0 = the reference's 1e-12.  Stream-ordered, results in self.dq[:B] / self.status[:B]"""
+        qb = self._qp_batch(B)
+        abi.check(self._lib.osot_ehqp_solve(self._h, C.byref(qb), float(sigma_min), _stream_ptr(self.device)), "osot_ehqp_solve")
+
     PHASES = ("hbuild", "chol", "inverse", "subst", "equalities", "inequalities", "opt_rhs", "total",
               "eq:J'a", "eq:reductions", "eq:z", "eq:householder",
               "in:scan", "in:d=J'n", "in:z", "in:r,steps", "in:householder", "in:drop")

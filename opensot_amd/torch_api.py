@@ -137,3 +137,28 @@ class nHQP(iHQP):
             B = self.stack.max_batch if B is None else B
         self.stack.solve_nhqp(B, **self._opts)
         return self.stack.dq[:B]
+
+
+class eHQP(iHQP):
+    """pyopensot.eHQP (bindings/python/solver.hpp:56-61: eHQP(stack), getSigmaMin, setSigmaMin): the equality-only front-end,
+    damped pseudo-inverses and projectors (src/solvers/eHQP.cpp); the stack's constraints and bounds are not used"""
+
+    def __init__(self, plan, max_batch, device=0):
+        super().__init__(plan, max_batch, device=device)
+        self._sigma_min = 1e-12          # eHQP.cpp:56
+
+    def getSigmaMin(self):
+        return self._sigma_min
+
+    def setSigmaMin(self, sigma_min):
+        if sigma_min > 0:                # eHQP.cpp:156-166: non-positive values are ignored
+            self._sigma_min = float(sigma_min)
+
+    def solve(self, dev_leaf=None, B=None):
+        if dev_leaf is not None:
+            B = self.stack.update(dev_leaf)
+        else:
+            B = self.stack.max_batch if B is None else B
+        self.stack.solve_ehqp(B, self._sigma_min)
+        return self.stack.dq[:B]
+

@@ -8,6 +8,7 @@
 #include "osot_id.h"
 #include "osot_nhqp_host.h"
 #include "osot_admm.h"
+#include "osot_ehqp.h"
 #include <vector>
 
 using namespace osot;
@@ -86,6 +87,18 @@ extern "C" __attribute__((visibility("default"))) int emu_nhqp_solve(const osot_
         [&](const DevNhqpAcc& A) { emu::launch(osot_nhqp_accumulate_kernel, grid, 0, 64, A); }, &why);
     if (rc != OSOT_OK) fprintf(stderr, "emu: %s\n", why);
     return rc;
+}
+
+// the equality-only front-end (osot_ehqp.h) on host pointers
+extern "C" __attribute__((visibility("default"))) int emu_ehqp_solve(const osot_plan_desc* plan, const osot_qp_batch* b, double sigma_min) {
+    const char* why = "";
+    int rc = plan_validate(plan, &why);
+    if (rc != OSOT_OK) { fprintf(stderr, "emu: %s\n", why); return rc; }
+    DevEhqp Q;
+    rc = ehqp_args(*plan, b, sigma_min, false, Q, &why);
+    if (rc != OSOT_OK) { fprintf(stderr, "emu: %s\n", why); return rc; }
+    emu::launch(osot_ehqp_kernel, (unsigned)b->B, 0, 64, Q);
+    return OSOT_OK;
 }
 
 // AutoStack::update (osot_update_kernel) on host pointers

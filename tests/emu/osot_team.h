@@ -93,6 +93,13 @@ template <int NP> inline double colmax(double v) {
     for (int i = 1; i < NP; ++i) m = std::fmax(m, all[h0 + i]);
     return m;
 }
+template <int NP> inline double colmin(double v) {
+    double all[64]; emu::allgather(&v, all, sizeof(double));
+    const int h0 = (emu_lane() / NP) * NP;
+    double m = all[h0];
+    for (int i = 1; i < NP; ++i) m = std::fmin(m, all[h0 + i]);
+    return m;
+}
 template <int NP> inline float colmax_f32(float v) {
     float all[64]; emu::allgather(&v, all, sizeof(float));
     const int h0 = (emu_lane() / NP) * NP;

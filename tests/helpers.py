@@ -371,6 +371,36 @@ def emu_nhqp(plan, asm, free_vars=None, min_sv_ratio=0.0, ab_regularization=True
     return dq, st
 
 
+def emu_ehqp(plan, asm, sigma_min=0.0, level_active=None):
+    """the equality-only front-end (osot_ehqp.h) on host pointers through the emulator -> dq, status, x_levels"""
+    B, n, L = asm["B"], asm["n"], asm["L"]
+    qb = abi.QpBatch()
+    qb.B = B
+    keep = []
+    for k in range(L):
+        for name in ("A", "b", "w"):
+            a = asm[name][k]
+            if a is not None:
+                a = np.ascontiguousarray(a, dtype=np.float64); keep.append(a)
+                getattr(qb, name)[k] = a.ctypes.data
+        for name, key in (("WA", "WA"), ("Wb", "Wb")):
+            arr = asm.get(key)
+            if arr is not None and arr[k] is not None:
+                a = np.ascontiguousarray(arr[k], dtype=np.float64); keep.append(a)
+                getattr(qb, name)[k] = a.ctypes.data
+    dq = np.zeros((B, n)); st = np.full(B, -1, dtype=np.int32); xl = np.zeros((B, L, n))
+    qb.dq, qb.status, qb.x_levels = dq.ctypes.data, st.ctypes.data, xl.ctypes.data
+    if level_active is not None:
+        la = np.ascontiguousarray(level_active, dtype=np.uint8); keep.append(la)
+        qb.level_active = la.ctypes.data
+    L_ = emu_lib()
+    L_.emu_ehqp_solve.argtypes = [C.POINTER(abi.PlanDesc), C.POINTER(abi.QpBatch), C.c_double]
+    pd = plan.to_c()
+    rc = L_.emu_ehqp_solve(C.byref(pd), C.byref(qb), float(sigma_min))
+    assert rc == 0
+    return dq, st, xl
+
+
 def emu_qp_admm(H, g, A, lA, uA, l, u, eps_reg=0.0, max_iter=0):
     """B generic QPs through the emulated OSQP-convention ADMM kernel (osot_admm.h); arrays are [B][...]"""
     H = np.ascontiguousarray(H, dtype=np.float64)

@@ -1,0 +1,170 @@
+"""The equality-only front-end (OpenSoT::solvers::eHQP, src/solvers/eHQP.cpp): oracle/pyehqp.py (numpy SVD) against the iHQP
+path where the two front-ends must agree (parity of the restatement is otherwise UNPINNED: the reference has no robot-free
+eHQP vector), the emulated kernel (opensot_amd/csrc/osot_ehqp.h) against the restatement, and the HIP kernel through the
+C-ABI on the GPU."""
+import numpy as np
+import pytest
+
+from helpers import emu_ehqp
+from opensot_amd import synth
+from opensot_amd.plan import StackPlan
+from oracle import pyehqp
+
+
+def _unconstrained(plan):
+    """the same stack without its constraints and bounds (what eHQP looks at)"""
+    return StackPlan(n=plan.n, levels=plan.levels, bounds=[], rowblocks=[], eps_abs=plan.eps_abs)
+
+
+def _generic(B, n, rows, seed, postural=True):
+    plan, leaf = synth.make_generic_stack(B, n, rows, n_eq=0, n_ineq=0, seed=seed, box=0.0, postural_last=postural, eps_factor=2e2)
+    return plan, leaf
+
+
+def test_damped_pinv_weights_follow_the_reference():
+    """getDampedPinv (eHQP.cpp:124-146): plain inverse above sigma_min, Tikhonov with lambda = min(sigma) below, rank by
+    Eigen's relative threshold"""
+    s = np.array([2.0, 1.0, 0.5])
+    np.testing.assert_allclose(pyehqp.damped_pinv_weights(s, 1e-12), 1.0 / s)
+    s = np.array([2.0, 1.0, 1e-14])                      # min below sigma_min -> damped, and the last one is out of the rank
+    w = pyehqp.damped_pinv_weights(s, 1e-12)
+    lam = 1e-14
+    np.testing.assert_allclose(w[:2], s[:2] / (s[:2] ** 2 + lam ** 2))
+    assert w[2] == 0.0
+    s = np.array([1.0, 0.3])                             # a large sigma_min switches the damping on for a healthy matrix
+    w = pyehqp.damped_pinv_weights(s, 0.5)
+    np.testing.assert_allclose(w[0], 1.0 / (1.0 + 0.09))
+    assert w[1] == 0.0                                   # 0.3 < 0.5 * 1.0: below the rank threshold
+
+
+@pytest.mark.parametrize("n,rows,seed", [(7, [3, 2], 1), (12, [4, 5], 2), (32, [3, 24], 3), (20, [6], 4)])
+def test_restatement_agrees_with_ihqp_where_both_pose_the_same_problem(n, rows, seed, oracle):
+    """no constraints, full-row-rank task levels and a Postural last level: the lexicographic least-squares solution is
+    unique, the damped pseudo-inverse chain (eHQP) and the eps-regularised QP cascade (iHQP) must both return it"""
+    plan, leaf = _generic(6, n, rows, seed)
+    asm = oracle.assemble(plan, leaf)
+    e = pyehqp.ehqp_solve(asm)
+    r = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+    assert (r["status"] == 1).all()
+    assert np.abs(e["dq"] - r["dq"]).max() < 1e-6
+    # (the intermediate x_k differ in the directions the level leaves free: minimum norm here, eps-damped there; what both
+    #  define is the level's task value)
+    for k in range(plan.L - 1):
+        Ak = asm["A"][k]
+        assert np.abs(np.einsum("brn,bn->br", Ak, e["x_levels"][:, k] - r["x_levels"][:, k])).max() < 1e-6
+
+
+@pytest.mark.parametrize("n,rows,seed", [(7, [3, 2], 1), (12, [4, 5], 2), (32, [3, 24], 3), (20, [6], 4), (9, [2, 2, 2], 5)])
+def test_emulated_kernel_vs_restatement(n, rows, seed, oracle):
+    plan, leaf = _generic(5, n, rows, seed)
+    asm = oracle.assemble(plan, leaf)
+    e = pyehqp.ehqp_solve(asm)
+    dq, st, xl = emu_ehqp(plan, asm)
+    assert (st == 0).all()
+    assert np.abs(dq - e["dq"]).max() < 1e-9
+    assert np.abs(xl - e["x_levels"]).max() < 1e-9
+
+
+def test_stack_without_a_full_rank_last_level(oracle):
+    """task levels only (4 + 5 rows in 16 variables): the minimum-norm choice among the solutions of the last level --
+    x stays in the row spaces -- and the hierarchy A_j x_k = A_j x_j"""
+    plan, leaf = _generic(5, 16, [4, 5], 7, postural=False)
+    asm = oracle.assemble(plan, leaf)
+    e = pyehqp.ehqp_solve(asm)
+    dq, st, xl = emu_ehqp(plan, asm)
+    assert np.abs(dq - e["dq"]).max() < 1e-9
+    A0, A1 = asm["A"][0], asm["A"][1]
+    assert np.abs(np.einsum("brn,bn->br", A0, dq) - asm["b"][0]).max() < 1e-9          # level 0 met exactly
+    assert np.abs(np.einsum("brn,bn->br", A0, xl[:, 1] - xl[:, 0])).max() < 1e-9       # and kept by level 1
+    assert np.abs(np.einsum("brn,bn->br", A1, dq) - asm["b"][1]).max() < 1e-9          # 9 rows in 16 variables: level 1 too
+
+
+def test_constraints_and_bounds_are_ignored_like_in_the_reference(oracle):
+    """eHQP.cpp:45-47: '# OF CONSTRAINTS: 0', '# OF BOUNDS: 0' -- a box that binds for iHQP changes nothing here"""
+    plan, leaf = synth.make_generic_stack(4, 10, [3, 3], n_eq=0, n_ineq=2, seed=11, box=0.01, eps_factor=2e2)
+    asm = oracle.assemble(plan, leaf)
+    dq, st, xl = emu_ehqp(plan, asm)
+    free = pyehqp.ehqp_solve(oracle.assemble(*_strip(plan, leaf)))
+    assert np.abs(dq - free["dq"]).max() < 1e-9
+    assert np.abs(dq).max() > 0.01                        # (outside the box the stack carries)
+
+
+def _strip(plan, leaf):
+    p2 = _unconstrained(plan)
+    l2 = dict(leaf); l2["bound"] = []; l2["rows"] = []
+    l2.pop("C", None)
+    return p2, l2
+
+
+def test_inactive_level_is_skipped(oracle):
+    plan, leaf = _generic(4, 12, [4, 5], 2)
+    asm = oracle.assemble(plan, leaf)
+    act = [1, 0, 1]
+    e = pyehqp.ehqp_solve(asm, level_active=act)
+    dq, st, xl = emu_ehqp(plan, asm, level_active=act)
+    assert np.abs(dq - e["dq"]).max() < 1e-9
+
+
+def test_weights_and_dense_weights(oracle):
+    """W = L L' enters as L'A, L'b in the reference; the kernel takes W A and W b (the update kernel's outputs)"""
+    plan, leaf = synth.make_feature_stack(4, seed=3, body_frame=False, dense=True, bands=False, candidates=0, many_blocks=False)
+    asm = oracle.assemble(plan, leaf)
+    assert any(w is not None for w in asm["Wdense"])
+    asm["WA"] = [None if W is None else W @ asm["A"][k] for k, W in enumerate(asm["Wdense"])]
+    asm["Wb"] = [None if W is None else np.einsum("brq,bq->br", W, asm["b"][k]) for k, W in enumerate(asm["Wdense"])]
+    e = pyehqp.ehqp_solve(asm)
+    dq, st, xl = emu_ehqp(plan, asm)
+    assert np.abs(dq - e["dq"]).max() < 1e-8
+
+
+def test_overdetermined_level_is_weighted_least_squares(oracle):
+    """8 rows in 6 variables: the level cannot be met, x = argmin |A x - b|_W (where the weights matter)"""
+    plan, leaf = _generic(5, 6, [8], 9, postural=False)
+    rng = np.random.default_rng(0)
+    asm = oracle.assemble(plan, leaf)
+    asm["w"][0] = rng.uniform(0.2, 3.0, size=asm["w"][0].shape)
+    e = pyehqp.ehqp_solve(asm)
+    dq, st, xl = emu_ehqp(plan, asm)
+    assert np.abs(dq - e["dq"]).max() < 1e-9
+    for i in range(5):
+        sw = np.sqrt(asm["w"][0][i])
+        want = np.linalg.lstsq(sw[:, None] * asm["A"][0][i], sw * asm["b"][0][i], rcond=None)[0]
+        assert np.abs(dq[i] - want).max() < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,rows,seed", [(7, [3, 2], 1), (32, [3, 24], 3)])
+def test_ehqp_gpu_vs_restatement(n, rows, seed, oracle, gpu_device):
+    import torch
+    from opensot_amd.solver import BatchedStack
+    B = 64
+    plan, leaf = _generic(B, n, rows, seed)
+    asm = oracle.assemble(plan, leaf)
+    st = BatchedStack(plan, B, device=0)
+    st.load_assembled(asm)
+    st.solve_ehqp(B)
+    torch.cuda.synchronize()
+    e = pyehqp.ehqp_solve(asm)
+    assert (st.status[:B].cpu().numpy() == 0).all()
+    assert np.abs(st.dq[:B].cpu().numpy() - e["dq"]).max() < 1e-9
+    assert np.abs(st.x_levels[:B].cpu().numpy() - e["x_levels"]).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_ehqp_gpu_benchmark_stack_and_torch_api(oracle, gpu_device):
+    """BASELINE config 3 through update + eHQP on the device (torch_api.eHQP mirrors pyopensot.eHQP); against the
+    restatement on the assembled arrays, and against iHQP without the box"""
+    import torch
+    from opensot_amd import torch_api
+    B = 128
+    plan, leaf = synth.make_velocity_stack("C3", B, seed=5)
+    sol = torch_api.eHQP(plan, B)
+    dev = sol.stack.load_leaf(leaf)
+    dq = sol.solve(dev)
+    torch.cuda.synchronize()
+    asm = oracle.assemble(plan, leaf)
+    e = pyehqp.ehqp_solve(asm)
+    assert np.abs(dq.cpu().numpy() - e["dq"]).max() < 1e-8
+    assert sol.getSigmaMin() == 1e-12
+    sol.setSigmaMin(-1.0)
+    assert sol.getSigmaMin() == 1e-12
