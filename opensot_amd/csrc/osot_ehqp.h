@@ -13,8 +13,8 @@
 // cascade builds, and  JP^+ (L'b - L'A x) = V D V' P A'W (b - A x) = V D V' (g' - H x)  with g' = A'W b and
 // D = diag(1 / sigma^2) (or 1 / (sigma^2 + lambda^2)) -- so neither the Cholesky factor of W nor the left singular vectors
 // are ever formed: a dense weight enters through W A and W b (the update kernel's outputs), a diagonal one through w.
-// The symmetric eigenproblem of K = P H P (n x n) is solved by the parallel two-sided Jacobi of the nHQP front-end
-// (jacobi_eig32): eigenvalues = sigma^2, eigenvectors = V.
+// The symmetric eigenproblem of K = P H P (n x n) is solved by the nHQP front-end's routine (sym_eig32: Householder
+// tridiagonalisation + implicit QL): eigenvalues = sigma^2, eigenvectors = V.
 // Resolution: squaring costs the singular values below ~1e-8 sigma_max; they are treated as zero (floor 1e-7 sigma_max,
 // kEhqpFloor), which is what the reference's threshold makes of the exactly-zero ones (a projected Jacobian has at most
 // rank(P) non-zero singular values: the trailing ones are zeroed by COUNT as well, rem below) -- a level that is nearly
@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(64) osot_ehqp_kernel(const DevEhqp Q) {
         for (int t = 0; t < 16; ++t) K[(2 * t + h) * kNS + c] = acc[t];
         wave_sync();
         // ---- eigen-decomposition: diag(K) = sigma^2, E = V ----------------------------------------------------------
-        jacobi_eig32(K, E, n, c, h);
+        sym_eig32(K, E, n, c, h);
         wave_sync();
         const double lam = valid ? fmax(K[c * kNS + c], 0.0) : 0.0;
         if (h == 0) Vv[c] = valid ? lam : -1.0;

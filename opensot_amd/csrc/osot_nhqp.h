@@ -10,9 +10,8 @@
 //
 // One wavefront per instance, lane = c + 32 h like the QP core; n <= 32, m <= 64 rows per level.
 // The SVD: AN is m x nf with k = min(m, nf) <= 32.  The SYMMETRIC eigenproblem of the SMALL Gram matrix (AN AN' when
-// m <= nf, AN'AN otherwise) is solved by parallel two-sided Jacobi in LDS -- step s pairs column c with column c ^ s
-// (s = 1 .. kp-1, kp = the power of two above k: every pair exactly once per sweep, sixteen disjoint rotations at a
-// time, each lane updating its own column / row) -- and the other factor follows from one product with AN.  Squaring
+// m <= nf, AN'AN otherwise) is solved in LDS by Householder tridiagonalisation + implicit QL (sym_eig32 below) and the other
+// factor follows from one product with AN.  Squaring
 // costs accuracy only in singular values below ~1e-8 sv_max, which the reference's own regularisation overwrites
 // (anything below min_sv_ratio * sv_max = 0.05 sv_max is lifted, nHQP.cpp:262-266).  A level's null-space basis V2 need
 // not be the SVD's: every orthonormal basis gives the same q (the QP is posed in its coordinates and both
@@ -46,59 +45,149 @@ constexpr int kNS = 33;              // LDS row stride of the 32-column work mat
 // sum over the 32 lanes of a half AND over the two halves; every lane gets it
 __device__ __forceinline__ double sum64(double v) { return halfsum<32>(colsum<32>(v)); }
 
-// Parallel two-sided Jacobi: K (k x k symmetric, LDS [32][33], zero beyond k) -> diag(lambda), E = eigenvectors (columns)
-__device__ inline void jacobi_eig32(double* K, double* E, int k, int c, int h) {
-    int kp = 1;
-    while (kp < k) kp <<= 1;
-    for (int e = c + 32 * h; e < 32 * kNS; e += 64) E[e] = 0.0;
-    wave_sync();
-    if (h == 0) E[c * kNS + c] = 1.0;
-    wave_sync();
-    for (int sweep = 0; sweep < 14; ++sweep) {
-        // convergence: off-diagonal mass against the diagonal's
-        double off = 0.0, dg = 0.0;
-        for (int t = 0; t < 16; ++t) {
-            const int i = 2 * t + h;
-            const double v = K[i * kNS + c];
-            if (i == c) dg += v * v; else off += v * v;
+// Symmetric eigenproblem of K (k x k, LDS [32][33], zero beyond k) -> K[c][c] = eigenvalue c, E[:, c] = its eigenvector.
+// Householder tridiagonalisation with accumulation of the transformations, then the implicit QL iteration with shifts
+// (the classic EISPACK pair tred2 / tql2).  Why not Jacobi: the parallel two-sided Jacobi this replaces moved ~60 k LDS
+// words per lane for a 24 x 24 matrix (14 sweeps x 31 steps, column AND row phase through LDS) and the kernel was bound by
+// the CU's LDS bandwidth (4.1 ms per level for 4096 instances); this form moves ~7 k: the reduction keeps rows in their
+// own lanes (lane j = row j, the inner index split over the two halves), and the QL sweep is a scalar recurrence on (d, e)
+// -- held one entry per lane, read with v_readlane -- whose plane rotations touch two entries of every lane's OWN row of
+// the eigenvector matrix.
+__device__ inline void sym_eig32(double* K, double* E, int k, int c, int h) {
+    constexpr double kEps = 2.220446049250313e-16;
+    double d = 0.0, e = 0.0;                 // lane j: d[j], e[j]
+    const bool wr = (h == 0);
+    // ---- reduction to tridiagonal form (tred2): for i = k-1 .. 1 the row i is reflected onto e_{i-1}
+    for (int i = k - 1; i >= 1; --i) {
+        const int l = i - 1;
+        double hv = 0.0, e_i;
+        if (l > 0) {
+            double ai = (c <= l) ? K[i * kNS + c] : 0.0;
+            const double scale = colsum<32>(fabs(ai));
+            if (scale == 0.0) {
+                e_i = bcast(ai, l);
+            } else {
+                ai *= fast_rcp(scale);
+                hv = colsum<32>(ai * ai);
+                const double f0 = bcast(ai, l);
+                double sq, rs;
+                fast_sqrt_rsqrt(hv, sq, rs);
+                const double g0 = (f0 >= 0.0) ? -sq : sq;
+                e_i = scale * g0;
+                hv -= f0 * g0;
+                if (c == l) ai = f0 - g0;
+                const double ih = fast_rcp(hv);
+                wave_sync();
+                if (wr && c <= l) { K[i * kNS + c] = ai; K[c * kNS + i] = ai * ih; }    // row i <- u, column i <- u / H
+                wave_sync();
+                double pj = 0.0;             // p = A u / H (full symmetric rows are kept up to date)
+                if (c <= l)
+                    for (int kk = h; kk <= l; kk += 2) pj = fma(K[c * kNS + kk], K[i * kNS + kk], pj);
+                pj = halfsum<32>(pj) * ih;
+                const double f1 = colsum<32>((c <= l) ? pj * ai : 0.0);
+                const double hh2 = 0.5 * f1 * ih;
+                const double qj = (c <= l) ? pj - hh2 * ai : 0.0;      // q = p - (u'p / 2H) u
+                if (wr) E[c] = qj;           // (E is free until the end: its first row carries q)
+                wave_sync();
+                if (c <= l)                  // A <- A - u q' - q u'
+                    for (int kk = h; kk <= l; kk += 2) K[c * kNS + kk] -= fma(ai, E[kk], qj * K[i * kNS + kk]);
+                wave_sync();
+            }
+        } else {
+            e_i = K[i * kNS + l];
         }
-        off = sum64(off); dg = sum64(dg);
-        if (!(off > 1.0e-30 * dg) || kp < 2) break;
-        for (int s = 1; s < kp; ++s) {
-            const int o = c ^ s;                       // partner column (same for both halves)
-            const int p = c < o ? c : o, q = c < o ? o : c;
-            const double app = K[p * kNS + p], aqq = K[q * kNS + q], apq = K[p * kNS + q];
-            double cs = 1.0, sn = 0.0;
-            if (fabs(apq) > 1.0e-300 && fabs(apq) > 1.0e-17 * sqrt(fabs(app * aqq))) {
-                const double tau = (aqq - app) / (2.0 * apq);
-                const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                cs = 1.0 / sqrt(1.0 + t * t);
-                sn = t * cs;
+        if (c == i) { e = e_i; d = hv; }
+    }
+    // ---- accumulate the transformations: K becomes the orthogonal Q
+    for (int i = 0; i < k; ++i) {
+        const int l = i - 1;
+        if (bcast(d, i) != 0.0) {
+            double gj = 0.0;
+            if (c <= l)
+                for (int kk = h; kk <= l; kk += 2) gj = fma(K[i * kNS + kk], K[kk * kNS + c], gj);
+            gj = halfsum<32>(gj);
+            if (c <= l)
+                for (int kk = h; kk <= l; kk += 2) K[kk * kNS + c] -= gj * K[kk * kNS + i];
+            wave_sync();
+        }
+        if (c == i) d = K[i * kNS + i];
+        wave_sync();
+        if (wr) {
+            if (c == i) K[i * kNS + i] = 1.0;
+            else if (c <= l) { K[c * kNS + i] = 0.0; K[i * kNS + c] = 0.0; }
+        }
+        wave_sync();
+    }
+    // ---- implicit QL with shifts on (d, e); the rotations go into the columns of K (tql2)
+    {   // e[j] <- e[j + 1]  (the shuffle OUTSIDE the select: a ds_bpermute under a partial exec mask reads zeros from the
+        // lanes that are masked off, and lane k - 2 needs lane k - 1)
+        const double es = shift_down<32>(e);
+        e = (c + 1 < k) ? es : 0.0;
+    }
+    // (deflation test against the norm of the whole tridiagonal matrix, as in EISPACK's tql2 -- not against the two
+    //  neighbouring diagonal entries: the Gram matrices here are often rank deficient, and a cluster of round-off-level
+    //  eigenvalues never passes a purely local test)
+    const double anorm = colmax<32>((c < k) ? fabs(d) + fabs(e) : 0.0);
+    const double etol = kEps * anorm;
+    for (int l = 0; l < k; ++l) {
+        for (int iter = 0; iter < 60; ++iter) {
+            const bool small = (c >= l && c < k - 1) && (fabs(e) <= etol);
+            const unsigned long long mk = wave_ballot(small) & 0xffffffffull;
+            const int m = mk ? __builtin_ctzll(mk) : k - 1;
+            if (m == l) break;
+            const double dl = bcast(d, l), dl1 = bcast(d, l + 1), el = bcast(e, l), dm = bcast(d, m);
+            double g = (dl1 - dl) / (2.0 * el);
+            double r = sqrt(fma(g, g, 1.0));
+            g = dm - dl + el / (g + (g >= 0.0 ? r : -r));
+            double sn = 1.0, cs = 1.0, p = 0.0;
+            bool underflow = false;
+            double di1 = dm;                 // d[i + 1] of the step about to run (d[i] of a step is not written by it)
+            // my row of the eigenvector matrix: the entry of column i + 1 travels in a register from step to step (it is
+            // the one the previous step produced), the entry of column i is fetched one step ahead: the LDS round trip is
+            // off the recurrence's chain.  All 64 lanes run it (rows >= k are zero rows, the halves write the same values).
+            double zc = K[c * kNS + m];
+            double z0n = K[c * kNS + m - 1];
+            for (int i = m - 1; i >= l; --i) {
+                const double z0 = z0n;
+                if (i > l) z0n = K[c * kNS + i - 1];
+                const double ei = bcast(e, i), di = bcast(d, i);
+                const double f = sn * ei, b = cs * ei;
+                const double rr2 = fma(f, f, g * g);
+                double ir;
+                if (rr2 > 0.0) fast_sqrt_rsqrt(rr2, r, ir);          // r and 1 / r from one Goldschmidt chain
+                else { r = 0.0; ir = 0.0; }
+                if (c == i + 1) e = r;
+                if (r == 0.0) {
+                    if (c == i + 1) d -= p;
+                    if (c == m) e = 0.0;
+                    K[c * kNS + i + 1] = zc;
+                    underflow = true;
+                    break;
+                }
+                sn = f * ir; cs = g * ir;
+                g = di1 - p;
+                r = fma(di - g, sn, 2.0 * cs * b);
+                p = sn * r;
+                if (c == i + 1) d = g + p;
+                g = fma(cs, r, -b);
+                di1 = di;
+                K[c * kNS + i + 1] = fma(sn, z0, cs * zc);
+                zc = fma(cs, z0, -sn * zc);
             }
-            const bool low = c < o;                    // I am the pair's p column
-            // column phase on K and on E:  col_p <- cs col_p - sn col_q,  col_q <- sn col_p + cs col_q
-            double nk[16], ne[16];
-            for (int t = 0; t < 16; ++t) {
-                const int i = 2 * t + h;
-                const double own = K[i * kNS + c], oth = K[i * kNS + o];
-                nk[t] = low ? cs * own - sn * oth : sn * oth + cs * own;
-                const double eo = E[i * kNS + c], et = E[i * kNS + o];
-                ne[t] = low ? cs * eo - sn * et : sn * et + cs * eo;
-            }
-            wave_sync();
-            for (int t = 0; t < 16; ++t) { const int i = 2 * t + h; K[i * kNS + c] = nk[t]; E[i * kNS + c] = ne[t]; }
-            wave_sync();
-            // row phase on K:  row_p <- cs row_p - sn row_q,  row_q <- sn row_p + cs row_q
-            for (int t = 0; t < 16; ++t) {
-                const int j = 2 * t + h;
-                const double own = K[c * kNS + j], oth = K[o * kNS + j];
-                nk[t] = low ? cs * own - sn * oth : sn * oth + cs * own;
-            }
-            wave_sync();
-            for (int t = 0; t < 16; ++t) { const int j = 2 * t + h; K[c * kNS + j] = nk[t]; }
-            wave_sync();
+            if (underflow) continue;
+            K[c * kNS + l] = zc;
+            if (c == l) { d -= p; e = g; }
+            if (c == m) e = 0.0;
         }
     }
+    wave_sync();
+    // ---- results where the callers expect them: E = eigenvectors (columns), diag(K) = eigenvalues, K otherwise zero
+    for (int t = 0; t < 16; ++t) { const int i = 2 * t + h; E[i * kNS + c] = (i < k && c < k) ? K[i * kNS + c] : 0.0; }
+    wave_sync();
+    for (int t = 0; t < 16; ++t) { const int i = 2 * t + h; K[i * kNS + c] = 0.0; }
+    wave_sync();
+    if (wr && c < k) K[c * kNS + c] = d;
+    wave_sync();
 }
 
 __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) {
@@ -166,7 +255,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
         }
     }
     wave_sync();
-    jacobi_eig32(K, E, k, c, h);
+    sym_eig32(K, E, k, c, h);
     // ---- singular values, sorted descending: pos = number of eigenvalues ahead of mine
     {
         const double lam = (c < k) ? K[c * kNS + c] : -1.0;
