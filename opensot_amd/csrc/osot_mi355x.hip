@@ -264,7 +264,10 @@ int osot_nhqp_solve(osot_solver* s, const osot_qp_batch* b, const osot_nhqp_opti
     const unsigned grid = (unsigned)b->B;
     const char* why = "";
     int rc = nhqp_run(pl, b, opt, s->nhqp,
-        [&](const DevNhqp& Q) { hipLaunchKernelGGL(osot_nhqp_prepare_kernel, dim3(grid), dim3(64), 0, st, Q); },
+        [&](const DevNhqp& Q) {
+            if (Q.m <= 32) hipLaunchKernelGGL(osot_nhqp_prepare_kernel<32>, dim3(grid), dim3(64), 0, st, Q);
+            else hipLaunchKernelGGL(osot_nhqp_prepare_kernel<64>, dim3(grid), dim3(64), 0, st, Q);
+        },
         [&](int B, int n, int nc, const double* H, const double* g, const double* A, const double* lA, const double* uA,
             const double* l, const double* u, double eps, double* x, int* status, int* iters) {
             return osot_qp_solve_batch(B, n, nc, H, g, A, lA, uA, l, u, eps, 0, x, status, iters, hip_stream);

@@ -190,12 +190,17 @@ __device__ inline void sym_eig32(double* K, double* E, int k, int c, int h) {
     wave_sync();
 }
 
+// MR = row capacity of A N (32 or 64).  LDS: three 32 x 33 work matrices + A N = 25.3 KB (MR = 32: six wavefronts per CU;
+// the first version held five matrices and a 64-row A N, 50 KB, three per CU).  The buffers are re-used as the level goes:
+//   NE : N (until the constraints are written, right after A N)  ->  eigenvectors E  ->  V2 on the row side
+//   K  : Gram matrix -> its eigenvalues on the diagonal -> the reflectors of the complement / V2 on the column side
+template <int MR>
 __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) {
-    OSOT_STATIC_LDS(double, AN, 64 * kNS);     // A N (m x nf)
-    OSOT_STATIC_LDS(double, Nl, 32 * kNS);     // N (n x nf)
-    OSOT_STATIC_LDS(double, K, 32 * kNS);      // Gram matrix -> diag(lambda)
-    OSOT_STATIC_LDS(double, E, 32 * kNS);      // eigenvectors of K
-    OSOT_STATIC_LDS(double, V2, 32 * kNS);     // null-space basis (nf x ns) / scratch
+    OSOT_STATIC_LDS(double, AN, MR * kNS);     // A N (m x nf)
+    OSOT_STATIC_LDS(double, NE, 32 * kNS);     // N (n x nf), then E, then V2 (row side)
+    OSOT_STATIC_LDS(double, K, 32 * kNS);      // Gram matrix -> diag(lambda) -> V1 scratch / V2 (column side)
+    double* Nl = NE;
+    double* E = NE;
     OSOT_STATIC_LDS(double, b0, 64);
     OSOT_STATIC_LDS(double, vec, 64);          // staging vector
     OSOT_STATIC_LDS(double, sig, 32);          // singular values, sorted descending
@@ -208,8 +213,8 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
     const bool first = Q.level == 0;
     const double* A = Q.A ? Q.A + inst * (long long)ma * n : nullptr;
     // ---- N -> LDS (identity at the first level)
-    for (int e = lane; e < 32 * kNS; e += 64) { Nl[e] = 0.0; K[e] = 0.0; V2[e] = 0.0; }
-    for (int e = lane; e < 64 * kNS; e += 64) AN[e] = 0.0;
+    for (int e = lane; e < 32 * kNS; e += 64) { Nl[e] = 0.0; K[e] = 0.0; }
+    for (int e = lane; e < MR * kNS; e += 64) AN[e] = 0.0;
     wave_sync();
     if (first) { if (h == 0 && c < n) Nl[c * kNS + c] = 1.0; }
     else {
@@ -236,6 +241,34 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
         b0[lane] = v;
     }
     wave_sync();
+    // ---- constraints in z-coordinates (levels below the first): rows [C N; N], bounds shifted by q0
+    if (!first) {
+        const int nr = Q.nc + (Q.has_box ? n : 0);
+        double* Rg = Q.R + inst * (long long)nr * nf;
+        if (lane < 64) vec[lane] = (lane < n) ? Q.q0[inst * n + lane] : 0.0;
+        wave_sync();
+        for (int r = 0; r < Q.nc; ++r) {
+            const double* Cr = Q.C + (inst * (long long)Q.nc + r) * n;
+            double acc = 0.0, cq = 0.0;
+            for (int i = h; i < n; i += 2) { const double ci = Cr[i]; acc = fma(ci, Nl[i * kNS + c], acc); cq = fma(ci, vec[i], cq); }
+            acc = halfsum<32>(acc); cq = halfsum<32>(cq);
+            if (h == 0 && c < nf) Rg[r * nf + c] = acc;
+            if (lane == 0) {
+                const double lo = Q.lo[inst * Q.nc + r], up = Q.up[inst * Q.nc + r];
+                Q.rlo[inst * nr + r] = (lo <= -1.0e20) ? -1.0e20 : lo - cq;
+                Q.rup[inst * nr + r] = (up >= 1.0e20) ? 1.0e20 : up - cq;
+            }
+        }
+        if (Q.has_box) {
+            for (int i = h; i < n; i += 2) if (c < nf) Rg[(Q.nc + i) * nf + c] = Nl[i * kNS + c];
+            if (lane < n) {
+                const double l = Q.l[inst * n + lane], u = Q.u[inst * n + lane];
+                Q.rlo[inst * nr + Q.nc + lane] = (l <= -1.0e20) ? -1.0e20 : l - vec[lane];
+                Q.rup[inst * nr + Q.nc + lane] = (u >= 1.0e20) ? 1.0e20 : u - vec[lane];
+            }
+        }
+    }
+    wave_sync();      // N is dead from here on: its buffer becomes E (and later V2)
     // ---- Gram matrix of the small side
     const bool rowside = m <= nf;
     const int k = rowside ? m : nf;
@@ -312,6 +345,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
         wave_sync();
     }
     // ---- null-space basis V2 (nf x ns) for the next level and for the selective regularisation
+    double* V2 = rowside ? NE : K;    // (E's last use on the row side is the construction of V1 below; K's on the column side is sig[])
     if (ns > 0) {
         if (!rowside) {
             // columns of E for the ns smallest eigenvalues
@@ -389,33 +423,6 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
     if (ns > 0 && Q.V2) {
         double* Vg = Q.V2 + inst * (long long)n * n;
         for (int i = h; i < nf; i += 2) if (c < ns) Vg[i * n + c] = V2[i * kNS + c];
-    }
-    // ---- constraints in z-coordinates (levels below the first): rows [C N; N], bounds shifted by q0
-    if (!first) {
-        const int nr = Q.nc + (Q.has_box ? n : 0);
-        double* Rg = Q.R + inst * (long long)nr * nf;
-        if (lane < 64) vec[lane] = (lane < n) ? Q.q0[inst * n + lane] : 0.0;
-        wave_sync();
-        for (int r = 0; r < Q.nc; ++r) {
-            const double* Cr = Q.C + (inst * (long long)Q.nc + r) * n;
-            double acc = 0.0, cq = 0.0;
-            for (int i = h; i < n; i += 2) { const double ci = Cr[i]; acc = fma(ci, Nl[i * kNS + c], acc); cq = fma(ci, vec[i], cq); }
-            acc = halfsum<32>(acc); cq = halfsum<32>(cq);
-            if (h == 0 && c < nf) Rg[r * nf + c] = acc;
-            if (lane == 0) {
-                const double lo = Q.lo[inst * Q.nc + r], up = Q.up[inst * Q.nc + r];
-                Q.rlo[inst * nr + r] = (lo <= -1.0e20) ? -1.0e20 : lo - cq;
-                Q.rup[inst * nr + r] = (up >= 1.0e20) ? 1.0e20 : up - cq;
-            }
-        }
-        if (Q.has_box) {
-            for (int i = h; i < n; i += 2) if (c < nf) Rg[(Q.nc + i) * nf + c] = Nl[i * kNS + c];
-            if (lane < n) {
-                const double l = Q.l[inst * n + lane], u = Q.u[inst * n + lane];
-                Q.rlo[inst * nr + Q.nc + lane] = (l <= -1.0e20) ? -1.0e20 : l - vec[lane];
-                Q.rup[inst * nr + Q.nc + lane] = (u >= 1.0e20) ? 1.0e20 : u - vec[lane];
-            }
-        }
     }
 }
 

@@ -79,7 +79,10 @@ extern "C" __attribute__((visibility("default"))) int emu_nhqp_solve(const osot_
     NhqpWorkspace ws = {{N0.data(), N1.data()}, q0.data(), H.data(), g.data(), R.data(), rlo.data(), rup.data(), zz.data(), V2.data(), st.data(), it.data()};
     const unsigned grid = (unsigned)b->B;
     rc = nhqp_run(*plan, b, opt, ws,
-        [&](const DevNhqp& Q) { emu::launch(osot_nhqp_prepare_kernel, grid, 0, 64, Q); },
+        [&](const DevNhqp& Q) {
+            if (Q.m <= 32) emu::launch(osot_nhqp_prepare_kernel<32>, grid, 0, 64, Q);
+            else emu::launch(osot_nhqp_prepare_kernel<64>, grid, 0, 64, Q);
+        },
         [&](int B, int n, int nc, const double* Hh, const double* gg, const double* A, const double* lA, const double* uA,
             const double* l, const double* u, double eps, double* x, int* status, int* iters) {
             return emu_qp_solve_batch(B, n, nc, Hh, gg, A, lA, uA, l, u, eps, 0, x, status, iters);
