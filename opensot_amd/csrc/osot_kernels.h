@@ -241,6 +241,11 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
             double gp0 = 0.0, gp1 = 0.0;
             // (a0, a1): the row of A (right operand);  (l0, l1): the row of W A (left operand) -- w_r * a for a diagonal W,
             // read from WA otherwise;  gb: b_r, or (W b)_r for a non-diagonal W: g = -A'(W b) (iHQP.cpp:153, Task::getWb)
+            // b_r and w_r of up to 64 rows in ONE load each, lane = row, handed to the quarter-rows through the LDS crossbar
+            // (ds_bpermute): as uniform-address loads inside fetch() they were a third of the level's vector-memory
+            // instructions, and eight synchronised wavefronts per CU queue on the CU's one address unit
+            double bw_b = 0.0, bw_w = 1.0;
+            int bw_base = -1;
             auto fetch = [&](int r0, double& a0, double& a1, double& l0, double& l1, double& gb) {
                 const int r = r0 + tq;
                 const bool in = r < ma && !(inact && row_off(r));
@@ -250,13 +255,15 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
                 const double v1 = Ak[rr * n + c1];
                 a0 = (in && ta < n) ? v0 : 0.0;
                 a1 = (in && 16 + ta < n) ? v1 : 0.0;
-                gb = dense ? Wbk[rr] : bk[rr];
                 if (dense) {
+                    gb = Wbk[rr];
                     const double u0 = WAk[rr * n + c0], u1 = WAk[rr * n + c1];
                     l0 = (in && ta < n) ? u0 : 0.0;
                     l1 = (in && 16 + ta < n) ? u1 : 0.0;
                 } else {
-                    const double wv = wk ? wk[rr] : 1.0;
+                    const int src4 = (rr - bw_base) << 2;
+                    gb = permute_f64(bw_b, src4);
+                    const double wv = wk ? permute_f64(bw_w, src4) : 1.0;
                     l0 = wv * a0; l1 = wv * a1;
                 }
             };
@@ -267,6 +274,12 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
 #endif
             constexpr int HBD = OSOT_HB_DEPTH;   // groups of four rows requested before the first MFMA
             for (int rb = 0; rb < ma; rb += 4 * HBD) {
+                if (!dense && (rb & 63) == 0) {          // rows rb .. rb + 63 of b and w, lane = row
+                    const int rl = rb + lane;
+                    bw_b = (rl < ma) ? bk[rl] : 0.0;
+                    bw_w = (wk && rl < ma) ? wk[rl] : 1.0;
+                    bw_base = rb;
+                }
                 double ca0[HBD], ca1[HBD], cl0[HBD], cl1[HBD], cbr[HBD];
 #pragma unroll
                 for (int ch = 0; ch < HBD; ++ch) {
