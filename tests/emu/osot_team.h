@@ -3,6 +3,11 @@
 // kernel headers are compiled for the emulator (tests/emu/emu_driver.cpp).  Every collective is a
 // rendezvous of the whole 64-lane wave, so a missing wave_sync() between an LDS write and another lane's
 // read produces a wrong result here even though real hardware executes the wave in lock-step.
+// What this emulation does NOT model: the exec mask.  A cross-lane read (ds_bpermute / __shfl, DPP) issued inside a branch
+// that only some lanes take reads ZEROS (bpermute) or stale registers (DPP, v_readlane) from the lanes that are masked off on
+// the hardware, while the rendezvous here hands over every lane's value -- `x = cond ? shift_down(v) : 0` compiled as two
+// masked arms cost a GPU-only failure in sym_eig32 once.  Rule for the kernels: cross-lane reads are issued by ALL lanes,
+// outside any lane-dependent select or branch; the GPU suite (tests -m gpu) is what checks it.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cmath>
