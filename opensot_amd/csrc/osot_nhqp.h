@@ -224,12 +224,22 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
     if (lane < 64) vec[lane] = (!first && lane < n) ? Q.q0[inst * n + lane] : 0.0;     // q0 staged
     wave_sync();
     // ---- AN = A N (stored rows: a row of A against the columns of N, i split over the halves; identity rows: rows of N)
-    for (int r = 0; r < ma; ++r) {
-        double acc = 0.0;
-        for (int i = h; i < n; i += 2) acc = fma(A[r * n + i], Nl[i * kNS + c], acc);
-        acc = halfsum<32>(acc);
-        if (h == 0 && c < nf) AN[r * kNS + c] = acc;
+    // (A goes through the Gram buffer, free until the Gram matrix is formed, 32 rows at a time with coalesced loads: read
+    //  element by element inside the product it was a uniform-address HBM load per multiply-add)
+    for (int rb = 0; rb < ma; rb += 32) {
+        const int nr = (ma - rb < 32) ? ma - rb : 32;
+        wave_sync();
+        for (int r = h; r < nr; r += 2) K[r * kNS + c] = (c < n) ? A[(rb + r) * n + c] : 0.0;
+        wave_sync();
+        for (int r = 0; r < nr; ++r) {
+            double acc = 0.0;
+            for (int i = h; i < n; i += 2) acc = fma(K[r * kNS + i], Nl[i * kNS + c], acc);
+            acc = halfsum<32>(acc);
+            if (h == 0 && c < nf) AN[(rb + r) * kNS + c] = acc;
+        }
     }
+    wave_sync();
+    for (int e = lane; e < 32 * kNS; e += 64) K[e] = 0.0;
     for (int r = ma + h; r < m; r += 2) if (c < nf) AN[r * kNS + c] = Nl[(r - ma) * kNS + c];
     // ---- b0 = b - A q0 (lane = row)
     if (lane < m) {
@@ -464,14 +474,14 @@ __global__ void __launch_bounds__(64) osot_nhqp_accumulate_kernel(const DevNhqpA
     if (!Q.last && ns > 0) {
         const double* Vg = Q.V2 + inst * (long long)n * n;
         double* Nn = Q.Nnext + inst * (long long)n * n;
-        for (int i = 0; i < n; ++i) {          // row i of N V2: lane c = column t
+        // N V2 (n x ns): one entry per lane, the n ns entries spread over all 64 lanes (with lane = column only ns of them
+        // worked: five at the second level of the benchmark stack)
+        for (int e = lane; e < n * ns; e += 64) {
+            const int i = e / ns, t = e - i * ns;
             double a2 = 0.0;
-            if (c < ns) {
-                if (Q.first) a2 = (h == 0 && i < nf) ? Vg[i * n + c] : 0.0;
-                else for (int j = h; j < nf; j += 2) a2 = fma(Ng[i * n + j], Vg[j * n + c], a2);
-            }
-            a2 = halfsum<32>(a2);
-            if (h == 0 && c < ns) Nn[i * n + c] = a2;
+            if (Q.first) a2 = (i < nf) ? Vg[i * n + t] : 0.0;
+            else for (int j = 0; j < nf; ++j) a2 = fma(Ng[i * n + j], Vg[j * n + t], a2);
+            Nn[i * n + t] = a2;
         }
     }
 }
