@@ -168,3 +168,15 @@ def test_ehqp_gpu_benchmark_stack_and_torch_api(oracle, gpu_device):
     assert sol.getSigmaMin() == 1e-12
     sol.setSigmaMin(-1.0)
     assert sol.getSigmaMin() == 1e-12
+
+
+@pytest.mark.gpu
+def test_frontends_random_sweep_gpu(gpu_device):
+    """tests/stress_frontends.py: eHQP and nHQP kernels against their restatements over random stacks (n = 2..32, one to three
+    task levels, with and without a Postural level, constraints for nHQP): the eigen-solver on many sizes and spectra"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "stress_frontends.py"), "5", "60"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "60 stacks x 24 instances: 0 with a mismatch" in out.stdout, out.stdout[-2000:]
+
