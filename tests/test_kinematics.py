@@ -213,7 +213,7 @@ def test_kernel_matches_restatement(gpu_device):
     K.forward(tq, frame_pose=poses, frame_J={f: (A, 6 * f) for f in range(4)}, com=com, com_J=(A, 24))
     torch.cuda.synchronize()
     Ah = A.cpu().numpy()
-    for i in range(0, B, 16):
+    for i in list(range(0, B, 7)) + [B - 2, B - 1]:      # (odd and even instances: two share a wavefront; B is odd)
         o = pykin.forward(m, q[i])
         for f in range(4):
             assert np.abs(Ah[i, 6 * f:6 * f + 6] - o["J"][f]).max() < 1e-13
