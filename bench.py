@@ -163,7 +163,8 @@ def cpu_baseline(plan, leaf_sample, budget_s=24.0):
             "sweep": sweep,
             "sample": f"the same C3 stack, solve only (coman_ik.cpp:186-192 protocol), "
                       f"{'qpOASES 3.1 hot-started across cycles' if kind == 'reference' else 'C Goldfarb-Idnani port'}; thread sweep "
-                      f"{counts}, {sum(s['seconds'] for s in sweep):.1f} s of CPU work in all; value = best point "
+                      f"{counts}, {sum(s['seconds'] for s in sweep) + r['seconds']:.1f} s of wall clock = "
+                      f"{sum(s['seconds'] * s['threads'] for s in sweep):.0f} thread-seconds of CPU work in all; value = best point "
                       f"({best['threads']} threads x {best['instances']} instances x {best['cycles']} cycles)" + note}
 
 
