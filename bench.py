@@ -141,6 +141,7 @@ def cpu_baseline(plan, leaf_sample, budget_s=24.0):
     cyc = int(max(50, min(200000, per_point / max(r["seconds"] / 50, 1e-7))))
     r = po.ihqp_solve_batch(asm, be, nthreads=1, cycles=cyc, sl=slice(0, 1))
     hot = cyc / r["seconds"]
+    hot_seconds = r["seconds"]
     sweep = []
     for nt in counts:
         nb = min(B, max(nt * 4, 64))                 # a few instances per thread, the whole sample for many threads
@@ -163,7 +164,7 @@ def cpu_baseline(plan, leaf_sample, budget_s=24.0):
             "sweep": sweep,
             "sample": f"the same C3 stack, solve only (coman_ik.cpp:186-192 protocol), "
                       f"{'qpOASES 3.1 hot-started across cycles' if kind == 'reference' else 'C Goldfarb-Idnani port'}; thread sweep "
-                      f"{counts}, {sum(s['seconds'] for s in sweep) + r['seconds']:.1f} s of wall clock = "
+                      f"{counts}, {sum(s['seconds'] for s in sweep) + hot_seconds:.1f} s of wall clock = "
                       f"{sum(s['seconds'] * s['threads'] for s in sweep):.0f} thread-seconds of CPU work in all; value = best point "
                       f"({best['threads']} threads x {best['instances']} instances x {best['cycles']} cycles)" + note}
 
