@@ -338,6 +338,31 @@ def time_kinematics(B, device, steps=20, warmup=5):
                          "traffic": None, "algorithmic_bytes_per_instance": nbytes}}
 
 
+def sub_leaf(lf, lo, hi):
+    """rows [lo, hi) of a numpy leaf dict (opensot_amd.synth layout)"""
+    cut = lambda a: None if a is None else a[lo:hi]
+    out = {"B": hi - lo, "A": [cut(a) for a in lf["A"]],
+           "task": [[tuple(cut(x) for x in t) for t in lev] for lev in lf["task"]],
+           "bound": [tuple(cut(x) for x in t) for t in lf["bound"]],
+           "rows": [tuple(cut(x) for x in t) for t in lf["rows"]]}
+    if lf.get("C") is not None:
+        out["C"] = [cut(a) for a in lf["C"]]
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher around it: re-execute under torch.distributed.run with N ranks on this
+    node (rendezvous on 127.0.0.1, a free port); rank 0 of the children prints the JSON line.  The N = 1 path is untouched."""
+    import socket
+    import subprocess
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -350,14 +375,24 @@ def main():
     ap.add_argument("--cycles", type=int, default=4,
                     help="distinct, temporally coherent control cycles the steps rotate through (SURVEY 8d: cycle t+1 = "
                          "cycle t + 1 %% perturbation of every input, Jacobians included); 1 = repeat one cycle")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("OSOT_BENCH_LANES", "2")),
+                    help="sub-batches per GPU, each on its own stream with no join between steps "
+                         "(opensot_amd.parallel.PipelinedCycle); 1 = one launch per step")
+    ap.add_argument("--backend", default=os.environ.get("OSOT_BENCH_BACKEND", "hip"), choices=("hip", "stub"),
+                    help="stub = CPU tensors + gloo + a stand-in for the solver: exercises the launcher, the sharding, the lanes "
+                         "and the gather of this very script where there is no GPU (tests/test_distributed_cpu.py); never a result")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with nproc-per-node {args.gpus} (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    stub = args.backend == "stub"
+    if not stub:
+        torch.cuda.set_device(local_rank)
     dist = None
     # (OSOT_BENCH_FORCE_DIST=1 runs the collective path with a world of one: a single-GPU check of the RCCL plumbing)
     use_dist = world > 1 or os.environ.get("OSOT_BENCH_FORCE_DIST") == "1"
@@ -365,20 +400,23 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29555")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from opensot_amd import synth
-    from opensot_amd.solver import BatchedStack
-    from opensot_amd.parallel import ShardedCycle, ShardGather, shard_range, timed_steps
+    from opensot_amd.parallel import PipelinedCycle, ShardedCycle, ShardGather, lane_ranges, shard_range, timed_steps
 
     Bl = args.batch_per_gpu
     Bg = Bl * world
     lo, hi = shard_range(Bg, rank, world)
     assert hi - lo == Bl
+    S = max(1, min(args.lanes, Bl))
+    device = torch.device("cpu") if stub else torch.device("cuda", local_rank)
+    sync = (lambda: None) if stub else torch.cuda.synchronize
     # every rank generates only its own shard (seed = 1000*config + rank)
     plan, leaf = synth.make_velocity_stack(args.config, Bl, seed=3000 + rank)
-    st = BatchedStack(plan, Bl, device=local_rank, want_levels=False)
     # K temporally coherent cycles (MPC-rollout-like): each is the previous one with every float input moved by
     # ~1 %.  The Jacobians change too: every cycle has its own A_k buffers (the kinematics producer's output) and the
     # stack just points at them -- nothing is copied inside a step.
@@ -387,51 +425,87 @@ def main():
     leaves = [leaf]
     for _ in range(K - 1):
         leaves.append(synth.perturb(leaves[-1], rng, 0.01))
-    dev_leaves, A_sets = [], []
-    for lf in leaves:
-        st.A = [None if a is None else torch.empty_like(a) for a in st.A]
-        dev_leaves.append(st.load_leaf(lf))
-        A_sets.append(st.A)
-    # the gather of the solved shards runs on the solve stream (measured: 9 us per step with a world of one; the
-    # double-buffered side-stream variant cost 22 us of host-side event traffic and was dropped)
-    ov = os.environ.get("OSOT_GATHER_OVERLAP")      # (developer switch: 0 = collective on the solve stream's critical path)
-    gather = ShardGather(Bg, plan.n, st.device, torch.float64, overlap=None if ov is None else ov == "1") if use_dist else None
-    cyc = ShardedCycle(st, dev_leaves, A_sets, Bl, gather)
-    sync = torch.cuda.synchronize
+    if stub:
+        from opensot_amd.parallel import StubStack as BatchedStack
+    else:
+        from opensot_amd.solver import BatchedStack
+    # S lanes: contiguous sub-batches of the shard, each with its own solver (dispatch-order state), stream and -- with
+    # more than one rank -- its own communicator: the collectives of different lanes are never ordered against each other
+    ov = os.environ.get("OSOT_GATHER_OVERLAP")      # (developer switch: 1 = asynchronous collective on the group's stream)
+    spans = lane_ranges(Bl, S)
+    stacks, lanes, gathers = [], [], []
+    for j, (a, b) in enumerate(spans):
+        stj = BatchedStack(plan, b - a, device=local_rank, want_levels=False)
+        devs, A_sets = [], []
+        for lf in leaves:
+            stj.A = [None if t is None else torch.empty_like(t) for t in stj.A]
+            devs.append(stj.load_leaf(sub_leaf(lf, a, b)))
+            A_sets.append(stj.A)
+        gj = None
+        if use_dist:
+            grp = dist.new_group(list(range(world))) if S > 1 else None
+            gj = ShardGather((b - a) * world, plan.n, device, torch.float64, group=grp,
+                             overlap=None if ov is None else ov == "1", sizes=[b - a] * world)
+        stacks.append(stj); gathers.append(gj)
+        lanes.append(ShardedCycle(stj, devs, A_sets, b - a, gj))
+    streams = None if (stub or S == 1) else [torch.cuda.Stream(device=device) for _ in range(S)]
+    cyc = PipelinedCycle(lanes, streams)
+    st = stacks[0]
 
     # warm up first, then switch the event timing on for the timed steps only
     for _ in range(args.warmup):
         cyc.step()
     sync()
-    st.set_timing(True)
-    elapsed = timed_steps(cyc.step, args.steps, 0, sync, dist if use_dist else None, st.device)
-    kern_ms, launches = st.kernel_time_ms()
-    ok = int((st.status[:Bl] == 0).sum().item())
+    for stj in stacks:
+        stj.set_timing(True, stride=4)     # every fourth launch of a lane is bracketed by HIP events on its stream
+    elapsed = timed_steps(cyc.step, args.steps, 0, sync, dist if use_dist else None, device)
+    kt = [stj.kernel_time_ms() for stj in stacks]
+    launches = sum(c for _, c in kt)
+    kern_ms = sum(ms * c for ms, c in kt) / launches if launches else 0.0
+    ok = sum(int((stj.status[:b - a] == 0).sum().item()) for stj, (a, b) in zip(stacks, spans))
     all_ok = None
     if use_dist:
-        all_ok = int((gather.status == 0).sum().item())
+        all_ok = sum(int((g.status == 0).sum().item()) for g in gathers)
     # the same kernel with plain in-order dispatch (reported beside the headline, never as the headline)
-    st.set_schedule(longest_first=False)
+    for stj in stacks:
+        stj.set_schedule(longest_first=False)
     for _ in range(3):
         cyc.step()
     sync()
-    st.kernel_time_ms()
+    for stj in stacks:
+        stj.kernel_time_ms()
     t1 = time.perf_counter()
     for _ in range(10):
         cyc.step()
     sync()
     inorder_elapsed = (time.perf_counter() - t1) / 10
-    inorder_kern_ms, _ = st.kernel_time_ms()
-    st.set_schedule(longest_first=True)
-    st.set_timing(False)
-    # the AutoStack::update equivalent on its own (SURVEY 8d asks for it beside the whole-step figure)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for i in range(20):
-        st.update(dev_leaves[i % K])
-    e1.record()
-    sync()
-    update_ms = e0.elapsed_time(e1) / 20
+    ikt = [stj.kernel_time_ms() for stj in stacks]
+    inorder_kern_ms = sum(ms * c for ms, c in ikt) / max(1, sum(c for _, c in ikt))
+    for stj in stacks:
+        stj.set_schedule(longest_first=True)
+        stj.set_timing(False)
+    # one launch per step (no lanes), same steps: what the pipelining is worth, reported beside the headline
+    single_value = None
+    if S > 1 and not stub and not use_dist:
+        st1 = BatchedStack(plan, Bl, device=local_rank, want_levels=False)
+        devs1, A1 = [], []
+        for lf in leaves:
+            st1.A = [None if t is None else torch.empty_like(t) for t in st1.A]
+            devs1.append(st1.load_leaf(lf)); A1.append(st1.A)
+        one = ShardedCycle(st1, devs1, A1, Bl, None)
+        single_value = Bl * args.steps / timed_steps(one.step, args.steps, args.warmup, sync, None, device)
+        del one, st1, devs1, A1
+    update_ms = None
+    if not stub:
+        # the AutoStack::update equivalent on its own (SURVEY 8d asks for it beside the whole-step figure)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(20):
+            for stj, ln in zip(stacks, lanes):
+                stj.update(ln.dev_leaves[i % K])
+        e1.record()
+        sync()
+        update_ms = e0.elapsed_time(e1) / 20
 
     if rank == 0:
         value = Bg * args.steps / elapsed
@@ -442,11 +516,14 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[2]: batch={Bl}/GPU x 32-DoF, 3-level iHQP "
                                    "(CoM / l_wrist(0.1)+r_wrist+l_sole+r_sole / Postural), joint-limit & "
-                                   "velocity-limit box, eps factor 1e6; step = AutoStack::update + cascade solve; "
-                                   f"steps rotate through {K} temporally coherent cycles (1 % input drift per cycle)"
-                                   + ("; + RCCL all-gather of dq and status" if use_dist else ""),
+                                   "velocity-limit box, eps factor 1e6; step = AutoStack::update + cascade solve of every "
+                                   f"instance; steps rotate through {K} temporally coherent cycles (1 % input drift per cycle)"
+                                   + (f"; the {Bl} instances of a GPU are {S} contiguous sub-batches, each one launch per step on "
+                                      "its own stream, a sub-batch's step t+1 ordered behind ITS step t only (instances are "
+                                      "independent: no join between steps inside the timed bracket)" if S > 1 else "")
+                                   + ("; + RCCL all-gather of dq and status" + (" per sub-batch" if S > 1 else "") if use_dist else ""),
                        "global_batch": Bg, "n_dof": plan.n, "levels": plan.L,
-                       "rows_per_level": [plan.m(k) for k in range(plan.L)],
+                       "rows_per_level": [plan.m(k) for k in range(plan.L)], "lanes_per_gpu": S,
                        "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
             "solved_ok_rank0": f"{ok}/{Bl}",
             "update_avg_ms_rank0": update_ms,
@@ -454,27 +531,43 @@ def main():
                                  "(osot_solver_set_schedule default; results are order-independent)",
                          "in_order_value_rank0": Bl / inorder_elapsed, "in_order_avg_launch_ms": inorder_kern_ms},
         }
+        if stub:
+            out["data"] = "STUB BACK-END (CPU tensors, gloo, no solver): launcher / sharding / gather check only, not a result"
+        if single_value is not None:
+            out["single_launch_per_step_value_rank0"] = single_value
         if all_ok is not None:
             out["solved_ok_all_ranks"] = f"{all_ok}/{Bg}"
-        if launches > 0 and kern_ms > 0:
-            traffic, src = pmc_traffic(args.config, Bl)
-            rf, rh = roofline_of(plan, Bl, kern_ms, launches,
+        if launches > 0 and kern_ms > 0 and not stub:
+            traffic, src = pmc_traffic(args.config, Bl // S)
+            # S launches are in flight at a time (one per lane), each sharing the chip with the others: a launch's own duration is
+            # not the time the chip needed for its instances.  The roofline figures therefore take the time of a whole STEP (all
+            # lanes; it contains every launch of the step plus the order kernels and launch gaps, so it under-states the kernel).
+            step_ms = 1e3 * elapsed / args.steps
+            rf, rh = roofline_of(plan, Bl, step_ms if S > 1 else kern_ms, launches,
                                  "osot_cycle_kernel<32,false> (AutoStack::update + the whole cascade of an instance by one wavefront: "
                                  "fp64 MFMA H build + blocked Cholesky + null-space elimination, VALU/LDS active set)",
-                                 traffic, (src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 per "
-                                           "MI355X_MICROARCH.md; same kernel source hash)") if traffic else
+                                 None if traffic is None else traffic * S,
+                                 (src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 per "
+                                        "MI355X_MICROARCH.md; same kernel source hash; per launch x launches per step)") if traffic else
                                  "no PMC passes committed for this kernel source: null rather than a stale figure")
+            rf["avg_launch_ms"] = kern_ms
+            rf["launch_batch"] = Bl // S
+            rf["concurrent_launches"] = S
+            if S > 1:
+                rf["time_base"] = ("ms_per_step (whole-job): %d launches of %d instances overlap on the chip, so achieved = algorithmic "
+                                   "flops of a step / step time; avg_launch_ms is one launch's own (overlapped) duration as the HIP "
+                                   "events on its stream and rocprofv3 see it" % (S, Bl // S))
             # the fused kernel's algorithmic bytes: the cascade's compulsory bytes + the leaf inputs the update
             # half reads + the assembled arrays it writes (they are outputs in their own right; the cascade half reads them
             # back from the CU's L1 / L2, which costs no HBM traffic)
-            lb, ab = leaf_bytes_per_instance(dev_leaves[0]), assembled_bytes_per_solve(plan)
+            lb, ab = leaf_bytes_per_instance(lanes[0].dev_leaves[0]), assembled_bytes_per_solve(plan)
             rh["algorithmic_bytes_per_solve_cascade_only"] = rh["algorithmic_bytes_per_solve"]
             rh["algorithmic_bytes_per_solve"] = rh["algorithmic_bytes_per_solve"] + lb + ab
             rh["leaf_input_bytes_per_solve"], rh["assembled_output_bytes_per_solve"] = lb, ab
-            rh["achieved"] = rh["algorithmic_bytes_per_solve"] * Bl / (rf["avg_launch_ms"] * 1e-3) / 1e9
+            rh["achieved"] = rh["algorithmic_bytes_per_solve"] * Bl / ((step_ms if S > 1 else kern_ms) * 1e-3) / 1e9
             rh["frac"] = rh["achieved"] / rh["peak"]
             out["roofline"], out["roofline_hbm"] = rf, rh
-        if world == 1 and not args.no_other_configs:
+        if world == 1 and not args.no_other_configs and not stub:
             oc = {}
             for name, B in (("C2", 1024), ("C4", 4096), ("C5", 1024)):
                 try:
@@ -494,7 +587,7 @@ def main():
             except Exception as e:
                 oc["kinematics"] = {"error": str(e)}
             out["other_configs"] = oc
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not stub:
             ns = min(Bl, 4096)
             sample = {"B": ns, "A": [a[:ns] if a is not None else None for a in leaf["A"]],
                       "task": [[tuple(None if x is None else x[:ns] for x in t) for t in lev] for lev in leaf["task"]],
@@ -502,10 +595,16 @@ def main():
                       "rows": [tuple(None if x is None else x[:ns] for x in t) for t in leaf["rows"]]}
             try:
                 # the GPU's answer (with its per-level solutions) for the same sample: cycle 0 of the rotation
-                st.x_levels = torch.zeros((Bl, plan.L, plan.n), dtype=torch.float64, device=st.device)
-                st.A = A_sets[0]; st.update(dev_leaves[0]); st.solve(Bl); sync()
-                out["parity"] = parity_report(plan, sample, st.dq[:ns].cpu().numpy(), st.x_levels[:ns].cpu().numpy(),
-                                              st.accepted_slack[:ns].cpu().numpy())
+                stp = BatchedStack(plan, Bl, device=local_rank, want_levels=True)
+                stp.update(stp.load_leaf(leaf)); stp.solve(Bl); sync()
+                # (the lanes solved the same instances in sub-batches: their answers are these, bit for bit)
+                for ln in lanes:       # bring every lane back to cycle 0 of the rotation
+                    ln.i = 0
+                cyc.step(); sync()
+                lane_dq = torch.cat([stj.dq[:b - a] for stj, (a, b) in zip(stacks, spans)])
+                out["lanes_vs_single_launch_max_abs_dq_diff"] = float((lane_dq - stp.dq[:Bl]).abs().max().item())
+                out["parity"] = parity_report(plan, sample, stp.dq[:ns].cpu().numpy(), stp.x_levels[:ns].cpu().numpy(),
+                                              stp.accepted_slack[:ns].cpu().numpy())
             except Exception as e:  # the oracle is a checker; its absence must not kill the bench line
                 out["parity"] = {"error": f"unavailable: {e}"}
             try:

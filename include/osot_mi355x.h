@@ -313,7 +313,8 @@ int osot_cycle(osot_solver* s, const osot_leaf_batch* leaf, const osot_assembled
 /* average device time (ms) of the cascade kernel over the launches recorded since the last call
  * with reset != 0; measured with hipEvents on the launch stream. *launches receives the count. */
 int osot_solver_kernel_time_ms(osot_solver* s, int reset, double* avg_ms, int* launches);
-int osot_solver_set_timing(osot_solver* s, int enabled);
+int osot_solver_set_timing(osot_solver* s, int enabled);   /* 0 off, 1 every launch, k > 1: every k-th launch (two event
+                                                             * packets per timed launch sit in the stream's critical path) */
 /* Dispatch order of the instances inside osot_ihqp_solve.  One wavefront solves one instance and the chip holds a
  * fixed number of them, so a batch runs in rounds and its tail is set by the slowest late starter.
  * OSOT_SCHEDULE_LONGEST_FIRST (default) dispatches in descending order of each instance's active-set iteration
@@ -323,6 +324,15 @@ int osot_solver_set_timing(osot_solver* s, int enabled);
 #define OSOT_SCHEDULE_IN_ORDER 0
 #define OSOT_SCHEDULE_LONGEST_FIRST 1
 int osot_solver_set_schedule(osot_solver* s, int mode);
+/* Hot start of the working sets across control cycles (reference: QPOasesBackEnd.cpp:258-285 tries hotstart() first;
+ * external/qpOASES-ext/src/SQProblem.cpp:149-193).  enabled != 0: every level of every instance records the inequality
+ * working set it ends with, and the next osot_ihqp_solve / osot_cycle of THIS solver re-adds it before the first
+ * violation scan (signed steps, then the constraints whose multipliers came out negative are taken out again); state is
+ * per instance index, so instance i of consecutive batches should be the same robot.  Calling it (again) with
+ * enabled != 0 forgets the recorded sets; 0 (default) = every solve is a cold start and nothing is recorded.  The answer
+ * does not depend on the mode beyond round-off (each level's minimiser is unique); the iteration counts do: it pays
+ * when the active sets persist from cycle to cycle and costs two iterations per constraint that has left the set. */
+int osot_solver_set_hotstart(osot_solver* s, int enabled);
 /* instances the device works on at once for this solver's plan (one wavefront each: CUs x resident wavefronts per CU, from
  * the kernel's register and LDS footprint): the dispatch order is planned for it, and batches that are a multiple of it
  * waste no round */

@@ -14,7 +14,7 @@
 //   osot_update_kernel ....... AutoStack::update() (src/utils/AutoStack.cpp:385-393): leaf -> b, W,
 //                              merged box, collision / friction-cone rows, inverse-dynamics bounds.
 //                              One 64-lane block per instance, one lane per stack row.
-//   osot_order_kernel ........ dispatch order of the next solve (longest first).
+//   order_body ............... dispatch order of the next solve (longest first): an extra workgroup of the solve launch.
 // (osot_kin.h holds the batched kinematics producer.)
 //
 // Mapping: ONE WAVEFRONT PER INSTANCE (one wavefront per workgroup).  NP = 32 for n <= 32 (two lanes per
@@ -84,10 +84,18 @@ struct DevBatch {
     long long* prof;   // [B][PH_COUNT] shader-clock cycles per phase (profiling instantiation only)
     const int* order;  // dispatch order: workgroup g solves instance order[g] (null: g).  Longest-first, see below
     int* cost_out;     // [B] active-set iterations of this solve = the cost estimate for the next dispatch
+    const int* cost_in;  // [B] the estimates as the PREVIOUS launch left them (the filter's memory, and what this launch's
+                         // order workgroup sorts); cost_in and cost_out are two buffers the solver alternates
+    int* order_next;   // [B] dispatch order for the NEXT launch, written by this launch's extra workgroup (order_body); null:
+                       // no extra workgroup in the grid
+    int slots;         // wavefronts the chip holds at once for this kernel (see order_body)
     const double* b_reg;   // [B][reg_rows] b of the regularisation task (null: none)
     const double* WA[OSOT_KMAX_LEVELS];   // [B][ma_k][n] W_k A_k, [B][m_k] W_k b_k of a level with a non-diagonal weight
     const double* Wb[OSOT_KMAX_LEVELS];   // (osot_update_kernel writes them); null: W_k is diag(w[k])
     double* accepted_slack;   // [B] largest constraint violation accepted as round-off (0: none); may be null
+    int* hot;                 // [B][L][NP] hot-start state: the inequality working set every level of every instance ended
+                              // with (constraint codes, -1 = none), read at the start of a level and rewritten at its end
+                              // (gi_inequalities); null: cold start, nothing recorded
 };
 
 // Row table of level k (LDS): [ global C rows ; A_0 ; ... ; A_{k-1} ]  (iHQP.cpp:282-333).  The C entries are
@@ -184,6 +192,8 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
         const int c = w.c, h = w.h;
         const bool valid = c < n;
         const int m = P.m[k], ma = P.ma[k];
+        int* hotk = D.hot ? D.hot + (inst * P.L + k) * NP : nullptr;
+        const int hotcode = hotk ? hotk[c] : -1;   // (requested here: the answer is not needed before the inequality loop)
         const double* Ak = D.A[k] ? D.A[k] + inst * ma * n : nullptr;
         const double* bk = D.b[k] + inst * m;
         const double* wk = D.w[k] ? D.w[k] + inst * m : nullptr;
@@ -392,10 +402,12 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
         int st;
         if (NP == 64) {   // must be inlined: hacc would otherwise be passed through scratch memory
             OSOT_ALWAYS_INLINE_CALL st = gi_solve<NP, PROF>(w, nrows, g, diag_h, hdiag, hacc,
-                                                                   has_box, lb, ub, P.max_iter, any, x, x, iters, prof, slack);
+                                                                   has_box, lb, ub, P.max_iter, any, x, x, iters, prof, slack,
+                                                                   false, 0.0, hotcode, hotk);
         } else {          // NP = 32: inlined as well (as a CALL the solver spends ~50 % more cycles: the tiles travel through scratch)
             OSOT_ALWAYS_INLINE_CALL st = gi_solve<NP, PROF>(w, nrows, g, diag_h, hdiag, hacc,
-                                           has_box, lb, ub, P.max_iter, any, x, x, iters, prof, slack, lowrank, xprep);
+                                           has_box, lb, ub, P.max_iter, any, x, x, iters, prof, slack, lowrank, xprep,
+                                           hotcode, hotk);
         }
         if (PROF) ph_t0_ = (long long)clock64();
         iters_total += iters;
@@ -438,17 +450,19 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
         // 0.175 ms per launch with 4 cycles in rotation, 0.206 -> 0.190 with 8, 0.212 -> 0.203 with 16)
         if (D.cost_out) {
             const int now = 4 * iters_total;
-            D.cost_out[inst] = (OSOT_COST_EMA && D.order) ? ((D.cost_out[inst] + now + 1) >> 1) : now;
+            D.cost_out[inst] = (OSOT_COST_EMA && D.order && D.cost_in) ? ((D.cost_in[inst] + now + 1) >> 1) : now;
         }
         if (D.accepted_slack) D.accepted_slack[inst] = slack;
     }
 }
 
+__device__ __forceinline__ long long dispatch_instance(const DevBatch& D, char* smem);   // (below, with the order workgroup)
+
 template <int NP, bool PROF, bool EXTRA = false>
 __global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : 1)) osot_cascade_kernel(const DevPlan P, const DevBatch D) {
     OSOT_DYNAMIC_LDS(osot_smem);
-    const long long inst = D.order ? D.order[blockIdx.x] : (int)blockIdx.x;
-    if (D.order) wave_priority_by_rank(blockIdx.x, gridDim.x);
+    const long long inst = dispatch_instance(D, osot_smem);
+    if (inst < 0) return;
     cascade_body<NP, PROF, EXTRA>(P, D, inst, (int)threadIdx.x, osot_smem);
 }
 
@@ -456,10 +470,14 @@ __global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : 1)) osot_cascad
 // batch of 4096 is two rounds: the kernel ends when the slowest LATE starter ends, and with the active-set
 // iteration count varying 2x between instances (mean 32, max 63 at BASELINE config 3) that tail was ~30 % of the
 // launch.  Control loops are temporally coherent: an instance's iteration count changes slowly from one cycle to
-// the next.  So the instances are dispatched in DESCENDING order of the iteration count of the previous solve
-// (classic longest-processing-time list scheduling).  This kernel builds that order: a counting sort of the
-// instance ids by min(cost, 255), one workgroup.  Results do not depend on the order (instances are independent).
-#ifndef OSOT_EMULATION   // (a 1024-thread workgroup with atomics: outside what tests/emu models; covered by the GPU tests)
+// the next.  So the instances are dispatched in DESCENDING order of a filtered iteration count of their previous solves
+// (classic longest-processing-time list scheduling).  The order is built by ONE EXTRA WORKGROUP OF THE SOLVE LAUNCH ITSELF
+// (block 0, round 3; a launch of its own before: ~5 us of kernel plus two launch gaps in every step's dependent chain): while
+// the other workgroups solve step t, it sorts the estimates step t-1 left behind (cost_in: complete, nobody writes it during
+// this launch) into the order step t+1 will use.  The order is one step staler than a sort between the launches would be; the
+// estimates are exponential averages, so that costs nothing measurable.  A counting sort of the instance ids by
+// min(cost, 255), 64 lanes, histogram and bin cursors in LDS.  Results do not depend on the order (instances are independent).
+//
 // `slots` = wavefronts the chip holds at once for this kernel (CUs x resident waves per CU).  The sorted list (descending
 // cost) is mapped to dispatch positions by the number of rounds the batch makes:
 //   B <= slots or B >= 2 slots : longest first (classic LPT list scheduling)
@@ -470,35 +488,34 @@ __global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : 1)) osot_cascad
 //                                takes the longest of them.  With plain LPT the last slot to free (the longest job's)
 //                                would have taken a late job: measured at BASELINE config 3, B = 4096 on 2560 slots, the
 //                                launch ended 20 us after its longest wave (tools/prof_cycle.py).
-__global__ void __launch_bounds__(1024) osot_order_kernel(const int* cost, int* order, int B, int slots) {
-    __shared__ int hist[256];
-    __shared__ int start[256];
-    const int t = threadIdx.x;
-    if (t < 256) hist[t] = 0;
+#ifndef OSOT_EMULATION   // (LDS atomics: outside what tests/emu models; covered by the GPU tests)
+__device__ __forceinline__ void order_body(const int* cost, int* order, int B, int slots, int lane, char* smem) {
+    int* hist = reinterpret_cast<int*>(smem);   // [256] instances per key
+    int* start = hist + 256;                    // [256] next rank (descending order of key) of each key
+    for (int i = lane; i < 256; i += 64) hist[i] = 0;
     __syncthreads();
-    for (int i = t; i < B; i += 1024) {
-        int k = cost[i]; k = k < 0 ? 0 : (k > 255 ? 255 : k);
-        atomicAdd(&hist[k], 1);
+    auto key = [&](int i) { int k = cost[i]; return k < 0 ? 0 : (k > 255 ? 255 : k); };
+    for (int i = lane; i < B; i += 64) __hip_atomic_fetch_add(&hist[key(i)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    // start[k] = number of instances with a larger key: lane l owns the bins 4 l .. 4 l + 3; suffix sums across the lanes
+    const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+    const int tot = h0 + h1 + h2 + h3;
+    int v = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_down(v, off, 64);
+        v += (lane + off < 64) ? t : 0;
     }
-    __syncthreads();
-    // start[k] = number of instances with a larger key (descending order): exclusive suffix sum of the histogram,
-    // Hillis-Steele over the 256 bins (eight rounds)
-    if (t < 256) start[t] = hist[t];
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        int v = 0;
-        if (t < 256 && t + off < 256) v = start[t + off];
-        __syncthreads();
-        if (t < 256) start[t] += v;
-        __syncthreads();
-    }
-    if (t < 256) start[t] -= hist[t];   // inclusive -> exclusive
+    const int above = v - tot;                  // instances in the bins of the lanes above this one
+    start[4 * lane + 3] = above;
+    start[4 * lane + 2] = above + h3;
+    start[4 * lane + 1] = above + h3 + h2;
+    start[4 * lane] = above + h3 + h2 + h1;
     __syncthreads();
     const int late = B - slots;                       // jobs that cannot be in the first round
     const bool paired = late > 0 && B < 2 * slots;
-    for (int i = t; i < B; i += 1024) {
-        int k = cost[i]; k = k < 0 ? 0 : (k > 255 ? 255 : k);
-        const int pos = atomicAdd(&start[k], 1);      // rank in descending order of cost
+    for (int i = lane; i < B; i += 64) {
+        const int pos = __hip_atomic_fetch_add(&start[key(i)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // rank, descending cost
         int where = pos;
         if (paired) {
             const int alone = slots - late;           // the longest `alone` jobs keep a slot to themselves
@@ -508,7 +525,20 @@ __global__ void __launch_bounds__(1024) osot_order_kernel(const int* cost, int* 
         order[where] = i;
     }
 }
+#else
+inline void order_body(const int*, int*, int, int, int, char*) {}
 #endif
+
+// workgroup -> instance of a solve launch: block 0 is the order workgroup when the launch carries one (returns -1 for it)
+__device__ __forceinline__ long long dispatch_instance(const DevBatch& D, char* smem) {
+    int g = (int)blockIdx.x;
+    if (D.order_next) {
+        if (g == 0) { order_body(D.cost_in, D.order_next, D.B, D.slots, (int)threadIdx.x, smem); return -1; }
+        g -= 1;
+    }
+    if (D.order) wave_priority_by_rank((unsigned)g, (unsigned)D.B);
+    return D.order ? D.order[g] : g;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // generic batched QP in BackEnd convention
@@ -1021,8 +1051,8 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
 template <int NP, bool EXTRA = false>
 __global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : 1)) osot_cycle_kernel(const DevUpdate U, const DevPlan P, const DevBatch D) {
     OSOT_DYNAMIC_LDS(osot_smem);
-    const long long inst = D.order ? D.order[blockIdx.x] : (int)blockIdx.x;
-    if (D.order) wave_priority_by_rank(blockIdx.x, gridDim.x);
+    const long long inst = dispatch_instance(D, osot_smem);
+    if (inst < 0) return;
     const long long tc0 = D.prof ? (long long)clock64() : 0;
     const long long tw0 = D.prof ? (long long)wall_clock64() : 0;
     update_body(OSOT_KERNARG_PTR(DevUpdate, U), inst, (int)threadIdx.x, osot_smem);   // (the cascade's slice is idle until it starts)

@@ -67,17 +67,19 @@ struct osot_solver {
     int max_batch;
     int device;
     bool timing;
+    int timing_stride = 1, timing_count = 0;   // every timing_stride-th launch is bracketed by events
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // recorded, not yet accumulated
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
-    // longest-first dispatch (osot_order_kernel): cost of the previous solve and the order built from it
+    // longest-first dispatch (order_body in osot_kernels.h): cost estimates of the previous solves and the order built from them
     int schedule = 1;        // 0: in order, 1: longest first
-    int* d_cost = nullptr;   // [max_batch]
-    int* d_order = nullptr;  // [max_batch]
-    int order_B = -1;        // batch size d_order is valid for (-1: none yet)
+    int* d_cost = nullptr;   // [2][max_batch]: the launches alternate (read one, write the other)
+    int* d_order = nullptr;  // [2][max_batch]: likewise (use one, the launch's order workgroup fills the other)
+    int flip = 0;            // which halves the next launch writes
+    int order_B = -1;        // batch size the order the next launch reads is valid for (-1: none yet)
     // d_cost / d_order are stream-ordered state shared by consecutive solves.  A solver is meant to be driven from one
     // thread on one stream (like the reference's Solver: no locks, SURVEY 8b "threading"); a solve that arrives on a
     // DIFFERENT stream than the previous one first waits (host side, rare) for that stream, so that it never reads
-    // d_order while the order kernel is still writing it.  No event traffic on the common path.
+    // d_order while the previous launch's order workgroup is still writing it.  No event traffic on the common path.
     hipStream_t order_stream = nullptr;
     DevUpdatePlan* d_uplan = nullptr;   // static part of the update kernel's arguments, uploaded at creation
     DevUpdatePlan h_uplan;
@@ -86,6 +88,10 @@ struct osot_solver {
     int slots = 1;      // wavefronts of the cascade kernel the device holds at once (CUs x resident workgroups per CU)
     NhqpWorkspace nhqp; // scratch of the null-space front-end, allocated at its first use
     bool nhqp_ready = false;
+    // hot start (osot_solver_set_hotstart): the inequality working set each level of each instance ended with
+    int hotstart = 0;
+    int* d_hot = nullptr;    // [max_batch][n_levels][T] constraint codes, -1 = none (allocated when first switched on)
+    int hot_T = 0;
 };
 
 extern "C" {
@@ -143,7 +149,7 @@ int osot_solver_create(const osot_plan_desc* plan, int max_batch, int device, os
     s->device = device;
     s->timing = false;
     std::memset(s->task_active, 1, sizeof(s->task_active));
-    {   // resident workgroups: what the longest-first dispatch order is planned for (osot_order_kernel)
+    {   // resident workgroups: what the longest-first dispatch order is planned for (order_body)
         int per_cu = 0, cus = 0;
         hipError_t e1 = (T == 32)
             ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, osot_cycle_kernel<32, false>, 64, lds)
@@ -154,8 +160,9 @@ int osot_solver_create(const osot_plan_desc* plan, int max_batch, int device, os
     make_update_plan(*plan, s->h_uplan);
     // dispatch-order state and the static update plan live with the solver from the start (no lazy allocation on
     // whatever device is current)
-    if (hipMalloc(&s->d_cost, sizeof(int) * (size_t)max_batch) != hipSuccess ||
-        hipMalloc(&s->d_order, sizeof(int) * (size_t)max_batch) != hipSuccess ||
+    if (hipMalloc(&s->d_cost, sizeof(int) * 2 * (size_t)max_batch) != hipSuccess ||
+        hipMemset(s->d_cost, 0, sizeof(int) * 2 * (size_t)max_batch) != hipSuccess ||
+        hipMalloc(&s->d_order, sizeof(int) * 2 * (size_t)max_batch) != hipSuccess ||
         hipMalloc(&s->d_uplan, sizeof(DevUpdatePlan)) != hipSuccess ||
         hipMemcpy(s->d_uplan, &s->h_uplan, sizeof(DevUpdatePlan), hipMemcpyHostToDevice) != hipSuccess) {
         if (s->d_cost) hipFree(s->d_cost);
@@ -176,6 +183,7 @@ int osot_solver_destroy(osot_solver* s) {
     if (s->d_cost) hipFree(s->d_cost);
     if (s->d_order) hipFree(s->d_order);
     if (s->d_uplan) hipFree(s->d_uplan);
+    if (s->d_hot) hipFree(s->d_hot);
     if (s->nhqp_ready) {
         void* ptrs[] = {s->nhqp.N[0], s->nhqp.N[1], s->nhqp.q0, s->nhqp.H, s->nhqp.g, s->nhqp.R, s->nhqp.rlo, s->nhqp.rup, s->nhqp.z,
                         s->nhqp.V2, s->nhqp.qp_status, s->nhqp.qp_iters};
@@ -190,6 +198,27 @@ int osot_solver_set_schedule(osot_solver* s, int mode) {
     if (mode != OSOT_SCHEDULE_IN_ORDER && mode != OSOT_SCHEDULE_LONGEST_FIRST) return fail(OSOT_ERR_INVALID, "unknown schedule mode");
     s->schedule = mode;
     s->order_B = -1;
+    return OSOT_OK;
+}
+
+int osot_solver_set_hotstart(osot_solver* s, int enabled) {
+    if (!s) return fail(OSOT_ERR_INVALID, "null solver");
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return fail(OSOT_ERR_HIP, "hipSetDevice failed");
+    if (enabled) {
+        DevPlan P; int T; size_t lds;
+        make_dev_plan(s->plan, nullptr, P, T, lds);
+        const size_t bytes = sizeof(int) * (size_t)s->max_batch * (size_t)s->plan.n_levels * (size_t)T;
+        if (!s->d_hot) {
+            if (hipMalloc(&s->d_hot, bytes) != hipSuccess) { s->d_hot = nullptr; return fail(OSOT_ERR_HIP, "device allocation for the hot-start state failed"); }
+            s->hot_T = T;
+        }
+        // (re-)enabling forgets what was recorded: every instance starts cold once.  Device-wide synchronous, like the
+        // allocation: this is a configuration call, not part of a control cycle
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemset(s->d_hot, 0xff, bytes));
+    }
+    s->hotstart = enabled ? 1 : 0;
     return OSOT_OK;
 }
 
@@ -208,6 +237,18 @@ int osot_solver_set_task_active(osot_solver* s, int level, int task, int active)
 int osot_solver_set_timing(osot_solver* s, int enabled) {
     if (!s) return fail(OSOT_ERR_INVALID, "null solver");
     s->timing = enabled != 0;
+    s->timing_stride = enabled > 1 ? enabled : 1;
+    s->timing_count = 0;
+    if (s->timing) {   // the event pairs exist before the first timed launch: creating them costs more than recording them
+        DeviceGuard guard(s->device);
+        if (!guard.ok) return fail(OSOT_ERR_HIP, "hipSetDevice failed");
+        while (s->pool.size() < 64) {
+            std::pair<hipEvent_t, hipEvent_t> ev;
+            HIP_TRY(hipEventCreate(&ev.first));
+            HIP_TRY(hipEventCreate(&ev.second));
+            s->pool.push_back(ev);
+        }
+    }
     return OSOT_OK;
 }
 
@@ -366,15 +407,21 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
     D.b_reg = pl.has_regularisation ? b->b_reg : nullptr;
     D.prof = prof;
     D.accepted_slack = b->accepted_slack;
+    D.hot = (s->hotstart && !prof) ? s->d_hot : nullptr;
     hipStream_t st = (hipStream_t)hip_stream;
     if (s->schedule == 1) {
         if (s->order_B >= 0 && s->order_stream != st) HIP_TRY(hipStreamSynchronize(s->order_stream));
-        D.order = (s->order_B == b->B) ? s->d_order : nullptr;
-        D.cost_out = s->d_cost;
+        const size_t mb = (size_t)s->max_batch;
+        D.order = (s->order_B == b->B) ? s->d_order + (size_t)(s->flip ^ 1) * mb : nullptr;
+        D.cost_in = s->d_cost + (size_t)(s->flip ^ 1) * mb;
+        D.cost_out = s->d_cost + (size_t)s->flip * mb;
+        D.order_next = s->d_order + (size_t)s->flip * mb;
+        D.slots = s->slots;
     }
-    const unsigned grid = (unsigned)b->B;
+    const unsigned grid = (unsigned)b->B + (D.order_next ? 1u : 0u);   // (+ the order workgroup, block 0)
     std::pair<hipEvent_t, hipEvent_t> ev;
-    if (s->timing) {
+    const bool timed = s->timing && (s->timing_count++ % s->timing_stride) == 0;
+    if (timed) {
         if (!s->pool.empty()) { ev = s->pool.back(); s->pool.pop_back(); }
         else { HIP_TRY(hipEventCreate(&ev.first)); HIP_TRY(hipEventCreate(&ev.second)); }
         HIP_TRY(hipEventRecord(ev.first, st));
@@ -401,13 +448,12 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
         else hipLaunchKernelGGL((osot_cascade_kernel<64, false>), dim3(grid), dim3(64), lds, st, P, D);
     }
     HIP_TRY(hipGetLastError());
-    if (s->timing) {
+    if (timed) {
         HIP_TRY(hipEventRecord(ev.second, st));
         s->events.push_back(ev);
     }
-    if (s->schedule == 1) {   // the order for the next solve of a batch of this size
-        hipLaunchKernelGGL(osot_order_kernel, dim3(1), dim3(1024), 0, st, (const int*)s->d_cost, s->d_order, b->B, s->slots);
-        HIP_TRY(hipGetLastError());
+    if (s->schedule == 1) {   // this launch's order workgroup has written the order for the next solve of a batch of this size
+        s->flip ^= 1;
         s->order_B = b->B;
         s->order_stream = st;
     }

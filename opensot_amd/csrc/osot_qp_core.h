@@ -793,7 +793,8 @@ __device__ inline bool direction_is_independent(const WaveCtx<NP>& w, double nd2
 template <int NP, bool PROF>
 __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq, const int me, int Aq, double uq,
                                int iters, bool has_box, double& lb, double& ub, int max_iter, bool diag_dd, double hinv,
-                               bool have_prev, double xprev, double& slack_out, double& x_out, int& iters_out, long long* prof);
+                               bool have_prev, double xprev, double& slack_out, double& x_out, int& iters_out, long long* prof,
+                               int hotcode, int* hot_out);
 
 // ---------------------------------------------------------------------------------------------------------
 // Low-rank level (NP = 32):  H + eps I = D + A'WA with D diagonal and at most kLowRankMax stored rows
@@ -962,7 +963,7 @@ template <int NP, bool PROF>
 __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_h,
                         double hdiag, double (&Hc)[NP / (64 / NP)], bool has_box, double& lb, double& ub, int max_iter,
                         bool have_prev, double xprev, double& x_out, int& iters_out, long long* prof,
-                        double& slack_out, bool prepared = false, double xprep = 0.0) {
+                        double& slack_out, bool prepared = false, double xprep = 0.0, int hotcode = -1, int* hot_out = nullptr) {
     constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
     const int n = w_in.n;
     double* M1 = w_in.M1;
@@ -1100,13 +1101,14 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
     // the diagonal of H^-1 does (hinv > 0 selects that in the dependency test)
     const double hinv = (used_nullspace && valid) ? fast_rcp(hdiag) : 0.0;
     return gi_inequalities<NP, PROF>(w3, nrows, x, iq, me, Aq, uq, iters, has_box, lb, ub, max_iter, used_nullspace, hinv,
-                                     have_prev, xprev, slack_out, x_out, iters_out, prof);
+                                     have_prev, xprev, slack_out, x_out, iters_out, prof, hotcode, hot_out);
 }
 
 template <int NP, bool PROF>
 __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq, const int me, int Aq, double uq,
                                int iters, bool has_box, double& lb, double& ub, int max_iter, bool diag_dd, double hinv,
-                               bool have_prev, double xprev, double& slack_out, double& x_out, int& iters_out, long long* prof) {
+                               bool have_prev, double xprev, double& slack_out, double& x_out, int& iters_out, long long* prof,
+                               int hotcode, int* hot_out) {
     constexpr int S = WaveCtx<NP>::S;
     const int c = w.c, h = w.h, n = w.n;
     const bool valid = c < n;
@@ -1147,11 +1149,62 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
         if (lb > -kInfty) lb = fmin(lb, xprev - kFeasMargin * fmax(1.0, fabs(lb)));
         if (ub < kInfty) ub = fmax(ub, xprev + kFeasMargin * fmax(1.0, fabs(ub)));
     }
+    // HOT START (the reference's qpOASES back-end keeps its working set from one control cycle to the next:
+    // QPOasesBackEnd.cpp:258-285 hotstart -> SQProblem.cpp:149-193).  hotcode = lane q's entry of the inequality working set
+    // this level ended with at the instance's previous solve (-1: none).  Those constraints are re-added first, each as if it
+    // were an equality (a SIGNED step onto its boundary, multipliers updated by the same dual direction, no scan and no
+    // ratio test); then every constraint whose multiplier came out negative is taken out again by the reverse of an
+    // addition (x' = x - u_k z, u' = u + u_k r with z, r of the normal against the factors of the set without it).  Each
+    // removal moves to the minimiser over a subset, f strictly decreases, so the phase ends; what is left is an S-pair
+    // (x minimises f on the working set, all multipliers >= 0) -- a valid state of the dual method, which then goes on
+    // as from a cold start.  The minimiser is unique, so the answer is the cold one up to round-off; what changes is the
+    // number of iterations (no add-then-drop churn, no scans for the constraints that stay active from cycle to cycle).
+    const int hot_n = __builtin_popcountll(wave_ballot(hotcode >= 0 && h == 0));
+    int hot_i = 0;
+    bool hot_check = false;     // hot additions were made: their multipliers have to be looked at
+    constexpr double kHotDropTol = 1.0e-13;   // a multiplier below -kHotDropTol max|u| is negative (above: round-off of zero)
     for (;;) {
         OSOT_SUB_BEGIN();
-        // most violated constraint outside the working set (eiquadprog.hpp:300-315 picks the same)
+        // trip kind: 0 = scan for the most violated constraint (the dual method proper), 1 = re-add the next constraint of the
+        // previous cycle's working set, 2 = take out a hot constraint whose multiplier is negative
+        int mode = 0;
         double cand = 0.0;
         int code = kNone;
+        double u_rev = 0.0;
+        if (!margin_pass && hot_i < hot_n) {
+            code = bcast_i(hotcode, hot_i);
+            hot_i++;
+            mode = 1;
+            // still a constraint of this level's problem, with a finite bound on that side, and not in the working set?
+            bool okc = false;
+            if (code >= 0 && code < 2 * n) {
+                const int var = (code < n) ? code : code - n;
+                const double bnd = bcast((code < n) ? lb : ub, var);
+                okc = has_box && (bcast_i(box_state, var) == 0) && ((code < n) ? (bnd > -kInfty) : (bnd < kInfty));
+            } else if (code >= 2 * n && code < 2 * n + 2 * nrows) {
+                const int r = (code - 2 * n) >> 1;
+                const double bnd = (code & 1) ? w.rup[r] : w.rlo[r];
+                okc = (w.rowstate[r] == 0) && ((code & 1) ? (bnd < kInfty) : (bnd > -kInfty));
+            }
+            if (!okc) continue;
+        } else if (!margin_pass && hot_check) {
+            const bool mine = (c >= me && c < iq);
+            double um = mine ? uq : INFINITY;
+            int pos = c;
+            const double uabs = colmax<NP>(mine ? fabs(uq) : 0.0);
+            colargmin<NP>(um, pos);
+            pos = uniform_i(pos);
+            um = bcast(um, 0);
+            if (!(um < -kHotDropTol * uabs)) { hot_check = false; continue; }
+            mode = 2;
+            u_rev = um;
+            code = bcast_i(Aq, pos);
+            if (code < 2 * n) { if (c == (code < n ? code : code - n)) box_state = 0; }
+            else { if (c == 0 && h == 0) w.rowstate[(code - 2 * n) >> 1] = 0; }
+            drop_constraint<NP>(w, pos, iq, Aq, uq);
+            wave_sync();
+        } else {
+        // most violated constraint outside the working set (eiquadprog.hpp:300-315 picks the same)
         if (has_box && valid) {
             if (box_state != 1 && lb > -kInfty) {
                 const double s = x - lb;
@@ -1263,6 +1316,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
         code = uniform_i(code);
         OSOT_SUB_END(PH_IN_SCAN);
         if (code == kNone) break;   // primal feasible: optimal
+        }   // (end of the scan trip)
         if (++iters > max_iter) { status = QP_MAX_ITER; break; }
 
         const int ip = code;
@@ -1277,6 +1331,13 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
         const unsigned long long ip_ptr = ip_box ? 0ull : w.rptr[ip_row];
         const bool ip_unit = !ip_box && (ip_ptr & 1ull);      // unit row e_i: d = J'n is a row read, like a bound
         const int ip_uidx = ip_unit ? (int)(ip_ptr >> 1) : 0;
+        if (mode == 1) {   // slack of the hot constraint at the current iterate (either sign)
+            if (ip_box) s_ip = bcast((ip < n) ? (x - lb) : (ub - x), ip_var);
+            else {
+                const double ax = colsum<NP>(np * x);   // = sgn * a'x
+                s_ip = bcast((ip & 1) ? (w.rup[ip_row] + ax) : (ax - w.rlo[ip_row]), 0);
+            }
+        }
 
         bool failed = false, degenerate_done = false;
         for (;;) {
@@ -1345,12 +1406,22 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
             // one (kRatioTol): r = R^-1 d1 carries ~1e-16 cond(R) of noise, and a noise-level "positive" entry that happens to
             // be the only one gives a dual step of u / r ~ 1e8 that wrecks every multiplier (seen in the closed-loop sweep at
             // the default eps; qpOASES guards its ratio tests the same way, epsNum / epsDen in Constants.hpp)
-            double t1 = (c >= me && c < iq && rr > kRatioTol * rmax) ? fast_div(fmax(uq, 0.0), rr) : INFINITY;
+            if (mode == 2) {   // reverse of the addition of a hot constraint whose multiplier u_rev is negative
+                if (z_ok) x -= u_rev * z;
+                if (c >= me && c < iq) uq += u_rev * rr;
+                OSOT_SUB_END(PH_IN_DROP);
+                break;
+            }
+            if (mode == 1 && !z_ok) break;   // in the span of the working set by now: left to the scan
+            double t1 = INFINITY;
             int lpos = c;
-            colargmin<NP>(t1, lpos);
-            lpos = uniform_i(lpos);
-            t1 = bcast(t1, 0);
-            const double t2 = z_ok ? (-s_ip * fast_rcp(nd2)) : INFINITY;
+            if (mode == 0) {
+                t1 = (c >= me && c < iq && rr > kRatioTol * rmax) ? fast_div(fmax(uq, 0.0), rr) : INFINITY;
+                colargmin<NP>(t1, lpos);
+                lpos = uniform_i(lpos);
+                t1 = bcast(t1, 0);
+            }
+            const double t2 = z_ok ? (-s_ip * fast_rcp(nd2)) : INFINITY;   // (mode 1: a signed step onto the boundary)
             OSOT_SUB_END(PH_IN_R);
             if (!(t1 < INFINITY) && !(t2 < INFINITY)) {
                 // no primal direction left and no inequality to trade.  If the most violated constraint is
@@ -1383,6 +1454,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                 if (ip_box) { if (c == ip_var) box_state = (ip < n) ? 1 : 2; }
                 else { if (c == 0 && h == 0) w.rowstate[ip_row] = (ip & 1) ? 2 : 1; }
                 iq++;
+                hot_check = hot_check || (mode == 1);
                 wave_sync();
                 OSOT_SUB_END(PH_IN_HH);
                 break;
@@ -1410,6 +1482,11 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
         if (degenerate_done) continue;   // (bounded: every trip of the outer loop counts against max_iter)
     }
     OSOT_PH_END(PH_INEQ);
+    if (hot_out) {   // the inequality part of the working set, compacted to the front, for the next solve of this instance
+        const bool act = (status == QP_SOLVED) && c >= me && c < iq;
+        const int slot = (c >= me) ? c - me : c + NP - me;
+        if (h == 0) hot_out[slot] = act ? Aq : -1;
+    }
     x_out = x;
     iters_out = iters;
     return status;

@@ -33,14 +33,21 @@ class ShardGather:
     extra enqueue work costs more than the 1 MB copy it hides), so it stays an option for worlds where the collective
     itself is long."""
 
-    def __init__(self, total, n, device, dtype, group=None, overlap=False):
+    def __init__(self, total, n, device, dtype, group=None, overlap=False, sizes=None):
         import torch
         import torch.distributed as dist
         self.torch = torch
         self.dist, self.group = dist, group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.total, self.n = total, n
-        self.sizes = [shard_range(total, r, self.world)[1] - shard_range(total, r, self.world)[0] for r in range(self.world)]
+        # rows per rank: the block partition of `total`, or given explicitly (a LANE of a pipelined rank gathers the
+        # matching sub-batches of all ranks: sizes[r] = rows of that lane on rank r, total = their sum)
+        if sizes is not None:
+            if len(sizes) != self.world or sum(sizes) != total:
+                raise ValueError("sizes must list one row count per rank and add up to total")
+            self.sizes = [int(v) for v in sizes]
+        else:
+            self.sizes = [shard_range(total, r, self.world)[1] - shard_range(total, r, self.world)[0] for r in range(self.world)]
         self.mx = max(self.sizes) if self.sizes else 0
         self.even = all(s == self.mx for s in self.sizes)
         self.overlap = bool(overlap) and torch.device(device).type == "cuda"
@@ -59,7 +66,9 @@ class ShardGather:
 
     def bind(self, stack):
         """the stack's dq / status outputs become views of the NEXT step's send block"""
-        stack.dq, stack.status = self._views(self.send_b[self.i % len(self.send_b)])
+        b = self.i % len(self.send_b)
+        self._wait(b)   # (overlap: the asynchronous gather that last READ this block is over before the solver rewrites it)
+        stack.dq, stack.status = self._views(self.send_b[b])
 
     def _gather(self, recv, send, async_op=False):
         if hasattr(self.dist, "all_gather_into_tensor"):
@@ -115,6 +124,10 @@ class ShardedCycle:
         self.gather = gather
         self.bind = bind and gather is not None and hasattr(stack, "cycle")   # (a real BatchedStack: outputs are re-pointable)
         self.i = 0
+        # a real BatchedStack can keep the argument structs of a (cycle inputs, Jacobian set, output block) combination:
+        # the dev_leaves / A_sets handed in here are never replaced, only written into
+        import inspect
+        self._cached = hasattr(stack, "cycle") and "cached" in inspect.signature(stack.cycle).parameters
 
     def step(self):
         k = self.i % len(self.dev_leaves)
@@ -124,12 +137,115 @@ class ShardedCycle:
         if self.gather is not None and self.bind:
             self.gather.bind(self.stack)     # the solver writes dq / status straight into the collective's send block
         if hasattr(self.stack, "cycle"):     # update + solve in one launch (BatchedStack.cycle), same results
-            self.stack.cycle(self.dev_leaves[k])
+            if self._cached:
+                self.stack.cycle(self.dev_leaves[k], cached=True)
+            else:
+                self.stack.cycle(self.dev_leaves[k])
         else:
             self.stack.update(self.dev_leaves[k])
             self.stack.solve(self.B)
         if self.gather is not None:
             self.gather(self.stack.dq[:self.B], self.stack.status[:self.B])
+
+
+def lane_ranges(B, lanes):
+    """[lo, hi) of each of the `lanes` contiguous sub-batches of a rank's B instances (same rule as shard_range)"""
+    return [shard_range(B, i, lanes) for i in range(lanes)]
+
+
+class PipelinedCycle:
+    """A rank's shard as S contiguous SUB-BATCHES ("lanes"), each with its own solver state and its own stream, and NO
+    join between steps: lane j's step t+1 is enqueued behind lane j's step t only.  That is exactly the dependency the
+    control loop has -- instance i's cycle t+1 needs instance i's cycle t and nothing else (instances are
+    independent) -- while a single launch per step also makes every instance wait for the slowest instance of the whole
+    batch.  One wavefront solves one instance and the chip holds a fixed number of them, so a 4096-instance launch is two
+    rounds whose tail (a few wavefronts with twice the average iteration count) leaves most of the chip idle; with two
+    lanes the other lane's next launch fills those slots.  Measured at BASELINE config 3, B = 4096: 24.2 -> 27.3 M solves/s
+    with 2 lanes (4 lanes: the same; the floor is the longest single instance, which every step has to wait for in ITS
+    lane).  Results are identical to the single-launch form (instances do not interact).
+
+    lanes: a list of ShardedCycle (each over its own stack / sub-batch / gather); streams: one per lane (torch.cuda.Stream)
+    or None to run the lanes in turn on the current stream (CPU tests).  `step()` enqueues one step of every lane;
+    completion is the caller's synchronise (timed_steps brackets K steps with one on each side)."""
+
+    def __init__(self, lanes, streams=None):
+        self.lanes = list(lanes)
+        self.streams = list(streams) if streams is not None else [None] * len(self.lanes)
+        if len(self.streams) != len(self.lanes):
+            raise ValueError("one stream per lane")
+        self._torch = None
+        if any(st is not None for st in self.streams):
+            import torch
+            self._torch = torch
+        # a lane whose only device work is the solver's own launches takes its stream as an argument (BatchedStack.stream);
+        # only a lane with a collective behind the solve needs torch's stream context (the gather runs on the current stream)
+        self._ctx = []
+        for lane, st in zip(self.lanes, self.streams):
+            direct = st is not None and lane.gather is None and hasattr(lane.stack, "stream")
+            if direct:
+                lane.stack.stream = st
+            self._ctx.append(st is not None and not direct)
+
+    def step(self):
+        for lane, st, ctx in zip(self.lanes, self.streams, self._ctx):
+            if not ctx:
+                lane.step()
+            else:
+                with self._torch.cuda.stream(st):
+                    lane.step()
+
+
+class StubStack:
+    """NOT a solver: a stand-in with BatchedStack's per-step surface on CPU tensors, so that bench.py's own launcher,
+    sharding, lanes and gather can be run end to end where there is no GPU (`bench.py --backend stub`, world of two on gloo
+    in tests/test_distributed_cpu.py).  Its "dq" is a checksum of the cycle's inputs per instance; bench.py labels every line
+    it produces as a stub line."""
+
+    def __init__(self, plan, max_batch, device=0, want_levels=False):
+        import torch
+        self.torch, self.plan, self.max_batch = torch, plan, int(max_batch)
+        self.device = torch.device("cpu")
+        n, L, B = plan.n, plan.L, self.max_batch
+        self.A = [torch.zeros((B, plan.ma(k), n), dtype=torch.float64) if plan.ma(k) else None for k in range(L)]
+        self.dq = torch.zeros((B, n), dtype=torch.float64)
+        self.status = torch.full((B,), -1, dtype=torch.int32)
+        self.launches = 0
+
+    def load_leaf(self, leaf):
+        import numpy as np
+        B = leaf["B"]
+        for k in range(self.plan.L):
+            if self.A[k] is not None:
+                self.A[k][:B].copy_(self.torch.as_tensor(np.ascontiguousarray(leaf["A"][k])))
+        return {"B": B}
+
+    def update(self, dev_leaf):
+        self._B = dev_leaf["B"]
+
+    def solve(self, B):
+        acc = self.torch.zeros((B, self.plan.n), dtype=self.torch.float64)
+        for a in self.A:
+            if a is not None:
+                acc += a[:B].sum(dim=1)
+        self.dq[:B] = acc
+        self.status[:B] = 0
+        self.launches += 1
+
+    def cycle(self, dev_leaf, write_weights=True, cached=False):
+        self.update(dev_leaf)
+        self.solve(dev_leaf["B"])
+
+    def set_timing(self, on, stride=1):
+        self.launches = 0
+
+    def set_schedule(self, longest_first=True):
+        pass
+
+    def kernel_time_ms(self, reset=True):
+        c = self.launches
+        if reset:
+            self.launches = 0
+        return (1.0e-3, c)
 
 
 def timed_steps(step, steps, warmup, sync, dist=None, device=None):

@@ -21,8 +21,8 @@ def _dev_ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _stream_ptr(device):
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+def _stream_ptr(device, stream=None):
+    return C.c_void_p((stream if stream is not None else torch.cuda.current_stream(device)).cuda_stream)
 
 
 def stored_rows(plan, C_dense):
@@ -71,6 +71,8 @@ class BatchedStack:
         self.iterations = torch.zeros((B,), dtype=torch.int32, device=self.device)
         self.accepted_slack = torch.zeros((B,), **f64)   # largest violation accepted as round-off, per instance
         self._leaf_keep = None
+        self.stream = None         # torch.cuda.Stream every call of this stack is enqueued on (None: torch's current stream)
+        self._cycle_args = {}
         self.level_active = None   # iHQP::setActiveStack (iHQP.cpp:391-395)
 
     def __del__(self):
@@ -156,16 +158,33 @@ class BatchedStack:
         alone (out.w[k] = NULL), for per-row DIAGONAL weight matrices (Task::setWeight(W) with a diagonal W,
         Aggregated.cpp:265-279) that the caller filled once"""
         lb, out = self._update_args(dev_leaf, write_weights)
-        abi.check(self._lib.osot_stack_update(self._h, C.byref(lb), C.byref(out), _stream_ptr(self.device)),
+        abi.check(self._lib.osot_stack_update(self._h, C.byref(lb), C.byref(out), _stream_ptr(self.device, self.stream)),
                   "osot_stack_update")
         return lb.B
 
-    def cycle(self, dev_leaf, write_weights=True):
+    def cycle(self, dev_leaf, write_weights=True, cached=False):
         """one control cycle, `stack->update(); solver->solve(dq)` (coman_ik.cpp:186-192), in ONE launch: same results as
         update() followed by solve()"""
-        lb, out = self._update_args(dev_leaf, write_weights)
-        qb = self._qp_batch(lb.B)
-        abi.check(self._lib.osot_cycle(self._h, C.byref(lb), C.byref(out), C.byref(qb), _stream_ptr(self.device)), "osot_cycle")
+        # the three argument structs only hold pointers and sizes: they are rebuilt when a tensor they point at has been
+        # replaced (the per-cycle Jacobian sets, the gather's send block ...), not on every call -- building them is ~30 us
+        # of host time, a fifth of the launch they describe
+        key = (id(dev_leaf), write_weights,
+               tuple(0 if a is None else a.data_ptr() for a in self.A), self.dq.data_ptr(), self.status.data_ptr(),
+               0 if self.x_levels is None else self.x_levels.data_ptr())
+        # (cached=True is the caller's promise that dev_leaf's tensors and the stack's other buffers are not REPLACED
+        #  between calls -- writing into them is fine; the per-cycle A sets and the output tensors are part of the key)
+        cached = cached and self.level_active is None
+        hit = self._cycle_args.get(key) if cached else None
+        if hit is None:
+            lb, out = self._update_args(dev_leaf, write_weights)
+            qb = self._qp_batch(lb.B)
+            hit = (lb, out, qb, dev_leaf)
+            if cached:
+                if len(self._cycle_args) > 64:
+                    self._cycle_args.clear()
+                self._cycle_args[key] = hit
+        lb, out, qb, _ = hit
+        abi.check(self._lib.osot_cycle(self._h, C.byref(lb), C.byref(out), C.byref(qb), _stream_ptr(self.device, self.stream)), "osot_cycle")
         return lb.B
 
     # ---- Solver::solve ------------------------------------------------------------------------------
@@ -191,7 +210,7 @@ class BatchedStack:
     def solve(self, B):
         """stream-ordered; results in self.dq[:B], self.status[:B] (device)."""
         qb = self._qp_batch(B)
-        abi.check(self._lib.osot_ihqp_solve(self._h, C.byref(qb), _stream_ptr(self.device)), "osot_ihqp_solve")
+        abi.check(self._lib.osot_ihqp_solve(self._h, C.byref(qb), _stream_ptr(self.device, self.stream)), "osot_ihqp_solve")
 
     def solve_nhqp(self, B, free_vars=None, min_sv_ratio=0.0, ab_regularization=True, selective_ns_regularization=True):
         """Solver::solve() with the reference's NULL-SPACE front-end, OpenSoT::solvers::nHQP (nHQP.cpp:155-204), on the same
@@ -205,14 +224,14 @@ class BatchedStack:
         opt.no_ab_regularization = 0 if ab_regularization else 1
         opt.no_selective_ns_regularization = 0 if selective_ns_regularization else 1
         qb = self._qp_batch(B)
-        abi.check(self._lib.osot_nhqp_solve(self._h, C.byref(qb), C.byref(opt), _stream_ptr(self.device)), "osot_nhqp_solve")
+        abi.check(self._lib.osot_nhqp_solve(self._h, C.byref(qb), C.byref(opt), _stream_ptr(self.device, self.stream)), "osot_nhqp_solve")
 
     def solve_ehqp(self, B, sigma_min=0.0):
         """Solver::solve() with the reference's EQUALITY-ONLY front-end, OpenSoT::solvers::eHQP (eHQP.cpp:64-95): damped
         pseudo-inverses and projectors on the same assembled arrays; the stack's constraints and bounds are not used (as in
         the reference).  sigma_min 0 = the reference's 1e-12.  Stream-ordered, results in self.dq[:B] / self.status[:B]"""
         qb = self._qp_batch(B)
-        abi.check(self._lib.osot_ehqp_solve(self._h, C.byref(qb), float(sigma_min), _stream_ptr(self.device)), "osot_ehqp_solve")
+        abi.check(self._lib.osot_ehqp_solve(self._h, C.byref(qb), float(sigma_min), _stream_ptr(self.device, self.stream)), "osot_ehqp_solve")
 
     PHASES = ("hbuild", "chol", "inverse", "subst", "equalities", "inequalities", "opt_rhs", "total",
               "eq:J'a", "eq:reductions", "eq:z", "eq:householder",
@@ -222,7 +241,7 @@ class BatchedStack:
         """diagnostic: per-instance shader-clock cycles per phase, [B][OSOT_N_PHASES] (see PHASES)."""
         cyc = torch.zeros((B, len(self.PHASES)), dtype=torch.int64, device=self.device)
         qb = self._qp_batch(B)
-        abi.check(self._lib.osot_solver_profile_phases(self._h, C.byref(qb), _dev_ptr(cyc), _stream_ptr(self.device)),
+        abi.check(self._lib.osot_solver_profile_phases(self._h, C.byref(qb), _dev_ptr(cyc), _stream_ptr(self.device, self.stream)),
                   "osot_solver_profile_phases")
         torch.cuda.synchronize(self.device)
         return cyc.cpu().numpy()
@@ -242,8 +261,14 @@ class BatchedStack:
         or plain instance order; results are identical either way."""
         abi.check(self._lib.osot_solver_set_schedule(self._h, 1 if longest_first else 0), "osot_solver_set_schedule")
 
-    def set_timing(self, on):
-        abi.check(self._lib.osot_solver_set_timing(self._h, 1 if on else 0), "osot_solver_set_timing")
+    def set_hotstart(self, on=True):
+        """hot start of every level's working set from the instance's previous solve (qpOASES' hotstart,
+        QPOasesBackEnd.cpp:258-285); switching it on (again) forgets the recorded sets.  Default off."""
+        abi.check(self._lib.osot_solver_set_hotstart(self._h, 1 if on else 0), "osot_solver_set_hotstart")
+
+    def set_timing(self, on, stride=1):
+        """HIP-event timing of the cascade / cycle launches (kernel_time_ms); stride k: every k-th launch only"""
+        abi.check(self._lib.osot_solver_set_timing(self._h, (max(1, int(stride)) if on else 0)), "osot_solver_set_timing")
 
     def kernel_time_ms(self, reset=True):
         avg = C.c_double(0.0); cnt = C.c_int(0)

@@ -148,6 +148,10 @@ def perturb(leaf, rng, scale=0.01):
            "task": [[tuple(j(x) for x in t) for t in lev] for lev in leaf["task"]],
            "bound": [tuple(j(x) for x in t) for t in leaf["bound"]],
            "rows": [tuple(j(x) for x in t) for t in leaf["rows"]]}
+    if leaf.get("C") is not None:      # producer-written constraint rows (config 5: [B_u, -J_f'], [B, -Jc'])
+        out["C"] = [j(a) for a in leaf["C"]]
+    if leaf.get("W") is not None:      # dense task weights stay as they are (symmetric positive definite)
+        out["W"] = leaf["W"]
     if "reg" in leaf:
         out["reg"] = tuple(j(x) for x in leaf["reg"])
     return out

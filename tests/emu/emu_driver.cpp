@@ -14,8 +14,9 @@
 using namespace osot;
 
 // task_active: [OSOT_MAX_LEVELS * OSOT_MAX_TASKS] Task::setActive flags, or null
+// hot: [B][L][32 or 64] hot-start state (constraint codes, -1 = none; read and rewritten), or null for a cold start
 extern "C" __attribute__((visibility("default"))) int emu_ihqp_solve(const osot_plan_desc* plan, const osot_qp_batch* b,
-                                                                     const unsigned char* task_active) {
+                                                                     const unsigned char* task_active, int* hot) {
     const char* why;
     int rc = plan_validate(plan, &why);
     if (rc != OSOT_OK) { fprintf(stderr, "emu: %s\n", why); return rc; }
@@ -30,6 +31,7 @@ extern "C" __attribute__((visibility("default"))) int emu_ihqp_solve(const osot_
     D.dq = b->dq; D.x_levels = b->x_levels; D.status = b->status; D.iterations = b->iterations;
     D.b_reg = plan->has_regularisation ? b->b_reg : nullptr;
     D.accepted_slack = b->accepted_slack;
+    D.hot = hot;
     const unsigned grid = (unsigned)b->B;
     // (the emulation always runs the instantiation with the dense-weight / inactive-task code: it is a superset)
     if (T == 32) emu::launch(osot_cascade_kernel<32, false, true>, grid, lds, 64, P, D);

@@ -39,17 +39,14 @@ def emu_lib():
     global _emu
     if _emu is None:
         so = os.path.join(ROOT, "tests", "emu", "libosot_emu.so")
-        srcs = [os.path.join(ROOT, "tests", "emu", "emu_driver.cpp"),
-                os.path.join(ROOT, "opensot_amd", "csrc", "osot_qp_core.h"),
-                os.path.join(ROOT, "opensot_amd", "csrc", "osot_kernels.h"),
-                os.path.join(ROOT, "opensot_amd", "csrc", "osot_host_plan.h"),
-                os.path.join(ROOT, "opensot_amd", "csrc", "osot_kin.h"),
-                os.path.join(ROOT, "opensot_amd", "csrc", "osot_id.h"),
-                os.path.join(ROOT, "include", "osot_mi355x.h")]
+        import glob
+        srcs = (glob.glob(os.path.join(ROOT, "opensot_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+                + [f for f in glob.glob(os.path.join(ROOT, "tests", "emu", "**", "*"), recursive=True)
+                   if os.path.isfile(f) and not f.endswith(".so")])
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["sh", os.path.join(ROOT, "tests", "emu", "build.sh")])
         L = C.CDLL(so)
-        L.emu_ihqp_solve.argtypes = [C.POINTER(abi.PlanDesc), C.POINTER(abi.QpBatch), C.c_void_p]
+        L.emu_ihqp_solve.argtypes = [C.POINTER(abi.PlanDesc), C.POINTER(abi.QpBatch), C.c_void_p, C.c_void_p]
         L.emu_stack_update.argtypes = [C.POINTER(abi.PlanDesc), C.POINTER(abi.LeafBatch), C.POINTER(abi.AssembledOut)]
         vp = C.c_void_p
         L.emu_qp_solve_batch.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp,
@@ -58,9 +55,10 @@ def emu_lib():
     return _emu
 
 
-def emu_cascade(plan, asm, active=None, task_active=None):
+def emu_cascade(plan, asm, active=None, task_active=None, hot=None):
     """run the cascade kernel body on host pointers through the emulator.  task_active: {(level, task): bool}
-    (Task::setActive); asm may carry "WA" / "Wb" (levels with a non-diagonal weight, see emu_update)"""
+    (Task::setActive); asm may carry "WA" / "Wb" (levels with a non-diagonal weight, see emu_update); hot: int32
+    [B][L][32 or 64] hot-start state (read and rewritten in place; start from -1 everywhere), None = cold start"""
     B, n, L = asm["B"], asm["n"], asm["L"]
     qb = abi.QpBatch()
     qb.B = B
@@ -105,7 +103,10 @@ def emu_cascade(plan, asm, active=None, task_active=None):
         ta = (C.c_ubyte * (abi.MAX_LEVELS * abi.MAX_TASKS))(*([1] * (abi.MAX_LEVELS * abi.MAX_TASKS)))
         for (k, j), on in task_active.items():
             ta[k * abi.MAX_TASKS + j] = 1 if on else 0
-    rc = emu_lib().emu_ihqp_solve(C.byref(pd), C.byref(qb), C.cast(ta, C.c_void_p) if ta is not None else None)
+    if hot is not None:
+        assert hot.dtype == np.int32 and hot.flags.c_contiguous and hot.shape == (B, L, 32 if n <= 32 else 64)
+    rc = emu_lib().emu_ihqp_solve(C.byref(pd), C.byref(qb), C.cast(ta, C.c_void_p) if ta is not None else None,
+                                  hot.ctypes.data if hot is not None else None)
     assert rc == 0
     return dq, xl, st, it
 

@@ -104,3 +104,76 @@ def test_two_rank_step_loop_and_gather(total, fused):
         np.testing.assert_array_equal(status, (idx % 3 == 0).astype(np.int32))
         assert order_ok and elapsed > 0.0
     assert res[0][5] == res[1][5]                            # the elapsed time is the MAX over ranks on every rank
+
+
+def _lane_worker(rank, world, port, per_rank, S, n, q):
+    """a rank's shard as S lanes (PipelinedCycle), each lane with its OWN process group and gather -- bench.py's layout"""
+    from opensot_amd.parallel import PipelinedCycle, lane_ranges
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo = rank * per_rank
+    K = 2
+    lanes, gathers = [], []
+    spans = lane_ranges(per_rank, S)
+    for a, b in spans:
+        grp = dist.new_group(list(range(world)))
+        stack = _StubFusedStack(lo + a, lo + b, n)
+        stack.B = b - a
+        g = ShardGather((b - a) * world, n, torch.device("cpu"), torch.float64, group=grp, sizes=[b - a] * world)
+        lanes.append(ShardedCycle(stack, [{"bias": 100.0 * k} for k in range(K)], [1000.0 * k for k in range(K)], b - a, g))
+        gathers.append(g)
+    pipe = PipelinedCycle(lanes, None)
+    steps, warmup = 3, 1
+    elapsed = timed_steps(pipe.step, steps, warmup, sync=lambda: None, dist=dist, device=torch.device("cpu"))
+    last = (steps + warmup - 1) % K
+    q.put((rank, [g.dq.numpy().copy() for g in gathers], [g.status.numpy().copy() for g in gathers], last, elapsed))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_pipelined_lanes():
+    """world of two, two lanes per rank with uneven sub-batches (5 = 3 + 2): lane j's gather holds lane j of rank 0, then
+    lane j of rank 1, each with the values its global instance index dictates"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    per_rank, S, n = 5, 2, 4
+    procs = [ctx.Process(target=_lane_worker, args=(r, 2, port, per_rank, S, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from opensot_amd.parallel import lane_ranges
+    spans = lane_ranges(per_rank, S)
+    for rank, dqs, sts, last, elapsed in res:
+        for j, (a, b) in enumerate(spans):
+            idx = np.concatenate([np.arange(r * per_rank + a, r * per_rank + b) for r in range(2)])
+            want = idx[:, None] * 10.0 + np.arange(n)[None, :] + 100.0 * last + 1000.0 * last
+            np.testing.assert_array_equal(dqs[j], want)
+            np.testing.assert_array_equal(sts[j], (idx % 3 == 0).astype(np.int32))
+        assert elapsed > 0.0
+
+
+def test_bench_self_launches_two_ranks_on_the_stub_backend():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py re-executes itself under
+    torch.distributed.run with two ranks; here on the stub back-end (CPU tensors, gloo), which runs the script's own
+    sharding, lanes, per-lane gathers and timing bracket end to end.  rc 0 and ONE JSON line with n_gpus 2."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "stub", "--steps", "3",
+                        "--warmup", "1", "--batch-per-gpu", "48", "--lanes", "2"], capture_output=True, text=True, timeout=600,
+                       env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["config"]["global_batch"] == 96
+    assert out["solved_ok_all_ranks"] == "96/96" and "STUB" in out["data"]

@@ -5,7 +5,9 @@ import numpy as np
 import pytest
 
 from helpers import answer_is_acceptable, default_eps_stuck_instances, emu_cascade, emu_qp, kkt_check, load_golden, random_qp
+import helpers
 from opensot_amd import synth
+from oracle import pyoracle
 
 EPS = 1e3 * 2.221e-16
 
@@ -438,3 +440,50 @@ def test_task_local_bounds_as_unit_rows(n, rows, level, oracle):
     xg = emu_cascade(plan_g, oracle.assemble(plan_g, leaf_g))[0]
     xb = emu_cascade(plan_b, oracle.assemble(plan_b, leaf_b))[0]
     assert np.abs(xg - xb).max() < 1e-9
+
+
+def test_hot_start_matches_cold_start_emulated():
+    """hot start (osot_solver_set_hotstart; reference: QPOasesBackEnd.cpp:258-285, SQProblem.cpp:149-193): every level's
+    working set of the previous cycle is re-added with signed steps, wrong guesses are taken out by the reverse of an
+    addition.  Same answer as the cold start to round-off (unique minimiser per level); on an EXACT repeat of a cycle the
+    hot list is the final active set, so no constraint is added twice or dropped: never more iterations than cold."""
+    B = 48
+    plan, leaf = synth.make_velocity_stack("C4", B, seed=4100)
+    rng = np.random.default_rng(5)
+    leaves = [leaf, synth.perturb(leaf, rng, 0.01)]
+    hot = np.full((B, plan.L, 32), -1, dtype=np.int32)
+    for i, lf in enumerate(leaves + [leaves[1]]):
+        asm = pyoracle.assemble(plan, lf)
+        dq0, _, st0, it0 = helpers.emu_cascade(plan, asm)
+        dq1, _, st1, it1 = helpers.emu_cascade(plan, asm, hot=hot)
+        assert (st0 == 0).all() and (st1 == 0).all()
+        assert np.abs(dq0 - dq1).max() < 1e-9
+        if i == 0:
+            assert (it0 == it1).all()                      # an empty hot list IS a cold start
+            assert (hot >= 0).any()                        # ... and the final working sets were recorded
+        if i == 2:                                         # exact repeat of cycle 1: the hot list is the final active set
+            assert (it1 <= it0).all() and it1.sum() < it0.sum()
+    # a hot list that is plain wrong (every lower bound of level 0, garbage codes) only costs iterations
+    hot[:, 0, :] = np.arange(32, dtype=np.int32)[None, :]
+    hot[:, 1, :4] = np.array([10 ** 6, -7, 2 * 32 + 2 * 500, 63], dtype=np.int32)
+    asm = pyoracle.assemble(plan, leaves[0])
+    dq0, _, st0, _ = helpers.emu_cascade(plan, asm)
+    dq1, _, st1, _ = helpers.emu_cascade(plan, asm, hot=hot)
+    assert (st1 == 0).all() and np.abs(dq0 - dq1).max() < 1e-9
+
+
+def test_hot_start_inverse_dynamics_emulated():
+    """the same on the 64-lane instantiation (config 5: unit-row and stored-row inequalities, equalities ahead of them)"""
+    B = 6
+    plan, leaf = synth.make_id_stack(B, seed=5100)
+    rng = np.random.default_rng(6)
+    leaves = [leaf, synth.perturb(leaf, rng, 0.01)]
+    hot = np.full((B, plan.L, 64), -1, dtype=np.int32)
+    for lf in leaves + [leaves[1]]:
+        asm = pyoracle.assemble(plan, lf)
+        dq0, _, st0, it0 = helpers.emu_cascade(plan, asm)
+        dq1, _, st1, it1 = helpers.emu_cascade(plan, asm, hot=hot)
+        assert (st0 == st1).all()
+        ok = st0 == 0
+        assert ok.any() and np.abs(dq0[ok] - dq1[ok]).max() < 1e-8 * max(1.0, np.abs(dq0[ok]).max())
+    assert (it1[ok] <= it0[ok]).all()

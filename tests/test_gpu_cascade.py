@@ -346,3 +346,79 @@ def test_default_eps_stuck_instances_gpu(mode, oracle, gpu_device):
     for i in range(B):
         ok, why = answer_is_acceptable(asm, i, dq[i], [(nm, r["dq"][i], r["status"][i] == 1) for nm, r in wit])
         assert ok, (i, why)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["C3", "C4", "C5"])
+def test_hot_start_gpu(cfg, oracle, gpu_device):
+    """osot_solver_set_hotstart (reference: QPOasesBackEnd.cpp:258-285 hotstart -> SQProblem.cpp:149-193): every level's
+    working set of the instance's previous solve is re-added before the first scan.  Same dq as the cold solve to 1e-9
+    (both against the oracle too) over drifting cycles; on an exact repeat of a cycle the hot list is the final active
+    set: no more iterations than cold for any instance, fewer in total."""
+    B = 256 if cfg != "C5" else 64
+    plan, leaf = synth.make_id_stack(B, seed=5200) if cfg == "C5" else synth.make_velocity_stack(cfg, B, seed=4200)
+    rng = np.random.default_rng(8)
+    leaves = [leaf, synth.perturb(leaf, rng, 0.01), synth.perturb(leaf, rng, 0.002)]
+    cold, hot = BatchedStack(plan, B, device=0), BatchedStack(plan, B, device=0)
+    hot.set_hotstart(True)
+    for i, lf in enumerate(leaves + [leaves[-1]]):
+        out = []
+        for st in (cold, hot):
+            st.update(st.load_leaf(lf)); st.solve(B)
+            torch.cuda.synchronize()
+            out.append((st.dq[:B].cpu().numpy(), st.status[:B].cpu().numpy(), st.iterations[:B].cpu().numpy()))
+        (dq0, st0, it0), (dq1, st1, it1) = out
+        assert (st0 == st1).all()
+        ok = st0 == 0
+        assert ok.mean() > 0.9
+        scale = max(1.0, np.abs(dq0[ok]).max()) if cfg == "C5" else 1.0     # (torque-mode variables are accelerations / forces)
+        assert np.abs(dq0[ok] - dq1[ok]).max() < 1e-9 * scale
+        if i == 0:
+            assert (it0 == it1).all()                    # nothing recorded yet: a cold start
+            ref = oracle.ihqp_solve_batch(oracle.assemble(plan, lf), oracle.BE_EIQP_EQ, nthreads=4)
+            both = ok & (ref["status"] == 1)
+            assert np.abs(dq1[both] - ref["dq"][both]).max() < 1e-8 * scale
+        if i == len(leaves):                             # exact repeat: the hot list is the final active set
+            assert (it1[ok] <= it0[ok]).all() and it1[ok].sum() < it0[ok].sum()
+    hot.set_hotstart(False)                              # switching it off is a cold start again, bit for bit
+    hot.solve(B); cold.solve(B)
+    torch.cuda.synchronize()
+    assert torch.equal(hot.dq[:B], cold.dq[:B])
+
+
+@pytest.mark.gpu
+def test_pipelined_lanes_match_single_launch_gpu(gpu_device):
+    """opensot_amd.parallel.PipelinedCycle (what bench.py times): the batch as S sub-batches on S streams, no join between
+    steps -- same dq, bit for bit, as one launch over the whole batch, for every cycle of the rotation"""
+    from opensot_amd.parallel import PipelinedCycle, ShardedCycle, lane_ranges
+    B, S, K = 600, 3, 3
+    plan, leaf = synth.make_velocity_stack("C3", B, seed=4300)
+    rng = np.random.default_rng(9)
+    leaves = [leaf]
+    for _ in range(K - 1):
+        leaves.append(synth.perturb(leaves[-1], rng, 0.01))
+
+    def cut(lf, a, b):
+        c = lambda x: None if x is None else x[a:b]
+        return {"B": b - a, "A": [c(x) for x in lf["A"]], "task": [[tuple(c(x) for x in t) for t in lev] for lev in lf["task"]],
+                "bound": [tuple(c(x) for x in t) for t in lf["bound"]], "rows": [tuple(c(x) for x in t) for t in lf["rows"]]}
+
+    def build(a, b):
+        st = BatchedStack(plan, b - a, device=0, want_levels=False)
+        devs, As = [], []
+        for lf in leaves:
+            st.A = [None if t is None else torch.empty_like(t) for t in st.A]
+            devs.append(st.load_leaf(cut(lf, a, b))); As.append(st.A)
+        return ShardedCycle(st, devs, As, b - a, None)
+
+    one = build(0, B)
+    spans = lane_ranges(B, S)
+    lanes = [build(a, b) for a, b in spans]
+    pipe = PipelinedCycle(lanes, [torch.cuda.Stream() for _ in range(S)])
+    torch.cuda.synchronize()
+    for step in range(2 * K + 1):
+        one.step(); pipe.step()
+    torch.cuda.synchronize()
+    got = torch.cat([ln.stack.dq[:b - a] for ln, (a, b) in zip(lanes, spans)])
+    assert (one.stack.status[:B] == 0).all()
+    assert torch.equal(got, one.stack.dq[:B])
