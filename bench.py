@@ -225,7 +225,10 @@ def parity_report(plan, leaf_sample, dq_dev, xl_dev, slack_dev, tol=1e-6, max_ev
         out["beyond_tolerance"] = {"count": int(far.size), "lexicographically_better": better, "evidence": ev,
                                    "reading": "per level: viol = constraint violation of x_k in level k's QP (box, rows, "
                                               "optimality equalities of the chain itself), kkt = stationarity residual with "
-                                              "least-squares multipliers on the active set; lex_cost_of_dq = the task cost of "
+                                              "NON-NEGATIVE least-squares multipliers on the active set (inequalities >= 0, "
+                                              "equalities free), so min_multiplier is 0 by construction and a point that is not a "
+                                              "KKT point shows as a residual; kkt_certificate_of_dq = the same for the final point "
+                                              "alone, every level's optimality rows posed at dq; lex_cost_of_dq = the task cost of "
                                               "every level at the final point: the lexicographically smaller FEASIBLE point is "
                                               "the optimum of iHQP.cpp:263-358's problem"}
     return out

@@ -362,9 +362,12 @@ typedef struct {
                                             singular values of A N at construction (>= 1e-6 counts as rank, nHQP.cpp:88-103)
                                             and never changes them; 0 = default: n, then previous minus the rows of the level
                                             above (full row rank) */
-    double min_sv_ratio;                 /* setMinSingularValueRatio; 0 = DEFAULT_MIN_SV_RATIO = 0.05 (nHQP.h:66) */
+    double min_sv_ratio;                 /* setMinSingularValueRatio (nHQP.cpp:342-355 accepts 0 <= s <= 1; 0 lifts nothing).
+                                            Read only when min_sv_ratio_is_set != 0; otherwise DEFAULT_MIN_SV_RATIO = 0.05
+                                            (nHQP.h:66), so that a zeroed struct means "the reference's defaults" */
     int no_ab_regularization;            /* setPerformAbRegularization(false) */
     int no_selective_ns_regularization;  /* setPerformSelectiveNullSpaceRegularization(false) */
+    int min_sv_ratio_is_set;             /* != 0: min_sv_ratio is the caller's value, 0 included */
 } osot_nhqp_options;
 int osot_nhqp_solve(osot_solver* s, const osot_qp_batch* batch, const osot_nhqp_options* options, void* hip_stream);
 

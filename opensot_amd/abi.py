@@ -86,7 +86,8 @@ class AssembledOut(C.Structure):
 
 class NhqpOptions(C.Structure):
     _fields_ = [("free_vars", C.c_int * MAX_LEVELS), ("min_sv_ratio", C.c_double),
-                ("no_ab_regularization", C.c_int), ("no_selective_ns_regularization", C.c_int)]
+                ("no_ab_regularization", C.c_int), ("no_selective_ns_regularization", C.c_int),
+                ("min_sv_ratio_is_set", C.c_int)]
 
 
 class IdModel(C.Structure):

@@ -429,6 +429,8 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
     // the instantiation with the dense-weight / inactive-task code only where the plan or the solver state asks for it
     bool extra = s->any_inactive;
     for (int k = 0; k < pl.n_levels; ++k) extra = extra || (s->h_uplan.dense_level[k] != 0);
+    if (prof && !fused && extra)   // (the instrumented instantiation carries no dense-weight / inactive-task code: it would
+        return fail(OSOT_ERR_UNSUPPORTED, "phase profiling is not available for plans with dense weights or inactive tasks");   // solve another problem)
     if (fused) {
         if (T == 32) {
             if (extra) hipLaunchKernelGGL((osot_cycle_kernel<32, true>), dim3(grid), dim3(64), lds, st, *fused, P, D);

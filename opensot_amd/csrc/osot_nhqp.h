@@ -205,6 +205,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
     OSOT_STATIC_LDS(double, vec, 64);          // staging vector
     OSOT_STATIC_LDS(double, sig, 32);          // singular values, sorted descending
     OSOT_STATIC_LDS(int, idx, 32);             // idx[pos] = eigen-column holding the pos-th largest
+    OSOT_STATIC_LDS(double, refl_beta, 32);    // 2 / |v|^2 of the Householder reflectors of the right singular vectors
     const long long inst = blockIdx.x;
     const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
     if (inst >= Q.B) return;
@@ -310,6 +311,63 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
         wave_sync();
     }
     const double sv_max = sig[0];
+    // ---- right singular vectors on the ROW side (m <= nf).  v_i = AN'u_i / |AN'u_i| only exists for sv_i > 0: for a singular
+    // value at round-off level (a rank-deficient level: duplicated or dependent task rows) that product is noise inside the
+    // row space, while the reference's full V (Eigen, nHQP.cpp:373) holds a NULL-SPACE vector there -- and regularize_A_b
+    // lifts exactly those triplets, so a noise v_i would put the lifted singular value on a genuine task direction (ADVICE
+    // r2: 2-4e-2 off on a stack with a duplicated row).  So: the rho well-defined v_i (sv_i >= kSvNoise sv_max; the Gram
+    // route resolves singular values down to ~1e-8 sv_max) are orthonormalised by Householder reflections H_1 .. H_r'
+    // (r' = min(rho, nf - ns)), and every other column of V is taken from the completion Q = H_1 .. H_r' : column j >= r' is
+    // Q e_j, orthogonal to v_1 .. v_r'.  The lifted null triplets use Q e_i, the next level's null space Q e_(r + t).
+    constexpr double kSvNoise = 1.0e-7;
+    int rho = 0;
+    for (int i = 0; i < k; ++i) rho += (sig[i] >= kSvNoise * sv_max && sig[i] > 0.0) ? 1 : 0;
+    const int r_next = nf - ns;
+    const int nrefl = rowside ? (rho < r_next ? rho : r_next) : 0;
+    const bool need_refl = rowside && (ns > 0 || (Q.ab_reg && rho < k));
+    double* V1 = K;          // K is free now (its diagonal went into sig[]): V1[t][i] = component t of v_i, then reflector i
+    if (need_refl) {
+        for (int i = 0; i < nrefl; ++i) {
+            const int ec = idx[i];
+            double acc = 0.0;
+            if (c < nf) for (int q = h; q < m; q += 2) acc = fma(AN[q * kNS + c], E[q * kNS + ec], acc);
+            double vv = halfsum<32>(acc);
+            const double nrm2 = colsum<32>((c < nf) ? vv * vv : 0.0);
+            vv = (nrm2 > 0.0) ? vv / sqrt(nrm2) : 0.0;
+            if (h == 0 && c < nf) V1[c * kNS + i] = vv;
+        }
+        wave_sync();
+        // Householder vectors: for column i, reflect x = V1[i:, i] onto alpha e_i; apply to the later columns
+        for (int i = 0; i < nrefl; ++i) {
+            const double x = (c >= i && c < nf) ? V1[c * kNS + i] : 0.0;
+            const double nrm2 = colsum<32>(x * x);
+            const double xi = bcast(x, i);
+            const double alpha = (xi > 0.0) ? -sqrt(nrm2) : sqrt(nrm2);
+            double hv = (c == i) ? x - alpha : x;             // reflector v (zero above i)
+            const double vn2 = colsum<32>(hv * hv);
+            const double beta = (vn2 > 0.0) ? 2.0 / vn2 : 0.0;
+            wave_sync();
+            if (h == 0 && c < nf) V1[c * kNS + i] = hv;        // keep the reflector in place of the column
+            for (int j = i + 1; j < nrefl; ++j) {              // later columns: y -= beta (v'y) v
+                const double y = (c < nf) ? V1[c * kNS + j] : 0.0;
+                const double dot = colsum<32>(hv * y);
+                wave_sync();
+                if (h == 0 && c < nf) V1[c * kNS + j] = y - beta * dot * hv;
+                wave_sync();
+            }
+            if (h == 0 && c == 0) refl_beta[i] = beta;
+            wave_sync();
+        }
+    }
+    auto completion_column = [&](int j) -> double {           // (Q e_j)[c], j >= nrefl
+        double y = (c == j) ? 1.0 : 0.0;
+        for (int i = nrefl - 1; i >= 0; --i) {
+            const double hv = (c >= i && c < nf) ? V1[c * kNS + i] : 0.0;
+            const double dot = colsum<32>(hv * y);
+            y -= refl_beta[i] * dot * hv;
+        }
+        return y;
+    };
     // ---- A / b regularisation (regularize_A_b, nHQP.cpp:236-279).  For singular triplet i (sorted): the known factor is a
     // column of E, the other one is a normalised product with AN.  AN <- AN + sum_i (sv'_i - sv_i) u_i v_i'  over the
     // lifted ones;  b0 <- sum_i d_i (u_i'b0) u_i  (+ the part of b0 in the complement of range(U_k) only when U_k is all
@@ -326,11 +384,16 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
             double uu = 0.0, vv = 0.0;
             if (rowside) {
                 uu = (lane < m) ? E[lane * kNS + ec] : 0.0;                       // u_i = column of E
-                double acc = 0.0;                                                 // v_i ~ AN' u_i
-                if (c < nf) for (int r = h; r < m; r += 2) acc = fma(AN[r * kNS + c], E[r * kNS + ec], acc);
-                vv = halfsum<32>(acc);
-                const double nrm2 = colsum<32>((c < nf) ? vv * vv : 0.0);
-                vv = (nrm2 > 0.0) ? vv / sqrt(nrm2) : 0.0;
+                if (i >= rho) {                                                   // null triplet: v_i from the completion
+                    const double qc = completion_column(i);                       // (a wave collective: every lane calls it)
+                    vv = (c < nf) ? qc : 0.0;
+                } else {
+                    double acc = 0.0;                                             // v_i ~ AN' u_i
+                    if (c < nf) for (int r = h; r < m; r += 2) acc = fma(AN[r * kNS + c], E[r * kNS + ec], acc);
+                    vv = halfsum<32>(acc);
+                    const double nrm2 = colsum<32>((c < nf) ? vv * vv : 0.0);
+                    vv = (nrm2 > 0.0) ? vv / sqrt(nrm2) : 0.0;
+                }
             } else {
                 vv = (c < nf) ? E[c * kNS + ec] : 0.0;                            // v_i = column of E
                 double acc = 0.0;                                                 // u_i ~ AN v_i (lane = row, all 64 lanes)
@@ -362,49 +425,10 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
             for (int t = 0; t < ns; ++t) { const int ec = idx[k - ns + t]; if (h == 0 && c < nf) V2[c * kNS + t] = E[c * kNS + ec]; }
             wave_sync();
         } else {
-            // orthogonal complement of the r = nf - ns leading right singular vectors v_i = AN'u_i / |.|: Householder QR
-            // of V1 = [v_1 .. v_r] kept as reflectors in the columns of V2 (scratch), then Q [0; I_ns]
-            const int r = nf - ns;
-            double* V1 = K;          // K is free now: V1[t][i] = component t of v_i (nf x r)
-            for (int i = 0; i < r; ++i) {
-                const int ec = idx[i];
-                double acc = 0.0;
-                if (c < nf) for (int q = h; q < m; q += 2) acc = fma(AN[q * kNS + c], E[q * kNS + ec], acc);
-                double vv = halfsum<32>(acc);
-                const double nrm2 = colsum<32>((c < nf) ? vv * vv : 0.0);
-                vv = (nrm2 > 0.0) ? vv / sqrt(nrm2) : 0.0;
-                if (h == 0 && c < nf) V1[c * kNS + i] = vv;
-            }
-            wave_sync();
-            // Householder vectors: for column i, reflect x = V1[i:, i] onto alpha e_i; apply to the later columns
-            for (int i = 0; i < r; ++i) {
-                const double x = (c >= i && c < nf) ? V1[c * kNS + i] : 0.0;
-                const double nrm2 = colsum<32>(x * x);
-                const double xi = bcast(x, i);
-                const double alpha = (xi > 0.0) ? -sqrt(nrm2) : sqrt(nrm2);
-                double hv = (c == i) ? x - alpha : x;             // reflector v (zero above i)
-                const double vn2 = colsum<32>(hv * hv);
-                const double beta = (vn2 > 0.0) ? 2.0 / vn2 : 0.0;
-                wave_sync();
-                if (h == 0 && c < nf) V1[c * kNS + i] = hv;        // keep the reflector in place of the column
-                for (int j = i + 1; j < r; ++j) {                  // later columns: y -= beta (v'y) v
-                    const double y = (c < nf) ? V1[c * kNS + j] : 0.0;
-                    const double dot = colsum<32>(hv * y);
-                    wave_sync();
-                    if (h == 0 && c < nf) V1[c * kNS + j] = y - beta * dot * hv;
-                    wave_sync();
-                }
-                if (h == 0 && c == 0) vec[i] = beta;
-                wave_sync();
-            }
-            // V2[:, t] = H_1 .. H_r e_(r + t)
+            // the last ns columns of the completion built above: Q e_(r + t), r = nf - ns (orthogonal to the leading
+            // well-defined right singular vectors)
             for (int t = 0; t < ns; ++t) {
-                double y = (c == r + t) ? 1.0 : 0.0;
-                for (int i = r - 1; i >= 0; --i) {
-                    const double hv = (c >= i && c < nf) ? V1[c * kNS + i] : 0.0;
-                    const double dot = colsum<32>(hv * y);
-                    y -= vec[i] * dot * hv;
-                }
+                const double y = completion_column(r_next + t);
                 if (h == 0 && c < nf) V2[c * kNS + t] = y;
             }
             wave_sync();

@@ -212,7 +212,7 @@ class BatchedStack:
         qb = self._qp_batch(B)
         abi.check(self._lib.osot_ihqp_solve(self._h, C.byref(qb), _stream_ptr(self.device, self.stream)), "osot_ihqp_solve")
 
-    def solve_nhqp(self, B, free_vars=None, min_sv_ratio=0.0, ab_regularization=True, selective_ns_regularization=True):
+    def solve_nhqp(self, B, free_vars=None, min_sv_ratio=None, ab_regularization=True, selective_ns_regularization=True):
         """Solver::solve() with the reference's NULL-SPACE front-end, OpenSoT::solvers::nHQP (nHQP.cpp:155-204), on the same
         assembled arrays; stream-ordered, results in self.dq[:B] / self.status[:B].  free_vars: free variables per level
         (the reference fixes them at construction); None = n, then minus the rows of the level above"""
@@ -220,7 +220,9 @@ class BatchedStack:
         if free_vars is not None:
             for k, v in enumerate(free_vars):
                 opt.free_vars[k] = int(v)
-        opt.min_sv_ratio = float(min_sv_ratio)
+        if min_sv_ratio is not None:       # None: the reference's default 0.05; 0.0 is a value (no singular value is lifted)
+            opt.min_sv_ratio = float(min_sv_ratio)
+            opt.min_sv_ratio_is_set = 1
         opt.no_ab_regularization = 0 if ab_regularization else 1
         opt.no_selective_ns_regularization = 0 if selective_ns_regularization else 1
         qb = self._qp_batch(B)

@@ -117,7 +117,7 @@ class nHQP(iHQP):
 
     def __init__(self, plan, max_batch, eps_regularisation=2e2, be_solver=solver_back_ends.qpOASES, device=0, free_vars=None):
         super().__init__(plan, max_batch, eps_regularisation, be_solver, device)
-        self._opts = dict(free_vars=free_vars, min_sv_ratio=0.0, ab_regularization=True, selective_ns_regularization=True)
+        self._opts = dict(free_vars=free_vars, min_sv_ratio=0.05, ab_regularization=True, selective_ns_regularization=True)
 
     def setMinSingularValueRatio(self, sv_min):
         if not 0.0 <= sv_min <= 1.0:

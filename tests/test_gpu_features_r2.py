@@ -100,9 +100,10 @@ def test_inverse_dynamics_producers_and_computed_torque_gpu(oracle, gpu_device):
     ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=0)
     assert (ref["status"] == 1).all() and np.abs(x - ref["dq"]).max() < 1e-8
     if oracle.ref_available():
+        from helpers import parity_census      # absolute 1e-6 against qpOASES, every instance counted (see helpers)
         rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=0)
-        okq = rq["status"] == 1
-        assert okq.mean() > 0.95 and np.abs(x[okq] - rq["dq"][okq]).max() < 1e-6 * max(1.0, np.abs(x).max())
+        within, rule, fails = parity_census(asm, x, [("qpOASES", rq), ("eiQuadProg", ref)], tol=1e-6, label="C5 device producers")
+        assert not fails and within >= 0.95 * asm["B"]
 
 
 @pytest.mark.parametrize("cfg,B", [("C3", 300), ("C4", 128), ("C5", 64), ("feature", 96)])

@@ -235,6 +235,10 @@ def test_inverse_dynamics_full_size(oracle, gpu_device):
     ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=0)
     assert (ref["status"] == 1).all() and np.abs(dq[sub] - ref["dq"]).max() < 1e-8
     if oracle.ref_available():
+        # north_star's tolerance as it is written: ABSOLUTE 1e-6 on x = [qddot; F] against qpOASES at OpenSoT's options, every
+        # instance counted (helpers.parity_census prints the census); an instance beyond it has to pass the literal
+        # acceptance rule (feasible to 1e-7 and lexicographically not worse than qpOASES and the eiQuadProg restatement)
+        from helpers import parity_census
         rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=0)
-        okq = rq["status"] == 1
-        assert okq.mean() > 0.95 and np.abs(dq[sub][okq] - rq["dq"][okq]).max() < 1e-6 * max(1.0, np.abs(dq).max())
+        within, rule, fails = parity_census(asm, dq[sub], [("qpOASES", rq), ("eiQuadProg", ref)], tol=1e-6, label="C5 full size")
+        assert not fails and within >= 0.95 * asm["B"]

@@ -29,7 +29,7 @@ def test_restatement_agrees_with_ihqp_without_regularisations(oracle):
 
 
 @pytest.mark.parametrize("cfg,opts", [("C3", {}), ("C3", dict(ab_regularization=False, selective_ns_regularization=False)),
-                                      ("C4", {}), ("C2", {}), ("C3", dict(min_sv_ratio=0.2))])
+                                      ("C4", {}), ("C2", {}), ("C3", dict(min_sv_ratio=0.2)), ("C3", dict(min_sv_ratio=0.0))])
 def test_emulated_kernels_match_restatement(cfg, opts, oracle):
     from oracle import pynhqp
     B = 6
@@ -42,8 +42,13 @@ def test_emulated_kernels_match_restatement(cfg, opts, oracle):
     ref = pynhqp.nhqp_solve(asm, backend=backend, termination_tolerance=10 * 2.221e-16, **kw)
     dq, st = emu_nhqp(plan, asm, **opts)
     ok = ref["status"] == 1
+    print(f"[nHQP emulated {cfg} {opts}] restatement solved {int(ok.sum())}/{B}; device solved {int((st == 0).sum())}/{B}; "
+          f"max |dq - restatement| over the compared ones {np.abs(dq[ok] - ref['dq'][ok]).max():.2e}")
     assert ok.mean() > 0.8 and (st[ok] == 0).all()
     assert np.abs(dq[ok] - ref["dq"][ok]).max() < 1e-7
+    # an instance the restatement's qpOASES gave up on is not compared; the device's answer there still has to be a point
+    # inside the box (or a reported failure with dq = 0)
+    assert np.isfinite(dq).all() and (dq >= asm["l"] - 1e-7).all() and (dq <= asm["u"] + 1e-7).all()
 
 
 def test_small_generic_stack_and_no_free_variables(oracle):
@@ -66,6 +71,59 @@ def test_small_generic_stack_and_no_free_variables(oracle):
     L.emu_nhqp_solve.argtypes = [C.POINTER(abi.PlanDesc), C.POINTER(abi.QpBatch), C.POINTER(abi.NhqpOptions)]
     pd = plan2.to_c()
     assert L.emu_nhqp_solve(C.byref(pd), C.byref(qb), C.byref(opt)) == abi.ERR_INVALID
+
+
+def _duplicated_row_stack(oracle):
+    from oracle import pynhqp
+    plan, leaf = synth.make_generic_stack(5, 12, [4, 5], n_eq=0, n_ineq=3, seed=2, box=0.4)
+    asm = oracle.assemble(plan, leaf)
+    fv = pynhqp.free_variables(asm)                       # fixed at construction from the full-rank stack (nHQP.cpp:6-117)
+    asm["A"][0][:, 3, :] = asm["A"][0][:, 0, :]           # then row 3 of the first level duplicates row 0: rank 3 of 4
+    asm["b"][0][:, 3] = asm["b"][0][:, 0]
+    return plan, asm, fv
+
+
+def _check_rank_deficient_level(asm, dq, st, ref):
+    """what is DEFINED on a rank-deficient level: regularize_A_b (nHQP.cpp:236-279) lifts the null triplet with the v_i of
+    Eigen's full V, an implementation-defined unit vector of the level's null space (numpy's LAPACK picks another one, this
+    build a Householder completion), and that direction is then closed to the levels below.  So dq itself is comparable
+    through the first level's task only: its residual must be the restatement's (2-6e-2 before the fix, where
+    the lifted singular value sat on a noise vector INSIDE the row space), and the answer must respect the box."""
+    assert (st == 0).all() and (ref["status"] == 1).all()
+    r_dev = np.einsum("bij,bj->bi", asm["A"][0], dq) - asm["b"][0]
+    r_ref = np.einsum("bij,bj->bi", asm["A"][0], ref["dq"]) - asm["b"][0]
+    assert np.abs(r_ref).max() < 1e-5 and np.abs(r_dev).max() < 1e-5
+    assert (dq >= asm["l"] - 1e-9).all() and (dq <= asm["u"] + 1e-9).all()
+
+
+def test_rank_deficient_level_emulated(oracle):
+    from oracle import pynhqp
+    plan, asm, fv = _duplicated_row_stack(oracle)
+    ref = pynhqp.nhqp_solve(asm, backend="qpoases" if oracle.ref_available() else "eiqp", termination_tolerance=10 * 2.221e-16,
+                            free_vars=fv)
+    dq, st = emu_nhqp(plan, asm, free_vars=fv)
+    _check_rank_deficient_level(asm, dq, st, ref)
+    # the lifted NULL triplet only adds a penalty on a direction nothing else moves along: with the null vector taken from the
+    # completion the answer is the one without the A/b regularisation (no other singular value is below the threshold
+    # here); with a noise vector inside the row space it was 0.2 away
+    dq_off, st_off = emu_nhqp(plan, asm, free_vars=fv, ab_regularization=False)
+    assert (st_off == 0).all() and np.abs(dq - dq_off).max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_rank_deficient_level_gpu(oracle, gpu_device):
+    import torch
+    from oracle import pynhqp
+    from opensot_amd.solver import BatchedStack
+    plan, asm, fv = _duplicated_row_stack(oracle)
+    B = asm["B"]
+    st = BatchedStack(plan, B, device=0)
+    st.load_assembled(asm)
+    st.solve_nhqp(B, free_vars=fv, min_sv_ratio=pynhqp.DEFAULT_MIN_SV_RATIO)
+    torch.cuda.synchronize()
+    ref = pynhqp.nhqp_solve(asm, backend="qpoases" if oracle.ref_available() else "eiqp", termination_tolerance=10 * 2.221e-16,
+                            free_vars=fv)
+    _check_rank_deficient_level(asm, st.dq[:B].cpu().numpy(), st.status[:B].cpu().numpy(), ref)
 
 
 @pytest.mark.gpu
@@ -92,8 +150,11 @@ def test_nhqp_gpu(cfg, opts, oracle, gpu_device):
     kw = dict(opts); kw.setdefault("min_sv_ratio", pynhqp.DEFAULT_MIN_SV_RATIO)
     ref = pynhqp.nhqp_solve(asm, backend="qpoases" if oracle.ref_available() else "eiqp", termination_tolerance=10 * 2.221e-16, **kw)
     ok = ref["status"] == 1
+    print(f"[nHQP gpu {cfg} {opts}] restatement solved {int(ok.sum())}/{ok.size} of the sample; device solved "
+          f"{int((status == 0).sum())}/{B}; max |dq - restatement| over the compared ones {np.abs(dq[sub][ok] - ref['dq'][ok]).max():.2e}")
     assert ok.mean() > 0.8 and (status[sub][ok] == 0).all()
     assert np.abs(dq[sub][ok] - ref["dq"][ok]).max() < 1e-7
+    assert np.isfinite(dq).all() and (dq[sub] >= asm["l"] - 1e-7).all() and (dq[sub] <= asm["u"] + 1e-7).all()
     if opts:
         st.solve(B); torch.cuda.synchronize()
         both = (status == 0) & (st.status[:B].cpu().numpy() == 0)
