@@ -462,7 +462,29 @@ typedef struct {
     unsigned long long frame_col_mask[OSOT_KIN_MAX_FRAMES]; /* Task::setActiveJointsMask (Task.h:129-139): bit j CLEAR =
                                                     column j of the frame's Jacobian is written as zero; 0 = no mask  */
     unsigned long long com_col_mask;             /* the same for the CoM Jacobian                                    */
+    /* ---- environment shapes and boxes (reference: CollisionAvoidance::addCollisionShape /
+     * moveCollisionShape / setLinksVsEnvironment, include/OpenSoT/constraints/velocity/CollisionAvoidance.h:115-144,
+     * src/constraints/velocity/CollisionAvoidance.cpp:166-200; the shapes are XBot::Collision::Shape's sphere / capsule /
+     * box).  Side a of a pair is a capsule (or sphere) on a link, as before.  Side b may be
+     *   - carried by the WORLD: pair_joint[p][1] = -1 (a static world shape: its data are in world coordinates), and, with
+     *     pair_env[p] = e + 1 > 0, placed by the RUNTIME pose osot_kin_batch.env_pose[e] (moveCollisionShape: the shape's
+     *     data are then in the shape's own frame);
+     *   - a BOX (pair_kind[p] = OSOT_SHAPE_BOX): half extents pair_box[p], box frame = carrier frame (link, world or
+     *     env pose) composed with (pair_shape_R[p], pair_shape_p[p]) = link_T_shape; pair_seg[p][1] is unused and
+     *     pair_radius[p][1] is a rounding radius (0 for a sharp box).
+     * Distance = exact closest points of side a's axis segment and the box (piecewise-quadratic minimisation over the
+     * segment parameter); a segment that touches or enters the box has no normal: distance -r_a - r_b, zero row (the
+     * reference caps the bound at 0 there, CollisionAvoidance.cpp:141-146).  Box against box is not offered.
+     * All zero (the value of a struct written before these fields existed) = capsule pairs on links only. */
+    int pair_kind[OSOT_KIN_MAX_PAIRS];
+    int pair_env[OSOT_KIN_MAX_PAIRS];
+    double pair_box[OSOT_KIN_MAX_PAIRS][3];
+    double pair_shape_R[OSOT_KIN_MAX_PAIRS][9];
+    double pair_shape_p[OSOT_KIN_MAX_PAIRS][3];
+    int n_env;                                   /* environment shapes with a runtime pose (env_pose entries)        */
 } osot_kin_desc;
+enum { OSOT_SHAPE_CAPSULE = 0, OSOT_SHAPE_BOX = 1 };
+#define OSOT_KIN_MAX_ENV 16
 typedef struct {
     int B;
     const double* q;                               /* [B][n]                                                    */
@@ -476,6 +498,9 @@ typedef struct {
     double* pair_J;                                /* first of the n_pairs rows J_d in instance 0, or NULL (the
                                                       OSOT_ROWS_COLLISION leaf p0: [B][rows][n])                */
     long long pair_J_stride;                       /* doubles from one instance to the next (rows * n)          */
+    const double* env_pose;                        /* [n_env][12] world_T_shape = [R row-major | p] of the environment
+                                                      shapes (moveCollisionShape), or NULL when n_env = 0           */
+    long long env_pose_stride;                     /* 0: one world shared by all instances; 12 n_env: per instance  */
 } osot_kin_batch;
 typedef struct osot_kin osot_kin;
 int osot_kin_create(const osot_kin_desc* desc, int device, osot_kin** out);

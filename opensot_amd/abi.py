@@ -97,6 +97,8 @@ class IdModel(C.Structure):
 
 # every symbol include/osot_mi355x.h declares (tests/test_abi_symbols.py checks the .so exports all)
 KIN_MAX_JOINTS, KIN_MAX_FRAMES, KIN_MAX_PAIRS = 64, 8, 32
+KIN_MAX_ENV = 16
+SHAPE_CAPSULE, SHAPE_BOX = 0, 1
 JOINT_REVOLUTE, JOINT_PRISMATIC = 0, 1
 
 
@@ -110,14 +112,18 @@ class KinDesc(C.Structure):
                 ("pair_joint", (C.c_int * 2) * KIN_MAX_PAIRS), ("pair_seg", ((C.c_double * 6) * 2) * KIN_MAX_PAIRS),
                 ("pair_radius", (C.c_double * 2) * KIN_MAX_PAIRS),
                 ("frame_body", C.c_int * KIN_MAX_FRAMES), ("frame_col_mask", C.c_ulonglong * KIN_MAX_FRAMES),
-                ("com_col_mask", C.c_ulonglong)]
+                ("com_col_mask", C.c_ulonglong),
+                ("pair_kind", C.c_int * KIN_MAX_PAIRS), ("pair_env", C.c_int * KIN_MAX_PAIRS),
+                ("pair_box", (C.c_double * 3) * KIN_MAX_PAIRS), ("pair_shape_R", (C.c_double * 9) * KIN_MAX_PAIRS),
+                ("pair_shape_p", (C.c_double * 3) * KIN_MAX_PAIRS), ("n_env", C.c_int)]
 
 
 class KinBatch(C.Structure):
     _fields_ = [("B", C.c_int), ("q", C.c_void_p), ("frame_pose", C.c_void_p * KIN_MAX_FRAMES),
                 ("frame_J", C.c_void_p * KIN_MAX_FRAMES), ("frame_J_stride", C.c_longlong * KIN_MAX_FRAMES),
                 ("com", C.c_void_p), ("com_J", C.c_void_p), ("com_J_stride", C.c_longlong),
-                ("pair_dist", C.c_void_p), ("pair_J", C.c_void_p), ("pair_J_stride", C.c_longlong)]
+                ("pair_dist", C.c_void_p), ("pair_J", C.c_void_p), ("pair_J_stride", C.c_longlong),
+                ("env_pose", C.c_void_p), ("env_pose_stride", C.c_longlong)]
 
 
 SYMBOLS = [

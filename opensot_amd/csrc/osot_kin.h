@@ -74,6 +74,62 @@ __device__ inline void closest_segment_points(const double* p1, const double* q1
     for (int i = 0; i < 3; ++i) { c1[i] = p1[i] + s * d1[i]; c2[i] = p2[i] + t * d2[i]; }
 }
 
+// closest points of the segment [p0, p1] and the axis-aligned box [-h, h] (all in the BOX frame): ca on the segment, cb on
+// the box.  dist^2(t) = sum_i max(|P_i(t)| - h_i, 0)^2 along P(t) = p0 + t (p1 - p0) is convex and piecewise quadratic with
+// at most six breakpoints (where a coordinate crosses one of its two faces): on every piece the minimiser of the quadratic
+// is clamped to the piece and the best piece wins -- exact, no iteration (FCL, which the reference's collision module
+// wraps, runs GJK on the same convex problem).
+__device__ inline void closest_segment_box(const double* p0, const double* p1, const double* h, double* ca, double* cb) {
+    double v[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+    double bp[8];
+    bp[0] = 0.0; bp[7] = 1.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const bool mv = fabs(v[i]) > 1.0e-300;
+        const double ta = mv ? (-h[i] - p0[i]) / v[i] : 0.0, tb = mv ? (h[i] - p0[i]) / v[i] : 0.0;
+        bp[1 + 2 * i] = clamp01(ta);
+        bp[2 + 2 * i] = clamp01(tb);
+    }
+    // sort the eight values (a fixed odd-even network: no data-dependent indexing, the array stays in registers)
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+#pragma unroll
+        for (int i = (pass & 1); i + 1 < 8; i += 2) {
+            const double lo = fmin(bp[i], bp[i + 1]), hi = fmax(bp[i], bp[i + 1]);
+            bp[i] = lo; bp[i + 1] = hi;
+        }
+    }
+    double best = INFINITY, tbest = 0.0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const double t0 = bp[k], t1 = bp[k + 1], tm = 0.5 * (t0 + t1);
+        double qa = 0.0, qb = 0.0;          // f(t) = qa t^2 + 2 qb t + qc on this piece; minimiser -qb / qa
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double pm = p0[i] + tm * v[i];
+            const double side = pm > h[i] ? 1.0 : (pm < -h[i] ? -1.0 : 0.0);
+            const double off = p0[i] - side * h[i];      // excess_i(t) = off + t v_i where the coordinate is outside
+            qa += (side != 0.0) ? v[i] * v[i] : 0.0;
+            qb += (side != 0.0) ? off * v[i] : 0.0;
+        }
+        double t = (qa > 0.0) ? -qb / qa : t0;
+        t = t < t0 ? t0 : (t > t1 ? t1 : t);
+        double f = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double pt = p0[i] + t * v[i];
+            const double ex = pt > h[i] ? pt - h[i] : (pt < -h[i] ? pt + h[i] : 0.0);
+            f += ex * ex;
+        }
+        if (f < best) { best = f; tbest = t; }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        ca[i] = p0[i] + tbest * v[i];
+        cb[i] = ca[i] > h[i] ? h[i] : (ca[i] < -h[i] ? -h[i] : ca[i]);
+    }
+}
+
 // PAIRS: the instantiation with the self-collision stage (step 5); the other one keeps the leaner register / LDS budget
 // JMAX = 32: TWO instances per wavefront (lanes 0..31 and 32..63 each run a robot of <= 32 joints: every instruction, every
 // 64-lane store carries two instances);  JMAX = 64: one instance per wavefront.  LDS per wavefront 16.5 KB either way.
@@ -280,22 +336,65 @@ __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__
         double* Pw = Pw_all + sub * (OSOT_KIN_MAX_PAIRS * 9);
         if (j < np && live) {
             double e[2][6];
+            double Rc[9], pc[3];      // carrier frame of side b (link, world, or the runtime pose of an environment shape)
 #pragma unroll
             for (int sd = 0; sd < 2; ++sd) {
                 const int js = K->d.pair_joint[j][sd];
                 double Rj[9], pj[3];
+                const int env = (sd == 1) ? K->d.pair_env[j] - 1 : -1;
+                if (js >= 0) {
 #pragma unroll
-                for (int i = 0; i < 9; ++i) Rj[i] = Tw[js * TS + i];
+                    for (int i = 0; i < 9; ++i) Rj[i] = Tw[js * TS + i];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) pj[i] = Tw[js * TS + 9 + i];
+                    for (int i = 0; i < 3; ++i) pj[i] = Tw[js * TS + 9 + i];
+                } else if (env >= 0 && Bt.env_pose) {
+                    const double* E = Bt.env_pose + inst * Bt.env_pose_stride + env * 12;
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) Rj[i] = E[i];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) pj[i] = E[9 + i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) Rj[i] = (i % 4 == 0) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) pj[i] = 0.0;
+                }
                 double t0[3], t1[3];
                 mat3_vec(Rj, &K->d.pair_seg[j][sd][0], t0);
                 mat3_vec(Rj, &K->d.pair_seg[j][sd][3], t1);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) { e[sd][i] = t0[i] + pj[i]; e[sd][3 + i] = t1[i] + pj[i]; }
+                if (sd == 1) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) Rc[i] = Rj[i];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) pc[i] = pj[i];
+                }
             }
             double ca[3], cb[3];
-            closest_segment_points(&e[0][0], &e[0][3], &e[1][0], &e[1][3], ca, cb);
+            if (K->d.pair_kind[j] == OSOT_SHAPE_BOX) {
+                // box frame in the world: (Rc, pc) o (shape_R, shape_p); side a's segment goes into it, the closest points
+                // come back out
+                double Rb[9], tb[3], pb[3];
+                mat3_mul(Rc, K->d.pair_shape_R[j], Rb);
+                mat3_vec(Rc, K->d.pair_shape_p[j], tb);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) pb[i] = pc[i] + tb[i];
+                double s0[3], s1[3], la[3], lb[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {   // R_b' (x - p_b)
+                    s0[i] = Rb[i] * (e[0][0] - pb[0]) + Rb[3 + i] * (e[0][1] - pb[1]) + Rb[6 + i] * (e[0][2] - pb[2]);
+                    s1[i] = Rb[i] * (e[0][3] - pb[0]) + Rb[3 + i] * (e[0][4] - pb[1]) + Rb[6 + i] * (e[0][5] - pb[2]);
+                }
+                closest_segment_box(s0, s1, K->d.pair_box[j], la, lb);
+                double wa[3], wb[3];
+                mat3_vec(Rb, la, wa);
+                mat3_vec(Rb, lb, wb);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { ca[i] = wa[i] + pb[i]; cb[i] = wb[i] + pb[i]; }
+            } else {
+                closest_segment_points(&e[0][0], &e[0][3], &e[1][0], &e[1][3], ca, cb);
+            }
             const double dv[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
             const double len = sqrt(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
             const bool deg = !(len > 1.0e-12);      // coincident axis points: no direction; the row is zero
@@ -309,7 +408,8 @@ __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__
             double* J = Bt.pair_J + inst * Bt.pair_J_stride;
             for (int p = 0; p < np; ++p) {
                 const int ja = K->d.pair_joint[p][0], jb = K->d.pair_joint[p][1];
-                const double sa = ((Anc[ja] >> j) & 1ull) ? 1.0 : 0.0, sb = ((Anc[jb] >> j) & 1ull) ? 1.0 : 0.0;
+                const double sa = ((Anc[ja] >> j) & 1ull) ? 1.0 : 0.0;
+                const double sb = (jb >= 0 && ((Anc[jb < 0 ? 0 : jb] >> j) & 1ull)) ? 1.0 : 0.0;   // (a world shape: no joint moves it)
                 const double nn[3] = {Pw[p * 9], Pw[p * 9 + 1], Pw[p * 9 + 2]};
                 double val;
                 if (revolute) {

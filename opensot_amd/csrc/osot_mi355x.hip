@@ -735,7 +735,7 @@ int osot_backend_get_num_constraints(osot_backend* be, int* nc) {
 // ---------------------------------------------------------------------------------------------------
 struct osot_kin {
     DevKin* dev;
-    int n, n_frames, n_pairs, device;
+    int n, n_frames, n_pairs, n_env, device;
 };
 
 extern "C" {
@@ -757,16 +757,23 @@ int osot_kin_create(const osot_kin_desc* d, int device, osot_kin** out) {
     for (int f = 0; f < d->n_frames; ++f)
         if (d->frame_joint[f] < 0 || d->frame_joint[f] >= d->n) return fail(OSOT_ERR_INVALID, "frame attached to a joint out of range");
     if (d->n_pairs < 0 || d->n_pairs > OSOT_KIN_MAX_PAIRS) return fail(OSOT_ERR_INVALID, "collision pair count out of range");
+    if (d->n_env < 0 || d->n_env > OSOT_KIN_MAX_ENV) return fail(OSOT_ERR_INVALID, "environment shape count out of range");
     for (int p = 0; p < d->n_pairs; ++p) {
-        for (int sd = 0; sd < 2; ++sd)
-            if (d->pair_joint[p][sd] < 0 || d->pair_joint[p][sd] >= d->n) return fail(OSOT_ERR_INVALID, "collision shape attached to a joint out of range");
+        if (d->pair_joint[p][0] < 0 || d->pair_joint[p][0] >= d->n) return fail(OSOT_ERR_INVALID, "collision shape attached to a joint out of range");
+        if (d->pair_joint[p][1] < -1 || d->pair_joint[p][1] >= d->n)      // (-1: side b is a world / environment shape)
+            return fail(OSOT_ERR_INVALID, "collision shape attached to a joint out of range");
         if (!(d->pair_radius[p][0] >= 0.0) || !(d->pair_radius[p][1] >= 0.0)) return fail(OSOT_ERR_INVALID, "negative capsule radius");
+        if (d->pair_kind[p] != OSOT_SHAPE_CAPSULE && d->pair_kind[p] != OSOT_SHAPE_BOX) return fail(OSOT_ERR_UNSUPPORTED, "unknown collision shape kind");
+        if (d->pair_env[p] < 0 || d->pair_env[p] > d->n_env) return fail(OSOT_ERR_INVALID, "pair refers to an environment shape out of range");
+        if (d->pair_env[p] > 0 && d->pair_joint[p][1] != -1) return fail(OSOT_ERR_INVALID, "an environment shape is carried by the world (joint -1)");
+        if (d->pair_kind[p] == OSOT_SHAPE_BOX)
+            for (int i = 0; i < 3; ++i) if (!(d->pair_box[p][i] > 0.0)) return fail(OSOT_ERR_INVALID, "box half extents must be positive");
     }
     if (!(h.total_mass > 0.0)) h.total_mass = 1.0;
     DeviceGuard guard(device);
     if (!guard.ok) return fail(OSOT_ERR_HIP, "hipSetDevice failed");
     osot_kin* k = new osot_kin();
-    k->n = d->n; k->n_frames = d->n_frames; k->n_pairs = d->n_pairs; k->device = device;
+    k->n = d->n; k->n_frames = d->n_frames; k->n_pairs = d->n_pairs; k->n_env = d->n_env; k->device = device;
     hipError_t e = hipMalloc(&k->dev, sizeof(DevKin));
     if (e == hipSuccess) e = hipMemcpy(k->dev, &h, sizeof(DevKin), hipMemcpyHostToDevice);
     if (e != hipSuccess) { delete k; return fail(OSOT_ERR_HIP, hipGetErrorString(e)); }
@@ -790,6 +797,7 @@ int osot_kinematics(osot_kin* k, const osot_kin_batch* b, void* hip_stream) {
     DeviceGuard guard(k->device);
     if (!guard.ok) return fail(OSOT_ERR_HIP, "hipSetDevice failed");
     const bool pairs = k->n_pairs > 0 && (b->pair_dist || b->pair_J);
+    if (pairs && k->n_env > 0 && !b->env_pose) return fail(OSOT_ERR_INVALID, "the model has environment shapes but env_pose is null");
     const dim3 grid((unsigned)(k->n <= 32 ? (b->B + 1) / 2 : b->B)), block(64);   // <= 32 joints: two instances per wavefront
     hipStream_t st = (hipStream_t)hip_stream;
     const DevKin* dk = (const DevKin*)k->dev;

@@ -30,6 +30,96 @@ class KinModel:
     frame_body: dict = field(default_factory=dict)
     frame_active_joints: dict = field(default_factory=dict)
     com_active_joints: list = None
+    # environment shapes and link-vs-environment pairs (CollisionAvoidance::addCollisionShape / moveCollisionShape /
+    # setLinksVsEnvironment, CollisionAvoidance.h:115-144).  link_shapes: link name -> (joint, a0, a1, radius), the capsule
+    # a link is checked with; env_shapes: dicts (name, link, kind, data ..., pose); self_pairs: the link-link pairs that
+    # stay in front of the generated link-environment pairs
+    link_shapes: dict = field(default_factory=dict)
+    env_shapes: list = field(default_factory=list)
+    self_pairs: list = None
+    env_links: list = field(default_factory=list)
+
+    # ---- the reference's three calls ------------------------------------------------------------------------------
+    def add_collision_shape(self, name, link, shape, link_T_shape=None):
+        """CollisionAvoidance::addCollisionShape(name, link, shape, link_T_shape) (CollisionAvoidance.cpp:166-173).  link:
+        "world" (an environment shape, movable afterwards) or a joint / link name of the model.  shape: ("sphere", r),
+        ("capsule", length, r) (axis = z of the shape frame, centred, like XBot::Collision::Shape::Capsule) or
+        ("box", (sx, sy, sz)) (full sizes).  link_T_shape: (R[3][3], p[3]), default identity.  False if the name is taken
+        or the link unknown (the reference returns false as well)."""
+        if any(e["name"] == name for e in self.env_shapes):
+            return False
+        if link != "world" and link not in self.names:
+            return False
+        R, p = (np.eye(3), np.zeros(3)) if link_T_shape is None else (np.asarray(link_T_shape[0], float).reshape(3, 3),
+                                                                      np.asarray(link_T_shape[1], float).reshape(3))
+        kind = shape[0]
+        if kind == "sphere":
+            e = dict(kind="capsule", a0=np.zeros(3), a1=np.zeros(3), r=float(shape[1]))
+        elif kind == "capsule":
+            L, r = float(shape[1]), float(shape[2])
+            e = dict(kind="capsule", a0=np.array([0, 0, -0.5 * L]), a1=np.array([0, 0, 0.5 * L]), r=r)
+        elif kind == "box":
+            e = dict(kind="box", half=0.5 * np.asarray(shape[1], float).reshape(3), r=0.0)
+        else:
+            raise ValueError("shape must be a sphere, a capsule or a box (meshes / box-box pairs are not offered)")
+        e.update(name=name, link=link, R=R, p=p)
+        self.env_shapes.append(e)
+        self._rebuild_pairs()
+        return True
+
+    def move_collision_shape(self, name, new_pose):
+        """CollisionAvoidance::moveCollisionShape(id, new_pose) (CollisionAvoidance.cpp:175-178): new world pose (R, p) of
+        an environment shape; takes effect at the next Kinematics.forward (the pose is a runtime input of the kernel)"""
+        for e in self.env_shapes:
+            if e["name"] == name and e["link"] == "world":
+                e["R"] = np.asarray(new_pose[0], float).reshape(3, 3); e["p"] = np.asarray(new_pose[1], float).reshape(3)
+                return True
+        return False
+
+    def set_links_vs_environment(self, links):
+        """CollisionAvoidance::setLinksVsEnvironment(links): the links (names with an entry in link_shapes) that are
+        checked against every environment shape; the pair list becomes self_pairs + links x environment"""
+        missing = [l for l in links if l not in self.link_shapes]
+        if missing:
+            raise KeyError(f"no collision capsule known for {missing}")
+        self.env_links = list(links)
+        self._rebuild_pairs()
+
+    def env_pose_array(self):
+        """[n_env][12] world_T_shape of the WORLD-carried shapes, in env-slot order (osot_kin_batch.env_pose)"""
+        W = [e for e in self.env_shapes if e["link"] == "world"]
+        out = np.zeros((len(W), 12))
+        for k, e in enumerate(W):
+            out[k, :9] = e["R"].reshape(9); out[k, 9:] = e["p"]
+        return out
+
+    def _rebuild_pairs(self):
+        if self.self_pairs is None:
+            self.self_pairs = list(self.pairs)
+        pairs = list(self.self_pairs)
+        names = list(getattr(self, "pair_names", [])[:len(self.self_pairs)])
+        world = [e for e in self.env_shapes if e["link"] == "world"]
+        for ln in self.env_links:
+            ja, a0, a1, ra = self.link_shapes[ln]
+            for e in self.env_shapes:
+                if e["link"] == "world":
+                    slot = [w["name"] for w in world].index(e["name"])
+                    jb, env, R, p = -1, slot + 1, np.eye(3), np.zeros(3)     # runtime pose; data in the shape frame
+                else:
+                    jb, env, R, p = self.names.index(e["link"]), 0, e["R"], e["p"]
+                    if jb == ja:
+                        continue
+                if e["kind"] == "box":
+                    pairs.append((ja, a0, a1, ra, jb, (0, 0, 0), (0, 0, 0), e["r"],
+                                  dict(kind=abi.SHAPE_BOX, env=env, half=e["half"], R=R, p=p)))
+                else:
+                    b0, b1 = R @ e["a0"] + p, R @ e["a1"] + p
+                    pairs.append((ja, a0, a1, ra, jb, b0, b1, e["r"], dict(kind=abi.SHAPE_CAPSULE, env=env)))
+                names.append((ln, e["name"]))
+        if len(pairs) > abi.KIN_MAX_PAIRS:
+            raise ValueError(f"{len(pairs)} collision pairs, the producer holds {abi.KIN_MAX_PAIRS}")
+        self.pairs = pairs
+        self.pair_names = names
 
     @property
     def n(self):
@@ -60,12 +150,24 @@ class KinModel:
             d.frame_col_mask[f] = mask(self.frame_active_joints[f]) if f in self.frame_active_joints else 0
         d.com_col_mask = mask(self.com_active_joints) if self.com_active_joints is not None else 0
         d.n_pairs = len(self.pairs)
-        for k, (ja, a0, a1, ra, jb, b0, b1, rb) in enumerate(self.pairs):
+        d.n_env = sum(1 for e in self.env_shapes if e["link"] == "world")
+        for k, pr in enumerate(self.pairs):
+            ja, a0, a1, ra, jb, b0, b1, rb = pr[:8]
+            ex = pr[8] if len(pr) > 8 else {}
             d.pair_joint[k][0], d.pair_joint[k][1] = int(ja), int(jb)
             d.pair_radius[k][0], d.pair_radius[k][1] = float(ra), float(rb)
             for i in range(3):
                 d.pair_seg[k][0][i], d.pair_seg[k][0][3 + i] = float(a0[i]), float(a1[i])
                 d.pair_seg[k][1][i], d.pair_seg[k][1][3 + i] = float(b0[i]), float(b1[i])
+            d.pair_kind[k] = int(ex.get("kind", abi.SHAPE_CAPSULE))
+            d.pair_env[k] = int(ex.get("env", 0))
+            R = np.asarray(ex.get("R", np.eye(3)), float).reshape(9)
+            pp = np.asarray(ex.get("p", np.zeros(3)), float)
+            hf = np.asarray(ex.get("half", np.zeros(3)), float)
+            for i in range(9):
+                d.pair_shape_R[k][i] = float(R[i])
+            for i in range(3):
+                d.pair_shape_p[k][i] = float(pp[i]); d.pair_box[k][i] = float(hf[i])
         return d
 
 
@@ -123,8 +225,9 @@ def humanoid32_pairs(m):
     """capsules on the forearms, hands, torso, pelvis and thighs of humanoid32() and the pairs a self-collision
     constraint would watch (hands / forearms against torso, pelvis, thighs and each other)"""
     nm = m.names.index
-    shape = {"torso": (nm("WaistYaw"), (0, 0, 0.05), (0, 0, 0.22), 0.10), "pelvis": (nm("base_yaw"), (0, -0.05, 0.0), (0, 0.05, 0.0), 0.09),
-             "head": (nm("NeckYaw"), (0, 0, 0.10), (0, 0, 0.10), 0.09)}
+    shape = m.link_shapes          # (kept on the model: setLinksVsEnvironment pairs these capsules with the environment)
+    shape.update({"torso": (nm("WaistYaw"), (0, 0, 0.05), (0, 0, 0.22), 0.10), "pelvis": (nm("base_yaw"), (0, -0.05, 0.0), (0, 0.05, 0.0), 0.09),
+                  "head": (nm("NeckYaw"), (0, 0, 0.10), (0, 0, 0.10), 0.09)})
     for s in "LR":
         shape[s + "forearm"] = (nm(s + "Elbj"), (0, 0, -0.02), (0, 0, -0.15), 0.035)
         shape[s + "hand"] = (nm(s + "Wrj"), (0, 0, -0.06), (0, 0, -0.06), 0.045)
@@ -135,6 +238,9 @@ def humanoid32_pairs(m):
              ("Lhand", "Rforearm"), ("Rhand", "Lforearm"), ("Lhand", "head"), ("Rhand", "head"), ("Lshin", "Rshin"), ("Lthigh", "Rthigh")]
     m.pairs = [shape[a] + shape[b] for a, b in names]
     m.pair_names = names
+    m.self_pairs = list(m.pairs)
+    if m.env_links:
+        m._rebuild_pairs()
     return m
 
 
@@ -168,6 +274,7 @@ class Kinematics:
         d = model.desc()
         abi.check(self._lib.osot_kin_create(C.byref(d), int(device), C.byref(self._h)), "osot_kin_create")
         self.device = torch.device("cuda", device)
+        self._env_host = self._env_dev = self._env_keep = None
 
     def __del__(self):
         try:
@@ -177,9 +284,11 @@ class Kinematics:
         except Exception:
             pass
 
-    def forward(self, q, frame_pose=None, frame_J=None, com=None, com_J=None, pair_dist=None, pair_J=None):
+    def forward(self, q, frame_pose=None, frame_J=None, com=None, com_J=None, pair_dist=None, pair_J=None, env_pose=None):
         """q [B][n] (device).  frame_pose: {frame index: tensor [B][12]}; frame_J: {frame index: (A_k tensor [B][ma][n],
-        first row)}; com: tensor [B][3]; com_J: (A_k tensor, first row).  Stream-ordered on torch's current stream."""
+        first row)}; com: tensor [B][3]; com_J: (A_k tensor, first row).  Stream-ordered on torch's current stream.
+        env_pose: poses of the environment shapes, a device tensor [n_env][12] (one world for all instances) or
+        [B][n_env][12]; default: the model's own (add_collision_shape / move_collision_shape), uploaded when they change"""
         B, n = q.shape
         assert n == self.model.n and q.is_contiguous()
         kb = abi.KinBatch()
@@ -207,5 +316,17 @@ class Kinematics:
             assert A.is_contiguous() and A.shape[2] == n and row + len(self.model.pairs) <= A.shape[1]
             kb.pair_J = A.data_ptr() + 8 * row * n
             kb.pair_J_stride = A.shape[1] * n
+        n_env = sum(1 for e in self.model.env_shapes if e["link"] == "world")
+        if n_env and (pair_dist is not None or pair_J is not None):
+            if env_pose is None:
+                host = self.model.env_pose_array()
+                if self._env_host is None or not np.array_equal(host, self._env_host):
+                    self._env_host = host.copy()
+                    self._env_dev = torch.as_tensor(host, dtype=torch.float64).to(self.device)
+                env_pose = self._env_dev
+            assert env_pose.is_contiguous() and env_pose.shape[-2:] == (n_env, 12)
+            kb.env_pose = env_pose.data_ptr()
+            kb.env_pose_stride = 12 * n_env if env_pose.dim() == 3 else 0
+            self._env_keep = env_pose
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         abi.check(self._lib.osot_kinematics(self._h, C.byref(kb), stream), "osot_kinematics")

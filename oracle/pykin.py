@@ -83,7 +83,45 @@ def closest_segment_points(p1, q1, p2, q2):
     return p1 + s * d1, p2 + t * d2
 
 
-def pair_distances(model, q, fk=None):
+def segment_box_closest(p0, p1, half):
+    """closest points of the segment [p0, p1] and the box [-half, half] (box frame), by an INDEPENDENT route from the
+    kernel's piecewise-quadratic pieces: dist^2 from P(t) to the box is convex in t and its derivative
+    g(t) = 2 sum_i excess_i(t) v_i is continuous and monotone, so the parameter is the root of g (or an end point):
+    bisection to the last bit"""
+    half = np.asarray(half, float)
+    v = p1 - p0
+    P = lambda t: p0 + t * v
+    g = lambda t: float(2.0 * ((P(t) - np.clip(P(t), -half, half)) @ v))
+    if g(0.0) >= 0.0:
+        t = 0.0
+    elif g(1.0) <= 0.0:
+        t = 1.0
+    else:
+        a, b = 0.0, 1.0
+        for _ in range(200):
+            m = 0.5 * (a + b)
+            if g(m) < 0.0:
+                a = m
+            else:
+                b = m
+        t = 0.5 * (a + b)
+    ca = P(t)
+    return ca, np.clip(ca, -half, half)
+
+
+def _carrier(model, fk, jb, ex, env_pose):
+    """world pose (R, p) of the frame side b's data are expressed in: its link, the world, or an environment shape's
+    runtime pose (moveCollisionShape)"""
+    if jb >= 0:
+        return fk["Rw"][jb], fk["pw"][jb]
+    env = int(ex.get("env", 0)) - 1
+    if env >= 0:
+        E = np.asarray(env_pose, float).reshape(-1, 12)[env]
+        return E[:9].reshape(3, 3), E[9:]
+    return np.eye(3), np.zeros(3)
+
+
+def pair_distances(model, q, fk=None, env_pose=None):
     """self-collision pairs (what CollisionAvoidance.cpp:96-118 obtains from the collision module): surface distances
     d[P] of the capsule pairs and the rows J_d[P][n] with delta d = J_d dq"""
     fk = forward(model, q) if fk is None else fk
@@ -94,10 +132,20 @@ def pair_distances(model, q, fk=None):
     for j in range(n):
         anc.append({j} | (anc[model.parent[j]] if model.parent[j] >= 0 else set()))
     d = np.zeros(len(model.pairs)); J = np.zeros((len(model.pairs), n))
-    for k, (ja, a0, a1, ra, jb, b0, b1, rb) in enumerate(model.pairs):
+    if env_pose is None and getattr(model, "env_shapes", None):
+        env_pose = model.env_pose_array()
+    for k, pr in enumerate(model.pairs):
+        ja, a0, a1, ra, jb, b0, b1, rb = pr[:8]
+        ex = pr[8] if len(pr) > 8 else {}
         wa0, wa1 = Rw[ja] @ np.asarray(a0, float) + pw[ja], Rw[ja] @ np.asarray(a1, float) + pw[ja]
-        wb0, wb1 = Rw[jb] @ np.asarray(b0, float) + pw[jb], Rw[jb] @ np.asarray(b1, float) + pw[jb]
-        ca, cb = closest_segment_points(wa0, wa1, wb0, wb1)
+        Rc, pc = _carrier(model, fk, jb, ex, env_pose)
+        if ex.get("kind", 0) == 1:      # box: carrier o link_T_shape is the box frame (CollisionAvoidance.h:115-119)
+            Rb = Rc @ np.asarray(ex["R"], float).reshape(3, 3); pb = pc + Rc @ np.asarray(ex["p"], float)
+            la, lb = segment_box_closest(Rb.T @ (wa0 - pb), Rb.T @ (wa1 - pb), ex["half"])
+            ca, cb = Rb @ la + pb, Rb @ lb + pb
+        else:
+            wb0, wb1 = Rc @ np.asarray(b0, float) + pc, Rc @ np.asarray(b1, float) + pc
+            ca, cb = closest_segment_points(wa0, wa1, wb0, wb1)
         dv = ca - cb
         ln = np.linalg.norm(dv)
         d[k] = ln - ra - rb
@@ -106,6 +154,6 @@ def pair_distances(model, q, fk=None):
         nn = dv / ln
         for j in range(n):
             va = (np.cross(z[j], ca - pw[j]) if model.jtype[j] == 0 else z[j]) if j in anc[ja] else np.zeros(3)
-            vb = (np.cross(z[j], cb - pw[j]) if model.jtype[j] == 0 else z[j]) if j in anc[jb] else np.zeros(3)
+            vb = (np.cross(z[j], cb - pw[j]) if model.jtype[j] == 0 else z[j]) if (jb >= 0 and j in anc[jb]) else np.zeros(3)
             J[k, j] = nn @ (va - vb)
     return d, J

@@ -238,7 +238,7 @@ def kkt_check(H, g, A, lA, uA, l, u, x, eps_abs, tol=1e-7):
     return resid
 
 
-def emu_kinematics(model, q):
+def emu_kinematics(model, q, env_pose=None):
     """the kinematics kernel body on host arrays through the emulator: q [B][n] -> poses, frame Jacobians, com, Jcom"""
     L = emu_lib()
     L.emu_kinematics.argtypes = [C.POINTER(abi.KinDesc), C.POINTER(abi.KinBatch)]
@@ -263,6 +263,12 @@ def emu_kinematics(model, q):
     if P:
         pd = np.zeros((B, P)); pJ = np.full((B, P + 1, n), 7.0)
         kb.pair_dist = pd.ctypes.data; kb.pair_J = pJ.ctypes.data; kb.pair_J_stride = (P + 1) * n
+        if env_pose is None and getattr(model, "env_shapes", None):
+            env_pose = model.env_pose_array()
+        if env_pose is not None and np.asarray(env_pose).size:
+            env_pose = np.ascontiguousarray(env_pose, dtype=np.float64)
+            kb.env_pose = env_pose.ctypes.data
+            kb.env_pose_stride = env_pose.shape[-2] * 12 if env_pose.ndim == 3 else 0
     assert L.emu_kinematics(C.byref(d), C.byref(kb)) == 0
     if P:
         return poses, J, com, pd, pJ

@@ -527,3 +527,173 @@ def test_closed_loop_coman_ik_stack_with_contact_constraints(oracle, gpu_device)
     assert err[1] < 3e-3 and err[0] < 2e-2           # r_wrist converged, l_wrist (weight 0.1, same level) follows
     assert err[2] < 5e-3 and err[3] < 5e-3           # the feet are CONSTRAINTS here: velocity-level rows, lambda = 0.1 on the drift
     assert float((com_d - com).norm(dim=1).max()) < 1e-3
+
+
+# ---- environment shapes and boxes (addCollisionShape / moveCollisionShape / setLinksVsEnvironment) ------------
+def _humanoid_with_environment():
+    """the 32-DoF humanoid's self-collision pairs plus its hands / forearms against a static world: a box (table edge in
+    front of the robot), a sphere and a capsule (a post), and a rotated box carried by the TORSO link"""
+    m = kin.humanoid32_pairs(kin.humanoid32())
+    m.self_pairs = m.pairs[:4]; m.pairs = m.pairs[:4]; m.pair_names = m.pair_names[:4]
+    Rz = lambda a: np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+    Rx = lambda a: np.array([[1.0, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+    assert m.add_collision_shape("table", "world", ("box", (0.30, 0.80, 0.04)), (Rz(0.3) @ Rx(0.1), (0.33, 0.05, 0.10)))
+    assert m.add_collision_shape("ball", "world", ("sphere", 0.08), (np.eye(3), (0.25, -0.30, 0.30)))
+    assert m.add_collision_shape("post", "world", ("capsule", 0.60, 0.03), (Rx(0.2), (0.20, 0.35, 0.10)))
+    assert m.add_collision_shape("chest_plate", "WaistYaw", ("box", (0.06, 0.20, 0.16)), (Rz(0.1), (0.11, 0.0, 0.14)))
+    assert not m.add_collision_shape("ball", "world", ("sphere", 0.1))           # the name is taken
+    assert not m.add_collision_shape("x", "no_such_link", ("sphere", 0.1))
+    m.set_links_vs_environment(["Lhand", "Rhand", "Lforearm", "Rforearm"])
+    assert len(m.pairs) == 4 + 4 * 4 and m.pair_names[4] == ("Lhand", "table")
+    return m
+
+
+def test_environment_pairs_match_finite_differences():
+    """link-vs-environment pairs of the restatement (sphere, capsule and BOX, world-fixed and link-carried): the rows against
+    central differences of the distances; a known-answer segment / box case; moveCollisionShape moves the distances"""
+    m = _humanoid_with_environment()
+    rng = np.random.default_rng(21)
+    h = 1e-6
+    for _ in range(3):
+        q = rng.uniform(-0.6, 0.6, m.n)
+        d, J = pykin.pair_distances(m, q)
+        Jfd = np.zeros_like(J)
+        for j in range(m.n):
+            e = np.zeros(m.n); e[j] = h
+            Jfd[:, j] = (pykin.pair_distances(m, q + e)[0] - pykin.pair_distances(m, q - e)[0]) / (2 * h)
+        ok = d + np.array([p[3] + p[7] for p in m.pairs]) > 1e-3      # (a segment inside a box has no normal: zero row)
+        assert ok.sum() >= 18 and np.abs(J[ok] - Jfd[ok]).max() < 2e-7
+    # known answers in the box frame: a point above a face, beside an edge, and a segment that passes over a corner
+    half = np.array([1.0, 2.0, 3.0])
+    ca, cb = pykin.segment_box_closest(np.array([0.5, 0.5, 5.0]), np.array([0.5, 0.5, 5.0]), half)
+    assert np.allclose(cb, [0.5, 0.5, 3.0]) and abs(np.linalg.norm(ca - cb) - 2.0) < 1e-15
+    ca, cb = pykin.segment_box_closest(np.array([4.0, 6.0, 0.0]), np.array([4.0, 6.0, 0.0]), half)
+    assert np.allclose(cb, [1.0, 2.0, 0.0]) and abs(np.linalg.norm(ca - cb) - 5.0) < 1e-15
+    ca, cb = pykin.segment_box_closest(np.array([3.0, 0.0, 4.0]), np.array([-1.0, 4.0, 4.0]), half)
+    assert np.allclose(cb, [1.0, 2.0, 3.0]) and abs(np.linalg.norm(ca - cb) - 1.0) < 1e-12
+    q = rng.uniform(-0.4, 0.4, m.n)
+    d0, _ = pykin.pair_distances(m, q)
+    assert m.move_collision_shape("ball", (np.eye(3), (0.25, -0.30, 0.80))) and not m.move_collision_shape("chest_plate", (np.eye(3), (0, 0, 0)))
+    d1, _ = pykin.pair_distances(m, q)
+    moved = [k for k, nm in enumerate(m.pair_names) if nm[1] == "ball"]
+    same = [k for k in range(len(m.pairs)) if k not in moved]
+    assert np.abs(d1[moved] - d0[moved]).min() > 1e-2 and np.abs(d1[same] - d0[same]).max() == 0.0
+
+
+def test_emulated_environment_pairs_match_restatement():
+    from helpers import emu_kinematics
+    m = _humanoid_with_environment()
+    rng = np.random.default_rng(22)
+    B = 5
+    q = rng.uniform(-0.8, 0.8, (B, m.n))
+    P = len(m.pairs)
+    poses, J, com, pd, pJ = emu_kinematics(m, q)
+    for i in range(B):
+        d, Jd = pykin.pair_distances(m, q[i])
+        assert np.abs(pd[i] - d).max() < 1e-12 and np.abs(pJ[i, :P] - Jd).max() < 1e-12
+    # one world per instance (a [B][n_env][12] pose array): instance i sees the ball shifted by 0.1 i
+    env = np.repeat(m.env_pose_array()[None], B, axis=0)
+    ball = [e["name"] for e in m.env_shapes if e["link"] == "world"].index("ball")
+    env[:, ball, 11] += 0.1 * np.arange(B)
+    poses, J, com, pd, pJ = emu_kinematics(m, q, env_pose=env)
+    for i in range(B):
+        d, Jd = pykin.pair_distances(m, q[i], env_pose=env[i])
+        assert np.abs(pd[i] - d).max() < 1e-12 and np.abs(pJ[i, :P] - Jd).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_environment_pairs_kernel_matches_restatement(gpu_device):
+    import torch
+    m = _humanoid_with_environment()
+    K = kin.Kinematics(m, device=0)
+    B, P = 200, len(m.pairs)
+    rng = np.random.default_rng(23)
+    q = rng.uniform(-0.8, 0.8, (B, m.n))
+    dev = torch.device("cuda", 0)
+    tq = torch.as_tensor(q, device=dev)
+    Jd = torch.full((B, P + 1, m.n), 7.0, dtype=torch.float64, device=dev)
+    dist = torch.zeros((B, P), dtype=torch.float64, device=dev)
+    K.forward(tq, pair_dist=dist, pair_J=(Jd, 0))
+    torch.cuda.synchronize()
+    Jh, dh = Jd.cpu().numpy(), dist.cpu().numpy()
+    for i in range(0, B, 9):
+        d, J = pykin.pair_distances(m, q[i])
+        assert np.abs(dh[i] - d).max() < 1e-12 and np.abs(Jh[i, :P] - J).max() < 1e-12
+    assert (Jh[:, P] == 7.0).all()
+    # moveCollisionShape: the new pose is a runtime input of the next launch
+    assert m.move_collision_shape("table", (np.eye(3), (0.40, 0.0, 0.25)))
+    K.forward(tq, pair_dist=dist, pair_J=(Jd, 0))
+    torch.cuda.synchronize()
+    d, J = pykin.pair_distances(m, q[7])
+    assert np.abs(dist[7].cpu().numpy() - d).max() < 1e-12 and np.abs(Jd[7, :P].cpu().numpy() - J).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_closed_loop_hand_stops_at_a_world_box(gpu_device):
+    """SURVEY 8f-3 end to end with an ENVIRONMENT shape: the right wrist is sent to a point behind a world box
+    (addCollisionShape + setLinksVsEnvironment); q -> distances and rows (osot_kinematics) -> CollisionAvoidance rows
+    (osot_stack_update, CollisionAvoidance.cpp:119-147) -> dq -> q += dq.  Without the constraint the hand ends inside the
+    box, with it the hand sphere stops at the distance threshold from the box surface."""
+    import torch
+    from opensot_amd.plan import Rows, subtask
+    from opensot_amd.solver import BatchedStack
+    dev = torch.device("cuda", 0)
+    f64 = dict(dtype=torch.float64, device=dev)
+    B, d_min = 32, 0.02
+    rng = np.random.default_rng(3)
+
+    def run(with_constraint):
+        m = kin.humanoid32_pairs(kin.humanoid32())
+        m.self_pairs = []; m.pairs = []; m.pair_names = []
+        n = m.n
+        q0 = np.zeros((B, n))
+        q0[:, [m.names.index(s + "Elbj") for s in "RL"]] = -0.9
+        q0 += rng.normal(0.0, 0.01, (B, n))
+        fk0 = pykin.forward(m, q0[0])
+        hand = fk0["frame_p"][m.frame_index("r_wrist")]
+        # a wall 12 cm in front of the hand, the target 10 cm behind its near face
+        wall_c = hand + np.array([0.12 + 0.05, 0.0, 0.0])
+        assert m.add_collision_shape("wall", "world", ("box", (0.10, 0.60, 0.60)), (np.eye(3), wall_c))
+        m.set_links_vs_environment(["Rhand", "Rforearm"])
+        P = len(m.pairs)
+        wrist = lambda nm: subtask(Task(abi.TASK_CARTESIAN, 6, lam=0.1, name=nm), [0, 1, 2])
+        levels = [[Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="l_sole"), Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="r_sole")],
+                  [wrist("r_wrist")], [Task(abi.TASK_POSTURAL, n, lam=0.01, name="postural")]]
+        rows = [Rows(abi.ROWS_COLLISION, P, d_threshold=d_min, detection_threshold=0.0, bound_scaling=0.2, name="env")] if with_constraint else []
+        plan = StackPlan(n=n, levels=levels, bounds=[Bound(abi.BOUND_VELOCITY_LIMITS, dT=0.01, name="vl")], rowblocks=rows,
+                         eps_abs=eps_abs_from_factor(1e6))
+        st = BatchedStack(plan, B, device=0, want_levels=False)
+        K = kin.Kinematics(m, device=0)
+        q = torch.as_tensor(q0, **f64).contiguous()
+        pose = [torch.zeros((B, 12), **f64) for _ in range(4)]
+        Jd = torch.zeros((B, P, n), **f64); dist = torch.zeros((B, P), **f64)
+        Jw = torch.zeros((B, 6, n), **f64)
+        fr = m.frame_index
+
+        def fk():
+            K.forward(q, frame_pose={f: pose[f] for f in range(4)},
+                      frame_J={fr("l_sole"): (st.A[0], 0), fr("r_sole"): (st.A[0], 6), fr("r_wrist"): (Jw, 0)}, pair_dist=dist, pair_J=(Jd, 0))
+            st.A[1][:B, 0:3].copy_(Jw[:, 0:3])
+        fk(); torch.cuda.synchronize()
+        pose_d = [p.clone() for p in pose]
+        pose_d[fr("r_wrist")][:, 9] += 0.22          # 10 cm behind the wall's near face
+        q_ref = q.clone()
+        leaf = {"B": B, "task": [[(pose[fr("l_sole")], pose_d[fr("l_sole")], None), (pose[fr("r_sole")], pose_d[fr("r_sole")], None)],
+                                 [(pose[fr("r_wrist")], pose_d[fr("r_wrist")], None)], [(q, q_ref, None)]],
+                "bound": [(torch.full((B, n), 2.0, **f64), None, None)], "rows": [(Jd, dist, None)] if with_constraint else []}
+        for cycle in range(300):
+            fk()
+            st.update(leaf); st.solve(B)
+            q += st.dq[:B]
+        fk(); torch.cuda.synchronize()
+        assert (st.status[:B] == 0).all()
+        return dist.cpu().numpy(), (pose_d[fr("r_wrist")][:, 9:] - pose[fr("r_wrist")][:, 9:]).norm(dim=1).cpu().numpy(), q.cpu().numpy(), m
+
+    free_d, free_err, _, _ = run(False)
+    safe_d, safe_err, q, m = run(True)
+    hand_pair = m.pair_names.index(("Rhand", "wall"))
+    assert free_err.max() < 5e-3 and free_d[:, hand_pair].max() < 0.0      # unconstrained: the wrist reaches the target INSIDE the wall
+    assert safe_d.min() > d_min - 2e-3                                     # constrained: nothing comes closer than the threshold
+    assert np.abs(safe_d[:, hand_pair] - d_min).max() < 5e-3 and safe_err.min() > 0.05    # the hand rests against the wall
+    d, _ = pykin.pair_distances(m, q[3])
+    assert np.abs(d - safe_d[3]).max() < 1e-12
