@@ -73,7 +73,8 @@ typedef enum {
     /* inverse-dynamics formulation, x = [qddot; contact forces] (src/utils/InverseDynamics.cpp:12-28).  The
      * producer writes the task matrix ([J 0] ...) into A_k; the update computes b from the supplied errors. */
     OSOT_TASK_ACC_CARTESIAN = 4, /* acceleration::Cartesian (src/tasks/acceleration/Cartesian.cpp:127-180):
-                                    b = a_ref + lambda2*vel_err + lambda*pose_err - Jdot*qdot (Kp = Kd = I) */
+                                    b = a_ref + lambda2*Kd*vel_err + lambda*Kp*pose_err - Jdot*qdot (Kp = Kd = I
+                                    unless osot_task_desc.acc_gain_matrices) */
     OSOT_TASK_ACC_COM = 5,       /* acceleration::CoM (src/tasks/acceleration/CoM.cpp:74-97), 3 rows */
     OSOT_TASK_ACC_POSTURAL = 6   /* acceleration::Postural (src/tasks/acceleration/Postural.cpp:135-163):
                                     A = [I_rows 0] implicit like OSOT_TASK_POSTURAL,
@@ -105,6 +106,15 @@ typedef struct {
      * (osot_assembled_out.WA / Wb) and the cascade takes them as the left operand of H = A'(WA), g = -A'(Wb).  A
      * Postural block with dense_weight is stored like any other block (its unit rows are written by the producer). */
     int dense_weight;
+    /* gain MATRICES of the acceleration tasks (acceleration::Cartesian::setGains(Kp, Kd), setKp / setKd,
+     * src/tasks/acceleration/Cartesian.cpp:152-173; round 3 -- before: Kp = Kd = I).  1: the task's leaf array p0 carries
+     * them per instance behind the errors, p0 = [pose_err (rows); vel_err (rows); Gp (rows x rows, row-major); Gd (rows x
+     * rows)], and b = a_ref + lambda2 Gd vel_err + lambda Gp pose_err - Jdot qdot.
+     *   GainType::Acceleration (:155-160): Gp = Kp, Gd = Kd, the same for every instance.
+     *   GainType::Force        (:161-169): Gp = Mi Kp, Gd = Mi Kd with Mi = J B^-1 J' the inverse Cartesian inertia, and the
+     *     virtual force enters as a_ref + Mi f -- osot_id_force_gains below writes all three from J, B^-1, Kp, Kd, f.
+     * Only OSOT_TASK_ACC_CARTESIAN / OSOT_TASK_ACC_COM; 0 = scalar gains. */
+    int acc_gain_matrices;
 } osot_task_desc;
 
 typedef struct {
@@ -189,10 +199,14 @@ typedef struct {
      * optimality row.  Supported: identity-Jacobian tasks A_r = [I_rows 0] with W_r = weight * I, i.e.
      * OSOT_TASK_GENERIC (b supplied: GenericTask(I, b) as in tests/solvers/TestiHQP.cpp:118-120, MinimumVelocity
      * with b = 0), OSOT_TASK_POSTURAL and OSOT_TASK_ACC_POSTURAL; row_mask must be 0.  Then Hr = weight * [I_rows 0;
-     * 0 0] is folded into the diagonal and gr = -weight * b_r.  A regularisation task with a dense Jacobian is
-     * rejected (OSOT_ERR_UNSUPPORTED). */
+     * 0 0] is folded into the diagonal and gr = -weight * b_r.  (A stored Jacobian: regularisation_dense below.) */
     int has_regularisation;
     osot_task_desc regularisation;
+    /* regularisation task with a STORED Jacobian (round 3; iHQP.cpp:265-278 takes any task): 1 = A_r is the
+     * [B][regularisation.rows][n] array osot_qp_batch.A_reg (written by the producer, like a level's A_k), W_r = weight * I,
+     * b_r from the update like any task of its kind (TASK_GENERIC, TASK_CARTESIAN, TASK_COM); H += A_r'W_r A_r and
+     * g -= A_r'W_r b_r at every level, never an optimality row.  0 = the identity-Jacobian form above. */
+    int regularisation_dense;
 } osot_plan_desc;
 
 /* ---- assembled, batched QP data (device pointers) ------------------------------------------ */
@@ -224,6 +238,8 @@ typedef struct {
                                            no multiplier to trade; at most min(1e-6 * max(1, |bound|), 1e-5)); 0 = none.
                                            The status stays OSOT_STATUS_SOLVED, like the reference's `true` when qpOASES
                                            stops inside its own tolerances */
+    const double* A_reg;                /* [B][regularisation.rows][n] Jacobian of the regularisation task; read iff
+                                           plan.regularisation_dense */
 } osot_qp_batch;
 
 /* ---- leaf inputs of AutoStack::update (device pointers) ------------------------------------ */
@@ -530,6 +546,14 @@ typedef struct {
 int osot_id_rows(const osot_id_model* m, double* C_dyn, long long dyn_stride, double* C_tau, long long tau_stride,
                  int n_tasks, const double* const* J, const int* J_rows, double* const* A_dst, const long long* A_stride,
                  void* hip_stream);
+/* GainType::Force of acceleration::Cartesian (src/tasks/acceleration/Cartesian.cpp:161-169, 517-524): per instance
+ * Mi = J Bi J' (compute_cartesian_inertia_inverse: Bi = the model's inverse inertia matrix, [B][nv][nv]; J [B][rows][nv]),
+ * then Gp = Mi Kp, Gd = Mi Kd written into the task's leaf array p0 behind its 2 rows errors (see
+ * osot_task_desc.acc_gain_matrices: p0_gains points at instance 0's Gp, p0_stride = 2 rows + 2 rows^2 doubles), and
+ * a_ref[B][rows] += Mi f for a virtual force f [B][rows] (NULL: none).  Kp, Kd: HOST pointers to rows x rows row-major
+ * matrices (the task's settings).  rows <= 6. */
+int osot_id_force_gains(int B, int nv, int rows, const double* J, const double* Bi, const double* Kp, const double* Kd,
+                        const double* f_virtual, double* p0_gains, long long p0_stride, double* a_ref, void* hip_stream);
 /* InverseDynamics::computedTorque (InverseDynamics.cpp:57-96): tau[B][nv] = B qddot + h - sum_c Jc' F_c from the solved
  * x[B][n]; ok[B] (may be NULL) = 0 where a floating-base row of tau exceeds fb_tol (the reference uses 10e-3 and
  * returns false). */

@@ -25,7 +25,7 @@ class TaskDesc(C.Structure):
     _fields_ = [("kind", C.c_int), ("rows", C.c_int), ("weight", C.c_double),
                 ("lambda_", C.c_double), ("orientation_gain", C.c_double), ("lambda2", C.c_double),
                 ("row_mask", C.c_ulonglong), ("parent_rows", C.c_int), ("sub_lambda", C.c_double),
-                ("body_frame", C.c_int), ("dense_weight", C.c_int)]
+                ("body_frame", C.c_int), ("dense_weight", C.c_int), ("acc_gain_matrices", C.c_int)]
 
 
 class LevelDesc(C.Structure):
@@ -50,7 +50,7 @@ class PlanDesc(C.Structure):
                 ("n_bounds", C.c_int), ("bound", BoundDesc * MAX_BOUNDS),
                 ("n_rowblocks", C.c_int), ("rowblock", RowsDesc * MAX_ROWBLOCKS),
                 ("eps_abs", C.c_double), ("max_iter", C.c_int),
-                ("has_regularisation", C.c_int), ("regularisation", TaskDesc)]
+                ("has_regularisation", C.c_int), ("regularisation", TaskDesc), ("regularisation_dense", C.c_int)]
 
 
 class QpBatch(C.Structure):
@@ -63,7 +63,7 @@ class QpBatch(C.Structure):
                 ("dq", C.c_void_p), ("x_levels", C.c_void_p),
                 ("status", C.c_void_p), ("iterations", C.c_void_p), ("b_reg", C.c_void_p),
                 ("WA", C.c_void_p * MAX_LEVELS), ("Wb", C.c_void_p * MAX_LEVELS),
-                ("accepted_slack", C.c_void_p)]
+                ("accepted_slack", C.c_void_p), ("A_reg", C.c_void_p)]
 
 
 class LeafPtrs(C.Structure):
@@ -132,7 +132,7 @@ SYMBOLS = [
     "osot_plan_stored_constraint_rows",
     "osot_solver_create", "osot_solver_destroy", "osot_stack_update", "osot_ihqp_solve", "osot_cycle", "osot_nhqp_solve", "osot_ehqp_solve",
     "osot_solver_kernel_time_ms", "osot_solver_set_timing", "osot_solver_set_schedule", "osot_solver_set_hotstart", "osot_solver_set_task_active", "osot_solver_resident_waves",
-    "osot_id_rows", "osot_computed_torque", "osot_kin_create", "osot_kin_destroy", "osot_kinematics", "osot_solver_profile_phases",
+    "osot_id_rows", "osot_id_force_gains", "osot_computed_torque", "osot_kin_create", "osot_kin_destroy", "osot_kinematics", "osot_solver_profile_phases",
     "osot_backend_create", "osot_backend_destroy", "osot_backend_init_problem",
     "osot_backend_update_task", "osot_backend_update_constraints", "osot_backend_update_bounds",
     "osot_backend_solve", "osot_backend_get_solution", "osot_backend_get_objective",
@@ -186,6 +186,7 @@ def lib():
     L.osot_solver_set_hotstart.argtypes = [vp, C.c_int]
     L.osot_solver_set_task_active.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.osot_solver_resident_waves.argtypes = [vp, ip]
+    L.osot_id_force_gains.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, dp, dp, vp, vp, C.c_longlong, vp, vp]
     L.osot_id_rows.argtypes = [C.POINTER(IdModel), vp, C.c_longlong, vp, C.c_longlong, C.c_int, vp, vp, vp, vp, vp]
     L.osot_computed_torque.argtypes = [C.POINTER(IdModel), vp, vp, vp, C.c_double, vp]
     L.osot_kin_create.argtypes = [C.POINTER(KinDesc), C.c_int, C.POINTER(vp)]

@@ -98,15 +98,23 @@ inline int plan_validate(const osot_plan_desc* p, const char** why) {
             if (!(t.weight >= 0.0)) { *why = "negative task weight"; return OSOT_ERR_INVALID; }
             if (t.body_frame && t.kind != OSOT_TASK_CARTESIAN) { *why = "body_frame is an option of velocity::Cartesian"; return OSOT_ERR_INVALID; }
             if (t.dense_weight && t.rows > 64) { *why = "dense weight: at most 64 rows per block"; return OSOT_ERR_INVALID; }
+            if (t.acc_gain_matrices && t.kind != OSOT_TASK_ACC_CARTESIAN && t.kind != OSOT_TASK_ACC_COM) {
+                *why = "gain matrices are an option of the acceleration Cartesian / CoM tasks"; return OSOT_ERR_INVALID; }
         }
     }
     if (p->has_regularisation) {   // identity-Jacobian regularisation only: Hr is folded into the diagonal
         const osot_task_desc& t = p->regularisation;
-        if (t.kind != OSOT_TASK_GENERIC && t.kind != OSOT_TASK_POSTURAL && t.kind != OSOT_TASK_ACC_POSTURAL) {
-            *why = "regularisation task: only identity-Jacobian kinds (generic b with A = [I 0], Postural) are supported"; return OSOT_ERR_UNSUPPORTED; }
+        if (p->regularisation_dense) {   // stored Jacobian A_r (osot_qp_batch.A_reg): any kind whose b the update forms without A
+            if (t.kind != OSOT_TASK_GENERIC && t.kind != OSOT_TASK_CARTESIAN && t.kind != OSOT_TASK_COM) {
+                *why = "regularisation task with a stored Jacobian: kinds GENERIC, CARTESIAN, COM"; return OSOT_ERR_UNSUPPORTED; }
+            if (t.rows < 1 || t.rows > 64) { *why = "regularisation task: rows out of range (1..64)"; return OSOT_ERR_INVALID; }
+        } else {
+            if (t.kind != OSOT_TASK_GENERIC && t.kind != OSOT_TASK_POSTURAL && t.kind != OSOT_TASK_ACC_POSTURAL) {
+                *why = "regularisation task without a stored Jacobian: identity-Jacobian kinds (generic b with A = [I 0], Postural)"; return OSOT_ERR_UNSUPPORTED; }
+            if (t.rows < 1 || t.rows > p->n) { *why = "regularisation task: rows out of range (1..n)"; return OSOT_ERR_INVALID; }
+        }
         if (t.row_mask != 0ull) { *why = "regularisation task cannot be a sub-task"; return OSOT_ERR_UNSUPPORTED; }
         if (t.dense_weight || t.body_frame) { *why = "regularisation task: scalar weight, no frame option"; return OSOT_ERR_UNSUPPORTED; }
-        if (t.rows < 1 || t.rows > p->n) { *why = "regularisation task: rows out of range (1..n)"; return OSOT_ERR_INVALID; }
         if (!(t.weight >= 0.0)) { *why = "negative task weight"; return OSOT_ERR_INVALID; }
         flat += 1;
     }
@@ -200,6 +208,7 @@ inline int make_dev_plan(const osot_plan_desc& p, const unsigned char* level_act
     P.eps_abs = p.eps_abs;
     P.reg_rows = p.has_regularisation ? p.regularisation.rows : 0;
     P.reg_w = p.has_regularisation ? p.regularisation.weight : 0.0;
+    P.reg_dense = (p.has_regularisation && p.regularisation_dense) ? 1 : 0;
     NP = (p.n <= 32) ? 32 : 64;
     // cascade layout: M1, M2, V | rlo, rup, rptr | rowstate, eqlist | rsrc bytes
     const int S = NP + 1;
@@ -229,6 +238,7 @@ inline void make_update_plan(const osot_plan_desc& pl, DevUpdatePlan& U) {
             d.level = k; d.kind = t.kind; d.rows = t.rows; d.off = off;
             d.weight = t.weight; d.lambda = t.lambda; d.ogain = t.orientation_gain; d.lambda2 = t.lambda2;
             d.mask = t.row_mask; d.prow = task_parent_rows(t, pl.n); d.sublam = t.row_mask ? t.sub_lambda : 1.0;
+            d.gains = t.acc_gain_matrices ? 1 : 0;
             d.body = t.body_frame; d.dense = t.dense_weight;
             if (t.dense_weight) U.dense_level[k] = 1;
             off += t.rows;
@@ -240,6 +250,7 @@ inline void make_update_plan(const osot_plan_desc& pl, DevUpdatePlan& U) {
         d.level = -1; d.kind = t.kind; d.rows = t.rows; d.off = 0;
         d.weight = t.weight; d.lambda = t.lambda; d.ogain = t.orientation_gain; d.lambda2 = t.lambda2;
         d.mask = 0ull; d.prow = t.rows; d.sublam = 1.0;
+        d.gains = 0; d.body = 0; d.dense = 0;
     }
     U.ntasks = flat;
     {

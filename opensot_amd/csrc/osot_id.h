@@ -101,4 +101,63 @@ __global__ void __launch_bounds__(64) osot_torque_kernel(const DevTorque T) {
     }
 }
 
+// GainType::Force of acceleration::Cartesian (src/tasks/acceleration/Cartesian.cpp:161-169): Mi = J Bi J' (:517-524), then
+// Gp = Mi Kp, Gd = Mi Kd into the task's leaf array and a_ref += Mi f.  One wavefront per instance; lane = column of Bi for
+// the product T = J Bi (rows x nv, through LDS), then lanes (r, s) < rows^2 each own one entry of the small products.
+struct DevForceGains {
+    int B, nv, rows;
+    const double* J;       // [B][rows][nv]
+    const double* Bi;      // [B][nv][nv] inverse inertia matrix (symmetric)
+    double Kp[36], Kd[36]; // rows x rows, row-major
+    const double* f;       // [B][rows] virtual force, may be null
+    double* G; long long G_stride;   // Gp of instance 0 (Gd follows it); doubles between instances
+    double* a_ref;         // [B][rows], += Mi f (may be null when f is)
+};
+
+__global__ void __launch_bounds__(64) osot_force_gains_kernel(const DevForceGains F) {
+    OSOT_STATIC_LDS(double, Ts, 6 * 64);    // T = J Bi
+    OSOT_STATIC_LDS(double, Js, 6 * 64);    // J
+    OSOT_STATIC_LDS(double, Ms, 36);        // Mi
+    const long long inst = blockIdx.x;
+    const int c = threadIdx.x;
+    if (inst >= F.B) return;
+    const int nv = F.nv, R = F.rows;
+    const double* J = F.J + inst * R * nv;
+    const double* Bi = F.Bi + inst * (long long)nv * nv;
+    for (int r = 0; r < R; ++r) Js[r * 64 + c] = (c < nv) ? J[r * nv + c] : 0.0;
+    wave_sync();
+    // T[r][c] = sum_k J[r][k] Bi[k][c]: lane c walks column c of Bi (coalesced rows), J[r][k] is an LDS broadcast
+    double t[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (c < nv)
+        for (int k = 0; k < nv; ++k) {
+            const double b = Bi[k * nv + c];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) if (r < R) t[r] = fma(Js[r * 64 + k], b, t[r]);
+        }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) if (r < R) Ts[r * 64 + c] = t[r];
+    wave_sync();
+    // Mi[r][s] = sum_c T[r][c] J[s][c]: lane (r, s)
+    if (c < R * R) {
+        const int r = c / R, sidx = c % R;
+        double acc = 0.0;
+        for (int k = 0; k < nv; ++k) acc = fma(Ts[r * 64 + k], Js[sidx * 64 + k], acc);
+        Ms[c] = acc;
+    }
+    wave_sync();
+    if (c < R * R) {
+        const int r = c / R, sidx = c % R;
+        double gp = 0.0, gd = 0.0;
+        for (int k = 0; k < R; ++k) { gp = fma(Ms[r * R + k], F.Kp[k * R + sidx], gp); gd = fma(Ms[r * R + k], F.Kd[k * R + sidx], gd); }
+        double* G = F.G + inst * F.G_stride;
+        G[c] = gp;
+        G[R * R + c] = gd;
+    }
+    if (F.f && F.a_ref && c < R) {
+        double acc = 0.0;
+        for (int k = 0; k < R; ++k) acc = fma(Ms[c * R + k], F.f[inst * R + k], acc);
+        F.a_ref[inst * R + c] += acc;
+    }
+}
+
 }  // namespace osot

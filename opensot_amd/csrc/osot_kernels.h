@@ -61,6 +61,8 @@ struct DevPlan {
     // entries of every level's H, gr = -w b_r
     int reg_rows;
     double reg_w;
+    int reg_dense;                  // 1: the regularisation task has a stored Jacobian A_r (DevBatch.A_reg): H += w A_r'A_r,
+                                    // g -= w A_r'b_r at every level, in the EXTRA instantiation (no folding into the diagonal)
     // LDS carve-up of the wave's slice (doubles): M1, M2, V first (sizes fixed by NP), then
     int lds_rows_off;               // the row table: rlo, rup, rptr (8 B per row), rowstate, eqlist, rsrc (4 B per row)
     int lds_rows_cap;               // capacity (rows), even
@@ -90,6 +92,7 @@ struct DevBatch {
                        // no extra workgroup in the grid
     int slots;         // wavefronts the chip holds at once for this kernel (see order_body)
     const double* b_reg;   // [B][reg_rows] b of the regularisation task (null: none)
+    const double* A_reg;   // [B][reg_rows][n] its Jacobian when the plan says reg_dense
     const double* WA[OSOT_KMAX_LEVELS];   // [B][ma_k][n] W_k A_k, [B][m_k] W_k b_k of a level with a non-diagonal weight
     const double* Wb[OSOT_KMAX_LEVELS];   // (osot_update_kernel writes them); null: W_k is diag(w[k])
     double* accepted_slack;   // [B] largest constraint violation accepted as round-off (0: none); may be null
@@ -146,7 +149,8 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
     wave_sync();
 
     // regularisation task (same for every level): its diagonal joins eps, its linear term joins g
-    const bool regc = D.b_reg != nullptr && c < P.reg_rows;
+    const bool regd = EXTRA && P.reg_dense && D.b_reg != nullptr;       // stored Jacobian: added row by row in the H build
+    const bool regc = D.b_reg != nullptr && !regd && c < P.reg_rows;
     const double greg = regc ? -P.reg_w * D.b_reg[inst * P.reg_rows + c] : 0.0;
     const double dreg = regc ? P.reg_w : 0.0;
 
@@ -212,13 +216,13 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
         };
         auto wrow = [&](int r) -> double { return (inact && row_off(r)) ? 0.0 : (wk ? wk[r] : 1.0); };
         double g = 0.0, hdiag = 0.0;
-        const bool diag_h = (ma == 0);
+        const bool diag_h = (ma == 0) && !regd;
         double hacc[NP / HV];
         bool lowrank = false;   // few stored rows: J and x in closed form, no H, no factorisation (lowrank_prepare32)
         double xprep = 0.0;
         if constexpr (NP == 32) {
 #ifndef OSOT_X_NO_LOWRANK
-            if (!diag_h && ma <= kLowRankMax && !dense && !inact) {
+            if (!diag_h && ma <= kLowRankMax && !dense && !inact && !regd) {
 #else
             if (false) {
 #endif
@@ -309,6 +313,23 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
                     }
                 }
             }
+            if (regd) {   // the regularisation task's rows: H += w A_r'A_r, g -= w A_r'b_r (iHQP.cpp:274-278), same operand layout
+                const double* Ar = D.A_reg + inst * (long long)P.reg_rows * n;
+                const double* br = D.b_reg + inst * P.reg_rows;
+                for (int r0 = 0; r0 < P.reg_rows; r0 += 4) {
+                    const int r = r0 + tq;
+                    const bool in = r < P.reg_rows;
+                    const int rr = in ? r : P.reg_rows - 1;
+                    const double v0 = Ar[rr * n + ((ta < n) ? ta : 0)], v1 = Ar[rr * n + ((16 + ta < n) ? 16 + ta : 0)];
+                    const double a0 = (in && ta < n) ? v0 : 0.0, a1 = (in && 16 + ta < n) ? v1 : 0.0;
+                    const double wa0 = P.reg_w * a0, wa1 = P.reg_w * a1, bb = br[rr];
+                    gp0 = fma(-wa0, bb, gp0);
+                    gp1 = fma(-wa1, bb, gp1);
+                    Ht[0][0] = mfma_f64_16x16x4(wa0, a0, Ht[0][0]);
+                    Ht[0][1] = mfma_f64_16x16x4(wa0, a1, Ht[0][1]);
+                    Ht[1][1] = mfma_f64_16x16x4(wa1, a1, Ht[1][1]);
+                }
+            }
             OSOT_PH_END(PH_INV);   // (profiling slot reused: MFMA loop of the H build)
             // g: the partial sums of a column sit in the four rows of 16 lanes
             gp0 = rowgroup_sum(gp0);
@@ -322,7 +343,7 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
                 const int i = 16 * I + ta;    // diagonal element (i, i) lives in tile (I, I) where a == q + 4 r
                 double dv = (i < n) ? P.eps_abs : 1.0;
                 if (i < npost) dv += wrow(ma + i);
-                if (D.b_reg && i < P.reg_rows) dv += P.reg_w;
+                if (D.b_reg && !regd && i < P.reg_rows) dv += P.reg_w;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Ht[I][I][r] += (ta == tq + 4 * r) ? dv : 0.0;
             }
@@ -371,6 +392,39 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
                     }
                 }
                 OSOT_SUB_END(PH_SUBST);   // (profiling slot reused: LDS broadcast + outer product)
+            }
+            if (regd) {   // the regularisation task's stored rows (see the NP = 32 branch)
+                const double* Ar = D.A_reg + inst * (long long)P.reg_rows * n;
+                const double* br = D.b_reg + inst * P.reg_rows;
+                for (int r0 = 0; r0 < P.reg_rows; r0 += 4) {
+                    double a[4], wa[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int r = r0 + u;
+                        const bool in = r < P.reg_rows;
+                        a[u] = (in && valid) ? Ar[r * n + c] : 0.0;
+                        wa[u] = P.reg_w * a[u];
+                        g -= wa[u] * (in ? br[r] : 0.0);
+                    }
+                    wave_sync();
+                    if (h == 0) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) w.V[u * NP + c] = a[u];
+                    }
+                    wave_sync();
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double* Vu = w.V + u * NP + h;
+#pragma unroll
+                        for (int i0 = 0; i0 < NP / HV; i0 += 16) {
+                            double vv[16];
+#pragma unroll
+                            for (int t = 0; t < 16; ++t) vv[t] = Vu[(i0 + t) * HV];
+#pragma unroll
+                            for (int t = 0; t < 16; ++t) hacc[i0 + t] = fma(wa[u], vv[t], hacc[i0 + t]);
+                        }
+                    }
+                }
             }
             if (m > ma && c < m - ma) {   // Postural block appended to the level: A = [I 0] (Postural.cpp:37)
                 const double wi = wrow(ma + c);
@@ -632,7 +686,7 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
 // The STATIC part of the update (kinds, sizes, gains: from the plan) lives in device memory, uploaded once per solver;
 // the per-call part (leaf and output pointers) travels as the kernel argument (kernel arguments are limited to 4 KB).
 struct DevTaskS {
-    int level, kind, rows, off, prow, body, dense;
+    int level, kind, rows, off, prow, body, dense, gains;
     double weight, lambda, ogain, lambda2, sublam;
     unsigned long long mask;   // SubTask: kept rows of the parent (0: whole task); prow = rows of the parent
 };
@@ -817,8 +871,20 @@ __device__ __forceinline__ void update_body(const DevUpdate* args_global, const 
             pr = __builtin_ctzll(mm);
         }
         const long long base = inst * (long long)prow + pr;
-        const double x0 = acc ? p0[inst * 2LL * prow + pr] : p0[base];
-        const double x1 = acc ? p0[inst * 2LL * prow + prow + pr] : 0.0;
+        double x0, x1;
+        if (acc && tk.gains) {
+            // gain matrices (acceleration/Cartesian.cpp:152-173): p0 = [pose_err; vel_err; Gp; Gd] per instance; this row
+            // takes (Gp pose_err)_pr and (Gd vel_err)_pr (Gp = Kp or Mi Kp, see osot_task_desc.acc_gain_matrices)
+            const double* e = p0 + inst * (2LL * prow + 2LL * prow * prow);
+            const double* Gp = e + 2 * prow + pr * prow;
+            const double* Gd = Gp + prow * prow;
+            double ap = 0.0, ad = 0.0;
+            for (int q = 0; q < prow; ++q) { ap = fma(Gp[q], e[q], ap); ad = fma(Gd[q], e[prow + q], ad); }
+            x0 = ap; x1 = ad;
+        } else {
+            x0 = acc ? p0[inst * 2LL * prow + pr] : p0[base];
+            x1 = acc ? p0[inst * 2LL * prow + prow + pr] : 0.0;
+        }
         const double x2 = (p1 && kind != 0 && kind != 6) ? p1[base] : 0.0;
         const double x3 = (p2 && kind != 0) ? p2[base] : 0.0;
         const double lam = tk.lambda, lam2 = tk.lambda2;
@@ -842,7 +908,8 @@ __device__ __forceinline__ void update_body(const DevUpdate* args_global, const 
     if (t < PL.ntasks && PL.task[t].kind == 1) {
         const DevTaskS& tk = PL.task[t];
         const double *cp0 = U.task[t].p0, *cp1 = U.task[t].p1, *cp2 = U.task[t].p2;
-        double* cb = U.b[tk.level] + inst * PL.m[tk.level] + tk.off;
+        double* cb = (tk.level < 0) ? U.b_reg + inst * tk.rows      // a Cartesian regularisation task (stored Jacobian)
+                                    : U.b[tk.level] + inst * PL.m[tk.level] + tk.off;
         const unsigned cmask = (tk.mask != 0ull) ? ((unsigned)tk.mask & 0x3fu) : 0x3fu;   // e.g. position only
         const double csub = (tk.mask != 0ull) ? tk.sublam : 1.0;
         double Ta[12], Td[12], tw[6], b6[6];

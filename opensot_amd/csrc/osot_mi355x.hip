@@ -405,6 +405,10 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
     D.dq = b->dq; D.x_levels = b->x_levels; D.status = b->status; D.iterations = b->iterations;
     if (pl.has_regularisation && !b->b_reg) return fail(OSOT_ERR_INVALID, "plan has a regularisation task but b_reg is null");
     D.b_reg = pl.has_regularisation ? b->b_reg : nullptr;
+    if (pl.has_regularisation && pl.regularisation_dense) {
+        if (!b->A_reg) return fail(OSOT_ERR_INVALID, "the regularisation task has a stored Jacobian but A_reg is null");
+        D.A_reg = b->A_reg;
+    }
     D.prof = prof;
     D.accepted_slack = b->accepted_slack;
     D.hot = (s->hotstart && !prof) ? s->d_hot : nullptr;
@@ -427,7 +431,7 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
         HIP_TRY(hipEventRecord(ev.first, st));
     }
     // the instantiation with the dense-weight / inactive-task code only where the plan or the solver state asks for it
-    bool extra = s->any_inactive;
+    bool extra = s->any_inactive || (pl.has_regularisation && pl.regularisation_dense);
     for (int k = 0; k < pl.n_levels; ++k) extra = extra || (s->h_uplan.dense_level[k] != 0);
     if (prof && !fused && extra)   // (the instrumented instantiation carries no dense-weight / inactive-task code: it would
         return fail(OSOT_ERR_UNSUPPORTED, "phase profiling is not available for plans with dense weights or inactive tasks");   // solve another problem)
@@ -853,6 +857,21 @@ int osot_id_rows(const osot_id_model* m, double* C_dyn, long long dyn_stride, do
         R.J[i] = J[i]; R.J_rows[i] = J_rows[i]; R.A_dst[i] = A_dst[i]; R.A_stride[i] = A_stride[i];
     }
     hipLaunchKernelGGL(osot_id_rows_kernel, dim3((unsigned)m->B), dim3(64), 0, (hipStream_t)hip_stream, R);
+    HIP_TRY(hipGetLastError());
+    return OSOT_OK;
+}
+
+int osot_id_force_gains(int B, int nv, int rows, const double* J, const double* Bi, const double* Kp, const double* Kd,
+                        const double* f_virtual, double* p0_gains, long long p0_stride, double* a_ref, void* hip_stream) {
+    if (B < 0 || nv < 1 || nv > 64 || rows < 1 || rows > 6) return fail(OSOT_ERR_INVALID, "force gains: sizes out of range (nv <= 64, rows <= 6)");
+    if (B == 0) return OSOT_OK;
+    if (!J || !Bi || !Kp || !Kd || !p0_gains) return fail(OSOT_ERR_INVALID, "force gains: null argument");
+    if (f_virtual && !a_ref) return fail(OSOT_ERR_INVALID, "force gains: a virtual force needs a_ref to add Mi f to");
+    DevForceGains F;
+    std::memset(&F, 0, sizeof(F));
+    F.B = B; F.nv = nv; F.rows = rows; F.J = J; F.Bi = Bi; F.f = f_virtual; F.G = p0_gains; F.G_stride = p0_stride; F.a_ref = a_ref;
+    for (int i = 0; i < rows * rows; ++i) { F.Kp[i] = Kp[i]; F.Kd[i] = Kd[i]; }
+    hipLaunchKernelGGL(osot_force_gains_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)hip_stream, F);
     HIP_TRY(hipGetLastError());
     return OSOT_OK;
 }

@@ -68,3 +68,20 @@ class IdModel:
         abi.check(self._lib.osot_computed_torque(C.byref(m), C.c_void_p(x.data_ptr()), C.c_void_p(tau.data_ptr()),
                                                  C.c_void_p(ok.data_ptr()), fb_tol, st), "osot_computed_torque")
         return tau, ok
+
+
+def force_gains(J, Bi, Kp, Kd, p0, rows, f_virtual=None, a_ref=None):
+    """GainType::Force of acceleration::Cartesian (src/tasks/acceleration/Cartesian.cpp:161-169): Mi = J Bi J' per instance
+    (compute_cartesian_inertia_inverse, :517-524), Gp = Mi Kp and Gd = Mi Kd written into the task's leaf array
+    p0 [B][2 rows + 2 rows^2] behind the errors (Task.acc_gain_matrices), a_ref [B][rows] += Mi f_virtual.
+    J [B][rows][nv], Bi [B][nv][nv] device tensors; Kp, Kd rows x rows (host)."""
+    B, r, nv = J.shape
+    assert r == rows and p0.shape == (B, 2 * rows + 2 * rows * rows) and p0.is_contiguous() and J.is_contiguous() and Bi.is_contiguous()
+    Kp = np.ascontiguousarray(Kp, dtype=np.float64).reshape(rows * rows)
+    Kd = np.ascontiguousarray(Kd, dtype=np.float64).reshape(rows * rows)
+    vp = C.c_void_p
+    st = vp(torch.cuda.current_stream(J.device).cuda_stream)
+    abi.check(abi.lib().osot_id_force_gains(B, nv, rows, vp(J.data_ptr()), vp(Bi.data_ptr()), Kp.ctypes.data_as(abi.dp),
+                                            Kd.ctypes.data_as(abi.dp), vp(f_virtual.data_ptr()) if f_virtual is not None else None,
+                                            vp(p0.data_ptr() + 8 * 2 * rows), 2 * rows + 2 * rows * rows,
+                                            vp(a_ref.data_ptr()) if a_ref is not None else None, st), "osot_id_force_gains")

@@ -35,6 +35,9 @@ class Task:
     body_frame: bool = False
     # non-diagonal weight matrix W_i [rows][rows] (Task::setWeight(W), Task.h:273-300): comes with the leaf inputs
     dense_weight: bool = False
+    # gain matrices of an acceleration task (acceleration::Cartesian::setGains, Cartesian.cpp:152-173): the leaf array p0
+    # carries [pose_err; vel_err; Gp; Gd] per instance (osot_task_desc.acc_gain_matrices)
+    acc_gain_matrices: bool = False
 
     @property
     def implicit(self):
@@ -117,6 +120,7 @@ class StackPlan:
     # AutoStack::setRegularisationTask (AutoStack.h:78-92): an identity-Jacobian task (TASK_GENERIC with b supplied,
     # TASK_POSTURAL, TASK_ACC_POSTURAL; rows <= n) whose cost iHQP adds to every level (iHQP.cpp:274-278)
     regularisation: Optional[Task] = None
+    regularisation_dense: bool = False   # the regularisation task has a stored Jacobian (osot_plan_desc.regularisation_dense)
 
     # ---- derived sizes -------------------------------------------------------------------
     @property
@@ -171,8 +175,12 @@ class StackPlan:
         assert len(self.bounds) <= abi.MAX_BOUNDS and len(self.rowblocks) <= abi.MAX_ROWBLOCKS
         if self.regularisation is not None:
             r = self.regularisation
-            assert r.kind in (abi.TASK_GENERIC, abi.TASK_POSTURAL, abi.TASK_ACC_POSTURAL) and not r.row_mask
-            assert 1 <= r.rows <= self.n
+            assert not r.row_mask
+            if self.regularisation_dense:      # stored Jacobian A_r [B][rows][n] (BatchedStack.A_reg)
+                assert r.kind in (abi.TASK_GENERIC, abi.TASK_CARTESIAN, abi.TASK_COM) and 1 <= r.rows <= 64
+            else:
+                assert r.kind in (abi.TASK_GENERIC, abi.TASK_POSTURAL, abi.TASK_ACC_POSTURAL)
+                assert 1 <= r.rows <= self.n
 
     def to_c(self) -> abi.PlanDesc:
         self.validate()
@@ -187,6 +195,7 @@ class StackPlan:
                     t.kind, t.rows, t.weight, t.lam, t.orientation_gain, t.lam2)
                 d.row_mask, d.parent_rows, d.sub_lambda = t.row_mask, t.parent_rows, t.sub_lam
                 d.body_frame, d.dense_weight = int(t.body_frame), int(t.dense_weight)
+                d.acc_gain_matrices = int(t.acc_gain_matrices)
         p.n_bounds = len(self.bounds)
         for j, b in enumerate(self.bounds):
             p.bound[j].kind, p.bound[j].scaling, p.bound[j].dT = b.kind, b.scaling, b.dT
@@ -212,4 +221,5 @@ class StackPlan:
             d.kind, d.rows, d.weight, d.lambda_, d.orientation_gain, d.lambda2 = (
                 t.kind, t.rows, t.weight, t.lam, t.orientation_gain, t.lam2)
             d.row_mask, d.parent_rows, d.sub_lambda = 0, 0, 1.0
+            p.regularisation_dense = 1 if self.regularisation_dense else 0
         return p

@@ -65,6 +65,9 @@ class BatchedStack:
         self.l = torch.zeros((B, n), **f64) if plan.bounds else None
         self.u = torch.zeros((B, n), **f64) if plan.bounds else None
         self.b_reg = torch.zeros((B, plan.regularisation.rows), **f64) if plan.regularisation is not None else None
+        # Jacobian of a regularisation task that has one (plan.regularisation_dense): written by the producer, like A[k]
+        self.A_reg = (torch.zeros((B, plan.regularisation.rows, n), **f64)
+                      if plan.regularisation is not None and plan.regularisation_dense else None)
         self.dq = torch.zeros((B, n), **f64)
         self.x_levels = torch.zeros((B, L, n), **f64) if want_levels else None
         self.status = torch.zeros((B,), dtype=torch.int32, device=self.device)
@@ -103,6 +106,8 @@ class BatchedStack:
                "rows": [tuple(to(x) for x in t) for t in leaf["rows"]]}
         if self.plan.regularisation is not None:
             dev["reg"] = tuple(to(x) for x in leaf["reg"])
+            if self.A_reg is not None:          # the regularisation task's Jacobian, written in place like the A_k
+                self.A_reg[:B].copy_(to(leaf["reg_A"]))
         return dev
 
     def load_assembled(self, asm):
@@ -123,6 +128,8 @@ class BatchedStack:
             self.l[:B].copy_(torch.as_tensor(asm["l"])); self.u[:B].copy_(torch.as_tensor(asm["u"]))
         if self.b_reg is not None:
             self.b_reg[:B].copy_(torch.as_tensor(asm["reg"]["b"]))
+        if self.A_reg is not None:
+            self.A_reg[:B].copy_(torch.as_tensor(asm["reg"]["A"]))
         return B
 
     # ---- AutoStack::update ------------------------------------------------------------------------
@@ -199,6 +206,7 @@ class BatchedStack:
         qb.dq, qb.x_levels = _dev_ptr(self.dq), _dev_ptr(self.x_levels)
         qb.status, qb.iterations = _dev_ptr(self.status), _dev_ptr(self.iterations)
         qb.b_reg = _dev_ptr(self.b_reg)
+        qb.A_reg = _dev_ptr(self.A_reg)
         for k in range(self.plan.L):
             qb.WA[k], qb.Wb[k] = _dev_ptr(self.WA[k]), _dev_ptr(self.Wb[k])
         qb.accepted_slack = _dev_ptr(self.accepted_slack)

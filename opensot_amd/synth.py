@@ -154,15 +154,32 @@ def perturb(leaf, rng, scale=0.01):
         out["W"] = leaf["W"]
     if "reg" in leaf:
         out["reg"] = tuple(j(x) for x in leaf["reg"])
+    if "reg_A" in leaf:
+        out["reg_A"] = j(leaf["reg_A"])
     return out
 
 
-def add_regularisation(plan, leaf, kind=abi.TASK_GENERIC, rows=None, weight=1e-3, lam=0.1, seed=0):
+def add_regularisation(plan, leaf, kind=abi.TASK_GENERIC, rows=None, weight=1e-3, lam=0.1, seed=0, dense=False):
     """attach a user regularisation task (AutoStack::setRegularisationTask) to a synthetic stack: the reference's own
-    use (tests/solvers/TestiHQP.cpp:112-120) is a minimum-velocity GenericTask(I, -qdot/dt); a Postural works alike."""
+    use (tests/solvers/TestiHQP.cpp:112-120) is a minimum-velocity GenericTask(I, -qdot/dt); a Postural works alike.
+    dense=True: a task with a STORED Jacobian (iHQP.cpp:265-278 takes any task): GENERIC (random A_r, b), CARTESIAN
+    (6 rows: a link Jacobian and poses) or COM (3 rows); leaf["reg_A"] is A_r [B][rows][n]."""
     rng = np.random.default_rng(seed + 977)
     n, B = plan.n, leaf["B"]
     rows = n if rows is None else rows
+    if dense:
+        rows = {abi.TASK_CARTESIAN: 6, abi.TASK_COM: 3}.get(kind, rows)
+        plan.regularisation = Task(kind, rows, weight=weight, lam=lam, name="regularisation")
+        plan.regularisation_dense = True
+        leaf["reg_A"] = rng.normal(0.0, 0.3, size=(B, rows, n))
+        if kind == abi.TASK_CARTESIAN:
+            leaf["reg"] = _cartesian_leaf(rng, B)
+        elif kind == abi.TASK_COM:
+            p = rng.uniform(-0.2, 0.2, size=(B, 3))
+            leaf["reg"] = (p, p + rng.uniform(-0.05, 0.05, size=(B, 3)), None)
+        else:
+            leaf["reg"] = (rng.normal(0.0, 0.1, size=(B, rows)), None, None)
+        return plan, leaf
     plan.regularisation = Task(kind, rows, weight=weight, lam=lam, lam2=2.0 * np.sqrt(lam), name="regularisation")
     if kind == abi.TASK_GENERIC:
         leaf["reg"] = (rng.normal(0.0, 0.1, size=(B, rows)), None, None)

@@ -149,6 +149,9 @@ void orc_collision_rows(int n, int P, int max_pairs, const double* Jd, const dou
 void orc_acc_task_b(int rows, const double* pose_err, const double* vel_err, const double* jdotqdot,
                     const double* a_ref, double lambda, double lambda2, double* b);
 /* acceleration::Postural, src/tasks/acceleration/Postural.cpp:145-158 (Acceleration gain type) */
+void orc_acc_task_b_gains(int rows, const double* pose_err, const double* vel_err, const double* jdotqdot,
+                          const double* a_ref, const double* Gp, const double* Gd, double lambda, double lambda2, double* b);
+void orc_cartesian_inertia_inverse(int rows, int nv, const double* J, const double* Bi, double* Mi);
 void orc_acc_postural_b(int rows, const double* q_err, const double* qdot_err, const double* qddot_ref,
                         double lambda, double lambda2, double* b);
 /* acceleration::TorqueLimits bounds, src/constraints/acceleration/TorqueLimits.cpp:44-45 */

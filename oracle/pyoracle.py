@@ -80,6 +80,8 @@ def lib():
         L.orc_collision_rows.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp, C.c_double, C.c_double,
                                          C.c_double, dp, dp, dp]
         L.orc_acc_task_b.argtypes = [C.c_int, dp, dp, dp, dp, C.c_double, C.c_double, dp]
+        L.orc_acc_task_b_gains.argtypes = [C.c_int, dp, dp, dp, dp, dp, dp, C.c_double, C.c_double, dp]
+        L.orc_cartesian_inertia_inverse.argtypes = [C.c_int, C.c_int, dp, dp, dp]
         L.orc_acc_postural_b.argtypes = [C.c_int, dp, dp, dp, C.c_double, C.c_double, dp]
         L.orc_torque_limit_bounds.argtypes = [C.c_int, dp, dp, dp, dp]
         L.orc_friction_cone_rows.argtypes = [dp, C.c_double, dp]
@@ -159,9 +161,15 @@ def assemble(plan, leaf, task_active=None):
                     L.orc_postural_b(rows_, _p(p0[i]), _p(p1[i]), _p(p2[i] if p2 is not None else zerosn),
                                      t.lam, _p(bi))
                 elif t.kind in (TASK_ACC_CARTESIAN, TASK_ACC_COM):
-                    pe = np.ascontiguousarray(p0[i, :rows_]); ve = np.ascontiguousarray(p0[i, rows_:])
-                    L.orc_acc_task_b(rows_, _p(pe), _p(ve), _p(p1[i]), _p(p2[i]) if p2 is not None else None,
-                                     t.lam, t.lam2, _p(bi))
+                    pe = np.ascontiguousarray(p0[i, :rows_]); ve = np.ascontiguousarray(p0[i, rows_:2 * rows_])
+                    if getattr(t, "acc_gain_matrices", False):     # p0 = [pose_err; vel_err; Gp; Gd] (Cartesian.cpp:152-173)
+                        Gp = np.ascontiguousarray(p0[i, 2 * rows_:2 * rows_ + rows_ * rows_])
+                        Gd = np.ascontiguousarray(p0[i, 2 * rows_ + rows_ * rows_:2 * rows_ + 2 * rows_ * rows_])
+                        L.orc_acc_task_b_gains(rows_, _p(pe), _p(ve), _p(p1[i]), _p(p2[i]) if p2 is not None else None,
+                                               _p(Gp), _p(Gd), t.lam, t.lam2, _p(bi))
+                    else:
+                        L.orc_acc_task_b(rows_, _p(pe), _p(ve), _p(p1[i]), _p(p2[i]) if p2 is not None else None,
+                                         t.lam, t.lam2, _p(bi))
                 elif t.kind == TASK_ACC_POSTURAL:
                     pe = np.ascontiguousarray(p0[i, :rows_]); ve = np.ascontiguousarray(p0[i, rows_:])
                     L.orc_acc_postural_b(rows_, _p(pe), _p(ve), _p(p2[i]) if p2 is not None else None,
@@ -188,9 +196,16 @@ def assemble(plan, leaf, task_active=None):
             elif t.kind == TASK_ACC_POSTURAL:
                 pe = np.ascontiguousarray(p0[i, :t.rows]); ve = np.ascontiguousarray(p0[i, t.rows:])
                 L.orc_acc_postural_b(t.rows, _p(pe), _p(ve), _p(p2[i]) if p2 is not None else None, t.lam, t.lam2, _p(br[i]))
+            elif t.kind == TASK_CARTESIAN:
+                L.orc_cartesian_b(_p(p0[i, :9]), _p(p0[i, 9:]), _p(p1[i, :9]), _p(p1[i, 9:]), _p(p2[i] if p2 is not None else zeros6),
+                                  t.lam, t.orientation_gain, _p(br[i]))
+            elif t.kind == TASK_COM:
+                L.orc_com_b(_p(p0[i]), _p(p1[i]), _p(p2[i] if p2 is not None else zeros6[:3]), t.lam, _p(br[i]))
             else:
                 br[i] = p0[i]
-        out["reg"] = {"A": None, "b": br, "w": t.weight}
+        # a regularisation task with a stored Jacobian (any task: iHQP.cpp:265-278): A_r [B][rows][n] from the producer
+        Ar = _c(leaf["reg_A"]) if getattr(plan, "regularisation_dense", False) else None
+        out["reg"] = {"A": Ar, "b": br, "w": t.weight}
     # box (constraints::Aggregated, Aggregated.cpp:141-148)
     if plan.bounds:
         l = np.full((B, n), -np.inf)
@@ -373,3 +388,20 @@ def backend_solve(H, g, A, lA, uA, l, u, eps_abs, form=BE_EIQP_EQ):
     ok = lib().orc_backend_solve(form, n, _p(H), _p(g), nc, _p(A), _p(lA), _p(uA), _p(l), _p(u),
                                  eps_abs, _p(x), C.byref(it))
     return bool(ok), x, it.value
+
+
+def force_gains(J, Bi, Kp, Kd, f=None):
+    """GainType::Force of acceleration::Cartesian (acceleration/Cartesian.cpp:161-169, 517-524), restated: per instance
+    Mi = J Bi J', Gp = Mi Kp, Gd = Mi Kd and the acceleration Mi f of a virtual force.  J [B][rows][nv], Bi [B][nv][nv].
+    -> (Gp [B][rows][rows], Gd, a_add [B][rows] or None)"""
+    L = lib()
+    B, rows, nv = J.shape
+    Gp = np.zeros((B, rows, rows)); Gd = np.zeros((B, rows, rows))
+    a = np.zeros((B, rows)) if f is not None else None
+    Mi = np.zeros((rows, rows))
+    for i in range(B):
+        L.orc_cartesian_inertia_inverse(rows, nv, _p(np.ascontiguousarray(J[i])), _p(np.ascontiguousarray(Bi[i])), _p(Mi))
+        Gp[i] = Mi @ Kp; Gd[i] = Mi @ Kd
+        if f is not None:
+            a[i] = Mi @ f[i]
+    return Gp, Gd, a

@@ -30,6 +30,7 @@ extern "C" __attribute__((visibility("default"))) int emu_ihqp_solve(const osot_
     D.C = b->C; D.lo = b->lo; D.up = b->up; D.l = b->l; D.u = b->u;
     D.dq = b->dq; D.x_levels = b->x_levels; D.status = b->status; D.iterations = b->iterations;
     D.b_reg = plan->has_regularisation ? b->b_reg : nullptr;
+    D.A_reg = (plan->has_regularisation && plan->regularisation_dense) ? b->A_reg : nullptr;
     D.accepted_slack = b->accepted_slack;
     D.hot = hot;
     const unsigned grid = (unsigned)b->B;

@@ -87,6 +87,10 @@ def emu_cascade(plan, asm, active=None, task_active=None, hot=None):
         a = np.ascontiguousarray(asm["reg"]["b"], dtype=np.float64)
         keep.append(a)
         qb.b_reg = a.ctypes.data
+        if asm["reg"].get("A") is not None:      # a regularisation task with a stored Jacobian (plan.regularisation_dense)
+            a = np.ascontiguousarray(asm["reg"]["A"], dtype=np.float64)
+            keep.append(a)
+            qb.A_reg = a.ctypes.data
     dq = np.zeros((B, n)); xl = np.zeros((B, L, n))
     st = np.full(B, -1, dtype=np.int32); it = np.zeros(B, dtype=np.int32)
     qb.dq, qb.x_levels, qb.status, qb.iterations = dq.ctypes.data, xl.ctypes.data, st.ctypes.data, it.ctypes.data

@@ -139,3 +139,27 @@ def test_inverse_dynamics_producers_and_computed_torque(oracle):
     x[2, 0] += 1.0     # break the floating-base balance of one instance: "Floating Base Wrench is not 0!"
     assert L.emu_computed_torque(C.byref(m), x.ctypes.data, tau.ctypes.data, ok.ctypes.data, 1e-2) == 0
     assert ok[2] == 0 and (np.delete(ok, 2) == 1).all()
+
+
+def test_acceleration_task_gain_matrices_emulated(oracle):
+    """Kp / Kd matrices of acceleration::Cartesian (src/tasks/acceleration/Cartesian.cpp:152-160): the update kernel's b
+    (emulator) against the oracle's restatement and a by-hand numpy evaluation of the reference's expression"""
+    from helpers import emu_update
+    B = 5
+    plan, leaf = synth.make_id_stack(B, seed=62)
+    rng = np.random.default_rng(63)
+    Kp = rng.normal(size=(6, 6)); Kd = rng.normal(size=(6, 6))      # (any matrices: the expression is linear in them)
+    t = plan.levels[0][1]
+    t.acc_gain_matrices = True
+    p0, jdq, a_ref = leaf["task"][0][1]
+    leaf["task"][0][1] = (np.concatenate([p0, np.tile(Kp.reshape(1, 36), (B, 1)), np.tile(Kd.reshape(1, 36), (B, 1))], axis=1), jdq, a_ref)
+    asm = oracle.assemble(plan, leaf)
+    want = t.lam2 * p0[:, 6:12] @ Kd.T + t.lam * p0[:, :6] @ Kp.T - jdq
+    np.testing.assert_allclose(asm["b"][0][:, 3:9], want, rtol=0, atol=1e-12)
+    got = emu_update(plan, leaf)
+    np.testing.assert_allclose(got["b"][0], asm["b"][0], rtol=0, atol=1e-13)
+    # the other tasks of the level keep their scalar gains
+    plan0, leaf0 = synth.make_id_stack(B, seed=62)
+    asm0 = oracle.assemble(plan0, leaf0)
+    np.testing.assert_array_equal(asm["b"][0][:, :3], asm0["b"][0][:, :3])
+    np.testing.assert_array_equal(asm["b"][0][:, 9:], asm0["b"][0][:, 9:])

@@ -333,6 +333,37 @@ def test_user_regularisation_task(name, kind, rows, weight, oracle):
         assert not qpoases_only, "this case needs oracle/_ref (qpOASES)"
 
 
+def _dense_reg_cases():
+    from opensot_amd import abi
+    # (stack, kind of the regularisation task, rows, weight): the matrix-core H build with and without stored level rows
+    # (a Postural-only level is no longer diagonal), the levels that would take the closed-form low-rank path, the 64-lane
+    # instantiation
+    return [("C3", abi.TASK_CARTESIAN, None, 1e-2), ("C3", abi.TASK_GENERIC, 9, 0.3), ("C2", abi.TASK_COM, None, 5e-2),
+            ("lowrank_plain", abi.TASK_GENERIC, 5, 0.1), ("generic40", abi.TASK_CARTESIAN, None, 1e-2), ("generic", abi.TASK_GENERIC, 4, 1.0)]
+
+
+@pytest.mark.parametrize("name,kind,rows,weight", _dense_reg_cases())
+def test_regularisation_task_with_a_stored_jacobian(name, kind, rows, weight, oracle):
+    """a regularisation task with a DENSE Jacobian (round 3; AutoStack::setRegularisationTask takes any task,
+    AutoStack.h:78-92; iHQP.cpp:265-278 adds its H and g to every level): H += w A_r'A_r, g -= w A_r'b_r through the
+    H build of every path, against the oracle's general form and the reference's qpOASES"""
+    plan, leaf = _reg_stack(name, 4, seed=6)
+    base = oracle.ihqp_solve_batch(oracle.assemble(plan, leaf), oracle.BE_EIQP_EQ, nthreads=1)["dq"]
+    synth.add_regularisation(plan, leaf, kind=kind, rows=rows, weight=weight, seed=4, dense=True)
+    asm = oracle.assemble(plan, leaf)
+    assert asm["reg"]["A"].shape == (4, plan.regularisation.rows, plan.n)
+    dq, xl, st, it = emu_cascade(plan, asm)
+    assert (st == 0).all()
+    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+    assert (ref["status"] == 1).all()
+    assert np.abs(dq - ref["dq"]).max() < 1e-9 * max(1.0, np.abs(ref["dq"]).max())
+    assert np.abs(ref["dq"] - base).max() > 1e-6          # the task does change the answer
+    if oracle.ref_available():
+        rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
+        ok = rq["status"] == 1
+        assert ok.all() and np.abs(dq[ok] - rq["dq"][ok]).max() < 1e-6
+
+
 @pytest.mark.parametrize("n,rows,local_level,n_local", [(7, [3, 3], 0, 2), (20, [5, 6], 1, 4), (31, [10, 12], 2, 3), (40, [10, 12], 0, 5)])
 def test_task_local_constraint_rows(n, rows, local_level, n_local, oracle):
     """`task << constraint` (Task::getConstraints(), iHQP.cpp:190, 282-287): the rows constrain the QP of THEIR level

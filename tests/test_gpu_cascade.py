@@ -176,6 +176,38 @@ def test_user_regularisation_task_gpu(name, kind, rows, weight, oracle, gpu_devi
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,kind,rows,weight", [("C3", 1, None, 1e-2), ("C3", 0, 9, 0.3), ("C2", 2, None, 5e-2),
+                                                   ("lowrank_plain", 0, 5, 0.1), ("generic40", 1, None, 1e-2)])
+def test_regularisation_task_with_a_stored_jacobian_gpu(name, kind, rows, weight, oracle, gpu_device):
+    """a regularisation task with a DENSE Jacobian (iHQP.cpp:265-278 takes any task): b_r through the update kernel, A_r
+    written in place, H += w A_r'A_r and g -= w A_r'b_r at every level of the cascade; against the eiQuadProg
+    restatement (1e-9) and qpOASES at OpenSoT's options (absolute 1e-6, census printed)"""
+    from helpers import parity_census
+    from test_emulated_kernels import _reg_stack
+    B = 192
+    plan, leaf = _reg_stack(name, B, seed=6)
+    synth.add_regularisation(plan, leaf, kind=kind, rows=rows, weight=weight, seed=4, dense=True)
+    asm = oracle.assemble(plan, leaf)
+    st = BatchedStack(plan, B, device=0)
+    st.update(st.load_leaf(leaf)); st.solve(B)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(st.b_reg.cpu().numpy(), asm["reg"]["b"], rtol=0, atol=1e-15)
+    dq = st.dq[:B].cpu().numpy()
+    assert (st.status[:B].cpu().numpy() == 0).all()
+    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=4)
+    okr = ref["status"] == 1
+    assert okr.all() and np.abs(dq - ref["dq"]).max() < 1e-9 * max(1.0, np.abs(dq).max())
+    # the fused cycle launch takes the same route
+    st2 = BatchedStack(plan, B, device=0)
+    st2.cycle(st2.load_leaf(leaf)); torch.cuda.synchronize()
+    assert torch.equal(st2.dq[:B], st.dq[:B])
+    if oracle.ref_available():
+        rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=4)
+        within, rule, fails = parity_census(asm, dq, [("qpOASES", rq), ("eiQuadProg", ref)], tol=1e-6, label=f"dense regularisation {name}")
+        assert not fails
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,rows,local_level,n_local", [(7, [3, 3], 0, 2), (20, [5, 6], 1, 4), (31, [10, 12], 2, 3), (40, [10, 12], 0, 5)])
 def test_task_local_constraint_rows_gpu(n, rows, local_level, n_local, oracle, gpu_device):
     """`task << constraint` rows (Task::getConstraints(), iHQP.cpp:190, 282-287) through update + cascade on the GPU"""

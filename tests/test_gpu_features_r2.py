@@ -129,3 +129,83 @@ def test_cycle_is_update_then_solve_gpu(cfg, B, gpu_device):
     # and a second cycle on the same objects (dispatch order from the first one's iteration counts)
     b.cycle(db); torch.cuda.synchronize()
     assert torch.equal(a.dq, b.dq)
+
+
+def _id_stack_with_gain_matrices(B, seed, force_type):
+    """config 5 with GAIN MATRICES on its two hand tasks (acceleration::Cartesian::setGains, Cartesian.cpp:152-173): the
+    left hand with GainType::Acceleration (Kp, Kd as they are), the right hand with GainType::Force when asked (Mi Kp,
+    Mi Kd with Mi = J B^-1 J', plus a virtual force)"""
+    plan, leaf = synth.make_id_stack(B, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    nv = leaf["model"]["nv"]
+
+    def spd(scale):
+        M = rng.normal(size=(6, 6))
+        return scale * (M @ M.T / 6.0 + np.eye(6))
+    Kp = [spd(1.0), spd(0.5)]; Kd = [spd(0.3), spd(0.2)]
+    Bi = np.linalg.inv(leaf["model"]["B"])
+    f_virtual = rng.normal(0.0, 2.0, size=(B, 6))
+    extra = {"Kp": Kp, "Kd": Kd, "Bi": Bi, "f": f_virtual, "J": [np.ascontiguousarray(leaf["A"][0][:, 3 + 6 * k:9 + 6 * k, :nv]) for k in range(2)]}
+    for k in range(2):
+        t = plan.levels[0][1 + k]
+        t.acc_gain_matrices = True
+        p0, p1, p2 = leaf["task"][0][1 + k]
+        if k == 1 and force_type:
+            Gp, Gd, a_add = oracle_mod().force_gains(extra["J"][1], Bi, Kp[1], Kd[1], f_virtual)
+            p2 = a_add                                            # a_ref was zero: a_ref + Mi f
+        else:
+            Gp = np.broadcast_to(Kp[k], (B, 6, 6)); Gd = np.broadcast_to(Kd[k], (B, 6, 6)); a_add = None
+        leaf["task"][0][1 + k] = (np.concatenate([p0, Gp.reshape(B, 36), Gd.reshape(B, 36)], axis=1), p1, p2)
+    return plan, leaf, extra
+
+
+def oracle_mod():
+    from oracle import pyoracle
+    return pyoracle
+
+
+@pytest.mark.parametrize("force_type", [False, True])
+def test_acceleration_cartesian_gain_matrices_gpu(force_type, oracle, gpu_device):
+    """Kp / Kd matrices and the Force gain type of acceleration::Cartesian (src/tasks/acceleration/Cartesian.cpp:152-173; round 2
+    fixed Kp = Kd = I): b through the update kernel against the restated formula AND a by-hand numpy evaluation of the
+    reference's expression; for the Force type the gains come from the device producer osot_id_force_gains (Mi = J B^-1 J',
+    :517-524) and are compared with the restatement; the solved x against the eiQuadProg restatement and qpOASES"""
+    from helpers import parity_census
+    from opensot_amd import dynamics
+    B = 96
+    plan, leaf, ex = _id_stack_with_gain_matrices(B, 61, force_type)
+    asm = oracle.assemble(plan, leaf)
+    # by hand, the reference's expression: b = a_ref + lambda2 [Mi] Kd vel_err + lambda [Mi] Kp pose_err [+ Mi f] - Jdot qdot
+    for k in range(2):
+        t = plan.levels[0][1 + k]
+        p0, jdq, a_ref = leaf["task"][0][1 + k]
+        pe, ve = p0[:, :6], p0[:, 6:12]
+        Mi = np.einsum("brk,bkl,bsl->brs", ex["J"][k], ex["Bi"], ex["J"][k]) if (k == 1 and force_type) else np.broadcast_to(np.eye(6), (B, 6, 6))
+        want = t.lam2 * np.einsum("brs,st,bt->br", Mi, ex["Kd"][k], ve) + t.lam * np.einsum("brs,st,bt->br", Mi, ex["Kp"][k], pe) - jdq
+        if k == 1 and force_type:
+            want = want + np.einsum("brs,bs->br", Mi, ex["f"])
+        np.testing.assert_allclose(asm["b"][0][:, 3 + 6 * k:9 + 6 * k], want, rtol=0, atol=1e-11)
+    st = BatchedStack(plan, B, device=0)
+    dev = st.load_leaf(leaf)
+    if force_type:       # the right hand's gains and Mi f from the device producer, into the leaf array / a_ref in place
+        p0d, _, _ = dev["task"][0][2]
+        Gref = p0d[:, 12:].clone()
+        p0d[:, 12:] = 0.0
+        a_ref = torch.zeros((B, 6), dtype=torch.float64, device=st.device)
+        f64 = dict(dtype=torch.float64, device=st.device)
+        dynamics.force_gains(torch.as_tensor(ex["J"][1], **f64).contiguous(), torch.as_tensor(ex["Bi"], **f64).contiguous(),
+                             ex["Kp"][1], ex["Kd"][1], p0d, 6, f_virtual=torch.as_tensor(ex["f"], **f64).contiguous(), a_ref=a_ref)
+        torch.cuda.synchronize()
+        assert (p0d[:, 12:] - Gref).abs().max().item() < 1e-12 * max(1.0, Gref.abs().max().item())
+        assert (a_ref - dev["task"][0][2][2]).abs().max().item() < 1e-12 * max(1.0, a_ref.abs().max().item())
+    st.update(dev); st.solve(B)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(st.b[0][:B].cpu().numpy(), asm["b"][0], rtol=0, atol=1e-12)
+    x = st.dq[:B].cpu().numpy()
+    assert (st.status[:B].cpu().numpy() == 0).all()
+    ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=0)
+    assert (ref["status"] == 1).all() and np.abs(x - ref["dq"]).max() < 1e-8
+    if oracle.ref_available():
+        rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=0)
+        within, rule, fails = parity_census(asm, x, [("qpOASES", rq), ("eiQuadProg", ref)], tol=1e-6, label=f"acc gains force={force_type}")
+        assert not fails
