@@ -30,7 +30,7 @@ import torch  # noqa: E402
 
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (AMD public spec; not in MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
-PMC_PROFILE = os.path.join("profiles", "r02_pmc_cascade.json")
+PMC_PROFILE = os.path.join("profiles", "r03_pmc_kernels.json")
 
 
 def algo_flops_per_solve(plan):
@@ -92,16 +92,34 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(config, Bl):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes -- only if they were taken on THIS kernel source and
-    workload; otherwise null (a stale figure is worse than none)"""
+def pmc_traffic(kernels):
+    """HBM bytes of one STEP from the committed rocprofv3 PMC passes (tools/profile_round.sh -> profiles/r03_pmc_kernels.json):
+    `kernels` = [(substring of the kernel name, workgroups of the launch, launches per step)]; the per-launch FETCH / WRITE
+    figures of every (kernel, grid) pair are summed.  Only if the passes were taken on THIS kernel source (hash) and every
+    pair is in the table; otherwise (None, None): a stale figure is worse than none."""
     try:
         pm = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
-        if pm.get("kernel_source_sha") == kernel_source_sha() and pm.get("config") == config and pm.get("batch") == Bl:
-            return pm["hbm_bytes_per_launch_corrected"], PMC_PROFILE
+        if pm.get("kernel_source_sha") != kernel_source_sha():
+            return None, None
+        total = 0.0
+        for name, wgs, count in kernels:
+            rows = [r for r in pm["kernels"] if name in r["kernel"] and r["workgroups"] == wgs and "hbm_bytes_per_launch_corrected" in r]
+            if not rows:
+                return None, None
+            total += count * max(rows, key=lambda r: r["launches"])["hbm_bytes_per_launch_corrected"]
+        return total, PMC_PROFILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 per MI355X_MICROARCH.md; same kernel source hash)"
     except Exception:
-        pass
-    return None, None
+        return None, None
+
+
+def hbm_roofline(bytes_per_instance, B, step_ms, kernels, kernel_label):
+    """roofline block of a path that is far from both roofs (nHQP, eHQP, ADMM, kinematics): bound "hbm", achieved = the
+    path's ALGORITHMIC bytes per step / step time, traffic = PMC bytes of the step's kernels"""
+    gbs = B * bytes_per_instance / (step_ms * 1e-3) / 1e9
+    traffic, src = pmc_traffic(kernels)
+    return {"bound": "hbm", "kernel": kernel_label, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": src or "no PMC passes committed for this kernel source: null rather than a stale figure",
+            "algorithmic_bytes_per_instance": bytes_per_instance, "step_ms": step_ms}
 
 
 def roofline_of(plan, Bl, kern_ms, launches, kernel_name, traffic=None, traffic_source=None):
@@ -258,7 +276,10 @@ def time_config(name, B, device, steps=20, warmup=5):
     kern_ms, launches = st.kernel_time_ms()
     st.set_timing(False)
     ok = int((st.status[:B] == 0).sum().item())
-    rf, rh = roofline_of(plan, B, kern_ms, launches, f"osot_cascade_kernel<{32 if plan.n <= 32 else 64},false>")
+    NPk = 32 if plan.n <= 32 else 64
+    traffic, src = pmc_traffic([(f"osot_cascade_kernel<{NPk}, false, false>", B + 1, 1)])
+    rf, rh = roofline_of(plan, B, kern_ms, launches, f"osot_cascade_kernel<{NPk},false>", traffic,
+                         src or "no PMC passes committed for this kernel source: null rather than a stale figure")
     return {"workload": {"C2": "BASELINE configs[1]: 1-level Cartesian + Postural (soft priority), joint-limit box",
                          "C3": "BASELINE configs[2]", "C4": "BASELINE configs[3] shard: C3 + 16 self-collision rows",
                          "C5": "BASELINE configs[4] shard: 38-DoF floating-base inverse dynamics, x = [qddot; 4 x 3 forces] (n = 50), "
@@ -289,7 +310,12 @@ def time_nhqp(B, device, steps=5, warmup=2):
     return {"workload": "BASELINE configs[2] stack through the reference's null-space front-end (nHQP.cpp:155-204; defaults: A/b "
                         "regularisation at 0.05 sv_max, selective null-space regularisation): per level an SVD of A N (parallel Jacobi in "
                         "LDS), the QP in the nf = 32 / 29 / 5 free coordinates, q += N z, N <- N V2; three launches per level",
-            "batch": B, "value": B * steps / el, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "solved_ok": f"{ok}/{B}"}
+            "batch": B, "value": B * steps / el, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "solved_ok": f"{ok}/{B}",
+            "roofline": hbm_roofline(algo_bytes_per_solve(plan), B, 1e3 * el / steps,
+                                     [("osot_update_kernel", B, 1), ("osot_nhqp_prepare_kernel<32>", B, plan.L),
+                                      ("osot_qp_kernel<32>", B, plan.L), ("osot_nhqp_accumulate_kernel", B, plan.L)],
+                                     "osot_nhqp_prepare_kernel<32> + osot_qp_kernel<32> + osot_nhqp_accumulate_kernel per level (far from "
+                                     "both roofs: the scalar QL recurrence of the per-level eigen-decomposition and nine dependent launches)")}
 
 
 def time_ehqp(B, device, steps=10, warmup=3):
@@ -311,7 +337,11 @@ def time_ehqp(B, device, steps=10, warmup=3):
     return {"workload": "BASELINE configs[2] stack through the reference's equality-only front-end (eHQP.cpp:64-95: damped pseudo-"
                         "inverses and projectors, the box is not used): per level an eigen-decomposition of P A'W A P (parallel Jacobi "
                         "in LDS); all levels of an instance in one launch",
-            "batch": B, "value": B * steps / el, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "solved_ok": f"{ok}/{B}"}
+            "batch": B, "value": B * steps / el, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "solved_ok": f"{ok}/{B}",
+            "roofline": hbm_roofline(algo_bytes_per_solve(plan), B, 1e3 * el / steps,
+                                     [("osot_update_kernel", B, 1), ("osot_ehqp_kernel", B, 1)],
+                                     "osot_ehqp_kernel (all levels of an instance in one launch; bound by the scalar QL recurrence of its "
+                                     "eigen-decompositions, far from both roofs)")}
 
 
 def time_kinematics(B, device, steps=20, warmup=5):
@@ -337,8 +367,8 @@ def time_kinematics(B, device, steps=20, warmup=5):
     gbs = B * nbytes / (ms * 1e-3) / 1e9
     return {"workload": "osot_kin_kernel: 32-DoF humanoid, 4 frame poses + 6xn Jacobians, CoM + 3xn Jacobian, written into the "
                         "stacked A_k (SURVEY 8f-1)", "batch": B, "value": B / (ms * 1e-3), "unit": "instances/s", "avg_launch_ms": ms,
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_instance": nbytes}}
+            "roofline": hbm_roofline(nbytes, B, ms, [("osot_kin_kernel<false, 32>", (B + 1) // 2, 1)],
+                                     "osot_kin_kernel<false,32> (two instances per wavefront)")}
 
 
 def sub_leaf(lf, lo, hi):
@@ -541,7 +571,7 @@ def main():
         if all_ok is not None:
             out["solved_ok_all_ranks"] = f"{all_ok}/{Bg}"
         if launches > 0 and kern_ms > 0 and not stub:
-            traffic, src = pmc_traffic(args.config, Bl // S)
+            traffic, src = pmc_traffic([("osot_cycle_kernel<32, false>", Bl // S + 1, 1)])   # (+ the order workgroup)
             # S launches are in flight at a time (one per lane), each sharing the chip with the others: a launch's own duration is
             # not the time the chip needed for its instances.  The roofline figures therefore take the time of a whole STEP (all
             # lanes; it contains every launch of the step plus the order kernels and launch gaps, so it under-states the kernel).
@@ -550,8 +580,7 @@ def main():
                                  "osot_cycle_kernel<32,false> (AutoStack::update + the whole cascade of an instance by one wavefront: "
                                  "fp64 MFMA H build + blocked Cholesky + null-space elimination, VALU/LDS active set)",
                                  None if traffic is None else traffic * S,
-                                 (src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 per "
-                                        "MI355X_MICROARCH.md; same kernel source hash; per launch x launches per step)") if traffic else
+                                 (src + "; per launch x launches per step") if traffic else
                                  "no PMC passes committed for this kernel source: null rather than a stale figure")
             rf["avg_launch_ms"] = kern_ms
             rf["launch_batch"] = Bl // S

@@ -32,6 +32,8 @@ constexpr double kEhqpFloor = 1.0e-7;
 
 struct DevEhqp {
     int B, n, L;
+    int use_qr;          // host side: launch osot_ehqp_qr_kernel (diagonal weights) instead of osot_ehqp_kernel
+    int rows8;           // the largest level's row count rounded up to a multiple of 8 (LDS rows of the QR kernel)
     unsigned active_mask;
     int m[OSOT_KMAX_LEVELS], ma[OSOT_KMAX_LEVELS];
     const double* A[OSOT_KMAX_LEVELS];    // [B][ma][n] stored rows
@@ -219,14 +221,306 @@ __global__ void __launch_bounds__(64) osot_ehqp_kernel(const DevEhqp Q) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 3: the same front-end WITHOUT an eigen-decomposition, for levels with diagonal weights (every benchmark stack;
+// a stack with a dense weight matrix keeps the kernel above).
+//
+// With P = Z Z' (Z: n x f, orthonormal columns: the null space the levels above have left) the reference's step is
+//     JP = L'A P = M Z',  M = W^1/2 A Z (m x f);      JP^+ = Z M^+;      P <- P - V V' = Z Q2 Q2' Z'
+// where the rows of M span range(Q1) and Q = [Q1 Q2] is ANY orthogonal completion: the pseudo-inverse and the projector
+// only need the ROW SPACE of M, not its singular values (they decide the rank; eHQP's damping only acts on a singular
+// value below sigma_min = 1e-12, a numerically singular level).  Per level:
+//   1. M = W^1/2 A Z and r = W^1/2 (b - A x)                                        (lane = row, or lane = column of M)
+//   2. Householder QR of M' with pivoting, ROW-ORIENTED: lane = task row, the reflector is broadcast from LDS and every
+//      lane updates ITS row (dot product and rank-1 update are lane-local: no cross-lane reduction per row); the same
+//      reflector goes through Z (lane = variable), so that Z [Q1 Q2] is built in place.  Stops at rank rho: largest
+//      remaining row norm <= kEhqpRankTol of the first.  Afterwards row r of M holds row r of T = M Q1 (m x rho).
+//   3. t = argmin |T t - r|:  rho = m: T is triangular in pivot order, forward substitution;  rho < m (more rows than free
+//      directions: the Postural last level, an over-determined level): a second Householder QR, of the tall T, in place.
+//   4. x += (Z Q1) t;   Z <- Z Q2;   f <- f - rho.
+// Work ~ m f^2 per level instead of an n^3 eigen-problem with its scalar QL recurrence, and no squaring of the condition
+// number on the full-row-rank levels.  Where it differs from the reference: a RANK-DEFICIENT level removes rho directions
+// from the null space, the reference's thin V removes min(m, n) (the extra ones are implementation-defined completion
+// vectors of Eigen's JacobiSVD, see oracle/pyehqp.py).  n <= 64, at most 64 rows per level.
+constexpr double kEhqpRankTol = 1.0e-11;
+
+// (every inner loop runs in chunks of eight with its LDS reads issued together: a loop with a run-time trip count and one LDS
+//  read per iteration costs a full LDS round trip, ~100 cycles, per element; the vectors are zero-padded to the chunk)
+// LDS per wavefront (dynamic, sized by the plan): Z [NP][NP+1], the level's rows [rows8][NP+1] (rows8 = the largest level
+// rounded up to 8), five 72-entry vectors, the pivot order: 19.7 KB at BASELINE config 3 -> eight wavefronts per CU.
+inline size_t ehqp_qr_lds_bytes(int NP, int rows8) { return sizeof(double) * ((size_t)NP * (NP + 1) + (size_t)rows8 * (NP + 1) + 5 * 72) + sizeof(int) * 64; }
+
+template <int NP>
+__global__ void __launch_bounds__(64) osot_ehqp_qr_kernel(const DevEhqp Q) {
+    constexpr int S = NP + 1;
+    OSOT_DYNAMIC_LDS(ehqp_smem);
+    double* Zs = reinterpret_cast<double*>(ehqp_smem);   // Z[c][i]: basis of the remaining null space, n x f (zero beyond f)
+    double* Ms = Zs + NP * S;                            // the level's rows: A (staged), then M = W^1/2 A Z, then T
+    double* Vv = Ms + Q.rows8 * S;
+    int* perm = reinterpret_cast<int*>(Vv + 5 * 72);     // pivot order: perm[j] = task row of step j
+    const int lane = threadIdx.x;
+    const long long inst = blockIdx.x;
+    const int n = Q.n;
+    double* xs = Vv; double* vs = Vv + 72; double* ts = Vv + 144; double* sws = Vv + 216; double* rps = Vv + 288;
+    for (int e = lane; e < NP * S; e += 64) Zs[e] = 0.0;
+    for (int e = lane; e < 5 * 72; e += 64) Vv[e] = 0.0;
+    wave_sync();
+    if (lane < n) Zs[lane * S + lane] = 1.0;
+    wave_sync();
+    // sum_{i in [i0, i1)} a[i] b[i], i0 a multiple of 8, both arrays readable and zero-padded up to the next multiple of 8
+    auto dot8 = [](const double* a, const double* b, int i0, int i1) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int i = i0; i < i1; i += 8) {
+            double va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { va[u] = a[i + u]; vb[u] = b[i + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { s0 = fma(va[u], vb[u], s0); s1 = fma(va[u + 1], vb[u + 1], s1); }
+        }
+        return s0 + s1;
+    };
+    int f = n;
+    double x = 0.0;                            // lane c < n: x_c
+    for (int k = 0; k < Q.L; ++k) {
+        const bool on = ((Q.active_mask >> k) & 1u) != 0u;
+        const int m = Q.m[k], ma = Q.ma[k];
+        if (on && f > 0 && m > 0) {
+            const int m8 = (m + 7) & ~7, f8 = (f + 7) & ~7, n8 = (n + 7) & ~7;
+            const double* Ak = Q.A[k] ? Q.A[k] + inst * ma * n : nullptr;
+            const double* bk = Q.b[k] + inst * m;
+            const double* wk = Q.w[k] ? Q.w[k] + inst * m : nullptr;
+            // ---- stage the STORED rows (coalesced: lane = column), eight loads in flight; zero rows up to m8.  The implicit
+            // Postural block [I 0] needs no staging: its rows of M are rows of Z.
+            const int ma8 = (ma + 7) & ~7;
+            for (int r0 = 0; r0 < ma8; r0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = (lane < n && r0 + u < ma) ? Ak[(r0 + u) * n + lane] : 0.0;
+                if (lane < NP) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) Ms[(r0 + u) * S + lane] = v[u];
+                }
+            }
+            wave_sync();
+            // ---- W^1/2 and r = W^1/2 (b - A x), lane = row (an implicit row r: (A x)_r = x_(r - ma))
+            {
+                double sw = 0.0, rp = 0.0;
+                if (lane < m) {
+                    const double wr = wk ? wk[lane] : 1.0;
+                    double sq, rs;
+                    fast_sqrt_rsqrt(wr > 0.0 ? wr : 1.0, sq, rs);
+                    sw = wr > 0.0 ? sq : 0.0;
+                    const double ax = (lane < ma) ? dot8(Ms + lane * S, xs, 0, n8) : xs[lane - ma];
+                    rp = sw * (bk[lane] - ax);
+                }
+                sws[lane] = sw; rps[lane] = rp;
+                if (lane < 8) { sws[64 + lane] = 0.0; rps[64 + lane] = 0.0; }
+            }
+            wave_sync();
+            // ---- M = W^1/2 A Z, lane = column i of M, FOUR rows at a time (a Z entry is read once for the four); the rows of A
+            // are LDS broadcasts and become the rows of M when they are done
+            {
+                const int li = (lane < NP) ? lane : 0;
+                for (int r0 = 0; r0 < ma; r0 += 4) {
+                    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                    for (int c = 0; c < n8; c += 8) {
+                        double vz[8], va[4][8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) vz[u] = Zs[((c + u < NP) ? c + u : 0) * S + li];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) va[q][u] = Ms[(r0 + q) * S + c + u];       // (rows up to ma8 - 1 exist and are zero)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) acc[q] = fma(va[q][u], vz[u], acc[q]);
+                    }
+                    wave_sync();
+                    if (lane < NP) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) if (r0 + q < ma8) Ms[(r0 + q) * S + lane] = (lane < f && r0 + q < ma) ? sws[r0 + q] * acc[q] : 0.0;
+                    }
+                }
+                // implicit rows: M[ma + j][i] = sw Z[j][i]; then zero rows up to m8
+                for (int r = ma8; r < m8; ++r) if (lane < NP) Ms[r * S + lane] = 0.0;
+                wave_sync();
+                for (int r = ma; r < m; ++r) if (lane < NP) Ms[r * S + lane] = (lane < f) ? sws[r] * Zs[(r - ma) * S + li] : 0.0;
+            }
+            wave_sync();
+            // ---- pivoted Householder QR of M' (row-oriented)
+            double nrm2 = -1.0;
+            bool used = !(lane < m);
+            if (lane < m) nrm2 = dot8(Ms + lane * S, Ms + lane * S, 0, f8);
+            int rho = 0;
+            double ref = 0.0;
+            const int kmax = (m < f) ? m : f;
+            for (int j = 0; j < kmax; ++j) {
+                double neg = used ? 1.0 : -nrm2;
+                int pidx = lane;
+                colargmin<64>(neg, pidx);
+                const int prow = uniform_i(pidx);
+                const double val = -bcast(neg, 0);
+                if (j == 0) ref = val;
+                if (!(val > kEhqpRankTol * kEhqpRankTol * ref) || !(val > 0.0)) break;
+                const int li = (lane < NP) ? lane : NP - 1;
+                double vi = Ms[prow * S + li];
+                const double x1 = bcast(vi, j);
+                double nrm, rnrm;
+                fast_sqrt_rsqrt(val, nrm, rnrm);
+                const double alpha = (x1 > 0.0) ? -nrm : nrm;
+                vi = (lane == j) ? vi - alpha : vi;
+                vi = (lane >= j && lane < f) ? vi : 0.0;
+                const double beta = fast_rcp(val - alpha * x1);
+                vs[lane] = vi;                 // (zero outside [j, f): the chunked loops below need no masks)
+                wave_sync();
+                // the lane's row of M (lane < m, not a pivot row yet) and its row of Z (lane < n) go through the reflector
+                // TOGETHER: both rows' chunks are requested before either is used
+                const int j8 = j & ~7;
+                const bool do_m = lane < m && !used && lane != prow, do_z = lane < n;
+                double* mrow = Ms + (do_m ? lane : 0) * S;
+                double* zrow = Zs + (do_z ? lane : 0) * S;
+                double dm0 = 0.0, dm1 = 0.0, dz0 = 0.0, dz1 = 0.0;
+                for (int i = j8; i < f8; i += 8) {
+                    double vv[8], mv[8], zv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { vv[u] = vs[i + u]; mv[u] = mrow[i + u]; zv[u] = zrow[i + u]; }
+#pragma unroll
+                    for (int u = 0; u < 8; u += 2) {
+                        dm0 = fma(vv[u], mv[u], dm0); dm1 = fma(vv[u + 1], mv[u + 1], dm1);
+                        dz0 = fma(vv[u], zv[u], dz0); dz1 = fma(vv[u + 1], zv[u + 1], dz1);
+                    }
+                }
+                const double scm = beta * (dm0 + dm1), scz = beta * (dz0 + dz1);
+                double n0 = 0.0, n1 = 0.0;
+                for (int i = j8; i < f8; i += 8) {
+                    double vv[8], mv[8], zv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { vv[u] = vs[i + u]; mv[u] = mrow[i + u]; zv[u] = zrow[i + u]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { mv[u] = fma(-scm, vv[u], mv[u]); zv[u] = fma(-scz, vv[u], zv[u]); }
+                    if (do_m) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) mrow[i + u] = mv[u];
+                    }
+                    if (do_z) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) zrow[i + u] = zv[u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u += 2) {
+                        n0 = fma((i + u > j) ? mv[u] : 0.0, mv[u], n0);
+                        n1 = fma((i + u + 1 > j) ? mv[u + 1] : 0.0, mv[u + 1], n1);
+                    }
+                }
+                if (do_m) nrm2 = n0 + n1;
+                wave_sync();
+                if (lane == prow) {
+                    Ms[prow * S + j] = alpha;
+                    for (int i = j + 1; i < f; ++i) Ms[prow * S + i] = 0.0;
+                    used = true;
+                }
+                if (lane == 0) perm[j] = prow;
+                rho++;
+                wave_sync();
+            }
+            const int rho8 = (rho + 7) & ~7;
+            ts[lane] = 0.0;
+            if (lane < 8) ts[64 + lane] = 0.0;
+            wave_sync();
+            // ---- t = argmin |T t - r|
+            if (rho == m) {
+                // T is triangular in pivot order: step j fixes t_j from row perm[j]; every other row takes the term out of
+                // its own right-hand side (lane-parallel forward substitution)
+                double rr = rps[lane];
+                for (int j = 0; j < rho; ++j) {
+                    const int prow = perm[j];
+                    const double tjj = Ms[((lane < m) ? lane : 0) * S + j];
+                    const double tj = bcast(rr, prow) * fast_rcp(bcast(tjj, prow));
+                    if (lane < m && lane != prow) rr = fma(-tjj, tj, rr);
+                    if (lane == 0) ts[j] = tj;
+                }
+                wave_sync();
+            } else if (rho > 0) {
+                // more rows than directions (or a rank-deficient level): Householder QR of the tall T (m x rho) IN PLACE, lane =
+                // row, the reflectors across the lanes (wave reductions); R ends up in rows 0 .. rho-1, Q'r in rr
+                double rr = rps[lane];                       // (zero for lane >= m)
+                const int lr = (lane < m) ? lane : 0;
+                for (int j = 0; j < rho; ++j) {
+                    const double tj = (lane < m && lane >= j) ? Ms[lr * S + j] : 0.0;
+                    const double nn = colsum<64>(tj * tj);
+                    const double x1 = bcast(tj, j);
+                    double nrm, rnrm;
+                    fast_sqrt_rsqrt(nn > 0.0 ? nn : 1.0, nrm, rnrm);
+                    const double alpha = (nn > 0.0) ? ((x1 > 0.0) ? -nrm : nrm) : 0.0;
+                    const double hv = (lane == j) ? tj - alpha : tj;       // reflector (zero above row j and beyond m)
+                    const double den = nn - alpha * x1;
+                    const double beta = (den > 0.0) ? fast_rcp(den) : 0.0;
+                    for (int c2 = j + 1; c2 < rho; ++c2) {
+                        const double tv = (lane < m) ? Ms[lr * S + c2] : 0.0;
+                        const double dd = colsum<64>(hv * tv);
+                        if (lane < m && lane >= j) Ms[lr * S + c2] = fma(-beta * dd, hv, tv);
+                    }
+                    const double dr = colsum<64>(hv * rr);
+                    rr = fma(-beta * dr, hv, rr);
+                    if (lane == j) Ms[lr * S + j] = alpha;
+                    wave_sync();
+                }
+                for (int j = rho - 1; j >= 0; --j) {               // R t = (Q'r)[0 .. rho)
+                    const double rjj = Ms[((lane < rho) ? lane : 0) * S + j];
+                    const double tj = bcast(rr, j) * fast_rcp(bcast(rjj, j));
+                    if (lane < j) rr = fma(-rjj, tj, rr);
+                    if (lane == 0) ts[j] = tj;
+                }
+                wave_sync();
+            }
+            // ---- x += (Z Q1) t;  Z <- Z Q2
+            if (lane < n) {
+                double* row = Zs + lane * S;
+                x += dot8(row, ts, 0, rho8);
+                for (int i = 0; i < f8; i += 8) {
+                    double zv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) zv[u] = (i + u + rho < f) ? row[(i + u + rho < NP) ? i + u + rho : 0] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) row[i + u] = zv[u];
+                }
+            }
+            wave_sync();
+            xs[lane] = (lane < n) ? x : 0.0;
+            f -= rho;
+            wave_sync();
+        }
+        if (Q.x_levels && lane < n) Q.x_levels[(inst * Q.L + k) * n + lane] = x;
+    }
+    if (lane < n) Q.dq[inst * n + lane] = x;
+    if (lane == 0) {
+        Q.status[inst] = QP_SOLVED;                        // eHQP::solve returns true (eHQP.cpp:94)
+        if (Q.iterations) Q.iterations[inst] = 0;
+    }
+}
+
 // validation + kernel arguments from the plan and the per-call batch (shared by the C-ABI entry and tests/emu)
 inline int ehqp_args(const osot_plan_desc& p, const osot_qp_batch* b, double sigma_min, bool any_task_inactive, DevEhqp& Q,
                      const char** why) {
-    if (p.n > 32) { *why = "eHQP front-end: n <= 32 in this build"; return OSOT_ERR_UNSUPPORTED; }
+    bool any_dense = false, wide = false;
+    for (int k = 0; k < p.n_levels; ++k) {
+        int m, ma; plan_level_rows(&p, k, &m, &ma);
+        wide = wide || m > 64;
+        for (int j = 0; j < p.level[k].n_tasks; ++j) any_dense = any_dense || p.level[k].task[j].dense_weight != 0;
+    }
+    // the QR kernel (round 3) takes diagonal weights, n <= 64 and <= 64 rows per level; the Gram / eigen kernel takes dense
+    // weights and any row count, n <= 32
+    const bool qr = !any_dense && !wide;
+    if (!qr && p.n > 32) { *why = "eHQP front-end: a stack with a dense weight matrix or more than 64 rows in a level needs n <= 32"; return OSOT_ERR_UNSUPPORTED; }
+    if (p.n > 64) { *why = "eHQP front-end: n <= 64"; return OSOT_ERR_UNSUPPORTED; }
     if (p.has_regularisation) { *why = "eHQP has no regularisation task"; return OSOT_ERR_UNSUPPORTED; }
     if (any_task_inactive) { *why = "eHQP front-end: Task::setActive(false) is not covered (switch whole levels with level_active)"; return OSOT_ERR_UNSUPPORTED; }
     std::memset(&Q, 0, sizeof(Q));
     Q.B = b->B; Q.n = p.n; Q.L = p.n_levels;
+    Q.use_qr = qr ? 1 : 0;
+    Q.rows8 = 8;
+    for (int k = 0; k < p.n_levels; ++k) { int m, ma; plan_level_rows(&p, k, &m, &ma); if (((m + 7) & ~7) > Q.rows8) Q.rows8 = (m + 7) & ~7; }
     Q.sigma_min = sigma_min > 0.0 ? sigma_min : 1.0e-12;     // eHQP.cpp:56
     Q.active_mask = 0u;
     for (int k = 0; k < p.n_levels; ++k) {

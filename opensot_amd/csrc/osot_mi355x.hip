@@ -264,7 +264,16 @@ int osot_ehqp_solve(osot_solver* s, const osot_qp_batch* b, double sigma_min, vo
     if (rc != OSOT_OK) return fail(rc, why);
     DeviceGuard guard(s->device);
     if (!guard.ok) return fail(OSOT_ERR_HIP, "hipSetDevice failed");
-    hipLaunchKernelGGL(osot_ehqp_kernel, dim3((unsigned)b->B), dim3(64), 0, (hipStream_t)hip_stream, Q);
+    if (Q.use_qr) {
+        const int NPq = Q.n <= 32 ? 32 : 64;
+        const size_t lds = ehqp_qr_lds_bytes(NPq, Q.rows8);
+        rc = NPq == 32 ? ensure_lds(osot_ehqp_qr_kernel<32>, lds) : ensure_lds(osot_ehqp_qr_kernel<64>, lds);
+        if (rc != OSOT_OK) return rc;
+        if (NPq == 32) hipLaunchKernelGGL(osot_ehqp_qr_kernel<32>, dim3((unsigned)b->B), dim3(64), lds, (hipStream_t)hip_stream, Q);
+        else hipLaunchKernelGGL(osot_ehqp_qr_kernel<64>, dim3((unsigned)b->B), dim3(64), lds, (hipStream_t)hip_stream, Q);
+    } else {
+        hipLaunchKernelGGL(osot_ehqp_kernel, dim3((unsigned)b->B), dim3(64), 0, (hipStream_t)hip_stream, Q);
+    }
     HIP_TRY(hipGetLastError());
     return OSOT_OK;
 }

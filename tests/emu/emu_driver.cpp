@@ -103,7 +103,9 @@ extern "C" __attribute__((visibility("default"))) int emu_ehqp_solve(const osot_
     DevEhqp Q;
     rc = ehqp_args(*plan, b, sigma_min, false, Q, &why);
     if (rc != OSOT_OK) { fprintf(stderr, "emu: %s\n", why); return rc; }
-    emu::launch(osot_ehqp_kernel, (unsigned)b->B, 0, 64, Q);
+    if (Q.use_qr && Q.n <= 32) emu::launch(osot_ehqp_qr_kernel<32>, (unsigned)b->B, ehqp_qr_lds_bytes(32, Q.rows8), 64, Q);
+    else if (Q.use_qr) emu::launch(osot_ehqp_qr_kernel<64>, (unsigned)b->B, ehqp_qr_lds_bytes(64, Q.rows8), 64, Q);
+    else emu::launch(osot_ehqp_kernel, (unsigned)b->B, 0, 64, Q);
     return OSOT_OK;
 }
 

@@ -54,15 +54,18 @@ def test_restatement_agrees_with_ihqp_where_both_pose_the_same_problem(n, rows, 
         assert np.abs(np.einsum("brn,bn->br", Ak, e["x_levels"][:, k] - r["x_levels"][:, k])).max() < 1e-6
 
 
-@pytest.mark.parametrize("n,rows,seed", [(7, [3, 2], 1), (12, [4, 5], 2), (32, [3, 24], 3), (20, [6], 4), (9, [2, 2, 2], 5)])
+@pytest.mark.parametrize("n,rows,seed", [(7, [3, 2], 1), (12, [4, 5], 2), (32, [3, 24], 3), (20, [6], 4), (9, [2, 2, 2], 5),
+                                         (35, [12, 6], 6), (40, [10, 12], 7), (50, [15], 8), (64, [20, 30], 9)])
 def test_emulated_kernel_vs_restatement(n, rows, seed, oracle):
+    """the QR kernel (round 3: no eigen-decomposition, n <= 64) against the numpy-SVD restatement: 1e-12 (the Gram / eigen
+    kernel of round 2 was held to 1e-9: it squared the condition number)"""
     plan, leaf = _generic(5, n, rows, seed)
     asm = oracle.assemble(plan, leaf)
     e = pyehqp.ehqp_solve(asm)
     dq, st, xl = emu_ehqp(plan, asm)
     assert (st == 0).all()
-    assert np.abs(dq - e["dq"]).max() < 1e-9
-    assert np.abs(xl - e["x_levels"]).max() < 1e-9
+    assert np.abs(dq - e["dq"]).max() < 1e-12
+    assert np.abs(xl - e["x_levels"]).max() < 1e-12
 
 
 def test_stack_without_a_full_rank_last_level(oracle):
@@ -133,7 +136,7 @@ def test_overdetermined_level_is_weighted_least_squares(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,rows,seed", [(7, [3, 2], 1), (32, [3, 24], 3)])
+@pytest.mark.parametrize("n,rows,seed", [(7, [3, 2], 1), (32, [3, 24], 3), (35, [12, 6], 6), (50, [15], 8), (64, [20, 30], 9)])
 def test_ehqp_gpu_vs_restatement(n, rows, seed, oracle, gpu_device):
     import torch
     from opensot_amd.solver import BatchedStack
@@ -146,8 +149,8 @@ def test_ehqp_gpu_vs_restatement(n, rows, seed, oracle, gpu_device):
     torch.cuda.synchronize()
     e = pyehqp.ehqp_solve(asm)
     assert (st.status[:B].cpu().numpy() == 0).all()
-    assert np.abs(st.dq[:B].cpu().numpy() - e["dq"]).max() < 1e-9
-    assert np.abs(st.x_levels[:B].cpu().numpy() - e["x_levels"]).max() < 1e-9
+    assert np.abs(st.dq[:B].cpu().numpy() - e["dq"]).max() < 1e-12
+    assert np.abs(st.x_levels[:B].cpu().numpy() - e["x_levels"]).max() < 1e-12
 
 
 @pytest.mark.gpu
