@@ -216,8 +216,16 @@ inline int make_dev_plan(const osot_plan_desc& p, const unsigned char* level_act
     int total = (((NP == 32 ? WaveCtx<32>::M1_DOUBLES : WaveCtx<64>::M1_DOUBLES) + NP * S + 4 * NP) + 1) & ~1;
     P.lds_rows_off = total;
     P.lds_rows_cap = cap;
-    total += 3 * cap + cap;
-    total += (cap + 7) / 8;
+    const int table = 3 * cap + cap + (cap + 7) / 8;      // doubles of the row table
+    P.rows_doubles = table;
+    // NP = 64 (round 3): the row table lives in a per-instance slice of device memory (DevBatch.rows_scratch, served by the
+    // CU's L1 / L2) whenever taking it out of LDS buys another resident wavefront per CU
+    P.rows_in_global = 0;
+    if (NP == 64) {
+        const size_t with = (size_t)(total + table) * sizeof(double), without = (size_t)total * sizeof(double);
+        if ((160 * 1024) / without > (160 * 1024) / with) P.rows_in_global = 1;
+    }
+    if (!P.rows_in_global) total += table;
     lds_bytes = (size_t)total * sizeof(double);
     return OSOT_OK;
 }

@@ -66,6 +66,8 @@ struct DevPlan {
     // LDS carve-up of the wave's slice (doubles): M1, M2, V first (sizes fixed by NP), then
     int lds_rows_off;               // the row table: rlo, rup, rptr (8 B per row), rowstate, eqlist, rsrc (4 B per row)
     int lds_rows_cap;               // capacity (rows), even
+    int rows_doubles;               // size of the row table (doubles)
+    int rows_in_global;             // 1: the row table is the instance's slice of DevBatch.rows_scratch, not LDS
 };
 
 struct DevBatch {
@@ -96,6 +98,7 @@ struct DevBatch {
     const double* WA[OSOT_KMAX_LEVELS];   // [B][ma_k][n] W_k A_k, [B][m_k] W_k b_k of a level with a non-diagonal weight
     const double* Wb[OSOT_KMAX_LEVELS];   // (osot_update_kernel writes them); null: W_k is diag(w[k])
     double* accepted_slack;   // [B] largest constraint violation accepted as round-off (0: none); may be null
+    double* rows_scratch;     // [B][rows_doubles] row tables of the instances when the plan keeps them out of LDS
     int* hot;                 // [B][L][NP] hot-start state: the inequality working set every level of every instance ended
                               // with (constraint codes, -1 = none), read at the start of a level and rewritten at its end
                               // (gi_inequalities); null: cold start, nothing recorded
@@ -117,7 +120,7 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
     w.M1 = base;
     w.M2 = base + WaveCtx<NP>::M1_DOUBLES;
     w.V = w.M2 + NP * S;
-    w.rlo = base + P.lds_rows_off;
+    w.rlo = P.rows_in_global ? D.rows_scratch + inst * P.rows_doubles : base + P.lds_rows_off;
     w.rup = w.rlo + P.lds_rows_cap;
     w.rptr = reinterpret_cast<unsigned long long*>(w.rup + P.lds_rows_cap);
     w.rowstate = reinterpret_cast<int*>(w.rptr + P.lds_rows_cap);

@@ -89,6 +89,7 @@ struct osot_solver {
     NhqpWorkspace nhqp; // scratch of the null-space front-end, allocated at its first use
     bool nhqp_ready = false;
     // hot start (osot_solver_set_hotstart): the inequality working set each level of each instance ended with
+    double* d_rows = nullptr;   // [max_batch][rows_doubles] row tables (plans whose 64-lane kernels keep them out of LDS)
     int hotstart = 0;
     int* d_hot = nullptr;    // [max_batch][n_levels][T] constraint codes, -1 = none (allocated when first switched on)
     int hot_T = 0;
@@ -157,6 +158,10 @@ int osot_solver_create(const osot_plan_desc* plan, int max_batch, int device, os
         hipError_t e2 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
         s->slots = (e1 == hipSuccess && e2 == hipSuccess && per_cu > 0 && cus > 0) ? per_cu * cus : 2048;
     }
+    if (P.rows_in_global && hipMalloc(&s->d_rows, sizeof(double) * (size_t)max_batch * (size_t)P.rows_doubles) != hipSuccess) {
+        delete s;
+        return fail(OSOT_ERR_HIP, "device allocation for the row tables failed");
+    }
     make_update_plan(*plan, s->h_uplan);
     // dispatch-order state and the static update plan live with the solver from the start (no lazy allocation on
     // whatever device is current)
@@ -184,6 +189,7 @@ int osot_solver_destroy(osot_solver* s) {
     if (s->d_order) hipFree(s->d_order);
     if (s->d_uplan) hipFree(s->d_uplan);
     if (s->d_hot) hipFree(s->d_hot);
+    if (s->d_rows) hipFree(s->d_rows);
     if (s->nhqp_ready) {
         void* ptrs[] = {s->nhqp.N[0], s->nhqp.N[1], s->nhqp.q0, s->nhqp.H, s->nhqp.g, s->nhqp.R, s->nhqp.rlo, s->nhqp.rup, s->nhqp.z,
                         s->nhqp.V2, s->nhqp.qp_status, s->nhqp.qp_iters};
@@ -421,6 +427,7 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
     D.prof = prof;
     D.accepted_slack = b->accepted_slack;
     D.hot = (s->hotstart && !prof) ? s->d_hot : nullptr;
+    D.rows_scratch = s->d_rows;
     hipStream_t st = (hipStream_t)hip_stream;
     if (s->schedule == 1) {
         if (s->order_B >= 0 && s->order_stream != st) HIP_TRY(hipStreamSynchronize(s->order_stream));

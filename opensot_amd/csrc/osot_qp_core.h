@@ -76,19 +76,22 @@ constexpr double kFeasMargin = OSOT_FEAS_MARGIN;  // cascade levels below the fi
 enum { QP_SOLVED = 0, QP_INFEASIBLE = 1, QP_MAX_ITER = 2, QP_NOT_PD = 3 };
 
 // R (the triangular factor of the working set; upper Hessenberg for a moment while a constraint is being dropped) lives in
-// M1.  NP = 64: plain [NP][S] storage, shared with the Cholesky factor L that factor_rows64 keeps there.  NP = 32: PACKED
-// by columns, column j holding rows 0 .. j+1 at offset j (j + 3) / 2 -- 560 doubles instead of 1056: the 4 KB that let ten
+// M1, PACKED by columns, column j holding rows 0 .. j+1 at offset j (j + 3) / 2 (NP = 64, round 3: 17 KB instead of 33, with the
+// Cholesky factor L of factor_rows64 packed by rows in the same slice and the row table moved out of LDS: 52 KB per wave, three
+// waves per CU instead of two).  NP = 32: 560 doubles instead of 1056: the 4 KB that let ten
 // waves (instead of eight) share a CU's 160 KB of LDS, i.e. 2560 instead of 2048 instances in flight.  (At BASELINE
 // config 3 a batch of 4096 then is 1.6 instead of 2 jobs per slot: the long jobs get a slot to themselves and the launch
 // ends with its longest instance instead of with a late-started short one; tools/prof_cycle.py shows the timeline.)  A
 // column's rows are contiguous, so lane-per-row accesses of one column are conflict-free and the column offset is uniform.
 template <int NP>
-__device__ __forceinline__ int ridx(int i, int j) { return NP == 32 ? ((j * (j + 3)) >> 1) + i : i * (NP + 1) + j; }
+__device__ __forceinline__ int ridx(int i, int j) { return ((j * (j + 3)) >> 1) + i; }   // (round 3: packed for NP = 64 as well)
+// the Cholesky factor L of the 64-lane path, PACKED by rows (row i holds columns 0 .. i) in the same M1 slice
+__device__ __forceinline__ int lidx(int i, int j) { return ((i * (i + 1)) >> 1) + j; }
 template <int NP>
 struct WaveCtx {
     static constexpr int HV = 64 / NP;
     static constexpr int S = NP + 1;
-    static constexpr int M1_DOUBLES = (NP == 32) ? 560 : NP * (NP + 1);   // 32 * 35 / 2 packed, or the full square
+    static constexpr int M1_DOUBLES = NP * (NP + 3) / 2;   // packed R: 560 doubles for NP = 32, 2144 for NP = 64 (the packed L of factor_rows64, 2080, fits too)
     int c, h;       // column index and half of this lane
     int n;
     double* M1;
@@ -445,7 +448,7 @@ __device__ __forceinline__ int factor_rows64(const WaveCtx<64>& w, double (&Hc)[
 #pragma unroll
             for (int j = j0; j < j0 + 8; ++j) {
                 double acc[4] = {Hc[j], 0.0, 0.0, 0.0};
-                const double* rowj = M1 + launder_i(j * S);   // opaque base: see the note on LDS addresses
+                const double* rowj = M1 + launder_i(lidx(j, 0));   // opaque base: see the note on LDS addresses
 #pragma unroll
                 for (int q = 0; q < NP / 16; ++q) {
                     if (16 * q < j) {
@@ -463,7 +466,7 @@ __device__ __forceinline__ int factor_rows64(const WaveCtx<64>& w, double (&Hc)[
                 fast_sqrt_rsqrt(piv, sq, rs);
                 const double lcj = (c == j) ? sq : ((c > j) ? sres * rs : 0.0);
                 Hc[j] = lcj;
-                M1[c * S + j] = lcj;            // zeros above the diagonal included
+                if (c >= j) M1[lidx(c, j)] = lcj;   // (packed: the zeros above the diagonal are not stored)
                 if (c == j) invd = rs;
                 const double yj = bcast(rhs, j) * rs;                       // forward substitution
                 rhs = (c == j) ? yj : fma(-lcj, yj, rhs);
@@ -485,7 +488,7 @@ __device__ __forceinline__ int factor_rows64(const WaveCtx<64>& w, double (&Hc)[
 #pragma unroll
                 for (int i = i0; i < i0 + 8; ++i) {
                     double acc[4] = {(i == c) ? 1.0 : 0.0, 0.0, 0.0, 0.0};
-                    const double* rowi = M1 + launder_i(i * S);
+                    const double* rowi = M1 + launder_i(lidx(i, 0));
 #pragma unroll
                     for (int q = 0; q < NP / 16; ++q) {
                         if (16 * q < i) {
@@ -514,7 +517,7 @@ __device__ __forceinline__ int factor_rows64(const WaveCtx<64>& w, double (&Hc)[
         if (FULL || i0 < n) {   // same block guard as above (the padded rows are identity rows)
             double lrow[8];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) lrow[t] = M1[(i0 + t) * S + c];   // zero for c > i; lane i itself is done
+            for (int t = 0; t < 8; ++t) { const double lv = M1[lidx(i0 + t, (c <= i0 + t) ? c : 0)]; lrow[t] = (c <= i0 + t) ? lv : 0.0; }   // zero for c > i; lane i itself is done
 #pragma unroll
             for (int t = 7; t >= 0; --t) {
                 const int i = i0 + t;

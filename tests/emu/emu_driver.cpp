@@ -33,6 +33,8 @@ extern "C" __attribute__((visibility("default"))) int emu_ihqp_solve(const osot_
     D.A_reg = (plan->has_regularisation && plan->regularisation_dense) ? b->A_reg : nullptr;
     D.accepted_slack = b->accepted_slack;
     D.hot = hot;
+    std::vector<double> rows_scratch(P.rows_in_global ? (size_t)b->B * P.rows_doubles : 1);
+    D.rows_scratch = rows_scratch.data();
     const unsigned grid = (unsigned)b->B;
     // (the emulation always runs the instantiation with the dense-weight / inactive-task code: it is a superset)
     if (T == 32) emu::launch(osot_cascade_kernel<32, false, true>, grid, lds, 64, P, D);
