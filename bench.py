@@ -87,8 +87,9 @@ def assembled_bytes_per_solve(plan):
 def kernel_source_sha():
     """identifies the cascade kernel a PMC traffic figure belongs to (profiles/*.json carry the same hash)"""
     h = hashlib.sha256()
-    for f in ("osot_qp_core.h", "osot_kernels.h", "osot_team.h"):
-        h.update(open(os.path.join(ROOT, "opensot_amd", "csrc", f), "rb").read())
+    csrc = os.path.join(ROOT, "opensot_amd", "csrc")
+    for f in sorted(x for x in os.listdir(csrc) if x.endswith(".h")):     # every kernel header (the bench line quotes them all)
+        h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -308,8 +309,8 @@ def time_nhqp(B, device, steps=5, warmup=2):
     el = time.perf_counter() - t0
     ok = int((st.status[:B] == 0).sum().item())
     return {"workload": "BASELINE configs[2] stack through the reference's null-space front-end (nHQP.cpp:155-204; defaults: A/b "
-                        "regularisation at 0.05 sv_max, selective null-space regularisation): per level an SVD of A N (parallel Jacobi in "
-                        "LDS), the QP in the nf = 32 / 29 / 5 free coordinates, q += N z, N <- N V2; three launches per level",
+                        "regularisation at 0.05 sv_max, selective null-space regularisation): per level an SVD of A N (Gram-side "
+                        "tridiagonalisation + implicit QL in LDS), the QP in the nf = 32 / 29 / 5 free coordinates, q += N z, N <- N V2; three launches per level",
             "batch": B, "value": B * steps / el, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "solved_ok": f"{ok}/{B}",
             "roofline": hbm_roofline(algo_bytes_per_solve(plan), B, 1e3 * el / steps,
                                      [("osot_update_kernel", B, 1), ("osot_nhqp_prepare_kernel<32>", B, plan.L),
@@ -335,13 +336,13 @@ def time_ehqp(B, device, steps=10, warmup=3):
     el = time.perf_counter() - t0
     ok = int((st.status[:B] == 0).sum().item())
     return {"workload": "BASELINE configs[2] stack through the reference's equality-only front-end (eHQP.cpp:64-95: damped pseudo-"
-                        "inverses and projectors, the box is not used): per level an eigen-decomposition of P A'W A P (parallel Jacobi "
-                        "in LDS); all levels of an instance in one launch",
+                        "inverses and projectors, the box is not used): null-space recursion, per level a pivoted Householder QR of "
+                        "W^1/2 A Z (no eigen-decomposition since round 3); all levels of an instance in one launch",
             "batch": B, "value": B * steps / el, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "solved_ok": f"{ok}/{B}",
             "roofline": hbm_roofline(algo_bytes_per_solve(plan), B, 1e3 * el / steps,
-                                     [("osot_update_kernel", B, 1), ("osot_ehqp_kernel", B, 1)],
-                                     "osot_ehqp_kernel (all levels of an instance in one launch; bound by the scalar QL recurrence of its "
-                                     "eigen-decompositions, far from both roofs)")}
+                                     [("osot_update_kernel", B, 1), ("osot_ehqp_qr_kernel<32>", B, 1)],
+                                     "osot_ehqp_qr_kernel<32> (all levels of an instance in one launch: row-oriented pivoted Householder QR "
+                                     "in LDS, a chain of dependent reflector steps: far from both roofs)")}
 
 
 def time_kinematics(B, device, steps=20, warmup=5):

@@ -413,6 +413,14 @@ int osot_backend_update_bounds(osot_backend* be, const double* l, const double* 
 int osot_backend_solve(osot_backend* be);
 int osot_backend_get_solution(osot_backend* be, double* x);
 int osot_backend_get_objective(osot_backend* be, double* f);
+/* BackEnd::getOptions / setOptions (include/OpenSoT/solvers/BackEnd.h:139-145; the qpOASES back-end hands out its
+ * qpOASES::Options through boost::any, QPOasesBackEnd.cpp:309-318).  What this back-end has to set is the iteration cap of
+ * the active-set loop (the counterpart of nWSR, QPOasesBackEnd.cpp:30: 0 = default 20 (n + nc) + 100); get also reports
+ * the iteration count and OSOT_STATUS_* of the last solve.  INTEGRATION.md: the adapter carries this struct in the
+ * boost::any. */
+typedef struct { int max_iterations; int last_iterations; int last_status; } osot_backend_options;
+int osot_backend_get_options(osot_backend* be, osot_backend_options* opt);
+int osot_backend_set_options(osot_backend* be, const osot_backend_options* opt);
 int osot_backend_set_eps_regularisation(osot_backend* be, double eps_abs);
 int osot_backend_get_eps_regularisation(osot_backend* be, double* eps_abs);
 int osot_backend_get_num_variables(osot_backend* be, int* nv);

@@ -84,6 +84,10 @@ class AssembledOut(C.Structure):
                 ("WA", C.c_void_p * MAX_LEVELS), ("Wb", C.c_void_p * MAX_LEVELS), ("A", C.c_void_p * MAX_LEVELS)]
 
 
+class BackendOptions(C.Structure):
+    _fields_ = [("max_iterations", C.c_int), ("last_iterations", C.c_int), ("last_status", C.c_int)]
+
+
 class NhqpOptions(C.Structure):
     _fields_ = [("free_vars", C.c_int * MAX_LEVELS), ("min_sv_ratio", C.c_double),
                 ("no_ab_regularization", C.c_int), ("no_selective_ns_regularization", C.c_int),
@@ -136,6 +140,7 @@ SYMBOLS = [
     "osot_backend_create", "osot_backend_destroy", "osot_backend_init_problem",
     "osot_backend_update_task", "osot_backend_update_constraints", "osot_backend_update_bounds",
     "osot_backend_solve", "osot_backend_get_solution", "osot_backend_get_objective",
+    "osot_backend_get_options", "osot_backend_set_options",
     "osot_backend_set_eps_regularisation", "osot_backend_get_eps_regularisation",
     "osot_backend_get_num_variables", "osot_backend_get_num_constraints",
     "osot_qp_solve_batch", "osot_qp_solve_batch_admm",
@@ -202,6 +207,8 @@ def lib():
     L.osot_backend_solve.argtypes = [vp]
     L.osot_backend_get_solution.argtypes = [vp, dp]
     L.osot_backend_get_objective.argtypes = [vp, dp]
+    L.osot_backend_get_options.argtypes = [vp, C.POINTER(BackendOptions)]
+    L.osot_backend_set_options.argtypes = [vp, C.POINTER(BackendOptions)]
     L.osot_backend_set_eps_regularisation.argtypes = [vp, C.c_double]
     L.osot_backend_get_eps_regularisation.argtypes = [vp, dp]
     L.osot_backend_get_num_variables.argtypes = [vp, ip]

@@ -565,6 +565,7 @@ struct osot_backend {
     size_t d_cap;
     int* d_status;
     int last_status, last_iters;
+    int max_iterations = 0;   // osot_backend_options: active-set iteration cap (0: the kernel's default, 20 (n + nc) + 100)
 };
 
 namespace {
@@ -600,7 +601,7 @@ int backend_run(osot_backend* be) {
         HIP_TRY(hipMemcpy(du, be->u.data(), sizeof(double) * n, hipMemcpyHostToDevice));
     }
     int rc = osot_qp_solve_batch(1, n, nc, dH, dg, nc ? dA : nullptr, nc ? dlA : nullptr, nc ? duA : nullptr,
-                                 be->has_bounds ? dl : nullptr, be->has_bounds ? du : nullptr, be->eps_abs, 0,
+                                 be->has_bounds ? dl : nullptr, be->has_bounds ? du : nullptr, be->eps_abs, be->max_iterations,
                                  dx, be->d_status, be->d_status + 1, nullptr);
     if (rc != OSOT_OK) return rc;
     int st[2];
@@ -723,6 +724,20 @@ int osot_backend_get_objective(osot_backend* be, double* f) {
         v += be->x[i] * (0.5 * (hx + be->eps_abs * be->x[i]) + be->g[i]);
     }
     *f = v;
+    return OSOT_OK;
+}
+
+int osot_backend_get_options(osot_backend* be, osot_backend_options* opt) {
+    if (!be || !opt) return fail(OSOT_ERR_INVALID, "null argument");
+    opt->max_iterations = be->max_iterations;
+    opt->last_iterations = be->last_iters;
+    opt->last_status = be->last_status;
+    return OSOT_OK;
+}
+int osot_backend_set_options(osot_backend* be, const osot_backend_options* opt) {
+    if (!be || !opt) return fail(OSOT_ERR_INVALID, "null argument");
+    if (opt->max_iterations < 0) return fail(OSOT_ERR_INVALID, "negative iteration cap");
+    be->max_iterations = opt->max_iterations;
     return OSOT_OK;
 }
 

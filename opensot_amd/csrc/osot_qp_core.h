@@ -1378,7 +1378,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
             // ahead, so that a step of the serial chain is readlane -> mul -> fma only.
             double rr = 0.0;
             double rmax = 0.0;   // max |r_j| (uniform): picked up on the way, every r_j passes through a broadcast
-            {
+            if (iq > me) {       // (no inequality in the working set yet -- the first addition of most levels: no dual direction)
                 // the residual is carried SCALED by the reciprocal diagonal, e_c = d1_c / R_cc, and so are the column entries
                 // (off the chain: the columns are fetched four steps ahead): a step of the serial chain is then
                 // readlane -> fma only (the unscaled form had a multiplication by 1 / R_jj in front of every broadcast)
@@ -1418,7 +1418,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
             if (mode == 1 && !z_ok) break;   // in the span of the working set by now: left to the scan
             double t1 = INFINITY;
             int lpos = c;
-            if (mode == 0) {
+            if (mode == 0 && iq > me) {
                 t1 = (c >= me && c < iq && rr > kRatioTol * rmax) ? fast_div(fmax(uq, 0.0), rr) : INFINITY;
                 colargmin<NP>(t1, lpos);
                 lpos = uniform_i(lpos);

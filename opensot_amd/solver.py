@@ -359,6 +359,18 @@ class BackEnd:
         self._lib.osot_backend_get_objective(self._h, C.byref(f))
         return f.value
 
+    def getOptions(self):
+        """BackEnd::getOptions (BackEnd.h:139): dict(max_iterations, last_iterations, last_status)"""
+        o = abi.BackendOptions()
+        self._lib.osot_backend_get_options(self._h, C.byref(o))
+        return {"max_iterations": o.max_iterations, "last_iterations": o.last_iterations, "last_status": o.last_status}
+
+    def setOptions(self, options):
+        """BackEnd::setOptions (BackEnd.h:145): the active-set iteration cap (the counterpart of qpOASES' nWSR)"""
+        o = abi.BackendOptions()
+        o.max_iterations = int(options.get("max_iterations", 0))
+        return self._lib.osot_backend_set_options(self._h, C.byref(o)) == abi.OK
+
     def getEpsRegularisation(self):
         e = C.c_double(0.0)
         self._lib.osot_backend_get_eps_regularisation(self._h, C.byref(e))

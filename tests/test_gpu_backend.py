@@ -137,3 +137,20 @@ def test_randomised_qp_sweep(oracle, gpu_device):
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "40 QP shapes x 64 instances" in out.stdout and ": 0 with a mismatch" in out.stdout, out.stdout[-2000:]
+
+
+def test_backend_options(gpu_device):
+    """BackEnd::getOptions / setOptions (BackEnd.h:139-145; the qpOASES back-end hands out its Options with nWSR,
+    QPOasesBackEnd.cpp:30, 309-318): the iteration cap of the active-set loop is settable, the last solve's iteration count
+    and status are readable; a cap below what the problem needs makes solve() return false like an exhausted nWSR does"""
+    n = 6
+    H = np.eye(n); g = -np.arange(1.0, n + 1.0)                 # unconstrained minimiser (1 .. 6): every upper bound 0.5 binds
+    qp = BackEnd(n, 0, abi.HST_IDENTITY, 1.0)
+    assert qp.initProblem(H, g, None, None, None, -np.ones(n), 0.5 * np.ones(n))
+    np.testing.assert_allclose(qp.getSolution(), 0.5 * np.ones(n), atol=1e-12)
+    o = qp.getOptions()
+    assert o["max_iterations"] == 0 and o["last_iterations"] == n and o["last_status"] == 0
+    assert qp.setOptions({"max_iterations": 3})
+    assert not qp.solve() and qp.getOptions()["last_status"] == 2          # OSOT_STATUS_MAX_ITER
+    assert qp.setOptions({"max_iterations": 0}) and qp.solve()
+    assert not qp.setOptions({"max_iterations": -1})
