@@ -351,10 +351,103 @@ __global__ void __launch_bounds__(64) osot_ehqp_qr_kernel(const DevEhqp Q) {
             // ---- pivoted Householder QR of M' (row-oriented)
             double nrm2 = -1.0;
             bool used = !(lane < m);
-            if (lane < m) nrm2 = dot8(Ms + lane * S, Ms + lane * S, 0, f8);
             int rho = 0;
             double ref = 0.0;
             const int kmax = (m < f) ? m : f;
+            if constexpr (NP == 32) {
+                // REGISTER-RESIDENT (n <= 32): the lane's row of M and its row of Z live in registers for the whole
+                // factorisation; a step publishes the pivot row through one LDS row, every lane reads it back as the
+                // reflector (32 broadcast reads) and the two rank-1 updates are register arithmetic -- no LDS pass over M or
+                // Z per step (the LDS form below moved 2 x 4 chunks x 24 words per lane and step)
+                double mr[32], zr[32];
+                {
+                    const int lm = (lane < m) ? lane : 0, lz = (lane < n) ? lane : 0;
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) { const double a = Ms[lm * S + i], z = Zs[lz * S + i]; mr[i] = (lane < m) ? a : 0.0; zr[i] = (lane < n) ? z : 0.0; }
+                }
+                {
+                    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 32; i += 2) { a0 = fma(mr[i], mr[i], a0); a1 = fma(mr[i + 1], mr[i + 1], a1); }
+                    if (lane < m) nrm2 = a0 + a1;
+                }
+                double* pub = Ms + (Q.rows8 - 1) * S;       // one row of the slice: the published pivot row / reflector
+                for (int j = 0; j < kmax; ++j) {
+                    double neg = used ? 1.0 : -nrm2;
+                    int pidx = lane;
+                    colargmin<64>(neg, pidx);
+                    const int prow = uniform_i(pidx);
+                    const double val = -bcast(neg, 0);
+                    if (j == 0) ref = val;
+                    if (!(val > kEhqpRankTol * kEhqpRankTol * ref) || !(val > 0.0)) break;
+                    wave_sync();
+                    if (lane == prow) {
+#pragma unroll
+                        for (int i = 0; i < 32; ++i) pub[i] = mr[i];
+                    }
+                    wave_sync();
+                    const double x1 = pub[j];
+                    double nrm, rnrm;
+                    fast_sqrt_rsqrt(val, nrm, rnrm);
+                    const double alpha = (x1 > 0.0) ? -nrm : nrm;
+                    const double beta = fast_rcp(val - alpha * x1);
+                    double v[32];
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) { const double pv = pub[i]; v[i] = (i == j) ? pv - alpha : ((i > j && i < f) ? pv : 0.0); }
+                    double dm0 = 0.0, dm1 = 0.0, dz0 = 0.0, dz1 = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (8 * q + 7 >= j && 8 * q < f) {           // (chunks below the pivot column hold zeros of v)
+#pragma unroll
+                            for (int u = 0; u < 8; u += 2) {
+                                const int i = 8 * q + u;
+                                dm0 = fma(v[i], mr[i], dm0); dm1 = fma(v[i + 1], mr[i + 1], dm1);
+                                dz0 = fma(v[i], zr[i], dz0); dz1 = fma(v[i + 1], zr[i + 1], dz1);
+                            }
+                        }
+                    }
+                    const bool do_m = lane < m && !used && lane != prow;
+                    const double scm = do_m ? beta * (dm0 + dm1) : 0.0, scz = beta * (dz0 + dz1);
+                    double n0 = 0.0, n1 = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (8 * q + 7 >= j && 8 * q < f) {
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const int i = 8 * q + u;
+                                mr[i] = fma(-scm, v[i], mr[i]);
+                                zr[i] = fma(-scz, v[i], zr[i]);
+                            }
+#pragma unroll
+                            for (int u = 0; u < 8; u += 2) {
+                                const int i = 8 * q + u;
+                                n0 = fma((i > j) ? mr[i] : 0.0, mr[i], n0);
+                                n1 = fma((i + 1 > j) ? mr[i + 1] : 0.0, mr[i + 1], n1);
+                            }
+                        }
+                    }
+                    if (do_m) nrm2 = n0 + n1;
+                    if (lane == prow) {
+#pragma unroll
+                        for (int i = 0; i < 32; ++i) mr[i] = (i == j) ? alpha : ((i > j) ? 0.0 : mr[i]);
+                        used = true;
+                    }
+                    if (lane == 0) perm[j] = prow;
+                    rho++;
+                }
+                wave_sync();
+                // T = the rows of M, Z [Q1 Q2] = the rows of Z: back into LDS for the solve and the next level
+                if (lane < m) {
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) Ms[lane * S + i] = mr[i];
+                }
+                if (lane < n) {
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) Zs[lane * S + i] = zr[i];
+                }
+                wave_sync();
+            } else {
+            if (lane < m) nrm2 = dot8(Ms + lane * S, Ms + lane * S, 0, f8);
             for (int j = 0; j < kmax; ++j) {
                 double neg = used ? 1.0 : -nrm2;
                 int pidx = lane;
@@ -423,6 +516,7 @@ __global__ void __launch_bounds__(64) osot_ehqp_qr_kernel(const DevEhqp Q) {
                 if (lane == 0) perm[j] = prow;
                 rho++;
                 wave_sync();
+            }
             }
             const int rho8 = (rho + 7) & ~7;
             ts[lane] = 0.0;
