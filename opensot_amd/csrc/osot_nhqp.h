@@ -41,9 +41,27 @@ struct DevNhqp {
 };
 
 constexpr int kNS = 33;              // LDS row stride of the 32-column work matrices
+#ifndef OSOT_QL_TOL
+#define OSOT_QL_TOL 1.0
+#endif
 
 // sum over the 32 lanes of a half AND over the two halves; every lane gets it
 __device__ __forceinline__ double sum64(double v) { return halfsum<32>(colsum<32>(v)); }
+
+// sum over i = h, h + 2, ... < 2 TRIPS of a[i sa] b[i sb]: a FIXED, fully unrolled trip count, so that the LDS reads of the
+// whole product are in flight together (a loop with a run-time trip count pays one LDS round trip, ~100 cycles, per
+// element).  Both arrays must be readable and ZERO beyond their logical length (the work matrices are zero-padded to 32).
+template <int TRIPS>
+__device__ __forceinline__ double dot_half(const double* a, int sa, const double* b, int sb, int h) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int t = 0; t < TRIPS; t += 2) {
+        const int i0 = 2 * t + h, i1 = 2 * (t + 1) + h;
+        s0 = fma(a[i0 * sa], b[i0 * sb], s0);
+        s1 = fma(a[i1 * sa], b[i1 * sb], s1);
+    }
+    return s0 + s1;
+}
 
 // Symmetric eigenproblem of K (k x k, LDS [32][33], zero beyond k) -> K[c][c] = eigenvalue c, E[:, c] = its eigenvector.
 // Householder tridiagonalisation with accumulation of the transformations, then the implicit QL iteration with shifts
@@ -128,7 +146,7 @@ __device__ inline void sym_eig32(double* K, double* E, int k, int c, int h) {
     //  neighbouring diagonal entries: the Gram matrices here are often rank deficient, and a cluster of round-off-level
     //  eigenvalues never passes a purely local test)
     const double anorm = colmax<32>((c < k) ? fabs(d) + fabs(e) : 0.0);
-    const double etol = kEps * anorm;
+    const double etol = OSOT_QL_TOL * kEps * anorm;
     for (int l = 0; l < k; ++l) {
         for (int iter = 0; iter < 60; ++iter) {
             const bool small = (c >= l && c < k - 1) && (fabs(e) <= etol);
@@ -227,29 +245,34 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
     // ---- AN = A N (stored rows: a row of A against the columns of N, i split over the halves; identity rows: rows of N)
     // (A goes through the Gram buffer, free until the Gram matrix is formed, 32 rows at a time with coalesced loads: read
     //  element by element inside the product it was a uniform-address HBM load per multiply-add)
+    double aq_row = 0.0;      // lane = stored row r: (A q0)_r
     for (int rb = 0; rb < ma; rb += 32) {
         const int nr = (ma - rb < 32) ? ma - rb : 32;
         wave_sync();
         for (int r = h; r < nr; r += 2) K[r * kNS + c] = (c < n) ? A[(rb + r) * n + c] : 0.0;
         wave_sync();
         for (int r = 0; r < nr; ++r) {
-            double acc = 0.0;
-            for (int i = h; i < n; i += 2) acc = fma(K[r * kNS + i], Nl[i * kNS + c], acc);
-            acc = halfsum<32>(acc);
+            const double acc = halfsum<32>(dot_half<16>(K + r * kNS, 1, Nl + c, kNS, h));
             if (h == 0 && c < nf) AN[(rb + r) * kNS + c] = acc;
+            // (A q0)_r for b0 = b - A q0, from the staged row (it was a loop of dependent HBM loads per row)
+            const double aq = halfsum<32>(dot_half<16>(K + r * kNS, 1, vec, 1, h));
+            if (lane == rb + r) aq_row = aq;
         }
     }
     wave_sync();
     for (int e = lane; e < 32 * kNS; e += 64) K[e] = 0.0;
     for (int r = ma + h; r < m; r += 2) if (c < nf) AN[r * kNS + c] = Nl[(r - ma) * kNS + c];
     // ---- b0 = b - A q0 (lane = row)
-    if (lane < m) {
-        double v = Q.b[inst * m + lane];
-        if (!first) {
-            if (lane < ma) { double acc = 0.0; for (int i = 0; i < n; ++i) acc = fma(A[lane * n + i], vec[i], acc); v -= acc; }
-            else v -= vec[lane - ma];
+    {
+        double v = 0.0;
+        if (lane < m) {
+            v = Q.b[inst * m + lane];
+            if (!first) {
+                if (lane < ma) v -= aq_row;
+                else v -= vec[lane - ma];
+            }
         }
-        b0[lane] = v;
+        b0[lane] = v;              // (zero beyond m: the fixed-trip products below read all 64 entries)
     }
     wave_sync();
     // ---- constraints in z-coordinates (levels below the first): rows [C N; N], bounds shifted by q0
@@ -286,14 +309,14 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
     if (rowside) {          // K[a][c] = <row a, row c> of AN
         for (int a = 0; a < m; ++a) {
             double acc = 0.0;
-            if (c < m) for (int t = h; t < nf; t += 2) acc = fma(AN[a * kNS + t], AN[c * kNS + t], acc);
+            if (c < m) acc = dot_half<16>(AN + a * kNS, 1, AN + c * kNS, 1, h);      // (A N is zero beyond column nf)
             acc = halfsum<32>(acc);
             if (h == 0 && c < m) K[a * kNS + c] = acc;
         }
     } else {                // K[a][c] = <column a, column c>
         for (int a = 0; a < nf; ++a) {
             double acc = 0.0;
-            if (c < nf) for (int r = h; r < m; r += 2) acc = fma(AN[r * kNS + a], AN[r * kNS + c], acc);
+            if (c < nf) acc = dot_half<MR / 2>(AN + a, kNS, AN + c, kNS, h);           // (... and beyond row m)
             acc = halfsum<32>(acc);
             if (h == 0 && c < nf) K[a * kNS + c] = acc;
         }
@@ -437,19 +460,40 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
     // ---- H = AN' W AN (+ sv_max V2 V2'), g = -AN' W b0   ->  HBM, nf x nf row-major
     {
         const double* w = Q.w ? Q.w + inst * m : nullptr;
-        if (lane < m) vec[lane] = w ? w[lane] : 1.0;
+        // (my column of W A N in registers, fixed trip counts: see dot_half)
+        vec[lane] = (lane < m) ? (w ? w[lane] : 1.0) : 0.0;
         wave_sync();
         double* Hg = Q.H + inst * (long long)nf * nf;
+        const int cc = (c < nf) ? c : 0;
+        double wan[MR / 2];                         // w_r (A N)[r][c] for r = 2 t + h
         double gacc = 0.0;
-        if (c < nf) for (int r = h; r < m; r += 2) gacc = fma(-vec[r] * AN[r * kNS + c], b0[r], gacc);
+#pragma unroll
+        for (int t = 0; t < MR / 2; ++t) {
+            const int r = 2 * t + h;
+            wan[t] = vec[r] * AN[r * kNS + cc];
+            gacc = fma(-wan[t], b0[r], gacc);       // (b0 beyond m: multiplied by w = 0)
+        }
         gacc = halfsum<32>(gacc);
         if (h == 0 && c < nf) Q.g[inst * nf + c] = gacc;
+        const bool sel = ns > 0 && Q.sel_reg;
+        double v2c[16];                             // my row of V2 (zero beyond ns)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v2c[t] = (sel && 2 * t + h < ns) ? sv_max * V2[cc * kNS + 2 * t + h] : 0.0;
         for (int i = 0; i < nf; ++i) {
-            double acc = 0.0;
-            if (c < nf) for (int r = h; r < m; r += 2) acc = fma(vec[r] * AN[r * kNS + i], AN[r * kNS + c], acc);
-            if (ns > 0 && Q.sel_reg && c < nf)
-                for (int t = h; t < ns; t += 2) acc = fma(sv_max * V2[i * kNS + t], V2[c * kNS + t], acc);
-            acc = halfsum<32>(acc);
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int t = 0; t < MR / 2; t += 2) {
+                a0 = fma(wan[t], AN[(2 * t + h) * kNS + i], a0);
+                a1 = fma(wan[t + 1], AN[(2 * (t + 1) + h) * kNS + i], a1);
+            }
+            if (sel) {
+#pragma unroll
+                for (int t = 0; t < 16; t += 2) {
+                    a0 = fma(v2c[t], (2 * t + h < ns) ? V2[i * kNS + 2 * t + h] : 0.0, a0);
+                    a1 = fma(v2c[t + 1], (2 * (t + 1) + h < ns) ? V2[i * kNS + 2 * (t + 1) + h] : 0.0, a1);
+                }
+            }
+            const double acc = halfsum<32>(a0 + a1);
             if (h == 0 && c < nf) Hg[i * nf + c] = acc;
         }
     }
