@@ -159,3 +159,27 @@ def test_nhqp_gpu(cfg, opts, oracle, gpu_device):
         st.solve(B); torch.cuda.synchronize()
         both = (status == 0) & (st.status[:B].cpu().numpy() == 0)
         assert both.mean() > 0.9 and np.abs(dq[both] - st.dq[:B].cpu().numpy()[both]).max() < 1e-6
+
+
+def test_symmetric_eigen_solver_emulated():
+    """sym_eig32 (Householder tridiagonalisation + implicit QL; round 3: the rotations of a sweep are recorded and applied to
+    the eigenvector rows after it) on its own, through the emulator: G V = V diag(lambda), V'V = I, eigenvalues against
+    numpy -- full rank, rank deficient (a duplicated row and column) and the sizes the front-ends meet (3, 5, 24, 32)"""
+    import ctypes as C
+    from helpers import emu_lib
+    L = emu_lib()
+    rng = np.random.default_rng(0)
+    for k in (2, 3, 5, 12, 24, 32):
+        for trial in range(3):
+            A = rng.normal(size=(k, k + 3 * (trial % 2)))
+            if trial == 2 and k > 3:
+                A[1] = A[0]                                   # rank deficient: a cluster of round-off-level eigenvalues
+            G = A @ A.T
+            K = np.zeros((32, 33)); K[:k, :k] = G
+            E = np.zeros((32, 33))
+            assert L.emu_sym_eig32(K.ctypes.data_as(C.c_void_p), E.ctypes.data_as(C.c_void_p), k) == 0
+            lam, V = np.diag(K)[:k], E[:k, :k]
+            scale = max(1.0, np.abs(G).max())
+            assert np.abs(G @ V - V * lam[None, :]).max() < 1e-13 * scale
+            assert np.abs(V.T @ V - np.eye(k)).max() < 1e-13
+            assert np.abs(np.sort(lam) - np.linalg.eigvalsh(G)).max() < 1e-13 * scale
