@@ -209,11 +209,11 @@ inline int make_dev_plan(const osot_plan_desc& p, const unsigned char* level_act
     P.reg_rows = p.has_regularisation ? p.regularisation.rows : 0;
     P.reg_w = p.has_regularisation ? p.regularisation.weight : 0.0;
     P.reg_dense = (p.has_regularisation && p.regularisation_dense) ? 1 : 0;
-    NP = (p.n <= 32) ? 32 : 64;
+    // 56: the 64-lane solver with the LDS of n <= 54, four wavefronts per CU instead of three (osot_qp_core.h, WaveCtx)
+    NP = (p.n <= 32) ? 32 : ((p.n <= WaveCtx<56>::NMAX) ? 56 : 64);
     // cascade layout: M1, M2, V | rlo, rup, rptr | rowstate, eqlist | rsrc bytes
-    const int S = NP + 1;
     const int cap = ((nrows_max > 0 ? nrows_max : 1) + 1) & ~1;
-    int total = (((NP == 32 ? WaveCtx<32>::M1_DOUBLES : WaveCtx<64>::M1_DOUBLES) + NP * S + 4 * NP) + 1) & ~1;
+    int total = ((NP == 32 ? WaveCtx<32>::LDS_DOUBLES : (NP == 56 ? WaveCtx<56>::LDS_DOUBLES : WaveCtx<64>::LDS_DOUBLES)) + 1) & ~1;
     P.lds_rows_off = total;
     P.lds_rows_cap = cap;
     const int table = 3 * cap + cap + (cap + 7) / 8;      // doubles of the row table
@@ -221,7 +221,7 @@ inline int make_dev_plan(const osot_plan_desc& p, const unsigned char* level_act
     // NP = 64 (round 3): the row table lives in a per-instance slice of device memory (DevBatch.rows_scratch, served by the
     // CU's L1 / L2) whenever taking it out of LDS buys another resident wavefront per CU
     P.rows_in_global = 0;
-    if (NP == 64) {
+    if (NP > 32) {
         const size_t with = (size_t)(total + table) * sizeof(double), without = (size_t)total * sizeof(double);
         if ((160 * 1024) / without > (160 * 1024) / with) P.rows_in_global = 1;
     }

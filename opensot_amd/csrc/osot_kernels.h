@@ -113,13 +113,14 @@ struct DevBatch {
 template <int NP, bool PROF, bool EXTRA>
 __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D, const long long inst, const int lane, char* osot_smem) {
     constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
+    constexpr int HB = (NP % 16 == 0) ? 16 : 8;   // rows of H per broadcast group of the register H build
     const int n = P.n;
     double* base = reinterpret_cast<double*>(osot_smem);
     WaveCtx<NP> w;
-    w.c = lane % NP; w.h = lane / NP; w.n = n;
+    w.c = WaveCtx<NP>::col_of(lane); w.h = WaveCtx<NP>::half_of(lane); w.n = n;
     w.M1 = base;
     w.M2 = base + WaveCtx<NP>::M1_DOUBLES;
-    w.V = w.M2 + NP * S;
+    w.V = w.M2 + WaveCtx<NP>::ROWS * S;
     w.rlo = P.rows_in_global ? D.rows_scratch + inst * P.rows_doubles : base + P.lds_rows_off;
     w.rup = w.rlo + P.lds_rows_cap;
     w.rptr = reinterpret_cast<unsigned long long*>(w.rup + P.lds_rows_cap);
@@ -130,7 +131,7 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
     const int c = w.c, h = w.h;
     const bool valid = c < n;
     // zero the matrices once: the padding beyond n stays zero for the whole kernel
-    for (int e = lane; e < WaveCtx<NP>::M1_DOUBLES + NP * S + 4 * NP; e += 64) base[e] = 0.0;
+    for (int e = lane; e < WaveCtx<NP>::LDS_DOUBLES; e += 64) base[e] = 0.0;
     wave_sync();
 
     const bool has_box = D.l != nullptr;
@@ -194,12 +195,12 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
         OSOT_PH_BEGIN();
         {   // re-derive the lane coordinates per level (see launder_i)
             const int l2 = launder_i(lane);
-            w.c = l2 % NP; w.h = l2 / NP;
+            w.c = WaveCtx<NP>::col_of(l2); w.h = WaveCtx<NP>::half_of(l2);
         }
         const int c = w.c, h = w.h;
         const bool valid = c < n;
         const int m = P.m[k], ma = P.ma[k];
-        int* hotk = D.hot ? D.hot + (inst * P.L + k) * NP : nullptr;
+        int* hotk = D.hot ? D.hot + (inst * P.L + k) * WaveCtx<NP>::LW : nullptr;
         const int hotcode = hotk ? hotk[c] : -1;   // (requested here: the answer is not needed before the inequality loop)
         const double* Ak = D.A[k] ? D.A[k] + inst * ma * n : nullptr;
         const double* bk = D.b[k] + inst * m;
@@ -379,19 +380,19 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
                 OSOT_SUB_END(PH_INV);     // (profiling slot reused: wait for the rows)
                 if (h == 0) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) w.V[u * NP + c] = a[u];
+                    for (int u = 0; u < 4; ++u) w.V[u * WaveCtx<NP>::LW + c] = a[u];
                 }
                 wave_sync();
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const double* Vu = w.V + u * NP + h;
+                    const double* Vu = w.V + u * WaveCtx<NP>::LW + h;
 #pragma unroll
-                    for (int i0 = 0; i0 < NP / HV; i0 += 16) {
-                        double vv[16];
+                    for (int i0 = 0; i0 < NP / HV; i0 += HB) {
+                        double vv[HB];
 #pragma unroll
-                        for (int t = 0; t < 16; ++t) vv[t] = Vu[(i0 + t) * HV];
+                        for (int t = 0; t < HB; ++t) vv[t] = Vu[(i0 + t) * HV];
 #pragma unroll
-                        for (int t = 0; t < 16; ++t) hacc[i0 + t] = fma(wa[u], vv[t], hacc[i0 + t]);
+                        for (int t = 0; t < HB; ++t) hacc[i0 + t] = fma(wa[u], vv[t], hacc[i0 + t]);
                     }
                 }
                 OSOT_SUB_END(PH_SUBST);   // (profiling slot reused: LDS broadcast + outer product)
@@ -412,19 +413,19 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
                     wave_sync();
                     if (h == 0) {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) w.V[u * NP + c] = a[u];
+                        for (int u = 0; u < 4; ++u) w.V[u * WaveCtx<NP>::LW + c] = a[u];
                     }
                     wave_sync();
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const double* Vu = w.V + u * NP + h;
+                        const double* Vu = w.V + u * WaveCtx<NP>::LW + h;
 #pragma unroll
-                        for (int i0 = 0; i0 < NP / HV; i0 += 16) {
-                            double vv[16];
+                        for (int i0 = 0; i0 < NP / HV; i0 += HB) {
+                            double vv[HB];
 #pragma unroll
-                            for (int t = 0; t < 16; ++t) vv[t] = Vu[(i0 + t) * HV];
+                            for (int t = 0; t < HB; ++t) vv[t] = Vu[(i0 + t) * HV];
 #pragma unroll
-                            for (int t = 0; t < 16; ++t) hacc[i0 + t] = fma(wa[u], vv[t], hacc[i0 + t]);
+                            for (int t = 0; t < HB; ++t) hacc[i0 + t] = fma(wa[u], vv[t], hacc[i0 + t]);
                         }
                     }
                 }
@@ -457,7 +458,7 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
         int iters = 0;
         OSOT_PH_END(PH_HBUILD);
         int st;
-        if (NP == 64) {   // must be inlined: hacc would otherwise be passed through scratch memory
+        if (NP > 32) {   // must be inlined: hacc would otherwise be passed through scratch memory
             OSOT_ALWAYS_INLINE_CALL st = gi_solve<NP, PROF>(w, nrows, g, diag_h, hdiag, hacc,
                                                                    has_box, lb, ub, P.max_iter, any, x, x, iters, prof, slack,
                                                                    false, 0.0, hotcode, hotk);
@@ -625,8 +626,8 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
     const int n = Q.n;
     double* base = reinterpret_cast<double*>(osot_smem);
     WaveCtx<NP> w;
-    w.c = lane % NP; w.h = lane / NP; w.n = n;
-    w.M1 = base; w.M2 = base + WaveCtx<NP>::M1_DOUBLES; w.V = w.M2 + NP * S;
+    w.c = WaveCtx<NP>::col_of(lane); w.h = WaveCtx<NP>::half_of(lane); w.n = n;
+    w.M1 = base; w.M2 = base + WaveCtx<NP>::M1_DOUBLES; w.V = w.M2 + WaveCtx<NP>::ROWS * S;
     w.rlo = base + Q.lds_rows_off;
     w.rup = w.rlo + Q.lds_rows_cap;
     w.rptr = reinterpret_cast<unsigned long long*>(w.rup + Q.lds_rows_cap);
@@ -636,7 +637,7 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
     w.rsrc = reinterpret_cast<signed char*>(w.eqlist + Q.lds_rows_cap);
     const int c = w.c, h = w.h;
     const bool valid = c < n;
-    for (int e = lane; e < WaveCtx<NP>::M1_DOUBLES + NP * S + 4 * NP; e += 64) base[e] = 0.0;
+    for (int e = lane; e < WaveCtx<NP>::LDS_DOUBLES; e += 64) base[e] = 0.0;
     wave_sync();
     constexpr int HV = WaveCtx<NP>::HV;
     double Hc[NP / HV];

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "osot_host_plan.h"
@@ -61,6 +62,14 @@ int ensure_lds(K kernel, size_t bytes) {
 }
 
 }  // namespace
+
+// calls f with the padded size of the cascade instantiation as a compile-time constant (make_dev_plan picks it: 32, 56 or 64)
+template <typename F>
+static inline auto by_np(int T, F&& f) {
+    if (T == 32) return f(std::integral_constant<int, 32>{});
+    if (T == 56) return f(std::integral_constant<int, 56>{});
+    return f(std::integral_constant<int, 64>{});
+}
 
 struct osot_solver {
     osot_plan_desc plan;
@@ -138,11 +147,15 @@ int osot_solver_create(const osot_plan_desc* plan, int max_batch, int device, os
     if (!guard.ok) return fail(OSOT_ERR_HIP, "hipSetDevice failed");
     DevPlan P; int T; size_t lds;
     make_dev_plan(*plan, nullptr, P, T, lds);
-    rc = (T == 32) ? ensure_lds(osot_cascade_kernel<32, false>, lds) : ensure_lds(osot_cascade_kernel<64, false>, lds);
-    if (rc == OSOT_OK) rc = (T == 32) ? ensure_lds(osot_cascade_kernel<32, true>, lds) : ensure_lds(osot_cascade_kernel<64, true>, lds);
-    if (rc == OSOT_OK) rc = (T == 32) ? ensure_lds(osot_cycle_kernel<32, false>, lds) : ensure_lds(osot_cycle_kernel<64, false>, lds);
-    if (rc == OSOT_OK) rc = (T == 32) ? ensure_lds(osot_cycle_kernel<32, true>, lds) : ensure_lds(osot_cycle_kernel<64, true>, lds);
-    if (rc == OSOT_OK) rc = (T == 32) ? ensure_lds(osot_cascade_kernel<32, false, true>, lds) : ensure_lds(osot_cascade_kernel<64, false, true>, lds);
+    rc = by_np(T, [&](auto np) {
+        constexpr int NP = decltype(np)::value;
+        int r = ensure_lds(osot_cascade_kernel<NP, false>, lds);
+        if (r == OSOT_OK) r = ensure_lds(osot_cascade_kernel<NP, true>, lds);
+        if (r == OSOT_OK) r = ensure_lds(osot_cycle_kernel<NP, false>, lds);
+        if (r == OSOT_OK) r = ensure_lds(osot_cycle_kernel<NP, true>, lds);
+        if (r == OSOT_OK) r = ensure_lds(osot_cascade_kernel<NP, false, true>, lds);
+        return r;
+    });
     if (rc != OSOT_OK) return rc;
     osot_solver* s = new osot_solver();
     s->plan = *plan;
@@ -152,9 +165,9 @@ int osot_solver_create(const osot_plan_desc* plan, int max_batch, int device, os
     std::memset(s->task_active, 1, sizeof(s->task_active));
     {   // resident workgroups: what the longest-first dispatch order is planned for (order_body)
         int per_cu = 0, cus = 0;
-        hipError_t e1 = (T == 32)
-            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, osot_cycle_kernel<32, false>, 64, lds)
-            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, osot_cycle_kernel<64, false>, 64, lds);
+        hipError_t e1 = by_np(T, [&](auto np) {
+            return hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, osot_cycle_kernel<decltype(np)::value, false>, 64, lds);
+        });
         hipError_t e2 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
         s->slots = (e1 == hipSuccess && e2 == hipSuccess && per_cu > 0 && cus > 0) ? per_cu * cus : 2048;
     }
@@ -214,7 +227,7 @@ int osot_solver_set_hotstart(osot_solver* s, int enabled) {
     if (enabled) {
         DevPlan P; int T; size_t lds;
         make_dev_plan(s->plan, nullptr, P, T, lds);
-        const size_t bytes = sizeof(int) * (size_t)s->max_batch * (size_t)s->plan.n_levels * (size_t)T;
+        const size_t bytes = sizeof(int) * (size_t)s->max_batch * (size_t)s->plan.n_levels * (size_t)(T <= 32 ? 32 : 64);   // (WaveCtx::LW entries per level)
         if (!s->d_hot) {
             if (hipMalloc(&s->d_hot, bytes) != hipSuccess) { s->d_hot = nullptr; return fail(OSOT_ERR_HIP, "device allocation for the hot-start state failed"); }
             s->hot_T = T;
@@ -451,24 +464,20 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
     for (int k = 0; k < pl.n_levels; ++k) extra = extra || (s->h_uplan.dense_level[k] != 0);
     if (prof && !fused && extra)   // (the instrumented instantiation carries no dense-weight / inactive-task code: it would
         return fail(OSOT_ERR_UNSUPPORTED, "phase profiling is not available for plans with dense weights or inactive tasks");   // solve another problem)
-    if (fused) {
-        if (T == 32) {
-            if (extra) hipLaunchKernelGGL((osot_cycle_kernel<32, true>), dim3(grid), dim3(64), lds, st, *fused, P, D);
-            else hipLaunchKernelGGL((osot_cycle_kernel<32, false>), dim3(grid), dim3(64), lds, st, *fused, P, D);
+    by_np(T, [&](auto np) {
+        constexpr int NP = decltype(np)::value;
+        if (fused) {
+            if (extra) hipLaunchKernelGGL((osot_cycle_kernel<NP, true>), dim3(grid), dim3(64), lds, st, *fused, P, D);
+            else hipLaunchKernelGGL((osot_cycle_kernel<NP, false>), dim3(grid), dim3(64), lds, st, *fused, P, D);
+        } else if (extra && !prof) {
+            hipLaunchKernelGGL((osot_cascade_kernel<NP, false, true>), dim3(grid), dim3(64), lds, st, P, D);
+        } else if (prof) {
+            hipLaunchKernelGGL((osot_cascade_kernel<NP, true>), dim3(grid), dim3(64), lds, st, P, D);
         } else {
-            if (extra) hipLaunchKernelGGL((osot_cycle_kernel<64, true>), dim3(grid), dim3(64), lds, st, *fused, P, D);
-            else hipLaunchKernelGGL((osot_cycle_kernel<64, false>), dim3(grid), dim3(64), lds, st, *fused, P, D);
+            hipLaunchKernelGGL((osot_cascade_kernel<NP, false>), dim3(grid), dim3(64), lds, st, P, D);
         }
-    } else if (extra && !prof) {
-        if (T == 32) hipLaunchKernelGGL((osot_cascade_kernel<32, false, true>), dim3(grid), dim3(64), lds, st, P, D);
-        else hipLaunchKernelGGL((osot_cascade_kernel<64, false, true>), dim3(grid), dim3(64), lds, st, P, D);
-    } else if (prof) {
-        if (T == 32) hipLaunchKernelGGL((osot_cascade_kernel<32, true>), dim3(grid), dim3(64), lds, st, P, D);
-        else hipLaunchKernelGGL((osot_cascade_kernel<64, true>), dim3(grid), dim3(64), lds, st, P, D);
-    } else {
-        if (T == 32) hipLaunchKernelGGL((osot_cascade_kernel<32, false>), dim3(grid), dim3(64), lds, st, P, D);
-        else hipLaunchKernelGGL((osot_cascade_kernel<64, false>), dim3(grid), dim3(64), lds, st, P, D);
-    }
+        return 0;
+    });
     HIP_TRY(hipGetLastError());
     if (timed) {
         HIP_TRY(hipEventRecord(ev.second, st));

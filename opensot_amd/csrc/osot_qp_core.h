@@ -89,14 +89,27 @@ __device__ __forceinline__ int ridx(int i, int j) { return ((j * (j + 3)) >> 1) 
 __device__ __forceinline__ int lidx(int i, int j) { return ((i * (i + 1)) >> 1) + j; }
 template <int NP>
 struct WaveCtx {
-    static constexpr int HV = 64 / NP;
+    // NP = padded problem size: 32 (two lanes per column), 64, or 56 -- the 64-lane solver with its LDS cut to what n <= 54
+    // needs, so that FOUR wavefronts (one per SIMD) fit the CU's 160 KB instead of three.  There the lanes 56 .. 63 all take
+    // the column index 56: a phantom all-zero column that lives in the padding element of every row (S = 57) and in one
+    // phantom row of M2, so every address formed from c stays in bounds, every value those lanes hold is the zero a
+    // padded column holds anyway, and no reduction has to know about them.  "Lane = row" loops use the physical lane.
+    static constexpr int LW = (NP <= 32) ? 32 : 64;        // lanes per half
+    static constexpr int HV = 64 / LW;
     static constexpr int S = NP + 1;
-    static constexpr int M1_DOUBLES = NP * (NP + 3) / 2;   // packed R: 560 doubles for NP = 32, 2144 for NP = 64 (the packed L of factor_rows64, 2080, fits too)
+    static constexpr int ROWS = (NP == 56) ? NP + 1 : NP;  // rows of M2 that exist
+    static constexpr int NMAX = (NP == 56) ? 54 : NP;      // largest n of this instantiation
+    // packed R: 560 doubles for NP = 32, 2144 for NP = 64 (the packed L of factor_rows64, 2080, fits too); NP = 56: the packed
+    // L of the 56 padded rows, 1596 (R of n <= 54 columns needs 1539)
+    static constexpr int M1_DOUBLES = (NP == 56) ? (56 * 57) / 2 : NP * (NP + 3) / 2;
+    static constexpr int LDS_DOUBLES = M1_DOUBLES + ROWS * S + 4 * LW;   // M1, M2, V (four staging vectors of LW)
+    __device__ static __forceinline__ int col_of(int lane) { return (NP == 56) ? ((lane < 56) ? lane : 56) : lane % NP; }
+    __device__ static __forceinline__ int half_of(int lane) { return (NP == 56) ? 0 : lane / NP; }
     int c, h;       // column index and half of this lane
     int n;
     double* M1;
     double* M2;
-    double* V;      // 4*NP
+    double* V;      // 4*LW
     // general-row table of the current QP, built in LDS by the calling kernel (one entry per row):
     double* rlo;                  // lower bound (already clamped to +-1e20)
     double* rup;                  // upper bound
@@ -134,7 +147,7 @@ __device__ __forceinline__ double jt_rows_dot(const WaveCtx<NP>& w, const double
 #ifndef OSOT_DOT_CH
 #define OSOT_DOT_CH 16
 #endif
-    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = OSOT_DOT_CH;
+    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = (NP % 16 == 0) ? OSOT_DOT_CH : 8;
     const double* row = w.M2 + w.c * S + w.h;
     const double* v = vec + w.h;
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
@@ -156,7 +169,7 @@ __device__ __forceinline__ double jt_rows_dot(const WaveCtx<NP>& w, const double
 // z_c = sum_j JT[j][c] * vec[j]   (column walk, j split over the halves)
 template <int NP>
 __device__ __forceinline__ double jt_cols_dot(const WaveCtx<NP>& w, const double* vec) {
-    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = OSOT_DOT_CH;
+    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = (NP % 16 == 0) ? OSOT_DOT_CH : 8;
     const double* col = w.M2 + w.h * S + w.c;
     const double* v = vec + w.h;
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
@@ -179,10 +192,11 @@ __device__ __forceinline__ double jt_cols_dot(const WaveCtx<NP>& w, const double
 // the same product when vec is known to vanish below row j0 (z = J2 d2 with a large working set), NP = 64: only
 // the rows from j0 rounded down to a multiple of sixteen are read (measured: -3 % on the 50-variable stack; for
 // NP = 32 the fixed, fully unrolled walk above is faster)
-__device__ __forceinline__ double jt_cols_dot_tail64(const WaveCtx<64>& w, const double* vec, int j0) {
-    constexpr int S = WaveCtx<64>::S, RT = 16;
+template <int NP>
+__device__ __forceinline__ double jt_cols_dot_tail64(const WaveCtx<NP>& w, const double* vec, int j0) {
+    constexpr int S = WaveCtx<NP>::S, RT = (NP % 16 == 0) ? 16 : 8;
     double acc0 = 0.0, acc1 = 0.0;
-    for (int jj = j0 & ~(RT - 1); jj < 64; jj += RT) {
+    for (int jj = j0 & ~(RT - 1); jj < NP; jj += RT) {
         const double* col = w.M2 + jj * S + w.c;
         const double* v = vec + jj;
         double a[RT], b[RT];
@@ -203,7 +217,7 @@ __device__ __forceinline__ void householder_add(const WaveCtx<NP>& w, double d, 
                                                 double nd2, int iq) {
     constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
     const int c = w.c, h = w.h, n = w.n;
-    double* V2 = w.V + 2 * NP;
+    double* V2 = w.V + 2 * WaveCtx<NP>::LW;
     const double d_iq = bcast(d, iq);
     double nrm, rnrm;
     fast_sqrt_rsqrt(nd2, nrm, rnrm);
@@ -218,7 +232,7 @@ __device__ __forceinline__ void householder_add(const WaveCtx<NP>& w, double d, 
     // only loads in flight hide the LDS latency there, and it has the registers for 16).  The start is rounded
     // DOWN to a multiple of the trip size: the extra rows j < iq have V2[j] = 0 (exact no-op) and every access
     // stays inside the NP rows of M2, so the loop needs no predicates and its LDS reads overlap.
-    constexpr int RT = (NP == 64) ? 16 : 4;
+    constexpr int RT = (NP == 64) ? 16 : ((NP == 56) ? 8 : 4);
     constexpr int TRIP = RT * HV;
     for (int jj = iq & ~(TRIP - 1); jj < n; jj += TRIP) {
         double* mrow = w.M2 + (jj + h) * S + c;
@@ -429,9 +443,9 @@ __device__ inline int factor_tiles32(const WaveCtx<32>& w, double (&Hf)[16], dou
 // The row bases are laundered: ds_read2_b64 only has an 8-bit offset field, so without it every pair of reads
 // gets its own constant address, and loop-invariant code motion parks ~900 of them in (spilled) SGPRs.
 // In : Hc[i] = (H + eps I)[i][c] (lane c owns column c = row c), g.  Out: M1 = L, M2 = JT = L^-1, x = -(H + eps I)^-1 g.  MUST be inlined (Hc would otherwise travel through scratch by reference).
-template <bool FULL>
-__device__ __forceinline__ int factor_rows64(const WaveCtx<64>& w, double (&Hc)[64], double g, double& x_out) {
-    constexpr int NP = 64, S = WaveCtx<64>::S;
+template <int NP, bool FULL>
+__device__ __forceinline__ int factor_rows64(const WaveCtx<NP>& w, double (&Hc)[NP], double g, double& x_out) {
+    constexpr int S = WaveCtx<NP>::S;   // (NP = 64 or 56; the phantom lanes of NP = 56 hold zeros and store nothing into M1)
     const int c = w.c, n = w.n;
     const bool valid = FULL || (c < n);
     double* M1 = w.M1;
@@ -450,7 +464,7 @@ __device__ __forceinline__ int factor_rows64(const WaveCtx<64>& w, double (&Hc)[
                 double acc[4] = {Hc[j], 0.0, 0.0, 0.0};
                 const double* rowj = M1 + launder_i(lidx(j, 0));   // opaque base: see the note on LDS addresses
 #pragma unroll
-                for (int q = 0; q < NP / 16; ++q) {
+                for (int q = 0; q < (NP + 15) / 16; ++q) {
                     if (16 * q < j) {
                         double lj[16];
 #pragma unroll
@@ -466,7 +480,7 @@ __device__ __forceinline__ int factor_rows64(const WaveCtx<64>& w, double (&Hc)[
                 fast_sqrt_rsqrt(piv, sq, rs);
                 const double lcj = (c == j) ? sq : ((c > j) ? sres * rs : 0.0);
                 Hc[j] = lcj;
-                if (c >= j) M1[lidx(c, j)] = lcj;   // (packed: the zeros above the diagonal are not stored)
+                if (c >= j && c < NP) M1[lidx(c, j)] = lcj;   // (packed: the zeros above the diagonal are not stored)
                 if (c == j) invd = rs;
                 const double yj = bcast(rhs, j) * rs;                       // forward substitution
                 rhs = (c == j) ? yj : fma(-lcj, yj, rhs);
@@ -490,7 +504,7 @@ __device__ __forceinline__ int factor_rows64(const WaveCtx<64>& w, double (&Hc)[
                     double acc[4] = {(i == c) ? 1.0 : 0.0, 0.0, 0.0, 0.0};
                     const double* rowi = M1 + launder_i(lidx(i, 0));
 #pragma unroll
-                    for (int q = 0; q < NP / 16; ++q) {
+                    for (int q = 0; q < (NP + 15) / 16; ++q) {
                         if (16 * q < i) {
                             double li[16];
 #pragma unroll
@@ -964,7 +978,7 @@ __device__ inline void lowrank_prepare32(const WaveCtx<32>& w, const double* Ak,
 // Pre (general H):  Hc[ii] = (H + eps I)[HV*ii+h][c] in registers (NP = 64, factor_rows64) or the accumulator tiles (NP = 32, factor_tiles32), M1 is scratch.
 template <int NP, bool PROF>
 __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_h,
-                        double hdiag, double (&Hc)[NP / (64 / NP)], bool has_box, double& lb, double& ub, int max_iter,
+                        double hdiag, double (&Hc)[NP / WaveCtx<NP>::HV], bool has_box, double& lb, double& ub, int max_iter,
                         bool have_prev, double xprev, double& x_out, int& iters_out, long long* prof,
                         double& slack_out, bool prepared = false, double xprep = 0.0, int hotcode = -1, int* hot_out = nullptr) {
     constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
@@ -972,14 +986,14 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
     double* M1 = w_in.M1;
     double* M2 = w_in.M2;
     double* V0 = w_in.V;
-    double* V1 = w_in.V + NP;
+    double* V1 = w_in.V + WaveCtx<NP>::LW;
     lb = clamp_inf(lb);
     ub = clamp_inf(ub);
     double x;
     OSOT_PH_BEGIN();
     {   // ---------------- factorisation phase (own scope: see the launder_i note below) ----------------
     WaveCtx<NP> w1 = w_in;
-    { const int l1 = launder_i(w_in.c + NP * w_in.h); w1.c = l1 % NP; w1.h = l1 / NP; }
+    { const int l1 = launder_i(phys_lane()); w1.c = WaveCtx<NP>::col_of(l1); w1.h = WaveCtx<NP>::half_of(l1); }
     const WaveCtx<NP>& w = w1;
     const int c = w.c, h = w.h;
     const bool valid = c < n;
@@ -994,7 +1008,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
         if (colsum<NP>(okd ? 0.0 : 1.0) != 0.0) { x_out = 0.0; iters_out = 0; return QP_NOT_PD; }
         double sq = 1.0, rs = 1.0;
         if (valid) fast_sqrt_rsqrt(hdiag, sq, rs);
-        for (int e = c + NP * h; e < NP * S; e += 64) M2[e] = 0.0;
+        for (int e = phys_lane(); e < WaveCtx<NP>::ROWS * S; e += 64) M2[e] = 0.0;
         wave_sync();
         if (h == 0 && valid) M2[c * S + c] = rs;
         x = valid ? -g * rs * rs : 0.0;
@@ -1002,7 +1016,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
         OSOT_PH_END(PH_CHOL);
     } else {
         int stf;
-        if constexpr (NP == 64) stf = factor_rows64<false>(w, Hc, g, x);
+        if constexpr (NP > 32) stf = factor_rows64<NP, false>(w, Hc, g, x);
         else stf = factor_tiles32(w, Hc, g, x);
         if (stf != QP_SOLVED) { x_out = 0.0; iters_out = 0; return stf; }
         OSOT_PH_END(PH_CHOL);
@@ -1014,7 +1028,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
     }   // end of the factorisation phase
     // (the lane coordinates are re-derived here so that nothing computed for the factorisation stays live)
     WaveCtx<NP> w2 = w_in;
-    { const int l2 = launder_i(w_in.c + NP * w_in.h); w2.c = l2 % NP; w2.h = l2 / NP; }
+    { const int l2 = launder_i(phys_lane()); w2.c = WaveCtx<NP>::col_of(l2); w2.h = WaveCtx<NP>::half_of(l2); }
     const WaveCtx<NP>& w = w2;
     const int c = w.c, h = w.h;
     const bool valid = c < n;
@@ -1029,7 +1043,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
     int n_eq = 0;
     bool local_eq = false;   // an equality among the level's task-local rows: x_prev does not satisfy it
     for (int r0 = 0; r0 < nrows; r0 += 64) {
-        const int r = r0 + c + NP * h;
+        const int r = r0 + phys_lane();
         bool is_eq = false, is_loc = false;
         if (r < nrows) {
             const double lo = w.rlo[r], up = w.rup[r];
@@ -1099,7 +1113,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
 
     // ---- inequality loop -----------------------------------------------------------------------------
     WaveCtx<NP> w3 = w_in;
-    { const int l3 = launder_i(w_in.c + NP * w_in.h); w3.c = l3 % NP; w3.h = l3 / NP; }
+    { const int l3 = launder_i(phys_lane()); w3.c = WaveCtx<NP>::col_of(l3); w3.h = WaveCtx<NP>::half_of(l3); }
     // after the null-space path the equality rows of J are zero, so |J'n|^2 no longer measures n'H^-1 n;
     // the diagonal of H^-1 does (hinv > 0 selects that in the dependency test)
     const double hinv = (used_nullspace && valid) ? fast_rcp(hdiag) : 0.0;
@@ -1118,7 +1132,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
     double* M1 = w.M1;
     double* M2 = w.M2;
     double* V0 = w.V;
-    double* V1 = w.V + NP;
+    double* V1 = w.V + WaveCtx<NP>::LW;
     int box_state = 0;   // lane c: 0 free, 1 lower bound active, 2 upper bound active
     OSOT_PH_BEGIN();
     // the stored rows that can ever be violated (not equalities, at least one finite bound), in row order;
@@ -1126,7 +1140,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
     int n_gen = 0;
     bool any_unit = false;   // is there a unit row that can ever be violated?  (none: its pass is skipped)
     for (int r0 = 0; r0 < nrows; r0 += 64) {
-        const int r = r0 + c + NP * h;
+        const int r = r0 + phys_lane();
         bool is_gen = false, is_unit = false;
         if (r < nrows) {
             const double lo = w.rlo[r], up = w.rup[r];
@@ -1225,7 +1239,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
             wave_sync();
         }
         if (any_unit) {
-            const int lane = c + NP * h;
+            const int lane = phys_lane();
             for (int r0 = 0; r0 < nrows; r0 += 64) {
                 const int r = r0 + lane;
                 if (r < nrows) {
@@ -1258,7 +1272,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
         // x (no cross-lane reduction at all).  Consecutive elements of a row share a cache line, so after the
         // first touch the walk is served from the CU's vector L1.
         for (int g0 = 0; g0 < n_gen; g0 += 64) {
-            const int gi = g0 + c + NP * h;
+            const int gi = g0 + phys_lane();
             if (gi < n_gen) {
                 const int r = w.eqlist[gi];
                 const auto* row = OSOT_GLOBAL_F64(w.rptr[r]);
@@ -1314,7 +1328,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
         if (margin_pass) { margin_pass = false; wave_sync(); continue; }   // bounds moved: now the real scan
         // all 64 lanes when the unit-row / stored-row passes ran (they hold different rows in the two halves);
         // box candidates alone are replicated over the halves, so the 32-lane network does
-        if (any_unit || n_gen > 0 || NP == 64) colargmin<64>(cand, code);
+        if (any_unit || n_gen > 0 || NP > 32) colargmin<64>(cand, code);
         else colargmin<NP>(cand, code);
         code = uniform_i(code);
         OSOT_SUB_END(PH_IN_SCAN);
@@ -1370,7 +1384,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
             if (h == 0) V1[c] = d2;
             wave_sync();
             double z;
-            if constexpr (NP == 64) z = (iq >= 16) ? jt_cols_dot_tail64(w, V1, iq) : jt_cols_dot<NP>(w, V1);   // d2 = 0 below iq
+            if constexpr (NP > 32) z = (iq >= 16) ? jt_cols_dot_tail64<NP>(w, V1, iq) : jt_cols_dot<NP>(w, V1);   // d2 = 0 below iq
             else z = jt_cols_dot<NP>(w, V1);
             OSOT_SUB_END(PH_IN_Z);
             // r = R^-1 d1 restricted to the inequality part [me, iq): dual step direction.  The reciprocals of
@@ -1488,7 +1502,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
     if (hot_out) {   // the inequality part of the working set, compacted to the front, for the next solve of this instance
         const bool act = (status == QP_SOLVED) && c >= me && c < iq;
         const int slot = (c >= me) ? c - me : c + NP - me;
-        if (h == 0) hot_out[slot] = act ? Aq : -1;
+        if (h == 0 && c < NP) hot_out[slot] = act ? Aq : -1;
     }
     x_out = x;
     iters_out = iters;

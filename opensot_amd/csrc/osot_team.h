@@ -59,6 +59,9 @@ __device__ __forceinline__ int launder_s(int v) { asm volatile("" : "+s"(v)); re
 
 __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// this lane's position in the wavefront ("lane = row" loops; not the column index c of osot_qp_core.h's WaveCtx)
+__device__ __forceinline__ int phys_lane() { return (int)(threadIdx.x & 63u); }
+
 // 64-bit mask of the lanes whose predicate is true, and the number of true lanes below this one
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __ballot(p ? 1 : 0); }
 __device__ __forceinline__ int lanes_below(unsigned long long mask) {
@@ -191,7 +194,7 @@ __device__ __forceinline__ double colsum(double v) {
     double a, b;
     swap16_pair(v, a, b);
     v = a + b;                       // 32 lanes of a half
-    if (NP == 64) { swap32_pair(v, a, b); v = a + b; }
+    if (NP > 32) { swap32_pair(v, a, b); v = a + b; }
     return v;
 }
 // maximum over the NP columns (lanes with equal h); every lane gets it
@@ -204,7 +207,7 @@ __device__ __forceinline__ double colmax(double v) {
     double a, b;
     swap16_pair(v, a, b);
     v = max_raw(a, b);
-    if (NP == 64) { swap32_pair(v, a, b); v = max_raw(a, b); }
+    if (NP > 32) { swap32_pair(v, a, b); v = max_raw(a, b); }
     return v;
 }
 // (inputs >= 0 or -0: non-negative floats order like unsigned integers, and v_max_u32 takes its DPP operand directly)
@@ -218,7 +221,7 @@ __device__ __forceinline__ float colmax_f32(float v) {
     int a, b;
     swap16_pair_i((int)u, a, b);
     u = umax((unsigned)a, (unsigned)b);
-    if (NP == 64) { swap32_pair_i((int)u, a, b); u = umax((unsigned)a, (unsigned)b); }
+    if (NP > 32) { swap32_pair_i((int)u, a, b); u = umax((unsigned)a, (unsigned)b); }
     return __uint_as_float(u);
 }
 __device__ __forceinline__ int first_lane_equal_f32(float v, float m) {
@@ -234,7 +237,7 @@ __device__ __forceinline__ int first_lane_equal(double v, double m) {
 // halves exchange their totals (NP = 32; plain two reductions for NP = 64)
 template <int NP>
 __device__ __forceinline__ void colsum2(double va, double vb, double& ra, double& rb) {
-    if (NP == 64) { ra = colsum<64>(va); rb = colsum<64>(vb); return; }
+    if (NP > 32) { ra = colsum<64>(va); rb = colsum<64>(vb); return; }
     double v = (threadIdx.x >= 32) ? vb : va;
     v = row16_sum(v);
     double a, b;
@@ -245,7 +248,7 @@ __device__ __forceinline__ void colsum2(double va, double vb, double& ra, double
 // v(c,0) + v(c,1): combines the partial results of the two halves (identity for NP = 64)
 template <int NP>
 __device__ __forceinline__ double halfsum(double v) {
-    if (NP == 64) return v;
+    if (NP > 32) return v;
     double a, b;
     swap32_pair(v, a, b);
     return a + b;
@@ -254,7 +257,7 @@ __device__ __forceinline__ double halfsum(double v) {
 // value held by lane (c, hsel) delivered to both halves (hsel is wave-uniform; identity for NP = 64)
 template <int NP>
 __device__ __forceinline__ double from_half(double v, int hsel) {
-    if (NP == 64) return v;
+    if (NP > 32) return v;
     double a, b;
     swap32_pair(v, a, b);
     return hsel ? b : a;
@@ -273,7 +276,7 @@ __device__ __forceinline__ double colmin(double v) {
     double a, b;
     swap16_pair(v, a, b);
     v = min_raw(a, b);
-    if (NP == 64) { swap32_pair(v, a, b); v = min_raw(a, b); }
+    if (NP > 32) { swap32_pair(v, a, b); v = min_raw(a, b); }
     return v;
 }
 template <int NP>
@@ -285,7 +288,7 @@ __device__ __forceinline__ int colmin_i(int v) {
     int a, b;
     swap16_pair_i(v, a, b);
     v = min(a, b);
-    if (NP == 64) { swap32_pair_i(v, a, b); v = min(a, b); }
+    if (NP > 32) { swap32_pair_i(v, a, b); v = min(a, b); }
     return v;
 }
 // NP = 32: BOTH HALVES MUST HOLD THE SAME CANDIDATES (they do wherever the solver reduces over 32 columns: vectors are
@@ -295,7 +298,7 @@ template <int NP>
 __device__ __forceinline__ void colargmin(double& v, int& p) {
     const double m = colmin<NP>(v);
     unsigned long long tie = wave_ballot(v == m);
-    if (NP == 32) tie &= 0xffffffffull;
+    if (NP <= 32) tie &= 0xffffffffull;
     if (__builtin_popcountll(tie) == 1) p = __builtin_amdgcn_readlane(p, __builtin_ctzll(tie));
     else p = colmin_i<NP>((v == m) ? p : 0x7fffffff);
     v = m;
@@ -312,9 +315,9 @@ __device__ __forceinline__ float bcast_f32(float v, int lane) { return __int_as_
 
 // value of lane c+1 of the same half (lane NP-1 keeps its own): used to shift the working-set bookkeeping
 template <int NP>
-__device__ __forceinline__ double shift_down(double v) { return __shfl_down(v, 1, NP); }
+__device__ __forceinline__ double shift_down(double v) { return __shfl_down(v, 1, NP <= 32 ? 32 : 64); }
 template <int NP>
-__device__ __forceinline__ int shift_down_i(int v) { return __shfl_down(v, 1, NP); }
+__device__ __forceinline__ int shift_down_i(int v) { return __shfl_down(v, 1, NP <= 32 ? 32 : 64); }
 
 // ---- fp64 reciprocal / square root without the IEEE corner-case sequences -----------------------------
 // v_rcp_f64 / v_rsq_f64 seeds + Newton steps: ~1 ulp for normal arguments, far cheaper than the compiler's

@@ -38,6 +38,7 @@ extern "C" __attribute__((visibility("default"))) int emu_ihqp_solve(const osot_
     const unsigned grid = (unsigned)b->B;
     // (the emulation always runs the instantiation with the dense-weight / inactive-task code: it is a superset)
     if (T == 32) emu::launch(osot_cascade_kernel<32, false, true>, grid, lds, 64, P, D);
+    else if (T == 56) emu::launch(osot_cascade_kernel<56, false, true>, grid, lds, 64, P, D);
     else emu::launch(osot_cascade_kernel<64, false, true>, grid, lds, 64, P, D);
     return OSOT_OK;
 }

@@ -22,6 +22,9 @@
 
 namespace osot {
 inline int emu_lane() { return emu::S().cur; }
+inline int phys_lane() { return emu_lane(); }
+// lanes per half of a padded size (32 -> 32; 56 and 64 -> 64: see WaveCtx in osot_qp_core.h)
+constexpr int LWOF(int np) { return np <= 32 ? 32 : 64; }
 inline void wave_sync() { int z = 0, out[64]; emu::allgather(&z, out, sizeof(int)); }
 inline void sched_fence() {}
 inline void workgroup_fence() {}
@@ -86,30 +89,30 @@ inline unsigned bcast_u32(unsigned v, int lane) { unsigned all[64]; emu::allgath
 inline unsigned uniform_u32(unsigned v) { return bcast_u32(v, 0); }
 template <int NP> inline double colsum(double v) {
     double all[64]; emu::allgather(&v, all, sizeof(double));
-    const int h0 = (emu_lane() / NP) * NP;
+    const int h0 = (emu_lane() / LWOF(NP)) * LWOF(NP);
     double s = 0.0;
-    for (int i = 0; i < NP; ++i) s += all[h0 + i];
+    for (int i = 0; i < LWOF(NP); ++i) s += all[h0 + i];
     return s;
 }
 template <int NP> inline double colmax(double v) {
     double all[64]; emu::allgather(&v, all, sizeof(double));
-    const int h0 = (emu_lane() / NP) * NP;
+    const int h0 = (emu_lane() / LWOF(NP)) * LWOF(NP);
     double m = all[h0];
-    for (int i = 1; i < NP; ++i) m = std::fmax(m, all[h0 + i]);
+    for (int i = 1; i < LWOF(NP); ++i) m = std::fmax(m, all[h0 + i]);
     return m;
 }
 template <int NP> inline double colmin(double v) {
     double all[64]; emu::allgather(&v, all, sizeof(double));
-    const int h0 = (emu_lane() / NP) * NP;
+    const int h0 = (emu_lane() / LWOF(NP)) * LWOF(NP);
     double m = all[h0];
-    for (int i = 1; i < NP; ++i) m = std::fmin(m, all[h0 + i]);
+    for (int i = 1; i < LWOF(NP); ++i) m = std::fmin(m, all[h0 + i]);
     return m;
 }
 template <int NP> inline float colmax_f32(float v) {
     float all[64]; emu::allgather(&v, all, sizeof(float));
-    const int h0 = (emu_lane() / NP) * NP;
+    const int h0 = (emu_lane() / LWOF(NP)) * LWOF(NP);
     float m = all[h0];
-    for (int i = 1; i < NP; ++i) m = std::fmax(m, all[h0 + i]);
+    for (int i = 1; i < LWOF(NP); ++i) m = std::fmax(m, all[h0 + i]);
     return m;
 }
 inline int first_lane_equal_f32(float v, float m) {
@@ -125,21 +128,21 @@ template <int NP> inline void colsum2(double va, double vb, double& ra, double& 
 }
 template <int NP> inline double halfsum(double v) {
     double all[64]; emu::allgather(&v, all, sizeof(double));
-    if (NP == 64) return v;
-    const int c = emu_lane() % NP;
-    return all[c] + all[c + NP];
+    if (NP > 32) return v;
+    const int c = emu_lane() % LWOF(NP);
+    return all[c] + all[c + LWOF(NP)];
 }
 template <int NP> inline double from_half(double v, int hsel) {
     double all[64]; emu::allgather(&v, all, sizeof(double));
-    if (NP == 64) return v;
-    return all[emu_lane() % NP + NP * hsel];
+    if (NP > 32) return v;
+    return all[emu_lane() % LWOF(NP) + LWOF(NP) * hsel];
 }
 template <int NP> inline void colargmin(double& v, int& p) {
     double av[64]; int ap[64];
     emu::allgather(&v, av, sizeof(double)); emu::allgather(&p, ap, sizeof(int));
-    const int h0 = (emu_lane() / NP) * NP;
+    const int h0 = (emu_lane() / LWOF(NP)) * LWOF(NP);
     double bv = av[h0]; int bp = ap[h0];
-    for (int i = 1; i < NP; ++i)
+    for (int i = 1; i < LWOF(NP); ++i)
         if (av[h0 + i] < bv || (av[h0 + i] == bv && ap[h0 + i] < bp)) { bv = av[h0 + i]; bp = ap[h0 + i]; }
     v = bv; p = bp;
 }
@@ -148,13 +151,13 @@ inline float bcast_f32(float v, int lane) { float all[64]; emu::allgather(&v, al
 inline int bcast_i(int v, int lane) { int all[64]; emu::allgather(&v, all, sizeof(int)); return all[lane]; }
 template <int NP> inline double shift_down(double v) {
     double all[64]; emu::allgather(&v, all, sizeof(double));
-    const int l = emu_lane(), c = l % NP;
-    return (c + 1 < NP) ? all[l + 1] : all[l];
+    const int l = emu_lane(), c = l % LWOF(NP);
+    return (c + 1 < LWOF(NP)) ? all[l + 1] : all[l];
 }
 template <int NP> inline int shift_down_i(int v) {
     int all[64]; emu::allgather(&v, all, sizeof(int));
-    const int l = emu_lane(), c = l % NP;
-    return (c + 1 < NP) ? all[l + 1] : all[l];
+    const int l = emu_lane(), c = l % LWOF(NP);
+    return (c + 1 < LWOF(NP)) ? all[l + 1] : all[l];
 }
 #ifndef OSOT_EMU_HW_ROUNDING
 inline double fast_rcp(double x) { return 1.0 / x; }

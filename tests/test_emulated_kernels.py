@@ -150,10 +150,13 @@ def test_inverse_dynamics_stack_properties(oracle):
     assert np.abs(dq - ref["dq"]).max() < 1e-8
 
 
-@pytest.mark.parametrize("n,rows,n_eq,n_ineq", [(7, [6], 0, 0), (7, [3, 3], 1, 2), (20, [5, 6], 4, 6), (31, [10, 12], 3, 0)])
+@pytest.mark.parametrize("n,rows,n_eq,n_ineq", [(7, [6], 0, 0), (7, [3, 3], 1, 2), (20, [5, 6], 4, 6), (31, [10, 12], 3, 0),
+                                                (33, [8, 10], 2, 4), (48, [12, 16], 3, 6), (54, [12, 20], 4, 8),
+                                                (55, [12, 20], 4, 8), (64, [16, 24], 5, 10)])
 def test_small_generic_cascades(n, rows, n_eq, n_ineq, oracle):
     """n < 32 goes through the guarded (FULLN = false) instantiation: Panda-like 7-variable stacks
-    (examples/cpp/panda_ik.cpp shape) and mid-size generic stacks with equality and inequality rows"""
+    (examples/cpp/panda_ik.cpp shape) and mid-size generic stacks with equality and inequality rows; 33 .. 54 variables
+    through the 64-lane solver with the short LDS layout (WaveCtx<56>: 54 is its last size), 55 .. 64 through the full one"""
     plan, leaf = synth.make_generic_stack(5, n, rows, n_eq=n_eq, n_ineq=n_ineq, seed=n)
     asm = oracle.assemble(plan, leaf)
     dq, xl, st, it = emu_cascade(plan, asm)

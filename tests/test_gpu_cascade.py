@@ -54,7 +54,9 @@ def test_update_kernel_matches_oracle_assembly(oracle, gpu_device):
 
 
 @pytest.mark.parametrize("n,rows,n_eq,n_ineq,dup", [(7, [6], 0, 0, None), (7, [3, 3], 1, 2, None), (20, [5, 6], 4, 6, None),
-                                                     (16, [4, 5], 6, 0, 0), (18, [2], 6, 0, 0)])
+                                                     (16, [4, 5], 6, 0, 0), (18, [2], 6, 0, 0),
+                                                     (33, [8, 10], 2, 4, None), (48, [12, 16], 3, 6, None), (54, [12, 20], 4, 8, None),
+                                                     (55, [12, 20], 4, 8, None), (64, [16, 24], 5, 10, None)])
 def test_small_generic_cascades_gpu(n, rows, n_eq, n_ineq, dup, oracle, gpu_device):
     """n < 32 (guarded factor instantiation), Panda-like 7-variable stacks, and a stack whose optimality rows
     duplicate its global equality rows (coman_ik.cpp:442; (18, [2]): with so many dependent rows that the null-space
