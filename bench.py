@@ -277,7 +277,7 @@ def time_config(name, B, device, steps=20, warmup=5):
     kern_ms, launches = st.kernel_time_ms()
     st.set_timing(False)
     ok = int((st.status[:B] == 0).sum().item())
-    NPk = 32 if plan.n <= 32 else 64
+    NPk = 32 if plan.n <= 32 else (56 if plan.n <= 54 else 64)   # the cascade instantiation make_dev_plan picks (osot_host_plan.h)
     traffic, src = pmc_traffic([(f"osot_cascade_kernel<{NPk}, false, false>", B + 1, 1)])
     rf, rh = roofline_of(plan, B, kern_ms, launches, f"osot_cascade_kernel<{NPk},false>", traffic,
                          src or "no PMC passes committed for this kernel source: null rather than a stale figure")

@@ -443,6 +443,25 @@ int osot_qp_solve_batch_admm(int B, int n, int nc, const double* H, const double
                              const double* lA, const double* uA, const double* l, const double* u,
                              double eps_reg, int max_iter, double* x, int* status, int* iterations, void* hip_stream);
 
+/* The same with osqp's settings exposed and WARM START: OSQPBackEnd keeps its osqp workspace between control cycles
+ * (src/solvers/OSQPBackEnd.cpp:120-143 updates P, q, A and the bounds in place; :268-287), so every solve after the first
+ * starts from the previous x and y with the rho the previous solve ended on (osqp's warm_start = 1).  Here the per-instance
+ * state is three device arrays owned by the caller: warm_x [B][n], warm_y [B][nc + n] (the rows of A, then the box rows;
+ * [B][nc] without l / u), warm_rho [B]; set warm_rho to 0 for "no state yet" (e.g. hipMemset the arrays once) -- an instance
+ * whose solve fails is reset to that.  All three null = cold start.  opt null = the defaults below. */
+typedef struct osot_admm_options {
+    double eps_abs, eps_rel;     /* 0 = 1e-5 each (OSQPBackEnd.cpp:38-39) */
+    double rho, sigma, alpha;    /* 0 = osqp's 0.1, 1e-6, 1.6 */
+    int max_iter;                /* 0 = 4000 */
+    int scaling;                 /* Ruiz equilibration passes: 0 = osqp's 10, negative = none */
+    int check_every;             /* residual test period, 0 = 25 */
+} osot_admm_options;
+int osot_qp_solve_batch_admm_warm(int B, int n, int nc, const double* H, const double* g, const double* A,
+                                  const double* lA, const double* uA, const double* l, const double* u,
+                                  double eps_reg, const osot_admm_options* opt,
+                                  double* warm_x, double* warm_y, double* warm_rho,
+                                  double* x, int* status, int* iterations, void* hip_stream);
+
 /* ---- batched kinematics producer ------------------------------------------------------
  * What the leaf tasks ask XBot::ModelInterface for every cycle: frame poses and 6 x n frame Jacobians
  * (velocity::Cartesian::_update, src/tasks/velocity/Cartesian.cpp:73-81: getJacobian / getPose), the centre

@@ -94,6 +94,11 @@ class NhqpOptions(C.Structure):
                 ("min_sv_ratio_is_set", C.c_int)]
 
 
+class AdmmOptions(C.Structure):
+    _fields_ = [("eps_abs", C.c_double), ("eps_rel", C.c_double), ("rho", C.c_double), ("sigma", C.c_double),
+                ("alpha", C.c_double), ("max_iter", C.c_int), ("scaling", C.c_int), ("check_every", C.c_int)]
+
+
 class IdModel(C.Structure):
     _fields_ = [("B", C.c_int), ("nv", C.c_int), ("n_contacts", C.c_int), ("contact_dim", C.c_int),
                 ("Bm", C.c_void_p), ("h", C.c_void_p), ("Jc", C.c_void_p), ("floating_base", C.c_int)]
@@ -143,7 +148,7 @@ SYMBOLS = [
     "osot_backend_get_options", "osot_backend_set_options",
     "osot_backend_set_eps_regularisation", "osot_backend_get_eps_regularisation",
     "osot_backend_get_num_variables", "osot_backend_get_num_constraints",
-    "osot_qp_solve_batch", "osot_qp_solve_batch_admm",
+    "osot_qp_solve_batch", "osot_qp_solve_batch_admm", "osot_qp_solve_batch_admm_warm",
     "osot_comm_unique_id", "osot_comm_create", "osot_comm_destroy", "osot_allgather_dq",
 ]
 
@@ -217,6 +222,8 @@ def lib():
                                       C.c_double, C.c_int, vp, vp, vp, vp]
     L.osot_qp_solve_batch_admm.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp,
                                            C.c_double, C.c_int, vp, vp, vp, vp]
+    L.osot_qp_solve_batch_admm_warm.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp,
+                                                C.c_double, C.POINTER(AdmmOptions), vp, vp, vp, vp, vp, vp, vp]
     L.osot_comm_unique_id.argtypes = [vp]
     L.osot_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.osot_comm_destroy.argtypes = [vp]

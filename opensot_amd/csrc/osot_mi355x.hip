@@ -535,25 +535,34 @@ int osot_qp_solve_batch(int B, int n, int nc, const double* H, const double* g, 
     return OSOT_OK;
 }
 
-int osot_qp_solve_batch_admm(int B, int n, int nc, const double* H, const double* g, const double* A,
-                             const double* lA, const double* uA, const double* l, const double* u,
-                             double eps_reg, int max_iter, double* x, int* status, int* iterations, void* hip_stream) {
+int osot_qp_solve_batch_admm_warm(int B, int n, int nc, const double* H, const double* g, const double* A,
+                                  const double* lA, const double* uA, const double* l, const double* u,
+                                  double eps_reg, const osot_admm_options* opt, double* warm_x, double* warm_y, double* warm_rho,
+                                  double* x, int* status, int* iterations, void* hip_stream) {
     if (B < 0 || n < 1 || n > OSOT_MAX_VARS || nc < 0) return fail(OSOT_ERR_INVALID, "bad sizes");
     if (B == 0) return OSOT_OK;
     if (!H || !g || !x || !status) return fail(OSOT_ERR_INVALID, "null H/g/x/status");
     if (nc > 0 && (!A || !lA || !uA)) return fail(OSOT_ERR_INVALID, "nc > 0 but A/lA/uA is null");
     if ((l == nullptr) != (u == nullptr)) return fail(OSOT_ERR_INVALID, "l and u must both be given or both be null");
-    DevAdmm Q;
-    std::memset(&Q, 0, sizeof(Q));
-    Q.B = B; Q.n = n; Q.nc = nc; Q.max_iter = max_iter > 0 ? max_iter : 4000; Q.check_every = 25;
-    Q.eps_reg = eps_reg; Q.eps_abs = 1.0e-5; Q.eps_rel = 1.0e-5; Q.rho0 = 0.1; Q.sigma = 1.0e-6; Q.alpha = 1.6;   // OSQPBackEnd.cpp:36-39 + osqp defaults
-    Q.H = H; Q.g = g; Q.A = A; Q.lA = lA; Q.uA = uA; Q.l = l; Q.u = u; Q.x = x; Q.status = status; Q.iterations = iterations;
+    const bool has_y = (nc + (l ? n : 0)) > 0;
+    if ((warm_x == nullptr) != (warm_rho == nullptr) || (warm_x && has_y && !warm_y) || (!warm_x && warm_y))
+        return fail(OSOT_ERR_INVALID, "warm_x, warm_y and warm_rho must be given together (or all be null)");
+    const DevAdmm Q = admm_args(B, n, nc, H, g, A, lA, uA, l, u, eps_reg, opt, warm_x, warm_y, warm_rho, x, status, iterations);
     const size_t lds = admm_lds_bytes(n, nc, l != nullptr);
     int rc = ensure_lds(osot_admm_kernel, lds);
     if (rc != OSOT_OK) return rc;
     hipLaunchKernelGGL(osot_admm_kernel, dim3((unsigned)B), dim3(64), lds, (hipStream_t)hip_stream, Q);
     HIP_TRY(hipGetLastError());
     return OSOT_OK;
+}
+
+int osot_qp_solve_batch_admm(int B, int n, int nc, const double* H, const double* g, const double* A,
+                             const double* lA, const double* uA, const double* l, const double* u,
+                             double eps_reg, int max_iter, double* x, int* status, int* iterations, void* hip_stream) {
+    osot_admm_options opt;
+    std::memset(&opt, 0, sizeof(opt));
+    opt.max_iter = max_iter;
+    return osot_qp_solve_batch_admm_warm(B, n, nc, H, g, A, lA, uA, l, u, eps_reg, &opt, nullptr, nullptr, nullptr, x, status, iterations, hip_stream);
 }
 
 }  // extern "C"

@@ -37,11 +37,22 @@ def _chk(t, name, shape=None, dtype=torch.float64):
     return C.c_void_p(t.data_ptr())
 
 
+def admm_state(B, n, nc, box=True, device=0):
+    """the warm-start state of the OSQP-convention back-end for B instances (what OSQPBackEnd's osqp workspace carries from
+    one control cycle to the next, OSQPBackEnd.cpp:120-143): x, y, rho; rho = 0 means "no state yet" """
+    dev = torch.device("cuda", device) if isinstance(device, int) else device
+    return {"x": torch.zeros((B, n), dtype=torch.float64, device=dev),
+            "y": torch.zeros((B, nc + (n if box else 0)), dtype=torch.float64, device=dev),
+            "rho": torch.zeros((B,), dtype=torch.float64, device=dev)}
+
+
 def qp_solve(H, g, A=None, lA=None, uA=None, l=None, u=None, eps_regularisation=2e2, be_solver=solver_back_ends.qpOASES,
-             max_iter=0):
+             max_iter=0, warm=None, scaling=0):
     """B QPs  min 1/2 x'Hx + g'x  s.t.  lA <= A x <= uA,  l <= x <= u  (BackEnd.h:125-150).
     H [B][n][n], g [B][n], A [B][nc][n], lA / uA [B][nc], l / u [B][n] (A.. and l, u optional), float64, on one GPU.
     eps_regularisation is the back-end factory's FACTOR (BackEndFactory.cpp:4-17).
+    OSQP back-end only: warm = admm_state(...) carried from call to call (warm start), scaling = Ruiz passes (0 = osqp's 10,
+    negative = none).
     Returns (x [B][n], status [B] int32 OSOT_STATUS_*, iterations [B] int32), stream-ordered on the current stream."""
     lib = abi.lib()
     if H.dim() != 3 or H.shape[1] != H.shape[2]:
@@ -58,10 +69,20 @@ def qp_solve(H, g, A=None, lA=None, uA=None, l=None, u=None, eps_regularisation=
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     with torch.cuda.device(dev):
         if be_solver == solver_back_ends.OSQP:
-            abi.check(lib.osot_qp_solve_batch_admm(B, n, nc, pH, pg, pA, plA, puA, pl, pu, 2.22e-13 * eps_regularisation, max_iter,
-                                                   C.c_void_p(x.data_ptr()), C.c_void_p(status.data_ptr()),
-                                                   C.c_void_p(iters.data_ptr()), stream), "osot_qp_solve_batch_admm")
+            opt = abi.AdmmOptions()
+            opt.max_iter = max_iter
+            opt.scaling = scaling
+            m = nc + (n if l is not None else 0)
+            wx = wy = wr = None
+            if warm is not None:
+                wx, wy, wr = _chk(warm["x"], "warm x", (B, n)), _chk(warm["y"], "warm y", (B, m)), _chk(warm["rho"], "warm rho", (B,))
+            abi.check(lib.osot_qp_solve_batch_admm_warm(B, n, nc, pH, pg, pA, plA, puA, pl, pu, 2.22e-13 * eps_regularisation,
+                                                        C.byref(opt), wx, wy, wr,
+                                                        C.c_void_p(x.data_ptr()), C.c_void_p(status.data_ptr()),
+                                                        C.c_void_p(iters.data_ptr()), stream), "osot_qp_solve_batch_admm_warm")
         else:
+            if warm is not None:
+                raise ValueError("warm is the OSQP back-end's state; the active-set back-end's hot start lives in BatchedStack.set_hotstart")
             abi.check(lib.osot_qp_solve_batch(B, n, nc, pH, pg, pA, plA, puA, pl, pu, eps_abs_from_factor(eps_regularisation), max_iter,
                                               C.c_void_p(x.data_ptr()), C.c_void_p(status.data_ptr()),
                                               C.c_void_p(iters.data_ptr()), stream), "osot_qp_solve_batch")

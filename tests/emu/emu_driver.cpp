@@ -60,15 +60,14 @@ extern "C" __attribute__((visibility("default"))) int emu_qp_solve_batch(int B, 
     return OSOT_OK;
 }
 
-// the OSQP-convention ADMM back-end (osot_admm.h) on host pointers
+// the OSQP-convention ADMM back-end (osot_admm.h) on host pointers; scaling as osot_admm_options.scaling, warm_* may be null
 extern "C" __attribute__((visibility("default"))) int emu_qp_solve_batch_admm(int B, int n, int nc, const double* H, const double* g,
         const double* A, const double* lA, const double* uA, const double* l, const double* u, double eps_reg, int max_iter,
-        double* x, int* status, int* iterations) {
-    DevAdmm Q;
-    memset(&Q, 0, sizeof(Q));
-    Q.B = B; Q.n = n; Q.nc = nc; Q.max_iter = max_iter > 0 ? max_iter : 4000; Q.check_every = 25;
-    Q.eps_reg = eps_reg; Q.eps_abs = 1.0e-5; Q.eps_rel = 1.0e-5; Q.rho0 = 0.1; Q.sigma = 1.0e-6; Q.alpha = 1.6;
-    Q.H = H; Q.g = g; Q.A = A; Q.lA = lA; Q.uA = uA; Q.l = l; Q.u = u; Q.x = x; Q.status = status; Q.iterations = iterations;
+        double* x, int* status, int* iterations, int scaling, double* warm_x, double* warm_y, double* warm_rho) {
+    osot_admm_options opt;
+    memset(&opt, 0, sizeof(opt));
+    opt.max_iter = max_iter; opt.scaling = scaling;
+    const DevAdmm Q = admm_args(B, n, nc, H, g, A, lA, uA, l, u, eps_reg, &opt, warm_x, warm_y, warm_rho, x, status, iterations);
     emu::launch(osot_admm_kernel, (unsigned)B, admm_lds_bytes(n, nc, l != nullptr), 64, Q);
     return OSOT_OK;
 }

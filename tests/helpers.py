@@ -423,8 +423,10 @@ def emu_ehqp(plan, asm, sigma_min=0.0, level_active=None):
     return dq, st, xl
 
 
-def emu_qp_admm(H, g, A, lA, uA, l, u, eps_reg=0.0, max_iter=0):
-    """B generic QPs through the emulated OSQP-convention ADMM kernel (osot_admm.h); arrays are [B][...]"""
+def emu_qp_admm(H, g, A, lA, uA, l, u, eps_reg=0.0, max_iter=0, scaling=0, warm=None):
+    """B generic QPs through the emulated OSQP-convention ADMM kernel (osot_admm.h); arrays are [B][...].  scaling as
+    osot_admm_options.scaling (0 = ten Ruiz passes, negative = none); warm: dict(x [B][n], y [B][nc + n or nc], rho [B]),
+    read and rewritten in place (start with rho = 0: no state)"""
     H = np.ascontiguousarray(H, dtype=np.float64)
     B, n = H.shape[0], H.shape[1]
     nc = 0 if A is None else A.shape[1]
@@ -433,8 +435,14 @@ def emu_qp_admm(H, g, A, lA, uA, l, u, eps_reg=0.0, max_iter=0):
     p = lambda a: None if a is None else a.ctypes.data
     L = emu_lib()
     vp = C.c_void_p
-    L.emu_qp_solve_batch_admm.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_double, C.c_int, vp, vp, vp]
-    assert L.emu_qp_solve_batch_admm(B, n, nc, p(H), *[p(a) for a in arrs], eps_reg, max_iter, p(x), p(st), p(it)) == 0
+    L.emu_qp_solve_batch_admm.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_double, C.c_int, vp, vp, vp,
+                                          C.c_int, vp, vp, vp]
+    wx = wy = wr = None
+    if warm is not None:
+        wx, wy, wr = warm["x"], warm["y"], warm["rho"]
+        assert wx.flags.c_contiguous and wy.flags.c_contiguous and wr.flags.c_contiguous and wx.dtype == wy.dtype == wr.dtype == np.float64
+    assert L.emu_qp_solve_batch_admm(B, n, nc, p(H), *[p(a) for a in arrs], eps_reg, max_iter, p(x), p(st), p(it),
+                                     scaling, p(wx), p(wy), p(wr)) == 0
     return x, st, it
 
 

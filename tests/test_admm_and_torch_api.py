@@ -40,6 +40,57 @@ def test_admm_known_answers_and_infeasibility():
     assert st[0] != 0 and (x[0] == 0).all()
 
 
+def test_admm_ruiz_equilibration_on_badly_scaled_problems():
+    """osqp's scaling = 10 (Ruiz, then the cost factor): variables in different units (columns of H and A scaled by
+    1e-2 .. 1e2).  The residual test is on the unscaled residuals either way, so both runs stop at the same accuracy of the
+    KKT conditions -- which on such a problem pins the objective (checked against the active-set kernel's optimum at 1e-3
+    relative) far better than x itself; the equilibrated iteration gets there in a few hundred steps, the plain one needs
+    thousands (this seed: 100 .. 425 against 225 .. 20000)"""
+    rng = np.random.default_rng(77)
+    B, n, nc = 6, 24, 12
+    H, g, A, lA, uA, l, u = random_qp(rng, B, n, nc, 2)
+    sc = 10.0 ** rng.uniform(-2, 2, size=(B, n))
+    H = H * sc[:, :, None] * sc[:, None, :]; g = g * sc; A = A * sc[:, None, :]; l = l / sc; u = u / sc
+    f = lambda x: 0.5 * np.einsum("bi,bij,bj->b", x, H, x) + (g * x).sum(1)
+    xa, sa, _ = emu_qp(H, g, A, lA, uA, l, u, eps_abs=1e-12)
+    x1, s1, it1 = emu_qp_admm(H, g, A, lA, uA, l, u, eps_reg=1e-12, scaling=0)
+    x0, s0, it0 = emu_qp_admm(H, g, A, lA, uA, l, u, eps_reg=1e-12, scaling=-1, max_iter=20000)
+    assert (sa == 0).all() and (s1 == 0).all()
+    assert (np.abs(f(x1) - f(xa)) < 1e-3 * np.abs(f(xa))).all()
+    assert np.abs((x1 - xa) * sc).max() < 1e-2                     # in the variables' own units
+    Ax = np.einsum("brn,bn->br", A, x1)
+    assert (Ax >= lA - 1e-3).all() and (Ax <= uA + 1e-3).all() and (x1 * sc >= l * sc - 1e-3).all() and (x1 * sc <= u * sc + 1e-3).all()
+    print(f"iterations with / without Ruiz: {it1.tolist()} / {it0.tolist()}")
+    assert (it1 <= 1000).all() and 5 * it1.sum() < it0.sum()
+
+
+def test_admm_warm_start_across_control_cycles():
+    """OSQPBackEnd keeps its workspace: the next cycle's solve starts from the previous x, y and rho (OSQPBackEnd.cpp:120-143,
+    268-287).  The same problem again converges at the first residual test; a drifted problem takes fewer iterations warm than
+    cold and lands on the same answer; an instance without state (rho = 0) runs cold"""
+    rng = np.random.default_rng(78)
+    B, n, nc = 5, 20, 14
+    H, g, A, lA, uA, l, u = random_qp(rng, B, n, nc, 2)
+    warm = {"x": np.zeros((B, n)), "y": np.zeros((B, nc + n)), "rho": np.zeros(B)}
+    x0, s0, it0 = emu_qp_admm(H, g, A, lA, uA, l, u, eps_reg=1e-9, warm=warm)
+    xc, sc_, itc = emu_qp_admm(H, g, A, lA, uA, l, u, eps_reg=1e-9)
+    assert (s0 == 0).all() and np.array_equal(it0, itc) and np.array_equal(x0, xc)   # no state yet: the cold solve, bit for bit
+    assert (warm["rho"] > 0).all() and np.abs(warm["x"] - x0).max() == 0.0
+    x1, s1, it1 = emu_qp_admm(H, g, A, lA, uA, l, u, eps_reg=1e-9, warm=warm)
+    assert (s1 == 0).all() and (it1 == 25).all() and np.abs(x1 - x0).max() < 1e-5
+    g2 = g + 0.02 * rng.normal(size=g.shape) * np.abs(g).max()
+    warm["rho"][3] = 0.0                                                                 # one instance forgets its state
+    xw, sw, itw = emu_qp_admm(H, g2, A, lA, uA, l, u, eps_reg=1e-9, warm=warm)
+    xk, sk, itk = emu_qp_admm(H, g2, A, lA, uA, l, u, eps_reg=1e-9)
+    xa, sa, _ = emu_qp(H, g2, A, lA, uA, l, u, eps_abs=1e-9)
+    assert (sw == 0).all() and (sk == 0).all() and (sa == 0).all()
+    assert np.abs(xw - xa).max() < 1e-4 and np.abs(xk - xa).max() < 1e-4
+    print(f"iterations warm / cold on the drifted problem: {itw.tolist()} / {itk.tolist()}")
+    assert itw[3] == itk[3] and np.array_equal(xw[3], xk[3])
+    others = np.arange(B) != 3
+    assert itw[others].sum() < itk[others].sum()
+
+
 @pytest.mark.gpu
 def test_torch_qp_solve_both_back_ends_gpu(oracle, gpu_device):
     """tensors in, tensors out: the caller's device pointers go straight to the C-ABI; the two back-ends agree at 1e-4, the
@@ -129,3 +180,34 @@ def test_admm_cross_checks_config5_qps_gpu(gpu_device):
     ax = np.einsum("brj,bj->br", asm["C"], Xo)
     viol = np.maximum(np.where(lo > -1e20, lo - ax, 0.0), np.where(up < 1e20, ax - up, 0.0)).max(axis=1)
     assert viol[ok].max() < 1e-2      # rows of norm ~30 and bounds of 30 .. 1e3: 1e-5-class relative residuals
+
+
+@pytest.mark.gpu
+def test_admm_warm_start_and_scaling_gpu(gpu_device):
+    """osot_qp_solve_batch_admm_warm on the device: the state tensors carry x, y, rho across drifting cycles (fewer iterations
+    than cold solves of the same problems, same answers); without state the call is the cold one"""
+    import torch
+    from opensot_amd import torch_api as ta
+    rng = np.random.default_rng(91)
+    B, n, nc = 256, 32, 20
+    H, g, A, lA, uA, l, u = random_qp(rng, B, n, nc, 2)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=dev).contiguous()
+    tH, tA, tlA, tuA, tl, tu = t(H), t(A), t(lA), t(uA), t(l), t(u)
+    warm = ta.admm_state(B, n, nc, box=True, device=0)
+    tot_w = tot_c = 0
+    for cyc in range(4):
+        gk = t(g + 0.01 * cyc * np.abs(g).max() * rng.normal(size=g.shape))
+        xw, sw, iw = ta.qp_solve(tH, gk, tA, tlA, tuA, tl, tu, eps_regularisation=1e4, be_solver=ta.solver_back_ends.OSQP, warm=warm)
+        xc, sc_, ic = ta.qp_solve(tH, gk, tA, tlA, tuA, tl, tu, eps_regularisation=1e4, be_solver=ta.solver_back_ends.OSQP)
+        xa, sa, _ = ta.qp_solve(tH, gk, tA, tlA, tuA, tl, tu, eps_regularisation=1e4)
+        torch.cuda.synchronize()
+        assert (sw == 0).all() and (sc_ == 0).all() and (sa == 0).all()
+        assert (xw - xa).abs().max().item() < 1e-4 and (xc - xa).abs().max().item() < 1e-4
+        if cyc == 0:
+            assert torch.equal(xw, xc) and torch.equal(iw, ic)
+        else:
+            tot_w += int(iw.sum()); tot_c += int(ic.sum())
+    print(f"ADMM iterations over 3 drifting cycles x {B} instances: warm {tot_w}, cold {tot_c}")
+    assert tot_w < 0.8 * tot_c
+    assert (warm["rho"] > 0).all()
