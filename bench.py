@@ -602,11 +602,12 @@ def main():
             out["roofline"], out["roofline_hbm"] = rf, rh
         if world == 1 and not args.no_other_configs and not stub:
             oc = {}
-            for name, B in (("C2", 1024), ("C4", 4096), ("C5", 1024)):
+            for key, name, B, st_ in (("C2", "C2", 1024, 20), ("C4", "C4", 4096, 20), ("C5", "C5", 1024, 20),
+                                      ("C5_B4096", "C5", 4096, 10)):   # (the last: config 5 beyond the shard size, four rounds of resident wavefronts)
                 try:
-                    oc[name] = time_config(name, B, local_rank)
+                    oc[key] = time_config(name, B, local_rank, steps=st_)
                 except Exception as e:
-                    oc[name] = {"error": str(e)}
+                    oc[key] = {"error": str(e)}
             try:
                 oc["nHQP_C3"] = time_nhqp(4096, local_rank)
             except Exception as e:
@@ -615,10 +616,11 @@ def main():
                 oc["eHQP_C3"] = time_ehqp(4096, local_rank)
             except Exception as e:
                 oc["eHQP_C3"] = {"error": str(e)}
-            try:
-                oc["kinematics"] = time_kinematics(4096, local_rank)
-            except Exception as e:
-                oc["kinematics"] = {"error": str(e)}
+            for key, Bk in (("kinematics", 4096), ("kinematics_B32768", 32768)):
+                try:
+                    oc[key] = time_kinematics(Bk, local_rank)
+                except Exception as e:
+                    oc[key] = {"error": str(e)}
             out["other_configs"] = oc
         if not args.no_cpu_baseline and world == 1 and not stub:
             ns = min(Bl, 4096)

@@ -105,6 +105,8 @@ struct WaveCtx {
     static constexpr int LDS_DOUBLES = M1_DOUBLES + ROWS * S + 4 * LW;   // M1, M2, V (four staging vectors of LW)
     __device__ static __forceinline__ int col_of(int lane) { return (NP == 56) ? ((lane < 56) ? lane : 56) : lane % NP; }
     __device__ static __forceinline__ int half_of(int lane) { return (NP == 56) ? 0 : lane / NP; }
+    // the wavefront position of lane (c, h): recomputed from the coordinates where they determine it (no extra live register)
+    __device__ static __forceinline__ int lane_of(int c, int h) { return (NP == 56) ? phys_lane() : c + LW * h; }
     int c, h;       // column index and half of this lane
     int n;
     double* M1;
@@ -993,7 +995,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
     OSOT_PH_BEGIN();
     {   // ---------------- factorisation phase (own scope: see the launder_i note below) ----------------
     WaveCtx<NP> w1 = w_in;
-    { const int l1 = launder_i(phys_lane()); w1.c = WaveCtx<NP>::col_of(l1); w1.h = WaveCtx<NP>::half_of(l1); }
+    { const int l1 = launder_i(WaveCtx<NP>::lane_of(w_in.c, w_in.h)); w1.c = WaveCtx<NP>::col_of(l1); w1.h = WaveCtx<NP>::half_of(l1); }
     const WaveCtx<NP>& w = w1;
     const int c = w.c, h = w.h;
     const bool valid = c < n;
@@ -1008,7 +1010,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
         if (colsum<NP>(okd ? 0.0 : 1.0) != 0.0) { x_out = 0.0; iters_out = 0; return QP_NOT_PD; }
         double sq = 1.0, rs = 1.0;
         if (valid) fast_sqrt_rsqrt(hdiag, sq, rs);
-        for (int e = phys_lane(); e < WaveCtx<NP>::ROWS * S; e += 64) M2[e] = 0.0;
+        for (int e = WaveCtx<NP>::lane_of(c, h); e < WaveCtx<NP>::ROWS * S; e += 64) M2[e] = 0.0;
         wave_sync();
         if (h == 0 && valid) M2[c * S + c] = rs;
         x = valid ? -g * rs * rs : 0.0;
@@ -1028,7 +1030,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
     }   // end of the factorisation phase
     // (the lane coordinates are re-derived here so that nothing computed for the factorisation stays live)
     WaveCtx<NP> w2 = w_in;
-    { const int l2 = launder_i(phys_lane()); w2.c = WaveCtx<NP>::col_of(l2); w2.h = WaveCtx<NP>::half_of(l2); }
+    { const int l2 = launder_i(WaveCtx<NP>::lane_of(w_in.c, w_in.h)); w2.c = WaveCtx<NP>::col_of(l2); w2.h = WaveCtx<NP>::half_of(l2); }
     const WaveCtx<NP>& w = w2;
     const int c = w.c, h = w.h;
     const bool valid = c < n;
@@ -1043,7 +1045,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
     int n_eq = 0;
     bool local_eq = false;   // an equality among the level's task-local rows: x_prev does not satisfy it
     for (int r0 = 0; r0 < nrows; r0 += 64) {
-        const int r = r0 + phys_lane();
+        const int r = r0 + WaveCtx<NP>::lane_of(c, h);
         bool is_eq = false, is_loc = false;
         if (r < nrows) {
             const double lo = w.rlo[r], up = w.rup[r];
@@ -1113,7 +1115,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
 
     // ---- inequality loop -----------------------------------------------------------------------------
     WaveCtx<NP> w3 = w_in;
-    { const int l3 = launder_i(phys_lane()); w3.c = WaveCtx<NP>::col_of(l3); w3.h = WaveCtx<NP>::half_of(l3); }
+    { const int l3 = launder_i(WaveCtx<NP>::lane_of(w_in.c, w_in.h)); w3.c = WaveCtx<NP>::col_of(l3); w3.h = WaveCtx<NP>::half_of(l3); }
     // after the null-space path the equality rows of J are zero, so |J'n|^2 no longer measures n'H^-1 n;
     // the diagonal of H^-1 does (hinv > 0 selects that in the dependency test)
     const double hinv = (used_nullspace && valid) ? fast_rcp(hdiag) : 0.0;
@@ -1140,7 +1142,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
     int n_gen = 0;
     bool any_unit = false;   // is there a unit row that can ever be violated?  (none: its pass is skipped)
     for (int r0 = 0; r0 < nrows; r0 += 64) {
-        const int r = r0 + phys_lane();
+        const int r = r0 + WaveCtx<NP>::lane_of(c, h);
         bool is_gen = false, is_unit = false;
         if (r < nrows) {
             const double lo = w.rlo[r], up = w.rup[r];
@@ -1239,7 +1241,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
             wave_sync();
         }
         if (any_unit) {
-            const int lane = phys_lane();
+            const int lane = WaveCtx<NP>::lane_of(c, h);
             for (int r0 = 0; r0 < nrows; r0 += 64) {
                 const int r = r0 + lane;
                 if (r < nrows) {
@@ -1272,7 +1274,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
         // x (no cross-lane reduction at all).  Consecutive elements of a row share a cache line, so after the
         // first touch the walk is served from the CU's vector L1.
         for (int g0 = 0; g0 < n_gen; g0 += 64) {
-            const int gi = g0 + phys_lane();
+            const int gi = g0 + WaveCtx<NP>::lane_of(c, h);
             if (gi < n_gen) {
                 const int r = w.eqlist[gi];
                 const auto* row = OSOT_GLOBAL_F64(w.rptr[r]);
