@@ -34,11 +34,13 @@ def test_update_kernel_vs_oracle_assembly(cfg, oracle):
     _check_update(plan, leaf, oracle)
 
 
-def test_feature_stack_update_and_cascade(oracle):
+@pytest.mark.parametrize("n", [32, 40, 60])
+def test_feature_stack_update_and_cascade(n, oracle):
     """body-frame b, per-row bands, candidate ordering, six row blocks and a full weight matrix in one stack: assembly
-    equal to the oracle's, W A and W b equal to numpy, cascade against the eiQuadProg restatement and qpOASES"""
+    equal to the oracle's, W A and W b equal to numpy, cascade against the eiQuadProg restatement and qpOASES.
+    n = 40 / 60: the same through the 64-lane cascade on its short (n <= 54) and full LDS layouts"""
     B = 6
-    plan, leaf = synth.make_feature_stack(B, seed=5)
+    plan, leaf = synth.make_feature_stack(B, seed=5, n=n)
     assert len(plan.rowblocks) == 6 and plan.dense_level(1) and not plan.dense_level(0)
     asm, res = _check_update(plan, leaf, oracle)
     # the collision block really had to choose: some candidates are closer than the first `rows` ones

@@ -11,11 +11,13 @@ from opensot_amd.solver import BatchedStack, stored_rows
 pytestmark = pytest.mark.gpu
 
 
-def test_feature_stack_gpu(oracle, gpu_device):
+@pytest.mark.parametrize("n", [32, 40, 60])
+def test_feature_stack_gpu(n, oracle, gpu_device):
     """body-frame Cartesian b, per-row TaskToConstraint bands, collision rows chosen among 24 candidates, six row blocks
-    and a full weight matrix: update bit-equal to the oracle's assembly, W A / W b equal to numpy, cascade vs witnesses"""
+    and a full weight matrix: update bit-equal to the oracle's assembly, W A / W b equal to numpy, cascade vs witnesses.
+    n = 40 / 60: the dense-weight instantiation of the 64-lane cascade on its short and full LDS layouts"""
     B = 192
-    plan, leaf = synth.make_feature_stack(B, seed=5)
+    plan, leaf = synth.make_feature_stack(B, seed=5, n=n)
     asm = oracle.assemble(plan, leaf)
     st = BatchedStack(plan, B, device=0)
     st.update(st.load_leaf(leaf)); st.solve(B)
