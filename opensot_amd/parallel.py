@@ -261,6 +261,7 @@ def timed_steps(step, steps, warmup, sync, dist=None, device=None):
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    timed_steps.host_enqueue_s = time.perf_counter() - t0    # this rank's time to ENQUEUE the steps (diagnostic: host-bound if ~ elapsed)
     sync()
     if dist is not None:
         dist.barrier()
