@@ -135,7 +135,10 @@ __device__ inline void closest_segment_box(const double* p0, const double* p1, c
 // 64-lane store carries two instances);  JMAX = 64: one instance per wavefront.  LDS per wavefront 16.5 KB either way.
 template <bool PAIRS, int JMAX>
 __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__ K, const osot_kin_batch Bt) {
-    constexpr int TS = 12;
+#ifndef OSOT_KIN_TS
+#define OSOT_KIN_TS 12
+#endif
+    constexpr int TS = OSOT_KIN_TS;
     constexpr int PACK = 64 / JMAX;
     OSOT_STATIC_LDS(double, Tb_all, PACK * 2 * JMAX * TS);   // two transform buffers [R | p] per joint (ping-pong of the pointer
     //                                              jumping: ONE array indexed by an offset, so that every access stays a DS op --
