@@ -140,16 +140,17 @@ __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__
 #endif
     constexpr int TS = OSOT_KIN_TS;
     constexpr int PACK = 64 / JMAX;
-    OSOT_STATIC_LDS(double, Tb_all, PACK * 2 * JMAX * TS);   // two transform buffers [R | p] per joint (ping-pong of the pointer
-    //                                              jumping: ONE array indexed by an offset, so that every access stays a DS op --
-    //                                              swapping two pointers made the compiler fall back to flat loads)
+    OSOT_STATIC_LDS(double, Tb_all, PACK * JMAX * TS);   // ONE transform buffer [R | p] per joint (round 3; it was a ping-pong
+    //                                              pair: a round of the pointer jumping reads, synchronises, writes, synchronises
+    //                                              either way, so the second buffer bought nothing and cost 3 KB per instance:
+    //                                              10.4 KB per wavefront instead of 16.5 -> 15 wavefronts per CU instead of 9)
     OSOT_STATIC_LDS(double, Zw_all, PACK * JMAX * 3);     // world joint axes
     OSOT_STATIC_LDS(double, Cw_all, PACK * JMAX * 4);     // world link centres of mass, mass
     OSOT_STATIC_LDS(int, Par_all, PACK * JMAX);           // parent indices (the chain walk must not chase pointers through HBM)
     OSOT_STATIC_LDS(unsigned long long, Anc_all, PACK * JMAX);   // ancestor masks
     const int sub = (PACK == 2) ? (int)(threadIdx.x >> 5) : 0;
     const int j = (PACK == 2) ? (int)(threadIdx.x & 31u) : (int)threadIdx.x;
-    double* Tb = Tb_all + sub * (2 * JMAX * TS);
+    double* Tb = Tb_all + sub * (JMAX * TS);
     double* Tl = Tb;
     double* Zw = Zw_all + sub * (JMAX * 3);
     double* Cw = Cw_all + sub * (JMAX * 4);
@@ -201,15 +202,14 @@ __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__
     for (int i = 0; i < 3; ++i) pw[i] = valid ? Tl[j * TS + 9 + i] : 0.0;
     {
         int jp = Par[j];
-        int cur = 0, nxt = JMAX * TS;
         while (wave_ballot(jp >= 0) != 0ull) {
             int njp = jp;
             if (jp >= 0) {
                 double Ra[9], pa[3], Rn[9], pn[3];
 #pragma unroll
-                for (int i = 0; i < 9; ++i) Ra[i] = Tb[cur + jp * TS + i];
+                for (int i = 0; i < 9; ++i) Ra[i] = Tb[jp * TS + i];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) pa[i] = Tb[cur + jp * TS + 9 + i];
+                for (int i = 0; i < 3; ++i) pa[i] = Tb[jp * TS + 9 + i];
                 mat3_mul(Ra, Rw, Rn);
                 mat3_vec(Ra, pw, pn);
 #pragma unroll
@@ -218,18 +218,17 @@ __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__
                 for (int i = 0; i < 3; ++i) pw[i] = pn[i] + pa[i];
                 njp = Par[jp];
             }
-            wave_sync();            // everybody has read Par / cur
+            wave_sync();            // everybody has read Par and the transforms of this round
 #pragma unroll
-            for (int i = 0; i < 9; ++i) Tb[nxt + j * TS + i] = Rw[i];
+            for (int i = 0; i < 9; ++i) Tb[j * TS + i] = Rw[i];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) Tb[nxt + j * TS + 9 + i] = pw[i];
+            for (int i = 0; i < 3; ++i) Tb[j * TS + 9 + i] = pw[i];
             Par[j] = njp;
             jp = njp;
             wave_sync();
-            const int t = cur; cur = nxt; nxt = t;
         }
     }
-    double* Tw = Tb + JMAX * TS;   // final world transforms (written below, after the last round's barrier)
+    double* Tw = Tb;               // final world transforms (re-written below, after the last round's barrier: a joint without a parent never entered the loop's writes)
     if (valid) {
         double z[3], cl[3];
         mat3_vec(Rw, K->d.axis[j], z);
