@@ -16,16 +16,17 @@
 //     not formed;
 //   * the triangular solve r = R^-1 d1 only runs over the inequality part of the working set.
 //
-// Lane layout (osot_team.h): lane = c + NP*h, NP = padded size (32 or 64), HV = 64/NP halves.  Vectors are
+// Lane layout (osot_team.h): lane = c + LW*h, LW = 32 or 64 lanes per half, HV = 64/LW halves; NP = padded size: 32, 64, or
+// 56 = the 64-lane layout on a shorter LDS slice (WaveCtx below).  Vectors are
 // one element per lane, replicated over h; for NP = 32 the halves split the inner range of every mat-vec.
 // LDS per wave (doubles, zero-padded beyond n, compile-time row stride S = NP+1 so that row- and column-
 // walks are bank-conflict free for ds_read_b64 and every inner-loop offset is an instruction immediate):
-//     M1[NP][S]  L (Cholesky factor, written from registers) -> R (working-set factor, upper triangular)
+//     M1 (packed) L (Cholesky factor, written from registers) -> R (working-set factor, upper triangular, by columns)
 //     M2[NP][S]  JT, JT[j][k] = J[k][j]  (starts as L^-1; or the closed-form J of a low-rank level, or the
 //                H-orthonormal null-space basis of the equality rows under a diagonal Hessian)
 // H itself never sits in LDS: it is built and factorised in registers (NP = 32: in the accumulator layout of
 // v_mfma_f64_16x16x4_f64, factor_tiles32; NP = 64: one column per lane, factor_rows64).
-//     V[4][NP]   staging vectors for broadcasts
+//     V[4][LW]   staging vectors for broadcasts
 // All control flow is wave-uniform.
 #pragma once
 #include <osot_team.h>  // resolved through -I: csrc/ for the product, tests/emu/ for the host emulation

@@ -1,7 +1,8 @@
 // osot_team.h -- wavefront primitives for gfx950 (wave64).
 //
-// ONE QP instance is solved by ONE wavefront.  With NP = padded problem size (32 or 64) the 64 lanes are
-// laid out as  lane = c + NP*h :  c = column/element index, h = "half" (HV = 64/NP halves).  Every length-n
+// ONE QP instance is solved by ONE wavefront.  With NP = padded problem size (32, 64, or 56 = 64 lanes on a shorter LDS
+// layout: osot_qp_core.h) the 64 lanes are
+// laid out as  lane = c + LW*h :  c = column/element index, h = "half" (LW = 32 or 64 lanes per half).  Every length-n
 // vector is held as one element per lane, REPLICATED across the halves; matrices live in the wave's LDS
 // slice.  For NP = 32 the two halves split the inner (k) range of every mat-vec and rank-1 update, so the
 // serial trip counts are n/2.  All control flow is wave-uniform: loop counters and working-set sizes live
