@@ -89,7 +89,11 @@ def kernel_source_sha():
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "opensot_amd", "csrc")
     for f in sorted(x for x in os.listdir(csrc) if x.endswith(".h")):     # every kernel header (the bench line quotes them all)
-        h.update(open(os.path.join(csrc, f), "rb").read())
+        # the CODE of the header: // comments (whole-line and trailing) and blank lines do not change a kernel
+        for line in open(os.path.join(csrc, f), "r", encoding="utf-8", errors="replace"):
+            code = line.split("//", 1)[0].rstrip()
+            if code.strip():
+                h.update(code.encode() + b"\n")
     return h.hexdigest()[:16]
 
 
