@@ -459,6 +459,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("OSOT_BENCH_LANES", "2")),
                     help="sub-batches per GPU, each on its own stream with no join between steps "
                          "(opensot_amd.parallel.PipelinedCycle); 1 = one launch per step")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="submit every launch of the timed steps one by one instead of replaying a HIP graph per lane "
+                         "(the graph form is used where a lane's step is the solver's own launch: one GPU, no gather)")
     ap.add_argument("--backend", default=os.environ.get("OSOT_BENCH_BACKEND", "hip"), choices=("hip", "stub"),
                     help="stub = CPU tensors + gloo + a stand-in for the solver: exercises the launcher, the sharding, the lanes "
                          "and the gather of this very script where there is no GPU (tests/test_distributed_cpu.py); never a result")
@@ -542,10 +545,41 @@ def main():
     for _ in range(args.warmup):
         cyc.step()
     sync()
+    # the steps of a lane as ONE HIP graph (opensot_amd.parallel.PipelinedCycle.capture): G steps per replay, G an even divisor
+    # of --steps so that EXACTLY that many steps are timed; the same steps submitted launch by launch are timed right after,
+    # with the HIP events that give the kernel's own duration
+    graph_steps, graph_note, graph_elapsed, graph_host_ms, graph_diff = 0, None, None, None, None
+    if not args.no_graph and not stub and not use_dist and streams is not None:
+        cand = [g for g in range(4, 21, 2) if args.steps % g == 0]
+        if cand:
+            try:
+                cyc.capture(max(cand))
+                graph_steps = cyc.graph_steps
+                k_last = (lanes[0].i - 1) % K          # the cycle of the rotation every replay ends on
+                cyc.replay(); sync()
+                graph_elapsed = timed_steps(cyc.replay, args.steps // graph_steps, 0, sync, None, device)
+                graph_host_ms = 1e3 * getattr(timed_steps, "host_enqueue_s", 0.0) / args.steps
+                g_dq = torch.cat([stj.dq[:b - a] for stj, (a, b) in zip(stacks, spans)]).clone()
+                g_ok = sum(int((stj.status[:b - a] == 0).sum().item()) for stj, (a, b) in zip(stacks, spans))
+                # the same cycle of the rotation through plain launches: bit-identical results expected
+                while (lanes[0].i - 1) % K != k_last:
+                    cyc.step()
+                sync()
+                graph_diff = float((torch.cat([stj.dq[:b - a] for stj, (a, b) in zip(stacks, spans)]) - g_dq).abs().max().item())
+                if g_ok != Bl or graph_diff != 0.0:
+                    graph_note = f"graph replay disagreed with plain launches (ok {g_ok}/{Bl}, max |ddq| {graph_diff}): not used"
+                    graph_elapsed = None
+            except Exception as e:      # capture is an optimisation of the submission, never a requirement
+                graph_note, graph_elapsed = f"graph capture unavailable: {e}"[:300], None
+        else:
+            graph_note = "--steps has no even divisor in 4..20: launches submitted one by one"
     for stj in stacks:
         stj.set_timing(True, stride=4)     # every fourth launch of a lane is bracketed by HIP events on its stream
     elapsed = timed_steps(cyc.step, args.steps, 0, sync, dist if use_dist else None, device)
     host_enqueue_ms = 1e3 * getattr(timed_steps, "host_enqueue_s", 0.0) / args.steps
+    stream_elapsed = elapsed
+    if graph_elapsed is not None:
+        elapsed, host_enqueue_ms = graph_elapsed, graph_host_ms
     kt = [stj.kernel_time_ms() for stj in stacks]
     launches = sum(c for _, c in kt)
     kern_ms = sum(ms * c for ms, c in kt) / launches if launches else 0.0
@@ -622,6 +656,14 @@ def main():
             out["data"] = "STUB BACK-END (CPU tensors, gloo, no solver): launcher / sharding / gather check only, not a result"
         if single_value is not None:
             out["single_launch_per_step_value_rank0"] = single_value
+        out["submission"] = {
+            "mode": ("hip graph: %d steps of a lane per graph, one graph launch per lane and %d steps" % (graph_steps, graph_steps))
+                    if graph_elapsed is not None else "one launch per lane and step on the lane's stream",
+            "stream_launch_value_rank0": Bl * args.steps / stream_elapsed,
+            "stream_launch_ms_per_step": 1e3 * stream_elapsed / args.steps,
+            "graph_vs_stream_launch_max_abs_dq_diff": graph_diff,
+            "note": graph_note or ("the timed region is EXACTLY --steps steps in both forms; avg_launch_ms (HIP events on the lane's "
+                                   "stream) is taken over the stream-launch steps, which follow the graph replays")}
         if all_ok is not None:
             out["solved_ok_all_ranks"] = f"{all_ok}/{Bg}"
         if launches > 0 and kern_ms > 0 and not stub:

@@ -456,3 +456,17 @@ def test_pipelined_lanes_match_single_launch_gpu(gpu_device):
     got = torch.cat([ln.stack.dq[:b - a] for ln, (a, b) in zip(lanes, spans)])
     assert (one.stack.status[:B] == 0).all()
     assert torch.equal(got, one.stack.dq[:B])
+    # the same steps as HIP graphs (PipelinedCycle.capture / replay): 2 K steps of every lane per graph; a replay ends on the
+    # cycle the capture ended on, and gives that cycle's dq bit for bit -- replayed twice, and against the single launch
+    pipe.capture(2 * K)
+    k_last = (lanes[0].i - 1) % K
+    pipe.replay(); pipe.replay()
+    torch.cuda.synchronize()
+    got_g = torch.cat([ln.stack.dq[:b - a] for ln, (a, b) in zip(lanes, spans)])
+    while (one.i - 1) % K != k_last:
+        one.step()
+    torch.cuda.synchronize()
+    assert (torch.cat([ln.stack.status[:b - a] for ln, (a, b) in zip(lanes, spans)]) == 0).all()
+    assert torch.equal(got_g, one.stack.dq[:B])
+    with pytest.raises(ValueError):
+        pipe.capture(3)            # odd: the solver's alternating order buffers would end on the wrong side
