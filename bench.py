@@ -272,7 +272,7 @@ def time_config(name, B, device, steps=20, warmup=5):
     for _ in range(warmup):
         st.update(dev); st.solve(B)
     torch.cuda.synchronize()
-    st.set_timing(True)
+    st.set_timing(True, stride=4)     # (every fourth launch bracketed by HIP events: the brackets themselves cost ~10 % at config 2)
     t0 = time.perf_counter()
     for _ in range(steps):
         st.update(dev); st.solve(B)
