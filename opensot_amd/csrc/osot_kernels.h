@@ -121,7 +121,11 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
     w.M1 = base;
     w.M2 = base + WaveCtx<NP>::M1_DOUBLES;
     w.V = w.M2 + WaveCtx<NP>::ROWS * S;
-    w.rlo = P.rows_in_global ? D.rows_scratch + inst * P.rows_doubles : base + P.lds_rows_off;
+    // NP = 32 never moves the table out of LDS (osot_host_plan.h): said at compile time, the table's pointers are LDS pointers
+    // (ds_read instead of flat_load, and loads from a uniform address are uniform values: a pointer that MAY be global makes
+    // every table entry a divergent value, and every branch on one an exec-mask branch with the loop state in vector registers)
+    if constexpr (NP == 32) w.rlo = base + P.lds_rows_off;
+    else w.rlo = P.rows_in_global ? D.rows_scratch + inst * P.rows_doubles : base + P.lds_rows_off;
     w.rup = w.rlo + P.lds_rows_cap;
     w.rptr = reinterpret_cast<unsigned long long*>(w.rup + P.lds_rows_cap);
     w.rowstate = reinterpret_cast<int*>(w.rptr + P.lds_rows_cap);

@@ -805,8 +805,8 @@ __device__ inline bool direction_is_independent(const WaveCtx<NP>& w, double nd2
     if (c >= iq && c < n)
         for (int i = 0; i < n; ++i) { const double v = w.M2[c * S + i]; cn = fma(v, v, cn); }
     const double cos2 = (cn > 0.0) ? d2 * d2 / cn : 0.0;
-    const double best = colmax<NP>(cos2);
-    const double nn = colsum<NP>(nv * nv);
+    const double best = uniform_d(colmax<NP>(cos2));
+    const double nn = uniform_d(colsum<NP>(nv * nv));
     return best > kDepFloor2 * nn;
 }
 
@@ -1008,7 +1008,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
     } else if (diag_h) {
         // H + eps I diagonal (a level made of a Postural block only): L = sqrt(diag), JT = diag(1/L)
         const bool okd = !valid || (hdiag > 0.0);
-        if (colsum<NP>(okd ? 0.0 : 1.0) != 0.0) { x_out = 0.0; iters_out = 0; return QP_NOT_PD; }
+        if (uniform_d(colsum<NP>(okd ? 0.0 : 1.0)) != 0.0) { x_out = 0.0; iters_out = 0; return QP_NOT_PD; }
         double sq = 1.0, rs = 1.0;
         if (valid) fast_sqrt_rsqrt(hdiag, sq, rs);
         for (int e = WaveCtx<NP>::lane_of(c, h); e < WaveCtx<NP>::ROWS * S; e += 64) M2[e] = 0.0;
@@ -1021,6 +1021,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
         int stf;
         if constexpr (NP > 32) stf = factor_rows64<NP, false>(w, Hc, g, x);
         else stf = factor_tiles32(w, Hc, g, x);
+        stf = uniform_i(stf);
         if (stf != QP_SOLVED) { x_out = 0.0; iters_out = 0; return stf; }
         OSOT_PH_END(PH_CHOL);
         // (the substitution, NOT x = -J J'g: with H = A'A + eps I rank deficient, g lies in range(A') and the
@@ -1069,19 +1070,21 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
 #else
     if (NP == 32 && diag_h && have_prev && !local_eq && n_eq >= 8 && n_eq <= 32 && n - n_eq <= kNullMax) {
 #endif
-        const int r_ns = nullspace_equalities32<PROF>(reinterpret_cast<const WaveCtx<32>&>(w), n_eq, hdiag, g, xprev, x, prof);
+        const int r_ns = uniform_i(nullspace_equalities32<PROF>(reinterpret_cast<const WaveCtx<32>&>(w), n_eq, hdiag, g, xprev, x, prof));
         if (r_ns >= 0) { iq = r_ns; iters += n_eq; used_nullspace = true; n_eq = 0; }
     }
-    double a_next = (n_eq > 0) ? row_elem<NP>(w, w.eqlist[0], c) : 0.0;
+    // (uniform_i / uniform_d below: table entries and reduction results ARE wave-uniform, said so that the loop's control flow
+    // and its counters stay on the scalar unit -- see osot_team.h)
+    double a_next = (n_eq > 0) ? row_elem<NP>(w, uniform_i(w.eqlist[0]), c) : 0.0;
     for (int e = 0; e < n_eq; ++e) {
-        const int r = w.eqlist[e];
+        const int r = uniform_i(w.eqlist[e]);
         const double a = a_next;
-        const double lo = w.rlo[r];
-        const int src = w.rsrc[r];
+        const double lo = uniform_d(w.rlo[r]);
+        const int src = uniform_i(w.rsrc[r]);
         // right-hand side relative to x: lo - a'x, or a'(x_prev - x) for an optimality row (x_prev, the solution of the
         // last level solved, satisfies a'x_prev = a'x_j for the rows of every level j above it)
         const double xref = (src >= 0) ? xprev : 0.0;
-        if (e + 1 < n_eq) a_next = row_elem<NP>(w, w.eqlist[e + 1], c);   // prefetch
+        if (e + 1 < n_eq) a_next = row_elem<NP>(w, uniform_i(w.eqlist[e + 1]), c);   // prefetch
         OSOT_SUB_BEGIN();
         if (h == 0) V0[c] = a;
         wave_sync();
@@ -1090,7 +1093,8 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
         const double d2 = (c >= iq) ? d : 0.0;
         double dd, nd2;
         colsum2<NP>(d * d, d2 * d2, dd, nd2);
-        const double resid = lo + colsum<NP>(a * (xref - x));
+        dd = uniform_d(dd); nd2 = uniform_d(nd2);
+        const double resid = lo + uniform_d(colsum<NP>(a * (xref - x)));
         OSOT_SUB_END(PH_EQ_RED);
         if (!direction_is_independent<NP>(w, nd2, dd, d2, a, iq)) {   // row is (numerically) a combination of the rows already in
             // an optimality row of an upper level (src >= 0) is consistent BY CONSTRUCTION (x of that level
@@ -1203,15 +1207,15 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                 okc = has_box && (bcast_i(box_state, var) == 0) && ((code < n) ? (bnd > -kInfty) : (bnd < kInfty));
             } else if (code >= 2 * n && code < 2 * n + 2 * nrows) {
                 const int r = (code - 2 * n) >> 1;
-                const double bnd = (code & 1) ? w.rup[r] : w.rlo[r];
-                okc = (w.rowstate[r] == 0) && ((code & 1) ? (bnd < kInfty) : (bnd > -kInfty));
+                const double bnd = uniform_d((code & 1) ? w.rup[r] : w.rlo[r]);
+                okc = (uniform_i(w.rowstate[r]) == 0) && ((code & 1) ? (bnd < kInfty) : (bnd > -kInfty));
             }
             if (!okc) continue;
         } else if (!margin_pass && hot_check) {
             const bool mine = (c >= me && c < iq);
             double um = mine ? uq : INFINITY;
             int pos = c;
-            const double uabs = colmax<NP>(mine ? fabs(uq) : 0.0);
+            const double uabs = uniform_d(colmax<NP>(mine ? fabs(uq) : 0.0));
             colargmin<NP>(um, pos);
             pos = uniform_i(pos);
             um = bcast(um, 0);
@@ -1339,7 +1343,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
         }   // (end of the scan trip)
         if (++iters > max_iter) { status = QP_MAX_ITER; break; }
 
-        const int ip = code;
+        const int ip = uniform_i(code);
         double s_ip = bcast(cand, 0);
         double u_new = 0.0;
         const bool ip_box = ip < 2 * n;
@@ -1349,8 +1353,8 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
         double np = 0.0;   // lane-distributed normal (general rows only)
         if (!ip_box) np = ip_sgn * row_elem<NP>(w, ip_row, c);
         const unsigned long long ip_ptr = ip_box ? 0ull : w.rptr[ip_row];
-        const bool ip_unit = !ip_box && (ip_ptr & 1ull);      // unit row e_i: d = J'n is a row read, like a bound
-        const int ip_uidx = ip_unit ? (int)(ip_ptr >> 1) : 0;
+        const bool ip_unit = uniform_b(!ip_box && (ip_ptr & 1ull));      // unit row e_i: d = J'n is a row read, like a bound
+        const int ip_uidx = uniform_i(ip_unit ? (int)(ip_ptr >> 1) : 0);
         if (mode == 1) {   // slack of the hot constraint at the current iterate (either sign)
             if (ip_box) s_ip = bcast((ip < n) ? (x - lb) : (ub - x), ip_var);
             else {
@@ -1375,10 +1379,11 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
             const double d2 = (c >= iq) ? d : 0.0;
             double dd, nd2;
             if (diag_dd) {   // n' H^-1 n from the diagonal of H^-1
-                nd2 = colsum<NP>(d2 * d2);
-                dd = ip_box ? bcast(hinv, ip_var) : (ip_unit ? bcast(hinv, ip_uidx) : colsum<NP>(np * np * hinv));
+                nd2 = uniform_d(colsum<NP>(d2 * d2));
+                dd = ip_box ? bcast(hinv, ip_var) : (ip_unit ? bcast(hinv, ip_uidx) : uniform_d(colsum<NP>(np * np * hinv)));
             } else {
                 colsum2<NP>(d * d, d2 * d2, dd, nd2);
+                dd = uniform_d(dd); nd2 = uniform_d(nd2);
             }
             const bool z_ok = direction_is_independent<NP>(w, nd2, dd, d2,
                                                            ip_box ? ((c == ip_var) ? 1.0 : 0.0) : (ip_unit ? ((c == ip_uidx) ? 1.0 : 0.0) : np), iq);
@@ -1449,7 +1454,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                 // optimality rows leave no freedom: slack = O(eps * cond)), the point is optimal; otherwise the
                 // QP is infeasible (eiquadprog.hpp:376-382).
                 const double bmag = ip_box ? fabs(bcast((ip < n) ? lb : ub, ip_var))
-                                           : fabs((ip & 1) ? w.rup[ip_row] : w.rlo[ip_row]);
+                                           : fabs(uniform_d((ip & 1) ? w.rup[ip_row] : w.rlo[ip_row]));
                 if (-s_ip <= fmin(kSlackTol * fmax(1.0, bmag), kSlackCap)) {
                     // accepted as satisfied: the LOWER levels must accept the same point (their optimality rows pin x
                     // to it), so the bound is relaxed by what was accepted for the rest of this instance's cascade --

@@ -59,6 +59,16 @@ __device__ __forceinline__ int launder_i(int v) { asm volatile("" : "+v"(v)); re
 __device__ __forceinline__ int launder_s(int v) { asm volatile("" : "+s"(v)); return v; }
 
 __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// The same for a double / a predicate that IS wave-uniform but that the compiler cannot know to be: the result of a DPP /
+// permlane reduction network, or a value loaded through a pointer that may be global.  Branching on such a value makes the
+// branch an exec-mask branch and -- when it leaves or continues a loop -- every loop-carried scalar (working-set size,
+// iteration count, mode) a vector register; two v_readfirstlane put the control flow back on the scalar unit.
+__device__ __forceinline__ double uniform_d(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ bool uniform_b(bool p) { return __builtin_amdgcn_readfirstlane(p ? 1 : 0) != 0; }
 
 // this lane's position in the wavefront ("lane = row" loops; not the column index c of osot_qp_core.h's WaveCtx)
 __device__ __forceinline__ int phys_lane() { return (int)(threadIdx.x & 63u); }

@@ -32,6 +32,8 @@ inline void wave_priority_by_rank(unsigned, unsigned) {}
 inline int launder_i(int v) { return v; }
 inline int launder_s(int v) { return v; }
 inline int uniform_i(int v) { int out[64]; emu::allgather(&v, out, sizeof(int)); return out[0]; }
+inline double uniform_d(double v) { double out[64]; emu::allgather(&v, out, sizeof(double)); return out[0]; }
+inline bool uniform_b(bool p) { int v = p ? 1 : 0; int out[64]; emu::allgather(&v, out, sizeof(int)); return out[0] != 0; }
 
 inline unsigned long long wave_ballot(bool p) {
     int v = p ? 1 : 0, all[64]; emu::allgather(&v, all, sizeof(int));
