@@ -110,7 +110,8 @@ struct DevBatch {
 // EXTRA: the instantiation that knows about non-diagonal weights (WA / Wb operands) and Task::setActive(false); the plain
 // one carries none of that code (registers, scalar loads, branches) -- launches pick it whenever the plan has no dense-weight
 // level and every task is active
-template <int NP, bool PROF, bool EXTRA>
+// BOX: plans without constraint rows (the bounds are the only inequalities; see gi_inequalities)
+template <int NP, bool PROF, bool EXTRA, bool BOX = false>
 __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D, const long long inst, const int lane, char* osot_smem) {
     constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
     constexpr int HB = (NP % 16 == 0) ? 16 : 8;   // rows of H per broadcast group of the register H build
@@ -204,7 +205,9 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
         const int c = w.c, h = w.h;
         const bool valid = c < n;
         const int m = P.m[k], ma = P.ma[k];
-        int* hotk = D.hot ? D.hot + (inst * P.L + k) * WaveCtx<NP>::LW : nullptr;
+        // hot start (osot_solver_set_hotstart, default off) lives in the EXTRA instantiation only: the plain one carries none of its
+        // code (its branches at the top of every active-set trip, a vector and a handful of scalar registers: measured +4 %)
+        int* hotk = (EXTRA && D.hot) ? D.hot + (inst * P.L + k) * WaveCtx<NP>::LW : nullptr;
         const int hotcode = hotk ? hotk[c] : -1;   // (requested here: the answer is not needed before the inequality loop)
         const double* Ak = D.A[k] ? D.A[k] + inst * ma * n : nullptr;
         const double* bk = D.b[k] + inst * m;
@@ -463,11 +466,11 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
         OSOT_PH_END(PH_HBUILD);
         int st;
         if (NP > 32) {   // must be inlined: hacc would otherwise be passed through scratch memory
-            OSOT_ALWAYS_INLINE_CALL st = gi_solve<NP, PROF>(w, nrows, g, diag_h, hdiag, hacc,
+            OSOT_ALWAYS_INLINE_CALL st = gi_solve<NP, PROF, BOX>(w, nrows, g, diag_h, hdiag, hacc,
                                                                    has_box, lb, ub, P.max_iter, any, x, x, iters, prof, slack,
                                                                    false, 0.0, hotcode, hotk);
         } else {          // NP = 32: inlined as well (as a CALL the solver spends ~50 % more cycles: the tiles travel through scratch)
-            OSOT_ALWAYS_INLINE_CALL st = gi_solve<NP, PROF>(w, nrows, g, diag_h, hdiag, hacc,
+            OSOT_ALWAYS_INLINE_CALL st = gi_solve<NP, PROF, BOX>(w, nrows, g, diag_h, hdiag, hacc,
                                            has_box, lb, ub, P.max_iter, any, x, x, iters, prof, slack, lowrank, xprep,
                                            hotcode, hotk);
         }
@@ -520,12 +523,12 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
 
 __device__ __forceinline__ long long dispatch_instance(const DevBatch& D, char* smem);   // (below, with the order workgroup)
 
-template <int NP, bool PROF, bool EXTRA = false>
+template <int NP, bool PROF, bool EXTRA = false, bool BOX = false>
 __global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : 1)) osot_cascade_kernel(const DevPlan P, const DevBatch D) {
     OSOT_DYNAMIC_LDS(osot_smem);
     const long long inst = dispatch_instance(D, osot_smem);
     if (inst < 0) return;
-    cascade_body<NP, PROF, EXTRA>(P, D, inst, (int)threadIdx.x, osot_smem);
+    cascade_body<NP, PROF, EXTRA, BOX>(P, D, inst, (int)threadIdx.x, osot_smem);
 }
 
 // Longest-first dispatch.  One wavefront solves one instance and an MI355X holds 2048 of them at a time, so a
@@ -1123,7 +1126,7 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
 // (coman_ik.cpp:186-192: `stack->update(); solver->solve(dq)`).  The assembled b / W / box / rows still go through their
 // HBM arrays (they are outputs of the update in their own right) but come back from the CU's own L1 / L2 lines; what is
 // saved is a launch, its tail and the gap between the two (18 + ~4 us of a 227 us step at BASELINE config 3).
-template <int NP, bool EXTRA = false>
+template <int NP, bool EXTRA = false, bool BOX = false>
 __global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : 1)) osot_cycle_kernel(const DevUpdate U, const DevPlan P, const DevBatch D) {
     OSOT_DYNAMIC_LDS(osot_smem);
     const long long inst = dispatch_instance(D, osot_smem);
@@ -1134,7 +1137,7 @@ __global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : 1)) osot_cycle_
     workgroup_fence();      // the update's global stores are visible to the cascade's loads (same workgroup)
     __syncthreads();
     const long long tc1 = D.prof ? (long long)clock64() : 0;
-    cascade_body<NP, false, EXTRA>(P, D, inst, (int)threadIdx.x, osot_smem);
+    cascade_body<NP, false, EXTRA, BOX>(P, D, inst, (int)threadIdx.x, osot_smem);
     if (D.prof && threadIdx.x == 0) {   // diagnostic (osot_solver_profile_cycle): shader-clock cycles of the two halves
         D.prof[inst * 4] = tc1 - tc0;
         D.prof[inst * 4 + 1] = (long long)clock64() - tc1;

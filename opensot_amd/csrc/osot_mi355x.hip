@@ -154,6 +154,10 @@ int osot_solver_create(const osot_plan_desc* plan, int max_batch, int device, os
         if (r == OSOT_OK) r = ensure_lds(osot_cycle_kernel<NP, false>, lds);
         if (r == OSOT_OK) r = ensure_lds(osot_cycle_kernel<NP, true>, lds);
         if (r == OSOT_OK) r = ensure_lds(osot_cascade_kernel<NP, false, true>, lds);
+        if constexpr (NP == 32) {
+            if (r == OSOT_OK) r = ensure_lds(osot_cascade_kernel<32, false, false, true>, lds);
+            if (r == OSOT_OK) r = ensure_lds(osot_cycle_kernel<32, false, true>, lds);
+        }
         return r;
     });
     if (rc != OSOT_OK) return rc;
@@ -464,8 +468,18 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
     for (int k = 0; k < pl.n_levels; ++k) extra = extra || (s->h_uplan.dense_level[k] != 0);
     if (prof && !fused && extra)   // (the instrumented instantiation carries no dense-weight / inactive-task code: it would
         return fail(OSOT_ERR_UNSUPPORTED, "phase profiling is not available for plans with dense weights or inactive tasks");   // solve another problem)
+    extra = extra || (D.hot != nullptr);   // (hot start: the EXTRA instantiation carries its code; never together with prof, see D.hot)
+    // plans without constraint rows (the bounds are the only inequalities): the BOX instantiation of the 32-column kernels
+    const bool box = !extra && !prof && P.nc == 0 && T == 32;
     by_np(T, [&](auto np) {
         constexpr int NP = decltype(np)::value;
+        if constexpr (NP == 32) {
+            if (box) {
+                if (fused) hipLaunchKernelGGL((osot_cycle_kernel<32, false, true>), dim3(grid), dim3(64), lds, st, *fused, P, D);
+                else hipLaunchKernelGGL((osot_cascade_kernel<32, false, false, true>), dim3(grid), dim3(64), lds, st, P, D);
+                return 0;
+            }
+        }
         if (fused) {
             if (extra) hipLaunchKernelGGL((osot_cycle_kernel<NP, true>), dim3(grid), dim3(64), lds, st, *fused, P, D);
             else hipLaunchKernelGGL((osot_cycle_kernel<NP, false>), dim3(grid), dim3(64), lds, st, *fused, P, D);
