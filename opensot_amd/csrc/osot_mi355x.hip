@@ -157,6 +157,7 @@ int osot_solver_create(const osot_plan_desc* plan, int max_batch, int device, os
         if constexpr (NP == 32) {
             if (r == OSOT_OK) r = ensure_lds(osot_cascade_kernel<32, false, false, true>, lds);
             if (r == OSOT_OK) r = ensure_lds(osot_cycle_kernel<32, false, true>, lds);
+            if (r == OSOT_OK) r = ensure_lds(osot_cascade_kernel<32, true, false, true>, lds);
         }
         return r;
     });
@@ -470,12 +471,13 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
         return fail(OSOT_ERR_UNSUPPORTED, "phase profiling is not available for plans with dense weights or inactive tasks");   // solve another problem)
     extra = extra || (D.hot != nullptr);   // (hot start: the EXTRA instantiation carries its code; never together with prof, see D.hot)
     // plans without constraint rows (the bounds are the only inequalities): the BOX instantiation of the 32-column kernels
-    const bool box = !extra && !prof && P.nc == 0 && T == 32;
+    const bool box = !extra && P.nc == 0 && T == 32;
     by_np(T, [&](auto np) {
         constexpr int NP = decltype(np)::value;
         if constexpr (NP == 32) {
             if (box) {
                 if (fused) hipLaunchKernelGGL((osot_cycle_kernel<32, false, true>), dim3(grid), dim3(64), lds, st, *fused, P, D);
+                else if (prof) hipLaunchKernelGGL((osot_cascade_kernel<32, true, false, true>), dim3(grid), dim3(64), lds, st, P, D);
                 else hipLaunchKernelGGL((osot_cascade_kernel<32, false, false, true>), dim3(grid), dim3(64), lds, st, P, D);
                 return 0;
             }
