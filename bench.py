@@ -282,8 +282,10 @@ def time_config(name, B, device, steps=20, warmup=5):
     st.set_timing(False)
     ok = int((st.status[:B] == 0).sum().item())
     NPk = 32 if plan.n <= 32 else (56 if plan.n <= 54 else 64)   # the cascade instantiation make_dev_plan picks (osot_host_plan.h)
-    traffic, src = pmc_traffic([(f"osot_cascade_kernel<{NPk}, false, false>", B + 1, 1)])
-    rf, rh = roofline_of(plan, B, kern_ms, launches, f"osot_cascade_kernel<{NPk},false>", traffic,
+    box = NPk == 32 and plan.nc == 0     # plans without constraint rows run the BOX instantiation (osot_solver_set_specialisation)
+    kname = f"osot_cascade_kernel<{NPk}, false, false, {'true' if box else 'false'}>"
+    traffic, src = pmc_traffic([(kname, B + 1, 1)])
+    rf, rh = roofline_of(plan, B, kern_ms, launches, kname + (" (BOX instantiation: bounds are the only inequalities)" if box else ""), traffic,
                          src or "no PMC passes committed for this kernel source: null rather than a stale figure")
     return {"workload": {"C2": "BASELINE configs[1]: 1-level Cartesian + Postural (soft priority), joint-limit box",
                          "C3": "BASELINE configs[2]", "C4": "BASELINE configs[3] shard: C3 + 16 self-collision rows",
@@ -667,14 +669,15 @@ def main():
         if all_ok is not None:
             out["solved_ok_all_ranks"] = f"{all_ok}/{Bg}"
         if launches > 0 and kern_ms > 0 and not stub:
-            traffic, src = pmc_traffic([("osot_cycle_kernel<32, false>", Bl // S + 1, 1)])   # (+ the order workgroup)
+            traffic, src = pmc_traffic([("osot_cycle_kernel<32, false, true>", Bl // S + 1, 1)])   # (+ the order workgroup)
             # S launches are in flight at a time (one per lane), each sharing the chip with the others: a launch's own duration is
             # not the time the chip needed for its instances.  The roofline figures therefore take the time of a whole STEP (all
             # lanes; it contains every launch of the step plus the order kernels and launch gaps, so it under-states the kernel).
             step_ms = 1e3 * elapsed / args.steps
             rf, rh = roofline_of(plan, Bl, step_ms if S > 1 else kern_ms, launches,
-                                 "osot_cycle_kernel<32,false> (AutoStack::update + the whole cascade of an instance by one wavefront: "
-                                 "fp64 MFMA H build + blocked Cholesky + null-space elimination, VALU/LDS active set)",
+                                 "osot_cycle_kernel<32,false,true> (AutoStack::update + the whole cascade of an instance by one wavefront: "
+                                 "fp64 MFMA H build + blocked Cholesky + null-space elimination, VALU/LDS active set; the BOX instantiation: "
+                                 "config 3 has no constraint rows, its only inequalities are the joint / velocity limit box)",
                                  None if traffic is None else traffic * S,
                                  (src + "; per launch x launches per step") if traffic else
                                  "no PMC passes committed for this kernel source: null rather than a stale figure")

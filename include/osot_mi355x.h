@@ -349,6 +349,13 @@ int osot_solver_set_schedule(osot_solver* s, int mode);
  * does not depend on the mode beyond round-off (each level's minimiser is unique); the iteration counts do: it pays
  * when the active sets persist from cycle to cycle and costs two iterations per constraint that has left the set. */
 int osot_solver_set_hotstart(osot_solver* s, int enabled);
+/* Kernel instantiation by plan structure.  enabled != 0 (default): a plan WITHOUT constraint rows (the bounds l <= x <= u are
+ * its only inequalities: a velocity stack with joint / velocity limits, BASELINE configs 2 and 3) of at most 32 variables runs
+ * the instantiation of the cascade that carries no constraint-row code (row classification, row scans, row normals);
+ * 0: every plan runs the general instantiation.  The two are the same arithmetic in the same order: results are bit-identical
+ * (tests/test_gpu_cascade.py), only the speed differs.  (The reference has nothing to mirror here: it is how one BackEnd
+ * covers plans of different shape without paying for the features a plan does not use.) */
+int osot_solver_set_specialisation(osot_solver* s, int enabled);
 /* instances the device works on at once for this solver's plan (one wavefront each: CUs x resident wavefronts per CU, from
  * the kernel's register and LDS footprint): the dispatch order is planned for it, and batches that are a multiple of it
  * waste no round */

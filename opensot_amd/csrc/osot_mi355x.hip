@@ -100,6 +100,7 @@ struct osot_solver {
     // hot start (osot_solver_set_hotstart): the inequality working set each level of each instance ended with
     double* d_rows = nullptr;   // [max_batch][rows_doubles] row tables (plans whose 64-lane kernels keep them out of LDS)
     int hotstart = 0;
+    int specialise = 1;         // osot_solver_set_specialisation: the BOX instantiation for plans without constraint rows
     int* d_hot = nullptr;    // [max_batch][n_levels][T] constraint codes, -1 = none (allocated when first switched on)
     int hot_T = 0;
 };
@@ -222,6 +223,12 @@ int osot_solver_set_schedule(osot_solver* s, int mode) {
     if (mode != OSOT_SCHEDULE_IN_ORDER && mode != OSOT_SCHEDULE_LONGEST_FIRST) return fail(OSOT_ERR_INVALID, "unknown schedule mode");
     s->schedule = mode;
     s->order_B = -1;
+    return OSOT_OK;
+}
+
+int osot_solver_set_specialisation(osot_solver* s, int enabled) {
+    if (!s) return fail(OSOT_ERR_INVALID, "null solver");
+    s->specialise = enabled ? 1 : 0;
     return OSOT_OK;
 }
 
@@ -471,7 +478,7 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
         return fail(OSOT_ERR_UNSUPPORTED, "phase profiling is not available for plans with dense weights or inactive tasks");   // solve another problem)
     extra = extra || (D.hot != nullptr);   // (hot start: the EXTRA instantiation carries its code; never together with prof, see D.hot)
     // plans without constraint rows (the bounds are the only inequalities): the BOX instantiation of the 32-column kernels
-    const bool box = !extra && P.nc == 0 && T == 32;
+    const bool box = s->specialise && !extra && P.nc == 0 && T == 32;
     by_np(T, [&](auto np) {
         constexpr int NP = decltype(np)::value;
         if constexpr (NP == 32) {

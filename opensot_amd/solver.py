@@ -276,6 +276,11 @@ class BatchedStack:
         QPOasesBackEnd.cpp:258-285); switching it on (again) forgets the recorded sets.  Default off."""
         abi.check(self._lib.osot_solver_set_hotstart(self._h, 1 if on else 0), "osot_solver_set_hotstart")
 
+    def set_specialisation(self, on=True):
+        """kernel instantiation by plan structure (default on): plans without constraint rows run the cascade instantiation
+        that carries no constraint-row code; results are bit-identical either way (osot_solver_set_specialisation)."""
+        abi.check(self._lib.osot_solver_set_specialisation(self._h, 1 if on else 0), "osot_solver_set_specialisation")
+
     def set_timing(self, on, stride=1):
         """HIP-event timing of the cascade / cycle launches (kernel_time_ms); stride k: every k-th launch only"""
         abi.check(self._lib.osot_solver_set_timing(self._h, (max(1, int(stride)) if on else 0)), "osot_solver_set_timing")

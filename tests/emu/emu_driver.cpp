@@ -1,3 +1,4 @@
+#include <cstdlib>
 // tests/emu/emu_driver.cpp -- TEST INFRASTRUCTURE ONLY.
 // Runs the product's kernel bodies (opensot_amd/csrc/osot_kernels.h, osot_qp_core.h) through the host
 // lock-step emulation in tests/emu/hip/hip_runtime.h, with HOST pointers in the batch structs.
@@ -36,7 +37,16 @@ extern "C" __attribute__((visibility("default"))) int emu_ihqp_solve(const osot_
     std::vector<double> rows_scratch(P.rows_in_global ? (size_t)b->B * P.rows_doubles : 1);
     D.rows_scratch = rows_scratch.data();
     const unsigned grid = (unsigned)b->B;
-    // (the emulation always runs the instantiation with the dense-weight / inactive-task code: it is a superset)
+    // (the emulation runs the instantiation with the dense-weight / inactive-task / hot-start code: it is a superset.  With
+    //  OSOT_EMU_BOX=1 in the environment a plan the product would give the BOX instantiation to -- no constraint rows, at most 32
+    //  variables, none of the EXTRA features in use -- runs THAT one: tests/test_emulated_kernels.py compares the two)
+    const char* want_box = getenv("OSOT_EMU_BOX");
+    bool extra = hot != nullptr || task_active != nullptr || (plan->has_regularisation && plan->regularisation_dense);
+    for (int k = 0; k < plan->n_levels; ++k) extra = extra || b->WA[k] != nullptr;
+    if (T == 32 && want_box && want_box[0] == '1' && !extra && P.nc == 0) {
+        emu::launch(osot_cascade_kernel<32, false, false, true>, grid, lds, 64, P, D);
+        return OSOT_OK + 100;   // (tells the test that the BOX instantiation ran)
+    }
     if (T == 32) emu::launch(osot_cascade_kernel<32, false, true>, grid, lds, 64, P, D);
     else if (T == 56) emu::launch(osot_cascade_kernel<56, false, true>, grid, lds, 64, P, D);
     else emu::launch(osot_cascade_kernel<64, false, true>, grid, lds, 64, P, D);

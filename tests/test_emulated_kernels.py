@@ -521,3 +521,25 @@ def test_hot_start_inverse_dynamics_emulated():
         ok = st0 == 0
         assert ok.any() and np.abs(dq0[ok] - dq1[ok]).max() < 1e-8 * max(1.0, np.abs(dq0[ok]).max())
     assert (it1[ok] <= it0[ok]).all()
+
+
+@pytest.mark.parametrize("cfg", ["C2", "C3"])
+def test_box_instantiation_matches_the_general_one(cfg, monkeypatch):
+    """plans without constraint rows (BASELINE configs 2 and 3: the bounds are the only inequalities) run the BOX instantiation
+    of the cascade on the device (osot_solver_set_specialisation, default on; osot_qp_core.h: gi_inequalities).  On the
+    emulator: the same instances through the BOX instantiation and through the full one agree bit for bit (dq, every level's
+    x, status, iteration counts), and the golden answers hold for both"""
+    plan, leaf = synth.make_velocity_stack(cfg, 24, seed=77)
+    po = pyoracle
+    asm = po.assemble(plan, leaf)
+    full = emu_cascade(plan, asm)
+    assert not emu_cascade.ran_box
+    monkeypatch.setenv("OSOT_EMU_BOX", "1")
+    box = emu_cascade(plan, asm)
+    assert emu_cascade.ran_box
+    for a, b in zip(full, box):
+        assert np.array_equal(a, b)
+    assert (box[2] == 0).all()
+    ref = po.ihqp_solve_batch(asm, po.BE_EIQP_EQ, nthreads=1)
+    ok = ref["status"] == 1
+    assert ok.all() and np.abs(box[0] - ref["dq"]).max() < 1e-8

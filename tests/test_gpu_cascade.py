@@ -470,3 +470,31 @@ def test_pipelined_lanes_match_single_launch_gpu(gpu_device):
     assert torch.equal(got_g, one.stack.dq[:B])
     with pytest.raises(ValueError):
         pipe.capture(3)            # odd: the solver's alternating order buffers would end on the wrong side
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,B", [("C2", 300), ("C3", 700)])
+def test_box_instantiation_is_bit_identical_gpu(gpu_device, cfg, B):
+    """osot_solver_set_specialisation: BASELINE configs 2 and 3 have no constraint rows (their only inequalities are the joint /
+    velocity limit box), so their launches run the BOX instantiation of the 32-column kernels (no row classification, no row
+    scans, no bound-or-row branches: osot_qp_core.h, gi_inequalities).  It is the same arithmetic in the same order as the
+    general instantiation: dq, status and iteration counts agree bit for bit, through osot_ihqp_solve and through osot_cycle,
+    over a rotation of drifting cycles"""
+    plan, leaf = synth.make_velocity_stack(cfg, B, seed=5150)
+    rng = np.random.default_rng(3)
+    leaves = [leaf, synth.perturb(leaf, rng, 0.01), synth.perturb(leaf, rng, 0.05)]
+    spec = BatchedStack(plan, B, device=0, want_levels=True)
+    gen = BatchedStack(plan, B, device=0, want_levels=True)
+    gen.set_specialisation(False)
+    for lf in leaves:
+        for st in (spec, gen):
+            st.update(st.load_leaf(lf)); st.solve(B)
+        torch.cuda.synchronize()
+        assert (spec.status[:B] == 0).all()
+        assert torch.equal(spec.dq[:B], gen.dq[:B])
+        assert torch.equal(spec.x_levels[:B], gen.x_levels[:B])
+        assert torch.equal(spec.status[:B], gen.status[:B]) and torch.equal(spec.iterations[:B], gen.iterations[:B])
+        for st in (spec, gen):
+            st.cycle(st.load_leaf(lf))
+        torch.cuda.synchronize()
+        assert torch.equal(spec.dq[:B], gen.dq[:B]) and torch.equal(spec.iterations[:B], gen.iterations[:B])
