@@ -476,7 +476,11 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
     for (int k = 0; k < pl.n_levels; ++k) extra = extra || (s->h_uplan.dense_level[k] != 0);
     if (prof && !fused && extra)   // (the instrumented instantiation carries no dense-weight / inactive-task code: it would
         return fail(OSOT_ERR_UNSUPPORTED, "phase profiling is not available for plans with dense weights or inactive tasks");   // solve another problem)
-    extra = extra || (D.hot != nullptr);   // (hot start: the EXTRA instantiation carries its code; never together with prof, see D.hot)
+    extra = extra || (D.hot != nullptr);
+    {   // developer knob: the EXTRA instantiation for every launch (A/B of the two register allocations)
+        static const char* force = getenv("OSOT_DEBUG_FORCE_EXTRA");
+        if (force && force[0] == '1' && !prof) extra = true;
+    }   // (hot start: the EXTRA instantiation carries its code; never together with prof, see D.hot)
     // plans without constraint rows (the bounds are the only inequalities): the BOX instantiation of the 32-column kernels
     const bool box = s->specialise && !extra && P.nc == 0 && T == 32;
     by_np(T, [&](auto np) {
