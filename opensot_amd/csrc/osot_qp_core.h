@@ -150,7 +150,11 @@ __device__ __forceinline__ double jt_rows_dot(const WaveCtx<NP>& w, const double
 #ifndef OSOT_DOT_CH
 #define OSOT_DOT_CH 16
 #endif
-    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = (NP % 16 == 0) ? OSOT_DOT_CH : 8;
+#ifndef OSOT_DOT_CH56
+#define OSOT_DOT_CH56 28    // elements in flight per trip of the 56-row layout (a divisor of 56, a multiple of 4): one wavefront per
+                            // SIMD hides an LDS round trip with loads in flight only -- 8 per trip: 579 us per config-5 launch, 28: 562
+#endif
+    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = (NP % 16 == 0) ? OSOT_DOT_CH : OSOT_DOT_CH56;
     const double* row = w.M2 + w.c * S + w.h;
     const double* v = vec + w.h;
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
@@ -172,7 +176,7 @@ __device__ __forceinline__ double jt_rows_dot(const WaveCtx<NP>& w, const double
 // z_c = sum_j JT[j][c] * vec[j]   (column walk, j split over the halves)
 template <int NP>
 __device__ __forceinline__ double jt_cols_dot(const WaveCtx<NP>& w, const double* vec) {
-    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = (NP % 16 == 0) ? OSOT_DOT_CH : 8;
+    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = (NP % 16 == 0) ? OSOT_DOT_CH : OSOT_DOT_CH56;
     const double* col = w.M2 + w.h * S + w.c;
     const double* v = vec + w.h;
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
