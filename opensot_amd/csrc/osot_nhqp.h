@@ -71,8 +71,12 @@ __device__ __forceinline__ double dot_half(const double* a, int sa, const double
 // own lanes (lane j = row j, the inner index split over the two halves), and the QL sweep is a scalar recurrence on (d, e)
 // -- held one entry per lane, read with v_readlane -- whose plane rotations touch two entries of every lane's OWN row of
 // the eigenvector matrix.
-__device__ inline void sym_eig32(double* K, double* E, int k, int c, int h) {
+// (force-inlined, and k / the reduction results said to be wave-uniform: as a CALL every argument arrives in a vector register, so
+//  the size, every loop bound derived from it and with them the whole QL recurrence were compiled as divergent control flow
+//  -- loop counters in VGPRs, exec-mask branches, a null check in front of every access through the generic pointers)
+__device__ __forceinline__ void sym_eig32(double* K, double* E, int k_in, int c, int h) {
     constexpr double kEps = 2.220446049250313e-16;
+    const int k = uniform_i(k_in);
     double d = 0.0, e = 0.0;                 // lane j: d[j], e[j]
     const bool wr = (h == 0);
     // ---- reduction to tridiagonal form (tred2): for i = k-1 .. 1 the row i is reflected onto e_{i-1}
@@ -81,12 +85,12 @@ __device__ inline void sym_eig32(double* K, double* E, int k, int c, int h) {
         double hv = 0.0, e_i;
         if (l > 0) {
             double ai = (c <= l) ? K[i * kNS + c] : 0.0;
-            const double scale = colsum<32>(fabs(ai));
+            const double scale = uniform_d(colsum<32>(fabs(ai)));
             if (scale == 0.0) {
                 e_i = bcast(ai, l);
             } else {
                 ai *= fast_rcp(scale);
-                hv = colsum<32>(ai * ai);
+                hv = uniform_d(colsum<32>(ai * ai));
                 const double f0 = bcast(ai, l);
                 double sq, rs;
                 fast_sqrt_rsqrt(hv, sq, rs);
@@ -102,7 +106,7 @@ __device__ inline void sym_eig32(double* K, double* E, int k, int c, int h) {
                 if (c <= l)
                     for (int kk = h; kk <= l; kk += 2) pj = fma(K[c * kNS + kk], K[i * kNS + kk], pj);
                 pj = halfsum<32>(pj) * ih;
-                const double f1 = colsum<32>((c <= l) ? pj * ai : 0.0);
+                const double f1 = uniform_d(colsum<32>((c <= l) ? pj * ai : 0.0));
                 const double hh2 = 0.5 * f1 * ih;
                 const double qj = (c <= l) ? pj - hh2 * ai : 0.0;      // q = p - (u'p / 2H) u
                 if (wr) E[c] = qj;           // (E is free until the end: its first row carries q)
@@ -145,7 +149,7 @@ __device__ inline void sym_eig32(double* K, double* E, int k, int c, int h) {
     // (deflation test against the norm of the whole tridiagonal matrix, as in EISPACK's tql2 -- not against the two
     //  neighbouring diagonal entries: the Gram matrices here are often rank deficient, and a cluster of round-off-level
     //  eigenvalues never passes a purely local test)
-    const double anorm = colmax<32>((c < k) ? fabs(d) + fabs(e) : 0.0);
+    const double anorm = uniform_d(colmax<32>((c < k) ? fabs(d) + fabs(e) : 0.0));
     const double etol = OSOT_QL_TOL * kEps * anorm;
     for (int l = 0; l < k; ++l) {
         for (int iter = 0; iter < 60; ++iter) {
