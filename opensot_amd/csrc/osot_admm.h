@@ -44,8 +44,10 @@ struct DevAdmm {
 };
 
 // lane-c value summed / maxed over the 64 lanes
-__device__ __forceinline__ double wsum64(double v) { return colsum<64>(v); }
-__device__ __forceinline__ double wmax64(double v) { return colmax<64>(v); }
+// (uniform_d: the results are wave-uniform and the iteration's exits depend on them -- said so, the loop's control flow and its
+//  counters stay on the scalar unit: osot_team.h)
+__device__ __forceinline__ double wsum64(double v) { return uniform_d(colsum<64>(v)); }
+__device__ __forceinline__ double wmax64(double v) { return uniform_d(colmax<64>(v)); }
 
 __global__ void __launch_bounds__(64) osot_admm_kernel(const DevAdmm Q) {
     OSOT_DYNAMIC_LDS(admm_smem);
