@@ -1297,7 +1297,10 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
 #ifndef OSOT_SCAN_SC
 #define OSOT_SCAN_SC 16
 #endif
-                constexpr int SC = OSOT_SCAN_SC;
+#ifndef OSOT_SCAN_SC56
+#define OSOT_SCAN_SC56 28   // (the 56-row layout: 28 loads per trip of the row walk -- two trips for n = 50 instead of four: 565 -> 546-553 us per config-5 launch; 52: 572)
+#endif
+                constexpr int SC = (NP == 56) ? OSOT_SCAN_SC56 : OSOT_SCAN_SC;
                 for (; cc + SC <= n; cc += SC) {
                     double e[SC];
 #pragma unroll
