@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
 
 #define OSOT_DYNAMIC_LDS(name) char* name = emu::dyn_smem_ptr()
 #define OSOT_STATIC_LDS(type, name, count) static type name[count]
@@ -32,8 +34,24 @@ inline void wave_priority_by_rank(unsigned, unsigned) {}
 inline int launder_i(int v) { return v; }
 inline int launder_s(int v) { return v; }
 inline int uniform_i(int v) { int out[64]; emu::allgather(&v, out, sizeof(int)); return out[0]; }
-inline double uniform_d(double v) { double out[64]; emu::allgather(&v, out, sizeof(double)); return out[0]; }
-inline bool uniform_b(bool p) { int v = p ? 1 : 0; int out[64]; emu::allgather(&v, out, sizeof(int)); return out[0] != 0; }
+// uniform_d / uniform_b DECLARE a value wave-uniform (on the device: v_readfirstlane, i.e. lane 0's value for everybody, silently).
+// Here every lane's value is at hand, so the declaration is CHECKED: a lane that disagrees with lane 0 (bit pattern; NaNs of
+// different payload count as different) aborts the test run with a message.  uniform_i is also used as "take the first
+// lane's value" on purpose (colargmin payloads), so it is not checked.
+inline void emu_uniform_violation(const char* what, int lane, double a, double b) {
+    fprintf(stderr, "emu: %s declared wave-uniform, but lane %d holds %.17g and lane 0 holds %.17g\n", what, lane, a, b);
+    abort();
+}
+inline double uniform_d(double v) {
+    double out[64]; emu::allgather(&v, out, sizeof(double));
+    for (int i = 1; i < 64; ++i) if (std::memcmp(&out[i], &out[0], sizeof(double)) != 0) emu_uniform_violation("uniform_d", i, out[i], out[0]);
+    return out[0];
+}
+inline bool uniform_b(bool p) {
+    int v = p ? 1 : 0; int out[64]; emu::allgather(&v, out, sizeof(int));
+    for (int i = 1; i < 64; ++i) if (out[i] != out[0]) emu_uniform_violation("uniform_b", i, out[i], out[0]);
+    return out[0] != 0;
+}
 
 inline unsigned long long wave_ballot(bool p) {
     int v = p ? 1 : 0, all[64]; emu::allgather(&v, all, sizeof(int));
