@@ -1490,10 +1490,6 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                 }
                 failed = true; break;
             }
-#ifdef OSOT_EMU_TRACE
-            if (c == 0 && h == 0) printf("  trip iq=%d me=%d ip=%d (%s %d) s_ip=%.3e t1=%.3e t2=%.3e nd2=%.3e dd=%.3e z_ok=%d -> %s\n", iq, me, ip,
-                ip_box ? "box" : (ip_unit ? "unit" : "row"), ip_box ? ip_var : ip_row, s_ip, t1, t2, nd2, dd, (int)z_ok, (t2 <= t1) ? "ADD" : "drop");
-#endif
             if (t2 <= t1) {
                 // full step: constraint ip becomes active
                 x += t2 * z;
