@@ -11,8 +11,9 @@ from opensot_amd.solver import BatchedStack
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 drift = float(sys.argv[2]) if len(sys.argv) > 2 else 0.01
+cfg = sys.argv[3] if len(sys.argv) > 3 else "C5"      # (C3 / C4: the velocity stacks, for comparison)
 K, steps = 4, 40
-plan, leaf = synth.make_id_stack(B, seed=5000)
+plan, leaf = synth.make_id_stack(B, seed=5000) if cfg == "C5" else synth.make_velocity_stack(cfg, B, seed=4000)
 rng = np.random.default_rng(77)
 leaves = [leaf]
 for _ in range(K - 1):
