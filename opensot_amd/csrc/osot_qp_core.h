@@ -129,6 +129,14 @@ struct WaveCtx {
 // a_r[col] for lane-column col (0 beyond n).  Branch-free: a unit row reads a harmless valid address
 // (safe_row) and discards the value; the load is a global_load (address space 1), not a flat one.
 template <int NP>
+__device__ __forceinline__ double row_elem_p(const WaveCtx<NP>& w, unsigned long long p, int col) {   // (p = the row's table entry)
+    const bool unit = (p & 1ull) != 0ull;
+    const unsigned long long addr = unit ? w.safe_row : p;
+    const double v = OSOT_GLOBAL_F64(addr)[(col < w.n) ? col : 0];
+    const double uv = (col == (int)(p >> 1)) ? 1.0 : 0.0;
+    return unit ? uv : ((col < w.n) ? v : 0.0);
+}
+template <int NP>
 __device__ __forceinline__ double row_elem(const WaveCtx<NP>& w, int r, int col) {
     const unsigned long long p = w.rptr[r];
     const bool unit = (p & 1ull) != 0ull;
@@ -1194,6 +1202,12 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
     const int hot_n = __builtin_popcountll(wave_ballot(hotcode >= 0 && h == 0));
     int hot_i = 0;
     bool hot_check = false;     // hot additions were made: their multipliers have to be looked at
+    // table entries of the hot list's rows, lane q = entry q, fetched in ONE round trip when the first hot trip starts (the
+    // table may live in device memory: bound, state and row address were three dependent loads in front of every hot trip)
+    bool hm_loaded = false;
+    double hm_bnd = 0.0;
+    int hm_state = 0;
+    unsigned long long hm_ptr = 0ull;
     constexpr double kHotDropTol = 1.0e-13;   // a multiplier below -kHotDropTol max|u| is negative (above: round-off of zero)
     for (;;) {
         OSOT_SUB_BEGIN();
@@ -1203,7 +1217,18 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
         double cand = 0.0;
         int code = kNone;
         double u_rev = 0.0;
+        unsigned long long hot_ptr = 0ull;    // mode 1, a row: its table entry (from the list's metadata)
         if (!margin_pass && hot_i < hot_n) {
+            if (!hm_loaded) {
+                hm_loaded = true;
+                if (hotcode >= 2 * n && hotcode < 2 * n + 2 * nrows) {
+                    const int rq = (hotcode - 2 * n) >> 1;
+                    hm_bnd = (hotcode & 1) ? w.rup[rq] : w.rlo[rq];
+                    hm_state = w.rowstate[rq];
+                    hm_ptr = w.rptr[rq];
+                }
+            }
+            const int hq = hot_i;      // (entry hq lives in lane hq)
             code = bcast_i(hotcode, hot_i);
             hot_i++;
             mode = 1;
@@ -1214,9 +1239,9 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                 const double bnd = bcast((code < n) ? lb : ub, var);
                 okc = has_box && (bcast_i(box_state, var) == 0) && ((code < n) ? (bnd > -kInfty) : (bnd < kInfty));
             } else if (code >= 2 * n && code < 2 * n + 2 * nrows) {
-                const int r = (code - 2 * n) >> 1;
-                const double bnd = uniform_d((code & 1) ? w.rup[r] : w.rlo[r]);
-                okc = (uniform_i(w.rowstate[r]) == 0) && ((code & 1) ? (bnd < kInfty) : (bnd > -kInfty));
+                const double bnd = bcast(hm_bnd, hq);
+                okc = (bcast_i(hm_state, hq) == 0) && ((code & 1) ? (bnd < kInfty) : (bnd > -kInfty));
+                hot_ptr = ((unsigned long long)(unsigned)bcast_i((int)(hm_ptr >> 32), hq) << 32) | (unsigned long long)(unsigned)bcast_i((int)(hm_ptr & 0xffffffffull), hq);
             }
             if (!okc) continue;
         } else if (!margin_pass && hot_check) {
@@ -1362,8 +1387,8 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
         const int ip_row = ip_box ? 0 : (ip - 2 * n) >> 1;
         const double ip_sgn = ip_box ? (ip < n ? 1.0 : -1.0) : ((ip & 1) ? -1.0 : 1.0);
         double np = 0.0;   // lane-distributed normal (general rows only)
-        if (!ip_box) np = ip_sgn * row_elem<NP>(w, ip_row, c);
-        const unsigned long long ip_ptr = ip_box ? 0ull : w.rptr[ip_row];
+        const unsigned long long ip_ptr = ip_box ? 0ull : ((mode == 1) ? hot_ptr : w.rptr[ip_row]);
+        if (!ip_box) np = ip_sgn * row_elem_p<NP>(w, ip_ptr, c);
         const bool ip_unit = uniform_b(!ip_box && (ip_ptr & 1ull));      // unit row e_i: d = J'n is a row read, like a bound
         const int ip_uidx = uniform_i(ip_unit ? (int)(ip_ptr >> 1) : 0);
         if (mode == 1) {   // slack of the hot constraint at the current iterate (either sign)
