@@ -594,7 +594,7 @@ def main():
     # with the HIP events that give the kernel's own duration
     graph_steps, graph_note, graph_elapsed, graph_host_ms, graph_diff = 0, None, None, None, None
     if not args.no_graph and not stub and not use_dist and streams is not None:
-        cand = [g for g in range(4, 21, 2) if args.steps % g == 0]
+        cand = [g for g in range(4, 51, 2) if args.steps % g == 0]
         if cand:
             try:
                 cyc.capture(max(cand))
