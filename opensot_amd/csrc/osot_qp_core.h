@@ -204,6 +204,77 @@ __device__ __forceinline__ double jt_cols_dot(const WaveCtx<NP>& w, const double
     return halfsum<NP>((acc0 + acc1) + (acc2 + acc3));
 }
 
+// TWO products in one pass over JT (the equality phase adds its rows in pairs: gi_solve): the reads of JT -- what a pass costs,
+// above all at one wavefront per SIMD -- are shared, each element feeds two accumulator sets.
+template <int NP>
+__device__ __forceinline__ void jt_rows_dot2(const WaveCtx<NP>& w, const double* va, const double* vb, double& da, double& db) {
+    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = (NP == 32) ? 8 : ((NP == 56) ? 28 : 16);
+    const double* row = w.M2 + w.c * S + w.h;
+    const double* pa = va + w.h;
+    const double* pb = vb + w.h;
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+#pragma unroll
+    for (int k0 = 0; k0 < NP / HV; k0 += CH) {
+        double m[CH], xa[CH], xb[CH];
+#pragma unroll
+        for (int t = 0; t < CH; ++t) m[t] = row[(k0 + t) * HV];
+#pragma unroll
+        for (int t = 0; t < CH; ++t) { xa[t] = pa[(k0 + t) * HV]; xb[t] = pb[(k0 + t) * HV]; }
+#pragma unroll
+        for (int t = 0; t < CH; t += 2) {
+            a0 = fma(m[t], xa[t], a0); a1 = fma(m[t + 1], xa[t + 1], a1);
+            b0 = fma(m[t], xb[t], b0); b1 = fma(m[t + 1], xb[t + 1], b1);
+        }
+    }
+    da = halfsum<NP>(a0 + a1);
+    db = halfsum<NP>(b0 + b1);
+}
+template <int NP>
+__device__ __forceinline__ void jt_cols_dot2(const WaveCtx<NP>& w, const double* va, const double* vb, double& za, double& zb) {
+    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = (NP == 32) ? 8 : ((NP == 56) ? 28 : 16);
+    const double* col = w.M2 + w.h * S + w.c;
+    const double* pa = va + w.h;
+    const double* pb = vb + w.h;
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+#pragma unroll
+    for (int j0 = 0; j0 < NP / HV; j0 += CH) {
+        double m[CH], xa[CH], xb[CH];
+#pragma unroll
+        for (int t = 0; t < CH; ++t) m[t] = col[(j0 + t) * HV * S];
+#pragma unroll
+        for (int t = 0; t < CH; ++t) { xa[t] = pa[(j0 + t) * HV]; xb[t] = pb[(j0 + t) * HV]; }
+#pragma unroll
+        for (int t = 0; t < CH; t += 2) {
+            a0 = fma(m[t], xa[t], a0); a1 = fma(m[t + 1], xa[t + 1], a1);
+            b0 = fma(m[t], xb[t], b0); b1 = fma(m[t + 1], xb[t + 1], b1);
+        }
+    }
+    za = halfsum<NP>(a0 + a1);
+    zb = halfsum<NP>(b0 + b1);
+}
+// the rank-2 form of householder_add's update: rows j >= iq of JT lose  va[j] wa[c] + vb[j] wb[c]  (va = beta_a v_a in one staging
+// vector, vb = beta_b v_b in another, both zero below their pivot; wa = J2 v_a, wb = (J2 H_a) v_b at my column)
+template <int NP>
+__device__ __forceinline__ void householder_apply2(const WaveCtx<NP>& w, const double* va, const double* vb, double wa, double wb, int iq) {
+    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
+    const int c = w.c, h = w.h, n = w.n;
+    constexpr int RT = (NP == 64) ? 16 : ((NP == 56) ? 8 : 4);
+    constexpr int TRIP = RT * HV;
+    for (int jj = iq & ~(TRIP - 1); jj < n; jj += TRIP) {
+        double* mrow = w.M2 + (jj + h) * S + c;
+        const double* pa = va + jj + h;
+        const double* pb = vb + jj + h;
+        double m[RT], xa[RT], xb[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) m[t] = mrow[t * HV * S];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) { xa[t] = pa[t * HV]; xb[t] = pb[t * HV]; }
+#pragma unroll
+        for (int t = 0; t < RT; ++t) mrow[t * HV * S] = fma(-xb[t], wb, fma(-xa[t], wa, m[t]));
+    }
+    wave_sync();
+}
+
 // the same product when vec is known to vanish below row j0 (z = J2 d2 with a large working set), NP = 64: only
 // the rows from j0 rounded down to a multiple of sixteen are read (measured: -3 % on the 50-variable stack; for
 // NP = 32 the fixed, fully unrolled walk above is faster)
@@ -1091,44 +1162,135 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
     }
     // (uniform_i / uniform_d below: table entries and reduction results ARE wave-uniform, said so that the loop's control flow
     // and its counters stay on the scalar unit -- see osot_team.h)
-    double a_next = (n_eq > 0) ? row_elem<NP>(w, uniform_i(w.eqlist[0]), c) : 0.0;
-    for (int e = 0; e < n_eq; ++e) {
+    // The equality rows are added IN PAIRS wherever two consecutive rows are both (clearly) independent of the working set: a pass
+    // over JT is what an addition costs (above all at one wavefront per SIMD: an LDS sweep nothing hides), and a pair needs
+    // three of them instead of six --
+    //   d_a = J'a and d_b = J'b in one pass (jt_rows_dot2);
+    //   b after a's reflection H_a = I - beta_a v_a v_a' without touching J: d_b' = H_a d_b is lane-local after one reduction,
+    //   its slack loses t_a (b'z_a) = t_a (d_b . d2_a), and z_b = (J2 H_a) d2_b' = J2 d2_b' - beta_a (v_a . d2_b') (J2 v_a): so
+    //   z_a = J2 d2_a and J2 d2_b' in one pass over the UNCHANGED J (jt_cols_dot2), the correction lane-local;
+    //   both reflections as one rank-2 update (householder_apply2), with w_b = (J2 H_a) v_b from z_b and row iq+1 of JT.
+    // A row that is dependent, or a pair of which either row is not WELL clear of the dependency threshold (nd2 <= 1e-6 dd: the finer
+    // tests look at J as it is AFTER the partner's reflection, and an ill-conditioned level needs the one-row path's accuracy), goes
+    // through the one-row path as before.
+    constexpr double kPairTol = 1.0e-6;
+    double* V2p = w.V + 2 * WaveCtx<NP>::LW;
+    double* V3p = w.V + 3 * WaveCtx<NP>::LW;
+    double rq[4];    // rows e .. e+3 of the list at my column, requested ahead of their use
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rq[i] = (i < n_eq) ? row_elem<NP>(w, uniform_i(w.eqlist[i]), c) : 0.0;
+    for (int e = 0; e < n_eq;) {
+        const bool have_b = e + 1 < n_eq;
         const int r = uniform_i(w.eqlist[e]);
-        const double a = a_next;
-        const double lo = uniform_d(w.rlo[r]);
-        const int src = uniform_i(w.rsrc[r]);
+        const int rb = uniform_i(w.eqlist[have_b ? e + 1 : e]);
+        const double a = rq[0], b = have_b ? rq[1] : 0.0;
+        const double lo = uniform_d(w.rlo[r]), lob = uniform_d(w.rlo[rb]);
+        const int src = uniform_i(w.rsrc[r]), srcb = uniform_i(w.rsrc[rb]);
         // right-hand side relative to x: lo - a'x, or a'(x_prev - x) for an optimality row (x_prev, the solution of the
         // last level solved, satisfies a'x_prev = a'x_j for the rows of every level j above it)
-        const double xref = (src >= 0) ? xprev : 0.0;
-        if (e + 1 < n_eq) a_next = row_elem<NP>(w, uniform_i(w.eqlist[e + 1]), c);   // prefetch
+        const double xref = (src >= 0) ? xprev : 0.0, xrefb = (srcb >= 0) ? xprev : 0.0;
         OSOT_SUB_BEGIN();
-        if (h == 0) V0[c] = a;
+        if (h == 0) { V0[c] = a; V3p[c] = b; }
         wave_sync();
-        const double d = jt_rows_dot<NP>(w, V0);
+        double d, db;
+        if (have_b) jt_rows_dot2<NP>(w, V0, V3p, d, db);
+        else { d = jt_rows_dot<NP>(w, V0); db = 0.0; }
         OSOT_SUB_END(PH_EQ_D);
         const double d2 = (c >= iq) ? d : 0.0;
         double dd, nd2;
         colsum2<NP>(d * d, d2 * d2, dd, nd2);
         dd = uniform_d(dd); nd2 = uniform_d(nd2);
-        const double resid = lo + uniform_d(colsum<NP>(a * (xref - x)));
+        double ra, rbx;      // a'(xref - x) and b'(xrefb - x)
+        colsum2<NP>(a * (xref - x), b * (xrefb - x), ra, rbx);
+        const double resid = lo + uniform_d(ra);
         OSOT_SUB_END(PH_EQ_RED);
-        if (!direction_is_independent<NP>(w, nd2, dd, d2, a, iq)) {   // row is (numerically) a combination of the rows already in
+        int adv = 1;
+        const bool ok_a = direction_is_independent<NP>(w, nd2, dd, d2, a, iq);
+        if (!ok_a) {   // row is (numerically) a combination of the rows already in
             // an optimality row of an upper level (src >= 0) is consistent BY CONSTRUCTION (x of that level
             // satisfies all of them, iHQP.cpp:164-170): a residual there is round-off of an ill-conditioned level
             // (default eps 4.4e-11: O(1e-16 / eps)), never infeasibility
-            if (src >= 0 || fabs(resid) <= kEqTol * fmax(1.0, fabs(lo))) continue;   // redundant and consistent
-            x_out = x; iters_out = iters; return QP_INFEASIBLE;
+            if (!(src >= 0 || fabs(resid) <= kEqTol * fmax(1.0, fabs(lo)))) { x_out = x; iters_out = iters; return QP_INFEASIBLE; }
+            // redundant and consistent: nothing to add
+        } else {
+            // the reflection of a (householder_add's scalars)
+            const double d_iq = bcast(d, iq);
+            double nrm, rnrm;
+            fast_sqrt_rsqrt(nd2, nrm, rnrm);
+            const double alpha = (d_iq > 0.0) ? -nrm : nrm;
+            const double va = (c > iq) ? d2 : ((c == iq) ? d_iq - alpha : 0.0);
+            const double beta = fast_rcp(nd2 - alpha * d_iq);
+            const double ta = resid * fast_rcp(nd2);
+            bool pair = false;
+            double d2b = 0.0, ddb = 0.0, nd2b = 0.0, dbp = 0.0, residb = 0.0;
+            if (have_b) {
+                // b against the working set WITH a: d_b' = H_a d_b; slack of b at x + t_a z_a
+                double sab, bza;
+                colsum2<NP>(va * db, db * d2, sab, bza);      // v_a . d_b  and  b'z_a = d_b . d2_a
+                sab = uniform_d(sab); bza = uniform_d(bza);
+                dbp = fma(-beta * sab, va, db);
+                d2b = (c >= iq + 1) ? dbp : 0.0;
+                colsum2<NP>(dbp * dbp, d2b * d2b, ddb, nd2b);
+                ddb = uniform_d(ddb); nd2b = uniform_d(nd2b);
+                residb = lob + uniform_d(rbx) - ta * bza;
+                // (well clear of the dependency threshold, BOTH of them: on an ill-conditioned level -- the default eps, where
+                //  J spans ten decades -- the pair's extra algebra costs accuracy that the one-row path keeps; there the rows go
+                //  one by one as they always did: default_eps_stuck_instances, hardware)
+                pair = (nd2 > kPairTol * dd) && (nd2b > kPairTol * ddb);
+            }
+            if (pair) {
+                const double d_iqb = bcast(dbp, iq + 1);
+                double nrmb, rnrmb;
+                fast_sqrt_rsqrt(nd2b, nrmb, rnrmb);
+                const double alphab = (d_iqb > 0.0) ? -nrmb : nrmb;
+                const double vb = (c > iq + 1) ? d2b : ((c == iq + 1) ? d_iqb - alphab : 0.0);
+                const double betab = fast_rcp(nd2b - alphab * d_iqb);
+                const double tb = residb * fast_rcp(nd2b);
+                // z_b = (J2 H_a) d2_b' = J2 d2_b' - beta_a (v_a . d2_b') (J2 v_a): the product with the UNCHANGED J takes the columns from
+                // iq + 1 on only (d2_b' is zero at iq), the correction is the rank-1 term the reflection of a would have put into J
+                const double s2 = uniform_d(colsum<NP>(va * d2b));
+                const double va_next = bcast(va, iq + 1);        // v_a[iq + 1]
+                const double m_iq = M2[iq * S + c], m_iq1 = M2[(iq + 1) * S + c];
+                if (h == 0) { V1[c] = d2; V3p[c] = d2b; V2p[c] = va * beta; V0[c] = vb * betab; }
+                wave_sync();
+                double z, zb;
+                jt_cols_dot2<NP>(w, V1, V3p, z, zb);
+                const double wa = z - alpha * m_iq;                                              // J2 v_a
+                zb = fma(-beta * s2, wa, zb);
+                x += ta * z;
+                x += tb * zb;
+                OSOT_SUB_END(PH_EQ_Z);
+                const double wb = zb - alphab * fma(-beta * va_next, wa, m_iq1);                   // (J2 H_a) v_b
+                householder_apply2<NP>(w, V2p, V0, wa, wb, iq);
+                OSOT_SUB_END(PH_EQ_HH);
+                if (c == iq) Aq = -2 - r;
+                if (c == iq + 1) Aq = -2 - rb;
+                iq += 2;
+                iters += 2;
+                adv = 2;
+            } else {
+                if (h == 0) V1[c] = d2;
+                wave_sync();
+                const double z = jt_cols_dot<NP>(w, V1);
+                x += ta * z;
+                OSOT_SUB_END(PH_EQ_Z);
+                householder_add<NP, false>(w, d, d2, z, nd2, iq);   // equality columns of R are never read
+                OSOT_SUB_END(PH_EQ_HH);
+                if (c == iq) Aq = -2 - r;
+                iq++;
+                iters++;
+            }
         }
-        if (h == 0) V1[c] = d2;
-        wave_sync();
-        const double z = jt_cols_dot<NP>(w, V1);
-        x += (resid * fast_rcp(nd2)) * z;
-        OSOT_SUB_END(PH_EQ_Z);
-        householder_add<NP, false>(w, d, d2, z, nd2, iq);   // equality columns of R are never read
-        OSOT_SUB_END(PH_EQ_HH);
-        if (c == iq) Aq = -2 - r;
-        iq++;
-        iters++;
+        // the rows ahead: shift the queue by what was consumed and request the missing ones
+        if (adv == 1) {
+            rq[0] = rq[1]; rq[1] = rq[2]; rq[2] = rq[3];
+            rq[3] = (e + 4 < n_eq) ? row_elem<NP>(w, uniform_i(w.eqlist[e + 4]), c) : 0.0;
+        } else {
+            rq[0] = rq[2]; rq[1] = rq[3];
+            rq[2] = (e + 4 < n_eq) ? row_elem<NP>(w, uniform_i(w.eqlist[e + 4]), c) : 0.0;
+            rq[3] = (e + 5 < n_eq) ? row_elem<NP>(w, uniform_i(w.eqlist[e + 5]), c) : 0.0;
+        }
+        e += adv;
     }
     const int me = iq;
     wave_sync();
