@@ -1180,7 +1180,9 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
 #pragma unroll
     for (int i = 0; i < 4; ++i) rq[i] = (i < n_eq) ? row_elem<NP>(w, uniform_i(w.eqlist[i]), c) : 0.0;
     for (int e = 0; e < n_eq;) {
-        const bool have_b = e + 1 < n_eq;
+        // (the 64-lane layouts only: at NP = 32 -- two wavefronts per SIMD, three such rows at config 3 -- the pair's code and registers
+        //  cost more than its passes save: measured -1.4 % on the headline batch with pairs on)
+        const bool have_b = (NP > 32) && e + 1 < n_eq;
         const int r = uniform_i(w.eqlist[e]);
         const int rb = uniform_i(w.eqlist[have_b ? e + 1 : e]);
         const double a = rq[0], b = have_b ? rq[1] : 0.0;
