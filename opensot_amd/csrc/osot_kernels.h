@@ -475,6 +475,9 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
                                            hotcode, hotk);
         }
         if (PROF) ph_t0_ = (long long)clock64();
+#ifdef OSOT_TRACE_LEVELS   // developer knob (emulator builds): one line per (instance, level) with the level's trip count
+        if (lane == 0) printf("LEVEL %lld %d %d %d\n", inst, k, iters, st);
+#endif
         iters_total += iters;
         if (st != QP_SOLVED) { status = st; break; }
         any = true;
