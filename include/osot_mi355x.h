@@ -386,11 +386,12 @@ typedef struct {
                                             and never changes them; 0 = default: n, then previous minus the rows of the level
                                             above (full row rank) */
     double min_sv_ratio;                 /* setMinSingularValueRatio (nHQP.cpp:342-355 accepts 0 <= s <= 1; 0 lifts nothing).
-                                            Read only when min_sv_ratio_is_set != 0; otherwise DEFAULT_MIN_SV_RATIO = 0.05
-                                            (nHQP.h:66), so that a zeroed struct means "the reference's defaults" */
+                                            A positive value is honoured as it is; 0 means DEFAULT_MIN_SV_RATIO = 0.05
+                                            (nHQP.h:66), so that a zeroed struct is "the reference's defaults", UNLESS
+                                            min_sv_ratio_is_set != 0, which makes 0 itself the value */
     int no_ab_regularization;            /* setPerformAbRegularization(false) */
     int no_selective_ns_regularization;  /* setPerformSelectiveNullSpaceRegularization(false) */
-    int min_sv_ratio_is_set;             /* != 0: min_sv_ratio is the caller's value, 0 included */
+    int min_sv_ratio_is_set;             /* != 0: min_sv_ratio is the caller's value, 0 included (only needed to say 0) */
 } osot_nhqp_options;
 int osot_nhqp_solve(osot_solver* s, const osot_qp_batch* batch, const osot_nhqp_options* options, void* hip_stream);
 
@@ -592,6 +593,12 @@ int osot_id_force_gains(int B, int nv, int rows, const double* J, const double* 
  * x[B][n]; ok[B] (may be NULL) = 0 where a floating-base row of tau exceeds fb_tol (the reference uses 10e-3 and
  * returns false). */
 int osot_computed_torque(const osot_id_model* m, const double* x, double* tau, int* ok, double fb_tol, void* hip_stream);
+
+/* ---- layout of the structs above as THIS library was compiled (for bindings that mirror them by hand: ctypes, cgo, JNI ...).
+ * name = the typedef's name ("osot_plan_desc", "osot_qp_batch", ...).  *size = sizeof; the byte offset of every member, in
+ * declaration order, goes to offsets[0 .. *n_fields) (at most max_fields are written; offsets may be NULL).  Unknown name:
+ * OSOT_ERR_INVALID.  opensot_amd/abi.py is checked against it in tests/test_abi_host.py. */
+int osot_abi_layout(const char* name, unsigned long long* size, unsigned long long* offsets, int max_fields, int* n_fields);
 
 /* ---- multi-GPU: collect solved dq shards ---------------------------------------------------- */
 typedef struct osot_comm osot_comm;

@@ -149,8 +149,14 @@ SYMBOLS = [
     "osot_backend_set_eps_regularisation", "osot_backend_get_eps_regularisation",
     "osot_backend_get_num_variables", "osot_backend_get_num_constraints",
     "osot_qp_solve_batch", "osot_qp_solve_batch_admm", "osot_qp_solve_batch_admm_warm",
-    "osot_comm_unique_id", "osot_comm_create", "osot_comm_destroy", "osot_allgather_dq",
+    "osot_comm_unique_id", "osot_comm_create", "osot_comm_destroy", "osot_allgather_dq", "osot_abi_layout",
 ]
+
+# the header's typedef name of every struct mirrored above (osot_abi_layout: tests/test_abi_host.py checks size and every offset)
+STRUCTS = {"osot_task_desc": TaskDesc, "osot_level_desc": LevelDesc, "osot_bound_desc": BoundDesc, "osot_rows_desc": RowsDesc,
+           "osot_plan_desc": PlanDesc, "osot_qp_batch": QpBatch, "osot_leaf_ptrs": LeafPtrs, "osot_leaf_batch": LeafBatch,
+           "osot_assembled_out": AssembledOut, "osot_backend_options": BackendOptions, "osot_nhqp_options": NhqpOptions,
+           "osot_admm_options": AdmmOptions, "osot_id_model": IdModel, "osot_kin_desc": KinDesc, "osot_kin_batch": KinBatch}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (OSOT_MI355X_LIB: developer override, to A/B two builds of the HIP library on the GPU box)

@@ -172,8 +172,11 @@ __global__ void __launch_bounds__(64) osot_ehqp_kernel(const DevEhqp Q) {
         const double dcoef = in_rank ? fast_rcp(sig * sig + lam2) : 0.0;
         // ---- x += V D V' u, then once more with the residual of that step, u - H dx (refinement of the normal equations:
         // the Gram route alone leaves an error of cond(JP)^2 eps in x, 1e-6 on the worst of a few hundred random stacks)
+        // (one pass only when the damping is on: a second application of the DAMPED inverse to the residual is a step towards the
+        //  undamped solution, not the reference's single J^+ of eHQP.cpp:124-146)
         double ucur = uvec;
-        for (int pass = 0; pass < 2; ++pass) {
+        const int passes = uniform_b(damped) ? 1 : 2;
+        for (int pass = 0; pass < passes; ++pass) {
             wave_sync();
             if (h == 0) Vv[c] = ucur;
             wave_sync();
@@ -605,8 +608,12 @@ inline int ehqp_args(const osot_plan_desc& p, const osot_qp_batch* b, double sig
     }
     // the QR kernel (round 3) takes diagonal weights, n <= 64 and <= 64 rows per level; the Gram / eigen kernel takes dense
     // weights and any row count, n <= 32
-    const bool qr = !any_dense && !wide;
-    if (!qr && p.n > 32) { *why = "eHQP front-end: a stack with a dense weight matrix or more than 64 rows in a level needs n <= 32"; return OSOT_ERR_UNSUPPORTED; }
+    // A non-default sigma_min (eHQP::setSigmaMin: the user asks for the Tikhonov-damped inverse near singular configurations,
+    // eHQP.cpp:124-146) is honoured by the Gram / eigen kernel only: the QR kernel cuts the rank at round-off and never damps
+    const bool damped = sigma_min > 1.0e-12;
+    const bool qr = !any_dense && !wide && !damped;
+    if (!qr && p.n > 32) { *why = damped ? "eHQP front-end: a non-default sigma_min (damped pseudo-inverse) needs n <= 32"
+                                         : "eHQP front-end: a stack with a dense weight matrix or more than 64 rows in a level needs n <= 32"; return OSOT_ERR_UNSUPPORTED; }
     if (p.n > 64) { *why = "eHQP front-end: n <= 64"; return OSOT_ERR_UNSUPPORTED; }
     if (p.has_regularisation) { *why = "eHQP has no regularisation task"; return OSOT_ERR_UNSUPPORTED; }
     if (any_task_inactive) { *why = "eHQP front-end: Task::setActive(false) is not covered (switch whole levels with level_active)"; return OSOT_ERR_UNSUPPORTED; }

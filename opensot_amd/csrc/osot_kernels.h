@@ -625,9 +625,13 @@ struct DevQP {
     int* status;
     int* iterations;
     int lds_rows_off, lds_rows_cap;
+    int* hot;          // [B][LW] hot-start state (HOT instantiation): the inequality working set of the instance's previous solve
+                       // (constraint codes, -1 = none), read before the first scan and rewritten at the end; null: cold start
 };
 
-template <int NP>
+// HOT: the instantiation that carries the hot-start code (the batch-of-one BackEnd surface keeps its working set from solve() to
+// solve() like QPOasesBackEnd::solve, QPOasesBackEnd.cpp:258-285); the plain one carries none of it
+template <int NP, bool HOT = false>
 __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
     OSOT_DYNAMIC_LDS(osot_smem);
     constexpr int S = WaveCtx<NP>::S;
@@ -682,10 +686,14 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
     double x = 0.0, slack = 0.0;
     int iters = 0;
     int st;
+    int* hotk = (HOT && Q.hot) ? Q.hot + inst * WaveCtx<NP>::LW : nullptr;
+    const int hotcode = hotk ? hotk[c] : -1;
     if (NP == 64) {
-        OSOT_ALWAYS_INLINE_CALL st = gi_solve<NP, false>(w, Q.nc, g, false, 0.0, Hc, has_box, lb, ub, Q.max_iter, false, 0.0, x, iters, nullptr, slack);
+        OSOT_ALWAYS_INLINE_CALL st = gi_solve<NP, false>(w, Q.nc, g, false, 0.0, Hc, has_box, lb, ub, Q.max_iter, false, 0.0, x, iters, nullptr, slack,
+                                                         false, 0.0, hotcode, hotk);
     } else {
-        st = gi_solve<NP, false>(w, Q.nc, g, false, 0.0, Hc, has_box, lb, ub, Q.max_iter, false, 0.0, x, iters, nullptr, slack);
+        st = gi_solve<NP, false>(w, Q.nc, g, false, 0.0, Hc, has_box, lb, ub, Q.max_iter, false, 0.0, x, iters, nullptr, slack,
+                                 false, 0.0, hotcode, hotk);
     }
     if (valid && h == 0) Q.x[inst * n + c] = (st == QP_SOLVED) ? x : 0.0;
     if (lane == 0) {

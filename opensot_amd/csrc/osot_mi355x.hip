@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -110,6 +111,53 @@ extern "C" {
 const char* osot_version(void) { return "osot-mi355x 0.1 (gfx950)"; }
 const char* osot_last_error(void) { return g_err.c_str(); }
 
+int osot_abi_layout(const char* name, unsigned long long* size, unsigned long long* offsets, int max_fields, int* n_fields) {
+    if (!name || !size) return fail(OSOT_ERR_INVALID, "null name/size");
+    std::vector<unsigned long long> off;
+    unsigned long long sz = 0;
+    const std::string nm(name);
+#define OSOT_LAYOUT_BEGIN(T) if (nm == #T) { typedef T osot_layout_t; sz = sizeof(T);
+#define OSOT_F(f) off.push_back((unsigned long long)offsetof(osot_layout_t, f));
+#define OSOT_LAYOUT_END() }
+    OSOT_LAYOUT_BEGIN(osot_task_desc) OSOT_F(kind) OSOT_F(rows) OSOT_F(weight) OSOT_F(lambda) OSOT_F(orientation_gain) OSOT_F(lambda2)
+        OSOT_F(row_mask) OSOT_F(parent_rows) OSOT_F(sub_lambda) OSOT_F(body_frame) OSOT_F(dense_weight) OSOT_F(acc_gain_matrices) OSOT_LAYOUT_END()
+    OSOT_LAYOUT_BEGIN(osot_level_desc) OSOT_F(n_tasks) OSOT_F(task) OSOT_LAYOUT_END()
+    OSOT_LAYOUT_BEGIN(osot_bound_desc) OSOT_F(kind) OSOT_F(scaling) OSOT_F(dT) OSOT_LAYOUT_END()
+    OSOT_LAYOUT_BEGIN(osot_rows_desc) OSOT_F(kind) OSOT_F(rows) OSOT_F(d_threshold) OSOT_F(detection_threshold) OSOT_F(bound_scaling)
+        OSOT_F(first_col) OSOT_F(dT) OSOT_F(p) OSOT_F(mu) OSOT_F(task_lambda) OSOT_F(task_orientation_gain) OSOT_F(err_lb) OSOT_F(err_ub)
+        OSOT_F(task_body_frame) OSOT_F(n_candidates) OSOT_F(only_level) OSOT_LAYOUT_END()
+    OSOT_LAYOUT_BEGIN(osot_plan_desc) OSOT_F(n) OSOT_F(n_levels) OSOT_F(level) OSOT_F(n_bounds) OSOT_F(bound) OSOT_F(n_rowblocks)
+        OSOT_F(rowblock) OSOT_F(eps_abs) OSOT_F(max_iter) OSOT_F(has_regularisation) OSOT_F(regularisation) OSOT_F(regularisation_dense) OSOT_LAYOUT_END()
+    OSOT_LAYOUT_BEGIN(osot_qp_batch) OSOT_F(B) OSOT_F(A) OSOT_F(b) OSOT_F(w) OSOT_F(c) OSOT_F(C) OSOT_F(lo) OSOT_F(up) OSOT_F(l) OSOT_F(u)
+        OSOT_F(level_active) OSOT_F(dq) OSOT_F(x_levels) OSOT_F(status) OSOT_F(iterations) OSOT_F(b_reg) OSOT_F(WA) OSOT_F(Wb)
+        OSOT_F(accepted_slack) OSOT_F(A_reg) OSOT_LAYOUT_END()
+    OSOT_LAYOUT_BEGIN(osot_leaf_ptrs) OSOT_F(p0) OSOT_F(p1) OSOT_F(p2) OSOT_F(W) OSOT_LAYOUT_END()
+    OSOT_LAYOUT_BEGIN(osot_leaf_batch) OSOT_F(B) OSOT_F(task) OSOT_F(bound) OSOT_F(rows) OSOT_F(regularisation) OSOT_LAYOUT_END()
+    OSOT_LAYOUT_BEGIN(osot_assembled_out) OSOT_F(b) OSOT_F(w) OSOT_F(C) OSOT_F(lo) OSOT_F(up) OSOT_F(l) OSOT_F(u) OSOT_F(b_reg) OSOT_F(WA)
+        OSOT_F(Wb) OSOT_F(A) OSOT_LAYOUT_END()
+    OSOT_LAYOUT_BEGIN(osot_backend_options) OSOT_F(max_iterations) OSOT_F(last_iterations) OSOT_F(last_status) OSOT_LAYOUT_END()
+    OSOT_LAYOUT_BEGIN(osot_nhqp_options) OSOT_F(free_vars) OSOT_F(min_sv_ratio) OSOT_F(no_ab_regularization)
+        OSOT_F(no_selective_ns_regularization) OSOT_F(min_sv_ratio_is_set) OSOT_LAYOUT_END()
+    OSOT_LAYOUT_BEGIN(osot_admm_options) OSOT_F(eps_abs) OSOT_F(eps_rel) OSOT_F(rho) OSOT_F(sigma) OSOT_F(alpha) OSOT_F(max_iter)
+        OSOT_F(scaling) OSOT_F(check_every) OSOT_LAYOUT_END()
+    OSOT_LAYOUT_BEGIN(osot_id_model) OSOT_F(B) OSOT_F(nv) OSOT_F(n_contacts) OSOT_F(contact_dim) OSOT_F(Bm) OSOT_F(h) OSOT_F(Jc)
+        OSOT_F(floating_base) OSOT_LAYOUT_END()
+    OSOT_LAYOUT_BEGIN(osot_kin_desc) OSOT_F(n) OSOT_F(parent) OSOT_F(type) OSOT_F(axis) OSOT_F(R0) OSOT_F(p0) OSOT_F(mass) OSOT_F(com)
+        OSOT_F(n_frames) OSOT_F(frame_joint) OSOT_F(frame_R) OSOT_F(frame_p) OSOT_F(n_pairs) OSOT_F(pair_joint) OSOT_F(pair_seg)
+        OSOT_F(pair_radius) OSOT_F(frame_body) OSOT_F(frame_col_mask) OSOT_F(com_col_mask) OSOT_F(pair_kind) OSOT_F(pair_env)
+        OSOT_F(pair_box) OSOT_F(pair_shape_R) OSOT_F(pair_shape_p) OSOT_F(n_env) OSOT_LAYOUT_END()
+    OSOT_LAYOUT_BEGIN(osot_kin_batch) OSOT_F(B) OSOT_F(q) OSOT_F(frame_pose) OSOT_F(frame_J) OSOT_F(frame_J_stride) OSOT_F(com)
+        OSOT_F(com_J) OSOT_F(com_J_stride) OSOT_F(pair_dist) OSOT_F(pair_J) OSOT_F(pair_J_stride) OSOT_F(env_pose) OSOT_F(env_pose_stride) OSOT_LAYOUT_END()
+#undef OSOT_LAYOUT_BEGIN
+#undef OSOT_F
+#undef OSOT_LAYOUT_END
+    if (sz == 0) return fail(OSOT_ERR_INVALID, std::string("osot_abi_layout: unknown struct ") + name);
+    *size = sz;
+    if (n_fields) *n_fields = (int)off.size();
+    if (offsets) for (int i = 0; i < (int)off.size() && i < max_fields; ++i) offsets[i] = off[i];
+    return OSOT_OK;
+}
+
 int osot_device_count(int* count) {
     if (!count) return fail(OSOT_ERR_INVALID, "null count");
     int c = 0;
@@ -187,6 +235,12 @@ int osot_solver_create(const osot_plan_desc* plan, int max_batch, int device, os
     if (hipMalloc(&s->d_cost, sizeof(int) * 2 * (size_t)max_batch) != hipSuccess ||
         hipMemset(s->d_cost, 0, sizeof(int) * 2 * (size_t)max_batch) != hipSuccess ||
         hipMalloc(&s->d_order, sizeof(int) * 2 * (size_t)max_batch) != hipSuccess ||
+        [&] {   // both halves of the order buffer start as the identity permutation: a half that no launch has written yet
+                // (a graph capture that failed half-way leaves the host-side flip ahead of the device) is still a valid order
+            std::vector<int> id(2 * (size_t)max_batch);
+            for (int i = 0; i < 2 * max_batch; ++i) id[i] = i % max_batch;
+            return hipMemcpy(s->d_order, id.data(), sizeof(int) * id.size(), hipMemcpyHostToDevice) != hipSuccess;
+        }() ||
         hipMalloc(&s->d_uplan, sizeof(DevUpdatePlan)) != hipSuccess ||
         hipMemcpy(s->d_uplan, &s->h_uplan, sizeof(DevUpdatePlan), hipMemcpyHostToDevice) != hipSuccess) {
         if (s->d_cost) hipFree(s->d_cost);
@@ -464,18 +518,18 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
         D.slots = s->slots;
     }
     const unsigned grid = (unsigned)b->B + (D.order_next ? 1u : 0u);   // (+ the order workgroup, block 0)
-    std::pair<hipEvent_t, hipEvent_t> ev;
-    const bool timed = s->timing && (s->timing_count++ % s->timing_stride) == 0;
-    if (timed) {
-        if (!s->pool.empty()) { ev = s->pool.back(); s->pool.pop_back(); }
-        else { HIP_TRY(hipEventCreate(&ev.first)); HIP_TRY(hipEventCreate(&ev.second)); }
-        HIP_TRY(hipEventRecord(ev.first, st));
-    }
     // the instantiation with the dense-weight / inactive-task code only where the plan or the solver state asks for it
     bool extra = s->any_inactive || (pl.has_regularisation && pl.regularisation_dense);
     for (int k = 0; k < pl.n_levels; ++k) extra = extra || (s->h_uplan.dense_level[k] != 0);
     if (prof && !fused && extra)   // (the instrumented instantiation carries no dense-weight / inactive-task code: it would
         return fail(OSOT_ERR_UNSUPPORTED, "phase profiling is not available for plans with dense weights or inactive tasks");   // solve another problem)
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    const bool timed = s->timing && (s->timing_count++ % s->timing_stride) == 0;   // (after every early return: nothing is taken from the pool for a launch that does not happen)
+    if (timed) {
+        if (!s->pool.empty()) { ev = s->pool.back(); s->pool.pop_back(); }
+        else { HIP_TRY(hipEventCreate(&ev.first)); HIP_TRY(hipEventCreate(&ev.second)); }
+        HIP_TRY(hipEventRecord(ev.first, st));
+    }
     extra = extra || (D.hot != nullptr);
     {   // developer knob: the EXTRA instantiation for every launch (A/B of the two register allocations)
         static const char* force = getenv("OSOT_DEBUG_FORCE_EXTRA");
@@ -535,10 +589,23 @@ int osot_stack_update(osot_solver* s, const osot_leaf_batch* leaf, const osot_as
     return OSOT_OK;
 }
 
+static int qp_solve_batch_impl(int B, int n, int nc, const double* H, const double* g, const double* A,
+                               const double* lA, const double* uA, const double* l, const double* u,
+                               double eps_abs, int max_iter, double* x, int* status, int* iterations,
+                               void* hip_stream, int* hot);
+
 int osot_qp_solve_batch(int B, int n, int nc, const double* H, const double* g, const double* A,
                         const double* lA, const double* uA, const double* l, const double* u,
                         double eps_abs, int max_iter, double* x, int* status, int* iterations,
                         void* hip_stream) {
+    return qp_solve_batch_impl(B, n, nc, H, g, A, lA, uA, l, u, eps_abs, max_iter, x, status, iterations, hip_stream, nullptr);
+}
+
+// hot: [B][32 or 64] device ints (see DevQP.hot) or null
+static int qp_solve_batch_impl(int B, int n, int nc, const double* H, const double* g, const double* A,
+                               const double* lA, const double* uA, const double* l, const double* u,
+                               double eps_abs, int max_iter, double* x, int* status, int* iterations,
+                               void* hip_stream, int* hot) {
     if (B < 0 || n < 1 || n > OSOT_MAX_VARS || nc < 0) return fail(OSOT_ERR_INVALID, "bad sizes");
     if (B == 0) return OSOT_OK;
     if (!H || !g || !x || !status) return fail(OSOT_ERR_INVALID, "null H/g/x/status");
@@ -553,11 +620,19 @@ int osot_qp_solve_batch(int B, int n, int nc, const double* H, const double* g, 
     Q.x = x; Q.status = status; Q.iterations = iterations;
     const int T = n <= 32 ? 32 : 64;
     const size_t lds = (size_t)lds_layout(T, nc, &Q.lds_rows_off, &Q.lds_rows_cap) * sizeof(double);
-    int rc = (T == 32) ? ensure_lds(osot_qp_kernel<32>, lds) : ensure_lds(osot_qp_kernel<64>, lds);
+    Q.hot = hot;
+    int rc;
+    if (hot) rc = (T == 32) ? ensure_lds(osot_qp_kernel<32, true>, lds) : ensure_lds(osot_qp_kernel<64, true>, lds);
+    else rc = (T == 32) ? ensure_lds(osot_qp_kernel<32>, lds) : ensure_lds(osot_qp_kernel<64>, lds);
     if (rc != OSOT_OK) return rc;
     const unsigned grid = (unsigned)B;
-    if (T == 32) hipLaunchKernelGGL(osot_qp_kernel<32>, dim3(grid), dim3(64), lds, (hipStream_t)hip_stream, Q);
-    else hipLaunchKernelGGL(osot_qp_kernel<64>, dim3(grid), dim3(64), lds, (hipStream_t)hip_stream, Q);
+    if (hot) {
+        if (T == 32) hipLaunchKernelGGL((osot_qp_kernel<32, true>), dim3(grid), dim3(64), lds, (hipStream_t)hip_stream, Q);
+        else hipLaunchKernelGGL((osot_qp_kernel<64, true>), dim3(grid), dim3(64), lds, (hipStream_t)hip_stream, Q);
+    } else {
+        if (T == 32) hipLaunchKernelGGL(osot_qp_kernel<32>, dim3(grid), dim3(64), lds, (hipStream_t)hip_stream, Q);
+        else hipLaunchKernelGGL(osot_qp_kernel<64>, dim3(grid), dim3(64), lds, (hipStream_t)hip_stream, Q);
+    }
     HIP_TRY(hipGetLastError());
     return OSOT_OK;
 }
@@ -611,6 +686,11 @@ struct osot_backend {
     int* d_status;
     int last_status, last_iters;
     int max_iterations = 0;   // osot_backend_options: active-set iteration cap (0: the kernel's default, 20 (n + nc) + 100)
+    // hot start across solve() calls (QPOasesBackEnd::solve hot-starts every call, QPOasesBackEnd.cpp:258-285): the inequality
+    // working set of the previous solve, 64 constraint codes on the device; forgotten (cold start) by initProblem and whenever
+    // the row count changes (the reference re-creates its SQProblem then, QPOasesBackEnd.cpp:229-244)
+    int* d_hot = nullptr;
+    int hot_nc = -1;          // row count the recorded set belongs to (-1: nothing recorded)
 };
 
 namespace {
@@ -645,9 +725,14 @@ int backend_run(osot_backend* be) {
         HIP_TRY(hipMemcpy(dl, be->l.data(), sizeof(double) * n, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(du, be->u.data(), sizeof(double) * n, hipMemcpyHostToDevice));
     }
-    int rc = osot_qp_solve_batch(1, n, nc, dH, dg, nc ? dA : nullptr, nc ? dlA : nullptr, nc ? duA : nullptr,
+    if (!be->d_hot) HIP_TRY(hipMalloc((void**)&be->d_hot, 64 * sizeof(int)));
+    if (be->hot_nc != nc) {   // nothing recorded for this problem shape: cold start
+        HIP_TRY(hipMemset(be->d_hot, 0xff, 64 * sizeof(int)));
+        be->hot_nc = nc;
+    }
+    int rc = qp_solve_batch_impl(1, n, nc, dH, dg, nc ? dA : nullptr, nc ? dlA : nullptr, nc ? duA : nullptr,
                                  be->has_bounds ? dl : nullptr, be->has_bounds ? du : nullptr, be->eps_abs, be->max_iterations,
-                                 dx, be->d_status, be->d_status + 1, nullptr);
+                                 dx, be->d_status, be->d_status + 1, nullptr, be->d_hot);
     if (rc != OSOT_OK) return rc;
     int st[2];
     HIP_TRY(hipMemcpy(st, be->d_status, 2 * sizeof(int), hipMemcpyDeviceToHost));
@@ -686,6 +771,7 @@ int osot_backend_destroy(osot_backend* be) {
     DeviceGuard guard(be->device);
     if (be->d_buf) hipFree(be->d_buf);
     if (be->d_status) hipFree(be->d_status);
+    if (be->d_hot) hipFree(be->d_hot);
     delete be;
     return OSOT_OK;
 }
@@ -741,6 +827,7 @@ int osot_backend_init_problem(osot_backend* be, const double* H, const double* g
     if (rc != OSOT_OK) return rc;
     rc = osot_backend_update_bounds(be, l, u);
     if (rc != OSOT_OK) return rc;
+    be->hot_nc = -1;          // initProblem is a cold start (QPOasesBackEnd::initProblem -> SQProblem::init)
     rc = backend_run(be);
     be->inited = (rc == OSOT_OK);
     return rc;

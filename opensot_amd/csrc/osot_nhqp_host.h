@@ -60,7 +60,8 @@ int nhqp_run(const osot_plan_desc& p, const osot_qp_batch* b, const osot_nhqp_op
         std::memset(&Q, 0, sizeof(Q));
         Q.B = B; Q.n = n; Q.nc = nc; Q.level = k; Q.m = m; Q.ma = ma; Q.nf = nf; Q.ns = ns; Q.has_box = has_box ? 1 : 0;
         Q.ab_reg = !(opt && opt->no_ab_regularization); Q.sel_reg = !(opt && opt->no_selective_ns_regularization);
-        Q.thr = (opt && opt->min_sv_ratio_is_set) ? opt->min_sv_ratio : 0.05;      // nHQP.h:66; 0 = no triplet is lifted
+        // nHQP.h:66: 0.05 by default.  A positive value is honoured as it is; the flag is only needed to express 0 ("lift nothing")
+        Q.thr = !opt ? 0.05 : (opt->min_sv_ratio_is_set ? opt->min_sv_ratio : (opt->min_sv_ratio > 0.0 ? opt->min_sv_ratio : 0.05));
         Q.A = b->A[k]; Q.b = b->b[k]; Q.w = b->w[k];
         Q.C = b->C; Q.lo = b->lo; Q.up = b->up; Q.l = b->l; Q.u = b->u;
         Q.N = ws.N[k & 1]; Q.q0 = ws.q0;

@@ -1363,9 +1363,15 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
     // (x minimises f on the working set, all multipliers >= 0) -- a valid state of the dual method, which then goes on
     // as from a cold start.  The minimiser is unique, so the answer is the cold one up to round-off; what changes is the
     // number of iterations (no add-then-drop churn, no scans for the constraints that stay active from cycle to cycle).
-    const int hot_n = __builtin_popcountll(wave_ballot(hotcode >= 0 && h == 0));
+    int hot_n = __builtin_popcountll(wave_ballot(hotcode >= 0 && h == 0));
     int hot_i = 0;
     bool hot_check = false;     // hot additions were made: their multipliers have to be looked at
+    // A STALE hot list must not cost more than it can save (round 4; the launch is its longest instance): the multipliers are looked
+    // at after every kHotBatch additions, and once kHotAbandon members of the list have been taken out again the rest of the list
+    // is dropped -- the instance goes on as from a cold start from the S-pair it has reached.  Worst case: kHotBatch + kHotAbandon - 1
+    // wasted additions and as many removals, instead of the whole list twice.
+    constexpr int kHotBatch = 4, kHotAbandon = 3;
+    int hot_since_check = 0, hot_drops = 0;
     // table entries of the hot list's rows, lane q = entry q, fetched in ONE round trip when the first hot trip starts (the
     // table may live in device memory: bound, state and row address were three dependent loads in front of every hot trip)
     bool hm_loaded = false;
@@ -1382,7 +1388,8 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
         int code = kNone;
         double u_rev = 0.0;
         unsigned long long hot_ptr = 0ull;    // mode 1, a row: its table entry (from the list's metadata)
-        if (!margin_pass && hot_i < hot_n) {
+        const bool hot_check_now = hot_check && (hot_i >= hot_n || hot_since_check >= kHotBatch);
+        if (!margin_pass && hot_i < hot_n && !hot_check_now) {
             if (!hm_loaded) {
                 hm_loaded = true;
                 if (hotcode >= 2 * n && hotcode < 2 * n + 2 * nrows) {
@@ -1416,7 +1423,8 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
             colargmin<NP>(um, pos);
             pos = uniform_i(pos);
             um = bcast(um, 0);
-            if (!(um < -kHotDropTol * uabs)) { hot_check = false; continue; }
+            if (!(um < -kHotDropTol * uabs)) { hot_check = false; hot_since_check = 0; continue; }
+            if (++hot_drops >= kHotAbandon) hot_n = hot_i;       // (the list is stale: no further member is tried)
             mode = 2;
             u_rev = um;
             code = bcast_i(Aq, pos);
@@ -1689,7 +1697,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                 if (ip_box) { if (c == ip_var) box_state = (ip < n) ? 1 : 2; }
                 else { if (c == 0 && h == 0) w.rowstate[ip_row] = (ip & 1) ? 2 : 1; }
                 iq++;
-                hot_check = hot_check || (mode == 1);
+                if (mode == 1) { hot_check = true; hot_since_check++; }
                 wave_sync();
                 OSOT_SUB_END(PH_IN_HH);
                 break;

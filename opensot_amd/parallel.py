@@ -27,13 +27,13 @@ class ShardGather:
     kernel in between; shards handed in from other tensors are copied.  Shards may be uneven (total % world != 0): every
     rank's block is sized for the largest shard; `dq` / `status` return the rows in global instance order.
 
-    `overlap` (default off): issue the collective with async_op so that it runs on the process group's stream while the rank
-    solves the next step (two blocks, alternating; with `bind` the caller re-binds every step, `ShardedCycle` does).
-    Measured with a world of one on an MI355X it is slower than the in-stream form (0.210 against 0.194 ms per step: the
-    extra enqueue work costs more than the 1 MB copy it hides), so it stays an option for worlds where the collective
-    itself is long."""
+    `overlap` (None = on for a world of more than one rank on GPUs): the collective is issued with async_op, so it runs on the
+    process group's stream while the rank solves the next step (two blocks, alternating; with `bind` the caller re-binds every
+    step, `ShardedCycle` does): step t + 1's solve is ordered behind step t's SOLVE only -- the gather of step t reads a block
+    the solver does not write before step t + 2, whose `bind` waits for it.  With a world of one the collective is a 1 MB
+    device copy and the in-stream form is as fast (round 3: 0.194 against 0.210 ms per step), hence the default."""
 
-    def __init__(self, total, n, device, dtype, group=None, overlap=False, sizes=None):
+    def __init__(self, total, n, device, dtype, group=None, overlap=None, sizes=None):
         import torch
         import torch.distributed as dist
         self.torch = torch
@@ -50,13 +50,14 @@ class ShardGather:
             self.sizes = [shard_range(total, r, self.world)[1] - shard_range(total, r, self.world)[0] for r in range(self.world)]
         self.mx = max(self.sizes) if self.sizes else 0
         self.even = all(s == self.mx for s in self.sizes)
-        self.overlap = bool(overlap) and torch.device(device).type == "cuda"
+        self.overlap = (self.world > 1 if overlap is None else bool(overlap)) and torch.device(device).type == "cuda"
         nb = 2 if self.overlap else 1
         self.ndq = self.mx * n                       # doubles of dq in a block
         self.blk = self.ndq + (self.mx + 1) // 2     # + the status words, two per double
         self.send_b = [torch.zeros((self.blk,), dtype=dtype, device=device) for _ in range(nb)]
         self.recv_b = [torch.empty((self.world * self.blk,), dtype=dtype, device=device) for _ in range(nb)]
         self.work = [None] * nb
+        self._send_views = [self._views(b) for b in self.send_b]     # (dq rows, status words) of each send block, made once
         self.i = 0
         self.last = 0
         self.has_status = False
@@ -68,7 +69,7 @@ class ShardGather:
         """the stack's dq / status outputs become views of the NEXT step's send block"""
         b = self.i % len(self.send_b)
         self._wait(b)   # (overlap: the asynchronous gather that last READ this block is over before the solver rewrites it)
-        stack.dq, stack.status = self._views(self.send_b[b])
+        stack.dq, stack.status = self._send_views[b]
 
     def _gather(self, recv, send, async_op=False):
         if hasattr(self.dist, "all_gather_into_tensor"):
@@ -88,7 +89,7 @@ class ShardGather:
         self.last = b
         self.has_status = status_shard is not None
         self._wait(b)             # (overlap: the gather that last used this pair of blocks is over)
-        sdq, sst = self._views(self.send_b[b])
+        sdq, sst = self._send_views[b]
         if dq_shard.data_ptr() != sdq.data_ptr():
             sdq[:mine].copy_(dq_shard[:mine])
         if self.has_status and status_shard.data_ptr() != sst.data_ptr():
@@ -195,30 +196,81 @@ class PipelinedCycle:
                     lane.step()
 
     def capture(self, steps):
-        """`steps` steps of every lane as ONE HIP graph per lane (torch.cuda.CUDAGraph around the C-ABI launches; call after
-        warm-up steps).  `replay()` then enqueues steps x lanes launches with two graph launches: the dependent launches of a
-        lane follow each other ~4 us sooner than the same launches submitted one by one (measured: 27.7 -> 28.5 M solves/s at
-        BASELINE config 3 with two lanes, 22.5 -> 25.1 M with one), and the host does almost nothing.  Only for lanes whose
-        step is the solver's own launch (no collective behind it); `steps` must be even: the solver alternates two sets of
-        dispatch-order buffers from launch to launch, and a replay has to leave them where the host believes they are."""
-        if self._torch is None or any(st is None for st in self.streams) or any(self._ctx):
-            raise RuntimeError("graph capture needs one stream per lane and lanes without a collective")
+        """`steps` steps of every lane as HIP graphs (torch.cuda.CUDAGraph around the C-ABI launches; call after warm-up steps).
+        `replay()` then enqueues steps x lanes launches with one graph launch per lane: the dependent launches of a lane follow
+        each other ~4 us sooner than the same launches submitted one by one (measured: 27.7 -> 28.5 M solves/s at BASELINE
+        config 3 with two lanes, 22.5 -> 25.1 M with one), and the host does almost nothing.  Only for lanes whose step is the
+        solver's own launch (no collective behind it).  `steps` must be even: the solver alternates two sets of dispatch-order
+        buffers from launch to launch, and a replay has to leave them where the host believes they are.
+        A graph starts on the cycle of the rotation it was captured on, so ONE GRAPH PER STARTING CYCLE that the replays can
+        meet is captured ((start + r steps) mod K, r = 0, 1, ...: a single graph when steps is a multiple of the K cycles a lane
+        rotates through): replays follow the rotation exactly like the same steps submitted one by one, and the state carried
+        from cycle to cycle (cost estimates, hot-start sets) never sees a jump at a replay boundary."""
+        if self._torch is None or any(st is None for st in self.streams):
+            raise RuntimeError("graph capture needs one stream per lane")
+        # (a lane with a collective behind its solve is captured with it -- RCCL collectives can be recorded into a HIP graph -- as
+        #  long as the collective is issued in the lane's own stream: the asynchronous two-block form keeps host-side work handles)
+        if any(getattr(lane.gather, "overlap", False) for lane in self.lanes):
+            raise RuntimeError("graph capture needs in-stream collectives (ShardGather(overlap=False))")
         if steps < 2 or steps % 2:
             raise ValueError("an even number of steps per graph")
-        graphs = []
-        for lane, st in zip(self.lanes, self.streams):
-            g = self._torch.cuda.CUDAGraph()
-            with self._torch.cuda.graph(g, stream=st):
-                for _ in range(steps):
-                    lane.step()
-            graphs.append(g)
-        self._graphs, self.graph_steps = graphs, steps
+        K = len(getattr(self.lanes[0], "dev_leaves", ())) or 1
+        if any((len(getattr(lane, "dev_leaves", ())) or 1) != K or lane.i != self.lanes[0].i for lane in self.lanes):
+            raise ValueError("lanes must rotate through the same number of cycles, in step")
+        i0 = self.lanes[0].i
+        phases = sorted({(i0 + r * steps) % K for r in range(K)})
+        # the solver's host-side launch state (which half of the order buffers the next launch reads) advances during capture
+        # although nothing runs (an even number of launches per graph leaves it where it was); if the capture fails the dispatch
+        # order is forgotten (the next plain launch runs in order and builds a fresh one: osot_solver_set_schedule)
+        graphs = {}
+        try:
+            for ph in phases:
+                per_lane = []
+                for lane, st in zip(self.lanes, self.streams):
+                    lane.i = ph
+                    if lane.gather is not None and (steps % len(lane.gather.send_b)):
+                        raise ValueError("steps per graph must be a multiple of the gather's blocks")
+                    g = self._torch.cuda.CUDAGraph()
+                    with self._torch.cuda.graph(g, stream=st):
+                        for _ in range(steps):
+                            lane.step()
+                    per_lane.append(g)
+                graphs[ph] = per_lane
+        except Exception:
+            for lane in self.lanes:
+                if hasattr(lane.stack, "set_schedule"):
+                    lane.stack.set_schedule(True)
+            raise
+        finally:
+            for lane in self.lanes:
+                lane.i = i0
+        self._graphs, self.graph_steps, self._K = graphs, steps, K
+        self._replay_events = []
 
-    def replay(self):
-        """one replay of every lane's graph: `graph_steps` steps of the whole shard"""
-        for g, st in zip(self._graphs, self.streams):
+    def replay(self, timed=False):
+        """one replay of every lane's graph: `graph_steps` steps of the whole shard, continuing the rotation.  timed: a pair of
+        events on the lane's stream around its graph (replay_launch_ms() turns them into the average duration of one launch of the
+        lane INSIDE the replays, the gap between consecutive launches of a graph included)"""
+        ph = self.lanes[0].i % self._K
+        for j, (lane, g, st) in enumerate(zip(self.lanes, self._graphs[ph], self.streams)):
             with self._torch.cuda.stream(st):
-                g.replay()
+                if timed:
+                    e0, e1 = self._torch.cuda.Event(enable_timing=True), self._torch.cuda.Event(enable_timing=True)
+                    e0.record(st)
+                    g.replay()
+                    e1.record(st)
+                    self._replay_events.append((e0, e1))
+                else:
+                    g.replay()
+            lane.i += self.graph_steps
+
+    def replay_launch_ms(self):
+        """average over the timed replays (all lanes) of graph time / steps per graph, in ms; None without timed replays.  Call after
+        a synchronise."""
+        ev, self._replay_events = self._replay_events, []
+        if not ev:
+            return None
+        return sum(a.elapsed_time(b) for a, b in ev) / (len(ev) * self.graph_steps)
 
 
 class StubStack:

@@ -474,3 +474,29 @@ def parity_census(asm, dq_dev, witnesses, tol=1e-6, feas_tol=1e-7, active=None, 
           f"{int((first['status'] == 1).sum())} solved by it; {rule} accepted by the feasibility + lexicographic rule "
           f"(farthest from {witnesses[0][0]}: {worst:.2e}); {len(fails)} not acceptable" + (f": {fails[:3]}" if fails else ""))
     return within, rule, fails
+
+
+def judge_remainder(asm, dq_dev, results, active=None, tol=1e-6, feas_tol=1e-7, label=""):
+    """The tests compare the device with each witness WHERE THAT WITNESS SOLVED the instance; this judges the rest, so that no
+    device answer goes unchecked: an instance that at least one of the witnesses in `results` (name -> result dict
+    of pyoracle.ihqp_solve_batch) did not solve must pass the literal acceptance rule against all of them
+    (answer_is_acceptable: within `tol` of a witness that did solve it, or feasible and lexicographically not worse, or -- when
+    nobody solved it -- feasible to `feas_tol` with its own KKT certificate).  Asserts; returns the number judged."""
+    B = asm["B"]
+    names = list(results)
+    todo = [i for i in range(B) if any(results[nm]["status"][i] != 1 for nm in names)]
+    fails = []
+    for i in todo:
+        w = [(nm, results[nm]["dq"][i], results[nm]["status"][i] == 1) for nm in names]
+        ok, why = answer_is_acceptable(asm, i, dq_dev[i], w, tol=tol, feas_tol=feas_tol, active=active)
+        if not ok:
+            fails.append((i, why))
+    print(f"[remainder{' ' + label if label else ''}] {len(todo)} of {B} instances were not solved by every witness "
+          f"({', '.join(names)}); judged by the acceptance rule: {len(todo) - len(fails)} accepted, {len(fails)} not" + (f": {fails[:3]}" if fails else ""))
+    assert not fails, fails[:5]
+    return len(todo)
+
+
+def max_where(mask, values):
+    """max of values[mask], 0 when the mask is empty (the remainder is judge_remainder's)"""
+    return float(values[mask].max()) if np.any(mask) else 0.0

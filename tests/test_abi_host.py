@@ -29,6 +29,24 @@ def test_header_symbols_are_exported(lib):
         assert hasattr(lib, s), s
 
 
+def test_struct_layouts_match_the_compiled_header(lib):
+    """opensot_amd/abi.py mirrors the header's structs by hand: size and the offset of EVERY member against what the library
+    was compiled with (osot_abi_layout), and every struct typedef of the header has a mirror"""
+    hdr = open(os.path.join(ROOT, "include", "osot_mi355x.h")).read()
+    typedefs = set(re.findall(r"\}\s*(osot_[a-z_0-9]+)\s*;", hdr)) - {"osot_task_kind", "osot_bound_kind", "osot_rows_kind"}
+    assert typedefs == set(abi.STRUCTS), typedefs ^ set(abi.STRUCTS)
+    lib.osot_abi_layout.argtypes = [C.c_char_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.c_int, C.POINTER(C.c_int)]
+    for name, cls in abi.STRUCTS.items():
+        size, nf = C.c_ulonglong(), C.c_int()
+        offs = (C.c_ulonglong * 64)()
+        assert lib.osot_abi_layout(name.encode(), C.byref(size), offs, 64, C.byref(nf)) == abi.OK, name
+        assert size.value == C.sizeof(cls), (name, size.value, C.sizeof(cls))
+        mine = [getattr(cls, f[0]).offset for f in cls._fields_]
+        assert nf.value == len(mine), (name, nf.value, len(mine))
+        assert list(offs[:nf.value]) == mine, (name, list(offs[:nf.value]), mine)
+    assert lib.osot_abi_layout(b"no_such_struct", C.byref(size), None, 0, None) == abi.ERR_INVALID
+
+
 def test_version_and_error_text(lib):
     assert b"gfx950" in lib.osot_version()
     assert lib.osot_plan_validate(None) == abi.ERR_INVALID

@@ -154,3 +154,41 @@ def test_backend_options(gpu_device):
     assert not qp.solve() and qp.getOptions()["last_status"] == 2          # OSOT_STATUS_MAX_ITER
     assert qp.setOptions({"max_iterations": 0}) and qp.solve()
     assert not qp.setOptions({"max_iterations": -1})
+
+
+def test_solve_hot_starts_from_the_previous_working_set(gpu_device):
+    """QPOasesBackEnd::solve hot-starts every call (QPOasesBackEnd.cpp:258-285): a repeated solve() of the same problem re-adds the
+    previous working set without scans (never more iterations than the cold solve, the same x), a drifted g still lands on the
+    cold answer, and initProblem / a changed row count forget the set (QPOasesBackEnd.cpp:229-244)"""
+    rng = np.random.default_rng(31)
+    n, nc = 24, 10
+    H, g, A, lA, uA, l, u = [a[0] if a is not None else None for a in random_qp(rng, 1, n, nc, box=True, scale=1.0)]
+    g = g * 4.0                                                   # push the minimiser well outside the box: many active bounds
+    qp = BackEnd(n, nc, abi.HST_SEMIDEF, 1e6)
+    assert qp.initProblem(H, g, A, lA, uA, l, u)
+    x_cold, it_cold = qp.getSolution(), qp.getOptions()["last_iterations"]
+    assert it_cold >= 4                                           # (the test needs a non-trivial active set)
+    assert qp.solve()
+    x_hot, it_hot = qp.getSolution(), qp.getOptions()["last_iterations"]
+    np.testing.assert_allclose(x_hot, x_cold, atol=1e-10)
+    # fewer iterations than the cold solve: the hot trips skip the scans, and what is re-added is (mostly) the final set.  (Not
+    # necessarily exactly the size of the final set: the multipliers are looked at after every few hot additions, and a partial
+    # working set can show a negative multiplier that the complete one does not -- such a member is taken out and found again.)
+    print(f"[backend hot start] iterations cold {it_cold}, hot {it_hot}")
+    assert it_hot < it_cold
+    kkt_check(H[None], g[None], A[None], lA[None], uA[None], l[None], u[None], x_hot[None], qp.getEpsRegularisation())
+    g2 = g * (1.0 + 0.01 * rng.normal(size=n))                    # a drifting linear term: hot and cold agree
+    assert qp.updateTask(H, g2) and qp.solve()
+    x2 = qp.getSolution()
+    cold = BackEnd(n, nc, abi.HST_SEMIDEF, 1e6)
+    assert cold.initProblem(H, g2, A, lA, uA, l, u)
+    np.testing.assert_allclose(x2, cold.getSolution(), atol=1e-10)
+    # initProblem is a cold start again: the iteration count of the first solve comes back
+    assert qp.initProblem(H, g, A, lA, uA, l, u)
+    assert qp.getOptions()["last_iterations"] == it_cold
+    # ... and so is a changed row count
+    assert qp.updateConstraints(A[:6], lA[:6], uA[:6]) and qp.solve()
+    c6 = BackEnd(n, 6, abi.HST_SEMIDEF, 1e6)
+    assert c6.initProblem(H, g, A[:6], lA[:6], uA[:6], l, u)
+    np.testing.assert_allclose(qp.getSolution(), c6.getSolution(), atol=1e-10)
+    assert qp.getOptions()["last_iterations"] == c6.getOptions()["last_iterations"]

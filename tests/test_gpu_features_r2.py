@@ -35,13 +35,16 @@ def test_feature_stack_gpu(n, oracle, gpu_device):
     dq = st.dq[:B].cpu().numpy(); status = st.status[:B].cpu().numpy()
     ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=0)
     okr = ref["status"] == 1
-    assert okr.mean() > 0.95 and (status[okr] == 0).all() and np.abs(dq[okr] - ref["dq"][okr]).max() < 1e-9
+    assert (status == 0).all() and np.abs(dq[okr] - ref["dq"][okr]).max(initial=0.0) < 1e-9
+    wit = {"eiQuadProg": ref}
     if oracle.ref_available():
-        rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=0)
-        rx = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=0, termination_tolerance=10 * 2.221e-16)
+        rq = wit["qpOASES"] = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=0)
+        rx = wit["qpOASES exact"] = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=0, termination_tolerance=10 * 2.221e-16)
         e = np.minimum(np.where(rq["status"] == 1, np.abs(dq - rq["dq"]).max(axis=1), np.inf),
                        np.where(rx["status"] == 1, np.abs(dq - rx["dq"]).max(axis=1), np.inf))
-        assert np.isfinite(e).mean() > 0.95 and e[np.isfinite(e)].max() < 1e-6
+        assert e[np.isfinite(e)].max(initial=0.0) < 1e-6
+    from helpers import judge_remainder
+    judge_remainder(asm, dq, wit, label="feature stack")     # (an instance a witness gave up on is still judged)
 
 
 @pytest.mark.parametrize("off", [[(1, 0)], [(1, 1), (1, 2)], [(2, 0)], [(0, 0)]])
@@ -65,7 +68,9 @@ def test_task_set_active_gpu(off, oracle, gpu_device):
         rd = oracle.ihqp_solve_batch(asm_ref, oracle.BE_QPOASES_REF, nthreads=0)
         e = np.minimum(np.where(rq["status"] == 1, np.abs(dq - rq["dq"]).max(axis=1), np.inf),
                        np.where(rd["status"] == 1, np.abs(dq - rd["dq"]).max(axis=1), np.inf))
-        assert np.isfinite(e).mean() > 0.95 and e[np.isfinite(e)].max() < 1e-6
+        assert e[np.isfinite(e)].max(initial=0.0) < 1e-6
+        from helpers import judge_remainder
+        judge_remainder(asm_ref, dq, {"qpOASES exact": rq, "qpOASES": rd}, label=f"tasks {off} inactive")
     for k, j in off:
         st.set_task_active(k, j, True)
     st.update(dev); st.solve(B); torch.cuda.synchronize()

@@ -242,3 +242,27 @@ def test_inverse_dynamics_full_size(oracle, gpu_device):
         rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=0)
         within, rule, fails = parity_census(asm, dq[sub], [("qpOASES", rq), ("eiQuadProg", ref)], tol=1e-6, label="C5 full size")
         assert not fails and within >= 0.95 * asm["B"]
+
+
+@pytest.mark.gpu
+def test_bench_rccl_path_with_a_world_of_one(gpu_device):
+    """bench.py's multi-GPU path on the one GPU a test box has (OSOT_BENCH_FORCE_DIST=1): init_process_group("nccl"), one process
+    group and one ShardGather per lane on DEVICE tensors, the solver writing dq / status straight into the collective's send
+    block, the timing bracket with its barriers.  Every instance solved on "all ranks", and what the collective delivered is
+    the solver's own dq bit for bit."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env.update(OSOT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
+                        "--no-other-configs", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 4
+    assert out["solved_ok_all_ranks"] == "4096/4096" and out["solved_ok_rank0"] == "4096/4096"
+    assert out["gathered_vs_own_max_abs_dq_diff_rank0"] == 0.0
+    assert "RCCL all-gather" in out["config"]["workload"] and out["value"] > 1.0e6

@@ -517,13 +517,16 @@ def test_closed_loop_coman_ik_stack_with_contact_constraints(oracle, gpu_device)
     assert (h(st.status[:B]) == 0).all()
     ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
     okr = ref["status"] == 1
-    assert okr.mean() > 0.9 and np.abs(dq[okr] - ref["dq"][okr]).max() < 1e-9
+    assert np.abs(dq[okr] - ref["dq"][okr]).max(initial=0.0) < 1e-9
+    wit = {"eiQuadProg": ref}
     if oracle.ref_available():
-        rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
-        rx = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1, termination_tolerance=10 * 2.221e-16)
+        rq = wit["qpOASES"] = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
+        rx = wit["qpOASES exact"] = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1, termination_tolerance=10 * 2.221e-16)
         e = np.minimum(np.where(rq["status"] == 1, np.abs(dq - rq["dq"]).max(axis=1), np.inf),
                        np.where(rx["status"] == 1, np.abs(dq - rx["dq"]).max(axis=1), np.inf))
-        assert np.isfinite(e).mean() > 0.9 and e[np.isfinite(e)].max() < 1e-6
+        assert e[np.isfinite(e)].max(initial=0.0) < 1e-6
+    from helpers import judge_remainder
+    judge_remainder(asm, dq, wit, label="coman_ik stack with contact constraints")    # (no instance goes unjudged)
     # the feet rows hold exactly: J_sole dq = b_sole
     Cs = h(st.C[:B]); los = h(st.lo[:B])
     assert np.abs(np.einsum("bri,bi->br", Cs, dq) - los).max() < 1e-10
