@@ -457,6 +457,106 @@ def time_coman35(which, B, device, steps=20, warmup=5, front_end="iHQP"):
     return out
 
 
+def time_full_cycle(B, device, lanes=2, steps=40, warmup=8):
+    """q -> kinematics -> AutoStack::update + cascade -> q += dq for the 32-DoF humanoid under BASELINE config 3's stack (CoM / l_wrist(0.1)
+    + r_wrist + l_sole + r_sole / Postural, joint-limit and velocity-limit box), everything resident, submitted like the headline: the
+    batch as `lanes` sub-batches on their own streams, the steps of a lane as ONE HIP graph (kinematics launch, fused update + cascade
+    launch, the integration of q).  The inputs of consecutive steps are the closed loop's own drift (every robot chases its own wrist
+    goals); nothing is replayed from a recorded cycle."""
+    from opensot_amd import abi
+    from opensot_amd import kinematics as kin
+    from opensot_amd.parallel import lane_ranges
+    from opensot_amd.plan import Bound, StackPlan, Task, eps_abs_from_factor
+    from opensot_amd.solver import BatchedStack
+    m = kin.humanoid32()
+    n = m.n
+    levels = [[Task(abi.TASK_COM, 3, lam=0.1, name="com")],
+              [Task(abi.TASK_CARTESIAN, 6, weight=0.1, lam=0.1, name="l_wrist"), Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="r_wrist"),
+               Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="l_sole"), Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="r_sole")],
+              [Task(abi.TASK_POSTURAL, n, lam=0.01, name="postural")]]
+    bounds = [Bound(abi.BOUND_JOINT_LIMITS, scaling=1.0, name="jl"), Bound(abi.BOUND_VELOCITY_LIMITS, dT=0.01, name="vl")]
+    plan = StackPlan(n=n, levels=levels, bounds=bounds, rowblocks=[], eps_abs=eps_abs_from_factor(1e6))
+    dev = torch.device("cuda", device)
+    f64 = dict(dtype=torch.float64, device=dev)
+    rng = np.random.default_rng(32)
+    K = kin.Kinematics(m, device=device)
+    work = []
+    for a, b in lane_ranges(B, lanes):
+        Bl = b - a
+        q0 = np.zeros((Bl, n))
+        q0[:, [m.names.index(s_ + "KneeSag") for s_ in "RL"]] = 0.5
+        q0[:, [m.names.index(s_ + "HipSag") for s_ in "RL"]] = -0.25
+        q0[:, [m.names.index(s_ + "AnkSag") for s_ in "RL"]] = -0.25
+        q0[:, [m.names.index(s_ + "Elbj") for s_ in "RL"]] = -0.6
+        q0 += rng.normal(0.0, 0.02, (Bl, n))
+        st = BatchedStack(plan, Bl, device=device, want_levels=False)
+        q = torch.as_tensor(q0, **f64).contiguous()
+        pose = [torch.zeros((Bl, 12), **f64) for _ in range(4)]
+        com = torch.zeros((Bl, 3), **f64)
+        stream = torch.cuda.Stream(device=dev)
+        st.stream = stream
+
+        def fk(q=q, pose=pose, com=com, st=st):
+            K.forward(q, frame_pose={f: pose[f] for f in range(4)}, frame_J={f: (st.A[1], 6 * f) for f in range(4)}, com=com, com_J=(st.A[0], 0))
+        fk(); torch.cuda.synchronize()
+        pose_d = [p_.clone() for p_ in pose]
+        for f in (0, 1):
+            pose_d[f][:, 9:] += torch.as_tensor(rng.uniform(-0.15, 0.15, (Bl, 3)), **f64)
+        com_d = com.clone()
+        qmin = torch.full((Bl, n), -2.5, **f64); qmax = torch.full((Bl, n), 2.5, **f64)
+        qdot_max = torch.full((Bl, n), 2.0, **f64)
+        q_ref = q.clone()
+        leaf = {"B": Bl, "task": [[(com, com_d, None)], [(pose[f], pose_d[f], None) for f in range(4)], [(q, q_ref, None)]],
+                "bound": [(q, qmin, qmax), (qdot_max, None, None)], "rows": []}
+
+        def step(fk=fk, st=st, leaf=leaf, q=q, Bl=Bl, stream=stream):
+            with torch.cuda.stream(stream):
+                fk()
+                st.cycle(leaf, cached=True)
+                q.add_(st.dq[:Bl])
+        work.append((st, step, stream, Bl))
+    for _ in range(warmup):
+        for _, step, _, _ in work:
+            step()
+    torch.cuda.synchronize()
+    graphs, note = [], None
+    try:
+        for st, step, stream, _ in work:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                for _ in range(steps):
+                    step()
+            graphs.append(g)
+    except Exception as e:
+        graphs, note = [], f"graph capture unavailable: {e}"[:200]
+        for st, _, _, _ in work:
+            st.set_schedule(True)
+    torch.cuda.synchronize()
+
+    def run_all():
+        if graphs:
+            for g, (_, _, stream, _) in zip(graphs, work):
+                with torch.cuda.stream(stream):
+                    g.replay()
+        else:
+            for _ in range(steps):
+                for _, step, _, _ in work:
+                    step()
+    run_all(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_all()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ok = sum(int((st.status[:Bl] == 0).sum().item()) for st, _, _, Bl in work)
+    return {"workload": "full control cycle on the device, BASELINE configs[2] stack on the 32-DoF humanoid: q -> osot_kin_kernel (4 frame poses + "
+                        "Jacobians, CoM + Jacobian, written into A_k) -> osot_cycle_kernel (update + cascade) -> q += dq; closed loop, every robot "
+                        f"chasing its own wrist goals; {lanes} sub-batches on their own streams, {steps} steps of a lane per HIP graph" + ("" if graphs else " (plain launches)"),
+            "batch": B, "lanes": lanes, "value": B * steps / el, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
+            "solved_ok": f"{ok}/{B}", "note": note,
+            "roofline": roofline_of(plan, B, 1e3 * el / steps, steps * lanes, "osot_kin_kernel<false,32> + osot_cycle_kernel<32,false,true> + the integration of q "
+                                    "(whole step time as the divisor)")[0]}
+
+
 def time_config5_coherent(B, device, steps=40, warmup=8, cycles=4, drift=0.01):
     """BASELINE config 5 at its shard size over TEMPORALLY COHERENT cycles (the headline's protocol: every input drifts 1 % from
     cycle to cycle), cold start against the hot start of the working sets (osot_solver_set_hotstart: what the reference's
@@ -937,6 +1037,10 @@ def main():
                     oc["COMAN35_" + which] = time_coman35(which, 4096, local_rank)
                 except Exception as e:
                     oc["COMAN35_" + which] = {"error": str(e)[:300]}
+            try:
+                oc["full_cycle"] = time_full_cycle(Bl, local_rank, lanes=S)
+            except Exception as e:
+                oc["full_cycle"] = {"error": str(e)[:300]}
             try:
                 oc["C5_coherent"] = time_config5_coherent(1024, local_rank)
             except Exception as e:

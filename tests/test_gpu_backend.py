@@ -176,7 +176,7 @@ def test_solve_hot_starts_from_the_previous_working_set(gpu_device):
     # working set can show a negative multiplier that the complete one does not -- such a member is taken out and found again.)
     print(f"[backend hot start] iterations cold {it_cold}, hot {it_hot}")
     assert it_hot < it_cold
-    kkt_check(H[None], g[None], A[None], lA[None], uA[None], l[None], u[None], x_hot[None], qp.getEpsRegularisation())
+    assert kkt_check(H, g, A, lA, uA, l, u, x_hot, qp.getEpsRegularisation()) < 1e-7
     g2 = g * (1.0 + 0.01 * rng.normal(size=n))                    # a drifting linear term: hot and cold agree
     assert qp.updateTask(H, g2) and qp.solve()
     x2 = qp.getSolution()
