@@ -1037,6 +1037,10 @@ def main():
                     oc["COMAN35_" + which] = time_coman35(which, 4096, local_rank)
                 except Exception as e:
                     oc["COMAN35_" + which] = {"error": str(e)[:300]}
+            try:     # the reference's S3 through its null-space front-end (published: 0.3191 ms per solve)
+                oc["COMAN35_S3_nHQP"] = time_coman35("S3", 4096, local_rank, steps=6, warmup=2, front_end="nHQP")
+            except Exception as e:
+                oc["COMAN35_S3_nHQP"] = {"error": str(e)[:300]}
             try:
                 oc["full_cycle"] = time_full_cycle(Bl, local_rank, lanes=S)
             except Exception as e:

@@ -378,7 +378,8 @@ int osot_solver_profile_phases(osot_solver* s, const osot_qp_batch* batch, long 
  * Same stack, same assembled arrays as osot_ihqp_solve; per level the task is projected into the cumulated null space N of
  * the levels above, an SVD of A N drives the reference's A/b regularisation and yields the level's null space, the QP is
  * solved in the nf free coordinates (bounds become rows N z, compute_contraints :282-317) and q += N z, N <- N V2.  Three
- * launches per level (prepare, the batched QP kernel, accumulate).  n <= 32, <= 64 rows per level, diagonal weights,
+ * launches per level (prepare, the batched QP kernel, accumulate).  n <= 64 (round 4; at every level min(rows, free
+ * variables) <= 32: the level's SVD goes through a 32-wide eigen-decomposition), <= 64 rows per level, diagonal weights,
  * global rows and the box only (the reference refuses task-local constraints, nHQP.cpp:41-44). */
 typedef struct {
     int free_vars[OSOT_MAX_LEVELS];      /* free variables of each level.  The reference fixes them in its constructor from the

@@ -508,6 +508,295 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: the same level preparation for 32 < n <= 64 variables (the reference's own COMAN has 35 coordinates, BASELINE config 5
+// has 50).  One lane per COLUMN of N / A N (64 lanes, no halves), row stride 65; the small-side Gram matrix and its
+// eigen-decomposition stay 32-wide (sym_eig32), i.e. min(rows of the level, free variables) <= 32 at every level -- what every stack
+// of the reference's example satisfies below its first level and with up to 32 task rows at the first (nhqp_validate refuses the
+// rest).  Same arithmetic as osot_nhqp_prepare_kernel, block by block; LDS: A N (MR x 65) + N / E / V2 (64 x 65) + the 64 x 33
+// work matrix + vectors, dynamic (nhqp_prepare64_lds_bytes).
+constexpr int kNS64 = 65;
+inline size_t nhqp_prepare64_lds_bytes(int MR) { return sizeof(double) * ((size_t)MR * kNS64 + 64 * kNS64 + 64 * kNS + 8 * 64 + 64 + 64 + 32 + 32) + sizeof(int) * 32; }
+
+template <int MR>
+__global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q) {
+    OSOT_DYNAMIC_LDS(nh_smem);
+    constexpr int S = kNS64;
+    double* AN = reinterpret_cast<double*>(nh_smem);   // A N (m x nf), stride 65
+    double* NE = AN + MR * S;                          // N (n x nf, stride 65) -> E (32 x 33 view) -> V2 on the row side (stride 65)
+    double* K = NE + 64 * S;                           // [64][33]: Gram matrix (k x k) -> V1 / reflectors (nf rows) -> V2 on the column side
+    double* stage = K + 64 * kNS;                      // [8][64]: eight rows of A / C staged for the products
+    double* b0 = stage + 8 * 64;                       // [64]
+    double* vec = b0 + 64;                             // [64]
+    double* sig = vec + 64;                            // [32]
+    double* refl_beta = sig + 32;                      // [32]
+    int* idx = reinterpret_cast<int*>(refl_beta + 32); // [32]
+    double* Nl = NE;
+    double* E = NE;                                    // (stride kNS inside the same buffer: N is dead by then)
+    const long long inst = blockIdx.x;
+    const int lane = threadIdx.x, c = lane;
+    const int c32 = lane & 31, h32 = lane >> 5;        // the lane coordinates sym_eig32 works in
+    if (inst >= Q.B) return;
+    if (Q.status && Q.status[inst] != 0) return;
+    const int n = Q.n, m = Q.m, ma = Q.ma, nf = Q.nf, ns = Q.ns;
+    const bool first = Q.level == 0;
+    const double* A = Q.A ? Q.A + inst * (long long)ma * n : nullptr;
+    for (int e = lane; e < 64 * S; e += 64) Nl[e] = 0.0;
+    for (int e = lane; e < 64 * kNS; e += 64) K[e] = 0.0;
+    for (int e = lane; e < MR * S; e += 64) AN[e] = 0.0;
+    wave_sync();
+    if (first) { if (c < n) Nl[c * S + c] = 1.0; }
+    else {
+        const double* Ng = Q.N + inst * (long long)n * n;
+        for (int i = 0; i < n; ++i) if (c < nf) Nl[i * S + c] = Ng[i * n + c];
+    }
+    vec[lane] = (!first && lane < n) ? Q.q0[inst * n + lane] : 0.0;     // q0 staged
+    wave_sync();
+    // ---- AN = A N, eight stored rows per batch: lane i loads A[r][i] (coalesced), the rows go through LDS, lane c accumulates
+    double aq_row = 0.0;      // lane = stored row r: (A q0)_r
+    for (int rb = 0; rb < ma; rb += 8) {
+        double a8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a8[u] = (rb + u < ma && lane < n) ? A[(rb + u) * n + lane] : 0.0;
+        wave_sync();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) stage[u * 64 + lane] = a8[u];
+        wave_sync();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (rb + u < ma) {
+                double acc = 0.0;
+                for (int i = 0; i < n; ++i) acc = fma(stage[u * 64 + i], Nl[i * S + c], acc);
+                if (c < nf) AN[(rb + u) * S + c] = acc;
+                const double aq = colsum<64>(a8[u] * vec[lane]);
+                if (lane == rb + u) aq_row = aq;
+            }
+        }
+    }
+    wave_sync();
+    for (int r = ma; r < m; ++r) if (c < nf) AN[r * S + c] = Nl[(r - ma) * S + c];
+    {
+        double v = 0.0;
+        if (lane < m) {
+            v = Q.b[inst * m + lane];
+            if (!first) { if (lane < ma) v -= aq_row; else v -= vec[lane - ma]; }
+        }
+        b0[lane] = v;
+    }
+    wave_sync();
+    // ---- constraints in z-coordinates (levels below the first): rows [C N; N], bounds shifted by q0
+    if (!first) {
+        const int nr = Q.nc + (Q.has_box ? n : 0);
+        double* Rg = Q.R + inst * (long long)nr * nf;
+        for (int rb = 0; rb < Q.nc; rb += 8) {
+            double c8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) c8[u] = (rb + u < Q.nc && lane < n) ? Q.C[(inst * (long long)Q.nc + rb + u) * n + lane] : 0.0;
+            wave_sync();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) stage[u * 64 + lane] = c8[u];
+            wave_sync();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (rb + u < Q.nc) {
+                    const int r = rb + u;
+                    double acc = 0.0;
+                    for (int i = 0; i < n; ++i) acc = fma(stage[u * 64 + i], Nl[i * S + c], acc);
+                    if (c < nf) Rg[r * nf + c] = acc;
+                    const double cq = colsum<64>(c8[u] * vec[lane]);
+                    if (lane == 0) {
+                        const double lo = Q.lo[inst * Q.nc + r], up = Q.up[inst * Q.nc + r];
+                        Q.rlo[inst * nr + r] = (lo <= -1.0e20) ? -1.0e20 : lo - cq;
+                        Q.rup[inst * nr + r] = (up >= 1.0e20) ? 1.0e20 : up - cq;
+                    }
+                }
+            }
+        }
+        if (Q.has_box) {
+            for (int i = 0; i < n; ++i) if (c < nf) Rg[(Q.nc + i) * nf + c] = Nl[i * S + c];
+            if (lane < n) {
+                const double l = Q.l[inst * n + lane], u = Q.u[inst * n + lane];
+                Q.rlo[inst * nr + Q.nc + lane] = (l <= -1.0e20) ? -1.0e20 : l - vec[lane];
+                Q.rup[inst * nr + Q.nc + lane] = (u >= 1.0e20) ? 1.0e20 : u - vec[lane];
+            }
+        }
+    }
+    wave_sync();      // N is dead from here on: its buffer becomes E (and later V2)
+    // ---- Gram matrix of the small side (k <= 32), stride kNS
+    const bool rowside = m <= nf;
+    const int k = rowside ? m : nf;
+    if (rowside) {
+        for (int a = 0; a < m; ++a) {
+            double acc = 0.0;
+            if (c < m) for (int t = 0; t < nf; ++t) acc = fma(AN[a * S + t], AN[c * S + t], acc);
+            if (c < m) K[a * kNS + c] = acc;
+        }
+    } else {
+        for (int a = 0; a < nf; ++a) {
+            double acc = 0.0;
+            if (c < nf) for (int r = 0; r < m; ++r) acc = fma(AN[r * S + a], AN[r * S + c], acc);
+            if (c < nf) K[a * kNS + c] = acc;
+        }
+    }
+    wave_sync();
+    for (int e = lane; e < 32 * kNS; e += 64) E[e] = 0.0;
+    wave_sync();
+    sym_eig32(K, E, k, c32, h32);
+    {
+        const double lam = (c < k) ? K[c * kNS + c] : -1.0;
+        vec[lane] = lam;
+        wave_sync();
+        int pos = 0;
+        for (int d = 0; d < k; ++d) { const double ld = vec[d]; pos += (ld > lam || (ld == lam && d < c)) ? 1 : 0; }
+        if (c < k) { idx[pos] = c; sig[pos] = sqrt(lam > 0.0 ? lam : 0.0); }
+        wave_sync();
+    }
+    const double sv_max = sig[0];
+    constexpr double kSvNoise = 1.0e-7;
+    int rho = 0;
+    for (int i = 0; i < k; ++i) rho += (sig[i] >= kSvNoise * sv_max && sig[i] > 0.0) ? 1 : 0;
+    const int r_next = nf - ns;
+    const int nrefl = rowside ? (rho < r_next ? rho : r_next) : 0;
+    const bool need_refl = rowside && (ns > 0 || (Q.ab_reg && rho < k));
+    double* V1 = K;          // V1[t][i]: component t (< nf <= 64) of v_i (i < 32), then reflector i
+    if (need_refl) {
+        // (K still holds the eigenvalues on its diagonal: they are in sig[] now; clear what V1 uses)
+        wave_sync();
+        for (int e = lane; e < 64 * kNS; e += 64) K[e] = 0.0;
+        wave_sync();
+        for (int i = 0; i < nrefl; ++i) {
+            const int ec = idx[i];
+            double vv = 0.0;
+            if (c < nf) for (int q = 0; q < m; ++q) vv = fma(AN[q * S + c], E[q * kNS + ec], vv);
+            const double nrm2 = colsum<64>((c < nf) ? vv * vv : 0.0);
+            vv = (nrm2 > 0.0) ? vv / sqrt(nrm2) : 0.0;
+            if (c < nf) V1[c * kNS + i] = vv;
+        }
+        wave_sync();
+        for (int i = 0; i < nrefl; ++i) {
+            const double x = (c >= i && c < nf) ? V1[c * kNS + i] : 0.0;
+            const double nrm2 = colsum<64>(x * x);
+            const double xi = bcast(x, i);
+            const double alpha = (xi > 0.0) ? -sqrt(nrm2) : sqrt(nrm2);
+            double hv = (c == i) ? x - alpha : x;
+            const double vn2 = colsum<64>(hv * hv);
+            const double beta = (vn2 > 0.0) ? 2.0 / vn2 : 0.0;
+            wave_sync();
+            if (c < nf) V1[c * kNS + i] = hv;
+            for (int j = i + 1; j < nrefl; ++j) {
+                const double y = (c < nf) ? V1[c * kNS + j] : 0.0;
+                const double dot = colsum<64>(hv * y);
+                wave_sync();
+                if (c < nf) V1[c * kNS + j] = y - beta * dot * hv;
+                wave_sync();
+            }
+            if (c == 0) refl_beta[i] = beta;
+            wave_sync();
+        }
+    }
+    auto completion_column = [&](int j) -> double {           // (Q e_j)[c], j >= nrefl
+        double y = (c == j) ? 1.0 : 0.0;
+        for (int i = nrefl - 1; i >= 0; --i) {
+            const double hv = (c >= i && c < nf) ? V1[c * kNS + i] : 0.0;
+            const double dot = colsum<64>(hv * y);
+            y -= refl_beta[i] * dot * hv;
+        }
+        return y;
+    };
+    if (Q.ab_reg) {
+        double bnew = 0.0;
+        const bool rebuild = !rowside;
+        for (int i = 0; i < k; ++i) {
+            const double sv = sig[i];
+            const bool lift = sv < Q.thr * sv_max;
+            if (!lift && !rebuild) continue;
+            const int ec = idx[i];
+            double uu = 0.0, vv = 0.0;
+            if (rowside) {
+                uu = (lane < m) ? E[lane * kNS + ec] : 0.0;
+                if (i >= rho) {
+                    const double qc = completion_column(i);
+                    vv = (c < nf) ? qc : 0.0;
+                } else {
+                    double acc = 0.0;
+                    if (c < nf) for (int r = 0; r < m; ++r) acc = fma(AN[r * S + c], E[r * kNS + ec], acc);
+                    vv = acc;
+                    const double nrm2 = colsum<64>((c < nf) ? vv * vv : 0.0);
+                    vv = (nrm2 > 0.0) ? vv / sqrt(nrm2) : 0.0;
+                }
+            } else {
+                vv = (c < nf) ? E[c * kNS + ec] : 0.0;
+                double acc = 0.0;
+                if (lane < m) for (int t = 0; t < nf; ++t) acc = fma(AN[lane * S + t], E[t * kNS + ec], acc);
+                const double nrm2 = colsum<64>(acc * acc);
+                uu = (nrm2 > 0.0) ? acc / sqrt(nrm2) : 0.0;
+            }
+            const double ub = colsum<64>((lane < m) ? uu * b0[lane] : 0.0);
+            double d = 1.0, svn = sv;
+            if (lift) { d = sv / (Q.thr * sv_max); svn = (Q.thr * sv_max) * (Q.thr * sv_max) / (sv + Q.thr / 100.0); }
+            if (rebuild) bnew = fma(d * ub, uu, bnew);
+            else if (lane < m) b0[lane] -= (1.0 - d) * ub * uu;
+            if (lift) {
+                wave_sync();
+                vec[lane] = (lane < m) ? uu : 0.0;
+                wave_sync();
+                const double dl = svn - sv;
+                for (int r = 0; r < m; ++r) if (c < nf) AN[r * S + c] = fma(dl * vec[r], vv, AN[r * S + c]);
+                wave_sync();
+            }
+        }
+        if (rebuild && lane < m) b0[lane] = bnew;
+        wave_sync();
+    }
+    // ---- null-space basis V2 (nf x ns): row side in NE (stride 65), column side in K (stride 33)
+    double* V2 = rowside ? NE : K;
+    const int v2s = rowside ? S : kNS;
+    if (ns > 0) {
+        if (!rowside) {
+            for (int t = 0; t < ns; ++t) { const int ec = idx[k - ns + t]; if (c < nf) V2[c * v2s + t] = E[c * kNS + ec]; }
+            wave_sync();
+        } else {
+            // the completion columns are computed first (they read V1 = K only), then written over E / N in NE
+            for (int t0 = 0; t0 < ns; t0 += 8) {
+                double y8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) y8[u] = (t0 + u < ns) ? completion_column(r_next + t0 + u) : 0.0;
+                wave_sync();
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (t0 + u < ns && c < nf) V2[c * v2s + t0 + u] = y8[u];
+            }
+            wave_sync();
+        }
+    }
+    // ---- H = AN' W AN (+ sv_max V2 V2'), g = -AN' W b0   ->  HBM, nf x nf row-major
+    {
+        const double* w = Q.w ? Q.w + inst * m : nullptr;
+        wave_sync();
+        vec[lane] = (lane < m) ? (w ? w[lane] : 1.0) : 0.0;
+        wave_sync();
+        double* Hg = Q.H + inst * (long long)nf * nf;
+        const int cc = (c < nf) ? c : 0;
+        double gacc = 0.0;
+        for (int r = 0; r < m; ++r) gacc = fma(-(vec[r] * AN[r * S + cc]), b0[r], gacc);
+        if (c < nf) Q.g[inst * nf + c] = gacc;
+        const bool sel = ns > 0 && Q.sel_reg;
+        for (int i = 0; i < nf; ++i) {
+            double a0 = 0.0, a1 = 0.0;
+            for (int r = 0; r + 1 < m; r += 2) {
+                a0 = fma(vec[r] * AN[r * S + cc], AN[r * S + i], a0);
+                a1 = fma(vec[r + 1] * AN[(r + 1) * S + cc], AN[(r + 1) * S + i], a1);
+            }
+            if (m & 1) a0 = fma(vec[m - 1] * AN[(m - 1) * S + cc], AN[(m - 1) * S + i], a0);
+            if (sel) for (int t = 0; t < ns; ++t) a0 = fma(sv_max * V2[cc * v2s + t], V2[i * v2s + t], a0);
+            if (c < nf) Hg[i * nf + c] = a0 + a1;
+        }
+    }
+    if (ns > 0 && Q.V2) {
+        double* Vg = Q.V2 + inst * (long long)n * n;
+        for (int i = 0; i < nf; ++i) if (c < ns) Vg[i * n + c] = V2[i * v2s + c];
+    }
+}
+
 struct DevNhqpAcc {
     int B, n, nf, ns, first, last;
     const double* z;       // [B][nf] the level's QP solution
@@ -520,12 +809,14 @@ struct DevNhqpAcc {
     double* dq;            // [B][n] written at the last level
 };
 
-// solution += N z;  N <- N V2  (nHQP.cpp:182-196).  lane = c + 32 h
+// solution += N z;  N <- N V2  (nHQP.cpp:182-196).  n <= 32: lane = c + 32 h (the halves split the sum); 32 < n <= 64: lane = row
 __global__ void __launch_bounds__(64) osot_nhqp_accumulate_kernel(const DevNhqpAcc Q) {
     const long long inst = blockIdx.x;
-    const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
+    const int lane = threadIdx.x;
     if (inst >= Q.B) return;
     const int n = Q.n, nf = Q.nf, ns = Q.ns;
+    const bool wide = n > 32;
+    const int c = wide ? lane : (lane & 31), h = wide ? 0 : (lane >> 5), hv = wide ? 1 : 2;
     int st = Q.first ? 0 : Q.status[inst];
     if (st == 0 && Q.qp_status[inst] != 0) st = Q.qp_status[inst];
     if (lane == 0) Q.status[inst] = st;
@@ -538,9 +829,9 @@ __global__ void __launch_bounds__(64) osot_nhqp_accumulate_kernel(const DevNhqpA
     double acc = 0.0;
     if (c < n) {
         if (Q.first) acc = (h == 0) ? z[c] : 0.0;
-        else for (int j = h; j < nf; j += 2) acc = fma(Ng[c * n + j], z[j], acc);
+        else for (int j = h; j < nf; j += hv) acc = fma(Ng[c * n + j], z[j], acc);
     }
-    acc = halfsum<32>(acc);
+    if (!wide) acc = halfsum<32>(acc);
     const double qn = (Q.first ? 0.0 : ((c < n) ? Q.q0[inst * n + c] : 0.0)) + acc;
     if (h == 0 && c < n) { Q.q0[inst * n + c] = qn; if (Q.last) Q.dq[inst * n + c] = qn; }
     if (!Q.last && ns > 0) {

@@ -20,7 +20,7 @@ inline NhqpSizes nhqp_sizes(const osot_plan_desc& p, int B) {
 
 // what the reference's constructor refuses, and what this build does not cover
 inline int nhqp_validate(const osot_plan_desc& p, const osot_nhqp_options* opt, int free_vars[OSOT_MAX_LEVELS], const char** why) {
-    if (p.n > 32) { *why = "nHQP front-end: n <= 32 in this build"; return OSOT_ERR_UNSUPPORTED; }
+    if (p.n > OSOT_MAX_VARS) { *why = "nHQP front-end: n <= 64"; return OSOT_ERR_UNSUPPORTED; }
     if (p.has_regularisation) { *why = "nHQP has no regularisation task"; return OSOT_ERR_UNSUPPORTED; }
     for (int j = 0; j < p.n_rowblocks; ++j) {
         if (p.rowblock[j].only_level != 0) { *why = "[nHQP] Local constraints not supported"; return OSOT_ERR_UNSUPPORTED; }   // nHQP.cpp:41-44
@@ -36,6 +36,8 @@ inline int nhqp_validate(const osot_plan_desc& p, const osot_nhqp_options* opt, 
         if (k == 0) { if (given != 0 && given != p.n) { *why = "free_vars[0] must be n"; return OSOT_ERR_INVALID; } }
         else if (given != 0) nf = given;
         if (nf <= 0 || nf > p.n) { *why = "[nHQP] No free variables left at a layer: decrease the number of layers!"; return OSOT_ERR_INVALID; }   // nHQP.cpp:32-35
+        // the level's SVD goes through the eigen-decomposition of the SMALL-side Gram matrix, 32-wide (sym_eig32)
+        if ((m < nf ? m : nf) > 32) { *why = "nHQP front-end: min(rows of a level, its free variables) <= 32"; return OSOT_ERR_UNSUPPORTED; }
         free_vars[k] = nf;
         nf = nf - m;       // default for the next level: full row rank (the constructor's count, nHQP.cpp:88-91, on a full-rank task)
     }

@@ -1367,11 +1367,12 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
     int hot_i = 0;
     bool hot_check = false;     // hot additions were made: their multipliers have to be looked at
     // A STALE hot list must not cost more than it can save (round 4; the launch is its longest instance): the multipliers are looked
-    // at after every kHotBatch additions, and once kHotAbandon members of the list have been taken out again the rest of the list
-    // is dropped -- the instance goes on as from a cold start from the S-pair it has reached.  Worst case: kHotBatch + kHotAbandon - 1
-    // wasted additions and as many removals, instead of the whole list twice.
+    // at after every kHotBatch additions, and when at least kHotAbandon of them AND a quarter of the additions made so far are negative
+    // the rest of the list is not tried -- the instance takes out what does not belong (below) and goes on as from a cold start from
+    // the S-pair it has reached.  Nothing is removed at such a look: a PARTIAL working set can show a negative multiplier that the
+    // complete one does not (on an exact repeat of a cycle the whole list goes in, as before).
     constexpr int kHotBatch = 4, kHotAbandon = 3;
-    int hot_since_check = 0, hot_drops = 0;
+    int hot_since_check = 0, hot_added = 0;
     // table entries of the hot list's rows, lane q = entry q, fetched in ONE round trip when the first hot trip starts (the
     // table may live in device memory: bound, state and row address were three dependent loads in front of every hot trip)
     bool hm_loaded = false;
@@ -1420,11 +1421,16 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
             double um = mine ? uq : INFINITY;
             int pos = c;
             const double uabs = uniform_d(colmax<NP>(mine ? fabs(uq) : 0.0));
+            if (hot_i < hot_n) {      // a look in the middle of the list: count, do not remove
+                const int nneg = __builtin_popcountll(wave_ballot(mine && h == 0 && uq < -kHotDropTol * uabs));
+                hot_since_check = 0;
+                if (nneg >= kHotAbandon && 4 * nneg >= hot_added) hot_n = hot_i;
+                continue;
+            }
             colargmin<NP>(um, pos);
             pos = uniform_i(pos);
             um = bcast(um, 0);
             if (!(um < -kHotDropTol * uabs)) { hot_check = false; hot_since_check = 0; continue; }
-            if (++hot_drops >= kHotAbandon) hot_n = hot_i;       // (the list is stale: no further member is tried)
             mode = 2;
             u_rev = um;
             code = bcast_i(Aq, pos);
@@ -1697,7 +1703,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                 if (ip_box) { if (c == ip_var) box_state = (ip < n) ? 1 : 2; }
                 else { if (c == 0 && h == 0) w.rowstate[ip_row] = (ip & 1) ? 2 : 1; }
                 iq++;
-                if (mode == 1) { hot_check = true; hot_since_check++; }
+                if (mode == 1) { hot_check = true; hot_since_check++; hot_added++; }
                 wave_sync();
                 OSOT_SUB_END(PH_IN_HH);
                 break;

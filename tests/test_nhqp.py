@@ -51,6 +51,65 @@ def test_emulated_kernels_match_restatement(cfg, opts, oracle):
     assert np.isfinite(dq).all() and (dq >= asm["l"] - 1e-7).all() and (dq <= asm["u"] + 1e-7).all()
 
 
+@pytest.mark.parametrize("n,rows,n_ineq,seed", [(35, [3, 12], 3, 2), (40, [10, 12], 4, 3), (50, [6, 20, 10], 0, 4), (64, [20, 30], 5, 5)])
+def test_more_than_32_variables_emulated(n, rows, n_ineq, seed, oracle):
+    """33 .. 64 variables (round 4: osot_nhqp_prepare64_kernel; the reference's COMAN has 35 coordinates, config 5 has 50): the
+    64-column level preparation + the 64-lane QP kernel + the accumulation against the numpy-SVD restatement"""
+    from oracle import pynhqp
+    plan, leaf = synth.make_generic_stack(4, n, rows, n_eq=0, n_ineq=n_ineq, seed=seed, box=0.4)
+    asm = oracle.assemble(plan, leaf)
+    ref = pynhqp.nhqp_solve(asm, backend="qpoases" if oracle.ref_available() else "eiqp", termination_tolerance=10 * 2.221e-16)
+    dq, st = emu_nhqp(plan, asm)
+    ok = ref["status"] == 1
+    assert ok.all() and (st == 0).all()
+    assert np.abs(dq - ref["dq"]).max() < 1e-9
+
+
+def test_level_wider_than_the_eigen_solver_is_refused(oracle):
+    """min(rows, free variables) of a level beyond 32 (a 40-row level in 48 variables): refused with a message, not mis-solved"""
+    import ctypes as C
+    from helpers import emu_lib
+    from opensot_amd import abi
+    plan, leaf = synth.make_generic_stack(2, 48, [40], n_eq=0, n_ineq=0, seed=1, box=0.4, postural_last=False)
+    qb = abi.QpBatch(); qb.B = 2
+    L = emu_lib()
+    L.emu_nhqp_solve.argtypes = [C.POINTER(abi.PlanDesc), C.POINTER(abi.QpBatch), C.POINTER(abi.NhqpOptions)]
+    pd = plan.to_c(); opt = abi.NhqpOptions()
+    assert L.emu_nhqp_solve(C.byref(pd), C.byref(qb), C.byref(opt)) == abi.ERR_UNSUPPORTED
+
+
+def test_min_sv_ratio_is_honoured_without_the_flag(oracle):
+    """osot_nhqp_options.min_sv_ratio = 0.2 with min_sv_ratio_is_set left at 0 used to be silently replaced by 0.05"""
+    import ctypes as C
+    from helpers import emu_lib
+    from opensot_amd import abi
+    from oracle import pynhqp
+    plan, leaf = synth.make_velocity_stack("C3", 4, seed=17)
+    asm = oracle.assemble(plan, leaf)
+    want, _ = emu_nhqp(plan, asm, min_sv_ratio=0.2)                 # (the helper sets the flag)
+    dflt, _ = emu_nhqp(plan, asm)
+    assert np.abs(want - dflt).max() > 1e-6                         # (the option matters on this stack)
+    dq = np.zeros_like(want); st = np.full(4, -1, dtype=np.int32)
+    qb = abi.QpBatch(); qb.B = 4
+    keep = []
+    for k in range(asm["L"]):
+        for name in ("A", "b", "w"):
+            a = asm[name][k]
+            if a is not None:
+                a = np.ascontiguousarray(a, dtype=np.float64); keep.append(a); getattr(qb, name)[k] = a.ctypes.data
+    for name in ("C", "lo", "up", "l", "u"):
+        a = asm[name]
+        if a is not None and a.size:
+            a = np.ascontiguousarray(a, dtype=np.float64); keep.append(a); setattr(qb, name, a.ctypes.data)
+    qb.dq, qb.status = dq.ctypes.data, st.ctypes.data
+    opt = abi.NhqpOptions(); opt.min_sv_ratio = 0.2                 # min_sv_ratio_is_set stays 0
+    L = emu_lib()
+    L.emu_nhqp_solve.argtypes = [C.POINTER(abi.PlanDesc), C.POINTER(abi.QpBatch), C.POINTER(abi.NhqpOptions)]
+    pd = plan.to_c()
+    assert L.emu_nhqp_solve(C.byref(pd), C.byref(qb), C.byref(opt)) == 0
+    np.testing.assert_array_equal(dq, want)
+
+
 def test_small_generic_stack_and_no_free_variables(oracle):
     """a 12-variable generic stack (row side and column side of the SVD both occur); a stack that runs out of free
     variables is refused like the reference's constructor does (nHQP.cpp:32-35)"""
@@ -183,3 +242,30 @@ def test_symmetric_eigen_solver_emulated():
             assert np.abs(G @ V - V * lam[None, :]).max() < 1e-13 * scale
             assert np.abs(V.T @ V - np.eye(k)).max() < 1e-13
             assert np.abs(np.sort(lam) - np.linalg.eigvalsh(G)).max() < 1e-13 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,rows,n_ineq,seed", [(35, [3, 12], 3, 2), (50, [6, 20, 10], 0, 4), (64, [20, 30], 5, 5)])
+def test_more_than_32_variables_gpu(n, rows, n_ineq, seed, oracle, gpu_device):
+    """the 64-column nHQP path on the device against the restatement (sample of the batch) -- see the emulated test of the same name"""
+    import torch
+    from opensot_amd.solver import BatchedStack
+    from oracle import pynhqp
+    B = 64
+    plan, leaf = synth.make_generic_stack(B, n, rows, n_eq=0, n_ineq=n_ineq, seed=seed, box=0.4)
+    asm = oracle.assemble(plan, leaf)
+    st = BatchedStack(plan, B, device=0)
+    st.load_assembled(asm)
+    st.solve_nhqp(B)
+    torch.cuda.synchronize()
+    dq = st.dq[:B].cpu().numpy(); status = st.status[:B].cpu().numpy()
+    sub = slice(0, B, 8)
+    sl = dict(asm); sl["B"] = 8
+    for key in ("A", "b", "w", "c"):
+        sl[key] = [None if a is None else a[sub] for a in asm[key]]
+    for key in ("C", "lo", "up", "l", "u"):
+        sl[key] = None if asm[key] is None else asm[key][sub]
+    ref = pynhqp.nhqp_solve(sl, backend="qpoases" if oracle.ref_available() else "eiqp", termination_tolerance=10 * 2.221e-16)
+    ok = ref["status"] == 1
+    assert ok.all() and (status == 0).all()
+    assert np.abs(dq[sub] - ref["dq"]).max() < 1e-9
