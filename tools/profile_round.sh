@@ -3,7 +3,7 @@
 # configurations of the bench line: the headline lanes, C2 / C4 / C5, nHQP, eHQP, ADMM, kinematics), then separate --pmc
 # passes (one counter group each, as MI355X_MICROARCH.md prescribes; --kernel-trace only beside them) over the same command.
 # Output under gpurun_out/prof_<tag>/ ; the summaries are copied into profiles/ by hand.
-TAG=${1:-r03_v15}
+TAG=${1:-r04}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
