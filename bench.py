@@ -457,7 +457,7 @@ def time_coman35(which, B, device, steps=20, warmup=5, front_end="iHQP"):
     return out
 
 
-def time_full_cycle(B, device, lanes=2, steps=40, warmup=8):
+def time_full_cycle(B, device, lanes=2, steps=40, warmup=8, streams=None):
     """q -> kinematics -> AutoStack::update + cascade -> q += dq for the 32-DoF humanoid under BASELINE config 3's stack (CoM / l_wrist(0.1)
     + r_wrist + l_sole + r_sole / Postural, joint-limit and velocity-limit box), everything resident, submitted like the headline: the
     batch as `lanes` sub-batches on their own streams, the steps of a lane as ONE HIP graph (kinematics launch, fused update + cascade
@@ -493,7 +493,9 @@ def time_full_cycle(B, device, lanes=2, steps=40, warmup=8):
         q = torch.as_tensor(q0, **f64).contiguous()
         pose = [torch.zeros((Bl, 12), **f64) for _ in range(4)]
         com = torch.zeros((Bl, 3), **f64)
-        stream = torch.cuda.Stream(device=dev)
+        # (the caller's streams where it has them: streams created later can land on a hardware queue another lane already uses,
+        #  and the lanes then run one after the other)
+        stream = streams[len(work)] if streams is not None else torch.cuda.Stream(device=dev)
         st.stream = stream
 
         def fk(q=q, pose=pose, com=com, st=st):
@@ -1042,7 +1044,7 @@ def main():
             except Exception as e:
                 oc["COMAN35_S3_nHQP"] = {"error": str(e)[:300]}
             try:
-                oc["full_cycle"] = time_full_cycle(Bl, local_rank, lanes=S)
+                oc["full_cycle"] = time_full_cycle(Bl, local_rank, lanes=S, streams=streams)
             except Exception as e:
                 oc["full_cycle"] = {"error": str(e)[:300]}
             try:
