@@ -74,45 +74,81 @@ __device__ __forceinline__ double dot_half(const double* a, int sa, const double
 // (force-inlined, and k / the reduction results said to be wave-uniform: as a CALL every argument arrives in a vector register, so
 //  the size, every loop bound derived from it and with them the whole QL recurrence were compiled as divergent control flow
 //  -- loop counters in VGPRs, exec-mask branches, a null check in front of every access through the generic pointers)
-__device__ __forceinline__ void sym_eig32(double* K, double* E, int k_in, int c, int h) {
+// phase 1 + 2 of sym_eig32: K (k x k symmetric) -> tridiagonal (d, e: one entry per lane, e[c] coupling c - 1 and c as tred2 leaves
+// it) and K <- the accumulated orthogonal transformation Q (A = Q T Q')
+__device__ __forceinline__ void sym_tred2_32(double* K, double* E, int k, int c, int h, double& d_out, double& e_out) {
     constexpr double kEps = 2.220446049250313e-16;
-    const int k = uniform_i(k_in);
     double d = 0.0, e = 0.0;                 // lane j: d[j], e[j]
     const bool wr = (h == 0);
+    // ---- one exact scaling of the whole matrix (a power of two, largest entry into [0.5, 1)) instead of tred2's scaling of every
+    // row by its 1-norm -- a wave reduction, a reciprocal and two multiplies on the dependent chain of each of the k - 1 steps; a row
+    // whose squared norm still underflows is negligible against the matrix and is skipped like tred2's all-zero row
+    int kexp = 0;
+    {
+        double mx[16], rmax = 0.0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { mx[t] = K[c * kNS + 2 * t + h]; rmax = fmax(rmax, fabs(mx[t])); }
+        rmax = fmax(rmax, from_half<32>(rmax, 1 - h));
+        kexp = frexp_exponent(uniform_d(colmax<32>(rmax)));
+#pragma unroll
+        for (int t = 0; t < 16; ++t) K[c * kNS + 2 * t + h] = scale_pow2(mx[t], -kexp);
+        wave_sync();
+    }
     // ---- reduction to tridiagonal form (tred2): for i = k-1 .. 1 the row i is reflected onto e_{i-1}
     for (int i = k - 1; i >= 1; --i) {
         const int l = i - 1;
         double hv = 0.0, e_i;
         if (l > 0) {
-            double ai = (c <= l) ? K[i * kNS + c] : 0.0;
-            const double scale = uniform_d(colsum<32>(fabs(ai)));
-            if (scale == 0.0) {
+            const double kic = K[i * kNS + c];       // (loaded by every lane, then masked: no exec-mask branch around the load)
+            double ai = (c <= l) ? kic : 0.0;
+            hv = uniform_d(colsum<32>(ai * ai));
+            if (hv < 1.0e-290) {
                 e_i = bcast(ai, l);
+                hv = 0.0;
             } else {
-                ai *= fast_rcp(scale);
-                hv = uniform_d(colsum<32>(ai * ai));
                 const double f0 = bcast(ai, l);
                 double sq, rs;
                 fast_sqrt_rsqrt(hv, sq, rs);
                 const double g0 = (f0 >= 0.0) ? -sq : sq;
-                e_i = scale * g0;
+                e_i = g0;
                 hv -= f0 * g0;
                 if (c == l) ai = f0 - g0;
                 const double ih = fast_rcp(hv);
                 wave_sync();
                 if (wr && c <= l) { K[i * kNS + c] = ai; K[c * kNS + i] = ai * ih; }    // row i <- u, column i <- u / H
                 wave_sync();
-                double pj = 0.0;             // p = A u / H (full symmetric rows are kept up to date)
-                if (c <= l)
-                    for (int kk = h; kk <= l; kk += 2) pj = fma(K[c * kNS + kk], K[i * kNS + kk], pj);
+                // p = A u / H (full symmetric rows are kept up to date).  The inner index runs in CHUNKS of 8 (4 per half) with the
+                // reads of a chunk in flight together and the entries beyond l masked: element by element the loop paid one LDS round
+                // trip per multiply-add (see dot_half; the chunk keeps the LDS traffic near the triangular minimum, which the fixed
+                // 32-wide form would triple).  Chunk bases are multiples of 8 and l <= 31, so every index read is a valid column.
+                double pj = 0.0;
+                for (int base = 0; base <= l; base += 8) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int kk = base + 2 * t + h;
+                        const double a = K[c * kNS + kk], u = K[i * kNS + kk];
+                        pj = fma((kk <= l) ? a : 0.0, u, pj);
+                    }
+                }
                 pj = halfsum<32>(pj) * ih;
                 const double f1 = uniform_d(colsum<32>((c <= l) ? pj * ai : 0.0));
                 const double hh2 = 0.5 * f1 * ih;
                 const double qj = (c <= l) ? pj - hh2 * ai : 0.0;      // q = p - (u'p / 2H) u
                 if (wr) E[c] = qj;           // (E is free until the end: its first row carries q)
                 wave_sync();
-                if (c <= l)                  // A <- A - u q' - q u'
-                    for (int kk = h; kk <= l; kk += 2) K[c * kNS + kk] -= fma(ai, E[kk], qj * K[i * kNS + kk]);
+                for (int base = 0; base <= l; base += 8) {        // A <- A - u q' - q u' (my row; same chunks)
+                    double nv[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int kk = base + 2 * t + h;
+                        nv[t] = K[c * kNS + kk] - fma(ai, E[kk], qj * K[i * kNS + kk]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int kk = base + 2 * t + h;
+                        if (c <= l && kk <= l) K[c * kNS + kk] = nv[t];
+                    }
+                }
                 wave_sync();
             }
         } else {
@@ -125,11 +161,28 @@ __device__ __forceinline__ void sym_eig32(double* K, double* E, int k_in, int c,
         const int l = i - 1;
         if (bcast(d, i) != 0.0) {
             double gj = 0.0;
-            if (c <= l)
-                for (int kk = h; kk <= l; kk += 2) gj = fma(K[i * kNS + kk], K[kk * kNS + c], gj);
+            for (int base = 0; base <= l; base += 8) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int kk = base + 2 * t + h;
+                    const double u = K[i * kNS + kk], a = K[kk * kNS + c];
+                    gj = fma((kk <= l) ? u : 0.0, a, gj);
+                }
+            }
             gj = halfsum<32>(gj);
-            if (c <= l)
-                for (int kk = h; kk <= l; kk += 2) K[kk * kNS + c] -= gj * K[kk * kNS + i];
+            for (int base = 0; base <= l; base += 8) {
+                double nv[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int kk = base + 2 * t + h;
+                    nv[t] = fma(-gj, K[kk * kNS + i], K[kk * kNS + c]);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int kk = base + 2 * t + h;
+                    if (c <= l && kk <= l) K[kk * kNS + c] = nv[t];
+                }
+            }
             wave_sync();
         }
         if (c == i) d = K[i * kNS + i];
@@ -140,6 +193,12 @@ __device__ __forceinline__ void sym_eig32(double* K, double* E, int k_in, int c,
         }
         wave_sync();
     }
+    d_out = scale_pow2(d, kexp); e_out = scale_pow2(e, kexp);
+}
+
+// phase 3 of sym_eig32: implicit QL with shifts on (d, e) (lane c: d[c]; e[c] couples c - 1 and c on entry), rotations into the columns of K
+__device__ __forceinline__ void sym_ql_32(double* K, int k, int c, int h, double& d, double& e) {
+    constexpr double kEps = 2.220446049250313e-16;
     // ---- implicit QL with shifts on (d, e); the rotations go into the columns of K (tql2)
     {   // e[j] <- e[j + 1]  (the shuffle OUTSIDE the select: a ds_bpermute under a partial exec mask reads zeros from the
         // lanes that are masked off, and lane k - 2 needs lane k - 1)
@@ -202,8 +261,12 @@ __device__ __forceinline__ void sym_eig32(double* K, double* E, int k_in, int c,
             if (c == m) e = 0.0;
         }
     }
+}
+
+// results where the callers expect them: E = eigenvectors (columns), diag(K) = eigenvalues (lane c: d), K otherwise zero
+__device__ __forceinline__ void sym_eig_finish_32(double* K, double* E, int k, int c, int h, double d) {
+    const bool wr = (h == 0);
     wave_sync();
-    // ---- results where the callers expect them: E = eigenvectors (columns), diag(K) = eigenvalues, K otherwise zero
     for (int t = 0; t < 16; ++t) { const int i = 2 * t + h; E[i * kNS + c] = (i < k && c < k) ? K[i * kNS + c] : 0.0; }
     wave_sync();
     for (int t = 0; t < 16; ++t) { const int i = 2 * t + h; K[i * kNS + c] = 0.0; }
@@ -212,10 +275,232 @@ __device__ __forceinline__ void sym_eig32(double* K, double* E, int k_in, int c,
     wave_sync();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: the eigen-decomposition of the tridiagonal form WITHOUT the QL recurrence (sym_eig32_fast; the nHQP level preparation).
+// tql2 is a scalar recurrence -- rotation i + 1 needs the result of rotation i, ~650 rotations for a 24 x 24 matrix, each followed by
+// two LDS columns per lane -- and was 54-73 % of the level-1 launch.  Here every lane works on ITS OWN eigenpair, all of them at once:
+//   eigenvalue j (lane j) by bisection on the Sturm count of T - x I (56 halvings of the Gershgorin interval; d and e^2 are read as
+//     LDS broadcasts, the recurrence q_i = (d_i - x) - e_(i-1)^2 / q_(i-1) is lane-local);
+//   eigenvector j by the twisted factorisation of T - lambda_j I (forward pivots D+ into the lane's column of E, backward pivots D-
+//     in registers, the twist index r where |gamma_i| = |D+_i + D-_i - (d_i - lambda)| is smallest, y_r = 1 and the two-term
+//     recurrences up and down from r);
+//   V = Q Y row by row into K (Q from tred2).
+// Eigenvalues closer than 1e-7 |T| to a neighbour (a rank-deficient Gram matrix: the zero cluster; accidental near-multiplicities)
+// make the routine return false BEFORE anything is overwritten, and the caller runs the QL iteration on the same (d, e, Q).
+// d, e as sym_tred2_32 leaves them (e[c] couples c - 1 and c).  On true: K = eigenvectors (columns), d = this lane's eigenvalue.
+__device__ __forceinline__ bool sym_bisect_32(double* K, double* E, int k, int c, int h, double& d, double e) {
+    const bool in = c < k;
+    // d[i] -> K[i][32], e2[i] = (coupling i, i + 1)^2 and e[i] -> E[i][32] / E[i][...]: the padding column of the two matrices
+    const double ec = shift_down<32>(e);                 // e[c] <- e[c + 1]: couples c and c + 1
+    const double eu = (c + 1 < k) ? ec : 0.0;
+    const double el = (c > 0 && in) ? e : 0.0;           // couples c - 1 and c
+    if (h == 0) { K[c * kNS + 32] = in ? d : 0.0; E[c * kNS + 32] = in ? eu : 0.0; }
+    wave_sync();
+    const double rad = fabs(el) + fabs(eu);
+    const double gl = -uniform_d(colmax<32>(in ? -(d - rad) : -INFINITY));
+    const double gu = uniform_d(colmax<32>(in ? d + rad : -INFINITY));
+    const double anorm = fmax(fabs(gl), fabs(gu));
+    if (!(anorm > 0.0)) return false;                    // the zero matrix: one k-fold cluster
+    const double e2max = uniform_d(colmax<32>(eu * eu));
+    const double pivmin = 2.2250738585072014e-308 * fmax(1.0, e2max) * 4.0;
+    // ---- bisection: lane c looks for eigenvalue number c (ascending); count(x) = eigenvalues below x
+    // The two halves of the wave test two abscissae of the same interval per sweep (it shrinks by 3: 36 sweeps for 2^-56).  The count
+    // is taken from the signs of the leading principal minors p_i = (d_i - x) p_(i-1) - e_i^2 p_(i-2) (d, e^2 of the matrix scaled
+    // to norm 1, in registers; rescaled by a power of two every 4 rows): the pivot form q_i = (d_i - x) - e_i^2 / q_(i-1) has a
+    // reciprocal on a dependent chain of ~110 clocks per row at the 1.5 waves per SIMD this kernel runs with, and reading d / e
+    // from LDS row by row another round trip -- the fixed 56 x k rows of the first version were slower than QL for small k.
+    // A minor that vanishes is given the sign opposite to its predecessor's (the pivot form's q = -pivmin).
+    const double inorm = fast_rcp(anorm);
+    // (rows beyond k: d = 4 > every abscissa and no coupling -- the minor keeps its sign, no flip is counted, no per-row predicate.
+    //  Couplings get a floor of 1e-30 of the norm: a perturbation far below round-off that keeps a vanished minor from zeroing its
+    //  successors, p_(i+1) = -e^2 p_(i-1) != 0, so zeros need no special case: +0 counts as positive and the flip shows up one row on.)
+    double ds[32], es2[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const double di = K[i * kNS + 32] * inorm;
+        const double ei = E[(i > 0 ? i - 1 : 0) * kNS + 32] * inorm;
+        ds[i] = (i < k) ? di : 4.0;
+        es2[i] = (i > 0 && i < k) ? fmax(ei * ei, 1.0e-60) : 0.0;
+    }
+    // (two abscissae per lane and sweep -- a second, independent chain, the interval shrinking by 5 -- measured slower: 100 k clocks
+    //  instead of 90 k at k = 24)
+    double lo = (gl - 2.0e-16 * anorm * k) * inorm - 1.0e-300, hi = (gu + 2.0e-16 * anorm * k) * inorm + 1.0e-300;
+    const int want = in ? c : 0;
+    for (int it = 0; it < 36; ++it) {
+        const double w = hi - lo;
+        const double x1 = fma(w, 1.0 / 3.0, lo), x2 = fma(w, 2.0 / 3.0, lo);
+        const double x = h ? x2 : x1;
+        double p1 = 1.0, p2 = 0.0;
+        int cnt = 0;
+#pragma unroll
+        for (int base = 0; base < 32; base += 4) {
+            if (base < k) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = base + j;
+                    const double pn = fma(ds[i] - x, p1, -(es2[i] * p2));
+                    cnt += ((pn < 0.0) != (p1 < 0.0)) ? 1 : 0;
+                    p2 = p1; p1 = pn;
+                }
+                const int ex = frexp_exponent(fabs(p1) + fabs(p2));
+                p1 = scale_pow2(p1, -ex); p2 = scale_pow2(p2, -ex);
+            }
+        }
+        const unsigned long long below = wave_ballot(cnt > want);      // bit c: lambda_c < x1; bit 32 + c: lambda_c < x2
+        const bool b1 = (below >> c) & 1ull, b2 = (below >> (32 + c)) & 1ull;
+        if (b1) hi = x1;
+        else if (b2) { lo = x1; hi = x2; }
+        else lo = x2;
+        if (it == 14) {
+            // an early look for clusters: two neighbours still in the same interval (3^-15 of the spectrum's width, ~1e-7) after 15
+            // sweeps will not separate to the 1e-7 the twisted factorisation needs -- leave now instead of after 36
+            const double lo_next = shift_down<32>(lo);
+            if (wave_ballot(c + 1 < k && lo_next == lo) != 0ull) return false;
+        }
+    }
+    lo *= anorm; hi *= anorm;
+    const double lam = 0.5 * (lo + hi);
+    // ---- clusters: the twisted factorisation needs separated eigenvalues
+    {
+        const double nxt = shift_down<32>(lam);
+        const bool close = (c + 1 < k) && (nxt - lam < 1.0e-7 * anorm);
+        if (wave_ballot(close) != 0ull) return false;
+    }
+    // ---- eigenvector of T for lam: twisted factorisation, lane-local (column c of E holds D+ and then y)
+    double Dm[32];
+    double nrm2 = 0.0;
+    {
+        const int col = in ? c : 0;                      // (idle lanes shadow lane 0: in-bounds addresses, results discarded)
+        double dp = K[32] - lam;
+        if (fabs(dp) < pivmin) dp = -pivmin;
+        if (in && h == 0) E[col] = dp;
+        for (int i = 1; i < k; ++i) {                    // forward: D+_i
+            const double ei = E[(i - 1) * kNS + 32];
+            dp = (K[i * kNS + 32] - lam) - ei * ei * fast_rcp(dp);
+            if (fabs(dp) < pivmin) dp = -pivmin;
+            if (in && h == 0) E[i * kNS + col] = dp;
+        }
+        wave_sync();
+        // backward: D-_i (registers, static indices), gamma_i and the twist index
+        double dmv = K[(k - 1) * kNS + 32] - lam;
+        if (fabs(dmv) < pivmin) dmv = -pivmin;
+        double gbest = INFINITY;
+        int r = k - 1;
+#pragma unroll
+        for (int i = 31; i >= 0; --i) {
+            if (i < k) {
+                if (i < k - 1) {
+                    const double ei = E[i * kNS + 32];
+                    dmv = (K[i * kNS + 32] - lam) - ei * ei * fast_rcp(dmv);
+                    if (fabs(dmv) < pivmin) dmv = -pivmin;
+                }
+                Dm[i] = dmv;
+                const double gam = fabs(E[i * kNS + col] + dmv - (K[i * kNS + 32] - lam));
+                if (gam < gbest) { gbest = gam; r = i; }
+            } else {
+                Dm[i] = 1.0;
+            }
+        }
+        // y_r = 1; upwards y_i = -(e_i / D+_i) y_(i+1); downwards y_(i+1) = -(e_i / D-_(i+1)) y_i.  y overwrites D+ in place.
+        double yv = 1.0;
+        nrm2 = 1.0;
+        for (int i = k - 2; i >= 0; --i) {               // (rows above the twist; the others are skipped by the select)
+            const double dpi = E[i * kNS + col];
+            const double ynew = -(E[i * kNS + 32] * fast_rcp(dpi)) * yv;
+            const bool up = i < r;
+            yv = up ? ynew : 1.0;                        // at i >= r the running value is re-seeded: y_r = 1
+            if (up) nrm2 = fma(yv, yv, nrm2);
+            if (up && in && h == 0) E[i * kNS + col] = yv;
+        }
+        wave_sync();
+        if (in && h == 0) E[r * kNS + col] = 1.0;
+        yv = 1.0;
+#pragma unroll
+        for (int i = 0; i < 31; ++i) {
+            if (i < k - 1) {
+                const double ynew = -(E[i * kNS + 32] * fast_rcp(Dm[i + 1])) * yv;
+                const bool down = i >= r;
+                yv = down ? ynew : 1.0;
+                if (down) nrm2 = fma(yv, yv, nrm2);
+                if (down && in && h == 0) E[(i + 1) * kNS + col] = yv;
+            }
+        }
+        wave_sync();
+    }
+    // ---- V = Q Y, row by row into K (Q's row i is read by every lane before it is overwritten); the columns are normalised on the way
+    // (the norm is the first half's: the second half runs the same recurrences on the same column, but its reads of D+ race with
+    //  the first half's in-place writes of y -- harmless in lock-step, and nothing of the second half's is used)
+    double sq, rs;
+    fast_sqrt_rsqrt(from_half<32>(nrm2, 0), sq, rs);
+    // (my column of Y in registers; Q is zero beyond column k and E holds finite numbers there: fixed trip counts, no masks; two rows
+    //  of Q per trip -- independent chains)
+    {
+        double yc[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) yc[t] = E[(2 * t + h) * kNS + c] * rs;
+        for (int i0 = 0; i0 < k; i0 += 2) {
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                a0 = fma(K[i0 * kNS + 2 * t + h], yc[t], a0);
+                a1 = fma(K[(i0 + 1) * kNS + 2 * t + h], yc[t], a1);
+            }
+            a0 = halfsum<32>(a0); a1 = halfsum<32>(a1);
+            wave_sync();
+            if (in && h == 0) { K[i0 * kNS + c] = a0; if (i0 + 1 < k) K[(i0 + 1) * kNS + c] = a1; }
+        }
+    }
+    wave_sync();
+    d = in ? lam : 0.0;
+    return true;
+}
+
+// sym_eig32 with the bisection / twisted-factorisation phase where the spectrum allows it (see sym_bisect_32), QL otherwise
+__device__ __forceinline__ void sym_eig32_fast(double* K, double* E, int k_in, int c, int h) {
+    const int k = uniform_i(k_in);
+    double d, e;
+#ifdef OSOT_NHQP_PHASES
+    long long t0_ = (long long)clock64();
+#endif
+    sym_tred2_32(K, E, k, c, h, d, e);
+#ifdef OSOT_NHQP_PHASES
+    if (blockIdx.x == 0 && threadIdx.x == 0) printf("PHASE    tred2 k=%d %lld\n", k, (long long)clock64() - t0_);
+    t0_ = (long long)clock64();
+#endif
+#ifndef OSOT_X_NO_BISECT
+    const bool done = (k >= 2) && uniform_b(sym_bisect_32(K, E, k, c, h, d, e));
+#else
+    const bool done = false;
+#endif
+    if (!done) sym_ql_32(K, k, c, h, d, e);
+#ifdef OSOT_NHQP_PHASES
+    if (blockIdx.x == 0 && threadIdx.x == 0) printf("PHASE    bisect/ql done=%d %lld\n", (int)done, (long long)clock64() - t0_);
+#endif
+    sym_eig_finish_32(K, E, k, c, h, d);
+    if (h == 0) { K[c * kNS + 32] = 0.0; E[c * kNS + 32] = 0.0; }      // (the padding columns carried d and e)
+    wave_sync();
+}
+
+__device__ __forceinline__ void sym_eig32(double* K, double* E, int k_in, int c, int h) {
+    const int k = uniform_i(k_in);
+    double d, e;
+    sym_tred2_32(K, E, k, c, h, d, e);
+    sym_ql_32(K, k, c, h, d, e);
+    sym_eig_finish_32(K, E, k, c, h, d);
+}
+
 // MR = row capacity of A N (32 or 64).  LDS: three 32 x 33 work matrices + A N = 25.3 KB (MR = 32: six wavefronts per CU;
 // the first version held five matrices and a 64-row A N, 50 KB, three per CU).  The buffers are re-used as the level goes:
 //   NE : N (until the constraints are written, right after A N)  ->  eigenvectors E  ->  V2 on the row side
 //   K  : Gram matrix -> its eigenvalues on the diagonal -> the reflectors of the complement / V2 on the column side
+// developer knob (tools/build_variant.sh NAME -DOSOT_NHQP_PHASES): instance 0 prints the clock count of every phase of its level
+// preparation (s_memtime deltas of one wave among the CU's six)
+#ifdef OSOT_NHQP_PHASES
+#define NHQP_PHASE(tag) do { const long long t_ = (long long)clock64(); if (inst == 0 && lane == 0) printf("PHASE L%d " tag " %lld\n", Q.level, t_ - ph_t_); ph_t_ = (long long)clock64(); } while (0)
+#else
+#define NHQP_PHASE(tag) do { } while (0)
+#endif
 template <int MR>
 __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) {
     OSOT_STATIC_LDS(double, AN, MR * kNS);     // A N (m x nf)
@@ -234,6 +519,9 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
     if (Q.status && Q.status[inst] != 0) return;
     const int n = Q.n, m = Q.m, ma = Q.ma, nf = Q.nf, ns = Q.ns;
     const bool first = Q.level == 0;
+#ifdef OSOT_NHQP_PHASES
+    long long ph_t_ = (long long)clock64();
+#endif
     const double* A = Q.A ? Q.A + inst * (long long)ma * n : nullptr;
     // ---- N -> LDS (identity at the first level)
     for (int e = lane; e < 32 * kNS; e += 64) { Nl[e] = 0.0; K[e] = 0.0; }
@@ -241,11 +529,18 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
     wave_sync();
     if (first) { if (h == 0 && c < n) Nl[c * kNS + c] = 1.0; }
     else {
+        // (fixed trip count, clamped addresses: the 16 loads of a lane are in flight together; a run-time loop waited for each)
         const double* Ng = Q.N + inst * (long long)n * n;
-        for (int i = h; i < n; i += 2) if (c < nf) Nl[i * kNS + c] = Ng[i * n + c];
+        const int cn = (c < nf) ? c : nf - 1;
+        double nv[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { const int i = 2 * t + h; nv[t] = Ng[((i < n) ? i : n - 1) * n + cn]; }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { const int i = 2 * t + h; if (i < n && c < nf) Nl[i * kNS + c] = nv[t]; }
     }
     if (lane < 64) vec[lane] = (!first && lane < n) ? Q.q0[inst * n + lane] : 0.0;     // q0 staged
     wave_sync();
+    NHQP_PHASE("loadN");
     // ---- AN = A N (stored rows: a row of A against the columns of N, i split over the halves; identity rows: rows of N)
     // (A goes through the Gram buffer, free until the Gram matrix is formed, 32 rows at a time with coalesced loads: read
     //  element by element inside the product it was a uniform-address HBM load per multiply-add)
@@ -253,7 +548,14 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
     for (int rb = 0; rb < ma; rb += 32) {
         const int nr = (ma - rb < 32) ? ma - rb : 32;
         wave_sync();
-        for (int r = h; r < nr; r += 2) K[r * kNS + c] = (c < n) ? A[(rb + r) * n + c] : 0.0;
+        {
+            const int ca = (c < n) ? c : n - 1;
+            double av[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { const int r = 2 * t + h; av[t] = A[(rb + ((r < nr) ? r : nr - 1)) * n + ca]; }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { const int r = 2 * t + h; if (r < nr) K[r * kNS + c] = (c < n) ? av[t] : 0.0; }
+        }
         wave_sync();
         for (int r = 0; r < nr; ++r) {
             const double acc = halfsum<32>(dot_half<16>(K + r * kNS, 1, Nl + c, kNS, h));
@@ -279,6 +581,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
         b0[lane] = v;              // (zero beyond m: the fixed-trip products below read all 64 entries)
     }
     wave_sync();
+    NHQP_PHASE("AN+b0");
     // ---- constraints in z-coordinates (levels below the first): rows [C N; N], bounds shifted by q0
     if (!first) {
         const int nr = Q.nc + (Q.has_box ? n : 0);
@@ -307,26 +610,29 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
         }
     }
     wave_sync();      // N is dead from here on: its buffer becomes E (and later V2)
+    NHQP_PHASE("constr");
     // ---- Gram matrix of the small side
     const bool rowside = m <= nf;
     const int k = rowside ? m : nf;
     if (rowside) {          // K[a][c] = <row a, row c> of AN
-        for (int a = 0; a < m; ++a) {
-            double acc = 0.0;
-            if (c < m) acc = dot_half<16>(AN + a * kNS, 1, AN + c * kNS, 1, h);      // (A N is zero beyond column nf)
-            acc = halfsum<32>(acc);
-            if (h == 0 && c < m) K[a * kNS + c] = acc;
+        const int cm = (c < m) ? c : 0;
+        for (int a = 0; a < m; a += 2) {       // (two rows per trip: independent chains; A N is zero beyond column nf and row m)
+            const double acc0 = halfsum<32>(dot_half<16>(AN + a * kNS, 1, AN + cm * kNS, 1, h));
+            const double acc1 = halfsum<32>(dot_half<16>(AN + (a + 1) * kNS, 1, AN + cm * kNS, 1, h));
+            if (h == 0 && c < m) { K[a * kNS + c] = acc0; if (a + 1 < m) K[(a + 1) * kNS + c] = acc1; }
         }
     } else {                // K[a][c] = <column a, column c>
-        for (int a = 0; a < nf; ++a) {
-            double acc = 0.0;
-            if (c < nf) acc = dot_half<MR / 2>(AN + a, kNS, AN + c, kNS, h);           // (... and beyond row m)
-            acc = halfsum<32>(acc);
-            if (h == 0 && c < nf) K[a * kNS + c] = acc;
+        const int cf = (c < nf) ? c : 0;
+        for (int a = 0; a < nf; a += 2) {
+            const double acc0 = halfsum<32>(dot_half<MR / 2>(AN + a, kNS, AN + cf, kNS, h));
+            const double acc1 = halfsum<32>(dot_half<MR / 2>(AN + a + 1, kNS, AN + cf, kNS, h));
+            if (h == 0 && c < nf) { K[a * kNS + c] = acc0; if (a + 1 < nf) K[(a + 1) * kNS + c] = acc1; }
         }
     }
     wave_sync();
-    sym_eig32(K, E, k, c, h);
+    NHQP_PHASE("gram");
+    sym_eig32_fast(K, E, k, c, h);
+    NHQP_PHASE("eig");
     // ---- singular values, sorted descending: pos = number of eigenvalues ahead of mine
     {
         const double lam = (c < k) ? K[c * kNS + c] : -1.0;
@@ -356,36 +662,50 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
     if (need_refl) {
         for (int i = 0; i < nrefl; ++i) {
             const int ec = idx[i];
-            double acc = 0.0;
-            if (c < nf) for (int q = h; q < m; q += 2) acc = fma(AN[q * kNS + c], E[q * kNS + ec], acc);
-            double vv = halfsum<32>(acc);
+            // (row side: m <= 32; A N is zero beyond row m and E finite there -- fixed-trip product, reads in flight together)
+            double vv = halfsum<32>(dot_half<16>(AN + c, kNS, E + ec, kNS, h));
             const double nrm2 = colsum<32>((c < nf) ? vv * vv : 0.0);
-            vv = (nrm2 > 0.0) ? vv / sqrt(nrm2) : 0.0;
-            if (h == 0 && c < nf) V1[c * kNS + i] = vv;
+            double nsq, nrs;
+            fast_sqrt_rsqrt(nrm2 > 0.0 ? nrm2 : 1.0, nsq, nrs);
+            vv = (nrm2 > 0.0 && c < nf) ? vv * nrs : 0.0;
+            if (h == 0) V1[c * kNS + i] = vv;                  // (zero beyond nf: the products below run over all 32 rows)
         }
         wave_sync();
-        // Householder vectors: for column i, reflect x = V1[i:, i] onto alpha e_i; apply to the later columns
+        // Householder vectors: for column i, reflect x = V1[i:, i] onto alpha e_i; apply to the later columns.  The update of the
+        // later columns is done with lane = COLUMN j (its 32 components split over the halves, fixed trip counts): with lane =
+        // component it was one wave reduction and two barriers per (i, j) pair -- 276 of them for 24 reflectors.
         for (int i = 0; i < nrefl; ++i) {
-            const double x = (c >= i && c < nf) ? V1[c * kNS + i] : 0.0;
+            const double v1ci = V1[c * kNS + i];
+            const double x = (c >= i && c < nf) ? v1ci : 0.0;
             const double nrm2 = colsum<32>(x * x);
             const double xi = bcast(x, i);
-            const double alpha = (xi > 0.0) ? -sqrt(nrm2) : sqrt(nrm2);
-            double hv = (c == i) ? x - alpha : x;             // reflector v (zero above i)
-            const double vn2 = colsum<32>(hv * hv);
-            const double beta = (vn2 > 0.0) ? 2.0 / vn2 : 0.0;
+            double nsq, nrs;
+            fast_sqrt_rsqrt(nrm2 > 0.0 ? nrm2 : 1.0, nsq, nrs);
+            if (!(nrm2 > 0.0)) nsq = 0.0;
+            const double alpha = (xi > 0.0) ? -nsq : nsq;
+            const double hv = (c == i) ? x - alpha : x;       // reflector v (zero above i)
+            // |v|^2 = |x|^2 - x_i^2 + (x_i - alpha)^2 = 2 (|x|^2 + |x_i| |x|): no second reduction
+            const double vn2h = fma(fabs(xi), nsq, nrm2);
+            const double beta = (vn2h > 0.0) ? fast_rcp(vn2h) : 0.0;
             wave_sync();
-            if (h == 0 && c < nf) V1[c * kNS + i] = hv;        // keep the reflector in place of the column
-            for (int j = i + 1; j < nrefl; ++j) {              // later columns: y -= beta (v'y) v
-                const double y = (c < nf) ? V1[c * kNS + j] : 0.0;
-                const double dot = colsum<32>(hv * y);
-                wave_sync();
-                if (h == 0 && c < nf) V1[c * kNS + j] = y - beta * dot * hv;
-                wave_sync();
+            if (h == 0) { V1[c * kNS + i] = hv; vec[c] = hv; }        // keep the reflector in place of the column
+            wave_sync();
+            {
+                const int j = (c > i && c < nrefl) ? c : i;     // (idle lanes shadow the reflector's own column; nothing stored)
+                double y[16], dot = 0.0;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) { y[t] = V1[(2 * t + h) * kNS + j]; dot = fma(vec[2 * t + h], y[t], dot); }
+                dot = halfsum<32>(dot) * beta;
+                if (c > i && c < nrefl) {
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) V1[(2 * t + h) * kNS + j] = fma(-dot, vec[2 * t + h], y[t]);
+                }
             }
             if (h == 0 && c == 0) refl_beta[i] = beta;
             wave_sync();
         }
     }
+    NHQP_PHASE("V1refl");
     auto completion_column = [&](int j) -> double {           // (Q e_j)[c], j >= nrefl
         double y = (c == j) ? 1.0 : 0.0;
         for (int i = nrefl - 1; i >= 0; --i) {
@@ -444,6 +764,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
         if (rebuild && lane < m) b0[lane] = bnew;
         wave_sync();
     }
+    NHQP_PHASE("ABreg");
     // ---- null-space basis V2 (nf x ns) for the next level and for the selective regularisation
     double* V2 = rowside ? NE : K;    // (E's last use on the row side is the construction of V1 below; K's on the column side is sig[])
     if (ns > 0) {
@@ -454,13 +775,35 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
         } else {
             // the last ns columns of the completion built above: Q e_(r + t), r = nf - ns (orthogonal to the leading
             // well-defined right singular vectors)
-            for (int t = 0; t < ns; ++t) {
-                const double y = completion_column(r_next + t);
-                if (h == 0 && c < nf) V2[c * kNS + t] = y;
+            // All ns columns at once, lane = column t with its 32 components in registers (split over the halves): one column
+            // at a time (completion_column) is a wave reduction per reflector and column.
+            {
+                double y[16];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) y[s] = (2 * s + h == r_next + c) ? 1.0 : 0.0;
+                for (int i = nrefl - 1; i >= 0; --i) {
+                    double hv[16], dot = 0.0;
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) {             // (the reflector: zero above i, V1 is zero beyond nf)
+                        const int r = 2 * s + h;
+                        const double v = V1[r * kNS + i];
+                        hv[s] = (r >= i) ? v : 0.0;
+                        dot = fma(hv[s], y[s], dot);
+                    }
+                    dot = halfsum<32>(dot) * refl_beta[i];
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) y[s] = fma(-dot, hv[s], y[s]);
+                }
+                wave_sync();
+                if (c < ns) {
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) if (2 * s + h < nf) V2[(2 * s + h) * kNS + c] = y[s];
+                }
             }
             wave_sync();
         }
     }
+    NHQP_PHASE("V2");
     // ---- H = AN' W AN (+ sv_max V2 V2'), g = -AN' W b0   ->  HBM, nf x nf row-major
     {
         const double* w = Q.w ? Q.w + inst * m : nullptr;
@@ -482,25 +825,33 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
         const bool sel = ns > 0 && Q.sel_reg;
         double v2c[16];                             // my row of V2 (zero beyond ns)
 #pragma unroll
-        for (int t = 0; t < 16; ++t) v2c[t] = (sel && 2 * t + h < ns) ? sv_max * V2[cc * kNS + 2 * t + h] : 0.0;
-        for (int i = 0; i < nf; ++i) {
-            double a0 = 0.0, a1 = 0.0;
+        for (int t = 0; t < 16; ++t) { const double v = V2[cc * kNS + 2 * t + h]; v2c[t] = (sel && 2 * t + h < ns) ? sv_max * v : 0.0; }
+        // (two rows of H per trip: their products are independent chains; row nf of an odd count is computed on row nf - 1 again)
+        for (int i0 = 0; i0 < nf; i0 += 2) {
+            const int i1 = (i0 + 1 < nf) ? i0 + 1 : i0;
+            double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;
 #pragma unroll
             for (int t = 0; t < MR / 2; t += 2) {
-                a0 = fma(wan[t], AN[(2 * t + h) * kNS + i], a0);
-                a1 = fma(wan[t + 1], AN[(2 * (t + 1) + h) * kNS + i], a1);
+                a0 = fma(wan[t], AN[(2 * t + h) * kNS + i0], a0);
+                a1 = fma(wan[t + 1], AN[(2 * (t + 1) + h) * kNS + i0], a1);
+                c0 = fma(wan[t], AN[(2 * t + h) * kNS + i1], c0);
+                c1 = fma(wan[t + 1], AN[(2 * (t + 1) + h) * kNS + i1], c1);
             }
             if (sel) {
 #pragma unroll
                 for (int t = 0; t < 16; t += 2) {
-                    a0 = fma(v2c[t], (2 * t + h < ns) ? V2[i * kNS + 2 * t + h] : 0.0, a0);
-                    a1 = fma(v2c[t + 1], (2 * (t + 1) + h < ns) ? V2[i * kNS + 2 * (t + 1) + h] : 0.0, a1);
+                    // (my row of V2 is zero beyond ns and the buffer holds finite numbers there: no mask on the other factor)
+                    a0 = fma(v2c[t], V2[i0 * kNS + 2 * t + h], a0);
+                    a1 = fma(v2c[t + 1], V2[i0 * kNS + 2 * (t + 1) + h], a1);
+                    c0 = fma(v2c[t], V2[i1 * kNS + 2 * t + h], c0);
+                    c1 = fma(v2c[t + 1], V2[i1 * kNS + 2 * (t + 1) + h], c1);
                 }
             }
-            const double acc = halfsum<32>(a0 + a1);
-            if (h == 0 && c < nf) Hg[i * nf + c] = acc;
+            const double acc0 = halfsum<32>(a0 + a1), acc1 = halfsum<32>(c0 + c1);
+            if (h == 0 && c < nf) { Hg[i0 * nf + c] = acc0; if (i1 != i0) Hg[i1 * nf + c] = acc1; }
         }
     }
+    NHQP_PHASE("Hg");
     // ---- V2 -> HBM (row stride n)
     if (ns > 0 && Q.V2) {
         double* Vg = Q.V2 + inst * (long long)n * n;
@@ -641,7 +992,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
     wave_sync();
     for (int e = lane; e < 32 * kNS; e += 64) E[e] = 0.0;
     wave_sync();
-    sym_eig32(K, E, k, c32, h32);
+    sym_eig32_fast(K, E, k, c32, h32);
     {
         const double lam = (c < k) ? K[c * kNS + c] : -1.0;
         vec[lane] = lam;

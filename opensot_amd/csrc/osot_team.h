@@ -341,6 +341,14 @@ __device__ __forceinline__ double fast_rcp(double x) {
     r = fma(r, e, r);
     return r;
 }
+// one Newton step only (~2 ulp): for counts and comparisons, not for values that are kept (sym_bisect_32's Sturm sequences)
+__device__ __forceinline__ double fast_rcp1(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(r, fma(-x, r, 1.0), r);
+}
+// binary exponent of x as frexp returns it (0 for x = 0), one instruction; x 2^e, one instruction
+__device__ __forceinline__ int frexp_exponent(double x) { return __builtin_amdgcn_frexp_exp(x); }
+__device__ __forceinline__ double scale_pow2(double x, int e) { return __builtin_amdgcn_ldexp(x, e); }
 __device__ __forceinline__ double fast_div(double a, double b) {
     const double r = fast_rcp(b);
     const double q = a * r;

@@ -200,6 +200,20 @@ static void emu_eig_kernel(double* Kg, double* Eg, int k) {
     wave_sync();
     for (int e = lane; e < 32 * kNS; e += 64) { Kg[e] = K[e]; Eg[e] = E[e]; }
 }
+static void emu_eig_fast_kernel(double* Kg, double* Eg, int k) {
+    OSOT_STATIC_LDS(double, K, 32 * kNS);
+    OSOT_STATIC_LDS(double, E, 32 * kNS);
+    const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
+    for (int e = lane; e < 32 * kNS; e += 64) { K[e] = Kg[e]; E[e] = 0.0; }
+    wave_sync();
+    sym_eig32_fast(K, E, k, c, h);
+    wave_sync();
+    for (int e = lane; e < 32 * kNS; e += 64) { Kg[e] = K[e]; Eg[e] = E[e]; }
+}
+extern "C" __attribute__((visibility("default"))) int emu_sym_eig32_fast(double* K, double* E, int k) {
+    emu::launch(emu_eig_fast_kernel, 1u, 0, 64, K, E, k);
+    return 0;
+}
 extern "C" __attribute__((visibility("default"))) int emu_sym_eig32(double* K, double* E, int k) {
     emu::launch(emu_eig_kernel, 1u, 0, 64, K, E, k);
     return 0;

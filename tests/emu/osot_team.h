@@ -179,8 +179,11 @@ template <int NP> inline int shift_down_i(int v) {
     const int l = emu_lane(), c = l % LWOF(NP);
     return (c + 1 < LWOF(NP)) ? all[l + 1] : all[l];
 }
+inline int frexp_exponent(double x) { int e = 0; if (x != 0.0) std::frexp(x, &e); return e; }
+inline double scale_pow2(double x, int e) { return std::ldexp(x, e); }
 #ifndef OSOT_EMU_HW_ROUNDING
 inline double fast_rcp(double x) { return 1.0 / x; }
+inline double fast_rcp1(double x) { return 1.0 / x; }
 inline double fast_div(double a, double b) { return a / b; }
 inline void fast_sqrt_rsqrt(double x, double& s, double& rs) { s = std::sqrt(x); rs = 1.0 / s; }
 #else
@@ -195,6 +198,7 @@ inline double ulp_jitter(double v, double key) {
     return sel == 0 ? v : std::nextafter(v, sel == 1 ? INFINITY : -INFINITY);
 }
 inline double fast_rcp(double x) { return ulp_jitter(1.0 / x, x); }
+inline double fast_rcp1(double x) { return ulp_jitter(1.0 / x, x + 1.0); }
 inline double fast_div(double a, double b) { return ulp_jitter(a / b, a + b); }
 inline void fast_sqrt_rsqrt(double x, double& s, double& rs) {
     s = std::sqrt(x);

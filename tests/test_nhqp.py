@@ -242,6 +242,15 @@ def test_symmetric_eigen_solver_emulated():
             assert np.abs(G @ V - V * lam[None, :]).max() < 1e-13 * scale
             assert np.abs(V.T @ V - np.eye(k)).max() < 1e-13
             assert np.abs(np.sort(lam) - np.linalg.eigvalsh(G)).max() < 1e-13 * scale
+            # round 4: the same through sym_eig32_fast (bisection + twisted factorisation per lane, QL only for clustered spectra);
+            # orthogonality there is eps |T| / gap with gaps down to 1e-7 |T|
+            K2 = np.zeros((32, 33)); K2[:k, :k] = G
+            E2 = np.zeros((32, 33))
+            assert L.emu_sym_eig32_fast(K2.ctypes.data_as(C.c_void_p), E2.ctypes.data_as(C.c_void_p), k) == 0
+            lam2, V2 = np.diag(K2)[:k], E2[:k, :k]
+            assert np.abs(G @ V2 - V2 * lam2[None, :]).max() < 1e-12 * scale
+            assert np.abs(V2.T @ V2 - np.eye(k)).max() < 1e-9
+            assert np.abs(np.sort(lam2) - np.linalg.eigvalsh(G)).max() < 1e-13 * scale
 
 
 @pytest.mark.gpu
