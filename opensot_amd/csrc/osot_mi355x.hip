@@ -401,10 +401,10 @@ int osot_nhqp_solve(osot_solver* s, const osot_qp_batch* b, const osot_nhqp_opti
     int rc = nhqp_run(pl, b, opt, s->nhqp,
         [&](const DevNhqp& Q) {
             if (Q.n > 32) {     // 33 .. 64 variables: the 64-column kernel (dynamic LDS beyond the 64 KB default)
-                if (Q.m <= 32) { if (ensure_lds(osot_nhqp_prepare64_kernel<32>, nhqp_prepare64_lds_bytes(32)) == OSOT_OK)
-                                     hipLaunchKernelGGL(osot_nhqp_prepare64_kernel<32>, dim3(grid), dim3(64), nhqp_prepare64_lds_bytes(32), st, Q); }
-                else { if (ensure_lds(osot_nhqp_prepare64_kernel<64>, nhqp_prepare64_lds_bytes(64)) == OSOT_OK)
-                           hipLaunchKernelGGL(osot_nhqp_prepare64_kernel<64>, dim3(grid), dim3(64), nhqp_prepare64_lds_bytes(64), st, Q); }
+                if (Q.m <= 32) { if (ensure_lds(osot_nhqp_prepare64_kernel<32>, nhqp_prepare64_lds_bytes(32, Q.n)) == OSOT_OK)
+                                     hipLaunchKernelGGL(osot_nhqp_prepare64_kernel<32>, dim3(grid), dim3(64), nhqp_prepare64_lds_bytes(32, Q.n), st, Q); }
+                else { if (ensure_lds(osot_nhqp_prepare64_kernel<64>, nhqp_prepare64_lds_bytes(64, Q.n)) == OSOT_OK)
+                           hipLaunchKernelGGL(osot_nhqp_prepare64_kernel<64>, dim3(grid), dim3(64), nhqp_prepare64_lds_bytes(64, Q.n), st, Q); }
             }
             else if (Q.m <= 32) hipLaunchKernelGGL(osot_nhqp_prepare_kernel<32>, dim3(grid), dim3(64), 0, st, Q);
             else hipLaunchKernelGGL(osot_nhqp_prepare_kernel<64>, dim3(grid), dim3(64), 0, st, Q);

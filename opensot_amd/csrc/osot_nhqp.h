@@ -81,8 +81,7 @@ __device__ __forceinline__ void sym_tred2_32(double* K, double* E, int k, int c,
     double d = 0.0, e = 0.0;                 // lane j: d[j], e[j]
     const bool wr = (h == 0);
     // ---- one exact scaling of the whole matrix (a power of two, largest entry into [0.5, 1)) instead of tred2's scaling of every
-    // row by its 1-norm -- a wave reduction, a reciprocal and two multiplies on the dependent chain of each of the k - 1 steps; a row
-    // whose squared norm still underflows is negligible against the matrix and is skipped like tred2's all-zero row
+    // row by its 1-norm -- a wave reduction, a reciprocal and two multiplies on the dependent chain of each of the k - 1 steps
     int kexp = 0;
     {
         double mx[16], rmax = 0.0;
@@ -102,8 +101,11 @@ __device__ __forceinline__ void sym_tred2_32(double* K, double* E, int k, int c,
             const double kic = K[i * kNS + c];       // (loaded by every lane, then masked: no exec-mask branch around the load)
             double ai = (c <= l) ? kic : 0.0;
             hv = uniform_d(colsum<32>(ai * ai));
-            if (hv < 1.0e-290) {
-                e_i = bcast(ai, l);
+            if (hv < 1.0e-30) {
+                // the part of row i still to be reduced is below 1e-15 of the matrix's largest entry: round-off (the Gram matrix of an
+                // orthonormal N at a Postural level is I + noise).  Dropped -- a backward error at the level of the arithmetic --
+                // instead of spending a full reflection on it and leaving QL a cluster of noise-level couplings to iterate on.
+                e_i = 0.0;
                 hv = 0.0;
             } else {
                 const double f0 = bcast(ai, l);
@@ -304,6 +306,9 @@ __device__ __forceinline__ bool sym_bisect_32(double* K, double* E, int k, int c
     if (!(anorm > 0.0)) return false;                    // the zero matrix: one k-fold cluster
     const double e2max = uniform_d(colmax<32>(eu * eu));
     const double pivmin = 2.2250738585072014e-308 * fmax(1.0, e2max) * 4.0;
+    // (a tridiagonal form that is already diagonal -- the Gram matrix of an orthonormal N at a Postural level is the identity -- is QL's
+    //  trivial case and usually one cluster: not worth 15 sweeps to find that out)
+    if (e2max <= 1.0e-28 * anorm * anorm) return false;
     // ---- bisection: lane c looks for eigenvalue number c (ascending); count(x) = eigenvalues below x
     // The two halves of the wave test two abscissae of the same interval per sweep (it shrinks by 3: 36 sweeps for 2^-56).  The count
     // is taken from the signs of the leading principal minors p_i = (d_i - x) p_(i-1) - e_i^2 p_(i-2) (d, e^2 of the matrix scaled
@@ -469,7 +474,8 @@ __device__ __forceinline__ void sym_eig32_fast(double* K, double* E, int k_in, i
     t0_ = (long long)clock64();
 #endif
 #ifndef OSOT_X_NO_BISECT
-    const bool done = (k >= 2) && uniform_b(sym_bisect_32(K, E, k, c, h, d, e));
+    // (the bisection has a floor of ~20 k clocks -- 36 sweeps whatever the size -- and QL costs ~470 k^2: they cross near k = 10)
+    const bool done = (k >= 10) && uniform_b(sym_bisect_32(K, E, k, c, h, d, e));
 #else
     const bool done = false;
 #endif
@@ -566,7 +572,6 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
         }
     }
     wave_sync();
-    for (int e = lane; e < 32 * kNS; e += 64) K[e] = 0.0;
     for (int r = ma + h; r < m; r += 2) if (c < nf) AN[r * kNS + c] = Nl[(r - ma) * kNS + c];
     // ---- b0 = b - A q0 (lane = row)
     {
@@ -588,16 +593,33 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
         double* Rg = Q.R + inst * (long long)nr * nf;
         if (lane < 64) vec[lane] = (lane < n) ? Q.q0[inst * n + lane] : 0.0;
         wave_sync();
-        for (int r = 0; r < Q.nc; ++r) {
-            const double* Cr = Q.C + (inst * (long long)Q.nc + r) * n;
-            double acc = 0.0, cq = 0.0;
-            for (int i = h; i < n; i += 2) { const double ci = Cr[i]; acc = fma(ci, Nl[i * kNS + c], acc); cq = fma(ci, vec[i], cq); }
-            acc = halfsum<32>(acc); cq = halfsum<32>(cq);
-            if (h == 0 && c < nf) Rg[r * nf + c] = acc;
-            if (lane == 0) {
+        // (the rows of C go through the Gram buffer like the rows of A above -- 32 at a time, coalesced; element by element inside
+        //  the product it was a uniform-address HBM load per multiply-add -- and the bounds of a block are loaded together, lane = row)
+        const double* Cg = Q.C + inst * (long long)Q.nc * n;
+        for (int rb = 0; rb < Q.nc; rb += 32) {
+            const int nr32 = (Q.nc - rb < 32) ? Q.nc - rb : 32;
+            wave_sync();
+            {
+                const int ca = (c < n) ? c : n - 1;
+                double cv[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) { const int r = 2 * t + h; cv[t] = Cg[(rb + ((r < nr32) ? r : nr32 - 1)) * n + ca]; }
+#pragma unroll
+                for (int t = 0; t < 16; ++t) { const int r = 2 * t + h; if (r < nr32) K[r * kNS + c] = (c < n) ? cv[t] : 0.0; }
+            }
+            wave_sync();
+            double cq_row = 0.0;               // lane = row r of the block: (C q0)_r
+            for (int r = 0; r < nr32; ++r) {
+                const double acc = halfsum<32>(dot_half<16>(K + r * kNS, 1, Nl + c, kNS, h));
+                if (h == 0 && c < nf) Rg[(rb + r) * nf + c] = acc;
+                const double cq = halfsum<32>(dot_half<16>(K + r * kNS, 1, vec, 1, h));
+                if (lane == r) cq_row = cq;
+            }
+            if (lane < nr32) {
+                const int r = rb + lane;
                 const double lo = Q.lo[inst * Q.nc + r], up = Q.up[inst * Q.nc + r];
-                Q.rlo[inst * nr + r] = (lo <= -1.0e20) ? -1.0e20 : lo - cq;
-                Q.rup[inst * nr + r] = (up >= 1.0e20) ? 1.0e20 : up - cq;
+                Q.rlo[inst * nr + r] = (lo <= -1.0e20) ? -1.0e20 : lo - cq_row;
+                Q.rup[inst * nr + r] = (up >= 1.0e20) ? 1.0e20 : up - cq_row;
             }
         }
         if (Q.has_box) {
@@ -610,6 +632,8 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
         }
     }
     wave_sync();      // N is dead from here on: its buffer becomes E (and later V2)
+    for (int e = lane; e < 32 * kNS; e += 64) K[e] = 0.0;       // (the staging of A / C rows is over: the Gram matrix starts from zero)
+    wave_sync();
     NHQP_PHASE("constr");
     // ---- Gram matrix of the small side
     const bool rowside = m <= nf;
@@ -861,22 +885,30 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Round 4: the same level preparation for 32 < n <= 64 variables (the reference's own COMAN has 35 coordinates, BASELINE config 5
-// has 50).  One lane per COLUMN of N / A N (64 lanes, no halves), row stride 65; the small-side Gram matrix and its
-// eigen-decomposition stay 32-wide (sym_eig32), i.e. min(rows of the level, free variables) <= 32 at every level -- what every stack
-// of the reference's example satisfies below its first level and with up to 32 task rows at the first (nhqp_validate refuses the
-// rest).  Same arithmetic as osot_nhqp_prepare_kernel, block by block; LDS: A N (MR x 65) + N / E / V2 (64 x 65) + the 64 x 33
-// work matrix + vectors, dynamic (nhqp_prepare64_lds_bytes).
-constexpr int kNS64 = 65;
-inline size_t nhqp_prepare64_lds_bytes(int MR) { return sizeof(double) * ((size_t)MR * kNS64 + 64 * kNS64 + 64 * kNS + 8 * 64 + 64 + 64 + 32 + 32) + sizeof(int) * 32; }
+// has 50).  One lane per COLUMN of N / A N (64 lanes, no halves); the small-side Gram matrix and its eigen-decomposition stay
+// 32-wide (sym_eig32_fast), i.e. min(rows of the level, free variables) <= 32 at every level -- what every stack of the
+// reference's example satisfies below its first level and with up to 32 task rows at the first (nhqp_validate refuses the rest).
+// Same arithmetic as osot_nhqp_prepare_kernel, block by block.
+// LDS, sized by the plan's n at launch (nhqp_prepare64_lds_bytes): rows padded to a multiple of 8 (every product reads its operands
+// in chunks of 8 with the reads of a chunk in flight together; the padding is zero), odd row stride RN + 1.  With the fixed 64 x 65
+// layout of the first version the COMAN35 plans held 71 KB per wavefront -- two wavefronts per CU, and this kernel is bound by the
+// latency of one wavefront's instruction stream; at n = 35 it is 38 KB, four per CU.
+constexpr int nhqp64_rows(int n) { return (n + 7) & ~7; }
+constexpr int nhqp64_stride(int n) { return nhqp64_rows(n) + 1; }
+inline size_t nhqp_prepare64_lds_bytes(int MR, int n) {
+    const size_t RN = (size_t)nhqp64_rows(n), S = (size_t)nhqp64_stride(n);
+    return sizeof(double) * ((size_t)MR * S + RN * S + RN * kNS + 8 * 64 + 64 + 64 + 32 + 32) + sizeof(int) * 32;
+}
 
 template <int MR>
 __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q) {
     OSOT_DYNAMIC_LDS(nh_smem);
-    constexpr int S = kNS64;
-    double* AN = reinterpret_cast<double*>(nh_smem);   // A N (m x nf), stride 65
-    double* NE = AN + MR * S;                          // N (n x nf, stride 65) -> E (32 x 33 view) -> V2 on the row side (stride 65)
-    double* K = NE + 64 * S;                           // [64][33]: Gram matrix (k x k) -> V1 / reflectors (nf rows) -> V2 on the column side
-    double* stage = K + 64 * kNS;                      // [8][64]: eight rows of A / C staged for the products
+    const int n = Q.n, m = Q.m, ma = Q.ma, nf = Q.nf, ns = Q.ns;
+    const int RN = nhqp64_rows(n), S = nhqp64_stride(n), hr = RN >> 1;
+    double* AN = reinterpret_cast<double*>(nh_smem);   // A N (m x nf), MR rows, stride S
+    double* NE = AN + MR * S;                          // N (n x nf, RN rows, stride S) -> E (32 x 33 view) -> V2 on the row side (stride S)
+    double* K = NE + RN * S;                           // [RN][33]: Gram matrix (k x k) -> V1 / reflectors (nf rows) -> V2 on the column side
+    double* stage = K + RN * kNS;                      // [8][64]: eight rows of A / C staged for the products
     double* b0 = stage + 8 * 64;                       // [64]
     double* vec = b0 + 64;                             // [64]
     double* sig = vec + 64;                            // [32]
@@ -886,46 +918,82 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
     double* E = NE;                                    // (stride kNS inside the same buffer: N is dead by then)
     const long long inst = blockIdx.x;
     const int lane = threadIdx.x, c = lane;
-    const int c32 = lane & 31, h32 = lane >> 5;        // the lane coordinates sym_eig32 works in
+    const int c32 = lane & 31, h32 = lane >> 5;        // the lane coordinates sym_eig32 works in (and the split products below)
     if (inst >= Q.B) return;
     if (Q.status && Q.status[inst] != 0) return;
-    const int n = Q.n, m = Q.m, ma = Q.ma, nf = Q.nf, ns = Q.ns;
     const bool first = Q.level == 0;
+#ifdef OSOT_NHQP_PHASES
+    long long ph_t_ = (long long)clock64();
+#endif
     const double* A = Q.A ? Q.A + inst * (long long)ma * n : nullptr;
-    for (int e = lane; e < 64 * S; e += 64) Nl[e] = 0.0;
-    for (int e = lane; e < 64 * kNS; e += 64) K[e] = 0.0;
+    const int cc = (c < nf) ? c : 0;                   // my column where it exists (reads of idle lanes are discarded)
+    const int ln = (lane < n) ? lane : n - 1;
+    for (int e = lane; e < RN * S; e += 64) Nl[e] = 0.0;
+    for (int e = lane; e < RN * kNS; e += 64) K[e] = 0.0;
     for (int e = lane; e < MR * S; e += 64) AN[e] = 0.0;
     wave_sync();
     if (first) { if (c < n) Nl[c * S + c] = 1.0; }
     else {
         const double* Ng = Q.N + inst * (long long)n * n;
-        for (int i = 0; i < n; ++i) if (c < nf) Nl[i * S + c] = Ng[i * n + c];
+        for (int i0 = 0; i0 < n; i0 += 8) {
+            double nv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u; nv[u] = Ng[((i < n) ? i : n - 1) * n + cc]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u; if (i < n && c < nf) Nl[i * S + c] = nv[u]; }
+        }
     }
-    vec[lane] = (!first && lane < n) ? Q.q0[inst * n + lane] : 0.0;     // q0 staged
+    vec[lane] = (!first && lane < n) ? Q.q0[inst * n + ln] : 0.0;     // q0 staged
     wave_sync();
-    // ---- AN = A N, eight stored rows per batch: lane i loads A[r][i] (coalesced), the rows go through LDS, lane c accumulates
-    double aq_row = 0.0;      // lane = stored row r: (A q0)_r
-    for (int rb = 0; rb < ma; rb += 8) {
+    NHQP_PHASE("loadN");
+    // ---- eight stored rows of A (or C) against N: lane i loads M[r][i] (coalesced), the rows go through LDS, lane c accumulates its
+    // column for all eight with N's entries read once per chunk of 8.  Lane 63 runs the same product against q0 instead of a column
+    // of N (below the first level nf < n <= 64, so it has no column of its own): (M q0)_r comes out of the same instructions instead
+    // of a wave reduction per row.  Returns my column of the eight rows; mq[u] = (M q0)_(rb+u) for everybody.
+    auto rows8_times_N = [&](const double* M, int rows, int rb, double (&acc8)[8], double (&mq)[8]) {
         double a8[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a8[u] = (rb + u < ma && lane < n) ? A[(rb + u) * n + lane] : 0.0;
+        for (int u = 0; u < 8; ++u) { const double v = M[(long long)((rb + u < rows) ? rb + u : rows - 1) * n + ln]; a8[u] = (rb + u < rows && lane < n) ? v : 0.0; }
         wave_sync();
 #pragma unroll
         for (int u = 0; u < 8; ++u) stage[u * 64 + lane] = a8[u];
         wave_sync();
+        const bool q0col = !first && nf < 64;          // (nf = 64 below the first level: every level above was empty -- the reduction then)
+        const bool q0lane = q0col && lane == 63;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc8[u] = 0.0;
+        for (int i0 = 0; i0 < n; i0 += 8) {
+            double nl[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const double a = Nl[(i0 + j) * S + cc], b = vec[i0 + j]; nl[j] = q0lane ? b : a; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc8[u] = fma(stage[u * 64 + i0 + j], nl[j], acc8[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mq[u] = first ? 0.0 : (q0col ? bcast(acc8[u], 63) : colsum<64>(a8[u] * vec[lane]));
+    };
+    double aq_row = 0.0;      // lane = stored row r: (A q0)_r
+    for (int rb = 0; rb < ma; rb += 8) {
+        double acc8[8], mq[8];
+        rows8_times_N(A, ma, rb, acc8, mq);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (rb + u < ma) {
-                double acc = 0.0;
-                for (int i = 0; i < n; ++i) acc = fma(stage[u * 64 + i], Nl[i * S + c], acc);
-                if (c < nf) AN[(rb + u) * S + c] = acc;
-                const double aq = colsum<64>(a8[u] * vec[lane]);
-                if (lane == rb + u) aq_row = aq;
+                if (c < nf) AN[(rb + u) * S + c] = acc8[u];
+                if (lane == rb + u) aq_row = mq[u];
             }
         }
     }
     wave_sync();
-    for (int r = ma; r < m; ++r) if (c < nf) AN[r * S + c] = Nl[(r - ma) * S + c];
+    for (int r0 = ma; r0 < m; r0 += 8) {          // identity rows of the task: rows of N
+        double t8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int r = r0 + u - ma; t8[u] = Nl[((r < RN) ? r : RN - 1) * S + cc]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (r0 + u < m && c < nf) AN[(r0 + u) * S + c] = t8[u];
+    }
     {
         double v = 0.0;
         if (lane < m) {
@@ -935,36 +1003,36 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
         b0[lane] = v;
     }
     wave_sync();
+    NHQP_PHASE("AN+b0");
     // ---- constraints in z-coordinates (levels below the first): rows [C N; N], bounds shifted by q0
     if (!first) {
         const int nr = Q.nc + (Q.has_box ? n : 0);
         double* Rg = Q.R + inst * (long long)nr * nf;
+        const double* Cg = Q.C + inst * (long long)Q.nc * n;
         for (int rb = 0; rb < Q.nc; rb += 8) {
-            double c8[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) c8[u] = (rb + u < Q.nc && lane < n) ? Q.C[(inst * (long long)Q.nc + rb + u) * n + lane] : 0.0;
-            wave_sync();
-#pragma unroll
-            for (int u = 0; u < 8; ++u) stage[u * 64 + lane] = c8[u];
-            wave_sync();
+            double acc8[8], mq[8];
+            rows8_times_N(Cg, Q.nc, rb, acc8, mq);
+            double myq = 0.0;                  // lane u < 8: (C q0) of row rb + u; the eight rows' bounds are loaded together
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                if (rb + u < Q.nc) {
-                    const int r = rb + u;
-                    double acc = 0.0;
-                    for (int i = 0; i < n; ++i) acc = fma(stage[u * 64 + i], Nl[i * S + c], acc);
-                    if (c < nf) Rg[r * nf + c] = acc;
-                    const double cq = colsum<64>(c8[u] * vec[lane]);
-                    if (lane == 0) {
-                        const double lo = Q.lo[inst * Q.nc + r], up = Q.up[inst * Q.nc + r];
-                        Q.rlo[inst * nr + r] = (lo <= -1.0e20) ? -1.0e20 : lo - cq;
-                        Q.rup[inst * nr + r] = (up >= 1.0e20) ? 1.0e20 : up - cq;
-                    }
-                }
+                if (rb + u < Q.nc && c < nf) Rg[(rb + u) * nf + c] = acc8[u];
+                if (lane == u) myq = mq[u];
+            }
+            if (lane < 8 && rb + lane < Q.nc) {
+                const int r = rb + lane;
+                const double lo = Q.lo[inst * Q.nc + r], up = Q.up[inst * Q.nc + r];
+                Q.rlo[inst * nr + r] = (lo <= -1.0e20) ? -1.0e20 : lo - myq;
+                Q.rup[inst * nr + r] = (up >= 1.0e20) ? 1.0e20 : up - myq;
             }
         }
         if (Q.has_box) {
-            for (int i = 0; i < n; ++i) if (c < nf) Rg[(Q.nc + i) * nf + c] = Nl[i * S + c];
+            for (int i0 = 0; i0 < n; i0 += 8) {
+                double t8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t8[u] = Nl[(i0 + u) * S + cc];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (i0 + u < n && c < nf) Rg[(Q.nc + i0 + u) * nf + c] = t8[u];
+            }
             if (lane < n) {
                 const double l = Q.l[inst * n + lane], u = Q.u[inst * n + lane];
                 Q.rlo[inst * nr + Q.nc + lane] = (l <= -1.0e20) ? -1.0e20 : l - vec[lane];
@@ -973,28 +1041,52 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
         }
     }
     wave_sync();      // N is dead from here on: its buffer becomes E (and later V2)
-    // ---- Gram matrix of the small side (k <= 32), stride kNS
+    NHQP_PHASE("constr");
+    // ---- Gram matrix of the small side (k <= 32), stride kNS: lane = (row c32 of the result, half h32 of the inner index),
+    // two rows of the result per trip
     const bool rowside = m <= nf;
     const int k = rowside ? m : nf;
     if (rowside) {
-        for (int a = 0; a < m; ++a) {
-            double acc = 0.0;
-            if (c < m) for (int t = 0; t < nf; ++t) acc = fma(AN[a * S + t], AN[c * S + t], acc);
-            if (c < m) K[a * kNS + c] = acc;
+        const int cm = (c32 < m) ? c32 : 0;
+        for (int a = 0; a < m; a += 2) {
+            double s0 = 0.0, s1 = 0.0;
+            for (int t0 = 0; t0 < nf; t0 += 8) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int t = t0 + 2 * j + h32;
+                    const double own = AN[cm * S + t];
+                    s0 = fma(AN[a * S + t], own, s0);
+                    s1 = fma(AN[(a + 1) * S + t], own, s1);
+                }
+            }
+            s0 = halfsum<32>(s0); s1 = halfsum<32>(s1);
+            if (h32 == 0 && c32 < m) { K[a * kNS + c32] = s0; if (a + 1 < m) K[(a + 1) * kNS + c32] = s1; }
         }
     } else {
-        for (int a = 0; a < nf; ++a) {
-            double acc = 0.0;
-            if (c < nf) for (int r = 0; r < m; ++r) acc = fma(AN[r * S + a], AN[r * S + c], acc);
-            if (c < nf) K[a * kNS + c] = acc;
+        const int cf = (c32 < nf) ? c32 : 0;
+        for (int a = 0; a < nf; a += 2) {
+            double s0 = 0.0, s1 = 0.0;
+            for (int r0 = 0; r0 < m; r0 += 8) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = r0 + 2 * j + h32;
+                    const double own = AN[r * S + cf];
+                    s0 = fma(AN[r * S + a], own, s0);
+                    s1 = fma(AN[r * S + a + 1], own, s1);
+                }
+            }
+            s0 = halfsum<32>(s0); s1 = halfsum<32>(s1);
+            if (h32 == 0 && c32 < nf) { K[a * kNS + c32] = s0; if (a + 1 < nf) K[(a + 1) * kNS + c32] = s1; }
         }
     }
     wave_sync();
     for (int e = lane; e < 32 * kNS; e += 64) E[e] = 0.0;
     wave_sync();
+    NHQP_PHASE("gram");
     sym_eig32_fast(K, E, k, c32, h32);
     {
-        const double lam = (c < k) ? K[c * kNS + c] : -1.0;
+        const double kcc = K[c32 * kNS + c32];
+        const double lam = (c < k) ? kcc : -1.0;
         vec[lane] = lam;
         wave_sync();
         int pos = 0;
@@ -1010,45 +1102,82 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
     const int nrefl = rowside ? (rho < r_next ? rho : r_next) : 0;
     const bool need_refl = rowside && (ns > 0 || (Q.ab_reg && rho < k));
     double* V1 = K;          // V1[t][i]: component t (< nf <= 64) of v_i (i < 32), then reflector i
+    // AN' e (a column of E, rows < m <= 32 on the row side) for my component: chunks of 8 rows
+    auto ANt_times_Ecol = [&](int ec) -> double {
+        double vv = 0.0;
+        for (int q0 = 0; q0 < m; q0 += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vv = fma(AN[(q0 + j) * S + cc], E[(q0 + j) * kNS + ec], vv);
+        }
+        return vv;
+    };
     if (need_refl) {
         // (K still holds the eigenvalues on its diagonal: they are in sig[] now; clear what V1 uses)
         wave_sync();
-        for (int e = lane; e < 64 * kNS; e += 64) K[e] = 0.0;
+        for (int e = lane; e < RN * kNS; e += 64) K[e] = 0.0;
         wave_sync();
         for (int i = 0; i < nrefl; ++i) {
-            const int ec = idx[i];
-            double vv = 0.0;
-            if (c < nf) for (int q = 0; q < m; ++q) vv = fma(AN[q * S + c], E[q * kNS + ec], vv);
+            double vv = ANt_times_Ecol(idx[i]);
             const double nrm2 = colsum<64>((c < nf) ? vv * vv : 0.0);
-            vv = (nrm2 > 0.0) ? vv / sqrt(nrm2) : 0.0;
+            double nsq, nrs;
+            fast_sqrt_rsqrt(nrm2 > 0.0 ? nrm2 : 1.0, nsq, nrs);
+            vv = (nrm2 > 0.0) ? vv * nrs : 0.0;
             if (c < nf) V1[c * kNS + i] = vv;
         }
         wave_sync();
+        // Householder orthonormalisation; the later columns are updated with lane = (column c32, half h32 of the components), see
+        // the 32-wide kernel
         for (int i = 0; i < nrefl; ++i) {
-            const double x = (c >= i && c < nf) ? V1[c * kNS + i] : 0.0;
+            const double v1ci = V1[cc * kNS + i];
+            const double x = (c >= i && c < nf) ? v1ci : 0.0;
             const double nrm2 = colsum<64>(x * x);
             const double xi = bcast(x, i);
-            const double alpha = (xi > 0.0) ? -sqrt(nrm2) : sqrt(nrm2);
-            double hv = (c == i) ? x - alpha : x;
-            const double vn2 = colsum<64>(hv * hv);
-            const double beta = (vn2 > 0.0) ? 2.0 / vn2 : 0.0;
+            double nsq, nrs;
+            fast_sqrt_rsqrt(nrm2 > 0.0 ? nrm2 : 1.0, nsq, nrs);
+            if (!(nrm2 > 0.0)) nsq = 0.0;
+            const double alpha = (xi > 0.0) ? -nsq : nsq;
+            const double hv = (c == i) ? x - alpha : x;
+            const double vn2h = fma(fabs(xi), nsq, nrm2);             // |v|^2 / 2
+            const double beta = (vn2h > 0.0) ? fast_rcp(vn2h) : 0.0;
             wave_sync();
             if (c < nf) V1[c * kNS + i] = hv;
-            for (int j = i + 1; j < nrefl; ++j) {
-                const double y = (c < nf) ? V1[c * kNS + j] : 0.0;
-                const double dot = colsum<64>(hv * y);
-                wave_sync();
-                if (c < nf) V1[c * kNS + j] = y - beta * dot * hv;
-                wave_sync();
+            vec[lane] = hv;
+            wave_sync();
+            {
+                const bool mine = c32 > i && c32 < nrefl;
+                const int j = mine ? c32 : i;
+                // (components 0 .. 39 exist for every n > 32: their reads carry no branch; the other 24 sit behind ONE, rows clamped)
+                double y[32], hq[32], dot = 0.0;
+#pragma unroll
+                for (int t = 0; t < 20; ++t) { const int r = 2 * t + h32; y[t] = V1[r * kNS + j]; hq[t] = vec[r]; }
+#pragma unroll
+                for (int t = 20; t < 32; ++t) { y[t] = 0.0; hq[t] = 0.0; }
+                if (hr > 20) {
+#pragma unroll
+                    for (int t = 20; t < 32; ++t) {
+                        const int r = 2 * t + h32;
+                        const double v = V1[((r < RN) ? r : RN - 1) * kNS + j];
+                        y[t] = (r < RN) ? v : 0.0; hq[t] = vec[r];
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 32; ++t) dot = fma(hq[t], y[t], dot);
+                dot = halfsum<32>(dot) * beta;
+                if (mine) {
+#pragma unroll
+                    for (int t = 0; t < 32; ++t) { const int r = 2 * t + h32; if (t < hr) V1[r * kNS + j] = fma(-dot, hq[t], y[t]); }
+                }
             }
             if (c == 0) refl_beta[i] = beta;
             wave_sync();
         }
     }
+    NHQP_PHASE("eig+V1refl");
     auto completion_column = [&](int j) -> double {           // (Q e_j)[c], j >= nrefl
         double y = (c == j) ? 1.0 : 0.0;
         for (int i = nrefl - 1; i >= 0; --i) {
-            const double hv = (c >= i && c < nf) ? V1[c * kNS + i] : 0.0;
+            const double v = V1[cc * kNS + i];
+            const double hv = (c >= i && c < nf) ? v : 0.0;
             const double dot = colsum<64>(hv * y);
             y -= refl_beta[i] * dot * hv;
         }
@@ -1057,6 +1186,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
     if (Q.ab_reg) {
         double bnew = 0.0;
         const bool rebuild = !rowside;
+        const int lr = (lane < m) ? lane : 0;
         for (int i = 0; i < k; ++i) {
             const double sv = sig[i];
             const bool lift = sv < Q.thr * sv_max;
@@ -1064,21 +1194,25 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
             const int ec = idx[i];
             double uu = 0.0, vv = 0.0;
             if (rowside) {
-                uu = (lane < m) ? E[lane * kNS + ec] : 0.0;
+                const double e_l = E[(lane & 31) * kNS + ec];
+                uu = (lane < m) ? e_l : 0.0;
                 if (i >= rho) {
                     const double qc = completion_column(i);
                     vv = (c < nf) ? qc : 0.0;
                 } else {
-                    double acc = 0.0;
-                    if (c < nf) for (int r = 0; r < m; ++r) acc = fma(AN[r * S + c], E[r * kNS + ec], acc);
-                    vv = acc;
+                    vv = ANt_times_Ecol(ec);
                     const double nrm2 = colsum<64>((c < nf) ? vv * vv : 0.0);
-                    vv = (nrm2 > 0.0) ? vv / sqrt(nrm2) : 0.0;
+                    vv = (nrm2 > 0.0 && c < nf) ? vv / sqrt(nrm2) : 0.0;
                 }
             } else {
-                vv = (c < nf) ? E[c * kNS + ec] : 0.0;
-                double acc = 0.0;
-                if (lane < m) for (int t = 0; t < nf; ++t) acc = fma(AN[lane * S + t], E[t * kNS + ec], acc);
+                const double e_c = E[c32 * kNS + ec];
+                vv = (c < nf) ? e_c : 0.0;
+                double acc = 0.0;                                     // u_i ~ AN v_i: lane = row, chunks of 8 columns (nf <= 32)
+                for (int t0 = 0; t0 < nf; t0 += 8) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc = fma(AN[lr * S + t0 + j], E[(t0 + j) * kNS + ec], acc);
+                }
+                if (lane >= m) acc = 0.0;
                 const double nrm2 = colsum<64>(acc * acc);
                 uu = (nrm2 > 0.0) ? acc / sqrt(nrm2) : 0.0;
             }
@@ -1092,59 +1226,124 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
                 vec[lane] = (lane < m) ? uu : 0.0;
                 wave_sync();
                 const double dl = svn - sv;
-                for (int r = 0; r < m; ++r) if (c < nf) AN[r * S + c] = fma(dl * vec[r], vv, AN[r * S + c]);
+                for (int r0 = 0; r0 < m; r0 += 8) {
+                    double t8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) t8[j] = fma(dl * vec[r0 + j], vv, AN[(r0 + j) * S + cc]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (r0 + j < m && c < nf) AN[(r0 + j) * S + c] = t8[j];
+                }
                 wave_sync();
             }
         }
         if (rebuild && lane < m) b0[lane] = bnew;
         wave_sync();
     }
-    // ---- null-space basis V2 (nf x ns): row side in NE (stride 65), column side in K (stride 33)
+    NHQP_PHASE("ABreg");
+    // ---- null-space basis V2 (nf x ns): row side in NE (stride S), column side in K (stride 33)
     double* V2 = rowside ? NE : K;
     const int v2s = rowside ? S : kNS;
     if (ns > 0) {
         if (!rowside) {
-            for (int t = 0; t < ns; ++t) { const int ec = idx[k - ns + t]; if (c < nf) V2[c * v2s + t] = E[c * kNS + ec]; }
-            wave_sync();
-        } else {
-            // the completion columns are computed first (they read V1 = K only), then written over E / N in NE
             for (int t0 = 0; t0 < ns; t0 += 8) {
-                double y8[8];
+                double t8[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) y8[u] = (t0 + u < ns) ? completion_column(r_next + t0 + u) : 0.0;
+                for (int u = 0; u < 8; ++u) t8[u] = E[c32 * kNS + idx[(t0 + u < ns) ? k - ns + t0 + u : 0]];
                 wave_sync();
 #pragma unroll
-                for (int u = 0; u < 8; ++u) if (t0 + u < ns && c < nf) V2[c * v2s + t0 + u] = y8[u];
+                for (int u = 0; u < 8; ++u) if (t0 + u < ns && c < nf) V2[c * v2s + t0 + u] = t8[u];
+            }
+            wave_sync();
+        } else {
+            // the completion columns Q e_(r_next + t), 32 at a time: lane = (column c32 of the pass, half h32 of the components),
+            // my column in registers; they read V1 = K only and are written over E / N in NE
+            for (int p0 = 0; p0 < ns; p0 += 32) {
+                double y[32];
+#pragma unroll
+                for (int s = 0; s < 32; ++s) y[s] = (2 * s + h32 == r_next + p0 + c32) ? 1.0 : 0.0;
+                for (int i = nrefl - 1; i >= 0; --i) {
+                    double hvv[32], dot = 0.0;
+#pragma unroll
+                    for (int s = 0; s < 20; ++s) hvv[s] = V1[(2 * s + h32) * kNS + i];
+#pragma unroll
+                    for (int s = 20; s < 32; ++s) hvv[s] = 0.0;
+                    if (hr > 20) {
+#pragma unroll
+                        for (int s = 20; s < 32; ++s) {
+                            const int r = 2 * s + h32;
+                            const double v = V1[((r < RN) ? r : RN - 1) * kNS + i];
+                            hvv[s] = (r < RN) ? v : 0.0;
+                        }
+                    }
+#pragma unroll
+                    for (int s = 0; s < 32; ++s) dot = fma(hvv[s], y[s], dot);
+                    dot = halfsum<32>(dot) * refl_beta[i];
+#pragma unroll
+                    for (int s = 0; s < 32; ++s) y[s] = fma(-dot, hvv[s], y[s]);
+                }
+                wave_sync();
+                if (p0 + c32 < ns) {
+#pragma unroll
+                    for (int s = 0; s < 32; ++s) if (s < hr && 2 * s + h32 < nf) V2[(2 * s + h32) * v2s + p0 + c32] = y[s];
+                }
             }
             wave_sync();
         }
     }
-    // ---- H = AN' W AN (+ sv_max V2 V2'), g = -AN' W b0   ->  HBM, nf x nf row-major
+    NHQP_PHASE("V2");
+    // ---- H = AN' W AN (+ sv_max V2 V2'), g = -AN' W b0   ->  HBM, nf x nf row-major.  Two rows of H per trip; the inner index in
+    // chunks of 8 (w_r (A N)[r][c] is rebuilt per chunk: 16 reads of my own column against 16 broadcast reads)
     {
         const double* w = Q.w ? Q.w + inst * m : nullptr;
         wave_sync();
         vec[lane] = (lane < m) ? (w ? w[lane] : 1.0) : 0.0;
         wave_sync();
         double* Hg = Q.H + inst * (long long)nf * nf;
-        const int cc = (c < nf) ? c : 0;
         double gacc = 0.0;
-        for (int r = 0; r < m; ++r) gacc = fma(-(vec[r] * AN[r * S + cc]), b0[r], gacc);
+        for (int r0 = 0; r0 < m; r0 += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gacc = fma(-(vec[r0 + j] * AN[(r0 + j) * S + cc]), b0[r0 + j], gacc);
+        }
         if (c < nf) Q.g[inst * nf + c] = gacc;
         const bool sel = ns > 0 && Q.sel_reg;
-        for (int i = 0; i < nf; ++i) {
+        for (int i0 = 0; i0 < nf; i0 += 2) {
+            const int i1 = (i0 + 1 < nf) ? i0 + 1 : i0;
             double a0 = 0.0, a1 = 0.0;
-            for (int r = 0; r + 1 < m; r += 2) {
-                a0 = fma(vec[r] * AN[r * S + cc], AN[r * S + i], a0);
-                a1 = fma(vec[r + 1] * AN[(r + 1) * S + cc], AN[(r + 1) * S + i], a1);
+            for (int r0 = 0; r0 < m; r0 += 8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int r = r0 + j;
+                    const double wan = vec[r] * AN[r * S + cc];
+                    a0 = fma(wan, AN[r * S + i0], a0);
+                    a1 = fma(wan, AN[r * S + i1], a1);
+                }
             }
-            if (m & 1) a0 = fma(vec[m - 1] * AN[(m - 1) * S + cc], AN[(m - 1) * S + i], a0);
-            if (sel) for (int t = 0; t < ns; ++t) a0 = fma(sv_max * V2[cc * v2s + t], V2[i * v2s + t], a0);
-            if (c < nf) Hg[i * nf + c] = a0 + a1;
+            if (sel) {
+                for (int t0 = 0; t0 < ns; t0 += 8) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int t = t0 + j;
+                        const double v2ct = V2[cc * v2s + t];               // (loaded, then masked: no branch between the reads of a chunk)
+                        const double own = (t < ns) ? sv_max * v2ct : 0.0;
+                        a0 = fma(own, V2[i0 * v2s + t], a0);
+                        a1 = fma(own, V2[i1 * v2s + t], a1);
+                    }
+                }
+            }
+            if (c < nf) { Hg[i0 * nf + c] = a0; if (i1 != i0) Hg[i1 * nf + c] = a1; }
         }
     }
+    NHQP_PHASE("Hg");
     if (ns > 0 && Q.V2) {
         double* Vg = Q.V2 + inst * (long long)n * n;
-        for (int i = 0; i < nf; ++i) if (c < ns) Vg[i * n + c] = V2[i * v2s + c];
+        const int cs = (c < ns) ? c : 0;
+        for (int i0 = 0; i0 < nf; i0 += 8) {
+            double t8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t8[u] = V2[((i0 + u < nf) ? i0 + u : 0) * v2s + cs];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + u < nf && c < ns) Vg[(i0 + u) * n + c] = t8[u];
+        }
     }
 }
 

@@ -96,8 +96,8 @@ extern "C" __attribute__((visibility("default"))) int emu_nhqp_solve(const osot_
     rc = nhqp_run(*plan, b, opt, ws,
         [&](const DevNhqp& Q) {
             if (Q.n > 32) {
-                if (Q.m <= 32) emu::launch(osot_nhqp_prepare64_kernel<32>, grid, nhqp_prepare64_lds_bytes(32), 64, Q);
-                else emu::launch(osot_nhqp_prepare64_kernel<64>, grid, nhqp_prepare64_lds_bytes(64), 64, Q);
+                if (Q.m <= 32) emu::launch(osot_nhqp_prepare64_kernel<32>, grid, nhqp_prepare64_lds_bytes(32, Q.n), 64, Q);
+                else emu::launch(osot_nhqp_prepare64_kernel<64>, grid, nhqp_prepare64_lds_bytes(64, Q.n), 64, Q);
             }
             else if (Q.m <= 32) emu::launch(osot_nhqp_prepare_kernel<32>, grid, 0, 64, Q);
             else emu::launch(osot_nhqp_prepare_kernel<64>, grid, 0, 64, Q);

@@ -228,7 +228,7 @@ def test_symmetric_eigen_solver_emulated():
     from helpers import emu_lib
     L = emu_lib()
     rng = np.random.default_rng(0)
-    for k in (2, 3, 5, 12, 24, 32):
+    for k in (2, 3, 5, 10, 12, 17, 24, 32):
         for trial in range(3):
             A = rng.normal(size=(k, k + 3 * (trial % 2)))
             if trial == 2 and k > 3:
