@@ -457,12 +457,13 @@ def time_coman35(which, B, device, steps=20, warmup=5, front_end="iHQP"):
     return out
 
 
-def time_full_cycle(B, device, lanes=2, steps=40, warmup=8, streams=None):
+def time_full_cycle(B, device, lanes=2, steps=40, warmup=8, streams=None, fused=True):
     """q -> kinematics -> AutoStack::update + cascade -> q += dq for the 32-DoF humanoid under BASELINE config 3's stack (CoM / l_wrist(0.1)
     + r_wrist + l_sole + r_sole / Postural, joint-limit and velocity-limit box), everything resident, submitted like the headline: the
-    batch as `lanes` sub-batches on their own streams, the steps of a lane as ONE HIP graph (kinematics launch, fused update + cascade
-    launch, the integration of q).  The inputs of consecutive steps are the closed loop's own drift (every robot chases its own wrist
-    goals); nothing is replayed from a recorded cycle."""
+    batch as `lanes` sub-batches on their own streams, the steps of a lane as ONE HIP graph.  fused: ONE launch per step
+    (osot_control_cycle: the instance's kinematics, update, cascade and integration by the same wavefront); otherwise three (the
+    kinematics launch, the fused update + cascade launch, the integration of q).  The inputs of consecutive steps are the closed
+    loop's own drift (every robot chases its own wrist goals); nothing is replayed from a recorded cycle."""
     from opensot_amd import abi
     from opensot_amd import kinematics as kin
     from opensot_amd.parallel import lane_ranges
@@ -511,11 +512,16 @@ def time_full_cycle(B, device, lanes=2, steps=40, warmup=8, streams=None):
         leaf = {"B": Bl, "task": [[(com, com_d, None)], [(pose[f], pose_d[f], None) for f in range(4)], [(q, q_ref, None)]],
                 "bound": [(q, qmin, qmax), (qdot_max, None, None)], "rows": []}
 
-        def step(fk=fk, st=st, leaf=leaf, q=q, Bl=Bl, stream=stream):
+        kb = K.batch_args(q, frame_pose={f: pose[f] for f in range(4)}, frame_J={f: (st.A[1], 6 * f) for f in range(4)}, com=com, com_J=(st.A[0], 0))
+
+        def step(fk=fk, st=st, leaf=leaf, q=q, Bl=Bl, stream=stream, kb=kb):
             with torch.cuda.stream(stream):
-                fk()
-                st.cycle(leaf, cached=True)
-                q.add_(st.dq[:Bl])
+                if fused:
+                    st.control_cycle(K, kb, leaf, q_integrate=q)
+                else:
+                    fk()
+                    st.cycle(leaf, cached=True)
+                    q.add_(st.dq[:Bl])
         work.append((st, step, stream, Bl))
     for _ in range(warmup):
         for _, step, _, _ in work:
@@ -550,13 +556,16 @@ def time_full_cycle(B, device, lanes=2, steps=40, warmup=8, streams=None):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     ok = sum(int((st.status[:Bl] == 0).sum().item()) for st, _, _, Bl in work)
-    return {"workload": "full control cycle on the device, BASELINE configs[2] stack on the 32-DoF humanoid: q -> osot_kin_kernel (4 frame poses + "
-                        "Jacobians, CoM + Jacobian, written into A_k) -> osot_cycle_kernel (update + cascade) -> q += dq; closed loop, every robot "
+    how = ("ONE launch per step (osot_control_cycle_kernel<32,false,true>: the instance's kinematics, update, cascade and q += dq by the same wavefront)"
+           if fused else "three launches per step (osot_kin_kernel, osot_cycle_kernel, the integration of q)")
+    return {"workload": "full control cycle on the device, BASELINE configs[2] stack on the 32-DoF humanoid: q -> kinematics (4 frame poses + "
+                        "Jacobians, CoM + Jacobian, written into A_k) -> update + cascade -> q += dq; " + how + "; closed loop, every robot "
                         f"chasing its own wrist goals; {lanes} sub-batches on their own streams, {steps} steps of a lane per HIP graph" + ("" if graphs else " (plain launches)"),
             "batch": B, "lanes": lanes, "value": B * steps / el, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
             "solved_ok": f"{ok}/{B}", "note": note,
-            "roofline": roofline_of(plan, B, 1e3 * el / steps, steps * lanes, "osot_kin_kernel<false,32> + osot_cycle_kernel<32,false,true> + the integration of q "
-                                    "(whole step time as the divisor)")[0]}
+            "roofline": roofline_of(plan, B, 1e3 * el / steps, steps * lanes, ("osot_control_cycle_kernel<32,false,true>" if fused else
+                                    "osot_kin_kernel<false,32> + osot_cycle_kernel<32,false,true> + the integration of q") +
+                                    " (whole step time as the divisor)")[0]}
 
 
 def time_config5_coherent(B, device, steps=40, warmup=8, cycles=4, drift=0.01):
@@ -1045,6 +1054,8 @@ def main():
                 oc["COMAN35_S3_nHQP"] = {"error": str(e)[:300]}
             try:
                 oc["full_cycle"] = time_full_cycle(Bl, local_rank, lanes=S, streams=streams)
+                three = time_full_cycle(Bl, local_rank, lanes=S, streams=streams, fused=False)
+                oc["full_cycle"]["as_three_launches_per_step"] = {"value": three["value"], "ms_per_step": three["ms_per_step"], "solved_ok": three["solved_ok"]}
             except Exception as e:
                 oc["full_cycle"] = {"error": str(e)[:300]}
             try:

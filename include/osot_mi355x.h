@@ -559,6 +559,17 @@ int osot_kin_create(const osot_kin_desc* desc, int device, osot_kin** out);
 int osot_kin_destroy(osot_kin* k);
 int osot_kinematics(osot_kin* k, const osot_kin_batch* batch, void* hip_stream);
 
+/* The body of the reference's control loop for B robots in ONE launch (examples/cpp/coman_ik.cpp:186-219:
+ * `model.update(); stack->update(); solver->solve(dq); q = model.sum(q, dq)`): per instance the same wavefront runs
+ * osot_kinematics (q -> frame poses, Jacobian rows, CoM, written where `kin_batch` says: the arrays the leaf inputs and A_k
+ * point into), then osot_cycle (AutoStack::update + the iHQP cascade), then, when q_integrate is not NULL,
+ * q_integrate[i] += dq[i] (usually kin_batch->q itself: the next call starts from the integrated posture).
+ * Results are those of the three calls; every array they write is still written.  Offered where it pays: models / plans of
+ * up to 32 variables without the collision-pair stage, dense weights, inactive tasks or the hot start (OSOT_ERR_UNSUPPORTED
+ * otherwise -- use the three calls).  Stream-ordered. */
+int osot_control_cycle(osot_solver* s, osot_kin* k, const osot_kin_batch* kin_batch, const osot_leaf_batch* leaf,
+                       const osot_assembled_out* out, const osot_qp_batch* batch, double* q_integrate, void* hip_stream);
+
 /* ---- inverse-dynamics formulation (BASELINE config 5): x = [qddot (nv); contact forces / wrenches] -------------
  * (src/utils/InverseDynamics.cpp:12-28).  The matrices that are pure copies of model quantities are written by these
  * producers straight into their row ranges of the stacked A_k / C (zero-copy, like the kinematics producer's Jacobians);

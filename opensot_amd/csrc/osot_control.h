@@ -1,0 +1,50 @@
+// opensot_amd/csrc/osot_control.h -- the reference's control-loop body for B robots in ONE launch
+// (examples/cpp/coman_ik.cpp:186-219: `model.update(); stack->update(); solver->solve(dq); q = model.sum(q, dq)`):
+// per instance the same wavefront runs the kinematics producer (osot_kin.h: frame poses, Jacobian rows written straight into
+// A_k, CoM), AutoStack::update() and the iHQP cascade (osot_kernels.h), and integrates q += dq.
+//
+// Why one launch: as three launches per step (kinematics, cycle, the integration) every step of a lane carries two more
+// dependent launch gaps, and -- measured, tools/full_cycle_trace.sh -- the kinematics kernel of one lane takes 57-77 us instead
+// of 17 because the other lane's cascade holds every wavefront slot of the chip while it waits (24.5 M solves/s against the
+// 33.6 M of the cycle alone at BASELINE config 3, B = 4096).  Here the kinematics of an instance is ~8 % more work in front of its
+// own update: no slots to wait for, no gaps, and the rows it writes come back from the CU's own L1 / L2 lines.
+#pragma once
+#include <osot_kernels.h>
+#include <osot_kin.h>
+
+namespace osot {
+
+struct DevControl {
+    const DevKin* K;           // the model (osot_kin_create)
+    osot_kin_batch Bt;         // where q is read and the poses / Jacobian rows / CoM are written (the leaf inputs and A_k point there)
+    double* q_int;             // [B][n] integrated at the end: q_int += dq (null: not integrated).  Usually Bt.q itself.
+};
+
+// LDS in front of the cycle's own use of the slice (the update stages its arguments there afterwards): two kinematics slices, the
+// second half of the wavefront runs as an idle instance (kin_instance is written for two robots per wavefront; its lanes store
+// their -- masked -- tables unconditionally)
+constexpr size_t kControlKinLdsBytes = 2 * sizeof(double) * (size_t)kin_lds_doubles<32>(false);
+
+template <int NP, bool EXTRA = false, bool BOX = false>
+__global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : 1)) osot_control_cycle_kernel(const DevUpdate U, const DevPlan P, const DevBatch D, const DevControl F) {
+    static_assert(NP == 32, "the fused control cycle is built for models of up to 32 joints");
+    OSOT_DYNAMIC_LDS(osot_smem);
+    const long long inst = dispatch_instance(D, osot_smem);
+    if (inst < 0) return;
+    {
+        const int sub = (int)(threadIdx.x >> 5), j = (int)(threadIdx.x & 31u);
+        kin_instance<false, 32>(F.K, F.Bt, inst, sub == 0, j, reinterpret_cast<double*>(osot_smem) + sub * kin_lds_doubles<32>(false));
+    }
+    workgroup_fence();      // the producer's global stores (poses, rows of A_k, CoM) are visible to the update's loads (same workgroup)
+    __syncthreads();
+    update_body(OSOT_KERNARG_PTR(DevUpdate, U), inst, (int)threadIdx.x, osot_smem);
+    workgroup_fence();
+    __syncthreads();
+    cascade_body<NP, false, EXTRA, BOX>(P, D, inst, (int)threadIdx.x, osot_smem);
+    if (F.q_int) {          // q += dq (the lane that stored dq[i] reads it back: its own store)
+        const int n = P.n, i = (int)threadIdx.x;
+        if (i < n) F.q_int[inst * n + i] += D.dq[inst * n + i];
+    }
+}
+
+}  // namespace osot

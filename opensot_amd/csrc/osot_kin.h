@@ -130,68 +130,88 @@ __device__ inline void closest_segment_box(const double* p0, const double* p1, c
     }
 }
 
-// PAIRS: the instantiation with the self-collision stage (step 5); the other one keeps the leaner register / LDS budget
-// JMAX = 32: TWO instances per wavefront (lanes 0..31 and 32..63 each run a robot of <= 32 joints: every instruction, every
-// 64-lane store carries two instances);  JMAX = 64: one instance per wavefront.  LDS per wavefront 16.5 KB either way.
-template <bool PAIRS, int JMAX>
-__global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__ K, const osot_kin_batch Bt) {
 #ifndef OSOT_KIN_TS
 #define OSOT_KIN_TS 12
 #endif
+// LDS one instance of kin_instance needs, in doubles (the int / 64-bit tables included): transforms, axes, centres of mass, parents,
+// ancestor masks -- and the pair table of the PAIRS instantiation
+template <int JMAX> constexpr int kin_lds_doubles(bool pairs) {
+    return JMAX * OSOT_KIN_TS + JMAX * 3 + JMAX * 4 + (JMAX + 1) / 2 + JMAX + OSOT_KIN_MAX_FRAMES * 13 + (pairs ? OSOT_KIN_MAX_PAIRS * 9 : 0);
+}
+// The kinematics of ONE instance by the JMAX lanes j = 0 .. JMAX - 1 that call it together (lane = joint; the reductions are
+// colsum<JMAX>).  `lds` = kin_lds_doubles<JMAX>(PAIRS) doubles of this instance's own.  The kernel below calls it for one instance
+// per wavefront (JMAX = 64) or two (JMAX = 32: the halves); osot_control_cycle_kernel calls it in front of the instance's update.
+// PAIRS: the instantiation with the self-collision stage (step 5); the other one keeps the leaner register / LDS budget
+// developer knob (tools/build_variant.sh NAME -DOSOT_KIN_PHASES): instance 0 prints the clock count of every stage
+#ifdef OSOT_KIN_PHASES
+#define KIN_PHASE(tag) do { const long long t_ = (long long)clock64(); if (inst == 0 && j == 0) printf("KIN " tag " %lld\n", t_ - kph_); kph_ = (long long)clock64(); } while (0)
+#else
+#define KIN_PHASE(tag) do { } while (0)
+#endif
+template <bool PAIRS, int JMAX>
+__device__ __forceinline__ void kin_instance(const DevKin* __restrict__ K, const osot_kin_batch& Bt, const long long inst, const bool live,
+                                             const int j, double* lds) {
     constexpr int TS = OSOT_KIN_TS;
-    constexpr int PACK = 64 / JMAX;
-    OSOT_STATIC_LDS(double, Tb_all, PACK * JMAX * TS);   // ONE transform buffer [R | p] per joint (round 3; it was a ping-pong
+    double* Tb = lds;                                     // ONE transform buffer [R | p] per joint (round 3; it was a ping-pong
     //                                              pair: a round of the pointer jumping reads, synchronises, writes, synchronises
     //                                              either way, so the second buffer bought nothing and cost 3 KB per instance:
     //                                              10.4 KB per wavefront instead of 16.5 -> 15 wavefronts per CU instead of 9)
-    OSOT_STATIC_LDS(double, Zw_all, PACK * JMAX * 3);     // world joint axes
-    OSOT_STATIC_LDS(double, Cw_all, PACK * JMAX * 4);     // world link centres of mass, mass
-    OSOT_STATIC_LDS(int, Par_all, PACK * JMAX);           // parent indices (the chain walk must not chase pointers through HBM)
-    OSOT_STATIC_LDS(unsigned long long, Anc_all, PACK * JMAX);   // ancestor masks
-    const int sub = (PACK == 2) ? (int)(threadIdx.x >> 5) : 0;
-    const int j = (PACK == 2) ? (int)(threadIdx.x & 31u) : (int)threadIdx.x;
-    double* Tb = Tb_all + sub * (JMAX * TS);
     double* Tl = Tb;
-    double* Zw = Zw_all + sub * (JMAX * 3);
-    double* Cw = Cw_all + sub * (JMAX * 4);
-    int* Par = Par_all + sub * JMAX;
-    unsigned long long* Anc = Anc_all + sub * JMAX;
-    const long long inst = (long long)blockIdx.x * PACK + sub;
-    const bool live = inst < Bt.B;            // (an odd batch leaves the last wavefront's second half idle)
+    double* Zw = Tb + JMAX * TS;                          // world joint axes
+    double* Cw = Zw + JMAX * 3;                           // world link centres of mass, mass
+    unsigned long long* Anc = reinterpret_cast<unsigned long long*>(Cw + JMAX * 4);   // ancestor masks
+    int* Par = reinterpret_cast<int*>(Anc + JMAX);        // parent indices (the chain walk must not chase pointers through HBM)
+    double* Fw = reinterpret_cast<double*>(Par + 2 * ((JMAX + 1) / 2));               // per frame: world [R | p] and its joint
+    double* Pw = Fw + OSOT_KIN_MAX_FRAMES * 13;                                       // per pair: normal n, axis points c_a, c_b (world)
+    (void)Pw;
+#ifdef OSOT_KIN_PHASES
+    long long kph_ = (long long)clock64();
+#endif
     const int n = K->d.n;
     const bool valid = j < n && live;
     Par[j] = valid ? K->d.parent[j] : -1;
     Anc[j] = valid ? K->anc[j] : 0ull;
-    // ---- 1. local transforms
-    if (valid) {
-        const double q = Bt.q[inst * n + j];
-        const double* R0 = K->d.R0[j];
-        const double* ax = K->d.axis[j];
+    // ---- 1. local transforms.  Everything the lane needs from the model (23 loads) and its q are fetched in ONE batch, in front of the
+    // sincos (computed whatever the joint type: its ~1.5 k clocks then run under the loads instead of behind the type's round trip)
+    const int jc = (j < n) ? j : 0;
+    const double qj = Bt.q[(live ? inst : 0) * n + jc];
+    const int type_j = K->d.type[jc];
+    const unsigned long long sub_j = K->sub[jc];
+    double R0[9], ax[3], p0j[3], comj[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R0[i] = K->d.R0[jc][i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { ax[i] = K->d.axis[jc][i]; p0j[i] = K->d.p0[jc][i]; comj[i] = K->d.com[jc][i]; }
+    const double mass_j = K->d.mass[jc];
+    {
+        double sn, cs;
+        sincos(qj, &sn, &cs);
         double R[9], p[3];
-        if (K->d.type[j] == OSOT_JOINT_REVOLUTE) {
-            double s, c;
-            sincos(q, &s, &c);
-            const double v = 1.0 - c, x = ax[0], y = ax[1], z = ax[2];
-            const double Rq[9] = {c + x * x * v,     x * y * v - z * s, x * z * v + y * s,
-                                  y * x * v + z * s, c + y * y * v,     y * z * v - x * s,
-                                  z * x * v - y * s, z * y * v + x * s, c + z * z * v};   // Rodrigues
+        if (type_j == OSOT_JOINT_REVOLUTE) {
+            const double v = 1.0 - cs, x = ax[0], y = ax[1], z = ax[2];
+            const double Rq[9] = {cs + x * x * v,     x * y * v - z * sn, x * z * v + y * sn,
+                                  y * x * v + z * sn, cs + y * y * v,     y * z * v - x * sn,
+                                  z * x * v - y * sn, z * y * v + x * sn, cs + z * z * v};   // Rodrigues
             mat3_mul(R0, Rq, R);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) p[i] = K->d.p0[j][i];
+            for (int i = 0; i < 3; ++i) p[i] = p0j[i];
         } else {
             double t[3];
             mat3_vec(R0, ax, t);
 #pragma unroll
             for (int i = 0; i < 9; ++i) R[i] = R0[i];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) p[i] = K->d.p0[j][i] + q * t[i];
+            for (int i = 0; i < 3; ++i) p[i] = p0j[i] + qj * t[i];
         }
+        if (valid) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) Tl[j * TS + i] = R[i];
+            for (int i = 0; i < 9; ++i) Tl[j * TS + i] = R[i];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) Tl[j * TS + 9 + i] = p[i];
+            for (int i = 0; i < 3; ++i) Tl[j * TS + 9 + i] = p[i];
+        }
     }
     wave_sync();
+    KIN_PHASE("local");
     // ---- 2. world transforms by POINTER JUMPING: every lane keeps T(jp -> j), the transform from the frame of its
     // jump pointer jp to its own frame, and in each round composes it with T(jp(jp) -> jp) read from LDS and jumps:
     // ceil(log2(depth + 1)) rounds (4 for a humanoid) instead of a walk of `depth` steps up the chain.
@@ -228,44 +248,77 @@ __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__
             wave_sync();
         }
     }
+    KIN_PHASE("jump");
     double* Tw = Tb;               // final world transforms (re-written below, after the last round's barrier: a joint without a parent never entered the loop's writes)
-    if (valid) {
+    double zj[3];
+    {
         double z[3], cl[3];
-        mat3_vec(Rw, K->d.axis[j], z);
-        mat3_vec(Rw, K->d.com[j], cl);
+        mat3_vec(Rw, ax, z);
+        mat3_vec(Rw, comj, cl);
+        if (valid) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) Tw[j * TS + i] = Rw[i];
+            for (int i = 0; i < 9; ++i) Tw[j * TS + i] = Rw[i];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { Tw[j * TS + 9 + i] = pw[i]; Zw[j * 3 + i] = z[i]; Cw[j * 4 + i] = cl[i] + pw[i]; }
-        Cw[j * 4 + 3] = K->d.mass[j];
+            for (int i = 0; i < 3; ++i) Tw[j * TS + 9 + i] = pw[i];
+        }
+        // (links beyond n: zero mass at the origin -- the fixed-trip sums below read all JMAX entries)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { Zw[j * 3 + i] = valid ? z[i] : 0.0; Cw[j * 4 + i] = valid ? cl[i] + pw[i] : 0.0; zj[i] = valid ? z[i] : 0.0; }
+        Cw[j * 4 + 3] = valid ? mass_j : 0.0;
     }
-    wave_sync();
-    const double zj[3] = {valid ? Zw[j * 3] : 0.0, valid ? Zw[j * 3 + 1] : 0.0, valid ? Zw[j * 3 + 2] : 0.0};
-    const bool revolute = valid && K->d.type[j] == OSOT_JOINT_REVOLUTE;
-    // ---- 3. frames
-    for (int f = 0; f < K->d.n_frames; ++f) {
+    const bool revolute = valid && type_j == OSOT_JOINT_REVOLUTE;
+    // ---- 3a. world frames, lane = frame: the frame's joint, offset and options in one batch of loads per lane, [R | p] and the joint
+    // into LDS for the Jacobian columns below; the pose goes out from here
+    const int nfr = K->d.n_frames;
+    {
+        const int f = (j < nfr) ? j : 0;
         const int jf = K->d.frame_joint[f];
+        double FR[9], Fp[3];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) FR[i] = K->d.frame_R[f][i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Fp[i] = K->d.frame_p[f][i];
+        double* pose_out = nullptr;        // (a select chain: a lane-indexed read of the argument struct would be served from a scratch copy)
+#pragma unroll
+        for (int ff = 0; ff < OSOT_KIN_MAX_FRAMES; ++ff) pose_out = (f == ff) ? Bt.frame_pose[ff] : pose_out;
+        wave_sync();               // the world transforms are in LDS
+        double Rj[9], pj[3], Rf[9], t[3];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rj[i] = Tw[jf * TS + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pj[i] = Tw[jf * TS + 9 + i];
+        mat3_mul(Rj, FR, Rf);
+        mat3_vec(Rj, Fp, t);
+        if (j < nfr) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Fw[j * 13 + i] = Rf[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) Fw[j * 13 + 9 + i] = pj[i] + t[i];
+            Fw[j * 13 + 12] = (double)jf;
+            if (pose_out && live) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) pose_out[inst * 12 + i] = Rf[i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) pose_out[inst * 12 + 9 + i] = pj[i] + t[i];
+            }
+        }
+        wave_sync();
+    }
+    KIN_PHASE("world");
+    // ---- 3. frames: the Jacobian columns, lane = joint
+    for (int f = 0; f < nfr; ++f) {
+        double* Jf = Bt.frame_J[f];
+        if (!Jf) continue;
+        const long long jstride = Bt.frame_J_stride[f];
+        const int body = K->d.frame_body[f];
+        const unsigned long long cm = K->d.frame_col_mask[f];   // Task::applyActiveJointsMask (Task.h:129-139)
         double Rf[9], pf[3];
-        {
-            double Rj[9], pj[3], t[3];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) Rj[i] = Tw[jf * TS + i];
+        for (int i = 0; i < 9; ++i) Rf[i] = Fw[f * 13 + i];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) pj[i] = Tw[jf * TS + 9 + i];
-            mat3_mul(Rj, K->d.frame_R[f], Rf);
-            mat3_vec(Rj, K->d.frame_p[f], t);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) pf[i] = pj[i] + t[i];
-        }
-        if (Bt.frame_pose[f] && j < 12 && live) {   // lane j stores element j of [R | p] (a select chain: a lane-indexed
-            double v = Rf[0];                //  read of Rf would put the arrays in scratch memory)
-#pragma unroll
-            for (int i = 1; i < 9; ++i) v = (j == i) ? Rf[i] : v;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) v = (j == 9 + i) ? pf[i] : v;
-            Bt.frame_pose[f][inst * 12 + j] = v;
-        }
-        if (Bt.frame_J[f] && valid) {
+        for (int i = 0; i < 3; ++i) pf[i] = Fw[f * 13 + 9 + i];
+        const int jf = (int)Fw[f * 13 + 12];
+        if (valid) {
             double col[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             if ((Anc[jf] >> j) & 1ull) {
                 if (revolute) {
@@ -276,7 +329,7 @@ __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__
                     col[0] = zj[0]; col[1] = zj[1]; col[2] = zj[2];
                 }
             }
-            if (K->d.frame_body[f]) {   // BODY Jacobian Ad(R_f') J (Cartesian.cpp:93-100): both halves rotated by R_f'
+            if (body) {   // BODY Jacobian Ad(R_f') J (Cartesian.cpp:93-100): both halves rotated by R_f'
                 double rl[3], ra[3];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
@@ -286,31 +339,35 @@ __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__
 #pragma unroll
                 for (int i = 0; i < 3; ++i) { col[i] = rl[i]; col[3 + i] = ra[i]; }
             }
-            const unsigned long long cm = K->d.frame_col_mask[f];   // Task::applyActiveJointsMask (Task.h:129-139)
             const bool masked = cm != 0ull && !((cm >> j) & 1ull);
-            double* J = Bt.frame_J[f] + inst * Bt.frame_J_stride[f];
+            double* J = Jf + inst * jstride;
 #pragma unroll
             for (int r = 0; r < 6; ++r) J[r * n + j] = masked ? 0.0 : col[r];
         }
     }
+    KIN_PHASE("frames");
     // ---- 4. centre of mass and its Jacobian
     if (Bt.com || Bt.com_J) {
-        const double M = K->total_mass;
+        const double iM = fast_rcp(K->total_mass);       // (one reciprocal instead of six fp64 divisions)
         if (Bt.com) {
             const double mj = valid ? Cw[j * 4 + 3] : 0.0;
             double c3[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) c3[i] = colsum<JMAX>(valid ? mj * Cw[j * 4 + i] : 0.0) / M;
+            for (int i = 0; i < 3; ++i) c3[i] = colsum<JMAX>(valid ? mj * Cw[j * 4 + i] : 0.0) * iM;
             if (j < 3 && live) Bt.com[inst * 3 + j] = c3[(j == 0) ? 0 : ((j == 1) ? 1 : 2)];
         }
         if (Bt.com_J) {
             // subtree aggregates S_j = sum over the links l that joint j moves of m_l [c_l, 1]: a 0/1 matrix-vector
             // product with the link values read at UNIFORM addresses (LDS broadcast), no divergence; then
             // column j = z_j x (Sc_j - Sm_j p_j) / M  (revolute)   or   (Sm_j / M) z_j  (prismatic)
-            const unsigned long long mine = valid ? K->sub[j] : 0ull;
+            // (a fixed trip count: the 4 JMAX reads are in flight together -- link by link it was one LDS round trip per link; links
+            //  beyond n are zeros)
+            const unsigned long long mine = valid ? sub_j : 0ull;
             double sc[3] = {0.0, 0.0, 0.0}, sm = 0.0;
-            for (int l = 0; l < n; ++l) {
-                const double ml = ((mine >> l) & 1ull) ? Cw[l * 4 + 3] : 0.0;
+#pragma unroll
+            for (int l = 0; l < JMAX; ++l) {
+                const double cm_l = Cw[l * 4 + 3];
+                const double ml = ((mine >> l) & 1ull) ? cm_l : 0.0;
                 sc[0] = fma(ml, Cw[l * 4], sc[0]); sc[1] = fma(ml, Cw[l * 4 + 1], sc[1]); sc[2] = fma(ml, Cw[l * 4 + 2], sc[2]);
                 sm += ml;
             }
@@ -326,16 +383,15 @@ __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__
                 const bool masked = cm != 0ull && !((cm >> j) & 1ull);
                 double* J = Bt.com_J + inst * Bt.com_J_stride;
 #pragma unroll
-                for (int r = 0; r < 3; ++r) J[r * n + j] = masked ? 0.0 : acc[r] / M;
+                for (int r = 0; r < 3; ++r) J[r * n + j] = masked ? 0.0 : acc[r] * iM;
             }
         }
     }
+    KIN_PHASE("com");
     // ---- 5. self-collision pairs
     if constexpr (PAIRS) {
     const int np = K->d.n_pairs;
     if (np > 0 && (Bt.pair_dist || Bt.pair_J)) {
-        OSOT_STATIC_LDS(double, Pw_all, PACK * OSOT_KIN_MAX_PAIRS * 9);   // per pair: normal n, axis points c_a, c_b (world)
-        double* Pw = Pw_all + sub * (OSOT_KIN_MAX_PAIRS * 9);
         if (j < np && live) {
             double e[2][6];
             double Rc[9], pc[3];      // carrier frame of side b (link, world, or the runtime pose of an environment shape)
@@ -430,6 +486,20 @@ __global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__
         }
     }
     }
+}
+
+// JMAX = 32: TWO instances per wavefront (lanes 0..31 and 32..63 each run a robot of <= 32 joints: every instruction, every
+// 64-lane store carries two instances);  JMAX = 64: one instance per wavefront.
+template <bool PAIRS, int JMAX>
+__global__ void __launch_bounds__(64) osot_kin_kernel(const DevKin* __restrict__ K, const osot_kin_batch Bt) {
+    constexpr int PACK = 64 / JMAX;
+    constexpr int SLICE = kin_lds_doubles<JMAX>(PAIRS);
+    OSOT_STATIC_LDS(double, kin_lds, PACK * SLICE);
+    const int sub = (PACK == 2) ? (int)(threadIdx.x >> 5) : 0;
+    const int j = (PACK == 2) ? (int)(threadIdx.x & 31u) : (int)threadIdx.x;
+    const long long inst = (long long)blockIdx.x * PACK + sub;
+    const bool live = inst < Bt.B;            // (an odd batch leaves the last wavefront's second half idle)
+    kin_instance<PAIRS, JMAX>(K, Bt, inst, live, j, kin_lds + sub * SLICE);
 }
 
 }  // namespace osot

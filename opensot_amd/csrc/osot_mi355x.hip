@@ -17,6 +17,7 @@
 
 #include "osot_host_plan.h"
 #include "osot_kin.h"
+#include "osot_control.h"
 #include "osot_ehqp.h"
 #include "osot_id.h"
 #include "osot_nhqp_host.h"
@@ -206,6 +207,8 @@ int osot_solver_create(const osot_plan_desc* plan, int max_batch, int device, os
         if constexpr (NP == 32) {
             if (r == OSOT_OK) r = ensure_lds(osot_cascade_kernel<32, false, false, true>, lds);
             if (r == OSOT_OK) r = ensure_lds(osot_cycle_kernel<32, false, true>, lds);
+            if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<32, false, true>, lds > kControlKinLdsBytes ? lds : kControlKinLdsBytes);
+            if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<32, false, false>, lds > kControlKinLdsBytes ? lds : kControlKinLdsBytes);
             if (r == OSOT_OK) r = ensure_lds(osot_cascade_kernel<32, true, false, true>, lds);
         }
         return r;
@@ -445,7 +448,8 @@ int osot_solver_kernel_time_ms(osot_solver* s, int reset, double* avg_ms, int* l
     return OSOT_OK;
 }
 
-static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream, long long* prof, const DevUpdate* fused = nullptr);
+static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream, long long* prof, const DevUpdate* fused = nullptr,
+                       const DevControl* control = nullptr);
 
 int osot_ihqp_solve(osot_solver* s, const osot_qp_batch* b, void* hip_stream) {
     return ihqp_launch(s, b, hip_stream, nullptr);
@@ -471,7 +475,7 @@ int osot_solver_profile_phases(osot_solver* s, const osot_qp_batch* b, long long
     return ihqp_launch(s, b, hip_stream, cycles);
 }
 
-static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream, long long* prof, const DevUpdate* fused) {
+static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream, long long* prof, const DevUpdate* fused, const DevControl* control) {
     if (!s || !b) return fail(OSOT_ERR_INVALID, "null solver/batch");
     if (b->B < 0 || b->B > s->max_batch) return fail(OSOT_ERR_INVALID, "batch size exceeds max_batch");
     if (b->B == 0) return OSOT_OK;   // empty batch: nothing to do
@@ -483,6 +487,10 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
     {   // developer knob: extra dynamic LDS per wave (lowers the occupancy; used to measure how the kernel responds to it)
         static const char* extra = getenv("OSOT_DEBUG_EXTRA_LDS");
         if (extra) lds += (size_t)atoi(extra);
+    }
+    if (control) {
+        if (T != 32) return fail(OSOT_ERR_UNSUPPORTED, "the fused control cycle is built for plans of up to 32 variables (use osot_kinematics + osot_cycle)");
+        if (lds < kControlKinLdsBytes) lds = kControlKinLdsBytes;
     }
     DevBatch D;
     std::memset(&D, 0, sizeof(D));
@@ -543,9 +551,16 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
     }   // (hot start: the EXTRA instantiation carries its code; never together with prof, see D.hot)
     // plans without constraint rows (the bounds are the only inequalities): the BOX instantiation of the 32-column kernels
     const bool box = s->specialise && !extra && P.nc == 0 && T == 32;
+    if (control && (extra || prof || !fused))
+        return fail(OSOT_ERR_UNSUPPORTED, "the fused control cycle carries no dense-weight / inactive-task / hot-start / profiling code (use osot_kinematics + osot_cycle)");
     by_np(T, [&](auto np) {
         constexpr int NP = decltype(np)::value;
         if constexpr (NP == 32) {
+            if (control) {
+                if (box) hipLaunchKernelGGL((osot_control_cycle_kernel<32, false, true>), dim3(grid), dim3(64), lds, st, *fused, P, D, *control);
+                else hipLaunchKernelGGL((osot_control_cycle_kernel<32, false, false>), dim3(grid), dim3(64), lds, st, *fused, P, D, *control);
+                return 0;
+            }
             if (box) {
                 if (fused) hipLaunchKernelGGL((osot_cycle_kernel<32, false, true>), dim3(grid), dim3(64), lds, st, *fused, P, D);
                 else if (prof) hipLaunchKernelGGL((osot_cascade_kernel<32, true, false, true>), dim3(grid), dim3(64), lds, st, P, D);
@@ -983,6 +998,29 @@ int osot_kinematics(osot_kin* k, const osot_kin_batch* b, void* hip_stream) {
     }
     HIP_TRY(hipGetLastError());
     return OSOT_OK;
+}
+
+int osot_control_cycle(osot_solver* s, osot_kin* k, const osot_kin_batch* kb, const osot_leaf_batch* leaf, const osot_assembled_out* out,
+                       const osot_qp_batch* b, double* q_integrate, void* hip_stream) {
+    if (!s || !k || !kb || !leaf || !out || !b) return fail(OSOT_ERR_INVALID, "null argument");
+    if (leaf->B != b->B || kb->B != b->B) return fail(OSOT_ERR_INVALID, "kinematics batch, leaf batch and qp batch disagree on B");
+    if (leaf->B < 0 || leaf->B > s->max_batch) return fail(OSOT_ERR_INVALID, "batch size exceeds max_batch");
+    if (leaf->B == 0) return OSOT_OK;
+    if (!kb->q) return fail(OSOT_ERR_INVALID, "q is null");
+    if (k->device != s->device) return fail(OSOT_ERR_INVALID, "the model and the solver live on different devices");
+    if (k->n != s->plan.n) return fail(OSOT_ERR_INVALID, "the model's joint count is not the plan's variable count");
+    if (k->n > 32) return fail(OSOT_ERR_UNSUPPORTED, "the fused control cycle is built for models of up to 32 joints (use osot_kinematics + osot_cycle)");
+    if (k->n_pairs > 0 && (kb->pair_dist || kb->pair_J))
+        return fail(OSOT_ERR_UNSUPPORTED, "the fused control cycle carries no collision-pair stage (use osot_kinematics + osot_cycle)");
+    DevUpdate U;
+    const char* why = "";
+    int rc = make_update_args(s->plan, s->h_uplan, leaf, out, s->d_uplan, U, &why);
+    if (rc != OSOT_OK) return fail(rc, why);
+    DevControl C;
+    C.K = (const DevKin*)k->dev;
+    C.Bt = *kb;
+    C.q_int = q_integrate;
+    return ihqp_launch(s, b, hip_stream, nullptr, &U, &C);
 }
 
 }  // extern "C"

@@ -285,8 +285,14 @@ class Kinematics:
             pass
 
     def forward(self, q, frame_pose=None, frame_J=None, com=None, com_J=None, pair_dist=None, pair_J=None, env_pose=None):
-        """q [B][n] (device).  frame_pose: {frame index: tensor [B][12]}; frame_J: {frame index: (A_k tensor [B][ma][n],
-        first row)}; com: tensor [B][3]; com_J: (A_k tensor, first row).  Stream-ordered on torch's current stream.
+        """osot_kinematics for the batch `batch_args` describes, stream-ordered on torch's current stream"""
+        kb = self.batch_args(q, frame_pose, frame_J, com, com_J, pair_dist, pair_J, env_pose)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        abi.check(self._lib.osot_kinematics(self._h, C.byref(kb), stream), "osot_kinematics")
+
+    def batch_args(self, q, frame_pose=None, frame_J=None, com=None, com_J=None, pair_dist=None, pair_J=None, env_pose=None):
+        """the osot_kin_batch of a call (pointers and strides only; the tensors must outlive its use).  q [B][n] (device).  frame_pose: {frame index: tensor [B][12]}; frame_J: {frame index: (A_k tensor [B][ma][n],
+        first row)}; com: tensor [B][3]; com_J: (A_k tensor, first row).
         env_pose: poses of the environment shapes, a device tensor [n_env][12] (one world for all instances) or
         [B][n_env][12]; default: the model's own (add_collision_shape / move_collision_shape), uploaded when they change"""
         B, n = q.shape
@@ -328,5 +334,4 @@ class Kinematics:
             kb.env_pose = env_pose.data_ptr()
             kb.env_pose_stride = 12 * n_env if env_pose.dim() == 3 else 0
             self._env_keep = env_pose
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        abi.check(self._lib.osot_kinematics(self._h, C.byref(kb), stream), "osot_kinematics")
+        return kb

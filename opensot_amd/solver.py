@@ -194,6 +194,27 @@ class BatchedStack:
         abi.check(self._lib.osot_cycle(self._h, C.byref(lb), C.byref(out), C.byref(qb), _stream_ptr(self.device, self.stream)), "osot_cycle")
         return lb.B
 
+    def control_cycle(self, kin, kin_batch, dev_leaf, q_integrate=None, write_weights=True):
+        """the body of the reference's control loop in ONE launch (osot_control_cycle; coman_ik.cpp:186-219): per instance the
+        kinematics producer `kin` (a kinematics.Kinematics; kin_batch = kin.batch_args(...), whose outputs are the tensors
+        dev_leaf and self.A point at), AutoStack::update, the cascade, and q_integrate += dq when a tensor is given.  The three
+        argument structs are cached per (kin_batch, dev_leaf): they hold pointers only."""
+        key = ("control", id(kin_batch), id(dev_leaf), write_weights, 0 if q_integrate is None else q_integrate.data_ptr(),
+               tuple(0 if a is None else a.data_ptr() for a in self.A), self.dq.data_ptr(), self.status.data_ptr())
+        hit = self._cycle_args.get(key) if self.level_active is None else None
+        if hit is None:
+            lb, out = self._update_args(dev_leaf, write_weights)
+            qb = self._qp_batch(lb.B)
+            hit = (lb, out, qb, dev_leaf, kin_batch)
+            if self.level_active is None:
+                if len(self._cycle_args) > 64:
+                    self._cycle_args.clear()
+                self._cycle_args[key] = hit
+        lb, out, qb, _, kb = hit
+        abi.check(self._lib.osot_control_cycle(self._h, kin._h, C.byref(kb), C.byref(lb), C.byref(out), C.byref(qb),
+                                               _dev_ptr(q_integrate), _stream_ptr(self.device, self.stream)), "osot_control_cycle")
+        return lb.B
+
     # ---- Solver::solve ------------------------------------------------------------------------------
     def _qp_batch(self, B):
         qb = abi.QpBatch()

@@ -294,6 +294,81 @@ def test_closed_loop_ik_on_device(gpu_device):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("with_rows", [False, True])
+def test_control_cycle_in_one_launch_matches_the_three_calls(with_rows, gpu_device):
+    """osot_control_cycle (round 4: per instance kinematics -> AutoStack::update -> cascade -> q += dq by the same wavefront,
+    coman_ik.cpp:186-219 in ONE launch) against osot_kinematics + osot_cycle + the integration as three launches, over 25
+    closed-loop steps from the same start: every array both write (poses, CoM, the Jacobian rows in A_k, b_k, the box, dq, q)
+    is bit-identical.  with_rows: a plan with constraint rows (the general instantiation; without: the BOX one).  An odd batch."""
+    import torch
+    from opensot_amd.plan import Rows
+    from opensot_amd.solver import BatchedStack
+    m = kin.humanoid32()
+    n, B = m.n, 203
+    dev = torch.device("cuda", 0)
+    f64 = dict(dtype=torch.float64, device=dev)
+    rng = np.random.default_rng(19)
+    q0 = np.zeros((B, n))
+    q0[:, [m.names.index(s + "KneeSag") for s in "RL"]] = 0.5
+    q0[:, [m.names.index(s + "HipSag") for s in "RL"]] = -0.25
+    q0[:, [m.names.index(s + "AnkSag") for s in "RL"]] = -0.25
+    q0[:, [m.names.index(s + "Elbj") for s in "RL"]] = -0.6
+    q0 += rng.normal(0.0, 0.02, (B, n))
+    levels = [[Task(abi.TASK_COM, 3, lam=0.1, name="com")],
+              [Task(abi.TASK_CARTESIAN, 6, weight=0.1, lam=0.1, name="l_wrist"), Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="r_wrist"),
+               Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="l_sole"), Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="r_sole")],
+              [Task(abi.TASK_POSTURAL, n, lam=0.01, name="postural")]]
+    bounds = [Bound(abi.BOUND_JOINT_LIMITS, scaling=1.0, name="jl"), Bound(abi.BOUND_VELOCITY_LIMITS, dT=0.01, name="vl")]
+    rowblocks = [Rows(abi.ROWS_GENERIC, 2, name="rows")] if with_rows else []
+    plan = StackPlan(n=n, levels=levels, bounds=bounds, rowblocks=rowblocks, eps_abs=eps_abs_from_factor(1e6))
+    K = kin.Kinematics(m, device=0)
+    Crow = torch.as_tensor(rng.normal(size=(B, 2, n)), **f64).contiguous()
+    rlo = torch.full((B, 2), -0.05, **f64); rup = torch.full((B, 2), 0.05, **f64)
+
+    def make():
+        st = BatchedStack(plan, B, device=0, want_levels=False)
+        q = torch.as_tensor(q0, **f64).contiguous()
+        pose = [torch.zeros((B, 12), **f64) for _ in range(4)]
+        com = torch.zeros((B, 3), **f64)
+        kw = dict(frame_pose={f: pose[f] for f in range(4)}, frame_J={f: (st.A[1], 6 * f) for f in range(4)}, com=com, com_J=(st.A[0], 0))
+        K.forward(q, **kw)
+        torch.cuda.synchronize()
+        pose_d = [p.clone() for p in pose]
+        pose_d[0][:, 9:] += torch.as_tensor([0.04, 0.03, 0.03], **f64)
+        pose_d[1][:, 9:] += torch.as_tensor([0.04, -0.03, 0.03], **f64)
+        com_d = com.clone(); com_d[:, 0] += 0.02
+        qmin = torch.full((B, n), -2.5, **f64); qmax = torch.full((B, n), 2.5, **f64)
+        qdot_max = torch.full((B, n), 2.0, **f64)
+        leaf = {"B": B, "task": [[(com, com_d, None)], [(pose[f], pose_d[f], None) for f in range(4)], [(q, q.clone(), None)]],
+                "bound": [(q, qmin, qmax), (qdot_max, None, None)], "rows": [(Crow, rlo, rup)] if with_rows else []}
+        return st, q, pose, com, kw, leaf
+
+    a = make()
+    b = make()
+    sta, qa, posea, coma, kwa, leafa = a
+    stb, qb, poseb, comb, kwb, leafb = b
+    kb = K.batch_args(qb, **kwb)
+    for step in range(25):
+        K.forward(qa, **kwa)
+        sta.cycle(leafa)
+        qa += sta.dq[:B]
+        stb.control_cycle(K, kb, leafb, q_integrate=qb)
+    torch.cuda.synchronize()
+    assert (sta.status[:B] == 0).all() and (stb.status[:B] == 0).all()
+    assert torch.equal(qa, qb) and torch.equal(sta.dq[:B], stb.dq[:B])
+    assert torch.equal(coma, comb) and all(torch.equal(posea[f], poseb[f]) for f in range(4))
+    for k in range(2):
+        assert torch.equal(sta.A[k][:B], stb.A[k][:B]) and torch.equal(sta.b[k][:B], stb.b[k][:B])
+    assert torch.equal(sta.l[:B], stb.l[:B]) and torch.equal(sta.u[:B], stb.u[:B])
+    assert float(sta.dq[:B].abs().max()) > 1e-4            # (the loop is still moving: the comparison is not of zeros)
+    # what the fused launch refuses, with a message: a model of another size, the hot start
+    import ctypes as C
+    stb.set_hotstart(True)
+    with pytest.raises(RuntimeError, match="fused control cycle"):
+        stb.control_cycle(K, kb, leafb, q_integrate=qb)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("front_end", ["iHQP", "eHQP", "nHQP"])
 def test_closed_loop_ik_coman35(front_end, gpu_device):
     """the reference's own robot and stack -- examples/cpp/coman_ik.cpp:425-449: 35 coordinates,
