@@ -628,13 +628,13 @@ def time_nhqp(B, device, steps=5, warmup=2):
     ok = int((st.status[:B] == 0).sum().item())
     return {"workload": "BASELINE configs[2] stack through the reference's null-space front-end (nHQP.cpp:155-204; defaults: A/b "
                         "regularisation at 0.05 sv_max, selective null-space regularisation): per level an SVD of A N (Gram-side "
-                        "tridiagonalisation + implicit QL in LDS), the QP in the nf = 32 / 29 / 5 free coordinates, q += N z, N <- N V2; three launches per level",
+                        "tridiagonalisation, eigenvalues by Sturm bisection, vectors by twisted factorisation, in LDS), the QP in the nf = 32 / 29 / 5 free coordinates, q += N z, N <- N V2; three launches per level",
             "batch": B, "value": B * steps / el, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "solved_ok": f"{ok}/{B}",
             "roofline": hbm_roofline(algo_bytes_per_solve(plan), B, 1e3 * el / steps,
                                      [("osot_update_kernel", B, 1), ("osot_nhqp_prepare_kernel<32>", B, plan.L),
                                       ("osot_qp_kernel<32>", B, plan.L), ("osot_nhqp_accumulate_kernel", B, plan.L)],
                                      "osot_nhqp_prepare_kernel<32> + osot_qp_kernel<32> + osot_nhqp_accumulate_kernel per level (far from "
-                                     "both roofs: the scalar QL recurrence of the per-level eigen-decomposition and nine dependent launches)")}
+                                     "both roofs: the level preparation is one wavefront's dependent instruction stream at six wavefronts per CU -- LDS-limited -- and there are nine dependent launches)")}
 
 
 def time_ehqp(B, device, steps=10, warmup=3):
