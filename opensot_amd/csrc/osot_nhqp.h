@@ -1379,7 +1379,17 @@ __global__ void __launch_bounds__(64) osot_nhqp_accumulate_kernel(const DevNhqpA
     double acc = 0.0;
     if (c < n) {
         if (Q.first) acc = (h == 0) ? z[c] : 0.0;
-        else for (int j = h; j < nf; j += hv) acc = fma(Ng[c * n + j], z[j], acc);
+        else {
+            // (eight products per trip with their sixteen loads in flight together, clamped addresses and masked terms: element by
+            //  element every multiply-add waited for its own HBM / L2 round trip -- 43 us of the level-1 accumulation at config 3)
+            for (int j0 = h; j0 < nf; j0 += 8 * hv) {
+                double a[8], b[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int j = j0 + hv * u, jc = (j < nf) ? j : nf - 1; a[u] = Ng[c * n + jc]; b[u] = z[jc]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = fma((j0 + hv * u < nf) ? a[u] : 0.0, b[u], acc);
+            }
+        }
     }
     if (!wide) acc = halfsum<32>(acc);
     const double qn = (Q.first ? 0.0 : ((c < n) ? Q.q0[inst * n + c] : 0.0)) + acc;
@@ -1393,7 +1403,15 @@ __global__ void __launch_bounds__(64) osot_nhqp_accumulate_kernel(const DevNhqpA
             const int i = e / ns, t = e - i * ns;
             double a2 = 0.0;
             if (Q.first) a2 = (i < nf) ? Vg[i * n + t] : 0.0;
-            else for (int j = 0; j < nf; ++j) a2 = fma(Ng[i * n + j], Vg[j * n + t], a2);
+            else {
+                for (int j0 = 0; j0 < nf; j0 += 8) {
+                    double a[8], b[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { const int j = j0 + u, jc = (j < nf) ? j : nf - 1; a[u] = Ng[i * n + jc]; b[u] = Vg[jc * n + t]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) a2 = fma((j0 + u < nf) ? a[u] : 0.0, b[u], a2);
+                }
+            }
             Nn[i * n + t] = a2;
         }
     }
