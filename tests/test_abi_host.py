@@ -110,6 +110,13 @@ def test_backend_argument_checks_without_gpu(lib):
     assert lib.osot_backend_destroy(h) == abi.OK
 
 
+def test_control_cycle_argument_checks_without_gpu(lib):
+    """osot_control_cycle (round 4) refuses null arguments before it touches a device"""
+    kb, lb, out, qb = abi.KinBatch(), abi.LeafBatch(), abi.AssembledOut(), abi.QpBatch()
+    assert lib.osot_control_cycle(None, None, C.byref(kb), C.byref(lb), C.byref(out), C.byref(qb), None, None) == abi.ERR_INVALID
+    assert b"null argument" in lib.osot_last_error()
+
+
 def test_eps_factor_convention():
     assert eps_abs_from_factor(1.0) == pytest.approx(2.221e-13)
     assert eps_abs_from_factor(2e2) == pytest.approx(4.442e-11)   # iHQP default (iHQP.h:32)
