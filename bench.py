@@ -360,7 +360,7 @@ def coman_stack(which, n):
     return StackPlan(n=n, levels=levels, bounds=bounds, rowblocks=rows, eps_abs=eps_abs_from_factor(1e6))
 
 
-def time_coman35(which, B, device, steps=20, warmup=5, front_end="iHQP"):
+def time_coman35(which, B, device, steps=20, warmup=5, front_end="iHQP", specialise=True):
     """the reference example's control loop (coman_ik.cpp:174-219) for B robots, everything resident: q -> frame poses, Jacobians,
     CoM (osot_kinematics, rows written straight into A_k / C) -> AutoStack::update + Solver::solve (one fused launch; nHQP: update +
     osot_nhqp_solve) -> q += dq.  Each robot chases its own random wrist goals (+-0.2 m, as the reference's harness draws them), so
@@ -382,6 +382,8 @@ def time_coman35(which, B, device, steps=20, warmup=5, front_end="iHQP"):
     q0[:, 6:] += rng.normal(0.0, 0.02, (B, n - 6))
     q0 = np.clip(q0, np.maximum(lo, -10.0) + 1e-3, np.minimum(up, 10.0) - 1e-3)
     st = BatchedStack(plan, B, device=device, want_levels=False)
+    if not specialise:
+        st.set_specialisation(False)
     K = kin.Kinematics(m, device=device)
     q = torch.as_tensor(q0, **f64).contiguous()
     pose = [torch.zeros((B, 12), **f64) for _ in range(4)]

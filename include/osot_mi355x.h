@@ -351,7 +351,10 @@ int osot_solver_set_schedule(osot_solver* s, int mode);
 int osot_solver_set_hotstart(osot_solver* s, int enabled);
 /* Kernel instantiation by plan structure.  enabled != 0 (default): a plan WITHOUT constraint rows (the bounds l <= x <= u are
  * its only inequalities: a velocity stack with joint / velocity limits, BASELINE configs 2 and 3) of at most 32 variables runs
- * the instantiation of the cascade that carries no constraint-row code (row classification, row scans, row normals);
+ * the instantiation of the cascade that carries no constraint-row code (row classification, row scans, row normals) -- and so
+ * does, at every size up to 64 variables, a plan whose constraint rows are all TaskToConstraint blocks with a point band
+ * (OSOT_ROWS_TASK_* with err_lb == err_ub: `stack << l_sole`, the feet of the reference's COMAN stacks,
+ * examples/cpp/coman_ik.cpp:425-449): those rows are equalities of every level, the bounds stay the only inequalities;
  * 0: every plan runs the general instantiation.  The two are the same arithmetic in the same order: results are bit-identical
  * (tests/test_gpu_cascade.py), only the speed differs.  (The reference has nothing to mirror here: it is how one BackEnd
  * covers plans of different shape without paying for the features a plan does not use.) */

@@ -47,6 +47,19 @@ inline int plan_constraint_rows(const osot_plan_desc* p, int* nc) {
 inline bool rows_are_implicit(int kind) {
     return kind == OSOT_ROWS_ACC_JOINT_LIMITS || kind == OSOT_ROWS_ACC_VELOCITY_LIMITS || kind == OSOT_ROWS_UNIT_GENERIC;
 }
+// every constraint row of the plan is an EQUALITY by construction: TaskToConstraint blocks (`stack << l_sole`,
+// TaskToConstraint.cpp:34-52) whose error band is a point -- the update writes lo = b + err_lb and up = b + err_ub, bit-equal
+// then.  Such rows live in the equality phase of every level; the bounds are the only inequalities, which is what the BOX
+// instantiation of the kernels assumes (a plan without rows is the trivial case).
+inline bool plan_rows_all_equalities(const osot_plan_desc& p) {
+    for (int j = 0; j < p.n_rowblocks; ++j) {
+        const osot_rows_desc& rb = p.rowblock[j];
+        if (rb.kind != OSOT_ROWS_TASK_CARTESIAN && rb.kind != OSOT_ROWS_TASK_COM) return false;
+        for (int i = 0; i < rb.rows && i < OSOT_MAX_BAND_ROWS; ++i)
+            if (!(rb.err_lb[i] == rb.err_ub[i])) return false;
+    }
+    return true;
+}
 inline int plan_stored_constraint_rows(const osot_plan_desc* p, int* nc_stored) {
     if (!p) return OSOT_ERR_INVALID;
     int s = 0;

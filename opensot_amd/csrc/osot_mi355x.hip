@@ -204,6 +204,10 @@ int osot_solver_create(const osot_plan_desc* plan, int max_batch, int device, os
         if (r == OSOT_OK) r = ensure_lds(osot_cycle_kernel<NP, false>, lds);
         if (r == OSOT_OK) r = ensure_lds(osot_cycle_kernel<NP, true>, lds);
         if (r == OSOT_OK) r = ensure_lds(osot_cascade_kernel<NP, false, true>, lds);
+        if constexpr (NP != 32) {
+            if (r == OSOT_OK) r = ensure_lds(osot_cascade_kernel<NP, false, false, true>, lds);
+            if (r == OSOT_OK) r = ensure_lds(osot_cycle_kernel<NP, false, true>, lds);
+        }
         if constexpr (NP == 32) {
             if (r == OSOT_OK) r = ensure_lds(osot_cascade_kernel<32, false, false, true>, lds);
             if (r == OSOT_OK) r = ensure_lds(osot_cycle_kernel<32, false, true>, lds);
@@ -550,7 +554,9 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
         if (force && force[0] == '1' && !prof) extra = true;
     }   // (hot start: the EXTRA instantiation carries its code; never together with prof, see D.hot)
     // plans without constraint rows (the bounds are the only inequalities): the BOX instantiation of the 32-column kernels
-    const bool box = s->specialise && !extra && P.nc == 0 && T == 32;
+    // ... and plans whose rows are all equalities by construction (the feet as TaskToConstraint rows: the reference's COMAN stacks), at
+    // every size
+    const bool box = s->specialise && !extra && (P.nc == 0 ? T == 32 : plan_rows_all_equalities(pl));
     if (control && (extra || prof || !fused))
         return fail(OSOT_ERR_UNSUPPORTED, "the fused control cycle carries no dense-weight / inactive-task / hot-start / profiling code (use osot_kinematics + osot_cycle)");
     by_np(T, [&](auto np) {
@@ -565,6 +571,13 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
                 if (fused) hipLaunchKernelGGL((osot_cycle_kernel<32, false, true>), dim3(grid), dim3(64), lds, st, *fused, P, D);
                 else if (prof) hipLaunchKernelGGL((osot_cascade_kernel<32, true, false, true>), dim3(grid), dim3(64), lds, st, P, D);
                 else hipLaunchKernelGGL((osot_cascade_kernel<32, false, false, true>), dim3(grid), dim3(64), lds, st, P, D);
+                return 0;
+            }
+        }
+        if constexpr (NP != 32) {
+            if (box && !prof) {
+                if (fused) hipLaunchKernelGGL((osot_cycle_kernel<NP, false, true>), dim3(grid), dim3(64), lds, st, *fused, P, D);
+                else hipLaunchKernelGGL((osot_cascade_kernel<NP, false, false, true>), dim3(grid), dim3(64), lds, st, P, D);
                 return 0;
             }
         }

@@ -543,3 +543,50 @@ def test_box_instantiation_matches_the_general_one(cfg, monkeypatch):
     ref = po.ihqp_solve_batch(asm, po.BE_EIQP_EQ, nthreads=1)
     ok = ref["status"] == 1
     assert ok.all() and np.abs(box[0] - ref["dq"]).max() < 1e-8
+
+
+@pytest.mark.parametrize("n", [32, 40])
+def test_box_instantiation_for_rows_that_are_all_equalities(n, monkeypatch):
+    """round 4: a plan whose constraint rows are all TaskToConstraint blocks with a POINT band (`stack << l_sole` with
+    err_lb = err_ub: the reference's COMAN stacks, coman_ik.cpp:425-449) has no inequality but the bounds, whatever its size:
+    the rows are equalities of every level (the update writes lo = b + err_lb, up = b + err_ub: bit-equal), so it runs the
+    BOX instantiation too (32-, 56- and 64-lane kernels).  On the emulator: bit-identical to the general instantiation, and
+    the rows hold in the answer; a block with a real band keeps the plan on the general path."""
+    from opensot_amd import abi
+    from opensot_amd.plan import Rows, StackPlan
+    B = 12
+    if n == 32:
+        plan, leaf = synth.make_velocity_stack("C3", B, seed=91)
+    else:
+        plan, leaf = synth.make_generic_stack(B, n, [6, 12, 8], n_eq=0, n_ineq=0, seed=92, box=0.4)
+    rng = np.random.default_rng(5)
+    J = rng.normal(0.0, 0.3, size=(B, 3, n))
+    pa = rng.uniform(-0.2, 0.2, size=(B, 3))
+    pd = pa + rng.uniform(-0.01, 0.01, size=(B, 3))
+
+    def with_rows(band):
+        rb = Rows(abi.ROWS_TASK_COM, 3, lam=0.1, err_lb=-band, err_ub=band, name="com_rows")
+        pl = StackPlan(n=plan.n, levels=plan.levels, bounds=plan.bounds, rowblocks=list(plan.rowblocks) + [rb], eps_abs=plan.eps_abs)
+        lf = dict(leaf)
+        lf["rows"] = list(leaf.get("rows", [])) + [(pa, pd, None)]
+        lf["C"] = list(leaf.get("C", [])) + [J]
+        return pl, lf
+
+    po = pyoracle
+    pl, lf = with_rows(0.0)
+    asm = po.assemble(pl, lf)
+    assert np.array_equal(asm["lo"], asm["up"])
+    full = emu_cascade(pl, asm)
+    assert not emu_cascade.ran_box
+    monkeypatch.setenv("OSOT_EMU_BOX", "1")
+    box = emu_cascade(pl, asm)
+    assert emu_cascade.ran_box
+    for a, b in zip(full, box):
+        assert np.array_equal(a, b)
+    assert (box[2] == 0).all()
+    res = np.einsum("bij,bj->bi", asm["C"], box[0]) - asm["lo"]
+    assert np.abs(res).max() < 1e-9
+    pl2, lf2 = with_rows(0.01)                     # a real band: inequalities -> the general instantiation, knob or not
+    emu_cascade(pl2, po.assemble(pl2, lf2))
+    assert not emu_cascade.ran_box
+

@@ -516,3 +516,46 @@ def test_box_instantiation_is_bit_identical_gpu(gpu_device, cfg, B):
             st.cycle(st.load_leaf(lf))
         torch.cuda.synchronize()
         assert torch.equal(spec.dq[:B], gen.dq[:B]) and torch.equal(spec.iterations[:B], gen.iterations[:B])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,B", [(32, 300), (40, 260)])
+def test_box_instantiation_for_equality_rows_is_bit_identical_gpu(gpu_device, n, B):
+    """round 4: plans whose constraint rows are all TaskToConstraint blocks with a point band (the reference's COMAN stacks:
+    the feet as `stack << l_sole`, coman_ik.cpp:425-449) run the BOX instantiation at every size -- the rows are equalities of
+    every level, the bounds the only inequalities.  Bit-identical to the general instantiation (dq, every level's x, status,
+    iteration counts) through osot_ihqp_solve and osot_cycle, over drifting cycles, 32-lane and 56-lane kernels; the rows hold
+    in the answer."""
+    from opensot_amd import abi
+    from opensot_amd.plan import Rows, StackPlan
+    if n == 32:
+        plan, leaf = synth.make_velocity_stack("C3", B, seed=6001)
+    else:
+        plan, leaf = synth.make_generic_stack(B, n, [6, 12, 8], n_eq=0, n_ineq=0, seed=6002, box=0.4)
+    rng = np.random.default_rng(8)
+    J = rng.normal(0.0, 0.3, size=(B, 3, n))
+    pa = rng.uniform(-0.2, 0.2, size=(B, 3))
+    rb = Rows(abi.ROWS_TASK_COM, 3, lam=0.1, err_lb=0.0, err_ub=0.0, name="com_rows")
+    plan = StackPlan(n=plan.n, levels=plan.levels, bounds=plan.bounds, rowblocks=list(plan.rowblocks) + [rb], eps_abs=plan.eps_abs)
+    leaf = dict(leaf)
+    leaf["rows"] = list(leaf.get("rows", [])) + [(pa, pa + rng.uniform(-0.01, 0.01, size=(B, 3)), None)]
+    leaf["C"] = list(leaf.get("C", [])) + [J]
+    leaves = [leaf, synth.perturb(leaf, rng, 0.01), synth.perturb(leaf, rng, 0.05)]
+    spec = BatchedStack(plan, B, device=0, want_levels=True)
+    gen = BatchedStack(plan, B, device=0, want_levels=True)
+    gen.set_specialisation(False)
+    for lf in leaves:
+        for st in (spec, gen):
+            st.update(st.load_leaf(lf)); st.solve(B)
+        torch.cuda.synchronize()
+        assert (spec.status[:B] == 0).all()
+        assert torch.equal(spec.dq[:B], gen.dq[:B])
+        assert torch.equal(spec.x_levels[:B], gen.x_levels[:B])
+        assert torch.equal(spec.status[:B], gen.status[:B]) and torch.equal(spec.iterations[:B], gen.iterations[:B])
+        res = torch.einsum("bij,bj->bi", spec.C[:B], spec.dq[:B]) - spec.lo[:B]
+        assert torch.equal(spec.lo[:B], spec.up[:B]) and float(res.abs().max()) < 1e-9
+        for st in (spec, gen):
+            st.cycle(st.load_leaf(lf))
+        torch.cuda.synchronize()
+        assert torch.equal(spec.dq[:B], gen.dq[:B]) and torch.equal(spec.iterations[:B], gen.iterations[:B])
+
