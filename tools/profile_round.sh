@@ -8,7 +8,7 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-python $GRAFT_REPO_ROOT/bench.py > $OUT/bench_line.json 2> $OUT/bench_stderr.txt
+T0=$(date +%s); python $GRAFT_REPO_ROOT/bench.py > $OUT/bench_line.json 2> $OUT/bench_stderr.txt; echo "default bench.py run: $(( $(date +%s) - T0 )) s" > $OUT/bench_wall_seconds.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/bench_line_under_rocprof.json 2>> $OUT/bench_stderr.txt
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 i=0
