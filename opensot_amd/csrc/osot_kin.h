@@ -26,7 +26,32 @@ struct DevKin {            // osot_kin_desc + ancestor masks, in device memory
     unsigned long long anc[OSOT_KIN_MAX_JOINTS];   // bit a set: joint a is an ancestor of (or is) joint j
     unsigned long long sub[OSOT_KIN_MAX_JOINTS];   // bit l set: link l is moved by joint j (j itself included)
     double total_mass;
+    // depth-first (pre-order) position of every joint: the links a joint moves are the positions dfs_pos[j] .. sub_end[j] - 1, so a
+    // subtree aggregate is a DIFFERENCE OF PREFIX SUMS over that order (the centre-of-mass Jacobian, stage 4)
+    int dfs_pos[OSOT_KIN_MAX_JOINTS];
+    int sub_end[OSOT_KIN_MAX_JOINTS];
 };
+
+// the tables derived from the tree (h.d set, parent[j] < j checked by the caller): shared by osot_kin_create and the emulator's driver
+inline void kin_build_tables(DevKin& h) {
+    const int n = h.d.n;
+    h.total_mass = 0.0;
+    for (int j = 0; j < OSOT_KIN_MAX_JOINTS; ++j) { h.anc[j] = 0ull; h.sub[j] = 0ull; h.dfs_pos[j] = j; h.sub_end[j] = j + 1; }
+    for (int j = 0; j < n; ++j) {
+        h.anc[j] = (1ull << j) | (h.d.parent[j] >= 0 ? h.anc[h.d.parent[j]] : 0ull);
+        for (int a = 0; a <= j; ++a) if ((h.anc[j] >> a) & 1ull) h.sub[a] |= (1ull << j);
+        h.total_mass += h.d.mass[j];
+    }
+    if (!(h.total_mass > 0.0)) h.total_mass = 1.0;
+    int next_child[OSOT_KIN_MAX_JOINTS], root_off = 0;      // parents come before their children: one pass
+    for (int j = 0; j < n; ++j) {
+        const int size = __builtin_popcountll(h.sub[j]), pa = h.d.parent[j];
+        if (pa < 0) { h.dfs_pos[j] = root_off; root_off += size; }
+        else { h.dfs_pos[j] = next_child[pa]; next_child[pa] += size; }
+        next_child[j] = h.dfs_pos[j] + 1;
+        h.sub_end[j] = h.dfs_pos[j] + size;
+    }
+}
 
 __device__ __forceinline__ void mat3_mul(const double* A, const double* B, double* C) {
 #pragma unroll
@@ -136,7 +161,7 @@ __device__ inline void closest_segment_box(const double* p0, const double* p1, c
 // LDS one instance of kin_instance needs, in doubles (the int / 64-bit tables included): transforms, axes, centres of mass, parents,
 // ancestor masks -- and the pair table of the PAIRS instantiation
 template <int JMAX> constexpr int kin_lds_doubles(bool pairs) {
-    return JMAX * OSOT_KIN_TS + JMAX * 3 + JMAX * 4 + (JMAX + 1) / 2 + JMAX + OSOT_KIN_MAX_FRAMES * 13 + (pairs ? OSOT_KIN_MAX_PAIRS * 9 : 0);
+    return JMAX * OSOT_KIN_TS + JMAX * 3 + JMAX * 4 + (JMAX + 1) / 2 + JMAX + OSOT_KIN_MAX_FRAMES * (14 + 1) + (pairs ? OSOT_KIN_MAX_PAIRS * 9 : 0);
 }
 // The kinematics of ONE instance by the JMAX lanes j = 0 .. JMAX - 1 that call it together (lane = joint; the reductions are
 // colsum<JMAX>).  `lds` = kin_lds_doubles<JMAX>(PAIRS) doubles of this instance's own.  The kernel below calls it for one instance
@@ -161,8 +186,9 @@ __device__ __forceinline__ void kin_instance(const DevKin* __restrict__ K, const
     double* Cw = Zw + JMAX * 3;                           // world link centres of mass, mass
     unsigned long long* Anc = reinterpret_cast<unsigned long long*>(Cw + JMAX * 4);   // ancestor masks
     int* Par = reinterpret_cast<int*>(Anc + JMAX);        // parent indices (the chain walk must not chase pointers through HBM)
-    double* Fw = reinterpret_cast<double*>(Par + 2 * ((JMAX + 1) / 2));               // per frame: world [R | p] and its joint
-    double* Pw = Fw + OSOT_KIN_MAX_FRAMES * 13;                                       // per pair: normal n, axis points c_a, c_b (world)
+    double* Fw = reinterpret_cast<double*>(Par + 2 * ((JMAX + 1) / 2));               // per frame: world [R | p], its joint, body flag
+    unsigned long long* Fq = reinterpret_cast<unsigned long long*>(Fw + OSOT_KIN_MAX_FRAMES * 14);   // ... column mask
+    double* Pw = reinterpret_cast<double*>(Fq + OSOT_KIN_MAX_FRAMES);                 // per pair: normal n, axis points c_a, c_b (world)
     (void)Pw;
 #ifdef OSOT_KIN_PHASES
     long long kph_ = (long long)clock64();
@@ -176,7 +202,7 @@ __device__ __forceinline__ void kin_instance(const DevKin* __restrict__ K, const
     const int jc = (j < n) ? j : 0;
     const double qj = Bt.q[(live ? inst : 0) * n + jc];
     const int type_j = K->d.type[jc];
-    const unsigned long long sub_j = K->sub[jc];
+    const int dfs_j = K->dfs_pos[jc], end_j = K->sub_end[jc];
     double R0[9], ax[3], p0j[3], comj[3];
 #pragma unroll
     for (int i = 0; i < 9; ++i) R0[i] = K->d.R0[jc][i];
@@ -261,10 +287,13 @@ __device__ __forceinline__ void kin_instance(const DevKin* __restrict__ K, const
 #pragma unroll
             for (int i = 0; i < 3; ++i) Tw[j * TS + 9 + i] = pw[i];
         }
-        // (links beyond n: zero mass at the origin -- the fixed-trip sums below read all JMAX entries)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { Zw[j * 3 + i] = valid ? z[i] : 0.0; Cw[j * 4 + i] = valid ? cl[i] + pw[i] : 0.0; zj[i] = valid ? z[i] : 0.0; }
-        Cw[j * 4 + 3] = valid ? mass_j : 0.0;
+        for (int i = 0; i < 3; ++i) { Zw[j * 3 + i] = valid ? z[i] : 0.0; zj[i] = valid ? z[i] : 0.0; }
+        // m_j [c_j, 1] at the joint's depth-first position (joints beyond n: zeros at their own index, which no joint below n has)
+        const int pos = valid ? dfs_j : j;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Cw[pos * 4 + i] = valid ? mass_j * (cl[i] + pw[i]) : 0.0;
+        Cw[pos * 4 + 3] = valid ? mass_j : 0.0;
     }
     const bool revolute = valid && type_j == OSOT_JOINT_REVOLUTE;
     // ---- 3a. world frames, lane = frame: the frame's joint, offset and options in one batch of loads per lane, [R | p] and the joint
@@ -278,6 +307,8 @@ __device__ __forceinline__ void kin_instance(const DevKin* __restrict__ K, const
         for (int i = 0; i < 9; ++i) FR[i] = K->d.frame_R[f][i];
 #pragma unroll
         for (int i = 0; i < 3; ++i) Fp[i] = K->d.frame_p[f][i];
+        const int body_f = K->d.frame_body[f];
+        const unsigned long long cm_f = K->d.frame_col_mask[f];   // Task::applyActiveJointsMask (Task.h:129-139)
         double* pose_out = nullptr;        // (a select chain: a lane-indexed read of the argument struct would be served from a scratch copy)
 #pragma unroll
         for (int ff = 0; ff < OSOT_KIN_MAX_FRAMES; ++ff) pose_out = (f == ff) ? Bt.frame_pose[ff] : pose_out;
@@ -291,10 +322,12 @@ __device__ __forceinline__ void kin_instance(const DevKin* __restrict__ K, const
         mat3_vec(Rj, Fp, t);
         if (j < nfr) {
 #pragma unroll
-            for (int i = 0; i < 9; ++i) Fw[j * 13 + i] = Rf[i];
+            for (int i = 0; i < 9; ++i) Fw[j * 14 + i] = Rf[i];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) Fw[j * 13 + 9 + i] = pj[i] + t[i];
-            Fw[j * 13 + 12] = (double)jf;
+            for (int i = 0; i < 3; ++i) Fw[j * 14 + 9 + i] = pj[i] + t[i];
+            Fw[j * 14 + 12] = (double)jf;
+            Fw[j * 14 + 13] = (double)body_f;
+            Fq[j] = cm_f;
             if (pose_out && live) {
 #pragma unroll
                 for (int i = 0; i < 9; ++i) pose_out[inst * 12 + i] = Rf[i];
@@ -306,18 +339,21 @@ __device__ __forceinline__ void kin_instance(const DevKin* __restrict__ K, const
     }
     KIN_PHASE("world");
     // ---- 3. frames: the Jacobian columns, lane = joint
+    // (a frame's transform and options come from the LDS table in one batch of reads -- fetched from the model here, every frame started
+    //  behind a round trip of scalar loads; the row address stays a scalar load of the argument struct: through LDS it became a
+    //  per-lane address and the six stores paid for it, 2.9 k -> 3.4 k clocks)
     for (int f = 0; f < nfr; ++f) {
-        double* Jf = Bt.frame_J[f];
-        if (!Jf) continue;
-        const long long jstride = Bt.frame_J_stride[f];
-        const int body = K->d.frame_body[f];
-        const unsigned long long cm = K->d.frame_col_mask[f];   // Task::applyActiveJointsMask (Task.h:129-139)
         double Rf[9], pf[3];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) Rf[i] = Fw[f * 13 + i];
+        for (int i = 0; i < 9; ++i) Rf[i] = Fw[f * 14 + i];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) pf[i] = Fw[f * 13 + 9 + i];
-        const int jf = (int)Fw[f * 13 + 12];
+        for (int i = 0; i < 3; ++i) pf[i] = Fw[f * 14 + 9 + i];
+        const int jf = (int)Fw[f * 14 + 12];
+        const bool body = Fw[f * 14 + 13] != 0.0;
+        const unsigned long long cm = Fq[f];
+        double* Jf = Bt.frame_J[f];                      // (the argument struct: scalar loads, a uniform base address for the stores)
+        if (!Jf) continue;
+        const long long jstride = Bt.frame_J_stride[f];
         if (valid) {
             double col[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             if ((Anc[jf] >> j) & 1ull) {
@@ -349,27 +385,41 @@ __device__ __forceinline__ void kin_instance(const DevKin* __restrict__ K, const
     // ---- 4. centre of mass and its Jacobian
     if (Bt.com || Bt.com_J) {
         const double iM = fast_rcp(K->total_mass);       // (one reciprocal instead of six fp64 divisions)
-        if (Bt.com) {
-            const double mj = valid ? Cw[j * 4 + 3] : 0.0;
-            double c3[3];
+        // Inclusive prefix sums of m_l [c_l, 1] over the depth-first order (written there by the world stage), lane = position:
+        // log2(JMAX) rounds of "read the entry d positions back, add, write".  The links joint j moves are a contiguous range of that
+        // order, so S_j = P[sub_end_j - 1] - P[dfs_j - 1]; the total is the last entry (positions beyond n hold zeros).
+        // (the 0/1 matrix-vector product this replaces read all 4 JMAX entries per lane: 4.4 k of the producer's 15.9 k clocks)
+        double a[4];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) c3[i] = colsum<JMAX>(valid ? mj * Cw[j * 4 + i] : 0.0) * iM;
-            if (j < 3 && live) Bt.com[inst * 3 + j] = c3[(j == 0) ? 0 : ((j == 1) ? 1 : 2)];
+        for (int i = 0; i < 4; ++i) a[i] = Cw[j * 4 + i];
+#pragma unroll
+        for (int d = 1; d < JMAX; d <<= 1) {
+            double t[4];
+            const int src = (j >= d) ? j - d : 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t[i] = Cw[src * 4 + i];
+            wave_sync();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] += (j >= d) ? t[i] : 0.0; Cw[j * 4 + i] = a[i]; }
+            wave_sync();
+        }
+        if (Bt.com) {
+            const int i3 = (j < 3) ? j : 0;
+            const double tot = Cw[(JMAX - 1) * 4 + i3];
+            if (j < 3 && live) Bt.com[inst * 3 + j] = tot * iM;
         }
         if (Bt.com_J) {
-            // subtree aggregates S_j = sum over the links l that joint j moves of m_l [c_l, 1]: a 0/1 matrix-vector
-            // product with the link values read at UNIFORM addresses (LDS broadcast), no divergence; then
             // column j = z_j x (Sc_j - Sm_j p_j) / M  (revolute)   or   (Sm_j / M) z_j  (prismatic)
-            // (a fixed trip count: the 4 JMAX reads are in flight together -- link by link it was one LDS round trip per link; links
-            //  beyond n are zeros)
-            const unsigned long long mine = valid ? sub_j : 0ull;
-            double sc[3] = {0.0, 0.0, 0.0}, sm = 0.0;
+            const int hi = valid ? end_j - 1 : 0, lo = (valid && dfs_j > 0) ? dfs_j - 1 : 0;
+            double sc[3], sm;
+            {
+                double ph[4], pl[4];
 #pragma unroll
-            for (int l = 0; l < JMAX; ++l) {
-                const double cm_l = Cw[l * 4 + 3];
-                const double ml = ((mine >> l) & 1ull) ? cm_l : 0.0;
-                sc[0] = fma(ml, Cw[l * 4], sc[0]); sc[1] = fma(ml, Cw[l * 4 + 1], sc[1]); sc[2] = fma(ml, Cw[l * 4 + 2], sc[2]);
-                sm += ml;
+                for (int i = 0; i < 4; ++i) { ph[i] = Cw[hi * 4 + i]; pl[i] = Cw[lo * 4 + i]; }
+                const bool from0 = !(valid && dfs_j > 0);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) sc[i] = ph[i] - (from0 ? 0.0 : pl[i]);
+                sm = ph[3] - (from0 ? 0.0 : pl[3]);
             }
             double acc[3];
             if (revolute) {

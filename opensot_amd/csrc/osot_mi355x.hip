@@ -951,10 +951,8 @@ int osot_kin_create(const osot_kin_desc* d, int device, osot_kin** out) {
     for (int j = 0; j < d->n; ++j) {
         if (d->parent[j] >= j || d->parent[j] < -1) return fail(OSOT_ERR_INVALID, "joints must be in tree order (parent[j] < j)");
         if (d->type[j] != OSOT_JOINT_REVOLUTE && d->type[j] != OSOT_JOINT_PRISMATIC) return fail(OSOT_ERR_INVALID, "unknown joint type");
-        h.anc[j] = (1ull << j) | (d->parent[j] >= 0 ? h.anc[d->parent[j]] : 0ull);
-        for (int a = 0; a <= j; ++a) if ((h.anc[j] >> a) & 1ull) h.sub[a] |= (1ull << j);
-        h.total_mass += d->mass[j];
     }
+    kin_build_tables(h);
     for (int f = 0; f < d->n_frames; ++f)
         if (d->frame_joint[f] < 0 || d->frame_joint[f] >= d->n) return fail(OSOT_ERR_INVALID, "frame attached to a joint out of range");
     if (d->n_pairs < 0 || d->n_pairs > OSOT_KIN_MAX_PAIRS) return fail(OSOT_ERR_INVALID, "collision pair count out of range");
@@ -970,7 +968,6 @@ int osot_kin_create(const osot_kin_desc* d, int device, osot_kin** out) {
         if (d->pair_kind[p] == OSOT_SHAPE_BOX)
             for (int i = 0; i < 3; ++i) if (!(d->pair_box[p][i] > 0.0)) return fail(OSOT_ERR_INVALID, "box half extents must be positive");
     }
-    if (!(h.total_mass > 0.0)) h.total_mass = 1.0;
     DeviceGuard guard(device);
     if (!guard.ok) return fail(OSOT_ERR_HIP, "hipSetDevice failed");
     osot_kin* k = new osot_kin();

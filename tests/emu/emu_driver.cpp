@@ -172,13 +172,8 @@ extern "C" __attribute__((visibility("default"))) int emu_kinematics(const osot_
     static DevKin h;
     memset(&h, 0, sizeof(h));
     h.d = *d;
-    for (int j = 0; j < d->n; ++j) {
-        if (d->parent[j] >= j) return OSOT_ERR_INVALID;
-        h.anc[j] = (1ull << j) | (d->parent[j] >= 0 ? h.anc[d->parent[j]] : 0ull);
-        for (int a = 0; a <= j; ++a) if ((h.anc[j] >> a) & 1ull) h.sub[a] |= (1ull << j);
-        h.total_mass += d->mass[j];
-    }
-    if (!(h.total_mass > 0.0)) h.total_mass = 1.0;
+    for (int j = 0; j < d->n; ++j) if (d->parent[j] >= j) return OSOT_ERR_INVALID;
+    kin_build_tables(h);
     const bool pairs = d->n_pairs > 0 && (b->pair_dist || b->pair_J);
     if (d->n <= 32) {
         if (pairs) emu::launch(osot_kin_kernel<true, 32>, (unsigned)((b->B + 1) / 2), 0, 64, (const DevKin*)&h, *b);
