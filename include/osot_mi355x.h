@@ -365,8 +365,10 @@ int osot_solver_set_specialisation(osot_solver* s, int enabled);
 int osot_solver_resident_waves(osot_solver* s, int* waves);
 /* Task::setActive (include/OpenSoT/Task.h:232-239, 375-400): an inactive task's A is zero -- it adds nothing to H and g
  * of its level and its optimality rows are void for the levels below.  The producer's Jacobian rows stay untouched in
- * A_k; the cascade ignores them.  Takes effect at the next osot_ihqp_solve.  (Column masks, Task::setActiveJointsMask,
- * are the producer's: osot_kin_desc.frame_col_mask.) */
+ * A_k; the cascade ignores them.  Takes effect at the next osot_ihqp_solve / osot_cycle / osot_ehqp_solve (the equality-only
+ * front-end gives the task's rows weight zero, i.e. treats the task as absent; a task beyond row 64 of its level is refused
+ * there).  osot_nhqp_solve does not take inactive tasks.  (Column masks, Task::setActiveJointsMask, are the producer's:
+ * osot_kin_desc.frame_col_mask.) */
 int osot_solver_set_task_active(osot_solver* s, int level, int task, int active);
 /* diagnostic: run the cascade once through the instrumented instantiation of the kernel and write, per
  * instance, OSOT_N_PHASES shader-clock cycle counts (H/g build, Cholesky, L^-1, substitution, equality

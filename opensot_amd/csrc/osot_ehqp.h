@@ -41,6 +41,8 @@ struct DevEhqp {
     const double* w[OSOT_KMAX_LEVELS];    // [B][m] diagonal of W (null: ones)
     const double* WA[OSOT_KMAX_LEVELS];   // [B][ma][n] W A of the stored rows (levels with a non-diagonal weight), else null
     const double* Wb[OSOT_KMAX_LEVELS];   // [B][m]
+    unsigned long long row_off[OSOT_KMAX_LEVELS];   // bit r: row r of the level belongs to a task with setActive(false) (Task.h:383-387:
+                                                    // its A and b are zero) -- taken as a zero weight on that row
     double sigma_min;
     double* dq;          // [B][n]
     int* status;         // [B]
@@ -75,6 +77,7 @@ __global__ void __launch_bounds__(64) osot_ehqp_kernel(const DevEhqp Q) {
         const bool dense = Q.WA[k] != nullptr;
         const double* WAk = dense ? Q.WA[k] + inst * ma * n : nullptr;
         const double* Wbk = dense ? Q.Wb[k] + inst * m : nullptr;
+        const unsigned long long roff = Q.row_off[k];
         // ---- H = A'W A (rows i = 2 t + h, column c, in registers) and g' = A'W b -------------------------------------
         double hacc[16];
 #pragma unroll
@@ -85,7 +88,7 @@ __global__ void __launch_bounds__(64) osot_ehqp_kernel(const DevEhqp Q) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int r = r0 + u;
-                const bool in = r < ma;
+                const bool in = r < ma && !((roff >> (r & 63)) & 1ull & (unsigned long long)(r < 64));   // (an inactive task's rows: absent)
                 a[u] = (in && valid) ? Ak[r * n + c] : 0.0;
                 if (dense) { la[u] = (in && valid) ? WAk[r * n + c] : 0.0; gp = fma(a[u], in ? Wbk[r] : 0.0, gp); }
                 else { la[u] = (in ? (wk ? wk[r] : 1.0) : 0.0) * a[u]; gp = fma(la[u], in ? bk[r] : 0.0, gp); }
@@ -102,7 +105,9 @@ __global__ void __launch_bounds__(64) osot_ehqp_kernel(const DevEhqp Q) {
                 for (int t = 0; t < 16; ++t) hacc[t] = fma(Vv[u * 32 + 2 * t + h], a[u], hacc[t]);
         }
         if (m > ma && c < m - ma) {         // Postural block appended to the level: A = [I 0] (Postural.cpp:37), diagonal weights
-            const double wi = wk ? wk[ma + c] : 1.0;
+            const int rp = ma + c;
+            const bool offp = rp < 64 && ((roff >> rp) & 1ull);
+            const double wi = offp ? 0.0 : (wk ? wk[ma + c] : 1.0);
             gp = fma(wi, bk[ma + c], gp);
 #pragma unroll
             for (int t = 0; t < 16; ++t) if (2 * t + h == c) hacc[t] += wi;
@@ -309,7 +314,7 @@ __global__ void __launch_bounds__(64) osot_ehqp_qr_kernel(const DevEhqp Q) {
             {
                 double sw = 0.0, rp = 0.0;
                 if (lane < m) {
-                    const double wr = wk ? wk[lane] : 1.0;
+                    const double wr = ((Q.row_off[k] >> lane) & 1ull) ? 0.0 : (wk ? wk[lane] : 1.0);   // (lane = row < 64)
                     double sq, rs;
                     fast_sqrt_rsqrt(wr > 0.0 ? wr : 1.0, sq, rs);
                     sw = wr > 0.0 ? sq : 0.0;
@@ -598,7 +603,8 @@ __global__ void __launch_bounds__(64) osot_ehqp_qr_kernel(const DevEhqp Q) {
 }
 
 // validation + kernel arguments from the plan and the per-call batch (shared by the C-ABI entry and tests/emu)
-inline int ehqp_args(const osot_plan_desc& p, const osot_qp_batch* b, double sigma_min, bool any_task_inactive, DevEhqp& Q,
+// task_active: [OSOT_MAX_LEVELS * OSOT_MAX_TASKS] Task::setActive flags (osot_solver_set_task_active), or null: all active
+inline int ehqp_args(const osot_plan_desc& p, const osot_qp_batch* b, double sigma_min, const unsigned char* task_active, DevEhqp& Q,
                      const char** why) {
     bool any_dense = false, wide = false;
     for (int k = 0; k < p.n_levels; ++k) {
@@ -616,8 +622,20 @@ inline int ehqp_args(const osot_plan_desc& p, const osot_qp_batch* b, double sig
                                          : "eHQP front-end: a stack with a dense weight matrix or more than 64 rows in a level needs n <= 32"; return OSOT_ERR_UNSUPPORTED; }
     if (p.n > 64) { *why = "eHQP front-end: n <= 64"; return OSOT_ERR_UNSUPPORTED; }
     if (p.has_regularisation) { *why = "eHQP has no regularisation task"; return OSOT_ERR_UNSUPPORTED; }
-    if (any_task_inactive) { *why = "eHQP front-end: Task::setActive(false) is not covered (switch whole levels with level_active)"; return OSOT_ERR_UNSUPPORTED; }
     std::memset(&Q, 0, sizeof(Q));
+    if (task_active) {      // Task::setActive(false): the rows of the task count with weight zero (its A and b are zero in the reference)
+        for (int k = 0; k < p.n_levels; ++k) {
+            int off = 0;
+            for (int j = 0; j < p.level[k].n_tasks; ++j) {
+                const int rows = p.level[k].task[j].rows;
+                if (!task_active[k * OSOT_MAX_TASKS + j]) {
+                    if (off + rows > 64) { *why = "eHQP front-end: an inactive task beyond row 64 of its level"; return OSOT_ERR_UNSUPPORTED; }
+                    for (int r = off; r < off + rows; ++r) Q.row_off[k] |= (1ull << r);
+                }
+                off += rows;
+            }
+        }
+    }
     Q.B = b->B; Q.n = p.n; Q.L = p.n_levels;
     Q.use_qr = qr ? 1 : 0;
     Q.rows8 = 8;

@@ -352,7 +352,7 @@ int osot_ehqp_solve(osot_solver* s, const osot_qp_batch* b, double sigma_min, vo
     const osot_plan_desc& pl = s->plan;
     DevEhqp Q;
     const char* why = "";
-    int rc = ehqp_args(pl, b, sigma_min, s->any_inactive, Q, &why);
+    int rc = ehqp_args(pl, b, sigma_min, s->any_inactive ? s->task_active : nullptr, Q, &why);
     if (rc != OSOT_OK) return fail(rc, why);
     DeviceGuard guard(s->device);
     if (!guard.ok) return fail(OSOT_ERR_HIP, "hipSetDevice failed");
@@ -378,6 +378,8 @@ int osot_nhqp_solve(osot_solver* s, const osot_qp_batch* b, const osot_nhqp_opti
     DeviceGuard guard(s->device);
     if (!guard.ok) return fail(OSOT_ERR_HIP, "hipSetDevice failed");
     const osot_plan_desc& pl = s->plan;
+    if (s->any_inactive)     // (said, not ignored: a zero-row task changes the level's singular values and what regularize_A_b lifts)
+        return fail(OSOT_ERR_UNSUPPORTED, "nHQP front-end: Task::setActive(false) is not covered (osot_ihqp_solve and osot_ehqp_solve take it)");
     {
         int fv[OSOT_MAX_LEVELS]; const char* why = "";
         int rc = nhqp_validate(pl, opt, fv, &why);

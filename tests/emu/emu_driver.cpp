@@ -114,12 +114,14 @@ extern "C" __attribute__((visibility("default"))) int emu_nhqp_solve(const osot_
 }
 
 // the equality-only front-end (osot_ehqp.h) on host pointers
-extern "C" __attribute__((visibility("default"))) int emu_ehqp_solve(const osot_plan_desc* plan, const osot_qp_batch* b, double sigma_min) {
+// task_active: [OSOT_MAX_LEVELS * OSOT_MAX_TASKS] Task::setActive flags, or null
+extern "C" __attribute__((visibility("default"))) int emu_ehqp_solve(const osot_plan_desc* plan, const osot_qp_batch* b, double sigma_min,
+                                                                     const unsigned char* task_active) {
     const char* why = "";
     int rc = plan_validate(plan, &why);
     if (rc != OSOT_OK) { fprintf(stderr, "emu: %s\n", why); return rc; }
     DevEhqp Q;
-    rc = ehqp_args(*plan, b, sigma_min, false, Q, &why);
+    rc = ehqp_args(*plan, b, sigma_min, task_active, Q, &why);
     if (rc != OSOT_OK) { fprintf(stderr, "emu: %s\n", why); return rc; }
     if (Q.use_qr && Q.n <= 32) emu::launch(osot_ehqp_qr_kernel<32>, (unsigned)b->B, ehqp_qr_lds_bytes(32, Q.rows8), 64, Q);
     else if (Q.use_qr) emu::launch(osot_ehqp_qr_kernel<64>, (unsigned)b->B, ehqp_qr_lds_bytes(64, Q.rows8), 64, Q);

@@ -394,7 +394,7 @@ def emu_nhqp(plan, asm, free_vars=None, min_sv_ratio=None, ab_regularization=Tru
     return dq, st
 
 
-def emu_ehqp(plan, asm, sigma_min=0.0, level_active=None):
+def emu_ehqp(plan, asm, sigma_min=0.0, level_active=None, task_active=None):
     """the equality-only front-end (osot_ehqp.h) on host pointers through the emulator -> dq, status, x_levels"""
     B, n, L = asm["B"], asm["n"], asm["L"]
     qb = abi.QpBatch()
@@ -417,9 +417,15 @@ def emu_ehqp(plan, asm, sigma_min=0.0, level_active=None):
         la = np.ascontiguousarray(level_active, dtype=np.uint8); keep.append(la)
         qb.level_active = la.ctypes.data
     L_ = emu_lib()
-    L_.emu_ehqp_solve.argtypes = [C.POINTER(abi.PlanDesc), C.POINTER(abi.QpBatch), C.c_double]
+    L_.emu_ehqp_solve.argtypes = [C.POINTER(abi.PlanDesc), C.POINTER(abi.QpBatch), C.c_double, C.c_void_p]
+    ta = None
+    if task_active is not None:      # {(level, task): False} -> the [MAX_LEVELS * MAX_TASKS] flag array of osot_solver_set_task_active
+        ta = np.ones(abi.MAX_LEVELS * abi.MAX_TASKS, dtype=np.uint8)
+        for (k, j), on in task_active.items():
+            ta[k * abi.MAX_TASKS + j] = 1 if on else 0
+        keep.append(ta)
     pd = plan.to_c()
-    rc = L_.emu_ehqp_solve(C.byref(pd), C.byref(qb), float(sigma_min))
+    rc = L_.emu_ehqp_solve(C.byref(pd), C.byref(qb), float(sigma_min), None if ta is None else ta.ctypes.data)
     assert rc == 0
     return dq, st, xl
 

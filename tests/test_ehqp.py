@@ -108,6 +108,51 @@ def test_inactive_level_is_skipped(oracle):
     assert np.abs(dq - e["dq"]).max() < 1e-9
 
 
+@pytest.mark.parametrize("n,split,second", [(12, (2, 3), 4), (40, (4, 5), 6)])
+def test_inactive_task_counts_as_zero_rows(n, split, second, oracle):
+    """round 4: Task::setActive(false) on a task inside a level (Task.h:383-387: its A and b are zero while it is inactive).
+    The front-end takes the flags of osot_solver_set_task_active and gives the task's rows weight zero; against the
+    restatement run on the same stack with that task's A and b zeroed (QR kernel, 32- and 64-lane instantiation)."""
+    from opensot_amd import abi
+    from opensot_amd.plan import Task
+    B, (ra, rb) = 5, split
+    base, bleaf = synth.make_generic_stack(B, n, [ra + rb, second], n_eq=0, n_ineq=0, seed=n, box=0.0, postural_last=True, eps_factor=2e2)
+    lv0 = [Task(abi.TASK_GENERIC, ra, name="a"), Task(abi.TASK_GENERIC, rb, name="b")]      # the first level as two tasks
+    plan = StackPlan(n=n, levels=[lv0] + list(base.levels[1:]), bounds=[], rowblocks=[], eps_abs=base.eps_abs)
+    leaf = dict(bleaf)
+    b0 = bleaf["task"][0][0][0]
+    leaf["task"] = [[(b0[:, :ra].copy(), None, None), (b0[:, ra:].copy(), None, None)]] + list(bleaf["task"][1:])
+    asm = oracle.assemble(plan, leaf)
+    full = pyehqp.ehqp_solve(asm)
+    dq, st, xl = emu_ehqp(plan, asm)
+    assert (st == 0).all() and np.abs(dq - full["dq"]).max() < 1e-9
+    # the restatement of the same stack WITHOUT the task (rows removed).  With the rows zeroed instead -- what the reference's
+    # Task::update leaves -- numpy's / Eigen's thin V still holds one (implementation-defined) completion vector per zero row
+    # and P_i = P_(i-1) - V V' spends a null-space direction on each: see oracle/pyehqp.py on rank-deficient levels; the
+    # rank-revealing QR of the kernel removes the row space only, i.e. it treats the task as absent.
+    ref_asm = dict(asm)
+    ref_asm["A"] = [a.copy() if a is not None else None for a in asm["A"]]
+    ref_asm["b"] = [b.copy() for b in asm["b"]]
+    ref_asm["w"] = [None if w is None else w.copy() for w in asm["w"]]
+    ref_asm["A"][0] = np.ascontiguousarray(asm["A"][0][:, :ra, :])
+    ref_asm["b"][0] = np.ascontiguousarray(asm["b"][0][:, :ra])
+    if ref_asm["w"][0] is not None:
+        ref_asm["w"][0] = np.ascontiguousarray(asm["w"][0][:, :ra])
+    ref_asm["m"] = [ra] + list(asm["m"][1:]) if "m" in asm else None
+    e = pyehqp.ehqp_solve(ref_asm)
+    dq, st, xl = emu_ehqp(plan, asm, task_active={(0, 1): False})          # the second task of the first level
+    assert (st == 0).all() and np.abs(dq - e["dq"]).max() < 1e-9
+    assert np.abs(full["dq"] - e["dq"]).max() > 1e-4                       # (the task mattered)
+    # ... and it is bit-identical to handing the kernel zeroed rows (the reference's arrays)
+    z = dict(asm)
+    z["A"] = [a.copy() if a is not None else None for a in asm["A"]]
+    z["b"] = [b.copy() for b in asm["b"]]
+    z["A"][0][:, ra:ra + rb, :] = 0.0
+    z["b"][0][:, ra:ra + rb] = 0.0
+    dqz, _, _ = emu_ehqp(plan, z)
+    assert np.array_equal(dq, dqz)
+
+
 def test_weights_and_dense_weights(oracle):
     """W = L L' enters as L'A, L'b in the reference; the kernel takes W A and W b (the update kernel's outputs)"""
     plan, leaf = synth.make_feature_stack(4, seed=3, body_frame=False, dense=True, bands=False, candidates=0, many_blocks=False)
@@ -214,6 +259,45 @@ def test_ehqp_gpu_vs_restatement(n, rows, seed, oracle, gpu_device):
     assert (st.status[:B].cpu().numpy() == 0).all()
     assert np.abs(st.dq[:B].cpu().numpy() - e["dq"]).max() < 1e-12
     assert np.abs(st.x_levels[:B].cpu().numpy() - e["x_levels"]).max() < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,split,second", [(12, (2, 3), 4), (40, (4, 5), 6)])
+def test_inactive_task_gpu(n, split, second, oracle, gpu_device):
+    """osot_solver_set_task_active + osot_ehqp_solve (round 4; refused before): the inactive task's rows count with weight zero
+    -- the restatement of the stack without the task, and the answer of the full stack again after re-activating it"""
+    import torch
+    from opensot_amd import abi
+    from opensot_amd.plan import Task
+    from opensot_amd.solver import BatchedStack
+    B, (ra, rb) = 48, split
+    base, bleaf = synth.make_generic_stack(B, n, [ra + rb, second], n_eq=0, n_ineq=0, seed=n, box=0.0, postural_last=True, eps_factor=2e2)
+    lv0 = [Task(abi.TASK_GENERIC, ra, name="a"), Task(abi.TASK_GENERIC, rb, name="b")]
+    plan = StackPlan(n=n, levels=[lv0] + list(base.levels[1:]), bounds=[], rowblocks=[], eps_abs=base.eps_abs)
+    leaf = dict(bleaf)
+    b0 = bleaf["task"][0][0][0]
+    leaf["task"] = [[(b0[:, :ra].copy(), None, None), (b0[:, ra:].copy(), None, None)]] + list(bleaf["task"][1:])
+    asm = oracle.assemble(plan, leaf)
+    full = pyehqp.ehqp_solve(asm)
+    ref = dict(asm)
+    ref["A"] = [np.ascontiguousarray(asm["A"][0][:, :ra, :])] + list(asm["A"][1:])
+    ref["b"] = [np.ascontiguousarray(asm["b"][0][:, :ra])] + list(asm["b"][1:])
+    ref["w"] = [None if asm["w"][0] is None else np.ascontiguousarray(asm["w"][0][:, :ra])] + list(asm["w"][1:])
+    ref["m"] = [ra] + list(asm["m"][1:]); ref["ma"] = [ra] + list(asm["ma"][1:])
+    e = pyehqp.ehqp_solve(ref)
+    st = BatchedStack(plan, B, device=0)
+    st.load_assembled(asm)
+    st.set_task_active(0, 1, False)
+    st.solve_ehqp(B)
+    torch.cuda.synchronize()
+    assert (st.status[:B].cpu().numpy() == 0).all()
+    assert np.abs(st.dq[:B].cpu().numpy() - e["dq"]).max() < 1e-11
+    with pytest.raises(RuntimeError, match="setActive"):        # the null-space front-end says so instead of ignoring the flag
+        st.solve_nhqp(B)
+    st.set_task_active(0, 1, True)
+    st.solve_ehqp(B)
+    torch.cuda.synchronize()
+    assert np.abs(st.dq[:B].cpu().numpy() - full["dq"]).max() < 1e-11
 
 
 @pytest.mark.gpu
