@@ -380,6 +380,9 @@ int osot_nhqp_solve(osot_solver* s, const osot_qp_batch* b, const osot_nhqp_opti
     const osot_plan_desc& pl = s->plan;
     if (s->any_inactive)     // (said, not ignored: a zero-row task changes the level's singular values and what regularize_A_b lifts)
         return fail(OSOT_ERR_UNSUPPORTED, "nHQP front-end: Task::setActive(false) is not covered (osot_ihqp_solve and osot_ehqp_solve take it)");
+    if (b->level_active)     // (iHQP::setActiveStack: the reference's nHQP has no such switch, nHQP.h)
+        for (int k = 0; k < pl.n_levels; ++k)
+            if (!b->level_active[k]) return fail(OSOT_ERR_UNSUPPORTED, "nHQP front-end: level_active is iHQP's setActiveStack; nHQP has no such switch");
     {
         int fv[OSOT_MAX_LEVELS]; const char* why = "";
         int rc = nhqp_validate(pl, opt, fv, &why);

@@ -295,6 +295,10 @@ def test_inactive_task_gpu(n, split, second, oracle, gpu_device):
     with pytest.raises(RuntimeError, match="setActive"):        # the null-space front-end says so instead of ignoring the flag
         st.solve_nhqp(B)
     st.set_task_active(0, 1, True)
+    st.level_active = [1, 0, 1]                                 # ... and iHQP's setActiveStack, which the reference's nHQP does not have
+    with pytest.raises(RuntimeError, match="setActiveStack"):
+        st.solve_nhqp(B)
+    st.level_active = None
     st.solve_ehqp(B)
     torch.cuda.synchronize()
     assert np.abs(st.dq[:B].cpu().numpy() - full["dq"]).max() < 1e-11
