@@ -360,7 +360,7 @@ def coman_stack(which, n):
     return StackPlan(n=n, levels=levels, bounds=bounds, rowblocks=rows, eps_abs=eps_abs_from_factor(1e6))
 
 
-def time_coman35(which, B, device, steps=20, warmup=5, front_end="iHQP", specialise=True):
+def time_coman35(which, B, device, steps=20, warmup=5, front_end="iHQP", specialise=True, fused=False):
     """the reference example's control loop (coman_ik.cpp:174-219) for B robots, everything resident: q -> frame poses, Jacobians,
     CoM (osot_kinematics, rows written straight into A_k / C) -> AutoStack::update + Solver::solve (one fused launch; nHQP: update +
     osot_nhqp_solve) -> q += dq.  Each robot chases its own random wrist goals (+-0.2 m, as the reference's harness draws them), so
@@ -413,7 +413,16 @@ def time_coman35(which, B, device, steps=20, warmup=5, front_end="iHQP", special
     leaf = {"B": B, "task": [[leaf_of[t.name] for t in lev] for lev in plan.levels],
             "bound": [(q, qmin, qmax), (qdot_max, None, None)], "rows": [(pose[2], pose_d[2], None), (pose[3], pose_d[3], None)]}
 
+    # fused: osot_control_cycle (kinematics, update, cascade, q += dq of a robot by one wavefront).  Not the default here: on this
+    # single-stream loop of 56-lane launches it is neutral (tools/coman_ab.py: 8.14 / 3.76 / 3.04 / 1.88 M either way) -- there is
+    # no second lane whose cascade starves the producer's launch, which is what the one-launch form removes at config 3
+    one_launch = fused and front_end == "iHQP"
+    kb = K.batch_args(q, frame_pose={f: pose[f] for f in range(4)}, frame_J=fj, com=com, com_J=where["com"])
+
     def step():
+        if one_launch:
+            st.control_cycle(K, kb, leaf, q_integrate=q)
+            return
         fk()
         if front_end == "nHQP":
             st.update(leaf); st.solve_nhqp(B)
@@ -441,7 +450,9 @@ def time_coman35(which, B, device, steps=20, warmup=5, front_end="iHQP", special
                        + {"S1": "(0.1 l_wrist + r_wrist + com + 1e-4 postural)", "S2": "((com + 0.1 l_wrist + r_wrist) / postural)",
                           "S3": "(com / (0.1 l_wrist + r_wrist) / postural)", "S4": "(com / l_wrist / r_wrist / postural)"}[which]
                        + " << joint_limits << vel_limits << (l_sole + r_sole as 12 TaskToConstraint equality rows), eps factor 1e6; closed loop of "
-                         f"{B} robots on the device: kinematics -> update + {front_end} solve -> q += dq, each robot chasing its own +-0.2 m wrist goals",
+                         f"{B} robots on the device: kinematics -> update + {front_end} solve -> q += dq"
+                         + (" as ONE launch per step (osot_control_cycle)" if one_launch else " (kinematics launch, " + ("update + cascade launch" if front_end == "iHQP" else "update and the front-end's launches") + ", integration)")
+                         + ", each robot chasing its own +-0.2 m wrist goals",
            "front_end": front_end, "batch": B, "n": n, "rows_per_level": [plan.m(k) for k in range(plan.L)], "constraint_rows": plan.nc,
            "value": B / (ms * 1e-3), "unit": "solves/s", "ms_per_step": ms, "steps": steps, "solved_ok": f"{ok}/{B}",
            "ms_per_solve_per_instance_stream": ms,
@@ -449,7 +460,8 @@ def time_coman35(which, B, device, steps=20, warmup=5, front_end="iHQP", special
            "note": "ms_per_step is the latency of one control cycle INCLUDING the kinematics producer and AutoStack::update, for all "
                    f"{B} robots at once; the reference's figure is one robot's solve alone"}
     if front_end == "iHQP" and launches:
-        kname = f"osot_cycle_kernel<{NPk}, false>"
+        kname = (f"osot_control_cycle_kernel<{NPk}, false, true>" if specialise else f"osot_control_cycle_kernel<{NPk}, false, false>") if one_launch \
+            else (f"osot_cycle_kernel<{NPk}, false, true>" if specialise else f"osot_cycle_kernel<{NPk}, false, false>")
         traffic, src = pmc_traffic([(kname, B + 1, 1)])
         rf, rh = roofline_of(plan, B, kern_ms, launches, kname, traffic, src or "no PMC passes committed for this kernel source: null rather than a stale figure")
         out["roofline"], out["roofline_hbm"] = rf, rh

@@ -569,9 +569,10 @@ int osot_kinematics(osot_kin* k, const osot_kin_batch* batch, void* hip_stream);
  * osot_kinematics (q -> frame poses, Jacobian rows, CoM, written where `kin_batch` says: the arrays the leaf inputs and A_k
  * point into), then osot_cycle (AutoStack::update + the iHQP cascade), then, when q_integrate is not NULL,
  * q_integrate[i] += dq[i] (usually kin_batch->q itself: the next call starts from the integrated posture).
- * Results are those of the three calls; every array they write is still written.  Offered where it pays: models / plans of
- * up to 32 variables without the collision-pair stage, dense weights, inactive tasks or the hot start (OSOT_ERR_UNSUPPORTED
- * otherwise -- use the three calls).  Stream-ordered. */
+ * Results are those of the three calls; every array they write is still written.  Not offered with the collision-pair
+ * stage, dense weights, inactive tasks or the hot start (OSOT_ERR_UNSUPPORTED -- use the three calls).  It pays where several
+ * sub-batches share the chip (a sub-batch's kinematics launch otherwise waits for wavefront slots the other's cascade holds).
+ * Stream-ordered. */
 int osot_control_cycle(osot_solver* s, osot_kin* k, const osot_kin_batch* kin_batch, const osot_leaf_batch* leaf,
                        const osot_assembled_out* out, const osot_qp_batch* batch, double* q_integrate, void* hip_stream);
 

@@ -8,6 +8,7 @@
 // of 17 because the other lane's cascade holds every wavefront slot of the chip while it waits (24.5 M solves/s against the
 // 33.6 M of the cycle alone at BASELINE config 3, B = 4096).  Here the kinematics of an instance is ~8 % more work in front of its
 // own update: no slots to wait for, no gaps, and the rows it writes come back from the CU's own L1 / L2 lines.
+// All three lane layouts (32, 56, 64): the reference's own 35-coordinate COMAN runs its loop body as one launch too.
 #pragma once
 #include <osot_kernels.h>
 #include <osot_kin.h>
@@ -20,20 +21,23 @@ struct DevControl {
     double* q_int;             // [B][n] integrated at the end: q_int += dq (null: not integrated).  Usually Bt.q itself.
 };
 
-// LDS in front of the cycle's own use of the slice (the update stages its arguments there afterwards): two kinematics slices, the
-// second half of the wavefront runs as an idle instance (kin_instance is written for two robots per wavefront; its lanes store
-// their -- masked -- tables unconditionally)
-constexpr size_t kControlKinLdsBytes = 2 * sizeof(double) * (size_t)kin_lds_doubles<32>(false);
+// LDS in front of the cycle's own use of the slice (the update stages its arguments there afterwards).  NP = 32: two kinematics
+// slices, the second half of the wavefront runs as an idle instance (kin_instance<.,32> is written for two robots per wavefront;
+// its lanes store their -- masked -- tables unconditionally); the 64-lane kernels: one slice, lane = joint over the whole wavefront
+constexpr size_t control_kin_lds_bytes(int NP) {
+    return NP == 32 ? 2 * sizeof(double) * (size_t)kin_lds_doubles<32>(false) : sizeof(double) * (size_t)kin_lds_doubles<64>(false);
+}
 
 template <int NP, bool EXTRA = false, bool BOX = false>
 __global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : 1)) osot_control_cycle_kernel(const DevUpdate U, const DevPlan P, const DevBatch D, const DevControl F) {
-    static_assert(NP == 32, "the fused control cycle is built for models of up to 32 joints");
     OSOT_DYNAMIC_LDS(osot_smem);
     const long long inst = dispatch_instance(D, osot_smem);
     if (inst < 0) return;
-    {
+    if constexpr (NP == 32) {
         const int sub = (int)(threadIdx.x >> 5), j = (int)(threadIdx.x & 31u);
         kin_instance<false, 32>(F.K, F.Bt, inst, sub == 0, j, reinterpret_cast<double*>(osot_smem) + sub * kin_lds_doubles<32>(false));
+    } else {
+        kin_instance<false, 64>(F.K, F.Bt, inst, true, (int)threadIdx.x, reinterpret_cast<double*>(osot_smem));
     }
     workgroup_fence();      // the producer's global stores (poses, rows of A_k, CoM) are visible to the update's loads (same workgroup)
     __syncthreads();

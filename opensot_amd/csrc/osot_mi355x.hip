@@ -207,12 +207,14 @@ int osot_solver_create(const osot_plan_desc* plan, int max_batch, int device, os
         if constexpr (NP != 32) {
             if (r == OSOT_OK) r = ensure_lds(osot_cascade_kernel<NP, false, false, true>, lds);
             if (r == OSOT_OK) r = ensure_lds(osot_cycle_kernel<NP, false, true>, lds);
+            if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<NP, false, true>, lds > control_kin_lds_bytes(NP) ? lds : control_kin_lds_bytes(NP));
+            if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<NP, false, false>, lds > control_kin_lds_bytes(NP) ? lds : control_kin_lds_bytes(NP));
         }
         if constexpr (NP == 32) {
             if (r == OSOT_OK) r = ensure_lds(osot_cascade_kernel<32, false, false, true>, lds);
             if (r == OSOT_OK) r = ensure_lds(osot_cycle_kernel<32, false, true>, lds);
-            if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<32, false, true>, lds > kControlKinLdsBytes ? lds : kControlKinLdsBytes);
-            if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<32, false, false>, lds > kControlKinLdsBytes ? lds : kControlKinLdsBytes);
+            if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<32, false, true>, lds > control_kin_lds_bytes(32) ? lds : control_kin_lds_bytes(32));
+            if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<32, false, false>, lds > control_kin_lds_bytes(32) ? lds : control_kin_lds_bytes(32));
             if (r == OSOT_OK) r = ensure_lds(osot_cascade_kernel<32, true, false, true>, lds);
         }
         return r;
@@ -497,10 +499,7 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
         static const char* extra = getenv("OSOT_DEBUG_EXTRA_LDS");
         if (extra) lds += (size_t)atoi(extra);
     }
-    if (control) {
-        if (T != 32) return fail(OSOT_ERR_UNSUPPORTED, "the fused control cycle is built for plans of up to 32 variables (use osot_kinematics + osot_cycle)");
-        if (lds < kControlKinLdsBytes) lds = kControlKinLdsBytes;
-    }
+    if (control && lds < control_kin_lds_bytes(T)) lds = control_kin_lds_bytes(T);
     DevBatch D;
     std::memset(&D, 0, sizeof(D));
     D.B = b->B;
@@ -580,6 +579,11 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
             }
         }
         if constexpr (NP != 32) {
+            if (control) {
+                if (box) hipLaunchKernelGGL((osot_control_cycle_kernel<NP, false, true>), dim3(grid), dim3(64), lds, st, *fused, P, D, *control);
+                else hipLaunchKernelGGL((osot_control_cycle_kernel<NP, false, false>), dim3(grid), dim3(64), lds, st, *fused, P, D, *control);
+                return 0;
+            }
             if (box && !prof) {
                 if (fused) hipLaunchKernelGGL((osot_cycle_kernel<NP, false, true>), dim3(grid), dim3(64), lds, st, *fused, P, D);
                 else hipLaunchKernelGGL((osot_cascade_kernel<NP, false, false, true>), dim3(grid), dim3(64), lds, st, P, D);
@@ -1024,7 +1028,6 @@ int osot_control_cycle(osot_solver* s, osot_kin* k, const osot_kin_batch* kb, co
     if (!kb->q) return fail(OSOT_ERR_INVALID, "q is null");
     if (k->device != s->device) return fail(OSOT_ERR_INVALID, "the model and the solver live on different devices");
     if (k->n != s->plan.n) return fail(OSOT_ERR_INVALID, "the model's joint count is not the plan's variable count");
-    if (k->n > 32) return fail(OSOT_ERR_UNSUPPORTED, "the fused control cycle is built for models of up to 32 joints (use osot_kinematics + osot_cycle)");
     if (k->n_pairs > 0 && (kb->pair_dist || kb->pair_J))
         return fail(OSOT_ERR_UNSUPPORTED, "the fused control cycle carries no collision-pair stage (use osot_kinematics + osot_cycle)");
     DevUpdate U;

@@ -369,6 +369,67 @@ def test_control_cycle_in_one_launch_matches_the_three_calls(with_rows, gpu_devi
 
 
 @pytest.mark.gpu
+def test_control_cycle_in_one_launch_on_the_35_coordinate_coman(gpu_device):
+    """osot_control_cycle on the reference's own robot (35 coordinates: the 56-lane kernels, the 64-joint producer with one
+    robot per wavefront): the stack of coman_ik.cpp:425-449, 20 closed-loop steps, bit-identical to osot_kinematics + osot_cycle
+    + q += dq"""
+    import torch
+    from opensot_amd.solver import BatchedStack
+    m, lo, up = _coman()
+    n, B = m.n, 77
+    dev = torch.device("cuda", 0)
+    f64 = dict(dtype=torch.float64, device=dev)
+    rng = np.random.default_rng(40)
+    q0 = np.zeros((B, n))
+    for s_ in "RL":
+        q0[:, m.names.index(s_ + "HipSag")] = -0.3; q0[:, m.names.index(s_ + "KneeSag")] = 0.6
+        q0[:, m.names.index(s_ + "AnkSag")] = -0.3; q0[:, m.names.index(s_ + "Elbj")] = -0.8
+        q0[:, m.names.index(s_ + "ShSag")] = 0.2
+    q0[:, m.names.index("LShLat")] = 0.3; q0[:, m.names.index("RShLat")] = -0.3
+    q0[:, 6:] += rng.normal(0.0, 0.01, (B, n - 6))
+    q0 = np.clip(q0, np.maximum(lo, -10.0) + 1e-3, np.minimum(up, 10.0) - 1e-3)
+    levels = [[Task(abi.TASK_COM, 3, lam=0.1, name="com")],
+              [Task(abi.TASK_CARTESIAN, 6, weight=0.1, lam=0.1, name="l_wrist"), Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="r_wrist"),
+               Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="l_sole"), Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="r_sole")],
+              [Task(abi.TASK_POSTURAL, n, lam=0.01, name="postural")]]
+    bounds = [Bound(abi.BOUND_JOINT_LIMITS, scaling=1.0, name="jl"), Bound(abi.BOUND_VELOCITY_LIMITS, dT=0.01, name="vl")]
+    plan = StackPlan(n=n, levels=levels, bounds=bounds, rowblocks=[], eps_abs=eps_abs_from_factor(1e6))
+    K = kin.Kinematics(m, device=0)
+    big = 1.0e3
+
+    def make():
+        st = BatchedStack(plan, B, device=0, want_levels=False)
+        q = torch.as_tensor(q0, **f64).contiguous()
+        pose = [torch.zeros((B, 12), **f64) for _ in range(4)]
+        com = torch.zeros((B, 3), **f64)
+        kw = dict(frame_pose={f: pose[f] for f in range(4)}, frame_J={f: (st.A[1], 6 * f) for f in range(4)}, com=com, com_J=(st.A[0], 0))
+        K.forward(q, **kw)
+        torch.cuda.synchronize()
+        pose_d = [p.clone() for p in pose]
+        pose_d[1][:, 9:] += torch.as_tensor([0.05, -0.02, 0.04], **f64)
+        qmin = torch.as_tensor(np.tile(np.maximum(lo, -big), (B, 1)), **f64); qmax = torch.as_tensor(np.tile(np.minimum(up, big), (B, 1)), **f64)
+        leaf = {"B": B, "task": [[(com, com.clone(), None)], [(pose[f], pose_d[f], None) for f in range(4)], [(q, q.clone(), None)]],
+                "bound": [(q, qmin, qmax), (torch.full((B, n), 2.0, **f64), None, None)], "rows": []}
+        return st, q, pose, com, kw, leaf
+
+    sta, qa, posea, coma, kwa, leafa = make()
+    stb, qb, poseb, comb, kwb, leafb = make()
+    kb = K.batch_args(qb, **kwb)
+    for step in range(20):
+        K.forward(qa, **kwa)
+        sta.cycle(leafa)
+        qa += sta.dq[:B]
+        stb.control_cycle(K, kb, leafb, q_integrate=qb)
+    torch.cuda.synchronize()
+    assert (sta.status[:B] == 0).all() and (stb.status[:B] == 0).all()
+    assert torch.equal(qa, qb) and torch.equal(sta.dq[:B], stb.dq[:B])
+    assert torch.equal(coma, comb) and all(torch.equal(posea[f], poseb[f]) for f in range(4))
+    for k in range(2):
+        assert torch.equal(sta.A[k][:B], stb.A[k][:B]) and torch.equal(sta.b[k][:B], stb.b[k][:B])
+    assert float(sta.dq[:B].abs().max()) > 1e-4
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("front_end", ["iHQP", "eHQP", "nHQP"])
 def test_closed_loop_ik_coman35(front_end, gpu_device):
     """the reference's own robot and stack -- examples/cpp/coman_ik.cpp:425-449: 35 coordinates,

@@ -7,4 +7,6 @@ for rep in range(2):
     for which in ("S1", "S2", "S3", "S4"):
         a = bench.time_coman35(which, 4096, 0, 20, 5, specialise=True)
         b = bench.time_coman35(which, 4096, 0, 20, 5, specialise=False)
-        print(which, "specialised", round(a["value"] / 1e6, 3), "M   general", round(b["value"] / 1e6, 3), "M", a.get("solved_ok"), b.get("solved_ok"))
+        c = bench.time_coman35(which, 4096, 0, 20, 5, specialise=True, fused=False)
+        print(which, "one launch, specialised", round(a["value"] / 1e6, 3), "M   general", round(b["value"] / 1e6, 3), "M   three launches, specialised",
+              round(c["value"] / 1e6, 3), "M", a.get("solved_ok"), b.get("solved_ok"), c.get("solved_ok"))
