@@ -360,12 +360,16 @@ def coman_stack(which, n):
     return StackPlan(n=n, levels=levels, bounds=bounds, rowblocks=rows, eps_abs=eps_abs_from_factor(1e6))
 
 
-def time_coman35(which, B, device, steps=20, warmup=5, front_end="iHQP", specialise=True, fused=False):
+def time_coman35(which, B, device, steps=20, warmup=5, front_end="iHQP", specialise=True, fused=True, lanes=1, streams=None, graph=True):
     """the reference example's control loop (coman_ik.cpp:174-219) for B robots, everything resident: q -> frame poses, Jacobians,
-    CoM (osot_kinematics, rows written straight into A_k / C) -> AutoStack::update + Solver::solve (one fused launch; nHQP: update +
-    osot_nhqp_solve) -> q += dq.  Each robot chases its own random wrist goals (+-0.2 m, as the reference's harness draws them), so
-    the inputs of consecutive steps are the closed loop's own drift."""
+    CoM (rows written straight into A_k / C) -> AutoStack::update + Solver::solve -> q += dq.  Each robot chases its own random
+    wrist goals (+-0.2 m, as the reference's harness draws them), so the inputs of consecutive steps are the closed loop's own
+    drift.  iHQP: submitted like the headline -- the batch as `lanes` sub-batches on their own streams, ONE launch per step and
+    lane (osot_control_cycle; fused=False: the kinematics launch, the update + cascade launch, the integration), the steps of a
+    lane as one HIP graph.  nHQP: kinematics launch, update launch, osot_nhqp_solve (three launches per level), integration, in
+    one stream."""
     from opensot_amd import kinematics as kin
+    from opensot_amd.parallel import lane_ranges
     from opensot_amd.solver import BatchedStack
     m, lo, up = kin.from_json(os.path.join(ROOT, "tests", "golden", "coman_tree.json"))
     n = m.n
@@ -373,99 +377,118 @@ def time_coman35(which, B, device, steps=20, warmup=5, front_end="iHQP", special
     dev = torch.device("cuda", device)
     f64 = dict(dtype=torch.float64, device=dev)
     rng = np.random.default_rng(35)
-    q0 = np.zeros((B, n))
-    for s_ in "RL":                                   # a slightly crouched, arms-bent posture inside the limits
-        q0[:, m.names.index(s_ + "HipSag")] = -0.3; q0[:, m.names.index(s_ + "KneeSag")] = 0.6
-        q0[:, m.names.index(s_ + "AnkSag")] = -0.3; q0[:, m.names.index(s_ + "Elbj")] = -0.8
-        q0[:, m.names.index(s_ + "ShSag")] = 0.2
-    q0[:, m.names.index("LShLat")] = 0.3; q0[:, m.names.index("RShLat")] = -0.3
-    q0[:, 6:] += rng.normal(0.0, 0.02, (B, n - 6))
-    q0 = np.clip(q0, np.maximum(lo, -10.0) + 1e-3, np.minimum(up, 10.0) - 1e-3)
-    st = BatchedStack(plan, B, device=device, want_levels=False)
-    if not specialise:
-        st.set_specialisation(False)
     K = kin.Kinematics(m, device=device)
-    q = torch.as_tensor(q0, **f64).contiguous()
-    pose = [torch.zeros((B, 12), **f64) for _ in range(4)]
-    com = torch.zeros((B, 3), **f64)
-    # where each task's Jacobian rows live: (level tensor, first row)
-    where, off = {}, [0] * plan.L
-    for k, lev in enumerate(plan.levels):
-        for t in lev:
-            if t.name in ("l_wrist", "r_wrist", "com"):
-                where[t.name] = (st.A[k], off[k])
-            if not t.implicit:
-                off[k] += t.rows
-    fj = {0: where["l_wrist"], 1: where["r_wrist"], 2: (st.C, 0), 3: (st.C, 6)}
+    if front_end != "iHQP":
+        lanes, graph, fused = 1, False, False
+    work = []
+    for a, b in lane_ranges(B, lanes):
+        Bl = b - a
+        q0 = np.zeros((Bl, n))
+        for s_ in "RL":                                   # a slightly crouched, arms-bent posture inside the limits
+            q0[:, m.names.index(s_ + "HipSag")] = -0.3; q0[:, m.names.index(s_ + "KneeSag")] = 0.6
+            q0[:, m.names.index(s_ + "AnkSag")] = -0.3; q0[:, m.names.index(s_ + "Elbj")] = -0.8
+            q0[:, m.names.index(s_ + "ShSag")] = 0.2
+        q0[:, m.names.index("LShLat")] = 0.3; q0[:, m.names.index("RShLat")] = -0.3
+        q0[:, 6:] += rng.normal(0.0, 0.02, (Bl, n - 6))
+        q0 = np.clip(q0, np.maximum(lo, -10.0) + 1e-3, np.minimum(up, 10.0) - 1e-3)
+        st = BatchedStack(plan, Bl, device=device, want_levels=False)
+        if not specialise:
+            st.set_specialisation(False)
+        # (the caller's streams where it has them: fresh ones can land on a hardware queue another lane already uses)
+        stream = streams[len(work)] if (streams is not None and len(work) < len(streams)) else torch.cuda.Stream(device=dev)
+        st.stream = stream
+        q = torch.as_tensor(q0, **f64).contiguous()
+        pose = [torch.zeros((Bl, 12), **f64) for _ in range(4)]
+        com = torch.zeros((Bl, 3), **f64)
+        # where each task's Jacobian rows live: (level tensor, first row)
+        where, off = {}, [0] * plan.L
+        for k, lev in enumerate(plan.levels):
+            for t in lev:
+                if t.name in ("l_wrist", "r_wrist", "com"):
+                    where[t.name] = (st.A[k], off[k])
+                if not t.implicit:
+                    off[k] += t.rows
+        kw = dict(frame_pose={f: pose[f] for f in range(4)}, frame_J={0: where["l_wrist"], 1: where["r_wrist"], 2: (st.C, 0), 3: (st.C, 6)},
+                  com=com, com_J=where["com"])
+        with torch.cuda.stream(stream):
+            K.forward(q, **kw)
+        torch.cuda.synchronize()
+        pose_d = [p.clone() for p in pose]
+        for f in (0, 1):
+            pose_d[f][:, 9:] += torch.as_tensor(rng.uniform(-0.2, 0.2, (Bl, 3)), **f64)
+        big = 1.0e3
+        qmin = torch.as_tensor(np.tile(np.maximum(lo, -big), (Bl, 1)), **f64); qmax = torch.as_tensor(np.tile(np.minimum(up, big), (Bl, 1)), **f64)
+        leaf_of = {"l_wrist": (pose[0], pose_d[0], None), "r_wrist": (pose[1], pose_d[1], None), "com": (com, com.clone(), None), "postural": (q, q.clone(), None)}
+        leaf = {"B": Bl, "task": [[leaf_of[t.name] for t in lev] for lev in plan.levels],
+                "bound": [(q, qmin, qmax), (torch.full((Bl, n), 2.0, **f64), None, None)], "rows": [(pose[2], pose_d[2], None), (pose[3], pose_d[3], None)]}
+        kb = K.batch_args(q, **kw)
 
-    def fk():
-        K.forward(q, frame_pose={f: pose[f] for f in range(4)}, frame_J=fj, com=com, com_J=where["com"])
-    fk(); torch.cuda.synchronize()
-    pose_d = [p.clone() for p in pose]
-    for f in (0, 1):
-        pose_d[f][:, 9:] += torch.as_tensor(rng.uniform(-0.2, 0.2, (B, 3)), **f64)
-    com_d = com.clone()
-    big = 1.0e3
-    qmin = torch.as_tensor(np.tile(np.maximum(lo, -big), (B, 1)), **f64); qmax = torch.as_tensor(np.tile(np.minimum(up, big), (B, 1)), **f64)
-    qdot_max = torch.full((B, n), 2.0, **f64)
-    q_ref = q.clone()
-    leaf_of = {"l_wrist": (pose[0], pose_d[0], None), "r_wrist": (pose[1], pose_d[1], None), "com": (com, com_d, None), "postural": (q, q_ref, None)}
-    leaf = {"B": B, "task": [[leaf_of[t.name] for t in lev] for lev in plan.levels],
-            "bound": [(q, qmin, qmax), (qdot_max, None, None)], "rows": [(pose[2], pose_d[2], None), (pose[3], pose_d[3], None)]}
-
-    # fused: osot_control_cycle (kinematics, update, cascade, q += dq of a robot by one wavefront).  Not the default here: on this
-    # single-stream loop of 56-lane launches it is neutral (tools/coman_ab.py: 8.14 / 3.76 / 3.04 / 1.88 M either way) -- there is
-    # no second lane whose cascade starves the producer's launch, which is what the one-launch form removes at config 3
-    one_launch = fused and front_end == "iHQP"
-    kb = K.batch_args(q, frame_pose={f: pose[f] for f in range(4)}, frame_J=fj, com=com, com_J=where["com"])
-
-    def step():
-        if one_launch:
-            st.control_cycle(K, kb, leaf, q_integrate=q)
-            return
-        fk()
-        if front_end == "nHQP":
-            st.update(leaf); st.solve_nhqp(B)
-        else:
-            st.cycle(leaf)
-        q.add_(st.dq[:B])
+        def step(st=st, leaf=leaf, q=q, Bl=Bl, stream=stream, kb=kb, kw=kw):
+            with torch.cuda.stream(stream):
+                if front_end == "nHQP":
+                    K.forward(q, **kw); st.update(leaf); st.solve_nhqp(Bl); q.add_(st.dq[:Bl])
+                elif fused:
+                    st.control_cycle(K, kb, leaf, q_integrate=q)
+                else:
+                    K.forward(q, **kw); st.cycle(leaf, cached=True); q.add_(st.dq[:Bl])
+        work.append((st, step, stream, Bl))
     for _ in range(warmup):
-        step()
+        for _, step, _, _ in work:
+            step()
     torch.cuda.synchronize()
-    if front_end == "iHQP":
-        st.set_timing(True, stride=2)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(steps):
-        step()
-    e1.record()
+    graphs, note = [], None
+    if graph:
+        try:
+            for st, step, stream, _ in work:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    for _ in range(steps):
+                        step()
+                graphs.append(g)
+        except Exception as e:
+            graphs, note = [], f"graph capture unavailable: {e}"[:200]
+            for st, _, _, _ in work:
+                st.set_schedule(True)
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / steps
-    kern_ms, launches = st.kernel_time_ms() if front_end == "iHQP" else (None, 0)
-    if front_end == "iHQP":
-        st.set_timing(False)
-    ok = int((st.status[:B] == 0).sum().item())
+
+    def run_all():
+        if graphs:
+            for g, (_, _, stream, _) in zip(graphs, work):
+                with torch.cuda.stream(stream):
+                    g.replay()
+        else:
+            for _ in range(steps):
+                for _, step, _, _ in work:
+                    step()
+    if graphs:
+        run_all(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_all()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    ok = sum(int((st.status[:Bl] == 0).sum().item()) for st, _, _, Bl in work)
     NPk = 32 if plan.n <= 32 else (56 if plan.n <= 54 else 64)
+    how = ("kinematics launch, update launch, osot_nhqp_solve, integration; one stream" if front_end == "nHQP" else
+           (f"{lanes} sub-batches on their own streams, " + ("ONE launch per step and sub-batch (osot_control_cycle)" if fused else
+            "kinematics launch + update-and-cascade launch + integration per step") + (f", {steps} steps of a sub-batch per HIP graph" if graphs else ", plain launches")))
     out = {"workload": f"the reference's published workload {which} (examples/cpp/coman_ik.cpp:425-449): COMAN, 35 coordinates, "
                        + {"S1": "(0.1 l_wrist + r_wrist + com + 1e-4 postural)", "S2": "((com + 0.1 l_wrist + r_wrist) / postural)",
                           "S3": "(com / (0.1 l_wrist + r_wrist) / postural)", "S4": "(com / l_wrist / r_wrist / postural)"}[which]
                        + " << joint_limits << vel_limits << (l_sole + r_sole as 12 TaskToConstraint equality rows), eps factor 1e6; closed loop of "
-                         f"{B} robots on the device: kinematics -> update + {front_end} solve -> q += dq"
-                         + (" as ONE launch per step (osot_control_cycle)" if one_launch else " (kinematics launch, " + ("update + cascade launch" if front_end == "iHQP" else "update and the front-end's launches") + ", integration)")
-                         + ", each robot chasing its own +-0.2 m wrist goals",
-           "front_end": front_end, "batch": B, "n": n, "rows_per_level": [plan.m(k) for k in range(plan.L)], "constraint_rows": plan.nc,
-           "value": B / (ms * 1e-3), "unit": "solves/s", "ms_per_step": ms, "steps": steps, "solved_ok": f"{ok}/{B}",
+                         f"{B} robots on the device: kinematics -> update + {front_end} solve -> q += dq ({how}), each robot chasing its own +-0.2 m wrist goals",
+           "front_end": front_end, "batch": B, "lanes": lanes, "n": n, "rows_per_level": [plan.m(k) for k in range(plan.L)], "constraint_rows": plan.nc,
+           "value": B / (ms * 1e-3), "unit": "solves/s", "ms_per_step": ms, "steps": steps, "solved_ok": f"{ok}/{B}", "note_capture": note,
            "ms_per_solve_per_instance_stream": ms,
            "reference_published_ms_per_solve": dict(COMAN_REFERENCE_MS[which], hardware="one core of a Ryzen 9 4900HS; solve only, update and model.update excluded (BASELINE.md section 1)"),
-           "note": "ms_per_step is the latency of one control cycle INCLUDING the kinematics producer and AutoStack::update, for all "
+           "note": "ms_per_step is the time per control cycle INCLUDING the kinematics producer and AutoStack::update, for all "
                    f"{B} robots at once; the reference's figure is one robot's solve alone"}
-    if front_end == "iHQP" and launches:
-        kname = (f"osot_control_cycle_kernel<{NPk}, false, true>" if specialise else f"osot_control_cycle_kernel<{NPk}, false, false>") if one_launch \
-            else (f"osot_cycle_kernel<{NPk}, false, true>" if specialise else f"osot_cycle_kernel<{NPk}, false, false>")
-        traffic, src = pmc_traffic([(kname, B + 1, 1)])
-        rf, rh = roofline_of(plan, B, kern_ms, launches, kname, traffic, src or "no PMC passes committed for this kernel source: null rather than a stale figure")
+    if front_end == "iHQP":
+        kname = (f"osot_control_cycle_kernel<{NPk}, false, {'true' if specialise else 'false'}>" if fused else
+                 f"osot_cycle_kernel<{NPk}, false, {'true' if specialise else 'false'}>")
+        traffic, src = pmc_traffic([(kname, (B // lanes) + 1, lanes)])
+        rf, rh = roofline_of(plan, B, ms, steps * lanes, kname + " (whole step time as the divisor)", traffic,
+                             src or "no PMC passes committed for this kernel source: null rather than a stale figure")
         out["roofline"], out["roofline_hbm"] = rf, rh
-        out["cycle_kernel_avg_ms"] = kern_ms
     else:
         out["roofline"] = hbm_roofline(algo_bytes_per_solve(plan), B, ms, [], "nHQP front-end kernels (see nHQP_C3)")
     return out
@@ -1059,7 +1082,7 @@ def main():
                     oc[key] = {"error": str(e)}
             for which in ("S1", "S2", "S3", "S4"):
                 try:
-                    oc["COMAN35_" + which] = time_coman35(which, 4096, local_rank)
+                    oc["COMAN35_" + which] = time_coman35(which, 4096, local_rank, lanes=S, streams=streams)
                 except Exception as e:
                     oc["COMAN35_" + which] = {"error": str(e)[:300]}
             try:     # the reference's S3 through its null-space front-end (published: 0.3191 ms per solve)

@@ -1,12 +1,12 @@
-"""developer helper (GPU box): the reference's COMAN stacks S1..S4 as closed loops of 4096 robots, with and without the
-instantiation by plan structure (osot_solver_set_specialisation)"""
+"""developer helper (GPU box): the reference's COMAN stacks S1..S4 as closed loops of 4096 robots -- sub-batches (lanes), the
+one-launch control cycle against three launches per step, the instantiation by plan structure on and off"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
 import bench
-for rep in range(2):
-    for which in ("S1", "S2", "S3", "S4"):
-        a = bench.time_coman35(which, 4096, 0, 20, 5, specialise=True)
-        b = bench.time_coman35(which, 4096, 0, 20, 5, specialise=False)
-        c = bench.time_coman35(which, 4096, 0, 20, 5, specialise=True, fused=False)
-        print(which, "one launch, specialised", round(a["value"] / 1e6, 3), "M   general", round(b["value"] / 1e6, 3), "M   three launches, specialised",
-              round(c["value"] / 1e6, 3), "M", a.get("solved_ok"), b.get("solved_ok"), c.get("solved_ok"))
+streams = [torch.cuda.Stream(device=torch.device("cuda", 0)) for _ in range(4)]
+for which in ("S1", "S2", "S3", "S4"):
+    for lanes, fused, spec, graph in ((1, False, True, False), (1, True, True, True), (2, True, True, True), (2, False, True, True), (4, True, True, True), (2, True, False, True)):
+        r = bench.time_coman35(which, 4096, 0, 20, 5, specialise=spec, fused=fused, lanes=lanes, streams=streams, graph=graph)
+        print(which, "lanes", lanes, "one launch" if fused else "three launches", "graph" if graph else "plain", "specialised" if spec else "general",
+              round(r["value"] / 1e6, 3), "M", round(r["ms_per_step"], 4), "ms", r.get("solved_ok"))
