@@ -283,14 +283,18 @@ def parity_report(plan, leaf_sample, dq_dev, xl_dev, slack_dev, tol=1e-6, max_ev
 # ------------------------------------------------------------------------------------------------------------------
 # the other BASELINE configurations and the kinematics producer (after the timed region, rank 0, outside the headline)
 # ------------------------------------------------------------------------------------------------------------------
-def time_config(name, B, device, steps=20, warmup=8, cycles=4, drift=0.01):
+def time_config(name, B, device, steps=20, warmup=8, cycles=4, drift=0.01, lanes=1, streams=None):
     """a BASELINE configuration at its per-GPU size under the HEADLINE'S PROTOCOL: the steps rotate through `cycles` temporally
     coherent control cycles (every input, Jacobians included, moved by `drift` from one to the next), one fused update + cascade
     launch per step, longest-first dispatch from the previous cycles' iteration counts (so the order is a prediction, never a
-    replay of the same cycle)"""
+    replay of the same cycle).  lanes > 1 (with the caller's streams): the headline's SUBMISSION as well -- the batch as sub-batches
+    on their own streams with no join between steps, the timed steps of a sub-batch as one HIP graph
+    (opensot_amd.parallel.PipelinedCycle); plain launches if the capture fails."""
     from opensot_amd import synth
-    from opensot_amd.parallel import ShardedCycle
+    from opensot_amd.parallel import PipelinedCycle, ShardedCycle, lane_ranges
     from opensot_amd.solver import BatchedStack
+    if lanes > 1 and streams is not None and len(streams) >= lanes and steps % 4 == 0:
+        return _time_config_lanes(name, B, device, steps, warmup, cycles, drift, lanes, streams)
     if name == "C5":
         plan, leaf = synth.make_id_stack(B, seed=5000)
     else:
@@ -332,6 +336,68 @@ def time_config(name, B, device, steps=20, warmup=8, cycles=4, drift=0.01):
             "solved_ok": f"{ok}/{B}",
             "protocol": f"the headline's: steps rotate through {cycles} temporally coherent cycles ({100 * drift:.0f} % drift of every input per "
                         "cycle), one fused update + cascade launch per step, cold start, longest-first dispatch predicted from the previous cycles",
+            "roofline": rf, "roofline_hbm": rh}
+
+
+def _time_config_lanes(name, B, device, steps, warmup, cycles, drift, lanes, streams):
+    """time_config with the headline's submission (see there)"""
+    from opensot_amd import synth
+    from opensot_amd.parallel import PipelinedCycle, ShardedCycle, lane_ranges
+    from opensot_amd.solver import BatchedStack
+    if name == "C5":
+        plan, leaf = synth.make_id_stack(B, seed=5000)
+    else:
+        plan, leaf = synth.make_velocity_stack(name, B, seed={"C2": 2000, "C3": 3000, "C4": 4000}[name])
+    rng = np.random.default_rng(77)
+    leaves = [leaf]
+    for _ in range(cycles - 1):
+        leaves.append(synth.perturb(leaves[-1], rng, drift))
+    spans = lane_ranges(B, lanes)
+    stacks, ls = [], []
+    for a, b in spans:
+        stj = BatchedStack(plan, b - a, device=device, want_levels=False)
+        devs, A_sets = [], []
+        for lf in leaves:
+            stj.A = [None if t is None else torch.empty_like(t) for t in stj.A]
+            devs.append(stj.load_leaf(sub_leaf(lf, a, b))); A_sets.append(stj.A)
+        stacks.append(stj)
+        ls.append(ShardedCycle(stj, devs, A_sets, b - a, None))
+    cyc = PipelinedCycle(ls, list(streams[:lanes]))
+    for _ in range(warmup):
+        cyc.step()
+    torch.cuda.synchronize()
+    note, graphed = None, False
+    try:
+        cyc.capture(steps)
+        cyc.replay(); torch.cuda.synchronize()
+        graphed = True
+    except Exception as e:
+        note = f"graph capture unavailable: {e}"[:200]
+    t0 = time.perf_counter()
+    if graphed:
+        cyc.replay()
+    else:
+        for _ in range(steps):
+            cyc.step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ok = sum(int((stj.status[:b - a] == 0).sum().item()) for stj, (a, b) in zip(stacks, spans))
+    NPk = 32 if plan.n <= 32 else (56 if plan.n <= 54 else 64)
+    box = NPk == 32 and plan.nc == 0
+    kname = f"osot_cycle_kernel<{NPk}, false{', true' if box else ', false'}>"
+    traffic, src = pmc_traffic([(kname, (B // lanes) + 1, lanes)])
+    rf, rh = roofline_of(plan, B, 1e3 * el / steps, steps * lanes, kname + " (whole step time as the divisor)", traffic,
+                         src or "no PMC passes committed for this kernel source: null rather than a stale figure")
+    return {"workload": {"C2": "BASELINE configs[1]: 1-level Cartesian + Postural (soft priority), joint-limit box",
+                         "C3": "BASELINE configs[2]", "C4": "BASELINE configs[3] shard: C3 + 16 self-collision rows",
+                         "C5": "BASELINE configs[4] shard: 38-DoF floating-base inverse dynamics, x = [qddot; 4 x 3 forces] (n = 50), "
+                               "102 constraint rows (dynamic feasibility, friction cones, torque limits, acceleration joint limits)"}[name],
+            "batch": B, "lanes": lanes, "n": plan.n, "rows_per_level": [plan.m(k) for k in range(plan.L)], "constraint_rows": plan.nc,
+            "value": B * steps / el, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
+            "solved_ok": f"{ok}/{B}", "note_capture": note,
+            "protocol": f"the headline's: steps rotate through {cycles} temporally coherent cycles ({100 * drift:.0f} % drift of every input per "
+                        f"cycle), one fused update + cascade launch per step, cold start, longest-first dispatch predicted from the previous cycles; {lanes} "
+                        "sub-batches on their own streams with no join between steps" + (f", the {steps} timed steps of a sub-batch as one HIP graph" if graphed else ", plain launches"),
             "roofline": rf, "roofline_hbm": rh}
 
 
@@ -1077,7 +1143,7 @@ def main():
             for key, name, B, st_ in (("C2", "C2", 1024, 20), ("C4", "C4", 4096, 20), ("C5", "C5", 1024, 20),
                                       ("C5_B4096", "C5", 4096, 12)):   # (the last: config 5 beyond the shard size, four rounds of resident wavefronts)
                 try:
-                    oc[key] = time_config(name, B, local_rank, steps=st_)
+                    oc[key] = time_config(name, B, local_rank, steps=st_, lanes=S, streams=streams)
                 except Exception as e:
                     oc[key] = {"error": str(e)}
             for which in ("S1", "S2", "S3", "S4"):
