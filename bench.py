@@ -445,7 +445,9 @@ def time_coman35(which, B, device, steps=20, warmup=5, front_end="iHQP", special
     rng = np.random.default_rng(35)
     K = kin.Kinematics(m, device=device)
     if front_end != "iHQP":
-        lanes, graph, fused = 1, False, False
+        graph, fused = False, False          # (the front-end's host loop launches ten kernels per step: sub-batches, no graphs)
+        if streams is None or len(streams) < lanes:
+            lanes = 1
     work = []
     for a, b in lane_ranges(B, lanes):
         Bl = b - a
@@ -534,7 +536,7 @@ def time_coman35(which, B, device, steps=20, warmup=5, front_end="iHQP", special
     ms = 1e3 * (time.perf_counter() - t0) / steps
     ok = sum(int((st.status[:Bl] == 0).sum().item()) for st, _, _, Bl in work)
     NPk = 32 if plan.n <= 32 else (56 if plan.n <= 54 else 64)
-    how = ("kinematics launch, update launch, osot_nhqp_solve, integration; one stream" if front_end == "nHQP" else
+    how = (f"kinematics launch, update launch, osot_nhqp_solve, integration; {lanes} sub-batch(es) on their own stream(s)" if front_end == "nHQP" else
            (f"{lanes} sub-batches on their own streams, " + ("ONE launch per step and sub-batch (osot_control_cycle)" if fused else
             "kinematics launch + update-and-cascade launch + integration per step") + (f", {steps} steps of a sub-batch per HIP graph" if graphs else ", plain launches")))
     out = {"workload": f"the reference's published workload {which} (examples/cpp/coman_ik.cpp:425-449): COMAN, 35 coordinates, "
@@ -713,29 +715,42 @@ def time_config5_coherent(B, device, steps=40, warmup=8, cycles=4, drift=0.01):
             "hot_vs_cold_max_abs_dq_diff": float(np.abs(dqs[True] - dqs[False]).max())}
 
 
-def time_nhqp(B, device, steps=5, warmup=2):
-    """the null-space front-end (OpenSoT::solvers::nHQP, SURVEY 8f-2) on the C3 stack: update + osot_nhqp_solve"""
+def time_nhqp(B, device, steps=5, warmup=2, lanes=1, streams=None):
+    """the null-space front-end (OpenSoT::solvers::nHQP, SURVEY 8f-2) on the C3 stack: update + osot_nhqp_solve.  lanes > 1 (with the
+    caller's streams): the batch as sub-batches on their own streams -- one sub-batch's level preparation runs under the other's
+    QP / accumulation launches and under the tail of its preparation (tools/exp_frontend_lanes.py: 4.16 -> 4.79 M)"""
     from opensot_amd import synth
+    from opensot_amd.parallel import lane_ranges
     from opensot_amd.solver import BatchedStack
     plan, leaf = synth.make_velocity_stack("C3", B, seed=3000)
-    st = BatchedStack(plan, B, device=device, want_levels=False)
-    dev = st.load_leaf(leaf)
+    if streams is None or len(streams) < lanes:
+        lanes = 1
+    work = []
+    for j, (a, b) in enumerate(lane_ranges(B, lanes)):
+        st = BatchedStack(plan, b - a, device=device, want_levels=False)
+        if lanes > 1:
+            st.stream = streams[j]
+        work.append((st, st.load_leaf(sub_leaf(leaf, a, b) if lanes > 1 else leaf), b - a))
+
+    def step():
+        for st, dv, Bl in work:
+            st.update(dv); st.solve_nhqp(Bl)
     for _ in range(warmup):
-        st.update(dev); st.solve_nhqp(B)
+        step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        st.update(dev); st.solve_nhqp(B)
+        step()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    ok = int((st.status[:B] == 0).sum().item())
+    ok = sum(int((st.status[:Bl] == 0).sum().item()) for st, _, Bl in work)
     return {"workload": "BASELINE configs[2] stack through the reference's null-space front-end (nHQP.cpp:155-204; defaults: A/b "
                         "regularisation at 0.05 sv_max, selective null-space regularisation): per level an SVD of A N (Gram-side "
                         "tridiagonalisation, eigenvalues by Sturm bisection, vectors by twisted factorisation, in LDS), the QP in the nf = 32 / 29 / 5 free coordinates, q += N z, N <- N V2; three launches per level",
-            "batch": B, "value": B * steps / el, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "solved_ok": f"{ok}/{B}",
+            "batch": B, "lanes": lanes, "value": B * steps / el, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "solved_ok": f"{ok}/{B}",
             "roofline": hbm_roofline(algo_bytes_per_solve(plan), B, 1e3 * el / steps,
-                                     [("osot_update_kernel", B, 1), ("osot_nhqp_prepare_kernel<32>", B, plan.L),
-                                      ("osot_qp_kernel<32>", B, plan.L), ("osot_nhqp_accumulate_kernel", B, plan.L)],
+                                     [("osot_update_kernel", B // lanes, lanes), ("osot_nhqp_prepare_kernel<32>", B // lanes, lanes * plan.L),
+                                      ("osot_qp_kernel<32>", B // lanes, lanes * plan.L), ("osot_nhqp_accumulate_kernel", B // lanes, lanes * plan.L)],
                                      "osot_nhqp_prepare_kernel<32> + osot_qp_kernel<32> + osot_nhqp_accumulate_kernel per level (far from "
                                      "both roofs: the level preparation is one wavefront's dependent instruction stream at six wavefronts per CU -- LDS-limited -- and there are nine dependent launches)")}
 
@@ -1152,7 +1167,7 @@ def main():
                 except Exception as e:
                     oc["COMAN35_" + which] = {"error": str(e)[:300]}
             try:     # the reference's S3 through its null-space front-end (published: 0.3191 ms per solve)
-                oc["COMAN35_S3_nHQP"] = time_coman35("S3", 4096, local_rank, steps=6, warmup=2, front_end="nHQP")
+                oc["COMAN35_S3_nHQP"] = time_coman35("S3", 4096, local_rank, steps=6, warmup=2, front_end="nHQP", lanes=S, streams=streams)
             except Exception as e:
                 oc["COMAN35_S3_nHQP"] = {"error": str(e)[:300]}
             try:
@@ -1166,7 +1181,7 @@ def main():
             except Exception as e:
                 oc["C5_coherent"] = {"error": str(e)}
             try:
-                oc["nHQP_C3"] = time_nhqp(4096, local_rank)
+                oc["nHQP_C3"] = time_nhqp(4096, local_rank, lanes=S, streams=streams)
             except Exception as e:
                 oc["nHQP_C3"] = {"error": str(e)}
             try:
