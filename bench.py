@@ -102,6 +102,8 @@ def pmc_traffic(kernels):
     `kernels` = [(substring of the kernel name, workgroups of the launch, launches per step)]; the per-launch FETCH / WRITE
     figures of every (kernel, grid) pair are summed.  Only if the passes were taken on THIS kernel source (hash) and every
     pair is in the table; otherwise (None, None): a stale figure is worse than none."""
+    if not kernels:
+        return None, None
     try:
         pm = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
         if pm.get("kernel_source_sha") != kernel_source_sha():
@@ -553,9 +555,10 @@ def time_coman35(which, B, device, steps=20, warmup=5, front_end="iHQP", special
     if front_end == "iHQP":
         kname = (f"osot_control_cycle_kernel<{NPk}, false, {'true' if specialise else 'false'}>" if fused else
                  f"osot_cycle_kernel<{NPk}, false, {'true' if specialise else 'false'}>")
-        traffic, src = pmc_traffic([(kname, (B // lanes) + 1, lanes)])
-        rf, rh = roofline_of(plan, B, ms, steps * lanes, kname + " (whole step time as the divisor)", traffic,
-                             src or "no PMC passes committed for this kernel source: null rather than a stale figure")
+        # (no PMC traffic here: S1 .. S4 run the same instantiation on the same grid, and the committed PMC table is keyed by
+        #  (kernel, grid) -- it cannot tell the four stacks apart)
+        rf, rh = roofline_of(plan, B, ms, steps * lanes, kname + " (whole step time as the divisor)", None,
+                             "the four COMAN stacks share one kernel instantiation and grid: the (kernel, grid)-keyed PMC table cannot tell them apart")
         out["roofline"], out["roofline_hbm"] = rf, rh
     else:
         out["roofline"] = hbm_roofline(algo_bytes_per_solve(plan), B, ms, [], "nHQP front-end kernels (see nHQP_C3)")
@@ -750,7 +753,7 @@ def time_nhqp(B, device, steps=5, warmup=2, lanes=1, streams=None):
             "batch": B, "lanes": lanes, "value": B * steps / el, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "solved_ok": f"{ok}/{B}",
             "roofline": hbm_roofline(algo_bytes_per_solve(plan), B, 1e3 * el / steps,
                                      [("osot_update_kernel", B // lanes, lanes), ("osot_nhqp_prepare_kernel<32>", B // lanes, lanes * plan.L),
-                                      ("osot_qp_kernel<32>", B // lanes, lanes * plan.L), ("osot_nhqp_accumulate_kernel", B // lanes, lanes * plan.L)],
+                                      ("osot_qp_kernel<32, false>", B // lanes, lanes * plan.L), ("osot_nhqp_accumulate_kernel", B // lanes, lanes * plan.L)],
                                      "osot_nhqp_prepare_kernel<32> + osot_qp_kernel<32> + osot_nhqp_accumulate_kernel per level (far from "
                                      "both roofs: the level preparation is one wavefront's dependent instruction stream at six wavefronts per CU -- LDS-limited -- and there are nine dependent launches)")}
 
