@@ -758,28 +758,40 @@ def time_nhqp(B, device, steps=5, warmup=2, lanes=1, streams=None):
                                      "both roofs: the level preparation is one wavefront's dependent instruction stream at six wavefronts per CU -- LDS-limited -- and there are nine dependent launches)")}
 
 
-def time_ehqp(B, device, steps=10, warmup=3):
-    """the equality-only front-end (OpenSoT::solvers::eHQP, SURVEY 8f-2) on the C3 stack: update + osot_ehqp_solve"""
+def time_ehqp(B, device, steps=10, warmup=3, lanes=1, streams=None):
+    """the equality-only front-end (OpenSoT::solvers::eHQP, SURVEY 8f-2) on the C3 stack: update + osot_ehqp_solve; lanes > 1 (with the
+    caller's streams): the batch as sub-batches on their own streams (the tail of one launch under the other's)"""
     from opensot_amd import synth
+    from opensot_amd.parallel import lane_ranges
     from opensot_amd.solver import BatchedStack
     plan, leaf = synth.make_velocity_stack("C3", B, seed=3000)
-    st = BatchedStack(plan, B, device=device, want_levels=False)
-    dev = st.load_leaf(leaf)
+    if streams is None or len(streams) < lanes:
+        lanes = 1
+    work = []
+    for j, (a, b) in enumerate(lane_ranges(B, lanes)):
+        st = BatchedStack(plan, b - a, device=device, want_levels=False)
+        if lanes > 1:
+            st.stream = streams[j]
+        work.append((st, st.load_leaf(sub_leaf(leaf, a, b) if lanes > 1 else leaf), b - a))
+
+    def step():
+        for st, dv, Bl in work:
+            st.update(dv); st.solve_ehqp(Bl)
     for _ in range(warmup):
-        st.update(dev); st.solve_ehqp(B)
+        step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        st.update(dev); st.solve_ehqp(B)
+        step()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    ok = int((st.status[:B] == 0).sum().item())
+    ok = sum(int((st.status[:Bl] == 0).sum().item()) for st, _, Bl in work)
     return {"workload": "BASELINE configs[2] stack through the reference's equality-only front-end (eHQP.cpp:64-95: damped pseudo-"
                         "inverses and projectors, the box is not used): null-space recursion, per level a pivoted Householder QR of "
                         "W^1/2 A Z (no eigen-decomposition since round 3); all levels of an instance in one launch",
-            "batch": B, "value": B * steps / el, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "solved_ok": f"{ok}/{B}",
+            "batch": B, "lanes": lanes, "value": B * steps / el, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "solved_ok": f"{ok}/{B}",
             "roofline": hbm_roofline(algo_bytes_per_solve(plan), B, 1e3 * el / steps,
-                                     [("osot_update_kernel", B, 1), ("osot_ehqp_qr_kernel<32>", B, 1)],
+                                     [("osot_update_kernel", B // lanes, lanes), ("osot_ehqp_qr_kernel<32>", B // lanes, lanes)],
                                      "osot_ehqp_qr_kernel<32> (all levels of an instance in one launch: row-oriented pivoted Householder QR "
                                      "in LDS, a chain of dependent reflector steps: far from both roofs)")}
 
@@ -1188,7 +1200,7 @@ def main():
             except Exception as e:
                 oc["nHQP_C3"] = {"error": str(e)}
             try:
-                oc["eHQP_C3"] = time_ehqp(4096, local_rank)
+                oc["eHQP_C3"] = time_ehqp(4096, local_rank, lanes=S, streams=streams)
             except Exception as e:
                 oc["eHQP_C3"] = {"error": str(e)}
             try:
