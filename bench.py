@@ -565,7 +565,7 @@ def time_coman35(which, B, device, steps=20, warmup=5, front_end="iHQP", special
     return out
 
 
-def time_full_cycle(B, device, lanes=2, steps=40, warmup=8, streams=None, fused=True):
+def time_full_cycle(B, device, lanes=2, steps=40, warmup=8, streams=None, fused=True, solve_only=False):
     """q -> kinematics -> AutoStack::update + cascade -> q += dq for the 32-DoF humanoid under BASELINE config 3's stack (CoM / l_wrist(0.1)
     + r_wrist + l_sole + r_sole / Postural, joint-limit and velocity-limit box), everything resident, submitted like the headline: the
     batch as `lanes` sub-batches on their own streams, the steps of a lane as ONE HIP graph.  fused: ONE launch per step
@@ -590,6 +590,7 @@ def time_full_cycle(B, device, lanes=2, steps=40, warmup=8, streams=None, fused=
     rng = np.random.default_rng(32)
     K = kin.Kinematics(m, device=device)
     work = []
+    frozen = [False]
     for a, b in lane_ranges(B, lanes):
         Bl = b - a
         q0 = np.zeros((Bl, n))
@@ -624,17 +625,24 @@ def time_full_cycle(B, device, lanes=2, steps=40, warmup=8, streams=None, fused=
 
         def step(fk=fk, st=st, leaf=leaf, q=q, Bl=Bl, stream=stream, kb=kb):
             with torch.cuda.stream(stream):
-                if fused:
+                if solve_only and frozen[0]:   # (diagnostic: update + cascade alone on the posture the closed loop has reached -- what the
+                    st.cycle(leaf, cached=True)   #  solve costs on THIS data, without the producer and the integration)
+                elif fused:
                     st.control_cycle(K, kb, leaf, q_integrate=q)
                 else:
                     fk()
                     st.cycle(leaf, cached=True)
                     q.add_(st.dq[:Bl])
         work.append((st, step, stream, Bl))
-    for _ in range(warmup):
+    for _ in range(warmup + (2 * steps if solve_only else 0)):      # (solve_only: the closed loop runs as long as the timed passes do, then freezes)
         for _, step, _, _ in work:
             step()
     torch.cuda.synchronize()
+    frozen[0] = True
+    if solve_only:
+        for _, step, _, _ in work:
+            step(); step()
+        torch.cuda.synchronize()
     graphs, note = [], None
     try:
         for st, step, stream, _ in work:
@@ -664,6 +672,7 @@ def time_full_cycle(B, device, lanes=2, steps=40, warmup=8, streams=None, fused=
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     ok = sum(int((st.status[:Bl] == 0).sum().item()) for st, _, _, Bl in work)
+    its = torch.cat([st.iterations[:Bl].float() for st, _, _, Bl in work])
     how = ("ONE launch per step (osot_control_cycle_kernel<32,false,true>: the instance's kinematics, update, cascade and q += dq by the same wavefront)"
            if fused else "three launches per step (osot_kin_kernel, osot_cycle_kernel, the integration of q)")
     return {"workload": "full control cycle on the device, BASELINE configs[2] stack on the 32-DoF humanoid: q -> kinematics (4 frame poses + "
@@ -671,6 +680,9 @@ def time_full_cycle(B, device, lanes=2, steps=40, warmup=8, streams=None, fused=
                         f"chasing its own wrist goals; {lanes} sub-batches on their own streams, {steps} steps of a lane per HIP graph" + ("" if graphs else " (plain launches)"),
             "batch": B, "lanes": lanes, "value": B * steps / el, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
             "solved_ok": f"{ok}/{B}", "note": note,
+            "iterations_last_step": {"mean": float(its.mean().item()), "max": int(its.max().item()),
+                                     "note": "active-set iterations per solve in the last step of the loop (the headline's synthetic batch: mean 32, max 63): "
+                                             "this sub-line and the headline do not solve the same problems"},
             "roofline": roofline_of(plan, B, 1e3 * el / steps, steps * lanes, ("osot_control_cycle_kernel<32,false,true>" if fused else
                                     "osot_kin_kernel<false,32> + osot_cycle_kernel<32,false,true> + the integration of q") +
                                     " (whole step time as the divisor)")[0]}
@@ -1189,6 +1201,11 @@ def main():
                 oc["full_cycle"] = time_full_cycle(Bl, local_rank, lanes=S, streams=streams)
                 three = time_full_cycle(Bl, local_rank, lanes=S, streams=streams, fused=False)
                 oc["full_cycle"]["as_three_launches_per_step"] = {"value": three["value"], "ms_per_step": three["ms_per_step"], "solved_ok": three["solved_ok"]}
+                alone = time_full_cycle(Bl, local_rank, lanes=S, streams=streams, solve_only=True)
+                oc["full_cycle"]["update_and_cascade_alone_on_the_posture_the_loop_reached"] = {
+                    "value": alone["value"], "ms_per_step": alone["ms_per_step"], "iterations_mean": alone["iterations_last_step"]["mean"],
+                    "note": "the yardstick for this sub-line: the same launches without the producer and the integration, on the same problems "
+                            "(the headline's synthetic batch is easier: 32 iterations per solve against 38.5 here)"}
             except Exception as e:
                 oc["full_cycle"] = {"error": str(e)[:300]}
             try:
