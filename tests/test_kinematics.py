@@ -124,18 +124,21 @@ def test_kin_desc_checks_without_gpu():
 def test_emulated_kernel_matches_restatement():
     """the kernel body (pointer jumping, ancestor masks, subtree aggregates) run lane by lane on the host emulator"""
     from helpers import emu_kinematics
-    m = kin.humanoid32()
-    rng = np.random.default_rng(6)
-    q = rng.uniform(-1.0, 1.0, (5, m.n))
-    poses, J, com = emu_kinematics(m, q)
-    for i in range(5):
-        o = pykin.forward(m, q[i])
-        for f in range(4):
-            assert np.abs(J[i, 6 * f:6 * f + 6] - o["J"][f]).max() < 1e-13
-            assert np.abs(poses[f][i][:9].reshape(3, 3) - o["frame_R"][f]).max() < 1e-14
-            assert np.abs(poses[f][i][9:] - o["frame_p"][f]).max() < 1e-14
-        assert np.abs(J[i, 24:27] - o["Jcom"]).max() < 1e-14
-        assert np.abs(com[i] - o["com"]).max() < 1e-14
+    forest = kin.humanoid32()       # (round 4: the CoM Jacobian comes from prefix sums over a depth-first numbering -- a second root,
+    forest.parent = list(forest.parent)                       #  the left arm cut loose from the torso, must get its own range of it)
+    forest.parent[forest.names.index("LShSag")] = -1
+    for m in (kin.humanoid32(), forest):
+        rng = np.random.default_rng(6)
+        q = rng.uniform(-1.0, 1.0, (5, m.n))
+        poses, J, com = emu_kinematics(m, q)
+        for i in range(5):
+            o = pykin.forward(m, q[i])
+            for f in range(4):
+                assert np.abs(J[i, 6 * f:6 * f + 6] - o["J"][f]).max() < 1e-13
+                assert np.abs(poses[f][i][:9].reshape(3, 3) - o["frame_R"][f]).max() < 1e-14
+                assert np.abs(poses[f][i][9:] - o["frame_p"][f]).max() < 1e-14
+            assert np.abs(J[i, 24:27] - o["Jcom"]).max() < 1e-14
+            assert np.abs(com[i] - o["com"]).max() < 1e-14
 
 
 def _frame_options_model():
