@@ -5,9 +5,11 @@
 //
 // Why one launch: as three launches per step (kinematics, cycle, the integration) every step of a lane carries two more
 // dependent launch gaps, and -- measured, tools/full_cycle_trace.sh -- the kinematics kernel of one lane takes 57-77 us instead
-// of 17 because the other lane's cascade holds every wavefront slot of the chip while it waits (24.5 M solves/s against the
-// 33.6 M of the cycle alone at BASELINE config 3, B = 4096).  Here the kinematics of an instance is ~8 % more work in front of its
-// own update: no slots to wait for, no gaps, and the rows it writes come back from the CU's own L1 / L2 lines.
+// of 17 because the other lane's cascade holds every wavefront slot of the chip while it waits (BASELINE config 3's stack on the
+// 32-DoF humanoid, 4096 robots in closed loop: 25.1 M solves/s as three launches, 26.2 M as one; update + cascade ALONE on the same
+// problems: 30.6 M).  Here the kinematics of an instance is ~10 % more work in front of its own update: no slots to wait for, no
+// gaps, and the rows it writes come back from the CU's own L1 / L2 lines.  With sub-batches on several streams it pays 4-8 % on the
+// reference's COMAN stacks as well.
 // All three lane layouts (32, 56, 64): the reference's own 35-coordinate COMAN runs its loop body as one launch too.
 #pragma once
 #include <osot_kernels.h>
