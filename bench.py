@@ -341,8 +341,8 @@ def time_config(name, B, device, steps=20, warmup=8, cycles=4, drift=0.01, lanes
             "roofline": rf, "roofline_hbm": rh}
 
 
-def _time_config_lanes(name, B, device, steps, warmup, cycles, drift, lanes, streams):
-    """time_config with the headline's submission (see there)"""
+def _time_config_lanes(name, B, device, steps, warmup, cycles, drift, lanes, streams, hot=False):
+    """time_config with the headline's submission (see there); hot: osot_solver_set_hotstart on every sub-batch"""
     from opensot_amd import synth
     from opensot_amd.parallel import PipelinedCycle, ShardedCycle, lane_ranges
     from opensot_amd.solver import BatchedStack
@@ -358,6 +358,8 @@ def _time_config_lanes(name, B, device, steps, warmup, cycles, drift, lanes, str
     stacks, ls = [], []
     for a, b in spans:
         stj = BatchedStack(plan, b - a, device=device, want_levels=False)
+        if hot:
+            stj.set_hotstart(True)
         devs, A_sets = [], []
         for lf in leaves:
             stj.A = [None if t is None else torch.empty_like(t) for t in stj.A]
