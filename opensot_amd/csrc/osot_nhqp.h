@@ -76,6 +76,8 @@ __device__ __forceinline__ double dot_half(const double* a, int sa, const double
 //  -- loop counters in VGPRs, exec-mask branches, a null check in front of every access through the generic pointers)
 // phase 1 + 2 of sym_eig32: K (k x k symmetric) -> tridiagonal (d, e: one entry per lane, e[c] coupling c - 1 and c as tred2 leaves
 // it) and K <- the accumulated orthogonal transformation Q (A = Q T Q')
+// ACCUM = false: the tridiagonal form only (d, e), K is left in pieces -- for callers that want eigenVALUES alone
+template <bool ACCUM = true>
 __device__ __forceinline__ void sym_tred2_32(double* K, double* E, int k, int c, int h, double& d_out, double& e_out) {
     constexpr double kEps = 2.220446049250313e-16;
     double d = 0.0, e = 0.0;                 // lane j: d[j], e[j]
@@ -157,6 +159,11 @@ __device__ __forceinline__ void sym_tred2_32(double* K, double* E, int k, int c,
             e_i = K[i * kNS + l];
         }
         if (c == i) { e = e_i; d = hv; }
+    }
+    if constexpr (!ACCUM) {       // the diagonal of the tridiagonal form sits on K's diagonal (the accumulation below does not move it)
+        const double kcc = K[c * kNS + c];
+        d_out = scale_pow2((c < k) ? kcc : 0.0, kexp); e_out = scale_pow2(e, kexp);
+        return;
     }
     // ---- accumulate the transformations: K becomes the orthogonal Q
     for (int i = 0; i < k; ++i) {
@@ -291,6 +298,8 @@ __device__ __forceinline__ void sym_eig_finish_32(double* K, double* E, int k, i
 // Eigenvalues closer than 1e-7 |T| to a neighbour (a rank-deficient Gram matrix: the zero cluster; accidental near-multiplicities)
 // make the routine return false BEFORE anything is overwritten, and the caller runs the QL iteration on the same (d, e, Q).
 // d, e as sym_tred2_32 leaves them (e[c] couples c - 1 and c).  On true: K = eigenvectors (columns), d = this lane's eigenvalue.
+// VECTORS = false: the eigenvalues alone (d <- eigenvalue number c, ascending; always succeeds: clusters are no obstacle to counting)
+template <bool VECTORS = true>
 __device__ __forceinline__ bool sym_bisect_32(double* K, double* E, int k, int c, int h, double& d, double e) {
     const bool in = c < k;
     // d[i] -> K[i][32], e2[i] = (coupling i, i + 1)^2 and e[i] -> E[i][32] / E[i][...]: the padding column of the two matrices
@@ -303,12 +312,12 @@ __device__ __forceinline__ bool sym_bisect_32(double* K, double* E, int k, int c
     const double gl = -uniform_d(colmax<32>(in ? -(d - rad) : -INFINITY));
     const double gu = uniform_d(colmax<32>(in ? d + rad : -INFINITY));
     const double anorm = fmax(fabs(gl), fabs(gu));
-    if (!(anorm > 0.0)) return false;                    // the zero matrix: one k-fold cluster
+    if (!(anorm > 0.0)) { if (!VECTORS) d = 0.0; return !VECTORS; }   // the zero matrix: one k-fold cluster (its eigenvalues: zeros)
     const double e2max = uniform_d(colmax<32>(eu * eu));
     const double pivmin = 2.2250738585072014e-308 * fmax(1.0, e2max) * 4.0;
     // (a tridiagonal form that is already diagonal -- the Gram matrix of an orthonormal N at a Postural level is the identity -- is QL's
     //  trivial case and usually one cluster: not worth 15 sweeps to find that out)
-    if (e2max <= 1.0e-28 * anorm * anorm) return false;
+    if (VECTORS && e2max <= 1.0e-28 * anorm * anorm) return false;
     // ---- bisection: lane c looks for eigenvalue number c (ascending); count(x) = eigenvalues below x
     // The two halves of the wave test two abscissae of the same interval per sweep (it shrinks by 3: 36 sweeps for 2^-56).  The count
     // is taken from the signs of the leading principal minors p_i = (d_i - x) p_(i-1) - e_i^2 p_(i-2) (d, e^2 of the matrix scaled
@@ -357,7 +366,7 @@ __device__ __forceinline__ bool sym_bisect_32(double* K, double* E, int k, int c
         if (b1) hi = x1;
         else if (b2) { lo = x1; hi = x2; }
         else lo = x2;
-        if (it == 14) {
+        if (VECTORS && it == 14) {
             // an early look for clusters: two neighbours still in the same interval (3^-15 of the spectrum's width, ~1e-7) after 15
             // sweeps will not separate to the 1e-7 the twisted factorisation needs -- leave now instead of after 36
             const double lo_next = shift_down<32>(lo);
@@ -366,6 +375,7 @@ __device__ __forceinline__ bool sym_bisect_32(double* K, double* E, int k, int c
     }
     lo *= anorm; hi *= anorm;
     const double lam = 0.5 * (lo + hi);
+    if constexpr (!VECTORS) { d = in ? lam : 0.0; return true; }
     // ---- clusters: the twisted factorisation needs separated eigenvalues
     {
         const double nxt = shift_down<32>(lam);
@@ -486,6 +496,21 @@ __device__ __forceinline__ void sym_eig32_fast(double* K, double* E, int k_in, i
     sym_eig_finish_32(K, E, k, c, h, d);
     if (h == 0) { K[c * kNS + 32] = 0.0; E[c * kNS + 32] = 0.0; }      // (the padding columns carried d and e)
     wave_sync();
+}
+
+// The eigenVALUES of K alone (k >= 2): lane c < k (both halves) gets number c in ascending order.  Tridiagonal form without the
+// accumulation of Q, then the bisection sweeps: ~60 % of the full decomposition's clocks at k = 24.  K is destroyed, E's first row
+// and the two padding columns are scratch.  For the level preparation's common case -- a full-rank level from which nothing is
+// lifted -- the singular values are all it needs: the null space then comes from a Householder QR of the level's own rows.
+__device__ __forceinline__ double sym_eigvals32(double* K, double* E, int k_in, int c, int h) {
+    const int k = uniform_i(k_in);
+    double d, e;
+    sym_tred2_32<false>(K, E, k, c, h, d, e);
+    sym_bisect_32<false>(K, E, k, c, h, d, e);
+    wave_sync();
+    if (h == 0) { K[c * kNS + 32] = 0.0; E[c * kNS + 32] = 0.0; }
+    wave_sync();
+    return d;
 }
 
 __device__ __forceinline__ void sym_eig32(double* K, double* E, int k_in, int c, int h) {
@@ -638,6 +663,8 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
     // ---- Gram matrix of the small side
     const bool rowside = m <= nf;
     const int k = rowside ? m : nf;
+    constexpr double kSvNoise = 1.0e-7;
+    auto build_gram = [&]() {
     if (rowside) {          // K[a][c] = <row a, row c> of AN
         const int cm = (c < m) ? c : 0;
         for (int a = 0; a < m; a += 2) {       // (two rows per trip: independent chains; A N is zero beyond column nf and row m)
@@ -654,7 +681,34 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
         }
     }
     wave_sync();
+    };
+    build_gram();
     NHQP_PHASE("gram");
+    // ---- the common case first: a row-side level of full rank from which nothing is lifted needs its singular VALUES only
+    // (sv_max for the selective regularisation, the smallest against the lifting threshold) -- the right singular vectors served
+    // to span the row space of A N, and the rows themselves do that: the Householder orthonormalisation below then starts from
+    // V1 = (A N)' and the completion is the same null space.  Eigenvalues without the accumulation of Q, the twisted
+    // factorisations and V = Q Y: ~60 % of the decomposition's clocks.  If a singular value turns out to be at noise level or
+    // below the lifting threshold, the Gram matrix is rebuilt and the full decomposition runs (the rare case pays twice).
+    // Tried only with the A / b regularisation OFF: with it on, a level whose smallest singular value is under min_sv_ratio of its
+    // largest needs the vectors of the lifted triplets after all -- 65 % of the instances of BASELINE config 3's level 1 (ratios
+    // 0.02 .. 0.09 against the default 0.05) -- and paying twice there cost more than the others gained (nHQP 4.18 -> 3.82 M).
+    bool values_only = false;
+    if (rowside && k >= 10 && nf - ns >= k && !Q.ab_reg) {
+        const double lamv = sym_eigvals32(K, E, k, c, h);
+        const double svc = sqrt(lamv > 0.0 ? lamv : 0.0);
+        const double smax = bcast(svc, k - 1), smin = bcast(svc, 0);       // (ascending: lane k - 1 holds the largest)
+        values_only = smin > 0.0 && smin >= kSvNoise * smax;
+        if (values_only) {
+            if (h == 0 && c < k) { idx[k - 1 - c] = c; sig[k - 1 - c] = svc; }
+            wave_sync();
+        } else {
+            for (int e = lane; e < 32 * kNS; e += 64) K[e] = 0.0;
+            wave_sync();
+            build_gram();
+        }
+    }
+    if (!values_only) {
     sym_eig32_fast(K, E, k, c, h);
     NHQP_PHASE("eig");
     // ---- singular values, sorted descending: pos = number of eigenvalues ahead of mine
@@ -667,6 +721,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
         if (h == 0 && c < k) { idx[pos] = c; sig[pos] = sqrt(lam > 0.0 ? lam : 0.0); }
         wave_sync();
     }
+    }
     const double sv_max = sig[0];
     // ---- right singular vectors on the ROW side (m <= nf).  v_i = AN'u_i / |AN'u_i| only exists for sv_i > 0: for a singular
     // value at round-off level (a rank-deficient level: duplicated or dependent task rows) that product is noise inside the
@@ -676,7 +731,6 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
     // route resolves singular values down to ~1e-8 sv_max) are orthonormalised by Householder reflections H_1 .. H_r'
     // (r' = min(rho, nf - ns)), and every other column of V is taken from the completion Q = H_1 .. H_r' : column j >= r' is
     // Q e_j, orthogonal to v_1 .. v_r'.  The lifted null triplets use Q e_i, the next level's null space Q e_(r + t).
-    constexpr double kSvNoise = 1.0e-7;
     int rho = 0;
     for (int i = 0; i < k; ++i) rho += (sig[i] >= kSvNoise * sv_max && sig[i] > 0.0) ? 1 : 0;
     const int r_next = nf - ns;
@@ -684,7 +738,15 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
     const bool need_refl = rowside && (ns > 0 || (Q.ab_reg && rho < k));
     double* V1 = K;          // K is free now (its diagonal went into sig[]): V1[t][i] = component t of v_i, then reflector i
     if (need_refl) {
-        for (int i = 0; i < nrefl; ++i) {
+        if (values_only) {          // V1 = (A N)': column i = row i of A N (nrefl = m here); the reflections orthonormalise them
+            double t16[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) t16[t] = AN[(2 * t + h) * kNS + c];
+            wave_sync();
+#pragma unroll
+            for (int t = 0; t < 16; ++t) V1[c * kNS + 2 * t + h] = (2 * t + h < nrefl && c < nf) ? t16[t] : 0.0;
+        }
+        for (int i = 0; i < (values_only ? 0 : nrefl); ++i) {
             const int ec = idx[i];
             // (row side: m <= 32; A N is zero beyond row m and E finite there -- fixed-trip product, reads in flight together)
             double vv = halfsum<32>(dot_half<16>(AN + c, kNS, E + ec, kNS, h));
@@ -1046,6 +1108,8 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
     // two rows of the result per trip
     const bool rowside = m <= nf;
     const int k = rowside ? m : nf;
+    constexpr double kSvNoise = 1.0e-7;
+    auto build_gram = [&]() {
     if (rowside) {
         const int cm = (c32 < m) ? c32 : 0;
         for (int a = 0; a < m; a += 2) {
@@ -1080,9 +1144,28 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
         }
     }
     wave_sync();
+    };
+    build_gram();
     for (int e = lane; e < 32 * kNS; e += 64) E[e] = 0.0;
     wave_sync();
     NHQP_PHASE("gram");
+    // (the values-only case first: see the 32-wide kernel)
+    bool values_only = false;
+    if (rowside && k >= 10 && nf - ns >= k && !Q.ab_reg) {
+        const double lamv = sym_eigvals32(K, E, k, c32, h32);
+        const double svc = sqrt(lamv > 0.0 ? lamv : 0.0);
+        const double smax = bcast(svc, k - 1), smin = bcast(svc, 0);
+        values_only = smin > 0.0 && smin >= kSvNoise * smax;
+        if (values_only) {
+            if (c < k) { idx[k - 1 - c] = c; sig[k - 1 - c] = svc; }
+            wave_sync();
+        } else {
+            for (int e = lane; e < 32 * kNS; e += 64) { K[e] = 0.0; E[e] = 0.0; }
+            wave_sync();
+            build_gram();
+        }
+    }
+    if (!values_only) {
     sym_eig32_fast(K, E, k, c32, h32);
     {
         const double kcc = K[c32 * kNS + c32];
@@ -1094,8 +1177,8 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
         if (c < k) { idx[pos] = c; sig[pos] = sqrt(lam > 0.0 ? lam : 0.0); }
         wave_sync();
     }
+    }
     const double sv_max = sig[0];
-    constexpr double kSvNoise = 1.0e-7;
     int rho = 0;
     for (int i = 0; i < k; ++i) rho += (sig[i] >= kSvNoise * sv_max && sig[i] > 0.0) ? 1 : 0;
     const int r_next = nf - ns;
@@ -1116,7 +1199,16 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
         wave_sync();
         for (int e = lane; e < RN * kNS; e += 64) K[e] = 0.0;
         wave_sync();
-        for (int i = 0; i < nrefl; ++i) {
+        if (values_only) {          // V1 = (A N)': column i = row i of A N
+            for (int i0 = 0; i0 < nrefl; i0 += 8) {
+                double t8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t8[u] = AN[(i0 + u) * S + cc];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (i0 + u < nrefl && c < nf) V1[c * kNS + i0 + u] = t8[u];
+            }
+        }
+        for (int i = 0; i < (values_only ? 0 : nrefl); ++i) {
             double vv = ANt_times_Ecol(idx[i]);
             const double nrm2 = colsum<64>((c < nf) ? vv * vv : 0.0);
             double nsq, nrs;

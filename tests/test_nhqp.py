@@ -132,9 +132,12 @@ def test_small_generic_stack_and_no_free_variables(oracle):
     assert L.emu_nhqp_solve(C.byref(pd), C.byref(qb), C.byref(opt)) == abi.ERR_INVALID
 
 
-def _duplicated_row_stack(oracle):
+def _duplicated_row_stack(oracle, wide=False):
+    """wide (round 4): a 12-row first level in 24 variables -- min(rows, free variables) >= 10, where the level preparation first asks
+    for the singular VALUES only (sym_eigvals32), finds one at noise level and falls back to the full decomposition"""
     from oracle import pynhqp
-    plan, leaf = synth.make_generic_stack(5, 12, [4, 5], n_eq=0, n_ineq=3, seed=2, box=0.4)
+    plan, leaf = synth.make_generic_stack(5, 24, [12, 6], n_eq=0, n_ineq=3, seed=3, box=0.4) if wide else \
+        synth.make_generic_stack(5, 12, [4, 5], n_eq=0, n_ineq=3, seed=2, box=0.4)
     asm = oracle.assemble(plan, leaf)
     fv = pynhqp.free_variables(asm)                       # fixed at construction from the full-rank stack (nHQP.cpp:6-117)
     asm["A"][0][:, 3, :] = asm["A"][0][:, 0, :]           # then row 3 of the first level duplicates row 0: rank 3 of 4
@@ -151,13 +154,19 @@ def _check_rank_deficient_level(asm, dq, st, ref):
     assert (st == 0).all() and (ref["status"] == 1).all()
     r_dev = np.einsum("bij,bj->bi", asm["A"][0], dq) - asm["b"][0]
     r_ref = np.einsum("bij,bj->bi", asm["A"][0], ref["dq"]) - asm["b"][0]
-    assert np.abs(r_ref).max() < 1e-5 and np.abs(r_dev).max() < 1e-5
+    # (an instance whose first level runs into the box keeps a residual in the restatement too: the same one up to what the
+    #  implementation-defined null vector of the lifted triplet moves, a few per cent of it)
+    rr, rd = np.abs(r_ref).max(axis=1), np.abs(r_dev).max(axis=1)
+    free = rr < 1e-5
+    assert free.any() and (rd[free] < 1e-5).all()
+    assert (np.abs(rd[~free] - rr[~free]) < 0.1 * rr[~free]).all()
     assert (dq >= asm["l"] - 1e-9).all() and (dq <= asm["u"] + 1e-9).all()
 
 
-def test_rank_deficient_level_emulated(oracle):
+@pytest.mark.parametrize("wide", [False, True])
+def test_rank_deficient_level_emulated(wide, oracle):
     from oracle import pynhqp
-    plan, asm, fv = _duplicated_row_stack(oracle)
+    plan, asm, fv = _duplicated_row_stack(oracle, wide)
     ref = pynhqp.nhqp_solve(asm, backend="qpoases" if oracle.ref_available() else "eiqp", termination_tolerance=10 * 2.221e-16,
                             free_vars=fv)
     dq, st = emu_nhqp(plan, asm, free_vars=fv)
@@ -166,15 +175,18 @@ def test_rank_deficient_level_emulated(oracle):
     # completion the answer is the one without the A/b regularisation (no other singular value is below the threshold
     # here); with a noise vector inside the row space it was 0.2 away
     dq_off, st_off = emu_nhqp(plan, asm, free_vars=fv, ab_regularization=False)
-    assert (st_off == 0).all() and np.abs(dq - dq_off).max() < 1e-4
+    assert (st_off == 0).all()
+    if not wide:          # (the wide stack has instances whose first level runs into the box: there the penalty does move the answer)
+        assert np.abs(dq - dq_off).max() < 1e-4
 
 
 @pytest.mark.gpu
-def test_rank_deficient_level_gpu(oracle, gpu_device):
+@pytest.mark.parametrize("wide", [False, True])
+def test_rank_deficient_level_gpu(wide, oracle, gpu_device):
     import torch
     from oracle import pynhqp
     from opensot_amd.solver import BatchedStack
-    plan, asm, fv = _duplicated_row_stack(oracle)
+    plan, asm, fv = _duplicated_row_stack(oracle, wide)
     B = asm["B"]
     st = BatchedStack(plan, B, device=0)
     st.load_assembled(asm)
