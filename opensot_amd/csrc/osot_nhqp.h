@@ -109,6 +109,9 @@ __device__ __forceinline__ void sym_tred2_32(double* K, double* E, int k, int c,
                 // instead of spending a full reflection on it and leaving QL a cluster of noise-level couplings to iterate on.
                 e_i = 0.0;
                 hv = 0.0;
+                wave_sync();
+                if (wr && c <= l) { K[i * kNS + c] = 0.0; K[c * kNS + i] = 0.0; }     // (no reflector: row / column i say so to whoever
+                wave_sync();                                                           //  applies the stored reflectors later)
             } else {
                 const double f0 = bcast(ai, l);
                 double sq, rs;
@@ -298,9 +301,14 @@ __device__ __forceinline__ void sym_eig_finish_32(double* K, double* E, int k, i
 // Eigenvalues closer than 1e-7 |T| to a neighbour (a rank-deficient Gram matrix: the zero cluster; accidental near-multiplicities)
 // make the routine return false BEFORE anything is overwritten, and the caller runs the QL iteration on the same (d, e, Q).
 // d, e as sym_tred2_32 leaves them (e[c] couples c - 1 and c).  On true: K = eigenvectors (columns), d = this lane's eigenvalue.
-// VECTORS = false: the eigenvalues alone (d <- eigenvalue number c, ascending; always succeeds: clusters are no obstacle to counting)
-template <bool VECTORS = true>
-__device__ __forceinline__ bool sym_bisect_32(double* K, double* E, int k, int c, int h, double& d, double e) {
+// MODE 1: the full decomposition (above).  MODE 0: the eigenvalues alone (d <- eigenvalue number c, ascending; always succeeds:
+// clusters are no obstacle to counting).  MODE 2 (K holds what sym_tred2_32<false> left: the reflectors, not Q): the eigenvalues
+// and the eigenVECTORS of the nl smallest ones only -- those below thr2 times the largest -- as columns 0 .. nl - 1 of E (twisted
+// factorisation, then back-transformed through the stored reflectors); false if the matrix is rank deficient at noise level or
+// one of those eigenvalues sits in a cluster (the caller then takes the full route).
+template <int MODE = 1>
+__device__ __forceinline__ bool sym_bisect_32(double* K, double* E, int k, int c, int h, double& d, double e, double thr2 = 0.0, int* nl_out = nullptr) {
+    constexpr bool VECTORS = MODE != 0;
     const bool in = c < k;
     // d[i] -> K[i][32], e2[i] = (coupling i, i + 1)^2 and e[i] -> E[i][32] / E[i][...]: the padding column of the two matrices
     const double ec = shift_down<32>(e);                 // e[c] <- e[c + 1]: couples c and c + 1
@@ -317,7 +325,7 @@ __device__ __forceinline__ bool sym_bisect_32(double* K, double* E, int k, int c
     const double pivmin = 2.2250738585072014e-308 * fmax(1.0, e2max) * 4.0;
     // (a tridiagonal form that is already diagonal -- the Gram matrix of an orthonormal N at a Postural level is the identity -- is QL's
     //  trivial case and usually one cluster: not worth 15 sweeps to find that out)
-    if (VECTORS && e2max <= 1.0e-28 * anorm * anorm) return false;
+    if (MODE == 1 && e2max <= 1.0e-28 * anorm * anorm) return false;
     // ---- bisection: lane c looks for eigenvalue number c (ascending); count(x) = eigenvalues below x
     // The two halves of the wave test two abscissae of the same interval per sweep (it shrinks by 3: 36 sweeps for 2^-56).  The count
     // is taken from the signs of the leading principal minors p_i = (d_i - x) p_(i-1) - e_i^2 p_(i-2) (d, e^2 of the matrix scaled
@@ -366,7 +374,7 @@ __device__ __forceinline__ bool sym_bisect_32(double* K, double* E, int k, int c
         if (b1) hi = x1;
         else if (b2) { lo = x1; hi = x2; }
         else lo = x2;
-        if (VECTORS && it == 14) {
+        if (MODE == 1 && it == 14) {
             // an early look for clusters: two neighbours still in the same interval (3^-15 of the spectrum's width, ~1e-7) after 15
             // sweeps will not separate to the 1e-7 the twisted factorisation needs -- leave now instead of after 36
             const double lo_next = shift_down<32>(lo);
@@ -376,10 +384,20 @@ __device__ __forceinline__ bool sym_bisect_32(double* K, double* E, int k, int c
     lo *= anorm; hi *= anorm;
     const double lam = 0.5 * (lo + hi);
     if constexpr (!VECTORS) { d = in ? lam : 0.0; return true; }
+    int nl = k;                                          // eigenvectors wanted: all (MODE 1) or the nl smallest (MODE 2)
+    if constexpr (MODE == 2) {
+        constexpr double kNoise2 = 1.0e-14;              // (singular values below 1e-7 of the largest: rank deficient at the Gram route's noise level)
+        const double lmax = bcast(lam, k - 1), lmin = bcast(lam, 0);
+        d = in ? lam : 0.0;
+        if (!(lmin > 0.0) || lmin < kNoise2 * lmax) return false;
+        nl = __builtin_popcountll(wave_ballot(in && h == 0 && lam < thr2 * lmax));
+        if (nl_out) *nl_out = nl;
+        if (nl == 0) return true;
+    }
     // ---- clusters: the twisted factorisation needs separated eigenvalues
     {
         const double nxt = shift_down<32>(lam);
-        const bool close = (c + 1 < k) && (nxt - lam < 1.0e-7 * anorm);
+        const bool close = (c + 1 < k) && (c < nl) && (nxt - lam < 1.0e-7 * anorm);
         if (wave_ballot(close) != 0ull) return false;
     }
     // ---- eigenvector of T for lam: twisted factorisation, lane-local (column c of E holds D+ and then y)
@@ -448,6 +466,42 @@ __device__ __forceinline__ bool sym_bisect_32(double* K, double* E, int k, int c
     //  the first half's in-place writes of y -- harmless in lock-step, and nothing of the second half's is used)
     double sq, rs;
     fast_sqrt_rsqrt(from_half<32>(nrm2, 0), sq, rs);
+    if constexpr (MODE == 2) {
+        // my column of Y normalised in place, then V = H_(k-1) .. H_2 Y for every column at once (lane = column, its entries split
+        // over the halves): tred2 left reflector i as row i of K (u) and column i of K (u / H); what Q would have cost to build
+        // and to multiply is k - 2 dot products and updates of a column here.  Only the first nl columns are used afterwards.
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { const int r = 2 * t + h; const double v = E[r * kNS + c]; if (r < k && in) E[r * kNS + c] = v * rs; }
+        wave_sync();
+        for (int i = 2; i < k; ++i) {
+            const int l = i - 1;
+            double dot = 0.0;
+            for (int base = 0; base <= l; base += 8) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int kk = base + 2 * t + h;
+                    const double u = K[i * kNS + kk], y = E[kk * kNS + c];
+                    dot = fma((kk <= l) ? u : 0.0, y, dot);
+                }
+            }
+            dot = halfsum<32>(dot);
+            for (int base = 0; base <= l; base += 8) {
+                double nv[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int kk = base + 2 * t + h;
+                    nv[t] = fma(-dot, K[kk * kNS + i], E[kk * kNS + c]);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int kk = base + 2 * t + h;
+                    if (kk <= l && in) E[kk * kNS + c] = nv[t];
+                }
+            }
+            wave_sync();
+        }
+        return true;
+    }
     // (my column of Y in registers; Q is zero beyond column k and E holds finite numbers there: fixed trip counts, no masks; two rows
     //  of Q per trip -- independent chains)
     {
@@ -502,11 +556,26 @@ __device__ __forceinline__ void sym_eig32_fast(double* K, double* E, int k_in, i
 // accumulation of Q, then the bisection sweeps: ~60 % of the full decomposition's clocks at k = 24.  K is destroyed, E's first row
 // and the two padding columns are scratch.  For the level preparation's common case -- a full-rank level from which nothing is
 // lifted -- the singular values are all it needs: the null space then comes from a Householder QR of the level's own rows.
+// ... and with the eigenvectors of the eigenvalues below thr2 times the largest as well (the nl smallest, columns 0 .. nl - 1 of E):
+// what regularize_A_b needs of a full-rank level whose smallest singular values it lifts.  false: rank deficient at noise level or
+// a cluster among the lifted ones -- rebuild the Gram matrix and take sym_eig32_fast.  lam: eigenvalue number c (ascending).
+__device__ __forceinline__ bool sym_eig_selected32(double* K, double* E, int k_in, int c, int h, double thr2, double& lam, int& nl) {
+    const int k = uniform_i(k_in);
+    double d, e;
+    sym_tred2_32<false>(K, E, k, c, h, d, e);
+    int nsel = 0;
+    const bool ok = uniform_b(sym_bisect_32<2>(K, E, k, c, h, d, e, thr2, &nsel));
+    wave_sync();
+    if (h == 0) { K[c * kNS + 32] = 0.0; E[c * kNS + 32] = 0.0; }
+    wave_sync();
+    lam = d; nl = uniform_i(nsel);
+    return ok;
+}
 __device__ __forceinline__ double sym_eigvals32(double* K, double* E, int k_in, int c, int h) {
     const int k = uniform_i(k_in);
     double d, e;
     sym_tred2_32<false>(K, E, k, c, h, d, e);
-    sym_bisect_32<false>(K, E, k, c, h, d, e);
+    sym_bisect_32<0>(K, E, k, c, h, d, e);
     wave_sync();
     if (h == 0) { K[c * kNS + 32] = 0.0; E[c * kNS + 32] = 0.0; }
     wave_sync();
@@ -694,11 +763,10 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
     // largest needs the vectors of the lifted triplets after all -- 65 % of the instances of BASELINE config 3's level 1 (ratios
     // 0.02 .. 0.09 against the default 0.05) -- and paying twice there cost more than the others gained (nHQP 4.18 -> 3.82 M).
     bool values_only = false;
-    if (rowside && k >= 10 && nf - ns >= k && !Q.ab_reg) {
-        const double lamv = sym_eigvals32(K, E, k, c, h);
+    if (rowside && k >= 10 && nf - ns >= k) {
+        double lamv; int nlift = 0;
+        values_only = sym_eig_selected32(K, E, k, c, h, Q.ab_reg ? Q.thr * Q.thr * (1.0 + 1.0e-9) : 0.0, lamv, nlift);
         const double svc = sqrt(lamv > 0.0 ? lamv : 0.0);
-        const double smax = bcast(svc, k - 1), smin = bcast(svc, 0);       // (ascending: lane k - 1 holds the largest)
-        values_only = smin > 0.0 && smin >= kSvNoise * smax;
         if (values_only) {
             if (h == 0 && c < k) { idx[k - 1 - c] = c; sig[k - 1 - c] = svc; }
             wave_sync();
@@ -1151,11 +1219,10 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
     NHQP_PHASE("gram");
     // (the values-only case first: see the 32-wide kernel)
     bool values_only = false;
-    if (rowside && k >= 10 && nf - ns >= k && !Q.ab_reg) {
-        const double lamv = sym_eigvals32(K, E, k, c32, h32);
+    if (rowside && k >= 10 && nf - ns >= k) {
+        double lamv; int nlift = 0;
+        values_only = sym_eig_selected32(K, E, k, c32, h32, Q.ab_reg ? Q.thr * Q.thr * (1.0 + 1.0e-9) : 0.0, lamv, nlift);
         const double svc = sqrt(lamv > 0.0 ? lamv : 0.0);
-        const double smax = bcast(svc, k - 1), smin = bcast(svc, 0);
-        values_only = smin > 0.0 && smin >= kSvNoise * smax;
         if (values_only) {
             if (c < k) { idx[k - 1 - c] = c; sig[k - 1 - c] = svc; }
             wave_sync();
