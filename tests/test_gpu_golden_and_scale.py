@@ -245,7 +245,8 @@ def test_inverse_dynamics_full_size(oracle, gpu_device):
 
 
 @pytest.mark.gpu
-def test_bench_rccl_path_with_a_world_of_one(gpu_device):
+@pytest.mark.parametrize("mode", ["graph_captured_collective", "async_two_block_gather"])
+def test_bench_rccl_path_with_a_world_of_one(gpu_device, mode):
     """bench.py's multi-GPU path on the one GPU a test box has (OSOT_BENCH_FORCE_DIST=1): init_process_group("nccl"), one process
     group and one ShardGather per lane on DEVICE tensors, the solver writing dq / status straight into the collective's send
     block, the timing bracket with its barriers.  Every instance solved on "all ranks", and what the collective delivered is
@@ -256,12 +257,17 @@ def test_bench_rccl_path_with_a_world_of_one(gpu_device):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     env.update(OSOT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if mode == "async_two_block_gather":
+        # what a world of MORE than one rank runs by default: plain launches, the collective asynchronous on its group's stream,
+        # two alternating send / receive blocks (ShardGather overlap) -- forced here on the one GPU a test box has
+        env.update(OSOT_GATHER_OVERLAP="1", OSOT_BENCH_DIST_GRAPH="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
                         "--no-other-configs", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    out = json.loads(lines[0])
+    assert len(lines[0]) < 12288 and r.stdout.rstrip().endswith(lines[0])
+    out = json.loads(lines[0], parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
     assert out["n_gpus"] == 1 and out["steps"] == 4
     assert out["solved_ok_all_ranks"] == "4096/4096" and out["solved_ok_rank0"] == "4096/4096"
     assert out["gathered_vs_own_max_abs_dq_diff_rank0"] == 0.0
