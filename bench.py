@@ -921,6 +921,7 @@ def compact_line(out):
     c["value"], c["ms_per_step"] = _num(out.get("value"), 9), _num(out.get("ms_per_step"), 9)
     cfg = dict(out.get("config", {}))
     cfg["workload"] = str(cfg.get("workload", ""))[:300]
+    cfg.pop("protocol", None)
     cfg["parallelism"] = str(cfg.get("parallelism", ""))[:80]
     c["config"] = cfg
     c["solved_ok_rank0"] = out.get("solved_ok_rank0")
@@ -1189,7 +1190,10 @@ def main():
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "host_enqueue_ms_per_step_rank0": host_enqueue_ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: batch={Bl}/GPU x 32-DoF, 3-level iHQP "
+            "config": {"workload": (f"BASELINE configs[2]: batch={Bl}/GPU x 32-DoF, 3-level iHQP (CoM / 4 Cartesian / Postural) + joint & velocity "
+                                    f"limit box, eps factor 1e6; step = AutoStack::update + cascade of every instance, {K} drifting cycles, "
+                                    f"{S} sub-batch stream(s)/GPU" + ("; + RCCL all-gather of dq and status" if use_dist else "")),
+                       "protocol": f"BASELINE configs[2]: batch={Bl}/GPU x 32-DoF, 3-level iHQP "
                                    "(CoM / l_wrist(0.1)+r_wrist+l_sole+r_sole / Postural), joint-limit & "
                                    "velocity-limit box, eps factor 1e6; step = AutoStack::update + cascade solve of every "
                                    f"instance; steps rotate through {K} temporally coherent cycles (1 % input drift per cycle)"

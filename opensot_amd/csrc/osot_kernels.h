@@ -527,7 +527,7 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
 __device__ __forceinline__ long long dispatch_instance(const DevBatch& D, char* smem);   // (below, with the order workgroup)
 
 template <int NP, bool PROF, bool EXTRA = false, bool BOX = false>
-__global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : 1)) osot_cascade_kernel(const DevPlan P, const DevBatch D) {
+__global__ void __launch_bounds__(64, (NP <= 40 ? OSOT_WAVES32 : 1)) osot_cascade_kernel(const DevPlan P, const DevBatch D) {
     OSOT_DYNAMIC_LDS(osot_smem);
     const long long inst = dispatch_instance(D, osot_smem);
     if (inst < 0) return;
@@ -1138,7 +1138,7 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
 // HBM arrays (they are outputs of the update in their own right) but come back from the CU's own L1 / L2 lines; what is
 // saved is a launch, its tail and the gap between the two (18 + ~4 us of a 227 us step at BASELINE config 3).
 template <int NP, bool EXTRA = false, bool BOX = false>
-__global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : 1)) osot_cycle_kernel(const DevUpdate U, const DevPlan P, const DevBatch D) {
+__global__ void __launch_bounds__(64, (NP <= 40 ? OSOT_WAVES32 : 1)) osot_cycle_kernel(const DevUpdate U, const DevPlan P, const DevBatch D) {
     OSOT_DYNAMIC_LDS(osot_smem);
     const long long inst = dispatch_instance(D, osot_smem);
     if (inst < 0) return;

@@ -69,6 +69,7 @@ int ensure_lds(K kernel, size_t bytes) {
 template <typename F>
 static inline auto by_np(int T, F&& f) {
     if (T == 32) return f(std::integral_constant<int, 32>{});
+    if (T == 40) return f(std::integral_constant<int, 40>{});
     if (T == 56) return f(std::integral_constant<int, 56>{});
     return f(std::integral_constant<int, 64>{});
 }

@@ -98,16 +98,21 @@ struct WaveCtx {
     static constexpr int LW = (NP <= 32) ? 32 : 64;        // lanes per half
     static constexpr int HV = 64 / LW;
     static constexpr int S = NP + 1;
-    static constexpr int ROWS = (NP == 56) ? NP + 1 : NP;  // rows of M2 that exist
-    static constexpr int NMAX = (NP == 56) ? 54 : NP;      // largest n of this instantiation
+    // PH ("phantom" layouts, NP = 56 and -- round 5 -- NP = 40 for n <= 38: the reference's own 35-coordinate COMAN; its 80-register
+    // factorisation arrays and 22 KB LDS slice run at TWO wavefronts per SIMD where the 56-lane layout runs at one)
+    static constexpr bool PH = (NP > 32 && NP < 64);
+    static constexpr int ROWS = PH ? NP + 1 : NP;          // rows of M2 that exist
+    static constexpr int NMAX = PH ? NP - 2 : NP;          // largest n of this instantiation
     // packed R: 560 doubles for NP = 32, 2144 for NP = 64 (the packed L of factor_rows64, 2080, fits too); NP = 56: the packed
     // L of the 56 padded rows, 1596 (R of n <= 54 columns needs 1539)
-    static constexpr int M1_DOUBLES = (NP == 56) ? (56 * 57) / 2 : NP * (NP + 3) / 2;
+    static constexpr int M1_DOUBLES = PH ? (NP * (NP + 1)) / 2 : NP * (NP + 3) / 2;
+    // elements in flight per trip of the mat-vec passes / the stored-row walk (divisors of NP, multiples of 4)
+    static constexpr int DOT_CH = (NP == 56) ? 28 : ((NP == 40) ? 20 : 16);
     static constexpr int LDS_DOUBLES = M1_DOUBLES + ROWS * S + 4 * LW;   // M1, M2, V (four staging vectors of LW)
-    __device__ static __forceinline__ int col_of(int lane) { return (NP == 56) ? ((lane < 56) ? lane : 56) : lane % NP; }
-    __device__ static __forceinline__ int half_of(int lane) { return (NP == 56) ? 0 : lane / NP; }
+    __device__ static __forceinline__ int col_of(int lane) { return PH ? ((lane < NP) ? lane : NP) : lane % NP; }
+    __device__ static __forceinline__ int half_of(int lane) { return PH ? 0 : lane / NP; }
     // the wavefront position of lane (c, h): recomputed from the coordinates where they determine it (no extra live register)
-    __device__ static __forceinline__ int lane_of(int c, int h) { return (NP == 56) ? phys_lane() : c + LW * h; }
+    __device__ static __forceinline__ int lane_of(int c, int h) { return PH ? phys_lane() : c + LW * h; }
     int c, h;       // column index and half of this lane
     int n;
     double* M1;
@@ -162,7 +167,7 @@ __device__ __forceinline__ double jt_rows_dot(const WaveCtx<NP>& w, const double
 #define OSOT_DOT_CH56 28    // elements in flight per trip of the 56-row layout (a divisor of 56, a multiple of 4): one wavefront per
                             // SIMD hides an LDS round trip with loads in flight only -- 8 per trip: 579 us per config-5 launch, 28: 562
 #endif
-    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = (NP % 16 == 0) ? OSOT_DOT_CH : OSOT_DOT_CH56;
+    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = (NP % 16 == 0) ? OSOT_DOT_CH : ((NP == 56) ? OSOT_DOT_CH56 : WaveCtx<NP>::DOT_CH);
     const double* row = w.M2 + w.c * S + w.h;
     const double* v = vec + w.h;
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
@@ -184,7 +189,7 @@ __device__ __forceinline__ double jt_rows_dot(const WaveCtx<NP>& w, const double
 // z_c = sum_j JT[j][c] * vec[j]   (column walk, j split over the halves)
 template <int NP>
 __device__ __forceinline__ double jt_cols_dot(const WaveCtx<NP>& w, const double* vec) {
-    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = (NP % 16 == 0) ? OSOT_DOT_CH : OSOT_DOT_CH56;
+    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = (NP % 16 == 0) ? OSOT_DOT_CH : ((NP == 56) ? OSOT_DOT_CH56 : WaveCtx<NP>::DOT_CH);
     const double* col = w.M2 + w.h * S + w.c;
     const double* v = vec + w.h;
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
@@ -208,7 +213,7 @@ __device__ __forceinline__ double jt_cols_dot(const WaveCtx<NP>& w, const double
 // above all at one wavefront per SIMD -- are shared, each element feeds two accumulator sets.
 template <int NP>
 __device__ __forceinline__ void jt_rows_dot2(const WaveCtx<NP>& w, const double* va, const double* vb, double& da, double& db) {
-    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = (NP == 32) ? 8 : ((NP == 56) ? 28 : 16);
+    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = (NP == 32) ? 8 : WaveCtx<NP>::DOT_CH;
     const double* row = w.M2 + w.c * S + w.h;
     const double* pa = va + w.h;
     const double* pb = vb + w.h;
@@ -231,7 +236,7 @@ __device__ __forceinline__ void jt_rows_dot2(const WaveCtx<NP>& w, const double*
 }
 template <int NP>
 __device__ __forceinline__ void jt_cols_dot2(const WaveCtx<NP>& w, const double* va, const double* vb, double& za, double& zb) {
-    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = (NP == 32) ? 8 : ((NP == 56) ? 28 : 16);
+    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = (NP == 32) ? 8 : WaveCtx<NP>::DOT_CH;
     const double* col = w.M2 + w.h * S + w.c;
     const double* pa = va + w.h;
     const double* pb = vb + w.h;
@@ -258,7 +263,7 @@ template <int NP>
 __device__ __forceinline__ void householder_apply2(const WaveCtx<NP>& w, const double* va, const double* vb, double wa, double wb, int iq) {
     constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
     const int c = w.c, h = w.h, n = w.n;
-    constexpr int RT = (NP == 64) ? 16 : ((NP == 56) ? 8 : 4);
+    constexpr int RT = (NP == 64) ? 16 : (WaveCtx<NP>::PH ? 8 : 4);
     constexpr int TRIP = RT * HV;
     for (int jj = iq & ~(TRIP - 1); jj < n; jj += TRIP) {
         double* mrow = w.M2 + (jj + h) * S + c;
@@ -318,7 +323,7 @@ __device__ __forceinline__ void householder_add(const WaveCtx<NP>& w, double d, 
     // only loads in flight hide the LDS latency there, and it has the registers for 16).  The start is rounded
     // DOWN to a multiple of the trip size: the extra rows j < iq have V2[j] = 0 (exact no-op) and every access
     // stays inside the NP rows of M2, so the loop needs no predicates and its LDS reads overlap.
-    constexpr int RT = (NP == 64) ? 16 : ((NP == 56) ? 8 : 4);
+    constexpr int RT = (NP == 64) ? 16 : (WaveCtx<NP>::PH ? 8 : 4);
     constexpr int TRIP = RT * HV;
     for (int jj = iq & ~(TRIP - 1); jj < n; jj += TRIP) {
         double* mrow = w.M2 + (jj + h) * S + c;
@@ -893,6 +898,62 @@ __device__ inline bool direction_is_independent(const WaveCtx<NP>& w, double nd2
     return best > kDepFloor2 * nn;
 }
 
+
+// ITERATIVE REFINEMENT OF THE ITERATE ONTO THE WORKING SET (round 5).  x is built up as x0 + sum t z, and at the reference's
+// default eps (J spans ten decades) the equalities it is supposed to satisfy -- the optimality rows A_j x = A_j x_prev above all --
+// are met to ~1e-11 only; when those rows leave little or no freedom that residual, divided by their smallest singular value,
+// is a displacement of 1e-6 .. 1e-5, and an inequality that was ACTIVE at the level above re-appears violated by that much with
+// its normal in the span of the working set (tests/golden/default_eps_accepted_slack_instance.npz: 25 optimality rows in 25
+// variables, 4.2e-7).  In exact arithmetic that cannot happen (x_prev is feasible and satisfies every equality), so before a
+// level accepts such a violation as round-off it takes the round-off out: the residuals rho_q of all iq members of the working
+// set at the current x (equalities: lo - a'x, or a'(x_prev - x) for an optimality row; active inequalities: minus their
+// slack), R'y = rho by forward substitution, x += J1 y -- the minimum-H-norm correction onto the manifold.  Cold path: a few
+// instances per thousand at the default eps, none at the benchmark's.
+#ifndef OSOT_REFINE_FLOOR
+#define OSOT_REFINE_FLOOR 1.0e-9
+#endif
+constexpr double kRefineFloor = OSOT_REFINE_FLOOR;   // violations below this (relative to max(1, |bound|)) are accepted without a refinement
+constexpr int kRefineMax = 2;             // refinements per level
+template <int NP, bool BOX>
+__device__ __forceinline__ double refine_on_working_set(const WaveCtx<NP>& w, double x, int iq, int Aq, double lb, double ub, double xprev) {
+    const int c = w.c, h = w.h, n = w.n;
+    double rho = 0.0;
+#pragma unroll 1
+    for (int q = 0; q < iq; ++q) {
+        const int code = bcast_i(Aq, q);
+        double rq;
+        if (code <= -2) {
+            const int r = -2 - code;
+            const double a = row_elem<NP>(w, r, c);
+            const double xref = (uniform_i(w.rsrc[r]) >= 0) ? xprev : 0.0;
+            rq = uniform_d(w.rlo[r]) + uniform_d(colsum<NP>(a * (xref - x)));
+        } else if (BOX || code < 2 * n) {
+            const int var = (code < n) ? code : code - n;
+            rq = bcast((code < n) ? (lb - x) : (x - ub), var);
+        } else {
+            const int r = (code - 2 * n) >> 1;
+            const double a = row_elem<NP>(w, r, c);
+            const double ax = uniform_d(colsum<NP>(a * x));
+            rq = (code & 1) ? (ax - uniform_d(w.rup[r])) : (uniform_d(w.rlo[r]) - ax);
+        }
+        if (c == q) rho = rq;
+    }
+    const bool in = c < iq;
+    double e = in ? rho : 0.0, y = 0.0;
+    const double rinv = in ? fast_rcp(w.M1[ridx<NP>(c, c)]) : 0.0;
+#pragma unroll 1
+    for (int i = 0; i < iq; ++i) {
+        const double yi = bcast(e * rinv, i);
+        if (c == i) y = yi;
+        if (in && c > i) e = fma(-w.M1[ridx<NP>(i, c)], yi, e);
+    }
+    // dx = J1 y, one column of J per trip (cold path: no unrolled LDS batches -- their registers would be the hot kernels')
+    double dx = 0.0;
+#pragma unroll 1
+    for (int j = 0; j < iq; ++j) dx = fma(w.M2[j * WaveCtx<NP>::S + c], bcast(y, j), dx);
+    return (c < n) ? x + dx : x;
+}
+
 // BOX: the instantiation for problems whose ONLY inequalities are the bounds l <= x <= u (a plan without constraint rows: every
 // row of the table is an optimality row, i.e. an equality -- BASELINE configs 2 and 3): the candidate of a trip is a bound
 // by construction, so the row classification, the unit-row and stored-row scans, the fetch of a row normal and every
@@ -1264,6 +1325,11 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
                 OSOT_SUB_END(PH_EQ_Z);
                 const double wb = zb - alphab * fma(-beta * va_next, wa, m_iq1);                   // (J2 H_a) v_b
                 householder_apply2<NP>(w, V2p, V0, wa, wb, iq);
+                if (h == 0) {   // the pair's two columns of R (refine_on_working_set)
+                    if (c < iq) { M1[ridx<NP>(c, iq)] = d; M1[ridx<NP>(c, iq + 1)] = dbp; }
+                    else if (c == iq) { M1[ridx<NP>(iq, iq)] = alpha; M1[ridx<NP>(iq, iq + 1)] = dbp; }
+                    else if (c == iq + 1) M1[ridx<NP>(iq + 1, iq + 1)] = alphab;
+                }
                 OSOT_SUB_END(PH_EQ_HH);
                 if (c == iq) Aq = -2 - r;
                 if (c == iq + 1) Aq = -2 - rb;
@@ -1276,7 +1342,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
                 const double z = jt_cols_dot<NP>(w, V1);
                 x += ta * z;
                 OSOT_SUB_END(PH_EQ_Z);
-                householder_add<NP, false>(w, d, d2, z, nd2, iq);   // equality columns of R are never read
+                householder_add<NP, true>(w, d, d2, z, nd2, iq);    // (the equality columns of R: read by refine_on_working_set only)
                 OSOT_SUB_END(PH_EQ_HH);
                 if (c == iq) Aq = -2 - r;
                 iq++;
@@ -1379,6 +1445,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
     double hm_bnd = 0.0;
     int hm_state = 0;
     unsigned long long hm_ptr = 0ull;
+    int refine_left = kRefineMax;
     constexpr double kHotDropTol = 1.0e-13;   // a multiplier below -kHotDropTol max|u| is negative (above: round-off of zero)
     for (;;) {
         OSOT_SUB_BEGIN();
@@ -1503,7 +1570,7 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
 #ifndef OSOT_SCAN_SC56
 #define OSOT_SCAN_SC56 28   // (the 56-row layout: 28 loads per trip of the row walk -- two trips for n = 50 instead of four: 565 -> 546-553 us per config-5 launch; 52: 572)
 #endif
-                constexpr int SC = (NP == 56) ? OSOT_SCAN_SC56 : OSOT_SCAN_SC;
+                constexpr int SC = (NP == 56) ? OSOT_SCAN_SC56 : ((NP == 40) ? 20 : OSOT_SCAN_SC);
                 for (; cc + SC <= n; cc += SC) {
                     double e[SC];
 #pragma unroll
@@ -1680,6 +1747,12 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
                 const double bmag = ip_box ? fabs(bcast((ip < n) ? lb : ub, ip_var))
                                            : fabs(uniform_d((ip & 1) ? w.rup[ip_row] : w.rlo[ip_row]));
                 if (-s_ip <= fmin(kSlackTol * fmax(1.0, bmag), kSlackCap)) {
+                    if (!diag_dd && refine_left > 0 && -s_ip > kRefineFloor * fmax(1.0, bmag)) {
+                        // round-off of the iterate, not of the problem: put x back onto the working set and scan again
+                        refine_left--;
+                        x = refine_on_working_set<NP, BOX>(w, x, iq, Aq, lb, ub, xprev);
+                        degenerate_done = true; break;
+                    }
                     // accepted as satisfied: the LOWER levels must accept the same point (their optimality rows pin x
                     // to it), so the bound is relaxed by what was accepted for the rest of this instance's cascade --
                     // otherwise they find the constraint violated by that much, trade it against a bound and end

@@ -45,11 +45,13 @@ extern "C" __attribute__((visibility("default"))) int emu_ihqp_solve(const osot_
     for (int k = 0; k < plan->n_levels; ++k) extra = extra || b->WA[k] != nullptr;
     if (want_box && want_box[0] == '1' && !extra && (P.nc == 0 ? T == 32 : plan_rows_all_equalities(*plan))) {
         if (T == 32) emu::launch(osot_cascade_kernel<32, false, false, true>, grid, lds, 64, P, D);
+        else if (T == 40) emu::launch(osot_cascade_kernel<40, false, false, true>, grid, lds, 64, P, D);
         else if (T == 56) emu::launch(osot_cascade_kernel<56, false, false, true>, grid, lds, 64, P, D);
         else emu::launch(osot_cascade_kernel<64, false, false, true>, grid, lds, 64, P, D);
         return OSOT_OK + 100;   // (tells the test that the BOX instantiation ran)
     }
     if (T == 32) emu::launch(osot_cascade_kernel<32, false, true>, grid, lds, 64, P, D);
+    else if (T == 40) emu::launch(osot_cascade_kernel<40, false, true>, grid, lds, 64, P, D);
     else if (T == 56) emu::launch(osot_cascade_kernel<56, false, true>, grid, lds, 64, P, D);
     else emu::launch(osot_cascade_kernel<64, false, true>, grid, lds, 64, P, D);
     return OSOT_OK;

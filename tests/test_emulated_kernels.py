@@ -151,12 +151,13 @@ def test_inverse_dynamics_stack_properties(oracle):
 
 
 @pytest.mark.parametrize("n,rows,n_eq,n_ineq", [(7, [6], 0, 0), (7, [3, 3], 1, 2), (20, [5, 6], 4, 6), (31, [10, 12], 3, 0),
-                                                (33, [8, 10], 2, 4), (48, [12, 16], 3, 6), (54, [12, 20], 4, 8),
+                                                (33, [8, 10], 2, 4), (35, [3, 12, 16], 3, 5), (38, [10, 14], 3, 6), (39, [10, 14], 3, 6),
+                                                (48, [12, 16], 3, 6), (54, [12, 20], 4, 8),
                                                 (55, [12, 20], 4, 8), (64, [16, 24], 5, 10)])
 def test_small_generic_cascades(n, rows, n_eq, n_ineq, oracle):
     """n < 32 goes through the guarded (FULLN = false) instantiation: Panda-like 7-variable stacks
     (examples/cpp/panda_ik.cpp shape) and mid-size generic stacks with equality and inequality rows; 33 .. 54 variables
-    through the 64-lane solver with the short LDS layout (WaveCtx<56>: 54 is its last size), 55 .. 64 through the full one"""
+    through the 64-lane solver with the short LDS layouts (WaveCtx<40>: 33 .. 38, WaveCtx<56>: 39 .. 54), 55 .. 64 through the full one"""
     plan, leaf = synth.make_generic_stack(5, n, rows, n_eq=n_eq, n_ineq=n_ineq, seed=n)
     asm = oracle.assemble(plan, leaf)
     dq, xl, st, it = emu_cascade(plan, asm)
@@ -430,6 +431,18 @@ def test_default_eps_stuck_instances(mode, oracle):
                                                             ("qpOASES", rd["dq"][i], rd["status"][i] == 1),
                                                             ("eiQuadProg", re_["dq"][i], re_["status"][i] == 1)])
             assert ok, (i, why)
+
+
+def test_accepted_slack_instance():
+    """tests/golden/default_eps_accepted_slack_instance.npz on the emulator (the hardware's round-off is what trips it; see
+    tests/test_gpu_cascade.py::test_accepted_slack_instance_gpu)"""
+    from helpers import accepted_slack_instance
+    plan, asm, wit = accepted_slack_instance()
+    dq, xl, st, it = emu_cascade(plan, asm)
+    assert st[0] == 0
+    ok, why = answer_is_acceptable(asm, 0, dq[0], wit)
+    assert ok, why
+    assert emu_cascade.last_accepted_slack[0] <= 1.0e-7
 
 
 def test_collision_instance_from_the_closed_loop(oracle):

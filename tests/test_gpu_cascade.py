@@ -401,6 +401,24 @@ def test_default_eps_stuck_instances_gpu(mode, oracle, gpu_device):
 
 
 @pytest.mark.gpu
+def test_accepted_slack_instance_gpu(gpu_device):
+    """tests/golden/default_eps_accepted_slack_instance.npz: the instance of round 4's randomised sweep on which the
+    kernel accepted a 4.2e-7 violation of a global inequality row as round-off of the levels above (default eps) and ended 1.6e-6
+    from qpOASES: the literal rule -- within 1e-6 of a witness, or feasible to 1e-7 and lexicographically not worse -- must hold,
+    and whatever the kernel accepts it reports (accepted_slack) and keeps below the rule's 1e-7"""
+    from helpers import accepted_slack_instance, answer_is_acceptable
+    plan, asm, wit = accepted_slack_instance()
+    st = BatchedStack(plan, 1, device=0)
+    st.load_assembled(asm); st.solve(1)
+    torch.cuda.synchronize()
+    assert int(st.status[0].item()) == 0
+    dq = st.dq[:1].cpu().numpy()
+    ok, why = answer_is_acceptable(asm, 0, dq[0], wit)
+    assert ok, why
+    assert float(st.accepted_slack[0].item()) <= 1.0e-7
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg", ["C3", "C4", "C5"])
 def test_hot_start_gpu(cfg, oracle, gpu_device):
     """osot_solver_set_hotstart (reference: QPOasesBackEnd.cpp:258-285 hotstart -> SQProblem.cpp:149-193): every level's
