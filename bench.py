@@ -329,7 +329,7 @@ def time_config(name, B, device, steps=20, warmup=8, cycles=4, drift=0.01, lanes
     kern_ms, launches = st.kernel_time_ms()
     st.set_timing(False)
     ok = int((st.status[:B] == 0).sum().item())
-    NPk = 32 if plan.n <= 32 else (56 if plan.n <= 54 else 64)   # the cascade instantiation make_dev_plan picks (osot_host_plan.h)
+    NPk = 32 if plan.n <= 32 else (40 if plan.n <= 38 else (56 if plan.n <= 54 else 64))   # the cascade instantiation make_dev_plan picks (osot_host_plan.h)
     box = NPk == 32 and plan.nc == 0     # plans without constraint rows run the BOX instantiation (osot_solver_set_specialisation)
     kname = f"osot_cycle_kernel<{NPk}, false{', true' if box else (', false' if NPk == 32 else '')}>"
     traffic, src = pmc_traffic([(kname, B + 1, 1)])
@@ -392,7 +392,7 @@ def _time_config_lanes(name, B, device, steps, warmup, cycles, drift, lanes, str
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     ok = sum(int((stj.status[:b - a] == 0).sum().item()) for stj, (a, b) in zip(stacks, spans))
-    NPk = 32 if plan.n <= 32 else (56 if plan.n <= 54 else 64)
+    NPk = 32 if plan.n <= 32 else (40 if plan.n <= 38 else (56 if plan.n <= 54 else 64))
     box = NPk == 32 and plan.nc == 0
     kname = f"osot_cycle_kernel<{NPk}, false{', true' if box else ', false'}>"
     traffic, src = pmc_traffic([(kname, (B // lanes) + 1, lanes)])
@@ -545,7 +545,7 @@ def time_coman35(which, B, device, steps=20, warmup=5, front_end="iHQP", special
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / steps
     ok = sum(int((st.status[:Bl] == 0).sum().item()) for st, _, _, Bl in work)
-    NPk = 32 if plan.n <= 32 else (56 if plan.n <= 54 else 64)
+    NPk = 32 if plan.n <= 32 else (40 if plan.n <= 38 else (56 if plan.n <= 54 else 64))
     how = (f"kinematics launch, update launch, osot_nhqp_solve, integration; {lanes} sub-batch(es) on their own stream(s)" if front_end == "nHQP" else
            (f"{lanes} sub-batches on their own streams, " + ("ONE launch per step and sub-batch (osot_control_cycle)" if fused else
             "kinematics launch + update-and-cascade launch + integration per step") + (f", {steps} steps of a sub-batch per HIP graph" if graphs else ", plain launches")))

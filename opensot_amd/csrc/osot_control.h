@@ -31,7 +31,7 @@ constexpr size_t control_kin_lds_bytes(int NP) {
 }
 
 template <int NP, bool EXTRA = false, bool BOX = false>
-__global__ void __launch_bounds__(64, (NP <= 40 ? OSOT_WAVES32 : 1)) osot_control_cycle_kernel(const DevUpdate U, const DevPlan P, const DevBatch D, const DevControl F) {
+__global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : (NP == 40 ? OSOT_WAVES40 : 1))) osot_control_cycle_kernel(const DevUpdate U, const DevPlan P, const DevBatch D, const DevControl F) {
     OSOT_DYNAMIC_LDS(osot_smem);
     const long long inst = dispatch_instance(D, osot_smem);
     if (inst < 0) return;

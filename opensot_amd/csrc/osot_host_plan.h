@@ -224,7 +224,11 @@ inline int make_dev_plan(const osot_plan_desc& p, const unsigned char* level_act
     P.reg_dense = (p.has_regularisation && p.regularisation_dense) ? 1 : 0;
     // 56: the 64-lane solver with the LDS of n <= 54, four wavefronts per CU instead of three (osot_qp_core.h, WaveCtx)
     // 40 (round 5): the same for n <= 38 (the reference's 35-coordinate COMAN) -- two wavefronts per SIMD
+#ifdef OSOT_X_NO_NP40   // developer knob (A/B builds)
+    NP = (p.n <= 32) ? 32 : ((p.n <= WaveCtx<56>::NMAX) ? 56 : 64);
+#else
     NP = (p.n <= 32) ? 32 : ((p.n <= WaveCtx<40>::NMAX) ? 40 : ((p.n <= WaveCtx<56>::NMAX) ? 56 : 64));
+#endif
     // cascade layout: M1, M2, V | rlo, rup, rptr | rowstate, eqlist | rsrc bytes
     const int cap = ((nrows_max > 0 ? nrows_max : 1) + 1) & ~1;
     int total = ((NP == 32 ? WaveCtx<32>::LDS_DOUBLES : (NP == 40 ? WaveCtx<40>::LDS_DOUBLES : (NP == 56 ? WaveCtx<56>::LDS_DOUBLES : WaveCtx<64>::LDS_DOUBLES))) + 1) & ~1;

@@ -30,6 +30,9 @@
                          // measured: 43 spilled registers make every wave 10 % slower, and a batch of 4096 still needs two
                          // jobs on 1536 of the slots -- launch 168 us against 166 us, bench step 0.229 ms against 0.218 ms
 #endif
+#ifndef OSOT_WAVES40
+#define OSOT_WAVES40 2   // waves per SIMD the NP = 40 instantiations (33 .. 38 variables) are compiled for
+#endif
 #define OSOT_KMAX_LEVELS 8
 #define OSOT_KMAX_TASKS 8
 #define OSOT_KMAX_FLAT_TASKS 24
@@ -527,7 +530,7 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
 __device__ __forceinline__ long long dispatch_instance(const DevBatch& D, char* smem);   // (below, with the order workgroup)
 
 template <int NP, bool PROF, bool EXTRA = false, bool BOX = false>
-__global__ void __launch_bounds__(64, (NP <= 40 ? OSOT_WAVES32 : 1)) osot_cascade_kernel(const DevPlan P, const DevBatch D) {
+__global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : (NP == 40 ? OSOT_WAVES40 : 1))) osot_cascade_kernel(const DevPlan P, const DevBatch D) {
     OSOT_DYNAMIC_LDS(osot_smem);
     const long long inst = dispatch_instance(D, osot_smem);
     if (inst < 0) return;
@@ -1138,7 +1141,7 @@ __global__ void __launch_bounds__(64) osot_update_kernel(const DevUpdate U) {
 // HBM arrays (they are outputs of the update in their own right) but come back from the CU's own L1 / L2 lines; what is
 // saved is a launch, its tail and the gap between the two (18 + ~4 us of a 227 us step at BASELINE config 3).
 template <int NP, bool EXTRA = false, bool BOX = false>
-__global__ void __launch_bounds__(64, (NP <= 40 ? OSOT_WAVES32 : 1)) osot_cycle_kernel(const DevUpdate U, const DevPlan P, const DevBatch D) {
+__global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : (NP == 40 ? OSOT_WAVES40 : 1))) osot_cycle_kernel(const DevUpdate U, const DevPlan P, const DevBatch D) {
     OSOT_DYNAMIC_LDS(osot_smem);
     const long long inst = dispatch_instance(D, osot_smem);
     if (inst < 0) return;

@@ -107,7 +107,10 @@ struct WaveCtx {
     // L of the 56 padded rows, 1596 (R of n <= 54 columns needs 1539)
     static constexpr int M1_DOUBLES = PH ? (NP * (NP + 1)) / 2 : NP * (NP + 3) / 2;
     // elements in flight per trip of the mat-vec passes / the stored-row walk (divisors of NP, multiples of 4)
-    static constexpr int DOT_CH = (NP == 56) ? 28 : ((NP == 40) ? 20 : 16);
+#ifndef OSOT_DOT_CH40
+#define OSOT_DOT_CH40 20
+#endif
+    static constexpr int DOT_CH = (NP == 56) ? 28 : ((NP == 40) ? OSOT_DOT_CH40 : 16);
     static constexpr int LDS_DOUBLES = M1_DOUBLES + ROWS * S + 4 * LW;   // M1, M2, V (four staging vectors of LW)
     __device__ static __forceinline__ int col_of(int lane) { return PH ? ((lane < NP) ? lane : NP) : lane % NP; }
     __device__ static __forceinline__ int half_of(int lane) { return PH ? 0 : lane / NP; }
@@ -1567,10 +1570,13 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
 #ifndef OSOT_SCAN_SC
 #define OSOT_SCAN_SC 16
 #endif
+#ifndef OSOT_SCAN_SC40
+#define OSOT_SCAN_SC40 20
+#endif
 #ifndef OSOT_SCAN_SC56
 #define OSOT_SCAN_SC56 28   // (the 56-row layout: 28 loads per trip of the row walk -- two trips for n = 50 instead of four: 565 -> 546-553 us per config-5 launch; 52: 572)
 #endif
-                constexpr int SC = (NP == 56) ? OSOT_SCAN_SC56 : ((NP == 40) ? 20 : OSOT_SCAN_SC);
+                constexpr int SC = (NP == 56) ? OSOT_SCAN_SC56 : ((NP == 40) ? OSOT_SCAN_SC40 : OSOT_SCAN_SC);
                 for (; cc + SC <= n; cc += SC) {
                     double e[SC];
 #pragma unroll
