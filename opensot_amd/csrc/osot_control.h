@@ -26,8 +26,10 @@ struct DevControl {
 // LDS in front of the cycle's own use of the slice (the update stages its arguments there afterwards).  NP = 32: two kinematics
 // slices, the second half of the wavefront runs as an idle instance (kin_instance<.,32> is written for two robots per wavefront;
 // its lanes store their -- masked -- tables unconditionally); the 64-lane kernels: one slice, lane = joint over the whole wavefront
-constexpr size_t control_kin_lds_bytes(int NP) {
-    return NP == 32 ? 2 * sizeof(double) * (size_t)kin_lds_doubles<32>(false) : sizeof(double) * (size_t)kin_lds_doubles<64>(false);
+// pairs: the instantiations whose producer carries the collision-pair stage (every one but BOX: a plan with collision rows has
+// inequality rows), with the pair table in the slice
+constexpr size_t control_kin_lds_bytes(int NP, bool pairs = true) {
+    return NP == 32 ? 2 * sizeof(double) * (size_t)kin_lds_doubles<32>(pairs) : sizeof(double) * (size_t)kin_lds_doubles<64>(pairs);
 }
 
 template <int NP, bool EXTRA = false, bool BOX = false>
@@ -35,11 +37,15 @@ __global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : (NP == 40 ? OSO
     OSOT_DYNAMIC_LDS(osot_smem);
     const long long inst = dispatch_instance(D, osot_smem);
     if (inst < 0) return;
+    // (round 5) the producer WITH its collision-pair stage (closest points, distances, distance-Jacobian rows straight into the
+    // CollisionAvoidance leaf buffers: velocity/CollisionAvoidance.cpp:96-152) in every instantiation that can meet inequality rows;
+    // the stage is skipped at run time when the model has no pairs or the batch no pair outputs
+    constexpr bool PAIRS = !BOX;
     if constexpr (NP == 32) {
         const int sub = (int)(threadIdx.x >> 5), j = (int)(threadIdx.x & 31u);
-        kin_instance<false, 32>(F.K, F.Bt, inst, sub == 0, j, reinterpret_cast<double*>(osot_smem) + sub * kin_lds_doubles<32>(false));
+        kin_instance<PAIRS, 32>(F.K, F.Bt, inst, sub == 0, j, reinterpret_cast<double*>(osot_smem) + sub * kin_lds_doubles<32>(PAIRS));
     } else {
-        kin_instance<false, 64>(F.K, F.Bt, inst, true, (int)threadIdx.x, reinterpret_cast<double*>(osot_smem));
+        kin_instance<PAIRS, 64>(F.K, F.Bt, inst, true, (int)threadIdx.x, reinterpret_cast<double*>(osot_smem));
     }
     workgroup_fence();      // the producer's global stores (poses, rows of A_k, CoM) are visible to the update's loads (same workgroup)
     __syncthreads();

@@ -210,12 +210,14 @@ int osot_solver_create(const osot_plan_desc* plan, int max_batch, int device, os
             if (r == OSOT_OK) r = ensure_lds(osot_cycle_kernel<NP, false, true>, lds);
             if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<NP, false, true>, lds > control_kin_lds_bytes(NP) ? lds : control_kin_lds_bytes(NP));
             if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<NP, false, false>, lds > control_kin_lds_bytes(NP) ? lds : control_kin_lds_bytes(NP));
+            if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<NP, true, false>, lds > control_kin_lds_bytes(NP) ? lds : control_kin_lds_bytes(NP));
         }
         if constexpr (NP == 32) {
             if (r == OSOT_OK) r = ensure_lds(osot_cascade_kernel<32, false, false, true>, lds);
             if (r == OSOT_OK) r = ensure_lds(osot_cycle_kernel<32, false, true>, lds);
             if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<32, false, true>, lds > control_kin_lds_bytes(32) ? lds : control_kin_lds_bytes(32));
             if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<32, false, false>, lds > control_kin_lds_bytes(32) ? lds : control_kin_lds_bytes(32));
+            if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<32, true, false>, lds > control_kin_lds_bytes(32) ? lds : control_kin_lds_bytes(32));
             if (r == OSOT_OK) r = ensure_lds(osot_cascade_kernel<32, true, false, true>, lds);
         }
         return r;
@@ -546,13 +548,6 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
     for (int k = 0; k < pl.n_levels; ++k) extra = extra || (s->h_uplan.dense_level[k] != 0);
     if (prof && !fused && extra)   // (the instrumented instantiation carries no dense-weight / inactive-task code: it would
         return fail(OSOT_ERR_UNSUPPORTED, "phase profiling is not available for plans with dense weights or inactive tasks");   // solve another problem)
-    std::pair<hipEvent_t, hipEvent_t> ev;
-    const bool timed = s->timing && (s->timing_count++ % s->timing_stride) == 0;   // (after every early return: nothing is taken from the pool for a launch that does not happen)
-    if (timed) {
-        if (!s->pool.empty()) { ev = s->pool.back(); s->pool.pop_back(); }
-        else { HIP_TRY(hipEventCreate(&ev.first)); HIP_TRY(hipEventCreate(&ev.second)); }
-        HIP_TRY(hipEventRecord(ev.first, st));
-    }
     extra = extra || (D.hot != nullptr);
     {   // developer knob: the EXTRA instantiation for every launch (A/B of the two register allocations)
         static const char* force = getenv("OSOT_DEBUG_FORCE_EXTRA");
@@ -560,15 +555,24 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
     }   // (hot start: the EXTRA instantiation carries its code; never together with prof, see D.hot)
     // plans without constraint rows (the bounds are the only inequalities): the BOX instantiation of the 32-column kernels
     // ... and plans whose rows are all equalities by construction (the feet as TaskToConstraint rows: the reference's COMAN stacks), at
-    // every size
-    const bool box = s->specialise && !extra && (P.nc == 0 ? T == 32 : plan_rows_all_equalities(pl));
-    if (control && (extra || prof || !fused))
-        return fail(OSOT_ERR_UNSUPPORTED, "the fused control cycle carries no dense-weight / inactive-task / hot-start / profiling code (use osot_kinematics + osot_cycle)");
+    // every size -- but only where THIS launch's update half writes lo == up itself (fused): on the solve-only path lo / up are the
+    // caller's arrays, and a row with lo < up would never be scanned by the BOX instantiation
+    const bool box = s->specialise && !extra && (P.nc == 0 ? T == 32 : (fused != nullptr && plan_rows_all_equalities(pl)));
+    if (control && (prof || !fused))
+        return fail(OSOT_ERR_UNSUPPORTED, "the fused control cycle carries no profiling code (use osot_kinematics + osot_cycle)");
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    const bool timed = s->timing && (s->timing_count++ % s->timing_stride) == 0;   // (after EVERY early return: nothing is taken from the pool for a launch that does not happen)
+    if (timed) {
+        if (!s->pool.empty()) { ev = s->pool.back(); s->pool.pop_back(); }
+        else { HIP_TRY(hipEventCreate(&ev.first)); HIP_TRY(hipEventCreate(&ev.second)); }
+        HIP_TRY(hipEventRecord(ev.first, st));
+    }
     by_np(T, [&](auto np) {
         constexpr int NP = decltype(np)::value;
         if constexpr (NP == 32) {
             if (control) {
                 if (box) hipLaunchKernelGGL((osot_control_cycle_kernel<32, false, true>), dim3(grid), dim3(64), lds, st, *fused, P, D, *control);
+                else if (extra) hipLaunchKernelGGL((osot_control_cycle_kernel<32, true, false>), dim3(grid), dim3(64), lds, st, *fused, P, D, *control);
                 else hipLaunchKernelGGL((osot_control_cycle_kernel<32, false, false>), dim3(grid), dim3(64), lds, st, *fused, P, D, *control);
                 return 0;
             }
@@ -582,6 +586,7 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
         if constexpr (NP != 32) {
             if (control) {
                 if (box) hipLaunchKernelGGL((osot_control_cycle_kernel<NP, false, true>), dim3(grid), dim3(64), lds, st, *fused, P, D, *control);
+                else if (extra) hipLaunchKernelGGL((osot_control_cycle_kernel<NP, true, false>), dim3(grid), dim3(64), lds, st, *fused, P, D, *control);
                 else hipLaunchKernelGGL((osot_control_cycle_kernel<NP, false, false>), dim3(grid), dim3(64), lds, st, *fused, P, D, *control);
                 return 0;
             }
@@ -1029,8 +1034,8 @@ int osot_control_cycle(osot_solver* s, osot_kin* k, const osot_kin_batch* kb, co
     if (!kb->q) return fail(OSOT_ERR_INVALID, "q is null");
     if (k->device != s->device) return fail(OSOT_ERR_INVALID, "the model and the solver live on different devices");
     if (k->n != s->plan.n) return fail(OSOT_ERR_INVALID, "the model's joint count is not the plan's variable count");
-    if (k->n_pairs > 0 && (kb->pair_dist || kb->pair_J))
-        return fail(OSOT_ERR_UNSUPPORTED, "the fused control cycle carries no collision-pair stage (use osot_kinematics + osot_cycle)");
+    if (k->n_pairs > 0 && (kb->pair_dist || kb->pair_J) && k->n_env > 0 && !kb->env_pose)
+        return fail(OSOT_ERR_INVALID, "the model has environment shapes but env_pose is null");
     DevUpdate U;
     const char* why = "";
     int rc = make_update_args(s->plan, s->h_uplan, leaf, out, s->d_uplan, U, &why);

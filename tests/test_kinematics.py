@@ -297,17 +297,23 @@ def test_closed_loop_ik_on_device(gpu_device):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("with_rows", [False, True])
-def test_control_cycle_in_one_launch_matches_the_three_calls(with_rows, gpu_device):
-    """osot_control_cycle (round 4: per instance kinematics -> AutoStack::update -> cascade -> q += dq by the same wavefront,
+@pytest.mark.parametrize("mode", ["box", "rows", "collision_pairs", "hotstart", "inactive_task", "dense_weight"])
+def test_control_cycle_in_one_launch_matches_the_three_calls(mode, gpu_device):
+    """osot_control_cycle (per instance kinematics -> AutoStack::update -> cascade -> q += dq by the same wavefront,
     coman_ik.cpp:186-219 in ONE launch) against osot_kinematics + osot_cycle + the integration as three launches, over 25
     closed-loop steps from the same start: every array both write (poses, CoM, the Jacobian rows in A_k, b_k, the box, dq, q)
-    is bit-identical.  with_rows: a plan with constraint rows (the general instantiation; without: the BOX one).  An odd batch."""
+    is bit-identical.  Modes: "box" a plan without constraint rows (the BOX instantiation), "rows" with generic rows (the
+    general one); round 5 -- every plan the three-call form takes: "collision_pairs" BASELINE config 4's shape, the
+    CollisionAvoidance rows PRODUCED ON THE DEVICE inside the launch (capsule-pair distances and distance Jacobians,
+    velocity/CollisionAvoidance.cpp:96-152), "hotstart" (osot_solver_set_hotstart), "inactive_task" (Task::setActive(false))
+    and "dense_weight" (Task::setWeight(W)) through the EXTRA instantiation.  An odd batch."""
     import torch
     from opensot_amd.plan import Rows
     from opensot_amd.solver import BatchedStack
-    m = kin.humanoid32()
+    pairs = mode == "collision_pairs"
+    m = kin.humanoid32_pairs(kin.humanoid32()) if pairs else kin.humanoid32()
     n, B = m.n, 203
+    P = len(m.pairs) if pairs else 0
     dev = torch.device("cuda", 0)
     f64 = dict(dtype=torch.float64, device=dev)
     rng = np.random.default_rng(19)
@@ -315,14 +321,24 @@ def test_control_cycle_in_one_launch_matches_the_three_calls(with_rows, gpu_devi
     q0[:, [m.names.index(s + "KneeSag") for s in "RL"]] = 0.5
     q0[:, [m.names.index(s + "HipSag") for s in "RL"]] = -0.25
     q0[:, [m.names.index(s + "AnkSag") for s in "RL"]] = -0.25
-    q0[:, [m.names.index(s + "Elbj") for s in "RL"]] = -0.6
+    q0[:, [m.names.index(s + "Elbj") for s in "RL"]] = -0.6 if not pairs else -0.9
+    if pairs:
+        q0[:, m.names.index("RShLat")] = -0.35; q0[:, m.names.index("LShLat")] = 0.35
     q0 += rng.normal(0.0, 0.02, (B, n))
+    Wd = None
+    if mode == "dense_weight":
+        Mw = rng.normal(size=(6, 6)); Wd = Mw @ Mw.T / 6.0 + np.eye(6)
     levels = [[Task(abi.TASK_COM, 3, lam=0.1, name="com")],
-              [Task(abi.TASK_CARTESIAN, 6, weight=0.1, lam=0.1, name="l_wrist"), Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="r_wrist"),
+              [Task(abi.TASK_CARTESIAN, 6, weight=0.1, lam=0.1, name="l_wrist", dense_weight=(mode == "dense_weight")),
+               Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="r_wrist"),
                Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="l_sole"), Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="r_sole")],
               [Task(abi.TASK_POSTURAL, n, lam=0.01, name="postural")]]
     bounds = [Bound(abi.BOUND_JOINT_LIMITS, scaling=1.0, name="jl"), Bound(abi.BOUND_VELOCITY_LIMITS, dT=0.01, name="vl")]
-    rowblocks = [Rows(abi.ROWS_GENERIC, 2, name="rows")] if with_rows else []
+    rowblocks = []
+    if mode == "rows":
+        rowblocks = [Rows(abi.ROWS_GENERIC, 2, name="rows")]
+    if pairs:
+        rowblocks = [Rows(abi.ROWS_COLLISION, P, d_threshold=0.02, detection_threshold=0.0, bound_scaling=0.2, name="self_collision")]
     plan = StackPlan(n=n, levels=levels, bounds=bounds, rowblocks=rowblocks, eps_abs=eps_abs_from_factor(1e6))
     K = kin.Kinematics(m, device=0)
     Crow = torch.as_tensor(rng.normal(size=(B, 2, n)), **f64).contiguous()
@@ -330,28 +346,45 @@ def test_control_cycle_in_one_launch_matches_the_three_calls(with_rows, gpu_devi
 
     def make():
         st = BatchedStack(plan, B, device=0, want_levels=False)
+        if mode == "hotstart":
+            st.set_hotstart(True)
+        if mode == "inactive_task":
+            st.set_task_active(1, 1, False)
         q = torch.as_tensor(q0, **f64).contiguous()
         pose = [torch.zeros((B, 12), **f64) for _ in range(4)]
         com = torch.zeros((B, 3), **f64)
         kw = dict(frame_pose={f: pose[f] for f in range(4)}, frame_J={f: (st.A[1], 6 * f) for f in range(4)}, com=com, com_J=(st.A[0], 0))
+        Jd = dist = None
+        if pairs:
+            Jd = torch.zeros((B, P, n), **f64); dist = torch.zeros((B, P), **f64)
+            kw.update(pair_dist=dist, pair_J=(Jd, 0))
         K.forward(q, **kw)
         torch.cuda.synchronize()
         pose_d = [p.clone() for p in pose]
-        pose_d[0][:, 9:] += torch.as_tensor([0.04, 0.03, 0.03], **f64)
-        pose_d[1][:, 9:] += torch.as_tensor([0.04, -0.03, 0.03], **f64)
+        if pairs:      # both hands to the same point: the capsule rows become active (test_closed_loop_self_collision_avoidance_on_device)
+            mid = 0.5 * (pose[0][:, 9:] + pose[1][:, 9:])
+            pose_d[0][:, 9:] = mid; pose_d[1][:, 9:] = mid
+        else:
+            pose_d[0][:, 9:] += torch.as_tensor([0.04, 0.03, 0.03], **f64)
+            pose_d[1][:, 9:] += torch.as_tensor([0.04, -0.03, 0.03], **f64)
         com_d = com.clone(); com_d[:, 0] += 0.02
         qmin = torch.full((B, n), -2.5, **f64); qmax = torch.full((B, n), 2.5, **f64)
         qdot_max = torch.full((B, n), 2.0, **f64)
+        Wt = None if Wd is None else torch.as_tensor(np.tile(Wd, (B, 1, 1)), **f64).contiguous()
         leaf = {"B": B, "task": [[(com, com_d, None)], [(pose[f], pose_d[f], None) for f in range(4)], [(q, q.clone(), None)]],
-                "bound": [(q, qmin, qmax), (qdot_max, None, None)], "rows": [(Crow, rlo, rup)] if with_rows else []}
-        return st, q, pose, com, kw, leaf
+                "bound": [(q, qmin, qmax), (qdot_max, None, None)],
+                "rows": [(Crow, rlo, rup)] if mode == "rows" else ([(Jd, dist, None)] if pairs else [])}
+        if Wt is not None:
+            leaf["W"] = [[None], [Wt, None, None, None], [None]]
+        return st, q, pose, com, kw, leaf, dist
 
     a = make()
     b = make()
-    sta, qa, posea, coma, kwa, leafa = a
-    stb, qb, poseb, comb, kwb, leafb = b
+    sta, qa, posea, coma, kwa, leafa, dista = a
+    stb, qb, poseb, comb, kwb, leafb, distb = b
     kb = K.batch_args(qb, **kwb)
-    for step in range(25):
+    nsteps = 25 if not pairs else 120
+    for step in range(nsteps):
         K.forward(qa, **kwa)
         sta.cycle(leafa)
         qa += sta.dq[:B]
@@ -363,12 +396,12 @@ def test_control_cycle_in_one_launch_matches_the_three_calls(with_rows, gpu_devi
     for k in range(2):
         assert torch.equal(sta.A[k][:B], stb.A[k][:B]) and torch.equal(sta.b[k][:B], stb.b[k][:B])
     assert torch.equal(sta.l[:B], stb.l[:B]) and torch.equal(sta.u[:B], stb.u[:B])
-    assert float(sta.dq[:B].abs().max()) > 1e-4            # (the loop is still moving: the comparison is not of zeros)
-    # what the fused launch refuses, with a message: a model of another size, the hot start
-    import ctypes as C
-    stb.set_hotstart(True)
-    with pytest.raises(RuntimeError, match="fused control cycle"):
-        stb.control_cycle(K, kb, leafb, q_integrate=qb)
+    assert float(sta.dq[:B].abs().max()) > 1e-5            # (the loop is still moving: the comparison is not of zeros)
+    if pairs:
+        assert torch.equal(dista, distb) and torch.equal(sta.C[:B], stb.C[:B]) and torch.equal(sta.up[:B], stb.up[:B])
+        assert float(distb.min()) < 0.03                    # (the capsule rows ARE what holds the hands apart by now)
+    if mode == "hotstart":
+        assert torch.equal(sta.iterations[:B], stb.iterations[:B])
 
 
 @pytest.mark.gpu
