@@ -1278,10 +1278,11 @@ def main():
                     oc["COMAN35_" + which] = time_coman35(which, 4096, local_rank, lanes=S, streams=streams)
                 except Exception as e:
                     oc["COMAN35_" + which] = {"error": str(e)[:300]}
-            try:     # the reference's S3 through its null-space front-end (published: 0.3191 ms per solve)
-                oc["COMAN35_S3_nHQP"] = time_coman35("S3", 4096, local_rank, steps=6, warmup=2, front_end="nHQP", lanes=S, streams=streams)
-            except Exception as e:
-                oc["COMAN35_S3_nHQP"] = {"error": str(e)[:300]}
+            for which in ("S1", "S2", "S3", "S4"):   # the same four through the reference's null-space front-end (published: 0.2969 / 0.2637 / 0.3191 / 0.3721 ms per solve)
+                try:
+                    oc[f"COMAN35_{which}_nHQP"] = time_coman35(which, 4096, local_rank, steps=6, warmup=2, front_end="nHQP", lanes=S, streams=streams)
+                except Exception as e:
+                    oc[f"COMAN35_{which}_nHQP"] = {"error": str(e)[:300]}
             try:
                 oc["full_cycle"] = time_full_cycle(Bl, local_rank, lanes=S, streams=streams)
                 three = time_full_cycle(Bl, local_rank, lanes=S, streams=streams, fused=False)

@@ -383,9 +383,10 @@ int osot_solver_profile_phases(osot_solver* s, const osot_qp_batch* batch, long 
  * Same stack, same assembled arrays as osot_ihqp_solve; per level the task is projected into the cumulated null space N of
  * the levels above, an SVD of A N drives the reference's A/b regularisation and yields the level's null space, the QP is
  * solved in the nf free coordinates (bounds become rows N z, compute_contraints :282-317) and q += N z, N <- N V2.  Three
- * launches per level (prepare, the batched QP kernel, accumulate).  n <= 64 (round 4; at every level min(rows, free
- * variables) <= 32: the level's SVD goes through a 32-wide eigen-decomposition), <= 64 rows per level, diagonal weights,
- * global rows and the box only (the reference refuses task-local constraints, nHQP.cpp:41-44). */
+ * launches per level (prepare, the batched QP kernel, accumulate).  n <= 64 (a level with min(rows, free variables) <= 32 goes
+ * through a 32-wide eigen-decomposition; round 5: the others -- the reference's one-level stack S1, 50 rows in 35 variables --
+ * through a Jacobi iteration on the full Gram matrix), <= 64 rows per level, diagonal weights, inactive tasks as zero rows
+ * (round 5), global rows and the box only (the reference refuses task-local constraints, nHQP.cpp:41-44). */
 typedef struct {
     int free_vars[OSOT_MAX_LEVELS];      /* free variables of each level.  The reference fixes them in its constructor from the
                                             singular values of A N at construction (>= 1e-6 counts as rank, nHQP.cpp:88-103)
@@ -398,6 +399,13 @@ typedef struct {
     int no_ab_regularization;            /* setPerformAbRegularization(false) */
     int no_selective_ns_regularization;  /* setPerformSelectiveNullSpaceRegularization(false) */
     int min_sv_ratio_is_set;             /* != 0: min_sv_ratio is the caller's value, 0 included (only needed to say 0) */
+    /* per level (round 5; nHQP::setPerformAbRegularization(level, .), setPerformSelectiveNullSpaceRegularization(level, .),
+       setMinSingularValueRatio(std::vector<double>): nHQP.cpp:127-152, 206-221).  A level's switch is OFF if the solver-wide one
+       or its own says so; a level's ratio, where level_min_sv_ratio_is_set[k] != 0, replaces the solver-wide one. */
+    int level_no_ab_regularization[OSOT_MAX_LEVELS];
+    int level_no_selective_ns_regularization[OSOT_MAX_LEVELS];
+    int level_min_sv_ratio_is_set[OSOT_MAX_LEVELS];
+    double level_min_sv_ratio[OSOT_MAX_LEVELS];
 } osot_nhqp_options;
 int osot_nhqp_solve(osot_solver* s, const osot_qp_batch* batch, const osot_nhqp_options* options, void* hip_stream);
 

@@ -91,7 +91,9 @@ class BackendOptions(C.Structure):
 class NhqpOptions(C.Structure):
     _fields_ = [("free_vars", C.c_int * MAX_LEVELS), ("min_sv_ratio", C.c_double),
                 ("no_ab_regularization", C.c_int), ("no_selective_ns_regularization", C.c_int),
-                ("min_sv_ratio_is_set", C.c_int)]
+                ("min_sv_ratio_is_set", C.c_int),
+                ("level_no_ab_regularization", C.c_int * MAX_LEVELS), ("level_no_selective_ns_regularization", C.c_int * MAX_LEVELS),
+                ("level_min_sv_ratio_is_set", C.c_int * MAX_LEVELS), ("level_min_sv_ratio", C.c_double * MAX_LEVELS)]
 
 
 class AdmmOptions(C.Structure):

@@ -100,6 +100,7 @@ struct osot_solver {
     int slots = 1;      // wavefronts of the cascade kernel the device holds at once (CUs x resident workgroups per CU)
     NhqpWorkspace nhqp; // scratch of the null-space front-end, allocated at its first use
     bool nhqp_ready = false;
+    bool nhqp_lds_ready = false;
     // hot start (osot_solver_set_hotstart): the inequality working set each level of each instance ended with
     double* d_rows = nullptr;   // [max_batch][rows_doubles] row tables (plans whose 64-lane kernels keep them out of LDS)
     int hotstart = 0;
@@ -139,7 +140,8 @@ int osot_abi_layout(const char* name, unsigned long long* size, unsigned long lo
         OSOT_F(Wb) OSOT_F(A) OSOT_LAYOUT_END()
     OSOT_LAYOUT_BEGIN(osot_backend_options) OSOT_F(max_iterations) OSOT_F(last_iterations) OSOT_F(last_status) OSOT_LAYOUT_END()
     OSOT_LAYOUT_BEGIN(osot_nhqp_options) OSOT_F(free_vars) OSOT_F(min_sv_ratio) OSOT_F(no_ab_regularization)
-        OSOT_F(no_selective_ns_regularization) OSOT_F(min_sv_ratio_is_set) OSOT_LAYOUT_END()
+        OSOT_F(no_selective_ns_regularization) OSOT_F(min_sv_ratio_is_set) OSOT_F(level_no_ab_regularization)
+        OSOT_F(level_no_selective_ns_regularization) OSOT_F(level_min_sv_ratio_is_set) OSOT_F(level_min_sv_ratio) OSOT_LAYOUT_END()
     OSOT_LAYOUT_BEGIN(osot_admm_options) OSOT_F(eps_abs) OSOT_F(eps_rel) OSOT_F(rho) OSOT_F(sigma) OSOT_F(alpha) OSOT_F(max_iter)
         OSOT_F(scaling) OSOT_F(check_every) OSOT_LAYOUT_END()
     OSOT_LAYOUT_BEGIN(osot_id_model) OSOT_F(B) OSOT_F(nv) OSOT_F(n_contacts) OSOT_F(contact_dim) OSOT_F(Bm) OSOT_F(h) OSOT_F(Jc)
@@ -383,8 +385,6 @@ int osot_nhqp_solve(osot_solver* s, const osot_qp_batch* b, const osot_nhqp_opti
     DeviceGuard guard(s->device);
     if (!guard.ok) return fail(OSOT_ERR_HIP, "hipSetDevice failed");
     const osot_plan_desc& pl = s->plan;
-    if (s->any_inactive)     // (said, not ignored: a zero-row task changes the level's singular values and what regularize_A_b lifts)
-        return fail(OSOT_ERR_UNSUPPORTED, "nHQP front-end: Task::setActive(false) is not covered (osot_ihqp_solve and osot_ehqp_solve take it)");
     if (b->level_active)     // (iHQP::setActiveStack: the reference's nHQP has no such switch, nHQP.h)
         for (int k = 0; k < pl.n_levels; ++k)
             if (!b->level_active[k]) return fail(OSOT_ERR_UNSUPPORTED, "nHQP front-end: level_active is iHQP's setActiveStack; nHQP has no such switch");
@@ -412,16 +412,26 @@ int osot_nhqp_solve(osot_solver* s, const osot_qp_batch* b, const osot_nhqp_opti
         if (!ok) return fail(OSOT_ERR_HIP, "device allocation for the nHQP workspace failed");
         s->nhqp_ready = true;
     }
+    if (pl.n > 32) {    // the 64-column preparation kernels' dynamic LDS, once per solver and with its error reported (a
+                        // failed attribute call used to skip the launch silently and the solve went on with a stale workspace)
+        if (!s->nhqp_lds_ready) {
+            int r = ensure_lds(osot_nhqp_prepare64_kernel<32>, nhqp_prepare64_lds_bytes(32, pl.n));
+            if (r == OSOT_OK) r = ensure_lds(osot_nhqp_prepare64_kernel<64>, nhqp_prepare64_lds_bytes(64, pl.n));
+            if (r == OSOT_OK) r = ensure_lds(osot_nhqp_prepare_wide_kernel, nhqp_prepare_wide_lds_bytes(64, pl.n));
+            if (r != OSOT_OK) return r;
+            s->nhqp_lds_ready = true;
+        }
+    }
     hipStream_t st = (hipStream_t)hip_stream;
     const unsigned grid = (unsigned)b->B;
     const char* why = "";
     int rc = nhqp_run(pl, b, opt, s->nhqp,
         [&](const DevNhqp& Q) {
-            if (Q.n > 32) {     // 33 .. 64 variables: the 64-column kernel (dynamic LDS beyond the 64 KB default)
-                if (Q.m <= 32) { if (ensure_lds(osot_nhqp_prepare64_kernel<32>, nhqp_prepare64_lds_bytes(32, Q.n)) == OSOT_OK)
-                                     hipLaunchKernelGGL(osot_nhqp_prepare64_kernel<32>, dim3(grid), dim3(64), nhqp_prepare64_lds_bytes(32, Q.n), st, Q); }
-                else { if (ensure_lds(osot_nhqp_prepare64_kernel<64>, nhqp_prepare64_lds_bytes(64, Q.n)) == OSOT_OK)
-                           hipLaunchKernelGGL(osot_nhqp_prepare64_kernel<64>, dim3(grid), dim3(64), nhqp_prepare64_lds_bytes(64, Q.n), st, Q); }
+            if (nhqp_level_is_wide(Q.m, Q.nf))      // min(rows, free variables) > 32: the Jacobi route on the full Gram matrix
+                hipLaunchKernelGGL(osot_nhqp_prepare_wide_kernel, dim3(grid), dim3(64), nhqp_prepare_wide_lds_bytes(Q.m, Q.n), st, Q);
+            else if (Q.n > 32) {     // 33 .. 64 variables: the 64-column kernel (dynamic LDS beyond the 64 KB default: raised once, below)
+                if (Q.m <= 32) hipLaunchKernelGGL(osot_nhqp_prepare64_kernel<32>, dim3(grid), dim3(64), nhqp_prepare64_lds_bytes(32, Q.n), st, Q);
+                else hipLaunchKernelGGL(osot_nhqp_prepare64_kernel<64>, dim3(grid), dim3(64), nhqp_prepare64_lds_bytes(64, Q.n), st, Q);
             }
             else if (Q.m <= 32) hipLaunchKernelGGL(osot_nhqp_prepare_kernel<32>, dim3(grid), dim3(64), 0, st, Q);
             else hipLaunchKernelGGL(osot_nhqp_prepare_kernel<64>, dim3(grid), dim3(64), 0, st, Q);
@@ -430,7 +440,8 @@ int osot_nhqp_solve(osot_solver* s, const osot_qp_batch* b, const osot_nhqp_opti
             const double* l, const double* u, double eps, double* x, int* status, int* iters) {
             return osot_qp_solve_batch(B, n, nc, H, g, A, lA, uA, l, u, eps, 0, x, status, iters, hip_stream);
         },
-        [&](const DevNhqpAcc& A) { hipLaunchKernelGGL(osot_nhqp_accumulate_kernel, dim3(grid), dim3(64), 0, st, A); }, &why);
+        [&](const DevNhqpAcc& A) { hipLaunchKernelGGL(osot_nhqp_accumulate_kernel, dim3(grid), dim3(64), 0, st, A); }, &why,
+        s->any_inactive ? s->task_active : nullptr);
     if (rc != OSOT_OK) return fail(rc, why);
     HIP_TRY(hipGetLastError());
     return OSOT_OK;

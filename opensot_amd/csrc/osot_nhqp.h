@@ -38,6 +38,8 @@ struct DevNhqp {
     double* R; double* rlo; double* rup;   // out (levels > 0) [B][nr][nf], [B][nr], nr = nc + (has_box ? n : 0)
     double* V2;                      // out [B][n][n] (nf x ns, row stride n)
     const int* status;               // [B] status so far (instances that failed above are skipped)
+    unsigned long long zero_rows;    // bit r: row r of the level belongs to an INACTIVE task (Task::setActive(false), Task.h:383-387: A is
+                                     // zeroed, b stays): the row of A N is a zero row
 };
 
 constexpr int kNS = 33;              // LDS row stride of the 32-column work matrices
@@ -465,6 +467,11 @@ __device__ __forceinline__ bool sym_bisect_32(double* K, double* E, int k, int c
     // (the norm is the first half's: the second half runs the same recurrences on the same column, but its reads of D+ race with
     //  the first half's in-place writes of y -- harmless in lock-step, and nothing of the second half's is used)
     double sq, rs;
+    {   // a pivot clamped to -pivmin can drive the y recurrence to Inf / NaN: such a vector is no eigenvector -- the caller's other
+        // route (QL iteration / the full decomposition) takes the matrix instead
+        const double n2 = from_half<32>(nrm2, 0);
+        if (wave_ballot(in && !(n2 > 0.0 && n2 < INFINITY)) != 0ull) return false;
+    }
     fast_sqrt_rsqrt(from_half<32>(nrm2, 0), sq, rs);
     if constexpr (MODE == 2) {
         // my column of Y normalised in place, then V = H_(k-1) .. H_2 Y for every column at once (lane = column, its entries split
@@ -677,7 +684,12 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
                 else v -= vec[lane - ma];
             }
         }
+        if ((Q.zero_rows >> lane) & 1ull) v = (lane < m) ? Q.b[inst * m + lane] : 0.0;     // inactive task: A = 0, so b0 = b
         b0[lane] = v;              // (zero beyond m: the fixed-trip products below read all 64 entries)
+    }
+    if (Q.zero_rows) {             // rows of inactive tasks are zero rows of A N
+        wave_sync();
+        for (int r = 0; r < m; ++r) if (((Q.zero_rows >> r) & 1ull) && h == 0) AN[r * kNS + c] = 0.0;
     }
     wave_sync();
     NHQP_PHASE("AN+b0");
@@ -994,11 +1006,15 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
             if (sel) {
 #pragma unroll
                 for (int t = 0; t < 16; t += 2) {
-                    // (my row of V2 is zero beyond ns and the buffer holds finite numbers there: no mask on the other factor)
-                    a0 = fma(v2c[t], V2[i0 * kNS + 2 * t + h], a0);
-                    a1 = fma(v2c[t + 1], V2[i0 * kNS + 2 * (t + 1) + h], a1);
-                    c0 = fma(v2c[t], V2[i1 * kNS + 2 * t + h], c0);
-                    c1 = fma(v2c[t + 1], V2[i1 * kNS + 2 * (t + 1) + h], c1);
+                    // (BOTH factors masked beyond ns: V2 shares its buffer with the twisted factorisation's work, whose unused part
+                    //  may hold Inf after a clamped pivot, and 0 * Inf would poison H -- ADVICE r4)
+                    const bool m0 = 2 * t + h < ns, m1 = 2 * (t + 1) + h < ns;
+                    const double f00 = V2[i0 * kNS + 2 * t + h], f01 = V2[i0 * kNS + 2 * (t + 1) + h];
+                    const double f10 = V2[i1 * kNS + 2 * t + h], f11 = V2[i1 * kNS + 2 * (t + 1) + h];
+                    a0 = fma(v2c[t], m0 ? f00 : 0.0, a0);
+                    a1 = fma(v2c[t + 1], m1 ? f01 : 0.0, a1);
+                    c0 = fma(v2c[t], m0 ? f10 : 0.0, c0);
+                    c1 = fma(v2c[t + 1], m1 ? f11 : 0.0, c1);
                 }
             }
             const double acc0 = halfsum<32>(a0 + a1), acc1 = halfsum<32>(c0 + c1);
@@ -1130,7 +1146,12 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
             v = Q.b[inst * m + lane];
             if (!first) { if (lane < ma) v -= aq_row; else v -= vec[lane - ma]; }
         }
+        if ((Q.zero_rows >> lane) & 1ull) v = (lane < m) ? Q.b[inst * m + lane] : 0.0;     // inactive task: A = 0, so b0 = b
         b0[lane] = v;
+    }
+    if (Q.zero_rows) {             // rows of inactive tasks are zero rows of A N
+        wave_sync();
+        for (int r = 0; r < m; ++r) if (((Q.zero_rows >> r) & 1ull) && c < nf) AN[r * S + c] = 0.0;
     }
     wave_sync();
     NHQP_PHASE("AN+b0");
@@ -1484,8 +1505,9 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
                         const int t = t0 + j;
                         const double v2ct = V2[cc * v2s + t];               // (loaded, then masked: no branch between the reads of a chunk)
                         const double own = (t < ns) ? sv_max * v2ct : 0.0;
-                        a0 = fma(own, V2[i0 * v2s + t], a0);
-                        a1 = fma(own, V2[i1 * v2s + t], a1);
+                        const double f0 = V2[i0 * v2s + t], f1 = V2[i1 * v2s + t];
+                        a0 = fma(own, (t < ns) ? f0 : 0.0, a0);
+                        a1 = fma(own, (t < ns) ? f1 : 0.0, a1);
                     }
                 }
             }
@@ -1502,6 +1524,302 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
             for (int u = 0; u < 8; ++u) t8[u] = V2[((i0 + u < nf) ? i0 + u : 0) * v2s + cs];
 #pragma unroll
             for (int u = 0; u < 8; ++u) if (i0 + u < nf && c < ns) Vg[(i0 + u) * n + c] = t8[u];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the level preparation for levels whose SMALL side exceeds 32 (min(rows, free variables) > 32, n <= 64): the reference's
+// own stack S1 -- (0.1 l_wrist + r_wrist + com + 1e-4 postural) on the 35-coordinate COMAN, one level of 50 rows
+// (examples/cpp/coman_ik.cpp:425-431) -- was refused until now.  A plain kernel, not a tuned one: lane = column / row, every loop
+// generic in n and m; what it does differently from the two kernels above is the decomposition --
+//   * always the COLUMN-side Gram matrix G = (A N)'(A N) (nf x nf): its eigenvectors are ALL of V, the null space of A N included
+//     (no Householder completion), whatever the rank;
+//   * a parallel cyclic Jacobi iteration (round-robin pairs, row phase with lane = column, column phase with lane = row) instead of
+//     tridiagonalisation + bisection: ~8 sweeps of nf - 1 rounds, slower than the 32-wide route by a small factor and three
+//     wavefronts per CU, but orthonormal to round-off at any rank and 60 lines;
+//   * U = A N V Sigma^-1 explicitly for the min(m, nf) triplets (null triplets: completed by Gram-Schmidt of unit vectors), so that
+//     regularize_A_b is the reference's own formula, b0 <- U diag(d) U'b0, A N <- A N + sum (sv' - sv) u v' (nHQP.cpp:236-279).
+// LDS (dynamic, nhqp_prepare_wide_lds_bytes): A N [RM][S], N -> V [RN][S], G -> U [RM][S], S = RN + 1, RN = n rounded up to 8,
+// RM = max(m, n) rounded up to 8: 50 KB at S1.
+inline size_t nhqp_prepare_wide_lds_bytes(int m, int n) {
+    const size_t RN = (size_t)nhqp64_rows(n), S = RN + 1, RM = (size_t)nhqp64_rows(m > n ? m : n);
+    return sizeof(double) * (2 * RM * S + RN * S + 5 * 64 + 2 * 32) + sizeof(int) * (64 + 2 * 32);
+}
+
+__global__ void __launch_bounds__(64) osot_nhqp_prepare_wide_kernel(const DevNhqp Q) {
+    OSOT_DYNAMIC_LDS(nw_smem);
+    const int n = Q.n, m = Q.m, ma = Q.ma, nf = Q.nf, ns = Q.ns;
+    const int RN = nhqp64_rows(n), S = RN + 1, RM = nhqp64_rows(m > n ? m : n);
+    double* AN = reinterpret_cast<double*>(nw_smem);   // [RM][S]  A N (m x nf)
+    double* NV = AN + RM * S;                          // [RN][S]  N (n x nf), then V (nf x nf)
+    double* G = NV + RN * S;                           // [RM][S]  Gram matrix (nf x nf), then U (m x ksv)
+    double* b0 = G + RM * S;                           // [64]
+    double* vec = b0 + 64;                             // [64]
+    double* sig = vec + 64;                            // [64] singular values, descending (zero beyond min(m, nf))
+    double* ub = sig + 64;                             // [64] u_i'b0
+    double* dl = ub + 64;                              // [64] sv'_i - sv_i of the lifted triplets (0: not lifted)
+    double* rc = dl + 64;                              // [32] rotation cosines of a round
+    double* rs = rc + 32;                              // [32] ... sines
+    int* idx = reinterpret_cast<int*>(rs + 32);        // [64] idx[pos] = eigen-column of the pos-th largest
+    int* pp = idx + 64;                                // [32] the pairs of a round
+    int* pq = pp + 32;
+    const long long inst = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (inst >= Q.B) return;
+    if (Q.status && Q.status[inst] != 0) return;
+    const bool first = Q.level == 0;
+    const double* A = Q.A ? Q.A + inst * (long long)ma * n : nullptr;
+    for (int e = lane; e < RM * S; e += 64) { AN[e] = 0.0; G[e] = 0.0; }
+    for (int e = lane; e < RN * S; e += 64) NV[e] = 0.0;
+    wave_sync();
+    // ---- N, q0
+    if (first) { if (lane < n) NV[lane * S + lane] = 1.0; }
+    else {
+        const double* Ng = Q.N + inst * (long long)n * n;
+        if (lane < nf) for (int i = 0; i < n; ++i) NV[i * S + lane] = Ng[i * n + lane];
+    }
+    vec[lane] = (!first && lane < n) ? Q.q0[inst * n + lane] : 0.0;
+    wave_sync();
+    // ---- A N (lane = column), b0 = b - A q0 (lane = row)
+    for (int r = 0; r < m; ++r) {
+        const bool zr = (Q.zero_rows >> r) & 1ull;
+        double acc = 0.0;
+        if (lane < nf && !zr) {
+            if (r < ma) { for (int i = 0; i < n; ++i) acc = fma(A[r * n + i], NV[i * S + lane], acc); }
+            else acc = NV[(r - ma) * S + lane];
+        }
+        if (lane < nf) AN[r * S + lane] = acc;
+    }
+    {
+        double v = 0.0;
+        if (lane < m) {
+            v = Q.b[inst * m + lane];
+            if (!first && !((Q.zero_rows >> lane) & 1ull)) {
+                if (lane < ma) { double aq = 0.0; for (int i = 0; i < n; ++i) aq = fma(A[lane * n + i], vec[i], aq); v -= aq; }
+                else v -= vec[lane - ma];
+            }
+        }
+        b0[lane] = v;
+    }
+    wave_sync();
+    // ---- constraints in z-coordinates (levels below the first): rows [C N; N], bounds shifted by q0 (compute_contraints, :282-317)
+    if (!first) {
+        const int nr = Q.nc + (Q.has_box ? n : 0);
+        double* Rg = Q.R + inst * (long long)nr * nf;
+        const double* Cg = Q.C + inst * (long long)Q.nc * n;
+        for (int r = 0; r < Q.nc; ++r) {
+            double acc = 0.0;
+            if (lane < nf) for (int i = 0; i < n; ++i) acc = fma(Cg[r * n + i], NV[i * S + lane], acc);
+            if (lane < nf) Rg[r * nf + lane] = acc;
+        }
+        if (lane < Q.nc) {
+            double cq = 0.0;
+            for (int i = 0; i < n; ++i) cq = fma(Cg[lane * n + i], vec[i], cq);
+            const double lo = Q.lo[inst * Q.nc + lane], up = Q.up[inst * Q.nc + lane];
+            Q.rlo[inst * nr + lane] = (lo <= -1.0e20) ? -1.0e20 : lo - cq;
+            Q.rup[inst * nr + lane] = (up >= 1.0e20) ? 1.0e20 : up - cq;
+        }
+        if (Q.has_box) {
+            if (lane < nf) for (int i = 0; i < n; ++i) Rg[(Q.nc + i) * nf + lane] = NV[i * S + lane];
+            if (lane < n) {
+                const double l = Q.l[inst * n + lane], u = Q.u[inst * n + lane];
+                Q.rlo[inst * nr + Q.nc + lane] = (l <= -1.0e20) ? -1.0e20 : l - vec[lane];
+                Q.rup[inst * nr + Q.nc + lane] = (u >= 1.0e20) ? 1.0e20 : u - vec[lane];
+            }
+        }
+    }
+    wave_sync();      // N is dead: NV becomes V
+    // ---- G = (A N)'(A N), V = I
+    {
+        const int cl = (lane < nf) ? lane : 0;
+        for (int a0 = 0; a0 < nf; a0 += 8) {           // eight rows of G per pass over A N (its columns are zero beyond nf: S > RN >= nf + ...)
+            double acc8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc8[j] = 0.0;
+            for (int r = 0; r < m; ++r) {
+                const double own = AN[r * S + cl];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc8[j] = fma(AN[r * S + ((a0 + j < nf) ? a0 + j : 0)], own, acc8[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (a0 + j < nf && lane < nf) G[(a0 + j) * S + lane] = acc8[j];
+        }
+    }
+    for (int e = lane; e < RN * S; e += 64) NV[e] = 0.0;
+    wave_sync();
+    if (lane < nf) NV[lane * S + lane] = 1.0;
+    wave_sync();
+    // ---- cyclic Jacobi on G, rotations accumulated in V.  kk = nf rounded up to even (a phantom index pairs with nobody); round r of
+    // a sweep: (kk - 1, r) and ((r + t) mod (kk - 1), (r - t) mod (kk - 1)), t = 1 .. kk / 2 - 1 -- every pair once per sweep.
+    {
+        const int kk = (nf + 1) & ~1, half = kk >> 1, md = kk - 1;
+        double tr = 0.0;
+        if (lane < nf) tr = G[lane * S + lane];
+        const double scale = uniform_d(colsum<64>(fabs(tr)));            // trace: the eigenvalues' scale
+        for (int sweep = 0; sweep < 14; ++sweep) {
+            double off = 0.0;
+            if (lane < nf) for (int a = 0; a < nf; ++a) if (a != lane) { const double v = G[a * S + lane]; off = fma(v, v, off); }
+            off = uniform_d(colsum<64>(off));
+            if (!(off > 1.0e-30 * scale * scale)) break;
+            for (int r = 0; r < md; ++r) {
+                if (lane < half) {
+                    int p, q;
+                    if (lane == 0) { p = md; q = r; }
+                    else { p = (r + lane) % md; q = (r - lane + md) % md; }
+                    if (p > q) { const int t = p; p = q; q = t; }
+                    double cs = 1.0, sn = 0.0;
+                    if (q < nf) {
+                        const double gpq = G[p * S + q], gpp = G[p * S + p], gqq = G[q * S + q];
+                        if (fabs(gpq) > 1.0e-300 && fabs(gpq) > 1.0e-17 * sqrt(fabs(gpp * gqq))) {
+                            const double tau = (gqq - gpp) / (2.0 * gpq);
+                            const double t = ((tau >= 0.0) ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                            cs = 1.0 / sqrt(1.0 + t * t); sn = t * cs;
+                        }
+                    }
+                    pp[lane] = p; pq[lane] = (q < nf) ? q : p; rc[lane] = cs; rs[lane] = sn;     // (phantom partner: identity on p alone)
+                }
+                wave_sync();
+                // rows p, q of G <- J'G (lane = column): (g_p, g_q) <- (c g_p - s g_q, s g_p + c g_q)
+                if (lane < nf) {
+                    for (int t = 0; t < half; ++t) {
+                        const int p = pp[t], q = pq[t];
+                        if (p == q) continue;
+                        const double cs = rc[t], sn = rs[t];
+                        const double gp = G[p * S + lane], gq = G[q * S + lane];
+                        G[p * S + lane] = cs * gp - sn * gq;
+                        G[q * S + lane] = sn * gp + cs * gq;
+                    }
+                }
+                wave_sync();
+                // columns p, q of G <- G J and of V <- V J (lane = row)
+                if (lane < nf) {
+                    for (int t = 0; t < half; ++t) {
+                        const int p = pp[t], q = pq[t];
+                        if (p == q) continue;
+                        const double cs = rc[t], sn = rs[t];
+                        const double gp = G[lane * S + p], gq = G[lane * S + q];
+                        G[lane * S + p] = cs * gp - sn * gq;
+                        G[lane * S + q] = sn * gp + cs * gq;
+                        const double vp = NV[lane * S + p], vq = NV[lane * S + q];
+                        NV[lane * S + p] = cs * vp - sn * vq;
+                        NV[lane * S + q] = sn * vp + cs * vq;
+                    }
+                }
+                wave_sync();
+            }
+        }
+    }
+    // ---- singular values, descending; ksv = min(m, nf) of them exist (svd.singularValues(), Eigen's thin count)
+    const int ksv = (m < nf) ? m : nf;
+    {
+        const double lam = (lane < nf) ? G[lane * S + lane] : -1.0;
+        wave_sync();
+        vec[lane] = lam;
+        wave_sync();
+        int pos = 0;
+        for (int d = 0; d < nf; ++d) { const double ld = vec[d]; pos += (ld > lam || (ld == lam && d < lane)) ? 1 : 0; }
+        sig[lane] = 0.0;
+        wave_sync();
+        if (lane < nf) { idx[pos] = lane; if (pos < ksv) sig[pos] = sqrt(lam > 0.0 ? lam : 0.0); }
+        wave_sync();
+    }
+    const double sv_max = sig[0];
+    constexpr double kSvNoise = 1.0e-7;
+    // ---- regularize_A_b (nHQP.cpp:236-279)
+    if (Q.ab_reg) {
+        double* U = G;                                 // (the Gram matrix is spent: its diagonal went into sig[])
+        wave_sync();
+        for (int e = lane; e < RM * S; e += 64) U[e] = 0.0;
+        wave_sync();
+        // U[:, i] = A N v_i / |A N v_i| where the triplet is genuine; a null triplet's u_i completes the basis: the first unit
+        // vector with a usable component outside the span of the u's found so far (modified Gram-Schmidt, lane = row)
+        int next_unit = 0;
+        for (int i = 0; i < ksv; ++i) {
+            const int ec = idx[i];
+            double u = 0.0;
+            bool have = false;
+            if (sig[i] >= kSvNoise * sv_max && sig[i] > 0.0) {
+                if (lane < m) for (int t = 0; t < nf; ++t) u = fma(AN[lane * S + t], NV[t * S + ec], u);
+                const double nrm2 = uniform_d(colsum<64>(u * u));
+                if (nrm2 > 0.0) { u = u / sqrt(nrm2); have = true; }
+            }
+            while (!have && next_unit < m) {
+                u = (lane == next_unit) ? 1.0 : 0.0;
+                next_unit++;
+                for (int pass = 0; pass < 2; ++pass)
+                    for (int j = 0; j < i; ++j) {
+                        const double uj = (lane < m) ? U[lane * S + j] : 0.0;
+                        const double dot = uniform_d(colsum<64>(uj * u));
+                        u = fma(-dot, uj, u);
+                    }
+                const double nrm2 = uniform_d(colsum<64>(u * u));
+                if (nrm2 > 0.25) { u = u / sqrt(nrm2); have = true; }
+            }
+            if (!have) u = 0.0;
+            wave_sync();
+            if (lane < m) U[lane * S + i] = u;
+            const double dotb = uniform_d(colsum<64>((lane < m) ? u * b0[lane] : 0.0));
+            const double sv = sig[i];
+            const bool lift = sv < Q.thr * sv_max;
+            double d = 1.0, svn = sv;
+            if (lift) { d = sv / (Q.thr * sv_max); svn = (Q.thr * sv_max) * (Q.thr * sv_max) / (sv + Q.thr / 100.0); }
+            if (lane == 0) { ub[i] = d * dotb; dl[i] = lift ? svn - sv : 0.0; }
+            wave_sync();
+        }
+        // b0 <- sum_i d_i (u_i'b0) u_i  (U diag(d) U'b0 with b0_rot(i) = 0 beyond the ksv singular values)
+        if (lane < m) {
+            double v = 0.0;
+            for (int i = 0; i < ksv; ++i) v = fma(ub[i], U[lane * S + i], v);
+            b0[lane] = v;
+        }
+        // A N <- A N + sum over the lifted triplets (sv' - sv) u v'   (lane = column)
+        for (int i = 0; i < ksv; ++i) {
+            const double del = dl[i];
+            if (del == 0.0) continue;
+            const int ec = idx[i];
+            if (lane < nf) {
+                const double vv = NV[lane * S + ec];
+                for (int r = 0; r < m; ++r) AN[r * S + lane] = fma(del * U[r * S + i], vv, AN[r * S + lane]);
+            }
+        }
+        wave_sync();
+    }
+    // ---- H = AN' W AN (+ sv_max V2 V2'), g = -AN' W b0, V2 = the columns of V of the ns smallest eigenvalues (svd.matrixV().rightCols)
+    {
+        const double* w = Q.w ? Q.w + inst * m : nullptr;
+        wave_sync();
+        vec[lane] = (lane < m) ? (w ? w[lane] : 1.0) : 0.0;
+        wave_sync();
+        double* Hg = Q.H + inst * (long long)nf * nf;
+        const bool sel = ns > 0 && Q.sel_reg;
+        {
+            const int cl = (lane < nf) ? lane : 0;
+            double gacc = 0.0;
+            for (int r = 0; r < m; ++r) gacc = fma(-(vec[r] * AN[r * S + cl]), b0[r], gacc);
+            if (lane < nf) Q.g[inst * nf + lane] = gacc;
+            for (int i0 = 0; i0 < nf; i0 += 8) {       // eight rows of H per pass
+                double acc8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc8[j] = 0.0;
+                for (int r = 0; r < m; ++r) {
+                    const double wan = vec[r] * AN[r * S + cl];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc8[j] = fma(wan, AN[r * S + ((i0 + j < nf) ? i0 + j : 0)], acc8[j]);
+                }
+                if (sel) for (int t = 0; t < ns; ++t) {
+                    const int ec = idx[nf - ns + t];
+                    const double own = sv_max * NV[cl * S + ec];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc8[j] = fma(own, NV[((i0 + j < nf) ? i0 + j : 0) * S + ec], acc8[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (i0 + j < nf && lane < nf) Hg[(i0 + j) * nf + lane] = acc8[j];
+            }
+        }
+        if (ns > 0 && Q.V2) {
+            double* Vg = Q.V2 + inst * (long long)n * n;
+            if (lane < ns) { const int ec = idx[nf - ns + lane]; for (int i = 0; i < nf; ++i) Vg[i * n + lane] = NV[i * S + ec]; }
         }
     }
 }

@@ -19,6 +19,17 @@ inline NhqpSizes nhqp_sizes(const osot_plan_desc& p, int B) {
 }
 
 // what the reference's constructor refuses, and what this build does not cover
+inline bool nhqp_level_is_wide(int m, int nf) { return (m < nf ? m : nf) > 32; }
+// the level's A / b regularisation, selective null-space regularisation and singular-value threshold: the solver-wide setting, or the
+// level's own (nHQP::setPerformAbRegularization(level, .), setPerformSelectiveNullSpaceRegularization(level, .),
+// setMinSingularValueRatio(vector): nHQP.cpp:127-152, 206-221)
+inline void nhqp_level_options(const osot_nhqp_options* opt, int k, int& ab_reg, int& sel_reg, double& thr) {
+    ab_reg = !(opt && (opt->no_ab_regularization || opt->level_no_ab_regularization[k]));
+    sel_reg = !(opt && (opt->no_selective_ns_regularization || opt->level_no_selective_ns_regularization[k]));
+    // nHQP.h:66: 0.05 by default.  A positive value is honoured as it is; the flag is only needed to express 0 ("lift nothing")
+    thr = !opt ? 0.05 : (opt->min_sv_ratio_is_set ? opt->min_sv_ratio : (opt->min_sv_ratio > 0.0 ? opt->min_sv_ratio : 0.05));
+    if (opt && opt->level_min_sv_ratio_is_set[k]) thr = opt->level_min_sv_ratio[k];
+}
 inline int nhqp_validate(const osot_plan_desc& p, const osot_nhqp_options* opt, int free_vars[OSOT_MAX_LEVELS], const char** why) {
     if (p.n > OSOT_MAX_VARS) { *why = "nHQP front-end: n <= 64"; return OSOT_ERR_UNSUPPORTED; }
     if (p.has_regularisation) { *why = "nHQP has no regularisation task"; return OSOT_ERR_UNSUPPORTED; }
@@ -36,8 +47,8 @@ inline int nhqp_validate(const osot_plan_desc& p, const osot_nhqp_options* opt, 
         if (k == 0) { if (given != 0 && given != p.n) { *why = "free_vars[0] must be n"; return OSOT_ERR_INVALID; } }
         else if (given != 0) nf = given;
         if (nf <= 0 || nf > p.n) { *why = "[nHQP] No free variables left at a layer: decrease the number of layers!"; return OSOT_ERR_INVALID; }   // nHQP.cpp:32-35
-        // the level's SVD goes through the eigen-decomposition of the SMALL-side Gram matrix, 32-wide (sym_eig32)
-        if ((m < nf ? m : nf) > 32) { *why = "nHQP front-end: min(rows of a level, its free variables) <= 32"; return OSOT_ERR_UNSUPPORTED; }
+        // (min(rows, free variables) <= 32: the SVD goes through the 32-wide eigen-decomposition of the small-side Gram matrix; beyond --
+        //  round 5 -- through osot_nhqp_prepare_wide_kernel: nhqp_level_is_wide)
         free_vars[k] = nf;
         nf = nf - m;       // default for the next level: full row rank (the constructor's count, nHQP.cpp:88-91, on a full-rank task)
     }
@@ -45,9 +56,10 @@ inline int nhqp_validate(const osot_plan_desc& p, const osot_nhqp_options* opt, 
 }
 
 // prepare(DevNhqp), qp(B, n, nc, H, g, A, lA, uA, l, u, eps, x, status, iters), accumulate(DevNhqpAcc)
+// task_active: [OSOT_MAX_LEVELS * OSOT_MAX_TASKS] Task::setActive flags, or null (every task active)
 template <class FPrep, class FQp, class FAcc>
 int nhqp_run(const osot_plan_desc& p, const osot_qp_batch* b, const osot_nhqp_options* opt, const NhqpWorkspace& ws,
-             FPrep prepare, FQp qp, FAcc accumulate, const char** why) {
+             FPrep prepare, FQp qp, FAcc accumulate, const char** why, const unsigned char* task_active = nullptr) {
     int free_vars[OSOT_MAX_LEVELS];
     int rc = nhqp_validate(p, opt, free_vars, why);
     if (rc != OSOT_OK) return rc;
@@ -61,9 +73,16 @@ int nhqp_run(const osot_plan_desc& p, const osot_qp_batch* b, const osot_nhqp_op
         DevNhqp Q;
         std::memset(&Q, 0, sizeof(Q));
         Q.B = B; Q.n = n; Q.nc = nc; Q.level = k; Q.m = m; Q.ma = ma; Q.nf = nf; Q.ns = ns; Q.has_box = has_box ? 1 : 0;
-        Q.ab_reg = !(opt && opt->no_ab_regularization); Q.sel_reg = !(opt && opt->no_selective_ns_regularization);
-        // nHQP.h:66: 0.05 by default.  A positive value is honoured as it is; the flag is only needed to express 0 ("lift nothing")
-        Q.thr = !opt ? 0.05 : (opt->min_sv_ratio_is_set ? opt->min_sv_ratio : (opt->min_sv_ratio > 0.0 ? opt->min_sv_ratio : 0.05));
+        nhqp_level_options(opt, k, Q.ab_reg, Q.sel_reg, Q.thr);
+        if (task_active) {         // rows of the level's inactive tasks (Task::setActive(false): A zeroed, Task.h:383-387)
+            int off = 0;
+            for (int j = 0; j < p.level[k].n_tasks; ++j) {
+                const int rows = p.level[k].task[j].rows;
+                if (!task_active[k * OSOT_MAX_TASKS + j])
+                    for (int r = off; r < off + rows && r < 64; ++r) Q.zero_rows |= (1ull << r);
+                off += rows;
+            }
+        }
         Q.A = b->A[k]; Q.b = b->b[k]; Q.w = b->w[k];
         Q.C = b->C; Q.lo = b->lo; Q.up = b->up; Q.l = b->l; Q.u = b->u;
         Q.N = ws.N[k & 1]; Q.q0 = ws.q0;

@@ -252,6 +252,11 @@ class PipelinedCycle:
         events on the lane's stream around its graph (replay_launch_ms() turns them into the average duration of one launch of the
         lane INSIDE the replays, the gap between consecutive launches of a graph included)"""
         ph = self.lanes[0].i % self._K
+        if ph not in self._graphs:
+            # (capture() records the phases whole replays can reach from where it was called; plain step() calls in between that
+            #  are not a multiple of the rotation land elsewhere)
+            raise RuntimeError(f"no graph was captured for cycle {ph} of the rotation (captured: {sorted(self._graphs)}): "
+                               "call capture() again after stepping, or step a multiple of the rotation between replays")
         for j, (lane, g, st) in enumerate(zip(self.lanes, self._graphs[ph], self.streams)):
             with self._torch.cuda.stream(st):
                 if timed:

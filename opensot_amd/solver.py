@@ -249,11 +249,25 @@ class BatchedStack:
         if free_vars is not None:
             for k, v in enumerate(free_vars):
                 opt.free_vars[k] = int(v)
-        if min_sv_ratio is not None:       # None: the reference's default 0.05; 0.0 is a value (no singular value is lifted)
+        # scalars: the solver-wide setters; lists (one entry per level): nHQP::setPerformAbRegularization(level, .),
+        # setPerformSelectiveNullSpaceRegularization(level, .), setMinSingularValueRatio(std::vector<double>) (nHQP.cpp:127-152, 206-221)
+        if isinstance(min_sv_ratio, (list, tuple)):
+            for k, v in enumerate(min_sv_ratio):
+                if v is not None:
+                    opt.level_min_sv_ratio[k] = float(v); opt.level_min_sv_ratio_is_set[k] = 1
+        elif min_sv_ratio is not None:       # None: the reference's default 0.05; 0.0 is a value (no singular value is lifted)
             opt.min_sv_ratio = float(min_sv_ratio)
             opt.min_sv_ratio_is_set = 1
-        opt.no_ab_regularization = 0 if ab_regularization else 1
-        opt.no_selective_ns_regularization = 0 if selective_ns_regularization else 1
+        if isinstance(ab_regularization, (list, tuple)):
+            for k, v in enumerate(ab_regularization):
+                opt.level_no_ab_regularization[k] = 0 if v else 1
+        else:
+            opt.no_ab_regularization = 0 if ab_regularization else 1
+        if isinstance(selective_ns_regularization, (list, tuple)):
+            for k, v in enumerate(selective_ns_regularization):
+                opt.level_no_selective_ns_regularization[k] = 0 if v else 1
+        else:
+            opt.no_selective_ns_regularization = 0 if selective_ns_regularization else 1
         qb = self._qp_batch(B)
         abi.check(self._lib.osot_nhqp_solve(self._h, C.byref(qb), C.byref(opt), _stream_ptr(self.device, self.stream)), "osot_nhqp_solve")
 

@@ -112,11 +112,19 @@ def nhqp_solve(asm, free_vars=None, min_sv_ratio=DEFAULT_MIN_SV_RATIO, ab_regula
     nf = list(free_vars) if free_vars is not None else free_variables(asm, 0)
     dq = np.zeros((B, n)); status = np.zeros(B, dtype=np.int32)
     clamp = lexcheck._clamp
+    # per-level switches (nHQP::setPerformAbRegularization(level, .), setPerformSelectiveNullSpaceRegularization(level, .),
+    # setMinSingularValueRatio(std::vector<double>): nHQP.cpp:127-152, 206-221): a list holds one entry per level
+    per_level = lambda v, k: v[k] if isinstance(v, (list, tuple)) else v
+    ab_all, sel_all, thr_all = ab_regularization, selective_ns_regularization, min_sv_ratio
     for i in range(B):
         q0 = np.zeros(n)
         N = np.eye(n)
         ok = True
         for k in range(L):
+            ab_regularization, selective_ns_regularization = per_level(ab_all, k), per_level(sel_all, k)
+            min_sv_ratio = per_level(thr_all, k)
+            if min_sv_ratio is None:
+                min_sv_ratio = DEFAULT_MIN_SV_RATIO
             A = lexcheck._level_matrix(asm, i, k)
             w = asm["w"][k][i] if asm["w"][k] is not None else np.ones(A.shape[0])
             W = np.diag(w)

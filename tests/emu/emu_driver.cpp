@@ -88,7 +88,7 @@ extern "C" __attribute__((visibility("default"))) int emu_qp_solve_batch_admm(in
 
 // the null-space front-end (osot_nhqp_host.h: the product's own orchestration) on host pointers
 extern "C" __attribute__((visibility("default"))) int emu_nhqp_solve(const osot_plan_desc* plan, const osot_qp_batch* b,
-                                                                     const osot_nhqp_options* opt) {
+                                                                     const osot_nhqp_options* opt, const unsigned char* task_active) {
     const char* why = "";
     int rc = plan_validate(plan, &why);
     if (rc != OSOT_OK) { fprintf(stderr, "emu: %s\n", why); return rc; }
@@ -99,7 +99,8 @@ extern "C" __attribute__((visibility("default"))) int emu_nhqp_solve(const osot_
     const unsigned grid = (unsigned)b->B;
     rc = nhqp_run(*plan, b, opt, ws,
         [&](const DevNhqp& Q) {
-            if (Q.n > 32) {
+            if (nhqp_level_is_wide(Q.m, Q.nf)) emu::launch(osot_nhqp_prepare_wide_kernel, grid, nhqp_prepare_wide_lds_bytes(Q.m, Q.n), 64, Q);
+            else if (Q.n > 32) {
                 if (Q.m <= 32) emu::launch(osot_nhqp_prepare64_kernel<32>, grid, nhqp_prepare64_lds_bytes(32, Q.n), 64, Q);
                 else emu::launch(osot_nhqp_prepare64_kernel<64>, grid, nhqp_prepare64_lds_bytes(64, Q.n), 64, Q);
             }
@@ -110,7 +111,7 @@ extern "C" __attribute__((visibility("default"))) int emu_nhqp_solve(const osot_
             const double* l, const double* u, double eps, double* x, int* status, int* iters) {
             return emu_qp_solve_batch(B, n, nc, Hh, gg, A, lA, uA, l, u, eps, 0, x, status, iters);
         },
-        [&](const DevNhqpAcc& A) { emu::launch(osot_nhqp_accumulate_kernel, grid, 0, 64, A); }, &why);
+        [&](const DevNhqpAcc& A) { emu::launch(osot_nhqp_accumulate_kernel, grid, 0, 64, A); }, &why, task_active);
     if (rc != OSOT_OK) fprintf(stderr, "emu: %s\n", why);
     return rc;
 }

@@ -378,8 +378,35 @@ def answer_is_acceptable(asm, i, dq_dev, witnesses, tol=1e-6, feas_tol=1e-7, act
     return True, f"{d:.1e} from the closest witness, feasible to {gv:.1e} and lexicographically not worse than any as-feasible witness"
 
 
-def emu_nhqp(plan, asm, free_vars=None, min_sv_ratio=None, ab_regularization=True, selective_ns_regularization=True):
-    """the null-space front-end (osot_nhqp_*.h: kernels AND host orchestration) on host pointers through the emulator"""
+def nhqp_fill_options(opt, free_vars=None, min_sv_ratio=None, ab_regularization=True, selective_ns_regularization=True):
+    """osot_nhqp_options from the reference's setters: scalars are the solver-wide form, lists (one entry per level) the per-level one
+    (nHQP::setPerformAbRegularization(level, .), setPerformSelectiveNullSpaceRegularization(level, .), setMinSingularValueRatio(vector))"""
+    if free_vars is not None:
+        for k, v in enumerate(free_vars):
+            opt.free_vars[k] = int(v)
+    if isinstance(min_sv_ratio, (list, tuple)):
+        for k, v in enumerate(min_sv_ratio):
+            if v is not None:
+                opt.level_min_sv_ratio[k] = float(v); opt.level_min_sv_ratio_is_set[k] = 1
+    elif min_sv_ratio is not None:
+        opt.min_sv_ratio = min_sv_ratio
+        opt.min_sv_ratio_is_set = 1
+    if isinstance(ab_regularization, (list, tuple)):
+        for k, v in enumerate(ab_regularization):
+            opt.level_no_ab_regularization[k] = 0 if v else 1
+    else:
+        opt.no_ab_regularization = 0 if ab_regularization else 1
+    if isinstance(selective_ns_regularization, (list, tuple)):
+        for k, v in enumerate(selective_ns_regularization):
+            opt.level_no_selective_ns_regularization[k] = 0 if v else 1
+    else:
+        opt.no_selective_ns_regularization = 0 if selective_ns_regularization else 1
+    return opt
+
+
+def emu_nhqp(plan, asm, free_vars=None, min_sv_ratio=None, ab_regularization=True, selective_ns_regularization=True, task_active=None):
+    """the null-space front-end (osot_nhqp_*.h: kernels AND host orchestration) on host pointers through the emulator.
+    task_active: {(level, task): bool} (Task::setActive)"""
     B, n, L = asm["B"], asm["n"], asm["L"]
     qb = abi.QpBatch()
     qb.B = B
@@ -397,19 +424,16 @@ def emu_nhqp(plan, asm, free_vars=None, min_sv_ratio=None, ab_regularization=Tru
             setattr(qb, name, a.ctypes.data)
     dq = np.zeros((B, n)); st = np.full(B, -1, dtype=np.int32)
     qb.dq, qb.status = dq.ctypes.data, st.ctypes.data
-    opt = abi.NhqpOptions()
-    if free_vars is not None:
-        for k, v in enumerate(free_vars):
-            opt.free_vars[k] = int(v)
-    if min_sv_ratio is not None:
-        opt.min_sv_ratio = min_sv_ratio
-        opt.min_sv_ratio_is_set = 1
-    opt.no_ab_regularization = 0 if ab_regularization else 1
-    opt.no_selective_ns_regularization = 0 if selective_ns_regularization else 1
+    opt = nhqp_fill_options(abi.NhqpOptions(), free_vars, min_sv_ratio, ab_regularization, selective_ns_regularization)
+    ta = None
+    if task_active:
+        ta = np.ones(abi.MAX_LEVELS * abi.MAX_TASKS, dtype=np.uint8)
+        for (k, j), on in task_active.items():
+            ta[k * abi.MAX_TASKS + j] = 1 if on else 0
     L_ = emu_lib()
-    L_.emu_nhqp_solve.argtypes = [C.POINTER(abi.PlanDesc), C.POINTER(abi.QpBatch), C.POINTER(abi.NhqpOptions)]
+    L_.emu_nhqp_solve.argtypes = [C.POINTER(abi.PlanDesc), C.POINTER(abi.QpBatch), C.POINTER(abi.NhqpOptions), C.c_void_p]
     pd = plan.to_c()
-    rc = L_.emu_nhqp_solve(C.byref(pd), C.byref(qb), C.byref(opt))
+    rc = L_.emu_nhqp_solve(C.byref(pd), C.byref(qb), C.byref(opt), None if ta is None else ta.ctypes.data)
     assert rc == 0
     return dq, st
 

@@ -466,6 +466,68 @@ def test_control_cycle_in_one_launch_on_the_35_coordinate_coman(gpu_device):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("which", ["S1", "S2", "S3", "S4"])
+def test_coman35_published_stacks_through_nhqp(which, gpu_device):
+    """the reference's four published stacks (examples/cpp/coman_ik.cpp:425-449) on its own 35-coordinate robot
+    through the null-space front-end, closed loop on the device.  S1 -- ONE level of 50 rows in 35 variables -- was refused until
+    round 5 (min(rows, free variables) > 32: osot_nhqp_prepare_wide_kernel).  Every robot solved at every checked step, the URDF's
+    joint limits held, the feet (TaskToConstraint rows) stayed, the right wrist moved towards its goal."""
+    import sys, os
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from opensot_amd.solver import BatchedStack
+    m, lo, up = _coman()
+    n, B = m.n, 64
+    plan = bench.coman_stack(which, n)
+    dev = torch.device("cuda", 0)
+    f64 = dict(dtype=torch.float64, device=dev)
+    rng = np.random.default_rng(4)
+    q0 = np.zeros((B, n))
+    for s_ in "RL":
+        q0[:, m.names.index(s_ + "HipSag")] = -0.3; q0[:, m.names.index(s_ + "KneeSag")] = 0.6
+        q0[:, m.names.index(s_ + "AnkSag")] = -0.3; q0[:, m.names.index(s_ + "Elbj")] = -0.8
+        q0[:, m.names.index(s_ + "ShSag")] = 0.2
+    q0[:, m.names.index("LShLat")] = 0.3; q0[:, m.names.index("RShLat")] = -0.3
+    q0[:, 6:] += rng.normal(0.0, 0.01, (B, n - 6))
+    q0 = np.clip(q0, np.maximum(lo, -10.0) + 1e-3, np.minimum(up, 10.0) - 1e-3)
+    st = BatchedStack(plan, B, device=0, want_levels=False)
+    K = kin.Kinematics(m, device=0)
+    q = torch.as_tensor(q0, **f64).contiguous()
+    pose = [torch.zeros((B, 12), **f64) for _ in range(4)]
+    com = torch.zeros((B, 3), **f64)
+    where, off = {}, [0] * plan.L
+    for k, lev in enumerate(plan.levels):
+        for t in lev:
+            if t.name in ("l_wrist", "r_wrist", "com"):
+                where[t.name] = (st.A[k], off[k])
+            if not t.implicit:
+                off[k] += t.rows
+    kw = dict(frame_pose={f: pose[f] for f in range(4)}, frame_J={0: where["l_wrist"], 1: where["r_wrist"], 2: (st.C, 0), 3: (st.C, 6)},
+              com=com, com_J=where["com"])
+    K.forward(q, **kw); torch.cuda.synchronize()
+    pose_d = [p.clone() for p in pose]
+    pose_d[1][:, 9:] += torch.as_tensor([0.05, -0.02, 0.04], **f64)
+    big = 1.0e3
+    qmin = torch.as_tensor(np.tile(np.maximum(lo, -big), (B, 1)), **f64); qmax = torch.as_tensor(np.tile(np.minimum(up, big), (B, 1)), **f64)
+    leaf_of = {"l_wrist": (pose[0], pose_d[0], None), "r_wrist": (pose[1], pose_d[1], None), "com": (com, com.clone(), None), "postural": (q, q.clone(), None)}
+    leaf = {"B": B, "task": [[leaf_of[t.name] for t in lev] for lev in plan.levels],
+            "bound": [(q, qmin, qmax), (torch.full((B, n), 2.0, **f64), None, None)], "rows": [(pose[2], pose_d[2], None), (pose[3], pose_d[3], None)]}
+    e0 = float((pose_d[1][:, 9:] - pose[1][:, 9:]).norm(dim=1).max())
+    for cycle in range(150):
+        K.forward(q, **kw); st.update(leaf); st.solve_nhqp(B); q += st.dq[:B]
+        if cycle in (0, 75, 149):
+            torch.cuda.synchronize()
+            assert (st.status[:B] == 0).all(), (which, cycle, st.status[:B].cpu().numpy())
+    K.forward(q, **kw); torch.cuda.synchronize()
+    qh = q.cpu().numpy()
+    assert (qh[:, 6:] >= lo[6:] - 1e-9).all() and (qh[:, 6:] <= up[6:] + 1e-9).all()
+    assert float((pose_d[1][:, 9:] - pose[1][:, 9:]).norm(dim=1).max()) < 0.5 * e0
+    for f in (2, 3):
+        assert float((pose_d[f][:, 9:] - pose[f][:, 9:]).norm(dim=1).max()) < 5e-3
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("front_end", ["iHQP", "eHQP", "nHQP"])
 def test_closed_loop_ik_coman35(front_end, gpu_device):
     """the reference's own robot and stack -- examples/cpp/coman_ik.cpp:425-449: 35 coordinates,
