@@ -1,0 +1,15 @@
+#!/bin/sh
+# developer helper, runs ON the GPU box (through gpurun): every randomised sweep of tests/stress_*.py against the witnesses
+# (qpOASES reference build + the restatements), one output file per sweep under gpurun_out/stress_<tag>/ ; the files are
+# copied into profiles/<tag>_stress_*.txt by hand.  The seeds are the ones every round since round 3 has used.
+TAG=${1:-r05}
+OUT=$PWD/gpurun_out/stress_$TAG
+mkdir -p $OUT
+cd "$GRAFT_REPO_ROOT"
+for s in 1 2 3 4; do python tests/stress_parity.py $s 800 2>&1 | grep -v amdgpu.ids; done > $OUT/stress_parity.txt
+python tests/stress_qp.py 1 60 2>&1 | grep -v amdgpu.ids > $OUT/stress_qp.txt
+python tests/stress_frontends.py 1 160 2>&1 | grep -v amdgpu.ids > $OUT/stress_frontends.txt
+for s in 11 12 13; do python tests/stress_hotstart.py $s 90 2>&1 | grep -v amdgpu.ids; done > $OUT/stress_hotstart.txt
+{ python tests/stress_closed_loop.py 41 1024 300 1e6 tasks; python tests/stress_closed_loop.py 42 1024 300 200 tasks;
+  python tests/stress_closed_loop.py 41 1024 300 1e6 ttc; python tests/stress_closed_loop.py 42 1024 300 200 ttc; } 2>&1 | grep -v amdgpu.ids > $OUT/stress_closed_loop.txt
+tail -n 3 $OUT/*.txt
