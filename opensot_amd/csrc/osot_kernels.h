@@ -232,6 +232,13 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
         double g = 0.0, hdiag = 0.0;
         const bool diag_h = (ma == 0) && !regd;
         double hacc[NP / HV];
+        // (defined on EVERY path through the level: left undefined on the diagonal / low-rank paths, the compiler resolves the merge by
+        //  keeping the PREVIOUS level's tiles alive across the whole loop body -- 2 x NP / HV registers through the active-set loops,
+        //  spilled and reloaded at the loop's back edge in the 64-lane layouts)
+#ifndef OSOT_X_HACC_UNDEF
+#pragma unroll
+        for (int ii = 0; ii < NP / HV; ++ii) hacc[ii] = 0.0;
+#endif
         bool lowrank = false;   // few stored rows: J and x in closed form, no H, no factorisation (lowrank_prepare32)
         double xprep = 0.0;
         if constexpr (NP == 32) {
@@ -369,6 +376,123 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
                 for (int C2 = 0; C2 < 2; ++C2)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) hacc[4 * (2 * I + C2) + r] = Ht[I][C2][r];
+          } else if constexpr (kWideTiles) {
+            // ---- round 5: the same H build on the matrix core for the 64-lane layouts (33 .. 64 variables): T x T tiles of
+            // 16 x 16, the UPPER triangle only (H is symmetric and factor_tiles_wide reads nothing else).  Lane (a, q) of the
+            // PHYSICAL lane loads A[r0 + q][16 X + a], X < T: T coalesced loads cover four rows, and those registers are the
+            // MFMA operands of every tile -- where the register build below spends an LDS broadcast and NP fma per row and lane.
+            constexpr int T = wide_tiles(NP), NT = (T * (T + 1)) / 2;
+            const int ta = lane & 15, tq = lane >> 4;
+            v4f64 Ht[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) Ht[t] = v4f64{0.0, 0.0, 0.0, 0.0};
+            double gp[T];
+#pragma unroll
+            for (int X = 0; X < T; ++X) gp[X] = 0.0;
+            double bw_b = 0.0, bw_w = 1.0;     // b_r and w_r of up to 64 rows, lane = row (see the NP = 32 branch)
+            int bw_base = -1;
+            auto fetch = [&](int r0, double (&a)[T], double (&l)[T], double& gb) {
+                const int r = r0 + tq;
+                const bool in = r < ma && !(inact && row_off(r));
+                const int rr = (r < ma) ? r : ma - 1;
+                double v[T];
+#pragma unroll
+                for (int X = 0; X < T; ++X) v[X] = Ak[rr * n + ((16 * X + ta < n) ? 16 * X + ta : 0)];
+#pragma unroll
+                for (int X = 0; X < T; ++X) a[X] = (in && 16 * X + ta < n) ? v[X] : 0.0;
+                if (dense) {
+                    gb = Wbk[rr];
+                    double u[T];
+#pragma unroll
+                    for (int X = 0; X < T; ++X) u[X] = WAk[rr * n + ((16 * X + ta < n) ? 16 * X + ta : 0)];
+#pragma unroll
+                    for (int X = 0; X < T; ++X) l[X] = (in && 16 * X + ta < n) ? u[X] : 0.0;
+                } else {
+                    const int src4 = (rr - bw_base) << 2;
+                    gb = permute_f64(bw_b, src4);
+                    const double wv = wk ? permute_f64(bw_w, src4) : 1.0;
+#pragma unroll
+                    for (int X = 0; X < T; ++X) l[X] = wv * a[X];
+                }
+            };
+#ifndef OSOT_HB_DEPTH_WIDE
+#define OSOT_HB_DEPTH_WIDE 4
+#endif
+            constexpr int HBW = OSOT_HB_DEPTH_WIDE;   // groups of four rows requested before the first MFMA
+            for (int rb = 0; rb < ma; rb += 4 * HBW) {
+                if (!dense && (rb & 63) == 0) {          // rows rb .. rb + 63 of b and w, lane = row
+                    const int rl = rb + lane;
+                    bw_b = (rl < ma) ? bk[rl] : 0.0;
+                    bw_w = (wk && rl < ma) ? wk[rl] : 1.0;
+                    bw_base = rb;
+                }
+                double ca[HBW][T], cl[HBW][T], cbr[HBW];
+#pragma unroll
+                for (int ch = 0; ch < HBW; ++ch) {
+#pragma unroll
+                    for (int X = 0; X < T; ++X) { ca[ch][X] = 0.0; cl[ch][X] = 0.0; }
+                    cbr[ch] = 0.0;
+                    if (rb + 4 * ch < ma) fetch(rb + 4 * ch, ca[ch], cl[ch], cbr[ch]);
+                }
+#pragma unroll
+                for (int ch = 0; ch < HBW; ++ch) {
+                    if (rb + 4 * ch < ma) {
+#pragma unroll
+                        for (int X = 0; X < T; ++X) gp[X] = fma(dense ? -ca[ch][X] : -cl[ch][X], cbr[ch], gp[X]);
+#pragma unroll
+                        for (int I = 0; I < T; ++I)
+#pragma unroll
+                            for (int C2 = I; C2 < T; ++C2)
+                                Ht[tile_u<T>(I, C2)] = mfma_f64_16x16x4(cl[ch][I], ca[ch][C2], Ht[tile_u<T>(I, C2)]);
+                    }
+                }
+            }
+            if (regd) {   // the regularisation task's rows: H += w A_r'A_r, g -= w A_r'b_r (iHQP.cpp:274-278), same operand layout
+                const double* Ar = D.A_reg + inst * (long long)P.reg_rows * n;
+                const double* br = D.b_reg + inst * P.reg_rows;
+                for (int r0 = 0; r0 < P.reg_rows; r0 += 4) {
+                    const int r = r0 + tq;
+                    const bool in = r < P.reg_rows;
+                    const int rr = in ? r : P.reg_rows - 1;
+                    double a[T], wa[T];
+#pragma unroll
+                    for (int X = 0; X < T; ++X) a[X] = Ar[rr * n + ((16 * X + ta < n) ? 16 * X + ta : 0)];
+                    const double bb = br[rr];
+#pragma unroll
+                    for (int X = 0; X < T; ++X) {
+                        a[X] = (in && 16 * X + ta < n) ? a[X] : 0.0;
+                        wa[X] = P.reg_w * a[X];
+                        gp[X] = fma(-wa[X], bb, gp[X]);
+                    }
+#pragma unroll
+                    for (int I = 0; I < T; ++I)
+#pragma unroll
+                        for (int C2 = I; C2 < T; ++C2) Ht[tile_u<T>(I, C2)] = mfma_f64_16x16x4(wa[I], a[C2], Ht[tile_u<T>(I, C2)]);
+                }
+            }
+            OSOT_PH_END(PH_INV);   // (profiling slot reused: MFMA loop of the H build)
+            // g: the partial sums of a column sit in the four rows of 16 lanes; lane = column 16 q + a takes tile column q
+            double gsel = 0.0;
+#pragma unroll
+            for (int X = 0; X < T; ++X) { const double gs = rowgroup_sum(gp[X]); gsel = (tq == X) ? gs : gsel; }
+            g = (lane < n) ? gsel : 0.0;
+            const int npost = m - ma;   // Postural block appended to the level: A = [I 0] (Postural.cpp:37)
+            if (npost > 0 && c < npost) g -= wrow(ma + c) * bk[ma + c];
+            // diagonal: Postural weights, eps I (+ the regularisation task's diagonal), unit diagonal beyond n
+#pragma unroll
+            for (int I = 0; I < T; ++I) {
+                const int i = 16 * I + ta;    // diagonal element (i, i) lives in tile (I, I) where a == q + 4 r
+                double dv = (i < n) ? P.eps_abs : 1.0;
+                if (i < npost) dv += wrow(ma + i);
+                if (D.b_reg && !regd && i < P.reg_rows) dv += P.reg_w;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ht[tile_u<T>(I, I)][r] += (ta == tq + 4 * r) ? dv : 0.0;
+            }
+            OSOT_PH_END(PH_SUBST);   // (profiling slot reused: g reduction + diagonal of the H build)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hacc[4 * t + r] = Ht[t][r];
           } else {
             // ---- H = A'WA + eps I, g = -A'Wb + c.  Lane (c,h) accumulates H[i][c] for i = ii*HV + h in
             // registers; stored rows are staged four at a time through LDS for the broadcasts.
@@ -666,6 +790,19 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
             Hc[t] = (i < n && cc < n) ? Q.H[(inst * n + i) * n + cc] + ((i == cc) ? Q.eps_abs : 0.0)
                                       : ((i == cc) ? 1.0 : 0.0);   // unit diagonal beyond n
         }
+    } else if constexpr (kWideTiles) {   // the upper triangle of 16 x 16 tiles (factor_tiles_wide): Hc[4 tile_u(I, C) + r] = H[16 I + q + 4 r][16 C + a]
+        constexpr int T = wide_tiles(NP);
+        const int ta = lane & 15, tq = lane >> 4;
+#pragma unroll
+        for (int I = 0; I < T; ++I)
+#pragma unroll
+            for (int C2 = I; C2 < T; ++C2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * I + tq + 4 * r, cc = 16 * C2 + ta;
+                    Hc[4 * tile_u<T>(I, C2) + r] = (i < n && cc < n) ? Q.H[(inst * n + i) * n + cc] + ((i == cc) ? Q.eps_abs : 0.0)
+                                                                      : ((i == cc) ? 1.0 : 0.0);   // unit diagonal beyond n
+                }
     } else {
 #pragma unroll
         for (int ii = 0; ii < NP / HV; ++ii) {

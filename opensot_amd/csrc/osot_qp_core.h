@@ -108,7 +108,12 @@ struct WaveCtx {
     static constexpr int M1_DOUBLES = PH ? (NP * (NP + 1)) / 2 : NP * (NP + 3) / 2;
     // elements in flight per trip of the mat-vec passes / the stored-row walk (divisors of NP, multiples of 4)
 #ifndef OSOT_DOT_CH40
-#define OSOT_DOT_CH40 20
+#define OSOT_DOT_CH40 8     // round 5, A/B on one box with the tile factorisation in (COMAN35 S1..S4, M solves/s): 8 -> 19.9 / 8.37 / 6.58 / 4.33 with 222
+                            // registers and NO spill; 20 (round 4's value) -> 19.6 / 8.33 / 6.52 / 4.32 with 26 spilled registers
+#endif
+#ifndef OSOT_DOT2_CH40
+#define OSOT_DOT2_CH40 8    // the two-product passes (jt_rows_dot2 / jt_cols_dot2) hold three arrays per trip: at 20 elements their 120 registers were
+                            // the NP = 40 kernels' peak
 #endif
     static constexpr int DOT_CH = (NP == 56) ? 28 : ((NP == 40) ? OSOT_DOT_CH40 : 16);
     static constexpr int LDS_DOUBLES = M1_DOUBLES + ROWS * S + 4 * LW;   // M1, M2, V (four staging vectors of LW)
@@ -216,7 +221,7 @@ __device__ __forceinline__ double jt_cols_dot(const WaveCtx<NP>& w, const double
 // above all at one wavefront per SIMD -- are shared, each element feeds two accumulator sets.
 template <int NP>
 __device__ __forceinline__ void jt_rows_dot2(const WaveCtx<NP>& w, const double* va, const double* vb, double& da, double& db) {
-    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = (NP == 32) ? 8 : WaveCtx<NP>::DOT_CH;
+    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = (NP == 32) ? 8 : ((NP == 40) ? OSOT_DOT2_CH40 : WaveCtx<NP>::DOT_CH);
     const double* row = w.M2 + w.c * S + w.h;
     const double* pa = va + w.h;
     const double* pb = vb + w.h;
@@ -239,7 +244,7 @@ __device__ __forceinline__ void jt_rows_dot2(const WaveCtx<NP>& w, const double*
 }
 template <int NP>
 __device__ __forceinline__ void jt_cols_dot2(const WaveCtx<NP>& w, const double* va, const double* vb, double& za, double& zb) {
-    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = (NP == 32) ? 8 : WaveCtx<NP>::DOT_CH;
+    constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S, CH = (NP == 32) ? 8 : ((NP == 40) ? OSOT_DOT2_CH40 : WaveCtx<NP>::DOT_CH);
     const double* col = w.M2 + w.h * S + w.c;
     const double* pa = va + w.h;
     const double* pb = vb + w.h;
@@ -522,6 +527,149 @@ __device__ inline int factor_tiles32(const WaveCtx<32>& w, double (&Hf)[16], dou
     OSOT_TT(3);   // backward substitution
 #undef OSOT_TT
     x_out = valid ? x : 0.0;
+    return QP_SOLVED;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Round 5: the SAME blocked factorisation for the 64-lane layouts (NP = 40 / 56 / 64: 33 .. 64 variables) on T x T tiles of
+// 16 x 16 (T = 3 covers 48 columns, T = 4 covers 64).  H + eps I arrives as the UPPER triangle of tiles (T (T + 1) / 2 of them,
+// tile_u), L^-1 is built as the LOWER triangle (tile_l): 24 + 24 fp64 registers for T = 3, 40 + 40 for T = 4, where the
+// register-resident row sweep (factor_rows64 below) holds NP-register arrays whose fully unrolled sweeps the allocator answers
+// with 50 .. 300 spilled registers (profiles/r05_v1_kernel_resources.txt).  Panel p = columns 4p .. 4p+3 is element p & 3 of the
+// tiles (p >> 2, X), X >= p >> 2; the trailing updates are one MFMA per live tile.  Panels that lie entirely in the identity
+// padding beyond n (only possible from p = 8 on: these layouts serve n > 32) are skipped under a uniform guard: the padding
+// factorises to itself and no earlier panel reaches it (its off-diagonal entries are zero).
+// In : Hf[4 tile_u(I, C) + r] = (H + eps I)[16 I + q + 4 r][16 C + a] with a unit diagonal beyond n, lane (a, q) = (lane & 15,
+// lane >> 4) of the PHYSICAL lane; g by lane = column.  Out: M2 = JT = L^-1 (identity on the padding n .. NP-1, nothing at or
+// beyond NP), x = -(H + eps I)^-1 g by substitution (forward panel by panel, backward as (L^-1)'y); M1 clobbered.
+// the 64-lane layouts factorise on tiles (factor_tiles_wide); OSOT_X_ROWS64 brings back the register row sweep (A/B builds)
+#ifdef OSOT_X_ROWS64
+constexpr bool kWideTiles = false;
+#else
+constexpr bool kWideTiles = true;
+#endif
+constexpr int wide_tiles(int np) { return np <= 48 ? 3 : 4; }      // 16 x 16 tiles per side: NP = 40 -> 3, NP = 56 / 64 -> 4
+template <int P, int N, class F>
+__device__ __forceinline__ void static_for(F& f) {       // f(integral_constant<int, P>) for P = P .. N-1, each a compile-time call
+    if constexpr (P < N) { f(std::integral_constant<int, P>{}); static_for<P + 1, N>(f); }
+}
+template <int T> __device__ __forceinline__ constexpr int tile_u(int I, int C) { return I * T - (I * (I - 1)) / 2 + (C - I); }   // I <= C
+__device__ __forceinline__ constexpr int tile_l(int I, int C) { return (I * (I + 1)) / 2 + C; }                                  // C <= I
+template <int NP, int T>
+__device__ __forceinline__ int factor_tiles_wide(const WaveCtx<NP>& w, double (&Hf)[NP], double g, double& x_out) {
+    static_assert(NP > 32 && 16 * T >= NP && 4 * (T * (T + 1)) / 2 <= NP, "tile count against the register array of the caller");
+    constexpr int S = WaveCtx<NP>::S, NT = (T * (T + 1)) / 2, PBS = 16 * T;
+    const int n = w.n;
+    const int lane = phys_lane();
+    const int ta = lane & 15, tq = lane >> 4;
+    double* PB = w.M1;   // [4][16 T] staging of the finished panel: PB[q * PBS + i] = L[i][4p + q]
+    double* M2 = w.M2;
+    double rhs = (lane < n) ? -g : 0.0;   // forward substitution, lane = row
+    v4f64 Hu[NT], Ll[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) Hu[t] = v4f64{Hf[4 * t], Hf[4 * t + 1], Hf[4 * t + 2], Hf[4 * t + 3]};
+#pragma unroll
+    for (int I = 0; I < T; ++I)
+#pragma unroll
+        for (int C = 0; C <= I; ++C)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ll[tile_l(I, C)][r] = (I == C && ta == tq + 4 * r) ? 1.0 : 0.0;
+    bool bad = false;
+    const int prow = (lane < PBS) ? lane : 0;   // my row of the staged panel (lanes beyond the tiles read a harmless entry)
+    auto panel = [&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        constexpr int Ip = p >> 2, rp = p & 3;
+        if (p >= 8 && 4 * p >= n) return;      // identity padding
+        double Pn[T], Rp[T], rsq[4];
+#pragma unroll
+        for (int X = 0; X < T; ++X) {
+            Pn[X] = (X < Ip) ? 0.0 : Hu[tile_u<T>(Ip, (X < Ip) ? Ip : X)][rp];      // rows above the panel's tile row: zero
+            Rp[X] = (X <= Ip) ? Ll[tile_l(Ip, (X <= Ip) ? X : 0)][rp] : 0.0;         // L^-1 has no entries right of the diagonal tile
+        }
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int j = 4 * p + qq;
+            const int lj = (4 * rp + qq) + 16 * qq;   // lane (a = j & 15, q = qq) holds H[j][j] in Pn[Ip]
+            double piv = bcast(Pn[Ip], lj);
+            if (!(piv > 0.0)) { bad = true; piv = 1.0; }
+            double sq, rs;
+            fast_sqrt_rsqrt(piv, sq, rs);
+            rsq[qq] = rs;
+            const bool mine = (tq == qq);
+#pragma unroll
+            for (int X = Ip; X < T; ++X) {
+                const int i = 16 * X + ta;
+                const double scaled = (i > j) ? Pn[X] * rs : ((i == j) ? sq : 0.0);
+                Pn[X] = mine ? scaled : Pn[X];
+            }
+#pragma unroll
+            for (int X = 0; X <= Ip; ++X) Rp[X] = mine ? Rp[X] * rs : Rp[X];
+            if (qq < 3) {
+                const int src = ta + 16 * qq;                                       // lane (a, qq): same row, column j
+                const double ljj = __shfl(Pn[Ip], (4 * rp + tq) + 16 * qq, 64);     // L[4p + q][j] for my column 4p + q
+                const bool later = (tq > qq);
+#pragma unroll
+                for (int X = Ip; X < T; ++X) {
+                    const double colj = __shfl(Pn[X], src, 64);
+                    Pn[X] = later ? fma(-colj, ljj, Pn[X]) : Pn[X];
+                }
+#pragma unroll
+                for (int X = 0; X <= Ip; ++X) {
+                    const double rowj = __shfl(Rp[X], src, 64);
+                    Rp[X] = later ? fma(-ljj, rowj, Rp[X]) : Rp[X];
+                }
+            }
+        }
+        // finished panel (zeros above the diagonal included) -> staging; final rows of L^-1 back into their tiles
+#pragma unroll
+        for (int X = 0; X < T; ++X) PB[tq * PBS + 16 * X + ta] = Pn[X];
+#pragma unroll
+        for (int X = 0; X <= Ip; ++X) Ll[tile_l(Ip, X)][rp] = Rp[X];
+        wave_sync();
+        {   // forward substitution through the panel's four columns
+            double lrow[4];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) lrow[qq] = PB[qq * PBS + prow];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int j = 4 * p + qq;
+                const double yj = bcast(rhs, j) * rsq[qq];
+                rhs = (lane == j) ? yj : ((lane > j && lane < PBS) ? fma(-lrow[qq], yj, rhs) : rhs);
+            }
+        }
+        wave_sync();   // the staging buffer is free for the next panel
+        // trailing updates on the matrix core; the A operand is the panel restricted to the rows below it
+        double Am[T];
+#pragma unroll
+        for (int X = 0; X < T; ++X) Am[X] = (X >= Ip && 16 * X + ta > 4 * p + 3) ? -Pn[X] : 0.0;
+#pragma unroll
+        for (int I = Ip; I < T; ++I) {
+            if (p < 4 * I + 3) {           // tile row I still has rows below the panel
+#pragma unroll
+                for (int C = I; C < T; ++C) Hu[tile_u<T>(I, C)] = mfma_f64_16x16x4(Am[I], -Am[C], Hu[tile_u<T>(I, C)]);
+#pragma unroll
+                for (int C = 0; C <= Ip; ++C) Ll[tile_l(I, C)] = mfma_f64_16x16x4(Am[I], Rp[C], Ll[tile_l(I, C)]);
+            }
+        }
+    };
+    static_for<0, 4 * T>(panel);
+    // JT = L^-1 (zero right of the diagonal tiles; rows / columns at or beyond NP do not exist in the slice)
+#pragma unroll
+    for (int I = 0; I < T; ++I)
+#pragma unroll
+        for (int C = 0; C < T; ++C)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * I + tq + 4 * r, col = 16 * C + ta;
+                if (row < NP && col < NP) M2[row * S + col] = (C <= I) ? Ll[tile_l(I, (C <= I) ? C : 0)][r] : 0.0;
+            }
+    wave_sync();
+    if (bad) { x_out = 0.0; return QP_NOT_PD; }
+    w.V[lane] = (lane < n) ? rhs : 0.0;
+    wave_sync();
+    const double x = jt_cols_dot<NP>(w, w.V);
+    wave_sync();
+    x_out = (w.c < n) ? x : 0.0;
     return QP_SOLVED;
 }
 
@@ -1129,7 +1277,8 @@ __device__ inline void lowrank_prepare32(const WaveCtx<32>& w, const double* Ak,
     wave_sync();
 }
 
-// Pre (general H):  Hc[ii] = (H + eps I)[HV*ii+h][c] in registers (NP = 64, factor_rows64) or the accumulator tiles (NP = 32, factor_tiles32), M1 is scratch.
+// Pre (general H):  Hc = the accumulator tiles of H + eps I (NP = 32: factor_tiles32; NP > 32: the upper triangle of tiles, factor_tiles_wide;
+// with OSOT_X_ROWS64 Hc[ii] = (H + eps I)[ii][c] in registers, factor_rows64), M1 is scratch.
 template <int NP, bool PROF, bool BOX = false>
 __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_h,
                         double hdiag, double (&Hc)[NP / WaveCtx<NP>::HV], bool has_box, double& lb, double& ub, int max_iter,
@@ -1170,8 +1319,10 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
         OSOT_PH_END(PH_CHOL);
     } else {
         int stf;
-        if constexpr (NP > 32) stf = factor_rows64<NP, false>(w, Hc, g, x);
-        else stf = factor_tiles32(w, Hc, g, x);
+        if constexpr (NP > 32) {
+            if constexpr (kWideTiles) stf = factor_tiles_wide<NP, wide_tiles(NP)>(w, Hc, g, x);
+            else stf = factor_rows64<NP, false>(w, Hc, g, x);
+        } else stf = factor_tiles32(w, Hc, g, x);
         stf = uniform_i(stf);
         if (stf != QP_SOLVED) { x_out = 0.0; iters_out = 0; return stf; }
         OSOT_PH_END(PH_CHOL);
