@@ -30,7 +30,7 @@ import torch  # noqa: E402
 
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (AMD public spec; not in MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
-PMC_PROFILE = os.path.join("profiles", "r04_pmc_kernels.json")
+PMC_PROFILE = os.path.join("profiles", "r05_pmc_kernels.json")
 
 
 def algo_flops_per_solve(plan):
@@ -98,7 +98,7 @@ def kernel_source_sha():
 
 
 def pmc_traffic(kernels):
-    """HBM bytes of one STEP from the committed rocprofv3 PMC passes (tools/profile_round.sh -> profiles/r04_pmc_kernels.json):
+    """HBM bytes of one STEP from the committed rocprofv3 PMC passes (tools/profile_round.sh -> profiles/r05_pmc_kernels.json):
     `kernels` = [(substring of the kernel name, workgroups of the launch, launches per step)]; the per-launch FETCH / WRITE
     figures of every (kernel, grid) pair are summed.  Only if the passes were taken on THIS kernel source (hash) and every
     pair is in the table; otherwise (None, None): a stale figure is worse than none."""
