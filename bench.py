@@ -573,18 +573,24 @@ def time_coman35(which, B, device, steps=20, warmup=5, front_end="iHQP", special
     return out
 
 
-def time_full_cycle(B, device, lanes=2, steps=40, warmup=8, streams=None, fused=True, solve_only=False):
+def time_full_cycle(B, device, lanes=2, steps=40, warmup=8, streams=None, fused=True, solve_only=False, rollout=1):
     """q -> kinematics -> AutoStack::update + cascade -> q += dq for the 32-DoF humanoid under BASELINE config 3's stack (CoM / l_wrist(0.1)
     + r_wrist + l_sole + r_sole / Postural, joint-limit and velocity-limit box), everything resident, submitted like the headline: the
     batch as `lanes` sub-batches on their own streams, the steps of a lane as ONE HIP graph.  fused: ONE launch per step
     (osot_control_cycle: the instance's kinematics, update, cascade and integration by the same wavefront); otherwise three (the
     kinematics launch, the fused update + cascade launch, the integration of q).  The inputs of consecutive steps are the closed
-    loop's own drift (every robot chases its own wrist goals); nothing is replayed from a recorded cycle."""
+    loop's own drift (every robot chases its own wrist goals); nothing is replayed from a recorded cycle.
+    rollout = K > 1 (round 5, fused only): K control cycles of every robot per launch (osot_control_rollout: the reference's loop
+    run by the robot's own wavefront); `steps` stays the number of control cycles timed, in steps / K launches per sub-batch."""
     from opensot_amd import abi
     from opensot_amd import kinematics as kin
     from opensot_amd.parallel import lane_ranges
     from opensot_amd.plan import Bound, StackPlan, Task, eps_abs_from_factor
     from opensot_amd.solver import BatchedStack
+    rollout = max(1, int(rollout)) if (fused and not solve_only) else 1
+    if steps % rollout:
+        steps += rollout - steps % rollout
+    calls = steps // rollout
     m = kin.humanoid32()
     n = m.n
     levels = [[Task(abi.TASK_COM, 3, lam=0.1, name="com")],
@@ -635,6 +641,8 @@ def time_full_cycle(B, device, lanes=2, steps=40, warmup=8, streams=None, fused=
             with torch.cuda.stream(stream):
                 if solve_only and frozen[0]:   # (diagnostic: update + cascade alone on the posture the closed loop has reached -- what the
                     st.cycle(leaf, cached=True)   #  solve costs on THIS data, without the producer and the integration)
+                elif fused and rollout > 1:
+                    st.control_rollout(K, kb, leaf, q, rollout)
                 elif fused:
                     st.control_cycle(K, kb, leaf, q_integrate=q)
                 else:
@@ -642,7 +650,7 @@ def time_full_cycle(B, device, lanes=2, steps=40, warmup=8, streams=None, fused=
                     st.cycle(leaf, cached=True)
                     q.add_(st.dq[:Bl])
         work.append((st, step, stream, Bl))
-    for _ in range(warmup + (2 * steps if solve_only else 0)):      # (solve_only: the closed loop runs as long as the timed passes do, then freezes)
+    for _ in range(-(-warmup // rollout) + (2 * steps if solve_only else 0)):      # (solve_only: the closed loop runs as long as the timed passes do, then freezes)
         for _, step, _, _ in work:
             step()
     torch.cuda.synchronize()
@@ -656,7 +664,7 @@ def time_full_cycle(B, device, lanes=2, steps=40, warmup=8, streams=None, fused=
         for st, step, stream, _ in work:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=stream):
-                for _ in range(steps):
+                for _ in range(calls):
                     step()
             graphs.append(g)
     except Exception as e:
@@ -671,7 +679,7 @@ def time_full_cycle(B, device, lanes=2, steps=40, warmup=8, streams=None, fused=
                 with torch.cuda.stream(stream):
                     g.replay()
         else:
-            for _ in range(steps):
+            for _ in range(calls):
                 for _, step, _, _ in work:
                     step()
     run_all(); torch.cuda.synchronize()
@@ -683,10 +691,13 @@ def time_full_cycle(B, device, lanes=2, steps=40, warmup=8, streams=None, fused=
     its = torch.cat([st.iterations[:Bl].float() for st, _, _, Bl in work])
     how = ("ONE launch per step (osot_control_cycle_kernel<32,false,true>: the instance's kinematics, update, cascade and q += dq by the same wavefront)"
            if fused else "three launches per step (osot_kin_kernel, osot_cycle_kernel, the integration of q)")
+    if rollout > 1:
+        how = (f"ROLLOUTS of {rollout} control cycles per launch (osot_control_rollout: every robot's cycles follow each other on its own "
+               "wavefront -- no launch and no wait for the batch's slowest robot between them)")
     return {"workload": "full control cycle on the device, BASELINE configs[2] stack on the 32-DoF humanoid: q -> kinematics (4 frame poses + "
                         "Jacobians, CoM + Jacobian, written into A_k) -> update + cascade -> q += dq; " + how + "; closed loop, every robot "
                         f"chasing its own wrist goals; {lanes} sub-batches on their own streams, {steps} steps of a lane per HIP graph" + ("" if graphs else " (plain launches)"),
-            "batch": B, "lanes": lanes, "value": B * steps / el, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
+            "batch": B, "lanes": lanes, "rollout": rollout, "value": B * steps / el, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
             "solved_ok": f"{ok}/{B}", "note": note,
             "iterations_last_step": {"mean": float(its.mean().item()), "max": int(its.max().item()),
                                      "note": "active-set iterations per solve in the last step of the loop (the headline's synthetic batch: mean 32, max 63): "

@@ -583,6 +583,18 @@ int osot_kinematics(osot_kin* k, const osot_kin_batch* batch, void* hip_stream);
  * Stream-ordered. */
 int osot_control_cycle(osot_solver* s, osot_kin* k, const osot_kin_batch* kin_batch, const osot_leaf_batch* leaf,
                        const osot_assembled_out* out, const osot_qp_batch* batch, double* q_integrate, void* hip_stream);
+/* A ROLLOUT (round 5): `steps` control cycles of every robot in ONE launch -- the loop of the reference's example
+ * (examples/cpp/coman_ik.cpp:174-219: for every iteration model.update(); stack->update(); solver->solve(dq); q = model.sum(q, dq))
+ * run by the robot's own wavefront, cycle after cycle, with the leaf inputs (references, gains) held fixed over the rollout.  The
+ * robots are independent, so the results are those of `steps` osot_control_cycle calls (tested bit-identical) -- without a launch
+ * per step and without every robot waiting, at every step, for the slowest robot of the batch.  What MPC rollouts and sample-based
+ * planners ask for: B candidate roll-outs advanced K control cycles each.
+ * q_integrate (required for steps > 1) is advanced by every cycle's dq; dq / status of the batch hold the LAST cycle's dq and the
+ * FIRST non-zero status of the rollout (a failed cycle leaves the robot where it is: dq = 0, coman_ik.cpp:189-190);
+ * dq_steps [steps][B][n] and status_steps [steps][B] (either may be NULL) receive every cycle's.  Stream-ordered. */
+int osot_control_rollout(osot_solver* s, osot_kin* k, const osot_kin_batch* kin_batch, const osot_leaf_batch* leaf,
+                         const osot_assembled_out* out, const osot_qp_batch* batch, double* q_integrate, int steps,
+                         double* dq_steps, int* status_steps, void* hip_stream);
 
 /* ---- inverse-dynamics formulation (BASELINE config 5): x = [qddot (nv); contact forces / wrenches] -------------
  * (src/utils/InverseDynamics.cpp:12-28).  The matrices that are pure copies of model quantities are written by these

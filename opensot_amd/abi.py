@@ -143,7 +143,7 @@ SYMBOLS = [
     "osot_plan_stored_constraint_rows",
     "osot_solver_create", "osot_solver_destroy", "osot_stack_update", "osot_ihqp_solve", "osot_cycle", "osot_nhqp_solve", "osot_ehqp_solve",
     "osot_solver_kernel_time_ms", "osot_solver_set_timing", "osot_solver_set_schedule", "osot_solver_set_hotstart", "osot_solver_set_specialisation", "osot_solver_set_task_active", "osot_solver_resident_waves",
-    "osot_id_rows", "osot_id_force_gains", "osot_computed_torque", "osot_kin_create", "osot_kin_destroy", "osot_kinematics", "osot_control_cycle", "osot_solver_profile_phases",
+    "osot_id_rows", "osot_id_force_gains", "osot_computed_torque", "osot_kin_create", "osot_kin_destroy", "osot_kinematics", "osot_control_cycle", "osot_control_rollout", "osot_solver_profile_phases",
     "osot_backend_create", "osot_backend_destroy", "osot_backend_init_problem",
     "osot_backend_update_task", "osot_backend_update_constraints", "osot_backend_update_bounds",
     "osot_backend_solve", "osot_backend_get_solution", "osot_backend_get_objective",
@@ -212,6 +212,7 @@ def lib():
     L.osot_kin_destroy.argtypes = [vp]
     L.osot_kinematics.argtypes = [vp, C.POINTER(KinBatch), vp]
     L.osot_control_cycle.argtypes = [vp, vp, C.POINTER(KinBatch), C.POINTER(LeafBatch), C.POINTER(AssembledOut), C.POINTER(QpBatch), vp, vp]
+    L.osot_control_rollout.argtypes = [vp, vp, C.POINTER(KinBatch), C.POINTER(LeafBatch), C.POINTER(AssembledOut), C.POINTER(QpBatch), vp, C.c_int, vp, vp, vp]
     L.osot_solver_profile_phases.argtypes = [vp, C.POINTER(QpBatch), vp, vp]
     L.osot_backend_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(vp)]
     L.osot_backend_destroy.argtypes = [vp]

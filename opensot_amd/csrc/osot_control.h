@@ -21,6 +21,10 @@ struct DevControl {
     const DevKin* K;           // the model (osot_kin_create)
     osot_kin_batch Bt;         // where q is read and the poses / Jacobian rows / CoM are written (the leaf inputs and A_k point there)
     double* q_int;             // [B][n] integrated at the end: q_int += dq (null: not integrated).  Usually Bt.q itself.
+    // round 5 -- a ROLLOUT: `steps` control cycles of every robot in this one launch (osot_control_rollout; 0 or 1: one cycle)
+    int steps;
+    double* dq_steps;          // [steps][B][n] every cycle's dq, or null (D.dq holds the last cycle's either way)
+    int* status_steps;         // [steps][B] every cycle's status, or null (D.status: the first non-zero status of the rollout)
 };
 
 // LDS in front of the cycle's own use of the slice (the update stages its arguments there afterwards).  NP = 32: two kinematics
@@ -41,22 +45,38 @@ __global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : (NP == 40 ? OSO
     // CollisionAvoidance leaf buffers: velocity/CollisionAvoidance.cpp:96-152) in every instantiation that can meet inequality rows;
     // the stage is skipped at run time when the model has no pairs or the batch no pair outputs
     constexpr bool PAIRS = !BOX;
-    if constexpr (NP == 32) {
-        const int sub = (int)(threadIdx.x >> 5), j = (int)(threadIdx.x & 31u);
-        kin_instance<PAIRS, 32>(F.K, F.Bt, inst, sub == 0, j, reinterpret_cast<double*>(osot_smem) + sub * kin_lds_doubles<32>(PAIRS));
-    } else {
-        kin_instance<PAIRS, 64>(F.K, F.Bt, inst, true, (int)threadIdx.x, reinterpret_cast<double*>(osot_smem));
-    }
-    workgroup_fence();      // the producer's global stores (poses, rows of A_k, CoM) are visible to the update's loads (same workgroup)
-    __syncthreads();
-    update_body(OSOT_KERNARG_PTR(DevUpdate, U), inst, (int)threadIdx.x, osot_smem);
-    workgroup_fence();
-    __syncthreads();
-    cascade_body<NP, false, EXTRA, BOX>(P, D, inst, (int)threadIdx.x, osot_smem);
-    if (F.q_int) {          // q += dq (the lane that stored dq[i] reads it back: its own store)
+    // ROLLOUT (round 5, osot_control_rollout): the loop of the reference's example itself (coman_ik.cpp:174-219) for this robot,
+    // `steps` times kinematics -> update -> cascade -> q += dq by the same wavefront.  As one launch per step every robot waits, at
+    // every step, for the slowest robot of its sub-batch (the launch IS its longest job) and every step pays a dispatch; here a
+    // robot's cycles follow each other directly and the launch ends with the robot whose SUM over the steps is largest -- which
+    // the law of large numbers keeps near the mean.  The robots are independent, so the results are those of `steps` launches.
+    const int steps = F.steps > 1 ? F.steps : 1;
+    int sticky = 0;
+    for (int t = 0; t < steps; ++t) {
+        if constexpr (NP == 32) {
+            const int sub = (int)(threadIdx.x >> 5), j = (int)(threadIdx.x & 31u);
+            kin_instance<PAIRS, 32>(F.K, F.Bt, inst, sub == 0, j, reinterpret_cast<double*>(osot_smem) + sub * kin_lds_doubles<32>(PAIRS));
+        } else {
+            kin_instance<PAIRS, 64>(F.K, F.Bt, inst, true, (int)threadIdx.x, reinterpret_cast<double*>(osot_smem));
+        }
+        workgroup_fence();      // the producer's global stores (poses, rows of A_k, CoM) are visible to the update's loads (same workgroup)
+        __syncthreads();
+        update_body(OSOT_KERNARG_PTR(DevUpdate, U), inst, (int)threadIdx.x, osot_smem);
+        workgroup_fence();
+        __syncthreads();
+        cascade_body<NP, false, EXTRA, BOX>(P, D, inst, (int)threadIdx.x, osot_smem);
         const int n = P.n, i = (int)threadIdx.x;
-        if (i < n) F.q_int[inst * n + i] += D.dq[inst * n + i];
+        if (F.q_int && i < n) F.q_int[inst * n + i] += D.dq[inst * n + i];       // q += dq (the lane that stored dq[i] reads it back: its own store)
+        if (F.dq_steps && i < n) F.dq_steps[((long long)t * D.B + inst) * n + i] = D.dq[inst * n + i];
+        if (steps > 1 || F.status_steps) {
+            workgroup_fence();      // q, dq and the status of this cycle before the next one's loads
+            __syncthreads();
+            const int st = uniform_i(D.status[inst]);
+            if (F.status_steps && i == 0) F.status_steps[(long long)t * D.B + inst] = st;
+            if (sticky == 0) sticky = st;
+        }
     }
+    if (steps > 1 && threadIdx.x == 0) D.status[inst] = sticky;
 }
 
 }  // namespace osot

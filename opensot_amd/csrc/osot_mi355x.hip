@@ -1036,8 +1036,23 @@ int osot_kinematics(osot_kin* k, const osot_kin_batch* b, void* hip_stream) {
     return OSOT_OK;
 }
 
+static int control_launch(osot_solver* s, osot_kin* k, const osot_kin_batch* kb, const osot_leaf_batch* leaf, const osot_assembled_out* out,
+                          const osot_qp_batch* b, double* q_integrate, int steps, double* dq_steps, int* status_steps, void* hip_stream);
+
 int osot_control_cycle(osot_solver* s, osot_kin* k, const osot_kin_batch* kb, const osot_leaf_batch* leaf, const osot_assembled_out* out,
                        const osot_qp_batch* b, double* q_integrate, void* hip_stream) {
+    return control_launch(s, k, kb, leaf, out, b, q_integrate, 1, nullptr, nullptr, hip_stream);
+}
+
+int osot_control_rollout(osot_solver* s, osot_kin* k, const osot_kin_batch* kb, const osot_leaf_batch* leaf, const osot_assembled_out* out,
+                         const osot_qp_batch* b, double* q_integrate, int steps, double* dq_steps, int* status_steps, void* hip_stream) {
+    if (steps < 1) return fail(OSOT_ERR_INVALID, "a rollout has at least one step");
+    if (steps > 1 && !q_integrate) return fail(OSOT_ERR_INVALID, "a rollout of several steps integrates q (q_integrate is null: every step would solve the same problem)");
+    return control_launch(s, k, kb, leaf, out, b, q_integrate, steps, dq_steps, status_steps, hip_stream);
+}
+
+static int control_launch(osot_solver* s, osot_kin* k, const osot_kin_batch* kb, const osot_leaf_batch* leaf, const osot_assembled_out* out,
+                          const osot_qp_batch* b, double* q_integrate, int steps, double* dq_steps, int* status_steps, void* hip_stream) {
     if (!s || !k || !kb || !leaf || !out || !b) return fail(OSOT_ERR_INVALID, "null argument");
     if (leaf->B != b->B || kb->B != b->B) return fail(OSOT_ERR_INVALID, "kinematics batch, leaf batch and qp batch disagree on B");
     if (leaf->B < 0 || leaf->B > s->max_batch) return fail(OSOT_ERR_INVALID, "batch size exceeds max_batch");
@@ -1055,6 +1070,7 @@ int osot_control_cycle(osot_solver* s, osot_kin* k, const osot_kin_batch* kb, co
     C.K = (const DevKin*)k->dev;
     C.Bt = *kb;
     C.q_int = q_integrate;
+    C.steps = steps; C.dq_steps = dq_steps; C.status_steps = status_steps;
     return ihqp_launch(s, b, hip_stream, nullptr, &U, &C);
 }
 

@@ -194,7 +194,7 @@ class BatchedStack:
         abi.check(self._lib.osot_cycle(self._h, C.byref(lb), C.byref(out), C.byref(qb), _stream_ptr(self.device, self.stream)), "osot_cycle")
         return lb.B
 
-    def control_cycle(self, kin, kin_batch, dev_leaf, q_integrate=None, write_weights=True):
+    def control_cycle(self, kin, kin_batch, dev_leaf, q_integrate=None, write_weights=True, steps=None, dq_steps=None, status_steps=None):
         """the body of the reference's control loop in ONE launch (osot_control_cycle; coman_ik.cpp:186-219): per instance the
         kinematics producer `kin` (a kinematics.Kinematics; kin_batch = kin.batch_args(...), whose outputs are the tensors
         dev_leaf and self.A point at), AutoStack::update, the cascade, and q_integrate += dq when a tensor is given.  The three
@@ -211,9 +211,21 @@ class BatchedStack:
                     self._cycle_args.clear()
                 self._cycle_args[key] = hit
         lb, out, qb, _, kb = hit
-        abi.check(self._lib.osot_control_cycle(self._h, kin._h, C.byref(kb), C.byref(lb), C.byref(out), C.byref(qb),
-                                               _dev_ptr(q_integrate), _stream_ptr(self.device, self.stream)), "osot_control_cycle")
+        if steps is None:
+            abi.check(self._lib.osot_control_cycle(self._h, kin._h, C.byref(kb), C.byref(lb), C.byref(out), C.byref(qb),
+                                                   _dev_ptr(q_integrate), _stream_ptr(self.device, self.stream)), "osot_control_cycle")
+        else:
+            abi.check(self._lib.osot_control_rollout(self._h, kin._h, C.byref(kb), C.byref(lb), C.byref(out), C.byref(qb),
+                                                     _dev_ptr(q_integrate), int(steps), _dev_ptr(dq_steps), _dev_ptr(status_steps),
+                                                     _stream_ptr(self.device, self.stream)), "osot_control_rollout")
         return lb.B
+
+    def control_rollout(self, kin, kin_batch, dev_leaf, q_integrate, steps, dq_steps=None, status_steps=None, write_weights=True):
+        """`steps` control cycles of every robot in ONE launch (osot_control_rollout): the loop of the reference's example
+        (coman_ik.cpp:174-219) by the robot's own wavefront, q_integrate advanced by every cycle's dq.  dq_steps [steps][B][n] /
+        status_steps [steps][B] (int32), when given, receive every cycle's dq / status; self.dq holds the last cycle's, self.status
+        the first non-zero status.  Same results as `steps` control_cycle calls."""
+        return self.control_cycle(kin, kin_batch, dev_leaf, q_integrate, write_weights, steps=steps, dq_steps=dq_steps, status_steps=status_steps)
 
     # ---- Solver::solve ------------------------------------------------------------------------------
     def _qp_batch(self, B):

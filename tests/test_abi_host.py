@@ -114,6 +114,12 @@ def test_control_cycle_argument_checks_without_gpu(lib):
     """osot_control_cycle (round 4) refuses null arguments before it touches a device"""
     kb, lb, out, qb = abi.KinBatch(), abi.LeafBatch(), abi.AssembledOut(), abi.QpBatch()
     assert lib.osot_control_cycle(None, None, C.byref(kb), C.byref(lb), C.byref(out), C.byref(qb), None, None) == abi.ERR_INVALID
+    # osot_control_rollout (round 5): a rollout has at least one step, several steps need q_integrate, then the same checks
+    assert lib.osot_control_rollout(None, None, C.byref(kb), C.byref(lb), C.byref(out), C.byref(qb), None, 0, None, None, None) == abi.ERR_INVALID
+    assert b"at least one step" in lib.osot_last_error()
+    assert lib.osot_control_rollout(None, None, C.byref(kb), C.byref(lb), C.byref(out), C.byref(qb), None, 4, None, None, None) == abi.ERR_INVALID
+    assert b"integrates q" in lib.osot_last_error()
+    assert lib.osot_control_rollout(None, None, C.byref(kb), C.byref(lb), C.byref(out), C.byref(qb), None, 1, None, None, None) == abi.ERR_INVALID
     assert b"null argument" in lib.osot_last_error()
 
 

@@ -380,16 +380,32 @@ def test_control_cycle_in_one_launch_matches_the_three_calls(mode, gpu_device):
 
     a = make()
     b = make()
+    c = make()
     sta, qa, posea, coma, kwa, leafa, dista = a
     stb, qb, poseb, comb, kwb, leafb, distb = b
+    stc, qc, posec, comc, kwc, leafc, distc = c
     kb = K.batch_args(qb, **kwb)
+    kc = K.batch_args(qc, **kwc)
     nsteps = 25 if not pairs else 120
+    dq_hist = []
     for step in range(nsteps):
         K.forward(qa, **kwa)
         sta.cycle(leafa)
         qa += sta.dq[:B]
         stb.control_cycle(K, kb, leafb, q_integrate=qb)
+        dq_hist.append(stb.dq[:B].clone())
+    # round 5 -- osot_control_rollout: the same steps as ROLLOUTS (several control cycles of every robot per launch: 7, then 1, then
+    # the rest), every cycle's dq and status recorded
+    dq_steps = torch.zeros((nsteps, B, n), **f64)
+    st_steps = torch.full((nsteps, B), -1, dtype=torch.int32, device=dev)
+    done = 0
+    for chunk in (7, 1, nsteps - 8):
+        stc.control_rollout(K, kc, leafc, qc, chunk, dq_steps=dq_steps[done:done + chunk], status_steps=st_steps[done:done + chunk])
+        done += chunk
     torch.cuda.synchronize()
+    assert torch.equal(qc, qb) and torch.equal(stc.dq[:B], stb.dq[:B]) and (stc.status[:B] == 0).all()
+    assert torch.equal(dq_steps, torch.stack(dq_hist)) and (st_steps == 0).all()
+    assert torch.equal(comc, comb) and all(torch.equal(posec[f], poseb[f]) for f in range(4))
     assert (sta.status[:B] == 0).all() and (stb.status[:B] == 0).all()
     assert torch.equal(qa, qb) and torch.equal(sta.dq[:B], stb.dq[:B])
     assert torch.equal(coma, comb) and all(torch.equal(posea[f], poseb[f]) for f in range(4))
