@@ -42,7 +42,7 @@ inline int nhqp_validate(const osot_plan_desc& p, const osot_nhqp_options* opt, 
         int m, ma; plan_level_rows(&p, k, &m, &ma);
         if (m > 64) { *why = "nHQP front-end: at most 64 rows per level"; return OSOT_ERR_UNSUPPORTED; }
         for (int j = 0; j < p.level[k].n_tasks; ++j)
-            if (p.level[k].task[j].dense_weight) { *why = "nHQP front-end: diagonal weights only"; return OSOT_ERR_UNSUPPORTED; }
+            if (p.level[k].task[j].dense_weight) { *why = "nHQP front-end: diagonal weights only (A/b regularisation needs W itself -- W u of a lifted null triplet is not in range(W A) -- and the batch carries W A and W b)"; return OSOT_ERR_UNSUPPORTED; }
         const int given = opt ? opt->free_vars[k] : 0;
         if (k == 0) { if (given != 0 && given != p.n) { *why = "free_vars[0] must be n"; return OSOT_ERR_INVALID; } }
         else if (given != 0) nf = given;
