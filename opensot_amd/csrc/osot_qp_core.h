@@ -1710,7 +1710,54 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
         // stored inequality rows, lane = row, 64 rows at a time: each lane walks its own row against the staged
         // x (no cross-lane reduction at all).  Consecutive elements of a row share a cache line, so after the
         // first touch the walk is served from the CU's vector L1.
-        for (int g0 = 0; g0 < n_gen; g0 += 64) {
+        // Few stored rows (round 5; BASELINE config 4's sixteen collision rows): FOUR lanes per row, each a quarter of the columns --
+        // the walk is one round trip of NP / 4 loads per lane and a two-stage quad reduction where lane = row needs two round
+        // trips of sixteen (the scan is a chain of L1 / L2 latencies: 2.7 k cycles per scan at config 4, 14 % of its job)
+#ifndef OSOT_X_NO_QUAD_SCAN
+        constexpr bool kQuadScan = (NP == 32);
+#else
+        constexpr bool kQuadScan = false;
+#endif
+        const bool quad_scan = kQuadScan && n_gen > 0 && n_gen <= 16;
+        if (quad_scan) {
+            const int lane = WaveCtx<NP>::lane_of(c, h);
+            const int gi = lane >> 2, part = lane & 3;
+            const bool on = gi < n_gen;
+            const int r = w.eqlist[on ? gi : 0];
+            const auto* row = OSOT_GLOBAL_F64(w.rptr[r]);
+            constexpr int QC = NP / 4;
+            double e[QC];
+#pragma unroll
+            for (int t = 0; t < QC; ++t) { const int col = part * QC + t; e[t] = row[(col < n) ? col : 0]; }
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int t = 0; t < QC; t += 2) {
+                const int col = part * QC + t;
+                a0 = fma((col < n) ? e[t] : 0.0, V0[col], a0);
+                a1 = fma((col + 1 < n) ? e[t + 1] : 0.0, V0[col + 1], a1);
+            }
+            const double ax = quad_sum(a0 + a1);
+            if (on && part == 0) {
+                const int st = w.rowstate[r];
+                const double lo = w.rlo[r], up = w.rup[r];
+                if (margin_pass) {
+                    if (w.rsrc[r] != -2) {
+                        if (lo > -kInfty) w.rlo[r] = fmin(lo, ax - kFeasMargin * fmax(1.0, fabs(lo)));
+                        if (up < kInfty) w.rup[r] = fmax(up, ax + kFeasMargin * fmax(1.0, fabs(up)));
+                    }
+                } else {
+                    if (st != 1 && lo > -kInfty) {
+                        const double s = ax - lo;
+                        if (s < -kViolTol * fmax(1.0, fabs(lo)) && s < cand) { cand = s; code = 2 * n + 2 * r; }
+                    }
+                    if (st != 2 && up < kInfty) {
+                        const double s = up - ax;
+                        if (s < -kViolTol * fmax(1.0, fabs(up)) && s < cand) { cand = s; code = 2 * n + 2 * r + 1; }
+                    }
+                }
+            }
+        }
+        for (int g0 = 0; g0 < (quad_scan ? 0 : n_gen); g0 += 64) {
             const int gi = g0 + WaveCtx<NP>::lane_of(c, h);
             if (gi < n_gen) {
                 const int r = w.eqlist[gi];

@@ -128,6 +128,12 @@ __device__ __forceinline__ double row16_sum(double v) {
     v += dpp_f64<DPP_MIRROR>(v);
     return v;
 }
+// sum over the four lanes of each quad (lanes 4k .. 4k+3); every lane of the quad gets it
+__device__ __forceinline__ double quad_sum(double v) {
+    v += dpp_f64<DPP_XOR1>(v);
+    v += dpp_f64<DPP_XOR2>(v);
+    return v;
+}
 // v_permlane16_swap with both operands = v returns {even rows duplicated, odd rows duplicated}
 __device__ __forceinline__ void swap16_pair(double v, double& a, double& b) {
     const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);

@@ -86,6 +86,14 @@ inline double rowgroup_sum(double v) {
     const int a = emu_lane() & 15;
     return (all[a] + all[a + 16]) + (all[a + 32] + all[a + 48]);
 }
+inline double quad_sum(double v) {
+    double all[64]; emu::allgather(&v, all, sizeof(double));
+    const int q0 = emu_lane() & ~3;
+    // (the order of the device's two butterfly stages: (l + l^1) + (l^2 + l^3))
+    const int l = emu_lane();
+    return (all[l] + all[l ^ 1]) + (all[l ^ 2] + all[l ^ 3]);
+    (void)q0;
+}
 struct Quad { double a, b, c, d; };
 inline Quad rowgroup_gather4(double v) {
     double all[64]; emu::allgather(&v, all, sizeof(double));
