@@ -243,7 +243,10 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
         double xprep = 0.0;
         if constexpr (NP == 32) {
 #ifndef OSOT_X_NO_LOWRANK
-            if (!diag_h && ma <= kLowRankMax && !dense && !inact && !regd) {
+            // (five or six stored rows -- one Cartesian task -- only next to a Postural block over every variable, BASELINE config 2: D >= w
+            //  there.  With D = eps alone the scaled rows carry 1 / sqrt(eps) and six of them lose what the Cholesky path keeps: at the
+            //  default eps the closed-loop instance of default_eps_stuck_instances[tasks] ended lexicographically worse than eiQuadProg)
+            if (!diag_h && (ma <= 4 || (ma <= kLowRankMax && m - ma >= n)) && !dense && !inact && !regd) {
 #else
             if (false) {
 #endif
@@ -256,6 +259,7 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
                 const WaveCtx<32>& w32 = reinterpret_cast<const WaveCtx<32>&>(w);
                 const bool has_c = D.c[k] != nullptr || npost > 0 || D.b_reg != nullptr;
                 if (ma <= 3) lowrank_prepare32<3>(w32, Ak, bk, wk, ma, P.eps_abs + wpost + dreg, cvec, has_c, xprep);
+                else if (kLowRankMax <= 4 || ma <= 4) lowrank_prepare32<(kLowRankMax < 4 ? kLowRankMax : 4)>(w32, Ak, bk, wk, ma, P.eps_abs + wpost + dreg, cvec, has_c, xprep);
                 else lowrank_prepare32<kLowRankMax>(w32, Ak, bk, wk, ma, P.eps_abs + wpost + dreg, cvec, has_c, xprep);
             }
         }

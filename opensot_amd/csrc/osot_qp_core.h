@@ -1127,7 +1127,10 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
 // A'Wb.  Cost: m(m+1)/2 reductions, an m x m Cholesky in uniform scalars and a rank-m update of the identity,
 // instead of the n x n x m product and a 32-column factorisation.  A numerically dependent row is dropped.
 // Out: M2 = JT (M2[j][c] = J[c][j]), x; M1 is used as staging.
-constexpr int kLowRankMax = 4;
+#ifndef OSOT_LOWRANK_MAX
+#define OSOT_LOWRANK_MAX 6      // round 5: one Cartesian task (six rows) next to a Postural block -- BASELINE config 2 -- takes the closed form too
+#endif
+constexpr int kLowRankMax = OSOT_LOWRANK_MAX;
 // MM = compile-time bound on the rows (3 for a CoM task, else kLowRankMax): the m x m algebra is fully unrolled
 template <int MM>
 __device__ inline void lowrank_prepare32(const WaveCtx<32>& w, const double* Ak, const double* bk, const double* wk,
