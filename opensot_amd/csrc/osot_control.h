@@ -36,7 +36,10 @@ constexpr size_t control_kin_lds_bytes(int NP, bool pairs = true) {
     return NP == 32 ? 2 * sizeof(double) * (size_t)kin_lds_doubles<32>(pairs) : sizeof(double) * (size_t)kin_lds_doubles<64>(pairs);
 }
 
-template <int NP, bool EXTRA = false, bool BOX = false>
+// ROLL: the instantiation that carries the rollout loop (osot_control_rollout); the single-cycle kernel does not (measured: the loop
+// around the body -- its trip count a run-time value -- cost the one-cycle launch 2-5 %: 26.1 -> 24.8 M on the full cycle, 20.1 -> 19.0 M
+// on COMAN35 S1, A/B on one box)
+template <int NP, bool EXTRA = false, bool BOX = false, bool ROLL = false>
 __global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : (NP == 40 ? OSOT_WAVES40 : 1))) osot_control_cycle_kernel(const DevUpdate U, const DevPlan P, const DevBatch D, const DevControl F) {
     OSOT_DYNAMIC_LDS(osot_smem);
     const long long inst = dispatch_instance(D, osot_smem);
@@ -50,7 +53,7 @@ __global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : (NP == 40 ? OSO
     // every step, for the slowest robot of its sub-batch (the launch IS its longest job) and every step pays a dispatch; here a
     // robot's cycles follow each other directly and the launch ends with the robot whose SUM over the steps is largest -- which
     // the law of large numbers keeps near the mean.  The robots are independent, so the results are those of `steps` launches.
-    const int steps = F.steps > 1 ? F.steps : 1;
+    const int steps = ROLL ? (F.steps > 1 ? F.steps : 1) : 1;
     int sticky = 0;
     for (int t = 0; t < steps; ++t) {
         if constexpr (NP == 32) {
@@ -67,8 +70,8 @@ __global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : (NP == 40 ? OSO
         cascade_body<NP, false, EXTRA, BOX>(P, D, inst, (int)threadIdx.x, osot_smem);
         const int n = P.n, i = (int)threadIdx.x;
         if (F.q_int && i < n) F.q_int[inst * n + i] += D.dq[inst * n + i];       // q += dq (the lane that stored dq[i] reads it back: its own store)
-        if (F.dq_steps && i < n) F.dq_steps[((long long)t * D.B + inst) * n + i] = D.dq[inst * n + i];
-        if (steps > 1 || F.status_steps) {
+        if (ROLL && F.dq_steps && i < n) F.dq_steps[((long long)t * D.B + inst) * n + i] = D.dq[inst * n + i];
+        if (ROLL && (steps > 1 || F.status_steps)) {
             workgroup_fence();      // q, dq and the status of this cycle before the next one's loads
             __syncthreads();
             const int st = uniform_i(D.status[inst]);
@@ -76,7 +79,7 @@ __global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : (NP == 40 ? OSO
             if (sticky == 0) sticky = st;
         }
     }
-    if (steps > 1 && threadIdx.x == 0) D.status[inst] = sticky;
+    if (ROLL && steps > 1 && threadIdx.x == 0) D.status[inst] = sticky;
 }
 
 }  // namespace osot

@@ -211,15 +211,21 @@ int osot_solver_create(const osot_plan_desc* plan, int max_batch, int device, os
             if (r == OSOT_OK) r = ensure_lds(osot_cascade_kernel<NP, false, false, true>, lds);
             if (r == OSOT_OK) r = ensure_lds(osot_cycle_kernel<NP, false, true>, lds);
             if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<NP, false, true>, lds > control_kin_lds_bytes(NP) ? lds : control_kin_lds_bytes(NP));
+            if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<NP, false, true, true>, lds > control_kin_lds_bytes(NP) ? lds : control_kin_lds_bytes(NP));
             if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<NP, false, false>, lds > control_kin_lds_bytes(NP) ? lds : control_kin_lds_bytes(NP));
+            if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<NP, false, false, true>, lds > control_kin_lds_bytes(NP) ? lds : control_kin_lds_bytes(NP));
             if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<NP, true, false>, lds > control_kin_lds_bytes(NP) ? lds : control_kin_lds_bytes(NP));
+            if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<NP, true, false, true>, lds > control_kin_lds_bytes(NP) ? lds : control_kin_lds_bytes(NP));
         }
         if constexpr (NP == 32) {
             if (r == OSOT_OK) r = ensure_lds(osot_cascade_kernel<32, false, false, true>, lds);
             if (r == OSOT_OK) r = ensure_lds(osot_cycle_kernel<32, false, true>, lds);
             if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<32, false, true>, lds > control_kin_lds_bytes(32) ? lds : control_kin_lds_bytes(32));
+            if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<32, false, true, true>, lds > control_kin_lds_bytes(32) ? lds : control_kin_lds_bytes(32));
             if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<32, false, false>, lds > control_kin_lds_bytes(32) ? lds : control_kin_lds_bytes(32));
+            if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<32, false, false, true>, lds > control_kin_lds_bytes(32) ? lds : control_kin_lds_bytes(32));
             if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<32, true, false>, lds > control_kin_lds_bytes(32) ? lds : control_kin_lds_bytes(32));
+            if (r == OSOT_OK) r = ensure_lds(osot_control_cycle_kernel<32, true, false, true>, lds > control_kin_lds_bytes(32) ? lds : control_kin_lds_bytes(32));
             if (r == OSOT_OK) r = ensure_lds(osot_cascade_kernel<32, true, false, true>, lds);
         }
         return r;
@@ -578,9 +584,16 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
         else { HIP_TRY(hipEventCreate(&ev.first)); HIP_TRY(hipEventCreate(&ev.second)); }
         HIP_TRY(hipEventRecord(ev.first, st));
     }
+    const bool roll = control && (control->steps > 1 || control->dq_steps || control->status_steps);
     by_np(T, [&](auto np) {
         constexpr int NP = decltype(np)::value;
         if constexpr (NP == 32) {
+            if (control && roll) {
+                if (box) hipLaunchKernelGGL((osot_control_cycle_kernel<32, false, true, true>), dim3(grid), dim3(64), lds, st, *fused, P, D, *control);
+                else if (extra) hipLaunchKernelGGL((osot_control_cycle_kernel<32, true, false, true>), dim3(grid), dim3(64), lds, st, *fused, P, D, *control);
+                else hipLaunchKernelGGL((osot_control_cycle_kernel<32, false, false, true>), dim3(grid), dim3(64), lds, st, *fused, P, D, *control);
+                return 0;
+            }
             if (control) {
                 if (box) hipLaunchKernelGGL((osot_control_cycle_kernel<32, false, true>), dim3(grid), dim3(64), lds, st, *fused, P, D, *control);
                 else if (extra) hipLaunchKernelGGL((osot_control_cycle_kernel<32, true, false>), dim3(grid), dim3(64), lds, st, *fused, P, D, *control);
@@ -595,6 +608,12 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
             }
         }
         if constexpr (NP != 32) {
+            if (control && roll) {
+                if (box) hipLaunchKernelGGL((osot_control_cycle_kernel<NP, false, true, true>), dim3(grid), dim3(64), lds, st, *fused, P, D, *control);
+                else if (extra) hipLaunchKernelGGL((osot_control_cycle_kernel<NP, true, false, true>), dim3(grid), dim3(64), lds, st, *fused, P, D, *control);
+                else hipLaunchKernelGGL((osot_control_cycle_kernel<NP, false, false, true>), dim3(grid), dim3(64), lds, st, *fused, P, D, *control);
+                return 0;
+            }
             if (control) {
                 if (box) hipLaunchKernelGGL((osot_control_cycle_kernel<NP, false, true>), dim3(grid), dim3(64), lds, st, *fused, P, D, *control);
                 else if (extra) hipLaunchKernelGGL((osot_control_cycle_kernel<NP, true, false>), dim3(grid), dim3(64), lds, st, *fused, P, D, *control);
