@@ -42,8 +42,8 @@ constexpr size_t control_kin_lds_bytes(int NP, bool pairs = true) {
 template <int NP, bool EXTRA = false, bool BOX = false, bool ROLL = false>
 __global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : (NP == 40 ? OSOT_WAVES40 : 1))) osot_control_cycle_kernel(const DevUpdate U, const DevPlan P, const DevBatch D, const DevControl F) {
     OSOT_DYNAMIC_LDS(osot_smem);
-    const long long inst = dispatch_instance(D, osot_smem);
-    if (inst < 0) return;
+    const long long inst0 = dispatch_instance(D, osot_smem);
+    if (inst0 < 0) return;
     // (round 5) the producer WITH its collision-pair stage (closest points, distances, distance-Jacobian rows straight into the
     // CollisionAvoidance leaf buffers: velocity/CollisionAvoidance.cpp:96-152) in every instantiation that can meet inequality rows;
     // the stage is skipped at run time when the model has no pairs or the batch no pair outputs
@@ -56,19 +56,23 @@ __global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : (NP == 40 ? OSO
     const int steps = ROLL ? (F.steps > 1 ? F.steps : 1) : 1;
     int sticky = 0;
     for (int t = 0; t < steps; ++t) {
+        // (ROLL: the instance number and the lane are made opaque once per cycle -- otherwise every address and mask derived from them
+        //  is loop-invariant, hoisted out of the rollout loop and kept alive across the whole body: 22 .. 71 spilled registers)
+        const long long inst = ROLL ? (long long)(((unsigned long long)(unsigned)launder_s(uniform_i((int)(inst0 >> 32))) << 32) | (unsigned)launder_s(uniform_i((int)inst0))) : inst0;
+        const unsigned tid = ROLL ? (unsigned)launder_i((int)threadIdx.x) : threadIdx.x;
         if constexpr (NP == 32) {
-            const int sub = (int)(threadIdx.x >> 5), j = (int)(threadIdx.x & 31u);
+            const int sub = (int)(tid >> 5), j = (int)(tid & 31u);
             kin_instance<PAIRS, 32>(F.K, F.Bt, inst, sub == 0, j, reinterpret_cast<double*>(osot_smem) + sub * kin_lds_doubles<32>(PAIRS));
         } else {
-            kin_instance<PAIRS, 64>(F.K, F.Bt, inst, true, (int)threadIdx.x, reinterpret_cast<double*>(osot_smem));
+            kin_instance<PAIRS, 64>(F.K, F.Bt, inst, true, (int)tid, reinterpret_cast<double*>(osot_smem));
         }
         workgroup_fence();      // the producer's global stores (poses, rows of A_k, CoM) are visible to the update's loads (same workgroup)
         __syncthreads();
-        update_body(OSOT_KERNARG_PTR(DevUpdate, U), inst, (int)threadIdx.x, osot_smem);
+        update_body(OSOT_KERNARG_PTR(DevUpdate, U), inst, (int)tid, osot_smem);
         workgroup_fence();
         __syncthreads();
-        cascade_body<NP, false, EXTRA, BOX>(P, D, inst, (int)threadIdx.x, osot_smem);
-        const int n = P.n, i = (int)threadIdx.x;
+        cascade_body<NP, false, EXTRA, BOX>(P, D, inst, (int)tid, osot_smem);
+        const int n = P.n, i = (int)tid;
         if (F.q_int && i < n) F.q_int[inst * n + i] += D.dq[inst * n + i];       // q += dq (the lane that stored dq[i] reads it back: its own store)
         if (ROLL && F.dq_steps && i < n) F.dq_steps[((long long)t * D.B + inst) * n + i] = D.dq[inst * n + i];
         if (ROLL && (steps > 1 || F.status_steps)) {
@@ -79,7 +83,7 @@ __global__ void __launch_bounds__(64, (NP == 32 ? OSOT_WAVES32 : (NP == 40 ? OSO
             if (sticky == 0) sticky = st;
         }
     }
-    if (ROLL && steps > 1 && threadIdx.x == 0) D.status[inst] = sticky;
+    if (ROLL && steps > 1 && threadIdx.x == 0) D.status[inst0] = sticky;
 }
 
 }  // namespace osot
