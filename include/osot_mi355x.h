@@ -385,7 +385,7 @@ int osot_solver_profile_phases(osot_solver* s, const osot_qp_batch* batch, long 
  * solved in the nf free coordinates (bounds become rows N z, compute_contraints :282-317) and q += N z, N <- N V2.  Three
  * launches per level (prepare, the batched QP kernel, accumulate).  n <= 64 (a level with min(rows, free variables) <= 32 goes
  * through a 32-wide eigen-decomposition; round 5: the others -- the reference's one-level stack S1, 50 rows in 35 variables --
- * through a Jacobi iteration on the full Gram matrix), <= 64 rows per level, diagonal weights, inactive tasks as zero rows
+ * through a Jacobi iteration on the full Gram matrix), <= 64 rows per level, inactive tasks as zero rows and non-diagonal weights through level_W
  * (round 5), global rows and the box only (the reference refuses task-local constraints, nHQP.cpp:41-44). */
 typedef struct {
     int free_vars[OSOT_MAX_LEVELS];      /* free variables of each level.  The reference fixes them in its constructor from the
@@ -406,6 +406,11 @@ typedef struct {
     int level_no_selective_ns_regularization[OSOT_MAX_LEVELS];
     int level_min_sv_ratio_is_set[OSOT_MAX_LEVELS];
     double level_min_sv_ratio[OSOT_MAX_LEVELS];
+    /* a level whose task(s) carry a NON-DIAGONAL weight (osot_task_desc.dense_weight; Task::setWeight(W)): the level's full weight
+       matrix [B][m_k][m_k] (device; Task::getWeight() of the level: block diagonal over its tasks, symmetric), which nHQP.cpp:381-382
+       multiplies the REGULARISED A N and b0 by -- so W A / W b (osot_qp_batch.WA / Wb, what iHQP and eHQP take) do not suffice.  NULL
+       for a level with diagonal weights; a dense_weight level without it is refused. */
+    const double* level_W[OSOT_MAX_LEVELS];
 } osot_nhqp_options;
 int osot_nhqp_solve(osot_solver* s, const osot_qp_batch* batch, const osot_nhqp_options* options, void* hip_stream);
 

@@ -93,7 +93,8 @@ class NhqpOptions(C.Structure):
                 ("no_ab_regularization", C.c_int), ("no_selective_ns_regularization", C.c_int),
                 ("min_sv_ratio_is_set", C.c_int),
                 ("level_no_ab_regularization", C.c_int * MAX_LEVELS), ("level_no_selective_ns_regularization", C.c_int * MAX_LEVELS),
-                ("level_min_sv_ratio_is_set", C.c_int * MAX_LEVELS), ("level_min_sv_ratio", C.c_double * MAX_LEVELS)]
+                ("level_min_sv_ratio_is_set", C.c_int * MAX_LEVELS), ("level_min_sv_ratio", C.c_double * MAX_LEVELS),
+                ("level_W", C.c_void_p * MAX_LEVELS)]
 
 
 class AdmmOptions(C.Structure):

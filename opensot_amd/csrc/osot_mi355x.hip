@@ -141,7 +141,7 @@ int osot_abi_layout(const char* name, unsigned long long* size, unsigned long lo
     OSOT_LAYOUT_BEGIN(osot_backend_options) OSOT_F(max_iterations) OSOT_F(last_iterations) OSOT_F(last_status) OSOT_LAYOUT_END()
     OSOT_LAYOUT_BEGIN(osot_nhqp_options) OSOT_F(free_vars) OSOT_F(min_sv_ratio) OSOT_F(no_ab_regularization)
         OSOT_F(no_selective_ns_regularization) OSOT_F(min_sv_ratio_is_set) OSOT_F(level_no_ab_regularization)
-        OSOT_F(level_no_selective_ns_regularization) OSOT_F(level_min_sv_ratio_is_set) OSOT_F(level_min_sv_ratio) OSOT_LAYOUT_END()
+        OSOT_F(level_no_selective_ns_regularization) OSOT_F(level_min_sv_ratio_is_set) OSOT_F(level_min_sv_ratio) OSOT_F(level_W) OSOT_LAYOUT_END()
     OSOT_LAYOUT_BEGIN(osot_admm_options) OSOT_F(eps_abs) OSOT_F(eps_rel) OSOT_F(rho) OSOT_F(sigma) OSOT_F(alpha) OSOT_F(max_iter)
         OSOT_F(scaling) OSOT_F(check_every) OSOT_LAYOUT_END()
     OSOT_LAYOUT_BEGIN(osot_id_model) OSOT_F(B) OSOT_F(nv) OSOT_F(n_contacts) OSOT_F(contact_dim) OSOT_F(Bm) OSOT_F(h) OSOT_F(Jc)

@@ -38,6 +38,8 @@ struct DevNhqp {
     double* R; double* rlo; double* rup;   // out (levels > 0) [B][nr][nf], [B][nr], nr = nc + (has_box ? n : 0)
     double* V2;                      // out [B][n][n] (nf x ns, row stride n)
     const int* status;               // [B] status so far (instances that failed above are skipped)
+    const double* Wd;                // [B][m][m] the level's FULL weight matrix (Task::getWeight() of the level: block diagonal over its tasks,
+                                     // symmetric), or null = diagonal weights w.  Round 5: osot_nhqp_options.level_W
     unsigned long long zero_rows;    // bit r: row r of the level belongs to an INACTIVE task (Task::setActive(false), Task.h:383-387: A is
                                      // zeroed, b stays): the row of A N is a zero row
 };
@@ -602,6 +604,26 @@ __device__ __forceinline__ void sym_eig32(double* K, double* E, int k_in, int c,
 //   NE : N (until the constraints are written, right after A N)  ->  eigenvectors E  ->  V2 on the row side
 //   K  : Gram matrix -> its eigenvalues on the diagonal -> the reflectors of the complement / V2 on the column side
 // developer knob (tools/build_variant.sh NAME -DOSOT_NHQP_PHASES): instance 0 prints the clock count of every phase of its level
+// A level with a NON-DIAGONAL weight matrix (Task::setWeight(W), nHQP.cpp:381-382: H = AN'W AN, g = -AN'W b0 with the REGULARISED AN and
+// b0 -- which is why W itself is needed: W u of a lifted null triplet is not in range(W A)).  The kernels below run their own H / g stage on
+// diag(W); this adds the rest, H += AN'(W - diag W) AN and g -= AN'(W - diag W) b0, column c of H and entry c of g by the lane that
+// stored them (its own stores, read back and rewritten: no other lane touches them).  A plain loop -- m (m + nf) steps per lane with a
+// read-modify-write of HBM in the inner one: a weight matrix is a rare configuration, not a benchmark.
+__device__ inline void nhqp_dense_weight_correction(const DevNhqp& Q, long long inst, const double* AN, int S, const double* b0, int c) {
+    const int m = Q.m, nf = Q.nf;
+    if (c < 0 || c >= nf) return;
+    const double* Wg = Q.Wd + inst * (long long)m * m;
+    double* Hg = Q.H + inst * (long long)nf * nf;
+    double gcor = 0.0;
+    for (int r = 0; r < m; ++r) {
+        double u = 0.0;                               // ((W - diag W) AN)[r][c]
+        for (int s2 = 0; s2 < m; ++s2) if (s2 != r) u = fma(Wg[r * m + s2], AN[s2 * S + c], u);
+        gcor = fma(-u, b0[r], gcor);                  // (W symmetric: AN'(W_off b0) = (W_off AN)'b0)
+        for (int i = 0; i < nf; ++i) Hg[i * nf + c] = fma(AN[r * S + i], u, Hg[i * nf + c]);
+    }
+    Q.g[inst * nf + c] += gcor;
+}
+
 // preparation (s_memtime deltas of one wave among the CU's six)
 #ifdef OSOT_NHQP_PHASES
 #define NHQP_PHASE(tag) do { const long long t_ = (long long)clock64(); if (inst == 0 && lane == 0) printf("PHASE L%d " tag " %lld\n", Q.level, t_ - ph_t_); ph_t_ = (long long)clock64(); } while (0)
@@ -974,7 +996,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
     {
         const double* w = Q.w ? Q.w + inst * m : nullptr;
         // (my column of W A N in registers, fixed trip counts: see dot_half)
-        vec[lane] = (lane < m) ? (w ? w[lane] : 1.0) : 0.0;
+        vec[lane] = (lane < m) ? (Q.Wd ? Q.Wd[inst * (long long)m * m + lane * (m + 1)] : (w ? w[lane] : 1.0)) : 0.0;   // (dense W: its diagonal here, the rest below)
         wave_sync();
         double* Hg = Q.H + inst * (long long)nf * nf;
         const int cc = (c < nf) ? c : 0;
@@ -1022,6 +1044,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
         }
     }
     NHQP_PHASE("Hg");
+    if (Q.Wd) { wave_sync(); nhqp_dense_weight_correction(Q, inst, AN, kNS, b0, (h == 0) ? c : -1); }
     // ---- V2 -> HBM (row stride n)
     if (ns > 0 && Q.V2) {
         double* Vg = Q.V2 + inst * (long long)n * n;
@@ -1476,7 +1499,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
     {
         const double* w = Q.w ? Q.w + inst * m : nullptr;
         wave_sync();
-        vec[lane] = (lane < m) ? (w ? w[lane] : 1.0) : 0.0;
+        vec[lane] = (lane < m) ? (Q.Wd ? Q.Wd[inst * (long long)m * m + lane * (m + 1)] : (w ? w[lane] : 1.0)) : 0.0;   // (dense W: its diagonal here, the rest below)
         wave_sync();
         double* Hg = Q.H + inst * (long long)nf * nf;
         double gacc = 0.0;
@@ -1515,6 +1538,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
         }
     }
     NHQP_PHASE("Hg");
+    if (Q.Wd) { wave_sync(); nhqp_dense_weight_correction(Q, inst, AN, S, b0, c); }
     if (ns > 0 && Q.V2) {
         double* Vg = Q.V2 + inst * (long long)n * n;
         const int cs = (c < ns) ? c : 0;
@@ -1789,7 +1813,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_wide_kernel(const DevNhq
     {
         const double* w = Q.w ? Q.w + inst * m : nullptr;
         wave_sync();
-        vec[lane] = (lane < m) ? (w ? w[lane] : 1.0) : 0.0;
+        vec[lane] = (lane < m) ? (Q.Wd ? Q.Wd[inst * (long long)m * m + lane * (m + 1)] : (w ? w[lane] : 1.0)) : 0.0;   // (dense W: its diagonal here, the rest below)
         wave_sync();
         double* Hg = Q.H + inst * (long long)nf * nf;
         const bool sel = ns > 0 && Q.sel_reg;
@@ -1817,6 +1841,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_wide_kernel(const DevNhq
                 for (int j = 0; j < 8; ++j) if (i0 + j < nf && lane < nf) Hg[(i0 + j) * nf + lane] = acc8[j];
             }
         }
+        if (Q.Wd) { wave_sync(); nhqp_dense_weight_correction(Q, inst, AN, S, b0, lane); }
         if (ns > 0 && Q.V2) {
             double* Vg = Q.V2 + inst * (long long)n * n;
             if (lane < ns) { const int ec = idx[nf - ns + lane]; for (int i = 0; i < nf; ++i) Vg[i * n + lane] = NV[i * S + ec]; }

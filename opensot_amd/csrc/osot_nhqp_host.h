@@ -42,7 +42,11 @@ inline int nhqp_validate(const osot_plan_desc& p, const osot_nhqp_options* opt, 
         int m, ma; plan_level_rows(&p, k, &m, &ma);
         if (m > 64) { *why = "nHQP front-end: at most 64 rows per level"; return OSOT_ERR_UNSUPPORTED; }
         for (int j = 0; j < p.level[k].n_tasks; ++j)
-            if (p.level[k].task[j].dense_weight) { *why = "nHQP front-end: diagonal weights only (A/b regularisation needs W itself -- W u of a lifted null triplet is not in range(W A) -- and the batch carries W A and W b)"; return OSOT_ERR_UNSUPPORTED; }
+            if (p.level[k].task[j].dense_weight && !(opt && opt->level_W[k])) {
+                *why = "nHQP front-end: a level with a non-diagonal weight needs osot_nhqp_options.level_W[k] (A/b regularisation multiplies the "
+                       "REGULARISED A N by W: W A and W b do not suffice)";
+                return OSOT_ERR_UNSUPPORTED;
+            }
         const int given = opt ? opt->free_vars[k] : 0;
         if (k == 0) { if (given != 0 && given != p.n) { *why = "free_vars[0] must be n"; return OSOT_ERR_INVALID; } }
         else if (given != 0) nf = given;
@@ -84,6 +88,7 @@ int nhqp_run(const osot_plan_desc& p, const osot_qp_batch* b, const osot_nhqp_op
             }
         }
         Q.A = b->A[k]; Q.b = b->b[k]; Q.w = b->w[k];
+        Q.Wd = opt ? opt->level_W[k] : nullptr;
         Q.C = b->C; Q.lo = b->lo; Q.up = b->up; Q.l = b->l; Q.u = b->u;
         Q.N = ws.N[k & 1]; Q.q0 = ws.q0;
         Q.H = ws.H; Q.g = ws.g; Q.R = ws.R; Q.rlo = ws.rlo; Q.rup = ws.rup; Q.V2 = ws.V2;

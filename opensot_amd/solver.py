@@ -253,7 +253,7 @@ class BatchedStack:
         qb = self._qp_batch(B)
         abi.check(self._lib.osot_ihqp_solve(self._h, C.byref(qb), _stream_ptr(self.device, self.stream)), "osot_ihqp_solve")
 
-    def solve_nhqp(self, B, free_vars=None, min_sv_ratio=None, ab_regularization=True, selective_ns_regularization=True):
+    def solve_nhqp(self, B, free_vars=None, min_sv_ratio=None, ab_regularization=True, selective_ns_regularization=True, level_W=None):
         """Solver::solve() with the reference's NULL-SPACE front-end, OpenSoT::solvers::nHQP (nHQP.cpp:155-204), on the same
         assembled arrays; stream-ordered, results in self.dq[:B] / self.status[:B].  free_vars: free variables per level
         (the reference fixes them at construction); None = n, then minus the rows of the level above"""
@@ -280,6 +280,12 @@ class BatchedStack:
                 opt.level_no_selective_ns_regularization[k] = 0 if v else 1
         else:
             opt.no_selective_ns_regularization = 0 if selective_ns_regularization else 1
+        # level_W: per level the FULL weight matrix [B][m_k][m_k] (device tensor) of a level with a non-diagonal weight, or None
+        if level_W is not None:
+            self._nhqp_W = list(level_W)            # (kept alive until the next call)
+            for k, Wk in enumerate(level_W):
+                if Wk is not None:
+                    opt.level_W[k] = Wk.data_ptr()
         qb = self._qp_batch(B)
         abi.check(self._lib.osot_nhqp_solve(self._h, C.byref(qb), C.byref(opt), _stream_ptr(self.device, self.stream)), "osot_nhqp_solve")
 

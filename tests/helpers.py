@@ -404,7 +404,7 @@ def nhqp_fill_options(opt, free_vars=None, min_sv_ratio=None, ab_regularization=
     return opt
 
 
-def emu_nhqp(plan, asm, free_vars=None, min_sv_ratio=None, ab_regularization=True, selective_ns_regularization=True, task_active=None):
+def emu_nhqp(plan, asm, free_vars=None, min_sv_ratio=None, ab_regularization=True, selective_ns_regularization=True, task_active=None, level_W=None):
     """the null-space front-end (osot_nhqp_*.h: kernels AND host orchestration) on host pointers through the emulator.
     task_active: {(level, task): bool} (Task::setActive)"""
     B, n, L = asm["B"], asm["n"], asm["L"]
@@ -425,6 +425,11 @@ def emu_nhqp(plan, asm, free_vars=None, min_sv_ratio=None, ab_regularization=Tru
     dq = np.zeros((B, n)); st = np.full(B, -1, dtype=np.int32)
     qb.dq, qb.status = dq.ctypes.data, st.ctypes.data
     opt = nhqp_fill_options(abi.NhqpOptions(), free_vars, min_sv_ratio, ab_regularization, selective_ns_regularization)
+    if level_W is not None:        # osot_nhqp_options.level_W: the full weight matrix of a level with a non-diagonal weight (host pointers here)
+        for k, Wk in enumerate(level_W):
+            if Wk is not None:
+                Wk = np.ascontiguousarray(Wk, dtype=np.float64); keep.append(Wk)
+                opt.level_W[k] = Wk.ctypes.data
     ta = None
     if task_active:
         ta = np.ones(abi.MAX_LEVELS * abi.MAX_TASKS, dtype=np.uint8)

@@ -398,3 +398,81 @@ def test_per_level_switches_and_inactive_task_gpu(oracle, gpu_device):
     torch.cuda.synchronize()
     assert (wst == 0).all() and (st.status[:B].cpu().numpy() == 0).all()
     assert np.abs(st.dq[:B].cpu().numpy() - want).max() < 1e-8
+
+
+def _dense_weight_stack(n, rows0, rows1, B, seed, box):
+    """a two-level stack whose first level holds a task with a NON-DIAGONAL weight (Task::setWeight(W)) next to a plain one"""
+    from opensot_amd import abi
+    from opensot_amd.plan import StackPlan, Task
+    rng = np.random.default_rng(seed)
+    ra = rows0 // 2
+    base, bleaf = synth.make_generic_stack(B, n, [rows0, rows1] if rows1 else [rows0], n_eq=0, n_ineq=0, seed=seed, box=box, postural_last=False, eps_factor=1e6)
+    lv0 = [Task(abi.TASK_GENERIC, ra, name="a", dense_weight=True), Task(abi.TASK_GENERIC, rows0 - ra, name="b")]
+    plan = StackPlan(n=n, levels=[lv0] + list(base.levels[1:]), bounds=list(base.bounds), rowblocks=[], eps_abs=base.eps_abs)
+    leaf = dict(bleaf)
+    b0 = bleaf["task"][0][0][0]
+    if rows0 > n:          # an over-determined level with an INCONSISTENT right-hand side: the weight decides the answer
+        b0 = b0 + rng.normal(0.0, 0.05, b0.shape)
+    leaf["task"] = [[(b0[:, :ra].copy(), None, None), (b0[:, ra:].copy(), None, None)]] + list(bleaf["task"][1:])
+    Mw = rng.normal(size=(B, ra, ra))
+    Wa = Mw @ np.transpose(Mw, (0, 2, 1)) / ra + 0.5 * np.eye(ra)
+    leaf["W"] = [[Wa, None]] + [[None] * len(lv) for lv in base.levels[1:]]
+    return plan, leaf
+
+
+@pytest.mark.parametrize("n,rows0,rows1,box", [(12, 6, 4, 0.0), (12, 16, 0, 0.0), (20, 10, 6, 0.3), (20, 26, 0, 0.2), (35, 12, 8, 0.0), (35, 40, 0, 0.0)])
+def test_nhqp_dense_weight_emulated(oracle, n, rows0, rows1, box):
+    """round 5 -- nHQP with a non-diagonal task weight (nHQP.cpp:381-382: H = AN'W AN, g = -AN'W b0 on the REGULARISED A N and b0):
+    osot_nhqp_options.level_W carries the level's full weight matrix; the kernels run their H / g stage on diag(W) and add the
+    off-diagonal part column by column.  n <= 32, 33..64 and a level wider than 32 on both sides (all three preparation kernels),
+    with and without a box; against the restatement (oracle/pynhqp.py, parity unpinned)"""
+    from oracle import pynhqp
+    B = 6
+    plan, leaf = _dense_weight_stack(n, rows0, rows1, B, seed=100 + n + rows0, box=box)
+    asm = oracle.assemble(plan, leaf)
+    assert asm["Wdense"][0] is not None
+    ref = pynhqp.nhqp_solve(asm)
+    LW = [asm["Wdense"][0]] + [None] * (asm["L"] - 1)
+    dq, st = emu_nhqp(plan, asm, level_W=LW)
+    assert (st == 0).all()
+    assert np.abs(dq - ref["dq"]).max() < 1e-8 * max(1.0, np.abs(ref["dq"]).max())
+    if rows0 > n:
+        # an over-determined level with an inconsistent right-hand side, A/b regularisation OFF (with it on regularize_A_b zeroes the
+        # part of b0 outside range(U_k), nHQP.cpp:254-257, and the level is solved exactly whatever W): the weight decides the answer,
+        # and its diagonal alone gives another one
+        ref2 = pynhqp.nhqp_solve(asm, ab_regularization=False)
+        dq2, st2 = emu_nhqp(plan, asm, level_W=LW, ab_regularization=False)
+        assert (st2 == 0).all() and np.abs(dq2 - ref2["dq"]).max() < 1e-8 * max(1.0, np.abs(ref2["dq"]).max())
+        asm_d = dict(asm); asm_d["Wdense"] = None
+        asm_d["w"] = [np.ascontiguousarray(np.diagonal(asm["Wdense"][0], axis1=1, axis2=2))] + list(asm["w"][1:])
+        assert np.abs(pynhqp.nhqp_solve(asm_d, ab_regularization=False)["dq"] - ref2["dq"]).max() > 1e-4
+
+
+def test_nhqp_dense_weight_without_level_W_is_refused(oracle):
+    """a level with a non-diagonal weight and no level_W: refused with the reason, not solved on W A / W b"""
+    plan, leaf = _dense_weight_stack(12, 6, 4, 4, seed=7, box=0.0)
+    asm = oracle.assemble(plan, leaf)
+    with pytest.raises(AssertionError):
+        emu_nhqp(plan, asm)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,rows0,rows1", [(20, 10, 6), (20, 26, 0), (35, 12, 8), (35, 40, 0)])
+def test_nhqp_dense_weight_gpu(oracle, gpu_device, n, rows0, rows1):
+    """the same through osot_nhqp_solve on the device (BatchedStack.solve_nhqp(level_W=...)): against the restatement"""
+    import torch
+    from oracle import pynhqp
+    from opensot_amd.solver import BatchedStack
+    B = 24
+    plan, leaf = _dense_weight_stack(n, rows0, rows1, B, seed=300 + n + rows0, box=0.0)
+    asm = oracle.assemble(plan, leaf)
+    ref = pynhqp.nhqp_solve(asm)
+    st = BatchedStack(plan, B, device=0)
+    st.load_assembled(asm)
+    W0 = torch.as_tensor(np.ascontiguousarray(asm["Wdense"][0]), dtype=torch.float64, device=torch.device("cuda", 0))
+    st.solve_nhqp(B, level_W=[W0] + [None] * (plan.L - 1))
+    torch.cuda.synchronize()
+    assert (st.status[:B].cpu().numpy() == 0).all()
+    assert np.abs(st.dq[:B].cpu().numpy() - ref["dq"]).max() < 1e-8 * max(1.0, np.abs(ref["dq"]).max())
+    with pytest.raises(RuntimeError, match="level_W"):
+        st.solve_nhqp(B)
