@@ -1593,6 +1593,9 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_wide_kernel(const DevNhq
     if (inst >= Q.B) return;
     if (Q.status && Q.status[inst] != 0) return;
     const bool first = Q.level == 0;
+#ifdef OSOT_NHQP_PHASES
+    long long ph_t_ = (long long)clock64();
+#endif
     const double* A = Q.A ? Q.A + inst * (long long)ma * n : nullptr;
     for (int e = lane; e < RM * S; e += 64) { AN[e] = 0.0; G[e] = 0.0; }
     for (int e = lane; e < RN * S; e += 64) NV[e] = 0.0;
@@ -1605,6 +1608,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_wide_kernel(const DevNhq
     }
     vec[lane] = (!first && lane < n) ? Q.q0[inst * n + lane] : 0.0;
     wave_sync();
+    NHQP_PHASE("w:loadN");
     // ---- A N (lane = column), b0 = b - A q0 (lane = row)
     for (int r = 0; r < m; ++r) {
         const bool zr = (Q.zero_rows >> r) & 1ull;
@@ -1627,6 +1631,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_wide_kernel(const DevNhq
         b0[lane] = v;
     }
     wave_sync();
+    NHQP_PHASE("w:AN+b0");
     // ---- constraints in z-coordinates (levels below the first): rows [C N; N], bounds shifted by q0 (compute_contraints, :282-317)
     if (!first) {
         const int nr = Q.nc + (Q.has_box ? n : 0);
@@ -1654,6 +1659,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_wide_kernel(const DevNhq
         }
     }
     wave_sync();      // N is dead: NV becomes V
+    NHQP_PHASE("w:constr");
     // ---- G = (A N)'(A N), V = I
     {
         const int cl = (lane < nf) ? lane : 0;
@@ -1674,6 +1680,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_wide_kernel(const DevNhq
     wave_sync();
     if (lane < nf) NV[lane * S + lane] = 1.0;
     wave_sync();
+    NHQP_PHASE("w:gram");
     // ---- cyclic Jacobi on G, rotations accumulated in V.  kk = nf rounded up to even (a phantom index pairs with nobody); round r of
     // a sweep: (kk - 1, r) and ((r + t) mod (kk - 1), (r - t) mod (kk - 1)), t = 1 .. kk / 2 - 1 -- every pair once per sweep.
     {
@@ -1735,6 +1742,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_wide_kernel(const DevNhq
         }
     }
     // ---- singular values, descending; ksv = min(m, nf) of them exist (svd.singularValues(), Eigen's thin count)
+    NHQP_PHASE("w:jacobi");
     const int ksv = (m < nf) ? m : nf;
     {
         const double lam = (lane < nf) ? G[lane * S + lane] : -1.0;
@@ -1750,6 +1758,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_wide_kernel(const DevNhq
     }
     const double sv_max = sig[0];
     constexpr double kSvNoise = 1.0e-7;
+    NHQP_PHASE("w:sort");
     // ---- regularize_A_b (nHQP.cpp:236-279)
     if (Q.ab_reg) {
         double* U = G;                                 // (the Gram matrix is spent: its diagonal went into sig[])
@@ -1810,6 +1819,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_wide_kernel(const DevNhq
         wave_sync();
     }
     // ---- H = AN' W AN (+ sv_max V2 V2'), g = -AN' W b0, V2 = the columns of V of the ns smallest eigenvalues (svd.matrixV().rightCols)
+    NHQP_PHASE("w:ABreg");
     {
         const double* w = Q.w ? Q.w + inst * m : nullptr;
         wave_sync();
