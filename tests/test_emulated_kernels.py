@@ -603,3 +603,21 @@ def test_box_instantiation_for_rows_that_are_all_equalities(n, monkeypatch):
     emu_cascade(pl2, po.assemble(pl2, lf2))
     assert not emu_cascade.ran_box
 
+
+
+@pytest.mark.parametrize("n", [8, 32, 40, 64])
+def test_indefinite_hessian_is_reported_not_solved(n):
+    """OSOT_STATUS_NOT_PD: the Cholesky of H + eps I breaks down (a non-positive pivot) -- both tile factorisations (factor_tiles32 for
+    n <= 32, round 5's factor_tiles_wide for 33 .. 64) flag it, return x = 0 and do not touch the instances beside it"""
+    rng = np.random.default_rng(n)
+    B = 4
+    M = rng.normal(size=(B, n, n))
+    H = M @ np.transpose(M, (0, 2, 1)) + 0.5 * np.eye(n)
+    H[1] = H[1] - 3.0 * np.linalg.eigvalsh(H[1]).max() * np.eye(n) * (np.arange(n) == n // 2)     # one negative pivot in the middle
+    H[3, n - 1, n - 1] = -1.0                                                                     # ... and one in the last column
+    g = rng.normal(size=(B, n))
+    x, st, it = emu_qp(H, g, None, None, None, None, None, eps_abs=1e-9)
+    assert list(st) == [0, 3, 0, 3]
+    assert np.abs(x[1]).max() == 0.0 and np.abs(x[3]).max() == 0.0
+    for i in (0, 2):
+        assert np.abs(x[i] + np.linalg.solve(H[i] + 1e-9 * np.eye(n), g[i])).max() < 1e-9
