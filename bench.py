@@ -749,7 +749,7 @@ def time_config5_coherent(B, device, steps=40, warmup=8, cycles=4, drift=0.01):
             "hot_vs_cold_max_abs_dq_diff": float(np.abs(dqs[True] - dqs[False]).max())}
 
 
-def time_nhqp(B, device, steps=5, warmup=2, lanes=1, streams=None):
+def time_nhqp(B, device, steps=5, warmup=2, lanes=1, streams=None, graph=True):
     """the null-space front-end (OpenSoT::solvers::nHQP, SURVEY 8f-2) on the C3 stack: update + osot_nhqp_solve.  lanes > 1 (with the
     caller's streams): the batch as sub-batches on their own streams -- one sub-batch's level preparation runs under the other's
     QP / accumulation launches and under the tail of its preparation (tools/exp_frontend_lanes.py: 4.16 -> 4.79 M)"""
@@ -772,9 +772,33 @@ def time_nhqp(B, device, steps=5, warmup=2, lanes=1, streams=None):
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
+    # the timed steps of a sub-batch as ONE HIP graph (like the headline: ten launches per step and sub-batch, and the host's share
+    # of a launch -- argument structs through ctypes -- is not what is being measured); plain launches if capture is unavailable
+    graphs = []
+    if graph and lanes > 1:
+        try:
+            for st, dv, Bl in work:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st.stream):
+                    for _ in range(steps):
+                        st.update(dv); st.solve_nhqp(Bl)
+                graphs.append(g)
+        except Exception:
+            graphs = []
+        torch.cuda.synchronize()
+
+    def run():
+        if graphs:
+            for g, (st, _, _) in zip(graphs, work):
+                with torch.cuda.stream(st.stream):
+                    g.replay()
+        else:
+            for _ in range(steps):
+                step()
+    if graphs:
+        run(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
+    run()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     ok = sum(int((st.status[:Bl] == 0).sum().item()) for st, _, Bl in work)
