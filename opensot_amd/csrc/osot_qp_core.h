@@ -1065,6 +1065,7 @@ __device__ inline bool direction_is_independent(const WaveCtx<NP>& w, double nd2
 #endif
 constexpr double kRefineFloor = OSOT_REFINE_FLOOR;   // violations below this (relative to max(1, |bound|)) are accepted without a refinement
 constexpr int kRefineMax = 2;             // refinements per level
+constexpr double kSpanAccept = 1.0e-8;    // (see gi_inequalities: a violation below this with the normal in the span of the working set is not exchanged)
 template <int NP, bool BOX>
 __device__ __forceinline__ double refine_on_working_set(const WaveCtx<NP>& w, double x, int iq, int Aq, double lb, double ub, double xprev) {
     const int c = w.c, h = w.h, n = w.n;
@@ -1946,6 +1947,39 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
             }
             const double t2 = z_ok ? (-s_ip * fast_rcp(nd2)) : INFINITY;   // (mode 1: a signed step onto the boundary)
             OSOT_SUB_END(PH_IN_R);
+#ifdef OSOT_TRACE_TRIPS   // developer knob: one line per pass of the inner loop (GPU or emulator; run ONE instance)
+            if (WaveCtx<NP>::lane_of(c, h) == 0)
+                printf("TRIP it %d iq %d me %d ip %d s_ip %.3e nd2 %.3e dd %.3e z_ok %d rmax %.3e t1 %.3e t2 %.3e mode %d\n", iters, iq, me, ip, s_ip, nd2, dd,
+                       (int)z_ok, rmax, t1, t2, mode);
+#endif
+            // A TINY VIOLATION WITH THE NORMAL IN THE SPAN OF THE WORKING SET, AHEAD OF A DUAL EXCHANGE (round 5).  No primal direction,
+            // a multiplier to trade: in exact arithmetic the exchange is the dual method's step.  But at the reference's default eps a
+            // violation of 1e-9 is what the working set's own round-off implies, and the exchange it triggers goes through a direction
+            // that is barely independent -- seen on hardware only (tests/golden/default_eps_roundoff_exchange_instance.npz, closed-loop
+            // seed 44): a bound 3.5e-9 outside was traded against a member of the set along |d2|^2 = 8e-7 |d|^2, another bound ended
+            // 1.6e-6 outside with nothing left to trade, and the level was called INFEASIBLE where both witnesses solve it.  So:
+            //   below kSpanAccept (1e-8 relative: a tenth of the 1e-7 the acceptance rule of DESIGN section 5 asks of a feasible point, far
+            //   inside qpOASES' own termination tolerance of 2.2e-7) the constraint counts as satisfied -- its bound is relaxed by the
+            //   violation for the rest of the cascade and the accepted slack is reported;
+            //   up to kSlackTol the round-off of the ITERATE is taken out first (refine_on_working_set) and the scan runs again; a
+            //   violation that survives is exchanged as before.
+            if (mode == 0 && !z_ok && t1 < INFINITY) {
+                const double bmag0 = ip_box ? fabs(bcast((ip < n) ? lb : ub, ip_var))
+                                            : fabs(uniform_d((ip & 1) ? w.rup[ip_row] : w.rlo[ip_row]));
+                if (-s_ip <= kSpanAccept * fmax(1.0, bmag0)) {
+                    const double relax = -1.001 * s_ip;
+                    if (ip_box) { if (c == ip_var) { if (ip < n) lb -= relax; else ub += relax; } }
+                    else if (c == 0 && h == 0) { if (ip & 1) w.rup[ip_row] += relax; else w.rlo[ip_row] -= relax; }
+                    wave_sync();
+                    slack_out = fmax(slack_out, -s_ip);
+                    degenerate_done = true; break;
+                }
+                if (!diag_dd && refine_left > 0 && -s_ip <= kSlackTol * fmax(1.0, bmag0)) {
+                    refine_left--;
+                    x = refine_on_working_set<NP, BOX>(w, x, iq, Aq, lb, ub, xprev);
+                    degenerate_done = true; break;
+                }
+            }
             if (!(t1 < INFINITY) && !(t2 < INFINITY)) {
                 // no primal direction left and no inequality to trade.  If the most violated constraint is
                 // violated only at round-off level (an active inequality of an upper level re-appearing when the

@@ -307,8 +307,11 @@ def default_eps_stuck_instances(mode="tasks"):
     INFEASIBLE while a witness went on -- kept as data (assembled arrays of the cycle).  mode "tasks": five instances of
     seeds 4 and 7 (round 1) and a sixth of seed 7 that only the hardware failed with a ratio tolerance of 1e-10; "ttc": one of seed 21 with the feet as TaskToConstraint rows (a noise-level "positive" entry
     of the dual direction gave a dual step of 6.6e8: kRatioTol in osot_qp_core.h)"""
-    plan, _ = closed_loop_plan(mode, 2e2)
-    z = np.load(os.path.join(GOLDEN, "default_eps_stuck_instances.npz" if mode == "tasks" else "default_eps_stuck_ttc_instance.npz"))
+    # "ttc_exchange" (round 5, seed 44 of the sweep, HARDWARE only): a bound 3.5e-9 outside with its normal in the span of the working set
+    # was exchanged along a barely independent direction and the level ended INFEASIBLE (kSpanAccept in osot_qp_core.h)
+    files = {"tasks": "default_eps_stuck_instances.npz", "ttc": "default_eps_stuck_ttc_instance.npz", "ttc_exchange": "default_eps_roundoff_exchange_instance.npz"}
+    plan, _ = closed_loop_plan("tasks" if mode == "tasks" else "ttc", 2e2)
+    z = np.load(os.path.join(GOLDEN, files[mode]))
     B = z["b0"].shape[0]
     L = plan.L
     asm = {"n": plan.n, "B": B, "L": L, "eps_abs": plan.eps_abs, "m": [plan.m(k) for k in range(L)], "ma": [plan.ma(k) for k in range(L)],

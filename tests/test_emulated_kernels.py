@@ -413,7 +413,7 @@ def test_task_local_equality_on_a_postural_last_level(n, rows, oracle):
         assert ok.any() and np.abs(dq[ok] - rq["dq"][ok]).max() < 1e-7
 
 
-@pytest.mark.parametrize("mode", ["tasks", "ttc"])
+@pytest.mark.parametrize("mode", ["tasks", "ttc", "ttc_exchange"])
 def test_default_eps_stuck_instances(mode, oracle):
     """the five closed-loop instances at iHQP's default eps (factor 2e2) that round 1 reported INFEASIBLE: every level's
     optimality rows are now posed relative to the previous level's solution, which is therefore an exactly feasible point

@@ -379,7 +379,7 @@ def test_task_local_equality_on_a_postural_last_level_gpu(n, rows, oracle, gpu_d
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["tasks", "ttc"])
+@pytest.mark.parametrize("mode", ["tasks", "ttc", "ttc_exchange"])
 def test_default_eps_stuck_instances_gpu(mode, oracle, gpu_device):
     """tests/golden/default_eps_stuck_instances.npz on hardware (see the emulator test of the same name)"""
     from helpers import answer_is_acceptable, default_eps_stuck_instances
