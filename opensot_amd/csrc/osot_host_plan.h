@@ -164,8 +164,8 @@ inline int plan_validate(const osot_plan_desc* p, const char** why) {
 // LDS carve-up (doubles) of one wave's slice for padded size NP: M1, M2, V, then the row table
 // (rlo, rup, rptr: 8 B per row each; rowstate, eqlist: 4 B per row each; rsrc: 1 B per row).  Returns the total in doubles.
 inline int lds_layout(int NP, int n_rows, int* rows_off, int* rows_cap) {
-    const int S = NP + 1;
-    int d = (NP == 32 ? WaveCtx<32>::M1_DOUBLES : WaveCtx<64>::M1_DOUBLES) + NP * S + 4 * NP;
+    // (round 5: the phantom-lane layouts 40 and 56 too -- osot_qp_kernel<40> / <56> for the plugin route and nHQP's level QPs)
+    int d = NP == 32 ? WaveCtx<32>::LDS_DOUBLES : (NP == 40 ? WaveCtx<40>::LDS_DOUBLES : (NP == 56 ? WaveCtx<56>::LDS_DOUBLES : WaveCtx<64>::LDS_DOUBLES));
     d = (d + 1) & ~1;
     *rows_off = d;
     const int cap = ((n_rows > 0 ? n_rows : 1) + 1) & ~1;

@@ -763,7 +763,7 @@ struct DevQP {
 // HOT: the instantiation that carries the hot-start code (the batch-of-one BackEnd surface keeps its working set from solve() to
 // solve() like QPOasesBackEnd::solve, QPOasesBackEnd.cpp:258-285); the plain one carries none of it
 template <int NP, bool HOT = false>
-__global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
+__global__ void __launch_bounds__(64, (NP == 40 ? OSOT_WAVES40 : 1)) osot_qp_kernel(const DevQP Q) {
     OSOT_DYNAMIC_LDS(osot_smem);
     constexpr int S = WaveCtx<NP>::S;
     const int lane = threadIdx.x;
@@ -832,7 +832,7 @@ __global__ void __launch_bounds__(64) osot_qp_kernel(const DevQP Q) {
     int st;
     int* hotk = (HOT && Q.hot) ? Q.hot + inst * WaveCtx<NP>::LW : nullptr;
     const int hotcode = hotk ? hotk[c] : -1;
-    if (NP == 64) {
+    if (NP > 32) {
         OSOT_ALWAYS_INLINE_CALL st = gi_solve<NP, false>(w, Q.nc, g, false, 0.0, Hc, has_box, lb, ub, Q.max_iter, false, 0.0, x, iters, nullptr, slack,
                                                          false, 0.0, hotcode, hotk);
     } else {

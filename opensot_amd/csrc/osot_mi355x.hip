@@ -697,21 +697,29 @@ static int qp_solve_batch_impl(int B, int n, int nc, const double* H, const doub
     Q.eps_abs = eps_abs;
     Q.H = H; Q.g = g; Q.A = A; Q.lA = lA; Q.uA = uA; Q.l = l; Q.u = u;
     Q.x = x; Q.status = status; Q.iterations = iterations;
+    // the lane layout of the cascade kernels (make_dev_plan): 32, 40 (33..38 variables, two wavefronts per SIMD), 56, 64
+#ifdef OSOT_X_NO_NP40
     const int T = n <= 32 ? 32 : 64;
+#else
+    const int T = n <= 32 ? 32 : (n <= WaveCtx<40>::NMAX ? 40 : (n <= WaveCtx<56>::NMAX ? 56 : 64));
+#endif
     const size_t lds = (size_t)lds_layout(T, nc, &Q.lds_rows_off, &Q.lds_rows_cap) * sizeof(double);
     Q.hot = hot;
-    int rc;
-    if (hot) rc = (T == 32) ? ensure_lds(osot_qp_kernel<32, true>, lds) : ensure_lds(osot_qp_kernel<64, true>, lds);
-    else rc = (T == 32) ? ensure_lds(osot_qp_kernel<32>, lds) : ensure_lds(osot_qp_kernel<64>, lds);
-    if (rc != OSOT_OK) return rc;
     const unsigned grid = (unsigned)B;
-    if (hot) {
-        if (T == 32) hipLaunchKernelGGL((osot_qp_kernel<32, true>), dim3(grid), dim3(64), lds, (hipStream_t)hip_stream, Q);
-        else hipLaunchKernelGGL((osot_qp_kernel<64, true>), dim3(grid), dim3(64), lds, (hipStream_t)hip_stream, Q);
-    } else {
-        if (T == 32) hipLaunchKernelGGL(osot_qp_kernel<32>, dim3(grid), dim3(64), lds, (hipStream_t)hip_stream, Q);
-        else hipLaunchKernelGGL(osot_qp_kernel<64>, dim3(grid), dim3(64), lds, (hipStream_t)hip_stream, Q);
-    }
+    const int rc = by_np(T, [&](auto np) -> int {
+        constexpr int NP = decltype(np)::value;
+        if (hot) {
+            const int r = ensure_lds(osot_qp_kernel<NP, true>, lds);
+            if (r != OSOT_OK) return r;
+            hipLaunchKernelGGL((osot_qp_kernel<NP, true>), dim3(grid), dim3(64), lds, (hipStream_t)hip_stream, Q);
+        } else {
+            const int r = ensure_lds(osot_qp_kernel<NP, false>, lds);
+            if (r != OSOT_OK) return r;
+            hipLaunchKernelGGL((osot_qp_kernel<NP, false>), dim3(grid), dim3(64), lds, (hipStream_t)hip_stream, Q);
+        }
+        return OSOT_OK;
+    });
+    if (rc != OSOT_OK) return rc;
     HIP_TRY(hipGetLastError());
     return OSOT_OK;
 }

@@ -1566,6 +1566,197 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
 //     regularize_A_b is the reference's own formula, b0 <- U diag(d) U'b0, A N <- A N + sum (sv' - sv) u v' (nHQP.cpp:236-279).
 // LDS (dynamic, nhqp_prepare_wide_lds_bytes): A N [RM][S], N -> V [RN][S], G -> U [RM][S], S = RN + 1, RN = n rounded up to 8,
 // RM = max(m, n) rounded up to 8: 50 KB at S1.
+// Symmetric eigenproblem of the wide path, G (k x k, k <= 64, LDS stride S, lane = column / row) -> G[c][c] = eigenvalue c, V[:, c] =
+// its eigenvector (V: LDS, stride S; both buffers ZERO beyond k up to the next multiple of eight, rows and columns).  Householder tridiagonalisation
+// (one reflector per column, lane = column for the matrix - vector product and the rank-two update, lane = row for V <- V H) and the
+// implicit QL iteration of sym_ql_32 over all 64 lanes: (d, e) one entry per lane read with v_readlane, a lane's own row of V carried
+// through the rotations.  Replaces the cyclic Jacobi iteration (kept under OSOT_NHQP_WIDE_JACOBI for A/B), which moved ~12 LDS words
+// per pair per round, ~280 rounds, and was 93 % of the launch.  vv / ww: 64 doubles of LDS scratch each.
+__device__ __forceinline__ void sym_eig_wide(double* G, double* V, double* vv, double* ww, int k_in, int S_in, int lane) {
+    constexpr double kEps = 2.220446049250313e-16;
+    const int k = uniform_i(k_in), S = uniform_i(S_in);
+    const int cl = (lane < k) ? lane : 0;
+    // ---- V = I
+    for (int i = 0; i < k; ++i) if (lane < k) V[i * S + lane] = (i == lane) ? 1.0 : 0.0;
+    double d = 0.0, e = 0.0;                       // lane c: T[c][c], T[c][c + 1]
+    wave_sync();
+    for (int j = 0; j + 2 < k; ++j) {
+        const bool in = lane > j && lane < k;
+        const double x = in ? G[j * S + cl] : 0.0;                   // column j below the diagonal (= row j: G is symmetric)
+        const double tail = uniform_d(colsum<64>((lane > j + 1) ? x * x : 0.0));
+        const double x1 = bcast(x, j + 1);
+        if (!(tail > 0.0)) { if (lane == j) e = x1; continue; }      // already tridiagonal in this column
+        // scaled against over- / underflow of the squares: the power of two of the column's largest entry
+        const int ex = frexp_exponent(uniform_d(colmax<64>(fabs(x))));
+        const double xs = scale_pow2(x, -ex), x1s = scale_pow2(x1, -ex);
+        const double sigma = uniform_d(colsum<64>(xs * xs));
+        double rt, irt;
+        fast_sqrt_rsqrt(sigma, rt, irt);
+        const double alpha = (x1s >= 0.0) ? -rt : rt;
+        const double v = xs - ((lane == j + 1) ? alpha : 0.0);       // v = x - alpha e_(j+1), |v|^2 = 2 (sigma - alpha x1)
+        const double beta = 1.0 / (sigma - alpha * x1s);             // H = I - beta v v'
+        if (lane == j) e = scale_pow2(alpha, ex);
+        vv[lane] = v;
+        wave_sync();
+        // p = beta G v (lane = column; rows j + 1 .. k - 1), w = p - (beta / 2)(v'p) v.  Every loop below runs over whole chunks of eight
+        // rows / columns from (j + 1) rounded down, eight LDS reads in flight (a loop with a run-time trip count pays one LDS round trip
+        // per element otherwise): v and w are ZERO outside (j, k), the rows and columns of G and V beyond k are zero, and the stale
+        // rows <= j of G are finite -- so the extra terms are exact zeros.
+        const int r0 = (j + 1) & ~7, r1 = (k + 7) & ~7;
+        double p0 = 0.0, p1 = 0.0, t0 = 0.0, t1 = 0.0;
+        for (int i = r0; i < r1; i += 8) {
+            double gg[8], v8[8], tt[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { gg[u] = G[(i + u) * S + cl]; v8[u] = vv[i + u]; tt[u] = V[cl * S + i + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                p0 = fma(gg[u], v8[u], p0); p1 = fma(gg[u + 1], v8[u + 1], p1);
+                t0 = fma(tt[u], v8[u], t0); t1 = fma(tt[u + 1], v8[u + 1], t1);          // my row of V times v (lane = row)
+            }
+        }
+        const double p = in ? beta * (p0 + p1) : 0.0;
+        const double kap = 0.5 * beta * uniform_d(colsum<64>(v * p));
+        const double w = fma(-kap, v, p);
+        ww[lane] = w;
+        const double bt = beta * (t0 + t1);
+        wave_sync();
+        // G <- G - v w' - w v' on the trailing block (lane = column), V <- V - (beta V v) v' (lane = row)
+        if (lane < k) for (int r = r0; r < r1; r += 8) {
+            double gg[8], v8[8], w8[8], tt[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { gg[u] = G[(r + u) * S + lane]; v8[u] = vv[r + u]; w8[u] = ww[r + u]; tt[u] = V[lane * S + r + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                G[(r + u) * S + lane] = fma(-v8[u], w, fma(-w8[u], v, gg[u]));
+                V[lane * S + r + u] = fma(-bt, v8[u], tt[u]);
+            }
+        }
+        wave_sync();
+    }
+    if (lane < k) d = G[lane * S + lane];
+    if (k >= 2) { const double el = G[(k - 2) * S + (k - 1)]; if (lane == k - 2) e = el; }
+    wave_sync();
+#ifdef OSOT_NHQP_PHASES
+    if (blockIdx.x == 0 && lane == 0) printf("PHASE w:tridiagonal done at %lld\n", (long long)clock64());
+#endif
+    // ---- implicit QL with shifts (tql2; see sym_ql_32): e[c] couples c and c + 1, e[k - 1] = 0
+    const double anorm = uniform_d(colmax<64>((lane < k) ? fabs(d) + fabs(e) : 0.0));
+    const double etol = OSOT_QL_TOL * kEps * anorm;
+    for (int l = 0; l < k; ++l) {
+        for (int iter = 0; iter < 60; ++iter) {
+            const bool small = (lane >= l && lane < k - 1) && (fabs(e) <= etol);
+            const unsigned long long mk = wave_ballot(small);
+            const int m = mk ? __builtin_ctzll(mk) : k - 1;
+            if (m == l) break;
+            const double dl = bcast(d, l), dl1 = bcast(d, l + 1), el = bcast(e, l), dm = bcast(d, m);
+            double g = (dl1 - dl) / (2.0 * el);
+            double r = sqrt(fma(g, g, 1.0));
+            g = dm - dl + el / (g + (g >= 0.0 ? r : -r));
+            double sn = 1.0, cs = 1.0, p = 0.0;
+            bool underflow = false;
+            double di1 = dm;
+            double zc = V[cl * S + m];
+            double z0n = V[cl * S + m - 1];
+            for (int i = m - 1; i >= l; --i) {
+                const double z0 = z0n;
+                if (i > l) z0n = V[cl * S + i - 1];
+                const double ei = bcast(e, i), di = bcast(d, i);
+                const double f = sn * ei, b = cs * ei;
+                const double rr2 = fma(f, f, g * g);
+                double ir;
+                if (rr2 > 0.0) fast_sqrt_rsqrt(rr2, r, ir);
+                else { r = 0.0; ir = 0.0; }
+                if (lane == i + 1) e = r;
+                if (r == 0.0) {
+                    if (lane == i + 1) d -= p;
+                    if (lane == m) e = 0.0;
+                    if (lane < k) V[lane * S + i + 1] = zc;
+                    underflow = true;
+                    break;
+                }
+                sn = f * ir; cs = g * ir;
+                g = di1 - p;
+                r = fma(di - g, sn, 2.0 * cs * b);
+                p = sn * r;
+                if (lane == i + 1) d = g + p;
+                g = fma(cs, r, -b);
+                di1 = di;
+                if (lane < k) V[lane * S + i + 1] = fma(sn, z0, cs * zc);
+                zc = fma(cs, z0, -sn * zc);
+            }
+            if (underflow) continue;
+            if (lane < k) V[lane * S + l] = zc;
+            if (lane == l) { d -= p; e = g; }
+            if (lane == m) e = 0.0;
+        }
+    }
+    wave_sync();
+    if (lane < k) G[lane * S + lane] = d;
+    wave_sync();
+}
+
+// X'diag(w) X of the LDS matrix X ([rows][S], zero rows beyond m up to the next multiple of four) on the fp64 matrix core: T x T tiles
+// of 16 x 16 (upper triangle), one v_mfma_f64_16x16x4 per tile per four rows of X; a lane's operand X[r0 + (lane >> 4)][16 J + (lane & 15)]
+// serves as A AND as B (the tile (I, J) is x_I' x_J), so a k-step costs T LDS reads.  Columns >= the logical width read the row's padding /
+// the next row: finite numbers that only reach tile entries nobody stores.  w: LDS weights per row (null: ones).  Optional second
+// operand set: `ns` columns idx2[0 .. ns) of the matrix Y ([.][S], lane's ROW 16 J + (lane & 15)) scaled by sqrt(s2): + s2 Y2 Y2'.
+// acc[4 tile + r] = entry (16 I + (lane >> 4) + 4 r, 16 J + (lane & 15)) of tile (I, J), tiles in row-major upper-triangle order.
+template <int T>
+__device__ __forceinline__ void nhqp_tile_gram(const double* X, int S, int m, const double* w, const double* Y, const int* idx2, int ns, double s2,
+                                               int lane, double (&acc)[2 * T * (T + 1)]) {
+    const int q = lane >> 4, a = lane & 15;
+    v4f64 t[T * (T + 1) / 2];
+#pragma unroll
+    for (int u = 0; u < T * (T + 1) / 2; ++u) { t[u][0] = 0.0; t[u][1] = 0.0; t[u][2] = 0.0; t[u][3] = 0.0; }
+    for (int r0 = 0; r0 < m; r0 += 4) {
+        double x[T];
+#pragma unroll
+        for (int J = 0; J < T; ++J) x[J] = X[(r0 + q) * S + 16 * J + a];
+        const double wr = w ? w[r0 + q] : 1.0;
+        int u = 0;
+#pragma unroll
+        for (int I = 0; I < T; ++I) {
+            const double xa = wr * x[I];
+#pragma unroll
+            for (int J = I; J < T; ++J) { t[u] = mfma_f64_16x16x4(xa, x[J], t[u]); ++u; }
+        }
+    }
+    if (ns > 0) {
+        const double rs2 = sqrt(s2);
+        for (int t0 = 0; t0 < ns; t0 += 4) {
+            const bool live = t0 + q < ns;
+            const int ec = idx2[live ? t0 + q : 0];
+            double y[T];
+#pragma unroll
+            for (int J = 0; J < T; ++J) { const double v = Y[(16 * J + a) * S + ec]; y[J] = live ? rs2 * v : 0.0; }
+            int u = 0;
+#pragma unroll
+            for (int I = 0; I < T; ++I)
+#pragma unroll
+                for (int J = I; J < T; ++J) { t[u] = mfma_f64_16x16x4(y[I], y[J], t[u]); ++u; }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < T * (T + 1) / 2; ++u) { acc[4 * u] = t[u][0]; acc[4 * u + 1] = t[u][1]; acc[4 * u + 2] = t[u][2]; acc[4 * u + 3] = t[u][3]; }
+}
+// the tiles of nhqp_tile_gram -> a symmetric k x k matrix with row stride ld (LDS or HBM), both triangles
+template <int T>
+__device__ __forceinline__ void nhqp_tile_store(const double (&acc)[2 * T * (T + 1)], double* M, int ld, int k, int lane) {
+    const int q = lane >> 4, a = lane & 15;
+    int u = 0;
+#pragma unroll
+    for (int I = 0; I < T; ++I)
+#pragma unroll
+        for (int J = I; J < T; ++J) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * I + q + 4 * r, j = 16 * J + a;
+                if (i < k && j < k) { M[i * ld + j] = acc[4 * u + r]; if (I != J) M[j * ld + i] = acc[4 * u + r]; }
+            }
+            ++u;
+        }
+}
+
 inline size_t nhqp_prepare_wide_lds_bytes(int m, int n) {
     const size_t RN = (size_t)nhqp64_rows(n), S = RN + 1, RM = (size_t)nhqp64_rows(m > n ? m : n);
     return sizeof(double) * (2 * RM * S + RN * S + 5 * 64 + 2 * 32) + sizeof(int) * (64 + 2 * 32);
@@ -1614,7 +1805,10 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_wide_kernel(const DevNhq
         const bool zr = (Q.zero_rows >> r) & 1ull;
         double acc = 0.0;
         if (lane < nf && !zr) {
-            if (r < ma) { for (int i = 0; i < n; ++i) acc = fma(A[r * n + i], NV[i * S + lane], acc); }
+            if (r < ma) {
+                if (first) acc = A[r * n + lane];                      // N = I: A N = A
+                else for (int i = 0; i < n; ++i) acc = fma(A[r * n + i], NV[i * S + lane], acc);
+            }
             else acc = NV[(r - ma) * S + lane];
         }
         if (lane < nf) AN[r * S + lane] = acc;
@@ -1660,27 +1854,19 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_wide_kernel(const DevNhq
     }
     wave_sync();      // N is dead: NV becomes V
     NHQP_PHASE("w:constr");
-    // ---- G = (A N)'(A N), V = I
-    {
-        const int cl = (lane < nf) ? lane : 0;
-        for (int a0 = 0; a0 < nf; a0 += 8) {           // eight rows of G per pass over A N (its columns are zero beyond nf: S > RN >= nf + ...)
-            double acc8[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc8[j] = 0.0;
-            for (int r = 0; r < m; ++r) {
-                const double own = AN[r * S + cl];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc8[j] = fma(AN[r * S + ((a0 + j < nf) ? a0 + j : 0)], own, acc8[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) if (a0 + j < nf && lane < nf) G[(a0 + j) * S + lane] = acc8[j];
-        }
-    }
+    // ---- G = (A N)'(A N) on the matrix core (nhqp_tile_gram: was eight rows of G per pass over A N through the vector unit, 53 k clocks
+    // of a 670 k-clock level at S1), V = I
+    if (nf <= 48) { double acc[24]; nhqp_tile_gram<3>(AN, S, m, nullptr, nullptr, nullptr, 0, 0.0, lane, acc); nhqp_tile_store<3>(acc, G, S, nf, lane); }
+    else { double acc[40]; nhqp_tile_gram<4>(AN, S, m, nullptr, nullptr, nullptr, 0, 0.0, lane, acc); nhqp_tile_store<4>(acc, G, S, nf, lane); }
     for (int e = lane; e < RN * S; e += 64) NV[e] = 0.0;
     wave_sync();
     if (lane < nf) NV[lane * S + lane] = 1.0;
     wave_sync();
     NHQP_PHASE("w:gram");
+#ifndef OSOT_NHQP_WIDE_JACOBI
+    // ---- eigen-decomposition of G: tridiagonalisation + implicit QL (sym_eig_wide); eigenvalues to the diagonal, V in NV
+    sym_eig_wide(G, NV, vec, ub, nf, S, lane);
+#else
     // ---- cyclic Jacobi on G, rotations accumulated in V.  kk = nf rounded up to even (a phantom index pairs with nobody); round r of
     // a sweep: (kk - 1, r) and ((r + t) mod (kk - 1), (r - t) mod (kk - 1)), t = 1 .. kk / 2 - 1 -- every pair once per sweep.
     {
@@ -1741,6 +1927,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_wide_kernel(const DevNhq
             }
         }
     }
+#endif
     // ---- singular values, descending; ksv = min(m, nf) of them exist (svd.singularValues(), Eigen's thin count)
     NHQP_PHASE("w:jacobi");
     const int ksv = (m < nf) ? m : nf;
@@ -1773,7 +1960,18 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_wide_kernel(const DevNhq
             double u = 0.0;
             bool have = false;
             if (sig[i] >= kSvNoise * sv_max && sig[i] > 0.0) {
-                if (lane < m) for (int t = 0; t < nf; ++t) u = fma(AN[lane * S + t], NV[t * S + ec], u);
+                {   // (columns of A N and rows of V beyond nf are zero up to the next multiple of eight: whole chunks, eight reads in flight)
+                    const int rl = (lane < m) ? lane : 0;
+                    double u0 = 0.0, u1 = 0.0;
+                    for (int t = 0; t < nf; t += 8) {
+                        double a8[8], v8[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { a8[q] = AN[rl * S + t + q]; v8[q] = NV[(t + q) * S + ec]; }
+#pragma unroll
+                        for (int q = 0; q < 8; q += 2) { u0 = fma(a8[q], v8[q], u0); u1 = fma(a8[q + 1], v8[q + 1], u1); }
+                    }
+                    u = (lane < m) ? u0 + u1 : 0.0;
+                }
                 const double nrm2 = uniform_d(colsum<64>(u * u));
                 if (nrm2 > 0.0) { u = u / sqrt(nrm2); have = true; }
             }
@@ -1830,26 +2028,18 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_wide_kernel(const DevNhq
         {
             const int cl = (lane < nf) ? lane : 0;
             double gacc = 0.0;
-            for (int r = 0; r < m; ++r) gacc = fma(-(vec[r] * AN[r * S + cl]), b0[r], gacc);
-            if (lane < nf) Q.g[inst * nf + lane] = gacc;
-            for (int i0 = 0; i0 < nf; i0 += 8) {       // eight rows of H per pass
-                double acc8[8];
+            for (int r = 0; r < m; r += 8) {             // (rows of A N and entries of vec beyond m are zero: whole chunks of eight)
+                double a8[8], w8[8], b8[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc8[j] = 0.0;
-                for (int r = 0; r < m; ++r) {
-                    const double wan = vec[r] * AN[r * S + cl];
+                for (int u = 0; u < 8; ++u) { a8[u] = AN[(r + u) * S + cl]; w8[u] = vec[r + u]; b8[u] = b0[(r + u) & 63]; }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc8[j] = fma(wan, AN[r * S + ((i0 + j < nf) ? i0 + j : 0)], acc8[j]);
-                }
-                if (sel) for (int t = 0; t < ns; ++t) {
-                    const int ec = idx[nf - ns + t];
-                    const double own = sv_max * NV[cl * S + ec];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc8[j] = fma(own, NV[((i0 + j < nf) ? i0 + j : 0) * S + ec], acc8[j]);
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) if (i0 + j < nf && lane < nf) Hg[(i0 + j) * nf + lane] = acc8[j];
+                for (int u = 0; u < 8; ++u) gacc = fma(-(w8[u] * a8[u]), b8[u], gacc);
             }
+            if (lane < nf) Q.g[inst * nf + lane] = gacc;
+            // H on the matrix core: rows of A N weighted by w, plus sv_max V2 V2' as extra k-steps (its columns scaled by sqrt(sv_max))
+            const int nsel = sel ? ns : 0;
+            if (nf <= 48) { double acc[24]; nhqp_tile_gram<3>(AN, S, m, vec, NV, idx + (nf - ns), nsel, sv_max, lane, acc); nhqp_tile_store<3>(acc, Hg, nf, nf, lane); }
+            else { double acc[40]; nhqp_tile_gram<4>(AN, S, m, vec, NV, idx + (nf - ns), nsel, sv_max, lane, acc); nhqp_tile_store<4>(acc, Hg, nf, nf, lane); }
         }
         if (Q.Wd) { wave_sync(); nhqp_dense_weight_correction(Q, inst, AN, S, b0, lane); }
         if (ns > 0 && Q.V2) {

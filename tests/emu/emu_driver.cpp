@@ -66,10 +66,12 @@ extern "C" __attribute__((visibility("default"))) int emu_qp_solve_batch(int B, 
     Q.max_iter = max_iter > 0 ? max_iter : 20 * (n + nc) + 100;
     Q.eps_abs = eps_abs;
     Q.H = H; Q.g = g; Q.A = A; Q.lA = lA; Q.uA = uA; Q.l = l; Q.u = u; Q.x = x; Q.status = status; Q.iterations = iterations;
-    const int T = n <= 32 ? 32 : 64;
+    const int T = n <= 32 ? 32 : (n <= WaveCtx<40>::NMAX ? 40 : (n <= WaveCtx<56>::NMAX ? 56 : 64));   // as qp_solve_batch_impl
     const size_t lds = (size_t)lds_layout(T, nc, &Q.lds_rows_off, &Q.lds_rows_cap) * sizeof(double);
     const unsigned grid = (unsigned)B;
     if (T == 32) emu::launch(osot_qp_kernel<32>, grid, lds, 64, Q);
+    else if (T == 40) emu::launch(osot_qp_kernel<40>, grid, lds, 64, Q);
+    else if (T == 56) emu::launch(osot_qp_kernel<56>, grid, lds, 64, Q);
     else emu::launch(osot_qp_kernel<64>, grid, lds, 64, Q);
     return OSOT_OK;
 }
