@@ -1062,6 +1062,84 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
 // in chunks of 8 with the reads of a chunk in flight together; the padding is zero), odd row stride RN + 1.  With the fixed 64 x 65
 // layout of the first version the COMAN35 plans held 71 KB per wavefront -- two wavefronts per CU, and this kernel is bound by the
 // latency of one wavefront's instruction stream; at n = 35 it is 38 KB, four per CU.
+// X'diag(w) X of the LDS matrix X ([rows][S], zero rows beyond m up to the next multiple of four) on the fp64 matrix core: T x T tiles
+// of 16 x 16 (upper triangle), one v_mfma_f64_16x16x4 per tile per four rows of X; a lane's operand X[r0 + (lane >> 4)][16 J + (lane & 15)]
+// serves as A AND as B (the tile (I, J) is x_I' x_J), so a k-step costs T LDS reads.  Columns >= the logical width read the row's padding /
+// the next row: finite numbers that only reach tile entries nobody stores.  w: LDS weights per row (null: ones).  Optional second
+// operand set: `ns` columns idx2[0 .. ns) (idx2 null: columns 0 .. ns - 1) of the matrix Y ([yrows][SY], lane's ROW 16 J + (lane & 15), rows
+// beyond yrows read as zero) scaled by sqrt(s2): + s2 Y2 Y2'.
+// acc[4 tile + r] = entry (16 I + (lane >> 4) + 4 r, 16 J + (lane & 15)) of tile (I, J), tiles in row-major upper-triangle order.
+template <int T>
+__device__ __forceinline__ void nhqp_tile_gram(const double* X, int S, int m, const double* w, const double* Y, int SY, int yrows, const int* idx2, int ns, double s2,
+                                               int lane, double (&acc)[2 * T * (T + 1)]) {
+    const int q = lane >> 4, a = lane & 15;
+    v4f64 t[T * (T + 1) / 2];
+#pragma unroll
+    for (int u = 0; u < T * (T + 1) / 2; ++u) { t[u][0] = 0.0; t[u][1] = 0.0; t[u][2] = 0.0; t[u][3] = 0.0; }
+    for (int r0 = 0; r0 < m; r0 += 4) {
+        double x[T];
+#pragma unroll
+        for (int J = 0; J < T; ++J) x[J] = X[(r0 + q) * S + 16 * J + a];
+        const double wr = w ? w[r0 + q] : 1.0;
+        int u = 0;
+#pragma unroll
+        for (int I = 0; I < T; ++I) {
+            const double xa = wr * x[I];
+#pragma unroll
+            for (int J = I; J < T; ++J) { t[u] = mfma_f64_16x16x4(xa, x[J], t[u]); ++u; }
+        }
+    }
+    if (ns > 0) {
+        const double rs2 = sqrt(s2);
+        for (int t0 = 0; t0 < ns; t0 += 4) {
+            const bool live = t0 + q < ns;
+            const int tq = live ? t0 + q : 0;
+            const int ec = idx2 ? idx2[tq] : tq;
+            double y[T];
+#pragma unroll
+            for (int J = 0; J < T; ++J) {
+                const int yr = 16 * J + a;
+                const double v = Y[((yr < yrows) ? yr : 0) * SY + ec];
+                y[J] = (live && yr < yrows) ? rs2 * v : 0.0;
+            }
+            int u = 0;
+#pragma unroll
+            for (int I = 0; I < T; ++I)
+#pragma unroll
+                for (int J = I; J < T; ++J) { t[u] = mfma_f64_16x16x4(y[I], y[J], t[u]); ++u; }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < T * (T + 1) / 2; ++u) { acc[4 * u] = t[u][0]; acc[4 * u + 1] = t[u][1]; acc[4 * u + 2] = t[u][2]; acc[4 * u + 3] = t[u][3]; }
+}
+// the tiles of nhqp_tile_gram -> a symmetric k x k matrix with row stride ld (LDS or HBM), both triangles
+template <int T>
+__device__ __forceinline__ void nhqp_tile_store(const double (&acc)[2 * T * (T + 1)], double* M, int ld, int k, int lane) {
+    const int q = lane >> 4, a = lane & 15;
+    int u = 0;
+#pragma unroll
+    for (int I = 0; I < T; ++I)
+#pragma unroll
+        for (int J = I; J < T; ++J) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * I + q + 4 * r, j = 16 * J + a;
+                if (i < k && j < k) { M[i * ld + j] = acc[4 * u + r]; if (I != J) M[j * ld + i] = acc[4 * u + r]; }
+            }
+            ++u;
+        }
+}
+
+// H (k x k, row stride ld) = X'diag(w) X + s2 Y2 Y2' through the tile products above, T = ceil(k / 16) tiles a side
+__device__ __forceinline__ void nhqp_gram_to(double* M, int ld, int k, const double* X, int S, int m, const double* w,
+                                             const double* Y, int SY, int yrows, const int* idx2, int ns, double s2, int lane) {
+    const int T = uniform_i((k + 15) >> 4);
+    if (T <= 1) { double acc[4]; nhqp_tile_gram<1>(X, S, m, w, Y, SY, yrows, idx2, ns, s2, lane, acc); nhqp_tile_store<1>(acc, M, ld, k, lane); }
+    else if (T == 2) { double acc[12]; nhqp_tile_gram<2>(X, S, m, w, Y, SY, yrows, idx2, ns, s2, lane, acc); nhqp_tile_store<2>(acc, M, ld, k, lane); }
+    else if (T == 3) { double acc[24]; nhqp_tile_gram<3>(X, S, m, w, Y, SY, yrows, idx2, ns, s2, lane, acc); nhqp_tile_store<3>(acc, M, ld, k, lane); }
+    else { double acc[40]; nhqp_tile_gram<4>(X, S, m, w, Y, SY, yrows, idx2, ns, s2, lane, acc); nhqp_tile_store<4>(acc, M, ld, k, lane); }
+}
+
 constexpr int nhqp64_rows(int n) { return (n + 7) & ~7; }
 constexpr int nhqp64_stride(int n) { return nhqp64_rows(n) + 1; }
 inline size_t nhqp_prepare64_lds_bytes(int MR, int n) {
@@ -1509,6 +1587,10 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
         }
         if (c < nf) Q.g[inst * nf + c] = gacc;
         const bool sel = ns > 0 && Q.sel_reg;
+#ifndef OSOT_NHQP_H_VALU
+        // (round 5) on the matrix core: nhqp_tile_gram -- was two rows of H per trip through the vector unit, 36-58 k clocks a level
+        nhqp_gram_to(Hg, nf, nf, AN, S, m, vec, V2, v2s, nf, nullptr, sel ? ns : 0, sv_max, lane);
+#else
         for (int i0 = 0; i0 < nf; i0 += 2) {
             const int i1 = (i0 + 1 < nf) ? i0 + 1 : i0;
             double a0 = 0.0, a1 = 0.0;
@@ -1536,6 +1618,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
             }
             if (c < nf) { Hg[i0 * nf + c] = a0; if (i1 != i0) Hg[i1 * nf + c] = a1; }
         }
+#endif
     }
     NHQP_PHASE("Hg");
     if (Q.Wd) { wave_sync(); nhqp_dense_weight_correction(Q, inst, AN, S, b0, c); }
@@ -1695,68 +1778,6 @@ __device__ __forceinline__ void sym_eig_wide(double* G, double* V, double* vv, d
     wave_sync();
 }
 
-// X'diag(w) X of the LDS matrix X ([rows][S], zero rows beyond m up to the next multiple of four) on the fp64 matrix core: T x T tiles
-// of 16 x 16 (upper triangle), one v_mfma_f64_16x16x4 per tile per four rows of X; a lane's operand X[r0 + (lane >> 4)][16 J + (lane & 15)]
-// serves as A AND as B (the tile (I, J) is x_I' x_J), so a k-step costs T LDS reads.  Columns >= the logical width read the row's padding /
-// the next row: finite numbers that only reach tile entries nobody stores.  w: LDS weights per row (null: ones).  Optional second
-// operand set: `ns` columns idx2[0 .. ns) of the matrix Y ([.][S], lane's ROW 16 J + (lane & 15)) scaled by sqrt(s2): + s2 Y2 Y2'.
-// acc[4 tile + r] = entry (16 I + (lane >> 4) + 4 r, 16 J + (lane & 15)) of tile (I, J), tiles in row-major upper-triangle order.
-template <int T>
-__device__ __forceinline__ void nhqp_tile_gram(const double* X, int S, int m, const double* w, const double* Y, const int* idx2, int ns, double s2,
-                                               int lane, double (&acc)[2 * T * (T + 1)]) {
-    const int q = lane >> 4, a = lane & 15;
-    v4f64 t[T * (T + 1) / 2];
-#pragma unroll
-    for (int u = 0; u < T * (T + 1) / 2; ++u) { t[u][0] = 0.0; t[u][1] = 0.0; t[u][2] = 0.0; t[u][3] = 0.0; }
-    for (int r0 = 0; r0 < m; r0 += 4) {
-        double x[T];
-#pragma unroll
-        for (int J = 0; J < T; ++J) x[J] = X[(r0 + q) * S + 16 * J + a];
-        const double wr = w ? w[r0 + q] : 1.0;
-        int u = 0;
-#pragma unroll
-        for (int I = 0; I < T; ++I) {
-            const double xa = wr * x[I];
-#pragma unroll
-            for (int J = I; J < T; ++J) { t[u] = mfma_f64_16x16x4(xa, x[J], t[u]); ++u; }
-        }
-    }
-    if (ns > 0) {
-        const double rs2 = sqrt(s2);
-        for (int t0 = 0; t0 < ns; t0 += 4) {
-            const bool live = t0 + q < ns;
-            const int ec = idx2[live ? t0 + q : 0];
-            double y[T];
-#pragma unroll
-            for (int J = 0; J < T; ++J) { const double v = Y[(16 * J + a) * S + ec]; y[J] = live ? rs2 * v : 0.0; }
-            int u = 0;
-#pragma unroll
-            for (int I = 0; I < T; ++I)
-#pragma unroll
-                for (int J = I; J < T; ++J) { t[u] = mfma_f64_16x16x4(y[I], y[J], t[u]); ++u; }
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < T * (T + 1) / 2; ++u) { acc[4 * u] = t[u][0]; acc[4 * u + 1] = t[u][1]; acc[4 * u + 2] = t[u][2]; acc[4 * u + 3] = t[u][3]; }
-}
-// the tiles of nhqp_tile_gram -> a symmetric k x k matrix with row stride ld (LDS or HBM), both triangles
-template <int T>
-__device__ __forceinline__ void nhqp_tile_store(const double (&acc)[2 * T * (T + 1)], double* M, int ld, int k, int lane) {
-    const int q = lane >> 4, a = lane & 15;
-    int u = 0;
-#pragma unroll
-    for (int I = 0; I < T; ++I)
-#pragma unroll
-        for (int J = I; J < T; ++J) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * I + q + 4 * r, j = 16 * J + a;
-                if (i < k && j < k) { M[i * ld + j] = acc[4 * u + r]; if (I != J) M[j * ld + i] = acc[4 * u + r]; }
-            }
-            ++u;
-        }
-}
-
 inline size_t nhqp_prepare_wide_lds_bytes(int m, int n) {
     const size_t RN = (size_t)nhqp64_rows(n), S = RN + 1, RM = (size_t)nhqp64_rows(m > n ? m : n);
     return sizeof(double) * (2 * RM * S + RN * S + 5 * 64 + 2 * 32) + sizeof(int) * (64 + 2 * 32);
@@ -1856,8 +1877,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_wide_kernel(const DevNhq
     NHQP_PHASE("w:constr");
     // ---- G = (A N)'(A N) on the matrix core (nhqp_tile_gram: was eight rows of G per pass over A N through the vector unit, 53 k clocks
     // of a 670 k-clock level at S1), V = I
-    if (nf <= 48) { double acc[24]; nhqp_tile_gram<3>(AN, S, m, nullptr, nullptr, nullptr, 0, 0.0, lane, acc); nhqp_tile_store<3>(acc, G, S, nf, lane); }
-    else { double acc[40]; nhqp_tile_gram<4>(AN, S, m, nullptr, nullptr, nullptr, 0, 0.0, lane, acc); nhqp_tile_store<4>(acc, G, S, nf, lane); }
+    nhqp_gram_to(G, S, nf, AN, S, m, nullptr, nullptr, 0, 0, nullptr, 0, 0.0, lane);
     for (int e = lane; e < RN * S; e += 64) NV[e] = 0.0;
     wave_sync();
     if (lane < nf) NV[lane * S + lane] = 1.0;
@@ -2038,8 +2058,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_wide_kernel(const DevNhq
             if (lane < nf) Q.g[inst * nf + lane] = gacc;
             // H on the matrix core: rows of A N weighted by w, plus sv_max V2 V2' as extra k-steps (its columns scaled by sqrt(sv_max))
             const int nsel = sel ? ns : 0;
-            if (nf <= 48) { double acc[24]; nhqp_tile_gram<3>(AN, S, m, vec, NV, idx + (nf - ns), nsel, sv_max, lane, acc); nhqp_tile_store<3>(acc, Hg, nf, nf, lane); }
-            else { double acc[40]; nhqp_tile_gram<4>(AN, S, m, vec, NV, idx + (nf - ns), nsel, sv_max, lane, acc); nhqp_tile_store<4>(acc, Hg, nf, nf, lane); }
+            nhqp_gram_to(Hg, nf, nf, AN, S, m, vec, NV, S, RN, idx + (nf - ns), nsel, sv_max, lane);
         }
         if (Q.Wd) { wave_sync(); nhqp_dense_weight_correction(Q, inst, AN, S, b0, lane); }
         if (ns > 0 && Q.V2) {
