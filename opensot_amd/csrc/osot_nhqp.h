@@ -599,6 +599,84 @@ __device__ __forceinline__ void sym_eig32(double* K, double* E, int k_in, int c,
     sym_eig_finish_32(K, E, k, c, h, d);
 }
 
+// X'diag(w) X of the LDS matrix X ([rows][S], zero rows beyond m up to the next multiple of four) on the fp64 matrix core: T x T tiles
+// of 16 x 16 (upper triangle), one v_mfma_f64_16x16x4 per tile per four rows of X; a lane's operand X[r0 + (lane >> 4)][16 J + (lane & 15)]
+// serves as A AND as B (the tile (I, J) is x_I' x_J), so a k-step costs T LDS reads.  Columns >= the logical width read the row's padding /
+// the next row: finite numbers that only reach tile entries nobody stores.  w: LDS weights per row (null: ones).  Optional second
+// operand set: `ns` columns idx2[0 .. ns) (idx2 null: columns 0 .. ns - 1) of the matrix Y ([yrows][SY], lane's ROW 16 J + (lane & 15), rows
+// beyond yrows read as zero) scaled by sqrt(s2): + s2 Y2 Y2'.
+// acc[4 tile + r] = entry (16 I + (lane >> 4) + 4 r, 16 J + (lane & 15)) of tile (I, J), tiles in row-major upper-triangle order.
+template <int T>
+__device__ __forceinline__ void nhqp_tile_gram(const double* X, int S, int m, const double* w, const double* Y, int SY, int yrows, const int* idx2, int ns, double s2,
+                                               int lane, double (&acc)[2 * T * (T + 1)]) {
+    const int q = lane >> 4, a = lane & 15;
+    v4f64 t[T * (T + 1) / 2];
+#pragma unroll
+    for (int u = 0; u < T * (T + 1) / 2; ++u) { t[u][0] = 0.0; t[u][1] = 0.0; t[u][2] = 0.0; t[u][3] = 0.0; }
+    for (int r0 = 0; r0 < m; r0 += 4) {
+        double x[T];
+#pragma unroll
+        for (int J = 0; J < T; ++J) x[J] = X[(r0 + q) * S + 16 * J + a];
+        const double wr = w ? w[r0 + q] : 1.0;
+        int u = 0;
+#pragma unroll
+        for (int I = 0; I < T; ++I) {
+            const double xa = wr * x[I];
+#pragma unroll
+            for (int J = I; J < T; ++J) { t[u] = mfma_f64_16x16x4(xa, x[J], t[u]); ++u; }
+        }
+    }
+    if (ns > 0) {
+        const double rs2 = sqrt(s2);
+        for (int t0 = 0; t0 < ns; t0 += 4) {
+            const bool live = t0 + q < ns;
+            const int tq = live ? t0 + q : 0;
+            const int ec = idx2 ? idx2[tq] : tq;
+            double y[T];
+#pragma unroll
+            for (int J = 0; J < T; ++J) {
+                const int yr = 16 * J + a;
+                const double v = Y[((yr < yrows) ? yr : 0) * SY + ec];
+                y[J] = (live && yr < yrows) ? rs2 * v : 0.0;
+            }
+            int u = 0;
+#pragma unroll
+            for (int I = 0; I < T; ++I)
+#pragma unroll
+                for (int J = I; J < T; ++J) { t[u] = mfma_f64_16x16x4(y[I], y[J], t[u]); ++u; }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < T * (T + 1) / 2; ++u) { acc[4 * u] = t[u][0]; acc[4 * u + 1] = t[u][1]; acc[4 * u + 2] = t[u][2]; acc[4 * u + 3] = t[u][3]; }
+}
+// the tiles of nhqp_tile_gram -> a symmetric k x k matrix with row stride ld (LDS or HBM), both triangles
+template <int T>
+__device__ __forceinline__ void nhqp_tile_store(const double (&acc)[2 * T * (T + 1)], double* M, int ld, int k, int lane) {
+    const int q = lane >> 4, a = lane & 15;
+    int u = 0;
+#pragma unroll
+    for (int I = 0; I < T; ++I)
+#pragma unroll
+        for (int J = I; J < T; ++J) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * I + q + 4 * r, j = 16 * J + a;
+                if (i < k && j < k) { M[i * ld + j] = acc[4 * u + r]; if (I != J) M[j * ld + i] = acc[4 * u + r]; }
+            }
+            ++u;
+        }
+}
+
+// H (k x k, row stride ld) = X'diag(w) X + s2 Y2 Y2' through the tile products above, T = ceil(k / 16) tiles a side
+__device__ __forceinline__ void nhqp_gram_to(double* M, int ld, int k, const double* X, int S, int m, const double* w,
+                                             const double* Y, int SY, int yrows, const int* idx2, int ns, double s2, int lane) {
+    const int T = uniform_i((k + 15) >> 4);
+    if (T <= 1) { double acc[4]; nhqp_tile_gram<1>(X, S, m, w, Y, SY, yrows, idx2, ns, s2, lane, acc); nhqp_tile_store<1>(acc, M, ld, k, lane); }
+    else if (T == 2) { double acc[12]; nhqp_tile_gram<2>(X, S, m, w, Y, SY, yrows, idx2, ns, s2, lane, acc); nhqp_tile_store<2>(acc, M, ld, k, lane); }
+    else if (T == 3) { double acc[24]; nhqp_tile_gram<3>(X, S, m, w, Y, SY, yrows, idx2, ns, s2, lane, acc); nhqp_tile_store<3>(acc, M, ld, k, lane); }
+    else { double acc[40]; nhqp_tile_gram<4>(X, S, m, w, Y, SY, yrows, idx2, ns, s2, lane, acc); nhqp_tile_store<4>(acc, M, ld, k, lane); }
+}
+
 // MR = row capacity of A N (32 or 64).  LDS: three 32 x 33 work matrices + A N = 25.3 KB (MR = 32: six wavefronts per CU;
 // the first version held five matrices and a 64-row A N, 50 KB, three per CU).  The buffers are re-used as the level goes:
 //   NE : N (until the constraints are written, right after A N)  ->  eigenvectors E  ->  V2 on the row side
@@ -1011,6 +1089,9 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
         gacc = halfsum<32>(gacc);
         if (h == 0 && c < nf) Q.g[inst * nf + c] = gacc;
         const bool sel = ns > 0 && Q.sel_reg;
+#ifndef OSOT_NHQP_H_VALU
+        nhqp_gram_to(Hg, nf, nf, AN, kNS, m, vec, V2, kNS, nf, nullptr, sel ? ns : 0, sv_max, lane);     // (round 5: on the matrix core)
+#else
         double v2c[16];                             // my row of V2 (zero beyond ns)
 #pragma unroll
         for (int t = 0; t < 16; ++t) { const double v = V2[cc * kNS + 2 * t + h]; v2c[t] = (sel && 2 * t + h < ns) ? sv_max * v : 0.0; }
@@ -1042,6 +1123,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
             const double acc0 = halfsum<32>(a0 + a1), acc1 = halfsum<32>(c0 + c1);
             if (h == 0 && c < nf) { Hg[i0 * nf + c] = acc0; if (i1 != i0) Hg[i1 * nf + c] = acc1; }
         }
+#endif
     }
     NHQP_PHASE("Hg");
     if (Q.Wd) { wave_sync(); nhqp_dense_weight_correction(Q, inst, AN, kNS, b0, (h == 0) ? c : -1); }
@@ -1062,84 +1144,6 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
 // in chunks of 8 with the reads of a chunk in flight together; the padding is zero), odd row stride RN + 1.  With the fixed 64 x 65
 // layout of the first version the COMAN35 plans held 71 KB per wavefront -- two wavefronts per CU, and this kernel is bound by the
 // latency of one wavefront's instruction stream; at n = 35 it is 38 KB, four per CU.
-// X'diag(w) X of the LDS matrix X ([rows][S], zero rows beyond m up to the next multiple of four) on the fp64 matrix core: T x T tiles
-// of 16 x 16 (upper triangle), one v_mfma_f64_16x16x4 per tile per four rows of X; a lane's operand X[r0 + (lane >> 4)][16 J + (lane & 15)]
-// serves as A AND as B (the tile (I, J) is x_I' x_J), so a k-step costs T LDS reads.  Columns >= the logical width read the row's padding /
-// the next row: finite numbers that only reach tile entries nobody stores.  w: LDS weights per row (null: ones).  Optional second
-// operand set: `ns` columns idx2[0 .. ns) (idx2 null: columns 0 .. ns - 1) of the matrix Y ([yrows][SY], lane's ROW 16 J + (lane & 15), rows
-// beyond yrows read as zero) scaled by sqrt(s2): + s2 Y2 Y2'.
-// acc[4 tile + r] = entry (16 I + (lane >> 4) + 4 r, 16 J + (lane & 15)) of tile (I, J), tiles in row-major upper-triangle order.
-template <int T>
-__device__ __forceinline__ void nhqp_tile_gram(const double* X, int S, int m, const double* w, const double* Y, int SY, int yrows, const int* idx2, int ns, double s2,
-                                               int lane, double (&acc)[2 * T * (T + 1)]) {
-    const int q = lane >> 4, a = lane & 15;
-    v4f64 t[T * (T + 1) / 2];
-#pragma unroll
-    for (int u = 0; u < T * (T + 1) / 2; ++u) { t[u][0] = 0.0; t[u][1] = 0.0; t[u][2] = 0.0; t[u][3] = 0.0; }
-    for (int r0 = 0; r0 < m; r0 += 4) {
-        double x[T];
-#pragma unroll
-        for (int J = 0; J < T; ++J) x[J] = X[(r0 + q) * S + 16 * J + a];
-        const double wr = w ? w[r0 + q] : 1.0;
-        int u = 0;
-#pragma unroll
-        for (int I = 0; I < T; ++I) {
-            const double xa = wr * x[I];
-#pragma unroll
-            for (int J = I; J < T; ++J) { t[u] = mfma_f64_16x16x4(xa, x[J], t[u]); ++u; }
-        }
-    }
-    if (ns > 0) {
-        const double rs2 = sqrt(s2);
-        for (int t0 = 0; t0 < ns; t0 += 4) {
-            const bool live = t0 + q < ns;
-            const int tq = live ? t0 + q : 0;
-            const int ec = idx2 ? idx2[tq] : tq;
-            double y[T];
-#pragma unroll
-            for (int J = 0; J < T; ++J) {
-                const int yr = 16 * J + a;
-                const double v = Y[((yr < yrows) ? yr : 0) * SY + ec];
-                y[J] = (live && yr < yrows) ? rs2 * v : 0.0;
-            }
-            int u = 0;
-#pragma unroll
-            for (int I = 0; I < T; ++I)
-#pragma unroll
-                for (int J = I; J < T; ++J) { t[u] = mfma_f64_16x16x4(y[I], y[J], t[u]); ++u; }
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < T * (T + 1) / 2; ++u) { acc[4 * u] = t[u][0]; acc[4 * u + 1] = t[u][1]; acc[4 * u + 2] = t[u][2]; acc[4 * u + 3] = t[u][3]; }
-}
-// the tiles of nhqp_tile_gram -> a symmetric k x k matrix with row stride ld (LDS or HBM), both triangles
-template <int T>
-__device__ __forceinline__ void nhqp_tile_store(const double (&acc)[2 * T * (T + 1)], double* M, int ld, int k, int lane) {
-    const int q = lane >> 4, a = lane & 15;
-    int u = 0;
-#pragma unroll
-    for (int I = 0; I < T; ++I)
-#pragma unroll
-        for (int J = I; J < T; ++J) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * I + q + 4 * r, j = 16 * J + a;
-                if (i < k && j < k) { M[i * ld + j] = acc[4 * u + r]; if (I != J) M[j * ld + i] = acc[4 * u + r]; }
-            }
-            ++u;
-        }
-}
-
-// H (k x k, row stride ld) = X'diag(w) X + s2 Y2 Y2' through the tile products above, T = ceil(k / 16) tiles a side
-__device__ __forceinline__ void nhqp_gram_to(double* M, int ld, int k, const double* X, int S, int m, const double* w,
-                                             const double* Y, int SY, int yrows, const int* idx2, int ns, double s2, int lane) {
-    const int T = uniform_i((k + 15) >> 4);
-    if (T <= 1) { double acc[4]; nhqp_tile_gram<1>(X, S, m, w, Y, SY, yrows, idx2, ns, s2, lane, acc); nhqp_tile_store<1>(acc, M, ld, k, lane); }
-    else if (T == 2) { double acc[12]; nhqp_tile_gram<2>(X, S, m, w, Y, SY, yrows, idx2, ns, s2, lane, acc); nhqp_tile_store<2>(acc, M, ld, k, lane); }
-    else if (T == 3) { double acc[24]; nhqp_tile_gram<3>(X, S, m, w, Y, SY, yrows, idx2, ns, s2, lane, acc); nhqp_tile_store<3>(acc, M, ld, k, lane); }
-    else { double acc[40]; nhqp_tile_gram<4>(X, S, m, w, Y, SY, yrows, idx2, ns, s2, lane, acc); nhqp_tile_store<4>(acc, M, ld, k, lane); }
-}
-
 constexpr int nhqp64_rows(int n) { return (n + 7) & ~7; }
 constexpr int nhqp64_stride(int n) { return nhqp64_rows(n) + 1; }
 inline size_t nhqp_prepare64_lds_bytes(int MR, int n) {
@@ -2080,6 +2084,48 @@ struct DevNhqpAcc {
     double* dq;            // [B][n] written at the last level
 };
 
+// Nn (n x ns, row stride n) = Ng (n x nf) Vg (nf x ns), all three in HBM with row stride n: 16 x 16 tiles, MB row blocks held at once,
+// one column block after the other; a lane's operands are Ng[16 I + (lane & 15)][k0 + (lane >> 4)] and Vg[k0 + (lane >> 4)][16 J + (lane & 15)]
+// (addresses clamped into the instance's block; the inner index masked beyond nf; rows / columns beyond n / ns are not stored).
+template <int MB>
+__device__ __forceinline__ void acc_tile_product(const double* Ng, const double* Vg, double* Nn, int n, int nf, int ns, int lane) {
+    const int q = lane >> 4, a = lane & 15;
+    for (int J = 0; 16 * J < ns; ++J) {
+        v4f64 t[MB];
+#pragma unroll
+        for (int I = 0; I < MB; ++I) { t[I][0] = 0.0; t[I][1] = 0.0; t[I][2] = 0.0; t[I][3] = 0.0; }
+        const int col = 16 * J + a, colc = (col < ns) ? col : ns - 1;
+        for (int k0 = 0; k0 < nf; k0 += 8) {            // two k-steps per trip: 2 (MB + 1) loads in flight
+            double xa[2][MB], xb[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = k0 + 4 * u + q;
+                const bool live = k < nf;
+                const int kc = live ? k : 0;
+                const double vb = Vg[kc * n + colc];
+                xb[u] = live ? vb : 0.0;
+#pragma unroll
+                for (int I = 0; I < MB; ++I) {
+                    const int row = 16 * I + a;
+                    const double va = Ng[((row < n) ? row : n - 1) * n + kc];
+                    xa[u][I] = live ? va : 0.0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int I = 0; I < MB; ++I) t[I] = mfma_f64_16x16x4(xa[u][I], xb[u], t[I]);
+        }
+#pragma unroll
+        for (int I = 0; I < MB; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * I + q + 4 * r;
+                if (i < n && col < ns) Nn[i * n + col] = t[I][r];
+            }
+    }
+}
+
 // solution += N z;  N <- N V2  (nHQP.cpp:182-196).  n <= 32: lane = c + 32 h (the halves split the sum); 32 < n <= 64: lane = row
 __global__ void __launch_bounds__(64) osot_nhqp_accumulate_kernel(const DevNhqpAcc Q) {
     const long long inst = blockIdx.x;
@@ -2118,8 +2164,19 @@ __global__ void __launch_bounds__(64) osot_nhqp_accumulate_kernel(const DevNhqpA
     if (!Q.last && ns > 0) {
         const double* Vg = Q.V2 + inst * (long long)n * n;
         double* Nn = Q.Nnext + inst * (long long)n * n;
-        // N V2 (n x ns): one entry per lane, the n ns entries spread over all 64 lanes (with lane = column only ns of them
-        // worked: five at the second level of the benchmark stack)
+        // N V2 (n x ns).  Levels below the first: on the fp64 matrix core, operands straight from HBM / L2 (round 5: acc_tile_product --
+        // one entry per lane through the vector unit issued 2 nf gathered loads per entry, 1400 per lane on the 35-coordinate COMAN;
+        // OSOT_NHQP_ACC_VALU keeps that form for A/B).  First level (N = I): the rows of V2 are copied.
+#ifndef OSOT_NHQP_ACC_VALU
+        if (!Q.first) {
+            const int MB = uniform_i((n + 15) >> 4);
+            if (MB <= 1) acc_tile_product<1>(Ng, Vg, Nn, n, nf, ns, lane);
+            else if (MB == 2) acc_tile_product<2>(Ng, Vg, Nn, n, nf, ns, lane);
+            else if (MB == 3) acc_tile_product<3>(Ng, Vg, Nn, n, nf, ns, lane);
+            else acc_tile_product<4>(Ng, Vg, Nn, n, nf, ns, lane);
+            return;
+        }
+#endif
         for (int e = lane; e < n * ns; e += 64) {
             const int i = e / ns, t = e - i * ns;
             double a2 = 0.0;
