@@ -1978,6 +1978,101 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_wide_kernel(const DevNhq
         wave_sync();
         // U[:, i] = A N v_i / |A N v_i| where the triplet is genuine; a null triplet's u_i completes the basis: the first unit
         // vector with a usable component outside the span of the u's found so far (modified Gram-Schmidt, lane = row)
+#ifndef OSOT_NHQP_WIDE_U_VALU
+        // (round 5) all genuine triplets at once: T = A N V on the fp64 matrix core with the columns of V gathered in singular-value
+        // order (column j of T belongs to idx[j]), then lane = triplet for the norms, u_j'b0, the scaling and the lifting rule; the
+        // null triplets (none on a full-rank level) are completed one by one afterwards as before.  Was one triplet after the other:
+        // a matrix - vector product, two wave reductions, a square root and a division each, 3.1 k clocks x 35 at S1.
+        {
+            const int q4 = lane >> 4, a16 = lane & 15;
+            for (int J = 0; 16 * J < ksv; ++J) {
+                const int pos = 16 * J + a16;
+                const int ec = idx[(pos < nf) ? pos : 0];
+                v4f64 t[4];
+#pragma unroll
+                for (int I = 0; I < 4; ++I) { t[I][0] = 0.0; t[I][1] = 0.0; t[I][2] = 0.0; t[I][3] = 0.0; }
+                for (int k0 = 0; k0 < nf; k0 += 4) {
+                    const double xb = NV[(k0 + q4) * S + ec];
+                    double xa[4];
+#pragma unroll
+                    for (int I = 0; I < 4; ++I) { const int row = 16 * I + a16; xa[I] = AN[((row < RM) ? row : 0) * S + k0 + q4]; }
+#pragma unroll
+                    for (int I = 0; I < 4; ++I) t[I] = mfma_f64_16x16x4(xa[I], xb, t[I]);
+                }
+#pragma unroll
+                for (int I = 0; I < 4; ++I)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * I + q4 + 4 * r;
+                        if (row < m && pos < ksv) U[row * S + pos] = t[I][r];
+                    }
+            }
+        }
+        wave_sync();
+        unsigned long long done;
+        {
+            const int j = (lane < ksv) ? lane : 0;
+            double n0 = 0.0, n1 = 0.0, d0 = 0.0, d1 = 0.0;
+            for (int r = 0; r < m; r += 8) {            // (rows of U beyond m are zero, b0 too)
+                double u8[8], b8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { u8[q] = U[(r + q) * S + j]; b8[q] = b0[(r + q) & 63]; }
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) {
+                    n0 = fma(u8[q], u8[q], n0); n1 = fma(u8[q + 1], u8[q + 1], n1);
+                    d0 = fma(u8[q], b8[q], d0); d1 = fma(u8[q + 1], b8[q + 1], d1);
+                }
+            }
+            const double nrm2 = n0 + n1, sv = sig[j];
+            const bool genuine = lane < ksv && sv >= kSvNoise * sv_max && sv > 0.0 && nrm2 > 0.0;
+            const double scale = genuine ? 1.0 / sqrt(nrm2) : 0.0;
+            const double dotb = (d0 + d1) * scale;
+            for (int r = 0; r < m; r += 8) {            // u_j = T[:, j] / |T[:, j]|  (a null triplet's column: zeros until it is completed below)
+                double u8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) u8[q] = U[(r + q) * S + j];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (lane < ksv && r + q < m) U[(r + q) * S + j] = scale * u8[q];
+            }
+            const bool lift = sv < Q.thr * sv_max;
+            double d = 1.0, svn = sv;
+            if (lift) { d = sv / (Q.thr * sv_max); svn = (Q.thr * sv_max) * (Q.thr * sv_max) / (sv + Q.thr / 100.0); }
+            if (genuine) { ub[lane] = d * dotb; dl[lane] = lift ? svn - sv : 0.0; }
+            done = wave_ballot(genuine);
+        }
+        wave_sync();
+        int next_unit = 0;
+        for (int i = 0; i < ksv; ++i) {
+            if ((done >> i) & 1ull) continue;
+            // a null triplet's u_i completes the basis: the first unit vector with a usable component outside the span of the u's so far
+            double u = 0.0;
+            bool have = false;
+            while (!have && next_unit < m) {
+                u = (lane == next_unit) ? 1.0 : 0.0;
+                next_unit++;
+                for (int pass = 0; pass < 2; ++pass)
+                    for (int j = 0; j < ksv; ++j) {
+                        if (!((done >> j) & 1ull)) continue;
+                        const double uj = (lane < m) ? U[lane * S + j] : 0.0;
+                        const double dot = uniform_d(colsum<64>(uj * u));
+                        u = fma(-dot, uj, u);
+                    }
+                const double nrm2 = uniform_d(colsum<64>(u * u));
+                if (nrm2 > 0.25) { u = u / sqrt(nrm2); have = true; }
+            }
+            if (!have) u = 0.0;
+            wave_sync();
+            if (lane < m) U[lane * S + i] = u;
+            const double dotb = uniform_d(colsum<64>((lane < m) ? u * b0[lane] : 0.0));
+            const double sv = sig[i];
+            const bool lift = sv < Q.thr * sv_max;
+            double d = 1.0, svn = sv;
+            if (lift) { d = sv / (Q.thr * sv_max); svn = (Q.thr * sv_max) * (Q.thr * sv_max) / (sv + Q.thr / 100.0); }
+            if (lane == 0) { ub[i] = d * dotb; dl[i] = lift ? svn - sv : 0.0; }
+            done |= 1ull << i;
+            wave_sync();
+        }
+#else
         int next_unit = 0;
         for (int i = 0; i < ksv; ++i) {
             const int ec = idx[i];
@@ -2022,6 +2117,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_wide_kernel(const DevNhq
             if (lane == 0) { ub[i] = d * dotb; dl[i] = lift ? svn - sv : 0.0; }
             wave_sync();
         }
+#endif
         // b0 <- sum_i d_i (u_i'b0) u_i  (U diag(d) U'b0 with b0_rot(i) = 0 beyond the ksv singular values)
         if (lane < m) {
             double v = 0.0;

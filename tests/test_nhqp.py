@@ -234,6 +234,43 @@ def test_rank_deficient_level_emulated(wide, oracle):
         assert np.abs(dq - dq_off).max() < 1e-4
 
 
+def _duplicated_row_wide_level(oracle):
+    """a level beyond 32 on both sides (40 rows in 48 variables: osot_nhqp_prepare_wide_kernel) whose row 3 duplicates row 0: rank 39 of
+    40, ONE null triplet -- the Gram-Schmidt completion behind the batched genuine triplets of the wide preparation"""
+    from oracle import pynhqp
+    plan, leaf = synth.make_generic_stack(4, 48, [40], n_eq=0, n_ineq=0, seed=7, box=0.4, postural_last=False)
+    asm = oracle.assemble(plan, leaf)
+    fv = pynhqp.free_variables(asm)
+    asm["A"][0][:, 3, :] = asm["A"][0][:, 0, :]
+    asm["b"][0][:, 3] = asm["b"][0][:, 0]
+    return plan, asm, fv
+
+
+def test_rank_deficient_wide_level_emulated(oracle):
+    from oracle import pynhqp
+    plan, asm, fv = _duplicated_row_wide_level(oracle)
+    ref = pynhqp.nhqp_solve(asm, backend="qpoases" if oracle.ref_available() else "eiqp", termination_tolerance=10 * 2.221e-16,
+                            free_vars=fv)
+    dq, st = emu_nhqp(plan, asm, free_vars=fv)
+    _check_rank_deficient_level(asm, dq, st, ref)
+
+
+@pytest.mark.gpu
+def test_rank_deficient_wide_level_gpu(oracle, gpu_device):
+    import torch
+    from oracle import pynhqp
+    from opensot_amd.solver import BatchedStack
+    plan, asm, fv = _duplicated_row_wide_level(oracle)
+    B = asm["B"]
+    st = BatchedStack(plan, B, device=0)
+    st.load_assembled(asm)
+    st.solve_nhqp(B, free_vars=fv, min_sv_ratio=pynhqp.DEFAULT_MIN_SV_RATIO)
+    torch.cuda.synchronize()
+    ref = pynhqp.nhqp_solve(asm, backend="qpoases" if oracle.ref_available() else "eiqp", termination_tolerance=10 * 2.221e-16,
+                            free_vars=fv)
+    _check_rank_deficient_level(asm, st.dq[:B].cpu().numpy(), st.status[:B].cpu().numpy(), ref)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("wide", [False, True])
 def test_rank_deficient_level_gpu(wide, oracle, gpu_device):
