@@ -385,7 +385,7 @@ int osot_solver_profile_phases(osot_solver* s, const osot_qp_batch* batch, long 
  * solved in the nf free coordinates (bounds become rows N z, compute_contraints :282-317) and q += N z, N <- N V2.  Three
  * launches per level (prepare, the batched QP kernel, accumulate).  n <= 64 (a level with min(rows, free variables) <= 32 goes
  * through a 32-wide eigen-decomposition; round 5: the others -- the reference's one-level stack S1, 50 rows in 35 variables --
- * through a Jacobi iteration on the full Gram matrix), <= 64 rows per level, inactive tasks as zero rows and non-diagonal weights through level_W
+ * through tridiagonalisation + QL on the full column-side Gram matrix), <= 64 rows per level, inactive tasks as zero rows and non-diagonal weights through level_W
  * (round 5), global rows and the box only (the reference refuses task-local constraints, nHQP.cpp:41-44). */
 typedef struct {
     int free_vars[OSOT_MAX_LEVELS];      /* free variables of each level.  The reference fixes them in its constructor from the

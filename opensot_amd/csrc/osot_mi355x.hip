@@ -433,7 +433,7 @@ int osot_nhqp_solve(osot_solver* s, const osot_qp_batch* b, const osot_nhqp_opti
     const char* why = "";
     int rc = nhqp_run(pl, b, opt, s->nhqp,
         [&](const DevNhqp& Q) {
-            if (nhqp_level_is_wide(Q.m, Q.nf))      // min(rows, free variables) > 32: the Jacobi route on the full Gram matrix
+            if (nhqp_level_is_wide(Q.m, Q.nf))      // min(rows, free variables) > 32: the full column-side Gram matrix (sym_eig_wide)
                 hipLaunchKernelGGL(osot_nhqp_prepare_wide_kernel, dim3(grid), dim3(64), nhqp_prepare_wide_lds_bytes(Q.m, Q.n), st, Q);
             else if (Q.n > 32) {     // 33 .. 64 variables: the 64-column kernel (dynamic LDS beyond the 64 KB default: raised once, below)
                 if (Q.m <= 32) hipLaunchKernelGGL(osot_nhqp_prepare64_kernel<32>, dim3(grid), dim3(64), nhqp_prepare64_lds_bytes(32, Q.n), st, Q);

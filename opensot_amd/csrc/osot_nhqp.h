@@ -1642,13 +1642,13 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
 // ---------------------------------------------------------------------------------------------------------------------
 // Round 5: the level preparation for levels whose SMALL side exceeds 32 (min(rows, free variables) > 32, n <= 64): the reference's
 // own stack S1 -- (0.1 l_wrist + r_wrist + com + 1e-4 postural) on the 35-coordinate COMAN, one level of 50 rows
-// (examples/cpp/coman_ik.cpp:425-431) -- was refused until now.  A plain kernel, not a tuned one: lane = column / row, every loop
+// (examples/cpp/coman_ik.cpp:425-431) -- was refused until now.  Lane = column / row, every loop
 // generic in n and m; what it does differently from the two kernels above is the decomposition --
 //   * always the COLUMN-side Gram matrix G = (A N)'(A N) (nf x nf): its eigenvectors are ALL of V, the null space of A N included
 //     (no Householder completion), whatever the rank;
-//   * a parallel cyclic Jacobi iteration (round-robin pairs, row phase with lane = column, column phase with lane = row) instead of
-//     tridiagonalisation + bisection: ~8 sweeps of nf - 1 rounds, slower than the 32-wide route by a small factor and three
-//     wavefronts per CU, but orthonormal to round-off at any rank and 60 lines;
+//   * Householder tridiagonalisation + implicit QL over all 64 lanes (sym_eig_wide) -- until late in round 5 a parallel cyclic Jacobi
+//     iteration (kept under OSOT_NHQP_WIDE_JACOBI): ~280 rounds of 2 x 18 dependent LDS hand-offs, 93 % of a 7.4 ms launch at S1;
+//     the Gram matrix, H and the triplets' u = A N v on the fp64 matrix core (nhqp_tile_gram; T = A N V in one go);
 //   * U = A N V Sigma^-1 explicitly for the min(m, nf) triplets (null triplets: completed by Gram-Schmidt of unit vectors), so that
 //     regularize_A_b is the reference's own formula, b0 <- U diag(d) U'b0, A N <- A N + sum (sv' - sv) u v' (nHQP.cpp:236-279).
 // LDS (dynamic, nhqp_prepare_wide_lds_bytes): A N [RM][S], N -> V [RN][S], G -> U [RM][S], S = RN + 1, RN = n rounded up to 8,

@@ -11,18 +11,23 @@ from oracle import pyoracle as oracle, pyehqp, pynhqp
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+WIDE = len(sys.argv) > 3 and sys.argv[3] == "wide"      # every stack with a level beyond 32 on both sides (osot_nhqp_prepare_wide_kernel)
 B = 24
 bad = 0
 worst_e = worst_n = 0.0
 n_nhqp = 0
 for it in range(N):
     n = int(rng.integers(2, 33)) if rng.integers(0, 4) else int(rng.integers(33, 65))      # (a quarter of the stacks beyond 32 variables: the 64-lane / 64-column kernels)
+    if WIDE:
+        n = int(rng.integers(34, 65))
     L = int(rng.integers(1, 4))
     rows, left = [], n
     for k in range(L):
         if left <= 1:
             break
         m = int(rng.integers(1, max(2, min(left, 24))))
+        if WIDE and k == 0:
+            m = int(rng.integers(33, 65))          # 33 .. 64 rows in 34 .. 64 variables; the levels below work in what is left
         rows.append(m); left -= m
     postural = bool(rng.integers(0, 2)) or left <= 0
     seed = int(rng.integers(1 << 30))
