@@ -75,7 +75,7 @@ def test_generic_task_sum_to_one(gpu_device):
     assert abs(qp.getSolution().sum() - 1.0) < 1e-9
 
 
-@pytest.mark.parametrize("n,nc,n_eq,B", [(7, 5, 2, 33), (32, 24, 8, 257), (50, 60, 6, 64), (64, 16, 4, 31)])
+@pytest.mark.parametrize("n,nc,n_eq,B", [(7, 5, 2, 33), (32, 24, 8, 257), (35, 12, 3, 48), (50, 60, 6, 64), (64, 16, 4, 31)])
 def test_qp_solve_batch_random(n, nc, n_eq, B, oracle, gpu_device):
     """B generic QPs of one shape through osot_qp_solve_batch (incl. the 64-lane team path, n > 32)"""
     rng = np.random.default_rng(n + nc)
@@ -156,12 +156,12 @@ def test_backend_options(gpu_device):
     assert not qp.setOptions({"max_iterations": -1})
 
 
-def test_solve_hot_starts_from_the_previous_working_set(gpu_device):
+@pytest.mark.parametrize("n,nc", [(24, 10), (36, 12), (50, 14)])     # osot_qp_kernel<32 / 40 / 56, HOT> (the 40- and 56-lane layouts: round 5)
+def test_solve_hot_starts_from_the_previous_working_set(n, nc, gpu_device):
     """QPOasesBackEnd::solve hot-starts every call (QPOasesBackEnd.cpp:258-285): a repeated solve() of the same problem re-adds the
     previous working set without scans (never more iterations than the cold solve, the same x), a drifted g still lands on the
     cold answer, and initProblem / a changed row count forget the set (QPOasesBackEnd.cpp:229-244)"""
     rng = np.random.default_rng(31)
-    n, nc = 24, 10
     H, g, A, lA, uA, l, u = [a[0] if a is not None else None for a in random_qp(rng, 1, n, nc, box=True, scale=1.0)]
     g = g * 4.0                                                   # push the minimiser well outside the box: many active bounds
     qp = BackEnd(n, nc, abi.HST_SEMIDEF, 1e6)
