@@ -5,10 +5,14 @@
 //
 //   osot_nhqp_prepare_kernel ..... compute_cost + compute_contraints (nHQP.cpp:357-390, 236-279, 282-317) of one level:
 //                                  H, g, constraint rows / bounds in z-coordinates and V2 -> per-instance scratch in HBM
-//   osot_qp_kernel<32> ........... the level's QP (BackEnd convention)
+//   osot_nhqp_prepare64_kernel ... the same for 33 .. 64 variables (round 4); osot_nhqp_prepare_wide_kernel: levels beyond 32 on BOTH
+//                                  sides (round 5: the reference's one-level COMAN stack S1)
+//   osot_qp_kernel<NP> ........... the level's QP (BackEnd convention; NP = 32 / 40 / 56 / 64 by its free variables)
 //   osot_nhqp_accumulate_kernel .. solution += N z; N <- N V2 (nHQP.cpp:182-196)
+// Round 5: the GEMM-shaped pieces -- Gram matrix, H = AN'W AN + sv_max V2 V2', the triplets' A N V, N V2 -- run on the fp64 matrix
+// core (nhqp_tile_gram, acc_tile_product); the eigen-decompositions and the Householder completions stay on the vector unit.
 //
-// One wavefront per instance, lane = c + 32 h like the QP core; n <= 32, m <= 64 rows per level.
+// One wavefront per instance, lane = c + 32 h like the QP core (the 32-wide kernel: n <= 32, m <= 64 rows per level).
 // The SVD: AN is m x nf with k = min(m, nf) <= 32.  The SYMMETRIC eigenproblem of the SMALL Gram matrix (AN AN' when
 // m <= nf, AN'AN otherwise) is solved in LDS by Householder tridiagonalisation + implicit QL (sym_eig32 below) and the other
 // factor follows from one product with AN.  Squaring
