@@ -681,6 +681,42 @@ __device__ __forceinline__ void nhqp_gram_to(double* M, int ld, int k, const dou
     else { double acc[40]; nhqp_tile_gram<4>(X, S, m, w, Y, SY, yrows, idx2, ns, s2, lane, acc); nhqp_tile_store<4>(acc, M, ld, k, lane); }
 }
 
+// Sixteen rows 16 I .. 16 I + 15 of a row-major HBM matrix M (ld n, `rows` of them) against the LDS matrix Nl (n x nf, stride S, zero rows
+// beyond n) on the fp64 matrix core: t[J] = tile (I, J) of M Nl.  With q0v (LDS, n entries, zero beyond) the product's column nf is M q0
+// (the B operand of that one column comes from q0v instead of Nl: needs nf < 16 T).  A lane's A operand M[16 I + (lane & 15)][k0 + (lane >> 4)]
+// is loaded straight from HBM / L2 (clamped, masked), its B operands Nl[k0 + (lane >> 4)][16 J + (lane & 15)] from LDS.
+template <int T>
+__device__ __forceinline__ void nhqp_rows16_times_N(const double* M, int rows, int n, const double* Nl, int S, int nf, const double* q0v,
+                                                    int I, int lane, v4f64 (&t)[T]) {
+    const int q = lane >> 4, a = lane & 15;
+#pragma unroll
+    for (int J = 0; J < T; ++J) { t[J][0] = 0.0; t[J][1] = 0.0; t[J][2] = 0.0; t[J][3] = 0.0; }
+    const int row = 16 * I + a;
+    const double* Mr = M + (long long)((row < rows) ? row : rows - 1) * n;
+    for (int k0 = 0; k0 < n; k0 += 8) {             // two k-steps per trip: 2 HBM + 2 T LDS reads in flight
+        double xa[2], xb[2][T];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = k0 + 4 * u + q;
+            const bool live = k < n && row < rows;
+            const double va = Mr[(k < n) ? k : n - 1];
+            xa[u] = live ? va : 0.0;
+            const int kc = (k < n) ? k : 0;
+#pragma unroll
+            for (int J = 0; J < T; ++J) {
+                const int col = 16 * J + a;
+                const double vb = Nl[kc * S + ((col < S) ? col : 0)];
+                const double vq = q0v ? q0v[kc] : 0.0;
+                xb[u][J] = (k < n) ? ((q0v && col == nf) ? vq : vb) : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int J = 0; J < T; ++J) t[J] = mfma_f64_16x16x4(xa[u], xb[u][J], t[J]);
+    }
+}
+
 // MR = row capacity of A N (32 or 64).  LDS: three 32 x 33 work matrices + A N = 25.3 KB (MR = 32: six wavefronts per CU;
 // the first version held five matrices and a 64-row A N, 50 KB, three per CU).  The buffers are re-used as the level goes:
 //   NE : N (until the constraints are written, right after A N)  ->  eigenvectors E  ->  V2 on the row side
@@ -1229,7 +1265,39 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
 #pragma unroll
         for (int u = 0; u < 8; ++u) mq[u] = first ? 0.0 : (q0col ? bcast(acc8[u], 63) : colsum<64>(a8[u] * vec[lane]));
     };
+    // (round 5) the same products on the fp64 matrix core, sixteen rows at a time (nhqp_rows16_times_N: the A operand straight from HBM / L2,
+    // M q0 as column nf of the product -- which needs a spare tile column: nf < 64 below the first level; OSOT_NHQP_ROWS8 keeps the staged form)
+#ifndef OSOT_NHQP_ROWS8
+    const bool use_tiles = first || nf < 64;
+#else
+    const bool use_tiles = false;
+#endif
+    const int Tt = uniform_i((nf + (first ? 0 : 1) + 15) >> 4);
+    auto rows16_times_N = [&](const double* M, int rows, int I, auto&& sink) {      // sink(row, col, value) for every entry of the 16 x 16 T tiles
+        auto run = [&](auto tc) {
+            constexpr int T = decltype(tc)::value;
+            v4f64 t[T];
+            nhqp_rows16_times_N<T>(M, rows, n, Nl, S, nf, first ? nullptr : vec, I, lane, t);
+            const int q4 = lane >> 4, a16 = lane & 15;
+#pragma unroll
+            for (int J = 0; J < T; ++J)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sink(16 * I + q4 + 4 * r, 16 * J + a16, t[J][r]);
+        };
+        if (Tt <= 1) run(std::integral_constant<int, 1>{});
+        else if (Tt == 2) run(std::integral_constant<int, 2>{});
+        else if (Tt == 3) run(std::integral_constant<int, 3>{});
+        else run(std::integral_constant<int, 4>{});
+    };
     double aq_row = 0.0;      // lane = stored row r: (A q0)_r
+    if (use_tiles) {
+        for (int I = 0; 16 * I < ma; ++I)
+            rows16_times_N(A, ma, I, [&](int row, int col, double v) {
+                if (row < ma) { if (col < nf) AN[row * S + col] = v; else if (!first && col == nf) stage[row] = v; }
+            });
+        wave_sync();
+        if (!first && lane < ma) aq_row = stage[lane];
+    } else
     for (int rb = 0; rb < ma; rb += 8) {
         double acc8[8], mq[8];
         rows8_times_N(A, ma, rb, acc8, mq);
@@ -1269,6 +1337,22 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
         const int nr = Q.nc + (Q.has_box ? n : 0);
         double* Rg = Q.R + inst * (long long)nr * nf;
         const double* Cg = Q.C + inst * (long long)Q.nc * n;
+        if (use_tiles) {
+            for (int I = 0; 16 * I < Q.nc; ++I) {
+                wave_sync();
+                rows16_times_N(Cg, Q.nc, I, [&](int row, int col, double v) {
+                    if (row < Q.nc) { if (col < nf) Rg[row * nf + col] = v; else if (col == nf) stage[row - 16 * I] = v; }
+                });
+                wave_sync();
+                if (lane < 16 && 16 * I + lane < Q.nc) {       // lane u < 16: the bounds of row 16 I + u, shifted by (C q0)
+                    const int r = 16 * I + lane;
+                    const double myq = stage[lane];
+                    const double lo = Q.lo[inst * Q.nc + r], up = Q.up[inst * Q.nc + r];
+                    Q.rlo[inst * nr + r] = (lo <= -1.0e20) ? -1.0e20 : lo - myq;
+                    Q.rup[inst * nr + r] = (up >= 1.0e20) ? 1.0e20 : up - myq;
+                }
+            }
+        } else
         for (int rb = 0; rb < Q.nc; rb += 8) {
             double acc8[8], mq[8];
             rows8_times_N(Cg, Q.nc, rb, acc8, mq);
