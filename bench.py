@@ -752,7 +752,8 @@ def time_config5_coherent(B, device, steps=40, warmup=8, cycles=4, drift=0.01):
 def time_nhqp(B, device, steps=5, warmup=2, lanes=1, streams=None, graph=True):
     """the null-space front-end (OpenSoT::solvers::nHQP, SURVEY 8f-2) on the C3 stack: update + osot_nhqp_solve.  lanes > 1 (with the
     caller's streams): the batch as sub-batches on their own streams -- one sub-batch's level preparation runs under the other's
-    QP / accumulation launches and under the tail of its preparation (tools/exp_frontend_lanes.py: 4.16 -> 4.79 M)"""
+    QP / accumulation launches and under the tail of its preparation (tools/exp_frontend_lanes.py: 4.16 -> 4.79 M; three sub-batches of
+    1365 / 1366 fit the preparation kernel's 1536 resident wavefronts in one round each: tools/exp_nhqp_lanes.py)"""
     from opensot_amd import synth
     from opensot_amd.parallel import lane_ranges
     from opensot_amd.solver import BatchedStack
@@ -1334,7 +1335,11 @@ def main():
             except Exception as e:
                 oc["C5_coherent"] = {"error": str(e)}
             try:
-                oc["nHQP_C3"] = time_nhqp(4096, local_rank, lanes=S, streams=streams)
+                # THREE sub-batches (tools/exp_nhqp_lanes.py: 5.32 -> 5.71 M): the 32-wide preparation holds 1536 wavefronts at once (25 KB of
+                # LDS each), so a launch of 1365 instances is one round of the chip where 2048 are one and a third
+                n3 = 3 if (streams is not None and S >= 2) else S
+                s3 = None if streams is None else (list(streams) + [torch.cuda.Stream(device=device) for _ in range(max(0, n3 - len(streams)))])
+                oc["nHQP_C3"] = time_nhqp(4096, local_rank, lanes=n3, streams=s3)
             except Exception as e:
                 oc["nHQP_C3"] = {"error": str(e)}
             try:
