@@ -1339,7 +1339,7 @@ def main():
                 # LDS each), so a launch of 1365 instances is one round of the chip where 2048 are one and a third
                 n3 = 3 if (streams is not None and S >= 2) else S
                 s3 = None if streams is None else (list(streams) + [torch.cuda.Stream(device=device) for _ in range(max(0, n3 - len(streams)))])
-                oc["nHQP_C3"] = time_nhqp(4096, local_rank, lanes=n3, streams=s3)
+                oc["nHQP_C3"] = time_nhqp(4096, local_rank, steps=10, warmup=3, lanes=n3, streams=s3)      # (ten timed steps: at five the fill and drain of three lanes is a tenth of the region)
             except Exception as e:
                 oc["nHQP_C3"] = {"error": str(e)}
             try:
