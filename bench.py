@@ -1309,9 +1309,13 @@ def main():
                     oc[key] = time_config(name, B, local_rank, steps=st_, lanes=S, streams=streams)
                 except Exception as e:
                     oc[key] = {"error": str(e)}
+            # THREE sub-batches for the 35-coordinate stacks (tools/exp_coman_lanes3.py: S1-S3 equal to two within 0.5 %, S4 4.39 -> 4.68 M):
+            # the 40-lane kernel holds 1792 wavefronts at once (22 KB of LDS each), 1365 instances are one round, 2048 one and a seventh
+            nc3 = 3 if (streams is not None and S >= 2) else S
+            sc3 = None if streams is None else (list(streams) + [torch.cuda.Stream(device=device) for _ in range(max(0, nc3 - len(streams)))])
             for which in ("S1", "S2", "S3", "S4"):
                 try:
-                    oc["COMAN35_" + which] = time_coman35(which, 4096, local_rank, lanes=S, streams=streams)
+                    oc["COMAN35_" + which] = time_coman35(which, 4096, local_rank, lanes=nc3, streams=sc3)
                 except Exception as e:
                     oc["COMAN35_" + which] = {"error": str(e)[:300]}
             for which in ("S1", "S2", "S3", "S4"):   # the same four through the reference's null-space front-end (published: 0.2969 / 0.2637 / 0.3191 / 0.3721 ms per solve)
