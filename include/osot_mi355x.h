@@ -497,7 +497,7 @@ int osot_qp_solve_batch_admm_warm(int B, int n, int nc, const double* H, const d
  * kinematic TREE of revolute / prismatic joints (a floating base is the usual chain of three prismatic and three
  * revolute virtual joints); parity at this boundary is pinned by the CPU restatement in oracle/pykin.py and by
  * finite differences, not by the reference.  Convention: Jacobians are expressed in the world
- * frame, rows [linear; angular] of the frame origin, columns = joints; poses are [R row-major | p] (the Cartesian
+ * frame (or the frame's base link frame: frame_base below), rows [linear; angular] of the frame origin, columns = joints; poses are [R row-major | p] (the Cartesian
  * leaf layout, osot_leaf_ptrs).  The Jacobians are written STRAIGHT into their row range of the stacked A_k. */
 #define OSOT_KIN_MAX_JOINTS 64
 #define OSOT_KIN_MAX_FRAMES 8
@@ -552,6 +552,16 @@ typedef struct {
     double pair_shape_R[OSOT_KIN_MAX_PAIRS][9];
     double pair_shape_p[OSOT_KIN_MAX_PAIRS][3];
     int n_env;                                   /* environment shapes with a runtime pose (env_pose entries)        */
+    /* RELATIVE BASE LINK of a frame (round 6; velocity::Cartesian with base_link != "world", src/tasks/velocity/Cartesian.cpp:73-81:
+     * getRelativeJacobian(distal, base, A) / getPose(distal, base, T); DefaultHumanoidStack's waist2LeftArm / waist2RightArm /
+     * right2LeftLeg, tests/DefaultHumanoidStack.cpp:24-35, 52).  frame_base[f] = 0: the world (as before); g + 1 > 0: frame g
+     * of this description is the base link frame (g != f; it may be a frame without outputs).  The producer then writes
+     *   pose  = base_T_distal = [R_b'R_d | R_b'(p_d - p_b)],
+     *   J     = R_b' (J_d - J_b shifted to the distal origin): column j = (anc_d(j) - anc_b(j)) [z_j x (p_d - p_j); z_j] rotated by
+     *           R_b' (prismatic: [z_j; 0]) -- the twist of the distal frame relative to the base frame, in base coordinates; the
+     *           joints both chains share drop out exactly, the joints of the base's own chain enter with a minus sign.
+     * With frame_body[f] the rotation is R_d' instead (Ad(bR_d') after the R_b' of the relative Jacobian, Cartesian.cpp:93-100). */
+    int frame_base[OSOT_KIN_MAX_FRAMES];
 } osot_kin_desc;
 enum { OSOT_SHAPE_CAPSULE = 0, OSOT_SHAPE_BOX = 1 };
 #define OSOT_KIN_MAX_ENV 16

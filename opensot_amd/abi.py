@@ -127,7 +127,8 @@ class KinDesc(C.Structure):
                 ("com_col_mask", C.c_ulonglong),
                 ("pair_kind", C.c_int * KIN_MAX_PAIRS), ("pair_env", C.c_int * KIN_MAX_PAIRS),
                 ("pair_box", (C.c_double * 3) * KIN_MAX_PAIRS), ("pair_shape_R", (C.c_double * 9) * KIN_MAX_PAIRS),
-                ("pair_shape_p", (C.c_double * 3) * KIN_MAX_PAIRS), ("n_env", C.c_int)]
+                ("pair_shape_p", (C.c_double * 3) * KIN_MAX_PAIRS), ("n_env", C.c_int),
+                ("frame_base", C.c_int * KIN_MAX_FRAMES)]
 
 
 class KinBatch(C.Structure):

@@ -308,6 +308,7 @@ __device__ __forceinline__ void kin_instance(const DevKin* __restrict__ K, const
 #pragma unroll
         for (int i = 0; i < 3; ++i) Fp[i] = K->d.frame_p[f][i];
         const int body_f = K->d.frame_body[f];
+        const int base_f = K->d.frame_base[f];                    // 0: the world; g + 1: frame g is the base link frame (Cartesian.cpp:73-81)
         const unsigned long long cm_f = K->d.frame_col_mask[f];   // Task::applyActiveJointsMask (Task.h:129-139)
         double* pose_out = nullptr;        // (a select chain: a lane-indexed read of the argument struct would be served from a scratch copy)
 #pragma unroll
@@ -326,9 +327,9 @@ __device__ __forceinline__ void kin_instance(const DevKin* __restrict__ K, const
 #pragma unroll
             for (int i = 0; i < 3; ++i) Fw[j * 14 + 9 + i] = pj[i] + t[i];
             Fw[j * 14 + 12] = (double)jf;
-            Fw[j * 14 + 13] = (double)body_f;
+            Fw[j * 14 + 13] = (double)((body_f ? 1 : 0) + 2 * base_f);   // options: bit 0 = BODY Jacobian, the rest = base frame + 1
             Fq[j] = cm_f;
-            if (pose_out && live) {
+            if (pose_out && live && base_f <= 0) {
 #pragma unroll
                 for (int i = 0; i < 9; ++i) pose_out[inst * 12 + i] = Rf[i];
 #pragma unroll
@@ -336,6 +337,23 @@ __device__ __forceinline__ void kin_instance(const DevKin* __restrict__ K, const
             }
         }
         wave_sync();
+        if (j < nfr && pose_out && live && base_f > 0) {
+            // relative pose base_T_distal = [R_b'R_d | R_b'(p_d - p_b)] (ModelInterface::getPose(distal, base, T), Cartesian.cpp:80-81);
+            // the base frame's world pose was published by its own lane above
+            const double* Bw = Fw + (base_f - 1) * 14;
+            double Rb[9], dp[3];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Rb[i] = Bw[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) dp[i] = (pj[i] + t[i]) - Bw[9 + i];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc)
+                    pose_out[inst * 12 + 3 * r + cc] = Rb[r] * Rf[cc] + Rb[3 + r] * Rf[3 + cc] + Rb[6 + r] * Rf[6 + cc];
+                pose_out[inst * 12 + 9 + r] = Rb[r] * dp[0] + Rb[3 + r] * dp[1] + Rb[6 + r] * dp[2];
+            }
+        }
     }
     KIN_PHASE("world");
     // ---- 3. frames: the Jacobian columns, lane = joint
@@ -349,14 +367,21 @@ __device__ __forceinline__ void kin_instance(const DevKin* __restrict__ K, const
 #pragma unroll
         for (int i = 0; i < 3; ++i) pf[i] = Fw[f * 14 + 9 + i];
         const int jf = (int)Fw[f * 14 + 12];
-        const bool body = Fw[f * 14 + 13] != 0.0;
+        const int opt = (int)Fw[f * 14 + 13];
+        const bool body = (opt & 1) != 0;
+        const int bf = (opt >> 1) - 1;                   // base frame of a relative Cartesian task, -1: the world
+        const int jb = (bf >= 0) ? (int)Fw[bf * 14 + 12] : 0;
         const unsigned long long cm = Fq[f];
         double* Jf = Bt.frame_J[f];                      // (the argument struct: scalar loads, a uniform base address for the stores)
         if (!Jf) continue;
         const long long jstride = Bt.frame_J_stride[f];
         if (valid) {
             double col[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            if ((Anc[jf] >> j) & 1ull) {
+            // joint j moves the distal link (+1), the base link (-1: the base body's point at the distal origin moves the same way,
+            // so the joints both chains share cancel), both or neither (0).  World base: the ancestor test as before
+            const bool in_d = ((Anc[jf] >> j) & 1ull) != 0ull;
+            const bool in_b = bf >= 0 && ((Anc[jb] >> j) & 1ull) != 0ull;
+            if (in_d != in_b) {
                 if (revolute) {
                     const double dlt[3] = {pf[0] - pw[0], pf[1] - pw[1], pf[2] - pw[2]};
                     cross3(zj, dlt, col);
@@ -364,13 +389,22 @@ __device__ __forceinline__ void kin_instance(const DevKin* __restrict__ K, const
                 } else {
                     col[0] = zj[0]; col[1] = zj[1]; col[2] = zj[2];
                 }
+                if (in_b) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) col[i] = -col[i];
+                }
             }
-            if (body) {   // BODY Jacobian Ad(R_f') J (Cartesian.cpp:93-100): both halves rotated by R_f'
+            if (body || bf >= 0) {
+                // BODY Jacobian Ad(R_f') J (Cartesian.cpp:93-100): both halves rotated by R_f'; a relative Jacobian is expressed in
+                // its base frame: R_b' (getRelativeJacobian, Cartesian.cpp:75-76) -- and BODY on top of that is Ad((R_b'R_d)') R_b' = R_d'
+                double Rr[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) Rr[i] = body ? Rf[i] : Fw[(bf >= 0 ? bf : 0) * 14 + i];
                 double rl[3], ra[3];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    rl[i] = Rf[i] * col[0] + Rf[3 + i] * col[1] + Rf[6 + i] * col[2];
-                    ra[i] = Rf[i] * col[3] + Rf[3 + i] * col[4] + Rf[6 + i] * col[5];
+                    rl[i] = Rr[i] * col[0] + Rr[3 + i] * col[1] + Rr[6 + i] * col[2];
+                    ra[i] = Rr[i] * col[3] + Rr[3 + i] * col[4] + Rr[6 + i] * col[5];
                 }
 #pragma unroll
                 for (int i = 0; i < 3; ++i) { col[i] = rl[i]; col[3 + i] = ra[i]; }

@@ -149,7 +149,7 @@ int osot_abi_layout(const char* name, unsigned long long* size, unsigned long lo
     OSOT_LAYOUT_BEGIN(osot_kin_desc) OSOT_F(n) OSOT_F(parent) OSOT_F(type) OSOT_F(axis) OSOT_F(R0) OSOT_F(p0) OSOT_F(mass) OSOT_F(com)
         OSOT_F(n_frames) OSOT_F(frame_joint) OSOT_F(frame_R) OSOT_F(frame_p) OSOT_F(n_pairs) OSOT_F(pair_joint) OSOT_F(pair_seg)
         OSOT_F(pair_radius) OSOT_F(frame_body) OSOT_F(frame_col_mask) OSOT_F(com_col_mask) OSOT_F(pair_kind) OSOT_F(pair_env)
-        OSOT_F(pair_box) OSOT_F(pair_shape_R) OSOT_F(pair_shape_p) OSOT_F(n_env) OSOT_LAYOUT_END()
+        OSOT_F(pair_box) OSOT_F(pair_shape_R) OSOT_F(pair_shape_p) OSOT_F(n_env) OSOT_F(frame_base) OSOT_LAYOUT_END()
     OSOT_LAYOUT_BEGIN(osot_kin_batch) OSOT_F(B) OSOT_F(q) OSOT_F(frame_pose) OSOT_F(frame_J) OSOT_F(frame_J_stride) OSOT_F(com)
         OSOT_F(com_J) OSOT_F(com_J_stride) OSOT_F(pair_dist) OSOT_F(pair_J) OSOT_F(pair_J_stride) OSOT_F(env_pose) OSOT_F(env_pose_stride) OSOT_LAYOUT_END()
 #undef OSOT_LAYOUT_BEGIN
@@ -1008,6 +1008,9 @@ int osot_kin_create(const osot_kin_desc* d, int device, osot_kin** out) {
     kin_build_tables(h);
     for (int f = 0; f < d->n_frames; ++f)
         if (d->frame_joint[f] < 0 || d->frame_joint[f] >= d->n) return fail(OSOT_ERR_INVALID, "frame attached to a joint out of range");
+    for (int f = 0; f < d->n_frames; ++f)      // relative base link (Cartesian.cpp:40-51: a base link that is not the distal link)
+        if (d->frame_base[f] < 0 || d->frame_base[f] > d->n_frames || d->frame_base[f] == f + 1)
+            return fail(OSOT_ERR_INVALID, "frame_base must be 0 (world) or 1 + the index of another frame");
     if (d->n_pairs < 0 || d->n_pairs > OSOT_KIN_MAX_PAIRS) return fail(OSOT_ERR_INVALID, "collision pair count out of range");
     if (d->n_env < 0 || d->n_env > OSOT_KIN_MAX_ENV) return fail(OSOT_ERR_INVALID, "environment shape count out of range");
     for (int p = 0; p < d->n_pairs; ++p) {

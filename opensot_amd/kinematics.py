@@ -29,6 +29,9 @@ class KinModel:
     # written as zero (Task::setActiveJointsMask, Task.h:129-139); the same for the CoM Jacobian
     frame_body: dict = field(default_factory=dict)
     frame_active_joints: dict = field(default_factory=dict)
+    # frame index -> index (or name) of the frame that is its BASE LINK: pose and Jacobian of the frame relative to that frame, in its
+    # coordinates (velocity::Cartesian with base_link != "world", Cartesian.cpp:73-81); absent = the world
+    frame_base: dict = field(default_factory=dict)
     com_active_joints: list = None
     # environment shapes and link-vs-environment pairs (CollisionAvoidance::addCollisionShape / moveCollisionShape /
     # setLinksVsEnvironment, CollisionAvoidance.h:115-144).  link_shapes: link name -> (joint, a0, a1, radius), the capsule
@@ -148,6 +151,11 @@ class KinModel:
         for f in range(len(self.frames)):
             d.frame_body[f] = 1 if self.frame_body.get(f) else 0
             d.frame_col_mask[f] = mask(self.frame_active_joints[f]) if f in self.frame_active_joints else 0
+        for f, g in self.frame_base.items():
+            g = self.frame_index(g) if isinstance(g, str) else int(g)
+            if g == f or not 0 <= g < len(self.frames):
+                raise ValueError(f"frame {f}: its base link frame must be another frame of the model")
+            d.frame_base[f] = g + 1
         d.com_col_mask = mask(self.com_active_joints) if self.com_active_joints is not None else 0
         d.n_pairs = len(self.pairs)
         d.n_env = sum(1 for e in self.env_shapes if e["link"] == "world")

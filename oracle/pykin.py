@@ -58,6 +58,23 @@ def forward(model, q):
     return out
 
 
+def _skew(v):
+    return np.array([[0.0, -v[2], v[1]], [v[2], 0.0, -v[0]], [-v[1], v[0], 0.0]])
+
+
+def relative(fk, f, g):
+    """frame f RELATIVE to the base frame g, from the WORLD quantities of forward(): what velocity::Cartesian with a base link
+    asks the model for (Cartesian.cpp:75-76, 80-81: getRelativeJacobian(distal, base, A), getPose(distal, base, T)).
+    Textbook route, on purpose not the kernel's: the twist of the distal frame relative to the base frame in base coordinates,
+        v_rel = R_b'(v_d - v_b - w_b x (p_d - p_b)),   w_rel = R_b'(w_d - w_b),
+    from the two world Jacobians.  Returns (R_rel, p_rel, J_rel 6 x n)."""
+    Rd, pd, Jd = fk["frame_R"][f], fk["frame_p"][f], fk["J"][f]
+    Rb, pb, Jb = fk["frame_R"][g], fk["frame_p"][g], fk["J"][g]
+    lin = Jd[:3] - Jb[:3] + _skew(pd - pb) @ Jb[3:]
+    ang = Jd[3:] - Jb[3:]
+    return Rb.T @ Rd, Rb.T @ (pd - pb), np.concatenate([Rb.T @ lin, Rb.T @ ang], axis=0)
+
+
 def closest_segment_points(p1, q1, p2, q2):
     """closest points of two segments (either may be a point): the standard clamped two-parameter minimisation"""
     d1, d2, r = q1 - p1, q2 - p2, p1 - p2

@@ -179,6 +179,139 @@ def test_emulated_frame_options():
     assert np.abs(J[:, 0:6, :6]).max() == 0.0 and np.abs(J[:, 6:12, :6]).max() > 0.1
 
 
+def _relative_model():
+    """the 32-DoF humanoid with DefaultHumanoidStack's relative Cartesian tasks (tests/DefaultHumanoidStack.cpp:24-35, 52):
+    waist2LeftArm / waist2RightArm (the wrists relative to the waist link) and right2LeftLeg (here: l_sole relative to r_sole);
+    r_sole stays a world task.  Frame 4 = the waist link frame (base link only: it has no outputs of its own)"""
+    m = kin.humanoid32()
+    m.frames = list(m.frames) + [("waist", m.names.index("WaistYaw"), kin._rpy(0.1, -0.2, 0.3), (0.01, 0.0, 0.05))]
+    m.frame_base = {0: "waist", 1: 4, 2: 3}
+    return m
+
+
+def _expected_relative(m, o, f):
+    """frame f as the producer writes it: relative to its base (oracle/pykin.relative, the textbook two-Jacobian route) or the
+    world quantities; then BODY (Ad(R') with R the pose the task sees, Cartesian.cpp:93-100) and the column mask"""
+    if f in m.frame_base:
+        g = m.frame_base[f]
+        g = m.frame_index(g) if isinstance(g, str) else g
+        R, p, J = pykin.relative(o, f, g)
+    else:
+        R, p, J = o["frame_R"][f], o["frame_p"][f], o["J"][f].copy()
+    if m.frame_body.get(f):
+        J = np.concatenate([R.T @ J[:3], R.T @ J[3:]], axis=0)
+    if f in m.frame_active_joints:
+        keep = np.zeros(m.n, dtype=bool); keep[m.frame_active_joints[f]] = True
+        J[:, ~keep] = 0.0
+    return R, p, J
+
+
+def test_relative_restatement_matches_finite_differences():
+    """getRelativeJacobian / relative getPose (Cartesian.cpp:75-76, 80-81) restated: the relative Jacobian against central
+    differences of the relative pose (linear: d p_rel; angular: d R_rel R_rel' = [w_rel]x, both in base coordinates)"""
+    m = _relative_model()
+    rng = np.random.default_rng(23)
+    h = 1e-6
+    for _ in range(3):
+        q = rng.uniform(-0.8, 0.8, m.n)
+        o = pykin.forward(m, q)
+        for f, g in ((0, 4), (1, 4), (2, 3)):
+            R, p, J = pykin.relative(o, f, g)
+            Jfd = np.zeros((6, m.n))
+            for j in range(m.n):
+                e = np.zeros(m.n); e[j] = h
+                Ra, pa, _ = pykin.relative(pykin.forward(m, q + e), f, g)
+                Rb, pb, _ = pykin.relative(pykin.forward(m, q - e), f, g)
+                Jfd[:3, j] = (pa - pb) / (2 * h)
+                S = (Ra - Rb) / (2 * h) @ R.T
+                Jfd[3:, j] = [S[2, 1], S[0, 2], S[1, 0]]
+            assert np.abs(J - Jfd).max() < 1e-6      # (the verdict's bound; observed ~1e-9)
+            assert np.abs(J - Jfd).max() < 5e-8
+            # the floating base moves both links alike: no relative motion
+            assert np.abs(J[:, :6]).max() < 1e-12
+        # wrists relative to the waist: only waist-to-wrist joints (the arm chains) have columns
+        arm = [m.names.index(s) for s in ("LShSag", "LShLat", "LShYaw", "LElbj", "LWrj")]
+        J0 = pykin.relative(o, 0, 4)[2]
+        assert np.abs(np.delete(J0, arm, axis=1)).max() < 1e-12 and np.abs(J0[:, arm]).max() > 0.1
+        # l_sole relative to r_sole: BOTH legs move it (the right leg's joints with a minus sign), nothing else
+        legs = [m.names.index(s + j) for s in "RL" for j in ("HipSag", "HipLat", "HipYaw", "KneeSag", "AnkLat", "AnkSag")]
+        J2 = pykin.relative(o, 2, 3)[2]
+        assert np.abs(np.delete(J2, legs, axis=1)).max() < 1e-12 and (np.abs(J2[:, legs]).max(axis=0) > 1e-3).all()
+
+
+def test_emulated_relative_base_frames():
+    """the producer's relative-base frames (the emulated kernel body; its route -- the difference of two ancestor tests on ONE column
+    formula -- against the restatement's difference of two world Jacobians), with and without the BODY option and a column mask"""
+    from helpers import emu_kinematics
+    for opts in (False, True):
+        m = _relative_model()
+        if opts:
+            m.frame_body = {1: True, 2: True}
+            m.frame_active_joints = {0: [j for j in range(m.n) if j % 4]}
+        rng = np.random.default_rng(29)
+        q = rng.uniform(-1.0, 1.0, (5, m.n))
+        poses, J, com = emu_kinematics(m, q)
+        for i in range(5):
+            o = pykin.forward(m, q[i])
+            for f in range(5):
+                R, p, Je = _expected_relative(m, o, f)
+                assert np.abs(J[i, 6 * f:6 * f + 6] - Je).max() < 1e-12
+                assert np.abs(poses[f][i][:9].reshape(3, 3) - R).max() < 1e-13
+                assert np.abs(poses[f][i][9:] - p).max() < 1e-13
+            assert np.abs(J[i, 30:33] - o["Jcom"]).max() < 1e-14
+
+
+def test_kin_desc_rejects_a_bad_base_frame():
+    L = abi.lib()
+    import ctypes as C
+    h = C.c_void_p()
+    d = _relative_model().desc()
+    assert [d.frame_base[f] for f in range(5)] == [5, 5, 4, 0, 0]
+    d.frame_base[1] = 2      # its own index + 1: a frame cannot be its own base link (Cartesian.cpp:50-51)
+    assert L.osot_kin_create(C.byref(d), 0, C.byref(h)) == abi.ERR_INVALID
+    d = _relative_model().desc(); d.frame_base[0] = 6      # beyond the frames
+    assert L.osot_kin_create(C.byref(d), 0, C.byref(h)) == abi.ERR_INVALID
+    d = _relative_model().desc(); d.frame_base[0] = -1
+    assert L.osot_kin_create(C.byref(d), 0, C.byref(h)) == abi.ERR_INVALID
+    with pytest.raises(ValueError):
+        mm = _relative_model(); mm.frame_base[3] = 3; mm.desc()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opts", [False, True])
+def test_relative_base_frames_gpu(opts, gpu_device):
+    """osot_kin_kernel with relative base links (Cartesian.cpp:73-81) against the restatement, <= 1e-12"""
+    import torch
+    m = _relative_model()
+    if opts:
+        m.frame_body = {1: True, 2: True}
+        m.frame_active_joints = {0: [j for j in range(m.n) if j % 4]}
+    K = kin.Kinematics(m, device=0)
+    B = 131
+    rng = np.random.default_rng(31)
+    q = rng.uniform(-1.0, 1.0, (B, m.n))
+    dev = torch.device("cuda", 0)
+    A = torch.full((B, 30 + 3 + 1, m.n), 7.0, dtype=torch.float64, device=dev)
+    poses = {f: torch.zeros((B, 12), dtype=torch.float64, device=dev) for f in range(5)}
+    K.forward(torch.as_tensor(q, device=dev), frame_pose=poses, frame_J={f: (A, 6 * f) for f in range(5)}, com_J=(A, 30))
+    torch.cuda.synchronize()
+    Ah = A.cpu().numpy()
+    for i in list(range(0, B, 11)) + [B - 1]:
+        o = pykin.forward(m, q[i])
+        for f in range(5):
+            R, p, Je = _expected_relative(m, o, f)
+            assert np.abs(Ah[i, 6 * f:6 * f + 6] - Je).max() < 1e-12
+            ph = poses[f][i].cpu().numpy()
+            assert np.abs(ph[:9].reshape(3, 3) - R).max() < 1e-13 and np.abs(ph[9:] - p).max() < 1e-13
+        assert np.abs(Ah[i, 30:33] - o["Jcom"]).max() < 1e-14
+    assert (Ah[:, 33] == 7.0).all()
+    # a base frame WITHOUT outputs (no pose, no Jacobian rows of its own): the relative frames are the same
+    A2 = torch.full((B, 24, m.n), 7.0, dtype=torch.float64, device=dev)
+    K.forward(torch.as_tensor(q, device=dev), frame_J={f: (A2, 6 * f) for f in range(4)})
+    torch.cuda.synchronize()
+    assert torch.equal(A2, A[:, :24])
+
+
 @pytest.mark.gpu
 def test_frame_options_gpu(gpu_device):
     import torch
@@ -297,7 +430,71 @@ def test_closed_loop_ik_on_device(gpu_device):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["box", "rows", "collision_pairs", "hotstart", "inactive_task", "dense_weight"])
+def test_closed_loop_default_humanoid_stack_relative_tasks(gpu_device):
+    """A DefaultHumanoidStack-shaped stack (tests/DefaultHumanoidStack.cpp:24-35, 52; the shape of
+    tests/solvers/TestQPOases_AutoStack.cpp:80-83) closed on the device with RELATIVE Cartesian tasks produced by the kinematics
+    kernel: (rightLeg + right2LeftLeg) / (waist2LeftArm + waist2RightArm) / postural << jointLimits << velocityLimits.  The wrists
+    reach their targets GIVEN IN THE WAIST FRAME, the feet keep their relative pose, and the device state agrees with the
+    restatement at the end."""
+    import torch
+    from opensot_amd.solver import BatchedStack
+    m = _relative_model()
+    n, B = m.n, 96
+    dev = torch.device("cuda", 0)
+    f64 = dict(dtype=torch.float64, device=dev)
+    rng = np.random.default_rng(37)
+    q0 = np.zeros((B, n))
+    q0[:, [m.names.index(s + "KneeSag") for s in "RL"]] = 0.5
+    q0[:, [m.names.index(s + "HipSag") for s in "RL"]] = -0.25
+    q0[:, [m.names.index(s + "AnkSag") for s in "RL"]] = -0.25
+    q0[:, [m.names.index(s + "Elbj") for s in "RL"]] = -0.6
+    q0 += rng.normal(0.0, 0.02, (B, n))
+    levels = [[Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="r_sole"), Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="right2LeftLeg")],
+              [Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="waist2LeftArm"), Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="waist2RightArm")],
+              [Task(abi.TASK_POSTURAL, n, lam=0.01, name="postural")]]
+    bounds = [Bound(abi.BOUND_JOINT_LIMITS, scaling=1.0, name="jl"), Bound(abi.BOUND_VELOCITY_LIMITS, dT=0.01, name="vl")]
+    plan = StackPlan(n=n, levels=levels, bounds=bounds, rowblocks=[], eps_abs=eps_abs_from_factor(1e6))
+    st = BatchedStack(plan, B, device=0, want_levels=False)
+    K = kin.Kinematics(m, device=0)
+    q = torch.as_tensor(q0, **f64).contiguous()
+    pose = [torch.zeros((B, 12), **f64) for _ in range(4)]
+    # frames: 0 l_wrist|waist, 1 r_wrist|waist, 2 l_sole|r_sole, 3 r_sole (world); rows: level 0 = [r_sole; l_sole|r_sole], level 1 = wrists
+    kw = dict(frame_pose={f: pose[f] for f in range(4)}, frame_J={3: (st.A[0], 0), 2: (st.A[0], 6), 0: (st.A[1], 0), 1: (st.A[1], 6)})
+    K.forward(q, **kw)
+    torch.cuda.synchronize()
+    pose_d = [p.clone() for p in pose]
+    pose_d[0][:, 9:] += torch.as_tensor([0.05, 0.02, 0.04], **f64)      # in WAIST coordinates
+    pose_d[1][:, 9:] += torch.as_tensor([0.05, -0.02, 0.04], **f64)
+    qmin = torch.full((B, n), -2.5, **f64); qmax = torch.full((B, n), 2.5, **f64)
+    leaf = {"B": B, "task": [[(pose[3], pose_d[3], None), (pose[2], pose_d[2], None)], [(pose[0], pose_d[0], None), (pose[1], pose_d[1], None)],
+                             [(q, q.clone(), None)]],
+            "bound": [(q, qmin, qmax), (torch.full((B, n), 2.0, **f64), None, None)], "rows": []}
+    kb = K.batch_args(q, **kw)
+    err0 = [float((pose_d[f][:, 9:] - pose[f][:, 9:]).norm(dim=1).max()) for f in range(4)]
+    for cycle in range(300):
+        st.control_cycle(K, kb, leaf, q_integrate=q)       # (kinematics incl. the relative frames inside the launch)
+        if cycle == 0:
+            torch.cuda.synchronize()
+            assert (st.status[:B] == 0).all()
+    K.forward(q, **kw)
+    torch.cuda.synchronize()
+    assert (st.status[:B] == 0).all()
+    err = [float((pose_d[f][:, 9:] - pose[f][:, 9:]).norm(dim=1).max()) for f in range(4)]
+    assert err0[0] > 0.05 and err0[1] > 0.05
+    assert err[0] < 0.05 * err0[0] and err[1] < 0.05 * err0[1]        # the wrists reached their waist-frame targets
+    assert err[2] < 1e-4 and err[3] < 1e-4                            # the feet (first level) kept their world / relative poses
+    i = 5
+    o = pykin.forward(m, q[i].cpu().numpy())
+    for f, g in ((0, 4), (1, 4), (2, 3)):
+        R, p, _ = pykin.relative(o, f, g)
+        ph = pose[f][i].cpu().numpy()
+        assert np.abs(ph[9:] - p).max() < 1e-12 and np.abs(ph[:9].reshape(3, 3) - R).max() < 1e-12
+    # the floating base is free to move: the relative tasks did not pin it, the world foot did
+    assert float((q[:, :6] - torch.as_tensor(q0[:, :6], **f64)).abs().max()) > 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["box", "rows", "collision_pairs", "hotstart", "inactive_task", "dense_weight", "relative_base"])
 def test_control_cycle_in_one_launch_matches_the_three_calls(mode, gpu_device):
     """osot_control_cycle (per instance kinematics -> AutoStack::update -> cascade -> q += dq by the same wavefront,
     coman_ik.cpp:186-219 in ONE launch) against osot_kinematics + osot_cycle + the integration as three launches, over 25
@@ -306,12 +503,14 @@ def test_control_cycle_in_one_launch_matches_the_three_calls(mode, gpu_device):
     general one); round 5 -- every plan the three-call form takes: "collision_pairs" BASELINE config 4's shape, the
     CollisionAvoidance rows PRODUCED ON THE DEVICE inside the launch (capsule-pair distances and distance Jacobians,
     velocity/CollisionAvoidance.cpp:96-152), "hotstart" (osot_solver_set_hotstart), "inactive_task" (Task::setActive(false))
-    and "dense_weight" (Task::setWeight(W)) through the EXTRA instantiation.  An odd batch."""
+    and "dense_weight" (Task::setWeight(W)) through the EXTRA instantiation; round 6 -- "relative_base": DefaultHumanoidStack's
+    waist2LeftArm / waist2RightArm / right2LeftLeg (Cartesian tasks with a base link, Cartesian.cpp:73-81) produced inside the launch.
+    An odd batch."""
     import torch
     from opensot_amd.plan import Rows
     from opensot_amd.solver import BatchedStack
     pairs = mode == "collision_pairs"
-    m = kin.humanoid32_pairs(kin.humanoid32()) if pairs else kin.humanoid32()
+    m = kin.humanoid32_pairs(kin.humanoid32()) if pairs else (_relative_model() if mode == "relative_base" else kin.humanoid32())
     n, B = m.n, 203
     P = len(m.pairs) if pairs else 0
     dev = torch.device("cuda", 0)
