@@ -25,6 +25,7 @@ struct DevControl {
     int steps;
     double* dq_steps;          // [steps][B][n] every cycle's dq, or null (D.dq holds the last cycle's either way)
     int* status_steps;         // [steps][B] every cycle's status, or null (D.status: the first non-zero status of the rollout)
+    int K_pairs;               // HOST side only: the model's collision-pair count (ihqp_launch: pair outputs need a PAIRS instantiation)
 };
 
 // LDS in front of the cycle's own use of the slice (the update stages its arguments there afterwards).  NP = 32: two kinematics

@@ -574,7 +574,11 @@ static int ihqp_launch(osot_solver* s, const osot_qp_batch* b, void* hip_stream,
     // ... and plans whose rows are all equalities by construction (the feet as TaskToConstraint rows: the reference's COMAN stacks), at
     // every size -- but only where THIS launch's update half writes lo == up itself (fused): on the solve-only path lo / up are the
     // caller's arrays, and a row with lo < up would never be scanned by the BOX instantiation
-    const bool box = s->specialise && !extra && (P.nc == 0 ? T == 32 : (fused != nullptr && plan_rows_all_equalities(pl)));
+    bool box = s->specialise && !extra && (P.nc == 0 ? T == 32 : (fused != nullptr && plan_rows_all_equalities(pl)));
+    // the BOX instantiations of osot_control_cycle_kernel are compiled WITHOUT the collision-pair stage of the kinematics (PAIRS = !BOX):
+    // a model with pairs whose batch asks for their outputs takes the general instantiation, whatever the plan's rows (such a
+    // launch used to leave pair_dist / pair_J unwritten without an error)
+    if (control && control->K_pairs > 0 && (control->Bt.pair_dist || control->Bt.pair_J)) box = false;
     if (control && (prof || !fused))
         return fail(OSOT_ERR_UNSUPPORTED, "the fused control cycle carries no profiling code (use osot_kinematics + osot_cycle)");
     std::pair<hipEvent_t, hipEvent_t> ev;
@@ -1098,6 +1102,7 @@ static int control_launch(osot_solver* s, osot_kin* k, const osot_kin_batch* kb,
     if (rc != OSOT_OK) return fail(rc, why);
     DevControl C;
     C.K = (const DevKin*)k->dev;
+    C.K_pairs = k->n_pairs;
     C.Bt = *kb;
     C.q_int = q_integrate;
     C.steps = steps; C.dq_steps = dq_steps; C.status_steps = status_steps;

@@ -1747,7 +1747,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare64_kernel(const DevNhqp Q
 // implicit QL iteration of sym_ql_32 over all 64 lanes: (d, e) one entry per lane read with v_readlane, a lane's own row of V carried
 // through the rotations.  Replaces the cyclic Jacobi iteration (kept under OSOT_NHQP_WIDE_JACOBI for A/B), which moved ~12 LDS words
 // per pair per round, ~280 rounds, and was 93 % of the launch.  vv / ww: 64 doubles of LDS scratch each.
-__device__ __forceinline__ void sym_eig_wide(double* G, double* V, double* vv, double* ww, int k_in, int S_in, int lane) {
+__device__ __forceinline__ bool sym_eig_wide(double* G, double* V, double* vv, double* ww, int k_in, int S_in, int lane) {
     constexpr double kEps = 2.220446049250313e-16;
     const int k = uniform_i(k_in), S = uniform_i(S_in);
     const int cl = (lane < k) ? lane : 0;
@@ -1817,12 +1817,14 @@ __device__ __forceinline__ void sym_eig_wide(double* G, double* V, double* vv, d
     // ---- implicit QL with shifts (tql2; see sym_ql_32): e[c] couples c and c + 1, e[k - 1] = 0
     const double anorm = uniform_d(colmax<64>((lane < k) ? fabs(d) + fabs(e) : 0.0));
     const double etol = OSOT_QL_TOL * kEps * anorm;
+    bool converged = true;      // (uniform) every eigenvalue's QL iteration ended on a negligible coupling within its 60 sweeps
     for (int l = 0; l < k; ++l) {
+        bool done = false;
         for (int iter = 0; iter < 60; ++iter) {
             const bool small = (lane >= l && lane < k - 1) && (fabs(e) <= etol);
             const unsigned long long mk = wave_ballot(small);
             const int m = mk ? __builtin_ctzll(mk) : k - 1;
-            if (m == l) break;
+            if (m == l) { done = true; break; }
             const double dl = bcast(d, l), dl1 = bcast(d, l + 1), el = bcast(e, l), dm = bcast(d, m);
             double g = (dl1 - dl) / (2.0 * el);
             double r = sqrt(fma(g, g, 1.0));
@@ -1864,10 +1866,19 @@ __device__ __forceinline__ void sym_eig_wide(double* G, double* V, double* vv, d
             if (lane == l) { d -= p; e = g; }
             if (lane == m) e = 0.0;
         }
+        // the sweep budget ran out (or the last sweep ended on an underflow restart): the eigenpairs from here on are not to be
+        // trusted -- said to the caller, which fails the instance instead of building a null space from them
+        if (!done) {
+            const bool small = (lane >= l && lane < k - 1) && (fabs(e) <= etol);
+            const unsigned long long mk = wave_ballot(small);
+            if ((mk ? __builtin_ctzll(mk) : k - 1) != l) converged = false;
+        }
     }
     wave_sync();
     if (lane < k) G[lane * S + lane] = d;
     wave_sync();
+    // (a non-finite eigenvalue -- NaN in G -- never passes `fabs(e) <= etol`: covered by the same flag)
+    return converged;
 }
 
 inline size_t nhqp_prepare_wide_lds_bytes(int m, int n) {
@@ -1977,8 +1988,9 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_wide_kernel(const DevNhq
     NHQP_PHASE("w:gram");
 #ifndef OSOT_NHQP_WIDE_JACOBI
     // ---- eigen-decomposition of G: tridiagonalisation + implicit QL (sym_eig_wide); eigenvalues to the diagonal, V in NV
-    sym_eig_wide(G, NV, vec, ub, nf, S, lane);
+    const bool eig_ok = sym_eig_wide(G, NV, vec, ub, nf, S, lane);
 #else
+    const bool eig_ok = true;
     // ---- cyclic Jacobi on G, rotations accumulated in V.  kk = nf rounded up to even (a phantom index pairs with nobody); round r of
     // a sweep: (kk - 1, r) and ((r + t) mod (kk - 1), (r - t) mod (kk - 1)), t = 1 .. kk / 2 - 1 -- every pair once per sweep.
     {
@@ -2247,6 +2259,10 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_wide_kernel(const DevNhq
             // H on the matrix core: rows of A N weighted by w, plus sv_max V2 V2' as extra k-steps (its columns scaled by sqrt(sv_max))
             const int nsel = sel ? ns : 0;
             nhqp_gram_to(Hg, nf, nf, AN, S, m, vec, NV, S, RN, idx + (nf - ns), nsel, sv_max, lane);
+            // an eigen-decomposition that did not converge (sym_eig_wide's flag): the level's QP is handed a NaN pivot, ends as NOT_PD, and
+            // the accumulation marks the instance failed (dq = 0, like every other failure) -- sigma, U, V2 of an unconverged iteration
+            // never reach the lower levels silently.  (Same wavefront, same address, program order: the store above lands first.)
+            if (!eig_ok && lane == 0) Hg[0] = __builtin_nan("");
         }
         if (Q.Wd) { wave_sync(); nhqp_dense_weight_correction(Q, inst, AN, S, b0, lane); }
         if (ns > 0 && Q.V2) {

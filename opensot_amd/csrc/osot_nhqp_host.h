@@ -37,6 +37,17 @@ inline int nhqp_validate(const osot_plan_desc& p, const osot_nhqp_options* opt, 
         if (p.rowblock[j].only_level != 0) { *why = "[nHQP] Local constraints not supported"; return OSOT_ERR_UNSUPPORTED; }   // nHQP.cpp:41-44
         if (rows_are_implicit(p.rowblock[j].kind)) { *why = "nHQP front-end: unit-row blocks are not covered (use the box)"; return OSOT_ERR_UNSUPPORTED; }
     }
+    // the singular-value threshold is a ratio: nHQP::setMinSingularValueRatio throws outside [0, 1] (nHQP.cpp:127-152)
+    if (opt) {
+        auto bad_ratio = [](double v) { return !(v >= 0.0 && v <= 1.0); };   // (NaN fails both comparisons)
+        if ((opt->min_sv_ratio_is_set || opt->min_sv_ratio != 0.0) && bad_ratio(opt->min_sv_ratio)) {
+            *why = "[nHQP] min_sv_ratio must be in [0, 1]"; return OSOT_ERR_INVALID;
+        }
+        for (int k = 0; k < p.n_levels; ++k)
+            if (opt->level_min_sv_ratio_is_set[k] && bad_ratio(opt->level_min_sv_ratio[k])) {
+                *why = "[nHQP] level_min_sv_ratio[k] must be in [0, 1]"; return OSOT_ERR_INVALID;
+            }
+    }
     int nf = p.n;
     for (int k = 0; k < p.n_levels; ++k) {
         int m, ma; plan_level_rows(&p, k, &m, &ma);

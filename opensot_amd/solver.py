@@ -215,6 +215,11 @@ class BatchedStack:
             abi.check(self._lib.osot_control_cycle(self._h, kin._h, C.byref(kb), C.byref(lb), C.byref(out), C.byref(qb),
                                                    _dev_ptr(q_integrate), _stream_ptr(self.device, self.stream)), "osot_control_cycle")
         else:
+            # the kernel indexes dq_steps as (t * B + inst) * n + c and status_steps as t * B + inst, int32: checked here, not trusted
+            n = self.plan.n
+            for name, t, dt, shape in (("dq_steps", dq_steps, torch.float64, (int(steps), lb.B, n)), ("status_steps", status_steps, torch.int32, (int(steps), lb.B))):
+                if t is not None and not (t.is_cuda and t.device == self.device and t.dtype == dt and t.is_contiguous() and tuple(t.shape) == shape):
+                    raise ValueError(f"control_rollout: {name} must be a contiguous {dt} tensor of shape {shape} on {self.device}")
             abi.check(self._lib.osot_control_rollout(self._h, kin._h, C.byref(kb), C.byref(lb), C.byref(out), C.byref(qb),
                                                      _dev_ptr(q_integrate), int(steps), _dev_ptr(dq_steps), _dev_ptr(status_steps),
                                                      _stream_ptr(self.device, self.stream)), "osot_control_rollout")
@@ -258,6 +263,13 @@ class BatchedStack:
         assembled arrays; stream-ordered, results in self.dq[:B] / self.status[:B].  free_vars: free variables per level
         (the reference fixes them at construction); None = n, then minus the rows of the level above"""
         opt = abi.NhqpOptions()
+        L = self.plan.L
+        # per-level lists have ONE entry per level (nHQP::setMinSingularValueRatio(std::vector<double>) throws on a size that
+        # differs from the number of layers, nHQP.cpp:127-152)
+        for name, val in (("free_vars", free_vars), ("min_sv_ratio", min_sv_ratio), ("ab_regularization", ab_regularization),
+                          ("selective_ns_regularization", selective_ns_regularization), ("level_W", level_W)):
+            if isinstance(val, (list, tuple)) and len(val) != L:
+                raise ValueError(f"solve_nhqp: {name} has {len(val)} entries, the stack has {L} levels")
         if free_vars is not None:
             for k, v in enumerate(free_vars):
                 opt.free_vars[k] = int(v)
@@ -285,6 +297,11 @@ class BatchedStack:
             self._nhqp_W = list(level_W)            # (kept alive until the next call)
             for k, Wk in enumerate(level_W):
                 if Wk is not None:
+                    mk = self.plan.m(k)
+                    # (the kernel indexes Wd as inst * m * m + r * m + s: anything else is silent garbage or an out-of-bounds read)
+                    if not (Wk.is_cuda and Wk.device == self.device and Wk.dtype == torch.float64 and Wk.is_contiguous()
+                            and Wk.dim() == 3 and Wk.shape[0] >= B and tuple(Wk.shape[1:]) == (mk, mk)):
+                        raise ValueError(f"solve_nhqp: level_W[{k}] must be a contiguous float64 tensor [>= {B}][{mk}][{mk}] on {self.device}")
                     opt.level_W[k] = Wk.data_ptr()
         qb = self._qp_batch(B)
         abi.check(self._lib.osot_nhqp_solve(self._h, C.byref(qb), C.byref(opt), _stream_ptr(self.device, self.stream)), "osot_nhqp_solve")
