@@ -28,9 +28,29 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (AMD public spec; not in MI355X_MICROARCH.md)
+FP64_SPEC_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (AMD public spec; not in MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
-PMC_PROFILE = os.path.join("profiles", "r05_pmc_kernels.json")
+PMC_PROFILE = os.path.join("profiles", "r06_pmc_kernels.json")
+FP64_PEAK_FILE = os.path.join("profiles", "r06_fp64_peak.json")   # tools/ubench_fp64_peak.hip on the GPU box ("verify with a micro-benchmark")
+SIMDS, PEAK_CLOCK_HZ = 1024, 2.4e9     # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md's throughput tables are quoted at 2.4 GHz
+
+
+def fp64_peak():
+    """(TFLOP/s, where it comes from): the MEASURED dependent-free v_fma_f64 / v_mfma_f64_16x16x4 rate of an MI355X
+    (profiles/r06_fp64_peak.json, the committed output of tools/ubench_fp64_peak.hip), the better of the two -- the kernels use
+    both units; AMD's public figure when no measurement is committed"""
+    try:
+        d = json.load(open(os.path.join(ROOT, FP64_PEAK_FILE)))
+        v = max(float(d["v_fma_f64_tflops"]), float(d["v_mfma_f64_16x16x4_tflops"]))
+        if 10.0 < v < 200.0:
+            return v, (FP64_PEAK_FILE + f" (tools/ubench_fp64_peak.hip, measured on an MI355X: v_fma_f64 {d['v_fma_f64_tflops']} / "
+                       f"v_mfma_f64_16x16x4 {d['v_mfma_f64_16x16x4_tflops']} TFLOP/s; AMD's public figure is {FP64_SPEC_TFLOPS})")
+    except Exception:
+        pass
+    return FP64_SPEC_TFLOPS, "AMD public FP64 vector = matrix spec (no measurement committed under " + FP64_PEAK_FILE + ")"
+
+
+FP64_PEAK_TFLOPS, FP64_PEAK_SOURCE = fp64_peak()
 
 
 def algo_flops_per_solve(plan):
@@ -119,6 +139,27 @@ def pmc_traffic(kernels):
         return None, None
 
 
+def pmc_mfma_busy(kernels, step_ms):
+    """north_star's "MFMA utilisation against gfx950 peak" of one STEP: SQ_VALU_MFMA_BUSY_CYCLES of the step's launches (the committed
+    PMC passes, same kernel-source hash as pmc_traffic; the counter counts CYCLES, MI355X_MICROARCH.md) over the cycles the chip's 1024
+    matrix cores have in the step at the peak clock.  None without matching passes."""
+    if not kernels or not step_ms:
+        return None
+    try:
+        pm = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
+        if pm.get("kernel_source_sha") != kernel_source_sha():
+            return None
+        busy = 0.0
+        for name, wgs, count in kernels:
+            rows = [r for r in pm["kernels"] if name in r["kernel"] and r["workgroups"] == wgs and "SQ_VALU_MFMA_BUSY_CYCLES" in r.get("per_launch", {})]
+            if not rows:
+                return None
+            busy += count * max(rows, key=lambda r: r["launches"])["per_launch"]["SQ_VALU_MFMA_BUSY_CYCLES"]
+        return busy / (step_ms * 1e-3 * PEAK_CLOCK_HZ * SIMDS)
+    except Exception:
+        return None
+
+
 def hbm_roofline(bytes_per_instance, B, step_ms, kernels, kernel_label):
     """roofline block of a path that is far from both roofs (nHQP, eHQP, ADMM, kinematics): bound "hbm", achieved = the
     path's ALGORITHMIC bytes per step / step time, traffic = PMC bytes of the step's kernels"""
@@ -136,9 +177,9 @@ def roofline_of(plan, Bl, kern_ms, launches, kernel_name, traffic=None, traffic_
     gbs = Bl * nbytes / ks / 1e9
     return ({"bound": "mfma", "kernel": kernel_name, "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
              "frac": tf / FP64_PEAK_TFLOPS, "traffic": traffic, "avg_launch_ms": kern_ms, "launches": launches,
-             "algorithmic_flops_per_solve": flops,
-             "note": "fp64 FMA roof (nominal algorithmic flops; AI ~ 20 flop/B > machine balance ~ 10). "
-                     "peak = AMD public FP64 vector/matrix spec, not in MI355X_MICROARCH.md"},
+             "algorithmic_flops_per_solve": flops, "peak_source": FP64_PEAK_SOURCE,
+             "peak_spec": FP64_SPEC_TFLOPS, "frac_of_spec": tf / FP64_SPEC_TFLOPS,
+             "note": "fp64 FMA roof (nominal algorithmic flops; AI ~ 20 flop/B > machine balance ~ 10)"},
             {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
              "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_solve": nbytes})
 
@@ -947,6 +988,9 @@ def _roof(r):
            "unit": r.get("unit"), "frac": _num(r.get("frac")), "traffic": _num(r.get("traffic"))}
     if r.get("avg_launch_ms") is not None:
         out["avg_launch_ms"] = _num(r.get("avg_launch_ms"))
+    for k in ("peak_spec", "frac_of_spec", "mfma_busy_frac"):
+        if r.get(k) is not None:
+            out[k] = _num(r.get(k))
     return out
 
 
@@ -1012,6 +1056,23 @@ def fit_line(c, limit=None):
     return line
 
 
+def lanes_auto(plan, B, device, front_end="iHQP"):
+    """sub-batch count of a sub-line from the LIBRARY's rule (opensot_amd.parallel.suggest_lanes) over the wavefronts the device
+    holds at once for this plan's kernel (osot_solver_resident_waves / _nhqp): nothing here is tuned per sub-line"""
+    from opensot_amd.parallel import suggest_lanes
+    from opensot_amd.solver import BatchedStack
+    probe = BatchedStack(plan, 1, device=device, want_levels=False)
+    resident = probe.resident_waves_nhqp() if front_end == "nHQP" else probe.resident_waves()
+    return suggest_lanes(B, resident)
+
+
+def streams_for(streams, n, device):
+    """the caller's streams first (fresh ones can land on a hardware queue another lane already uses), more where a sub-line has more lanes"""
+    if streams is None:
+        return None
+    return list(streams[:n]) + [torch.cuda.Stream(device=device) for _ in range(max(0, n - len(streams)))]
+
+
 def sub_leaf(lf, lo, hi):
     """rows [lo, hi) of a numpy leaf dict (opensot_amd.synth layout)"""
     cut = lambda a: None if a is None else a[lo:hi]
@@ -1054,9 +1115,11 @@ def main():
     ap.add_argument("--cycles", type=int, default=4,
                     help="distinct, temporally coherent control cycles the steps rotate through (SURVEY 8d: cycle t+1 = "
                          "cycle t + 1 %% perturbation of every input, Jacobians included); 1 = repeat one cycle")
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("OSOT_BENCH_LANES", "2")),
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("OSOT_BENCH_LANES", "0")),
                     help="sub-batches per GPU, each on its own stream with no join between steps "
-                         "(opensot_amd.parallel.PipelinedCycle); 1 = one launch per step")
+                         "(opensot_amd.parallel.PipelinedCycle); 1 = one launch per step; 0 (default) = the library's rule: "
+                         "opensot_amd.parallel.suggest_lanes over the wavefronts the device holds for the plan's kernel "
+                         "(osot_solver_resident_waves), for the headline and every sub-line")
     ap.add_argument("--no-graph", action="store_true",
                     help="submit every launch of the timed steps one by one instead of replaying a HIP graph per lane "
                          "(the graph form is used where a lane's step is the solver's own launch: one GPU, no gather)")
@@ -1099,7 +1162,8 @@ def main():
     Bg = Bl * world
     lo, hi = shard_range(Bg, rank, world)
     assert hi - lo == Bl
-    S = max(1, min(args.lanes, Bl))
+    plan_probe, _ = synth.make_velocity_stack(args.config, 1, seed=1)
+    S = max(1, min(args.lanes, Bl)) if args.lanes > 0 else (2 if stub else lanes_auto(plan_probe, Bl, local_rank))
     device = torch.device("cpu") if stub else torch.device("cuda", local_rank)
     sync = (lambda: None) if stub else torch.cuda.synchronize
     # every rank generates only its own shard (seed = 1000*config + rank)
@@ -1288,6 +1352,7 @@ def main():
             # not the time the chip needed for its instances.  The roofline figures therefore take the time of a whole STEP (all
             # lanes; it contains every launch of the step plus the order kernels and launch gaps, so it under-states the kernel).
             step_ms = 1e3 * elapsed / args.steps
+            mfma_busy = pmc_mfma_busy([("osot_cycle_kernel<32, false, true>", Bl // S + 1, S)], step_ms)
             rf, rh = roofline_of(plan, Bl, step_ms if S > 1 else kern_ms, launches,
                                  "osot_cycle_kernel<32,false,true> (AutoStack::update + the whole cascade of an instance by one wavefront: "
                                  "fp64 MFMA H build + blocked Cholesky + null-space elimination, VALU/LDS active set; the BOX instantiation: "
@@ -1308,6 +1373,10 @@ def main():
                 rf["avg_launch_ms_source"] = "HIP events bracketing every fourth launch on the lane's stream, in the timed (stream-launch) pass"
             rf["launch_batch"] = Bl // S
             rf["concurrent_launches"] = S
+            # MFMA utilisation of the step against the chip's matrix cores at the peak clock (north_star asks for it beside the HBM GB/s)
+            rf["mfma_busy_frac"] = mfma_busy
+            rf["mfma_busy_source"] = (PMC_PROFILE + ": SQ_VALU_MFMA_BUSY_CYCLES of the step's launches / (step time x 2.4 GHz x 1024 SIMDs)"
+                                      if mfma_busy is not None else "no PMC passes committed for this kernel source")
             if S > 1:
                 rf["time_base"] = ("ms_per_step (whole-job): %d launches of %d instances overlap on the chip, so achieved = algorithmic "
                                    "flops of a step / step time; avg_launch_ms is one launch's own (overlapped) duration as the HIP "
@@ -1330,18 +1399,20 @@ def main():
                     oc[key] = time_config(name, B, local_rank, steps=st_, lanes=S, streams=streams)
                 except Exception as e:
                     oc[key] = {"error": str(e)}
-            # THREE sub-batches for the 35-coordinate stacks (tools/exp_coman_lanes3.py: S1-S3 equal to two within 0.5 %, S4 4.39 -> 4.68 M):
-            # the 40-lane kernel holds 1792 wavefronts at once (22 KB of LDS each), 1365 instances are one round, 2048 one and a seventh
-            nc3 = 3 if (streams is not None and S >= 2) else S
-            sc3 = None if streams is None else (list(streams) + [torch.cuda.Stream(device=device) for _ in range(max(0, nc3 - len(streams)))])
+            # sub-batches by the library's rule (suggest_lanes: the 40-lane kernel holds 1792 wavefronts at once -- 22 KB of LDS each --, so
+            # 4096 robots go as three launches of one round each; rounds 4-5 found the same count by hand, tools/exp_coman_lanes3.py)
             for which in ("S1", "S2", "S3", "S4"):
                 try:
-                    oc["COMAN35_" + which] = time_coman35(which, 4096, local_rank, lanes=nc3, streams=sc3)
+                    nl = lanes_auto(coman_stack(which, 35), 4096, local_rank) if (streams is not None and S >= 2) else S
+                    oc["COMAN35_" + which] = time_coman35(which, 4096, local_rank, lanes=nl, streams=streams_for(streams, nl, device))
+                    oc["COMAN35_" + which]["lanes"] = nl
                 except Exception as e:
                     oc["COMAN35_" + which] = {"error": str(e)[:300]}
             for which in ("S1", "S2", "S3", "S4"):   # the same four through the reference's null-space front-end (published: 0.2969 / 0.2637 / 0.3191 / 0.3721 ms per solve)
                 try:
-                    oc[f"COMAN35_{which}_nHQP"] = time_coman35(which, 4096, local_rank, steps=6, warmup=2, front_end="nHQP", lanes=S, streams=streams)
+                    nl = lanes_auto(coman_stack(which, 35), 4096, local_rank, front_end="nHQP") if (streams is not None and S >= 2) else S
+                    oc[f"COMAN35_{which}_nHQP"] = time_coman35(which, 4096, local_rank, steps=6, warmup=2, front_end="nHQP", lanes=nl, streams=streams_for(streams, nl, device))
+                    oc[f"COMAN35_{which}_nHQP"]["lanes"] = nl
                 except Exception as e:
                     oc[f"COMAN35_{which}_nHQP"] = {"error": str(e)[:300]}
             try:
@@ -1360,11 +1431,10 @@ def main():
             except Exception as e:
                 oc["C5_coherent"] = {"error": str(e)}
             try:
-                # THREE sub-batches (tools/exp_nhqp_lanes.py: 5.32 -> 5.71 M): the 32-wide preparation holds 1536 wavefronts at once (25 KB of
-                # LDS each), so a launch of 1365 instances is one round of the chip where 2048 are one and a third
-                n3 = 3 if (streams is not None and S >= 2) else S
-                s3 = None if streams is None else (list(streams) + [torch.cuda.Stream(device=device) for _ in range(max(0, n3 - len(streams)))])
-                oc["nHQP_C3"] = time_nhqp(4096, local_rank, steps=10, warmup=3, lanes=n3, streams=s3)      # (ten timed steps: at five the fill and drain of three lanes is a tenth of the region)
+                # sub-batches by the library's rule over the preparation kernels' resident wavefronts (osot_solver_resident_waves_nhqp)
+                n3 = lanes_auto(synth.make_velocity_stack("C3", 1, seed=1)[0], 4096, local_rank, front_end="nHQP") if (streams is not None and S >= 2) else S
+                oc["nHQP_C3"] = time_nhqp(4096, local_rank, steps=10, warmup=3, lanes=n3, streams=streams_for(streams, n3, device))      # (ten timed steps: at five the fill and drain of three lanes is a tenth of the region)
+                oc["nHQP_C3"]["lanes"] = n3
             except Exception as e:
                 oc["nHQP_C3"] = {"error": str(e)}
             try:

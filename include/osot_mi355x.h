@@ -413,6 +413,10 @@ typedef struct {
     const double* level_W[OSOT_MAX_LEVELS];
 } osot_nhqp_options;
 int osot_nhqp_solve(osot_solver* s, const osot_qp_batch* batch, const osot_nhqp_options* options, void* hip_stream);
+/* instances the device works on at once in the null-space front-end's level preparation (the kernels a solve's time goes to; the
+ * level with the fewest resident wavefronts counts): what a sub-batch size is chosen against, like osot_solver_resident_waves for
+ * the cascade (opensot_amd/parallel.py: suggest_lanes).  opt: as for osot_nhqp_solve (its free_vars decide which kernel a level takes). */
+int osot_solver_resident_waves_nhqp(osot_solver* s, const osot_nhqp_options* opt, int* waves);
 
 /* ---- the equality-only front-end: OpenSoT::solvers::eHQP (src/solvers/eHQP.cpp:64-95, 124-146) -----------
  * Same stack, same assembled arrays (A_k, b_k, w_k or WA_k / Wb_k) as osot_ihqp_solve; the constraints and bounds of the

@@ -144,7 +144,7 @@ SYMBOLS = [
     "osot_plan_validate", "osot_plan_level_rows", "osot_plan_constraint_rows",
     "osot_plan_stored_constraint_rows",
     "osot_solver_create", "osot_solver_destroy", "osot_stack_update", "osot_ihqp_solve", "osot_cycle", "osot_nhqp_solve", "osot_ehqp_solve",
-    "osot_solver_kernel_time_ms", "osot_solver_set_timing", "osot_solver_set_schedule", "osot_solver_set_hotstart", "osot_solver_set_specialisation", "osot_solver_set_task_active", "osot_solver_resident_waves",
+    "osot_solver_kernel_time_ms", "osot_solver_set_timing", "osot_solver_set_schedule", "osot_solver_set_hotstart", "osot_solver_set_specialisation", "osot_solver_set_task_active", "osot_solver_resident_waves", "osot_solver_resident_waves_nhqp",
     "osot_id_rows", "osot_id_force_gains", "osot_computed_torque", "osot_kin_create", "osot_kin_destroy", "osot_kinematics", "osot_control_cycle", "osot_control_rollout", "osot_solver_profile_phases",
     "osot_backend_create", "osot_backend_destroy", "osot_backend_init_problem",
     "osot_backend_update_task", "osot_backend_update_constraints", "osot_backend_update_bounds",
@@ -207,6 +207,7 @@ def lib():
     L.osot_solver_set_specialisation.argtypes = [vp, C.c_int]
     L.osot_solver_set_task_active.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.osot_solver_resident_waves.argtypes = [vp, ip]
+    L.osot_solver_resident_waves_nhqp.argtypes = [vp, vp, ip]
     L.osot_id_force_gains.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, dp, dp, vp, vp, C.c_longlong, vp, vp]
     L.osot_id_rows.argtypes = [C.POINTER(IdModel), vp, C.c_longlong, vp, C.c_longlong, C.c_int, vp, vp, vp, vp, vp]
     L.osot_computed_torque.argtypes = [C.POINTER(IdModel), vp, vp, vp, C.c_double, vp]

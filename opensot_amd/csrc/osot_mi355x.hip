@@ -68,6 +68,10 @@ int ensure_lds(K kernel, size_t bytes) {
 // calls f with the padded size of the cascade instantiation as a compile-time constant (make_dev_plan picks it: 32, 56 or 64)
 template <typename F>
 static inline auto by_np(int T, F&& f) {
+#ifdef OSOT_ONLY_NP32      // developer builds (tools/build_variant.sh NAME -DOSOT_ONLY_NP32): the 32-lane instantiations only -- a fifth of the
+    (void)T;               // compile time for A/B runs of the headline kernel; every other layout would run THIS one: never shipped
+    return f(std::integral_constant<int, 32>{});
+#endif
     if (T == 32) return f(std::integral_constant<int, 32>{});
     if (T == 40) return f(std::integral_constant<int, 40>{});
     if (T == 56) return f(std::integral_constant<int, 56>{});
@@ -456,6 +460,37 @@ int osot_nhqp_solve(osot_solver* s, const osot_qp_batch* b, const osot_nhqp_opti
 int osot_solver_resident_waves(osot_solver* s, int* waves) {
     if (!s || !waves) return fail(OSOT_ERR_INVALID, "null argument");
     *waves = s->slots;
+    return OSOT_OK;
+}
+
+// the same for the null-space front-end: its level-preparation kernels are what a solve's time goes to, and the one with the fewest
+// resident wavefronts sets the round (static 25 KB of LDS at n <= 32: six per CU; the 64-column and wide kernels by the plan's sizes)
+int osot_solver_resident_waves_nhqp(osot_solver* s, const osot_nhqp_options* opt, int* waves) {
+    if (!s || !waves) return fail(OSOT_ERR_INVALID, "null argument");
+    DeviceGuard guard(s->device);
+    if (!guard.ok) return fail(OSOT_ERR_HIP, "hipSetDevice failed");
+    const osot_plan_desc& pl = s->plan;
+    int fv[OSOT_MAX_LEVELS]; const char* why = "";
+    int rc = nhqp_validate(pl, opt, fv, &why);
+    if (rc != OSOT_OK) return fail(rc, why);
+    int cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device));
+    int least = 1 << 30;
+    for (int k = 0; k < pl.n_levels; ++k) {
+        int m, ma; plan_level_rows(&pl, k, &m, &ma);
+        int per_cu = 0;
+        hipError_t e;
+        if (nhqp_level_is_wide(m, fv[k])) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, osot_nhqp_prepare_wide_kernel, 64, nhqp_prepare_wide_lds_bytes(m, pl.n));
+        else if (pl.n > 32) {
+            if (m <= 32) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, osot_nhqp_prepare64_kernel<32>, 64, nhqp_prepare64_lds_bytes(32, pl.n));
+            else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, osot_nhqp_prepare64_kernel<64>, 64, nhqp_prepare64_lds_bytes(64, pl.n));
+        }
+        else if (m <= 32) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, osot_nhqp_prepare_kernel<32>, 64, 0);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, osot_nhqp_prepare_kernel<64>, 64, 0);
+        if (e != hipSuccess || per_cu < 1) return fail(OSOT_ERR_HIP, "occupancy query of a preparation kernel failed");
+        if (per_cu * cus < least) least = per_cu * cus;
+    }
+    *waves = least;
     return OSOT_OK;
 }
 

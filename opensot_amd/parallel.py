@@ -154,6 +154,33 @@ def lane_ranges(B, lanes):
     return [shard_range(B, i, lanes) for i in range(lanes)]
 
 
+def suggest_lanes(B, resident, min_lanes=2, max_lanes=4):
+    """How many sub-batches ("lanes") a rank's B instances are driven as (PipelinedCycle), from what the chip holds at once.
+
+    One wavefront solves one instance and the device keeps `resident` of them in flight for the plan's kernel
+    (BatchedStack.resident_waves() = osot_solver_resident_waves: CUs x wavefronts per CU from the kernel's register and LDS
+    footprint; resident_waves_nhqp() for the null-space front-end), so a lane's launch of b = B / S instances runs as
+    ceil(b / resident) ROUNDS, and the part of its last round that stays empty is slots nothing fills until the launch's longest
+    instance ends.  The rule: among min_lanes .. max_lanes take the count whose launches waste the smallest fraction of their rounds,
+    1 - b / (ceil(b / resident) resident); ties go to the fewer lanes (fewer, larger launches: less fill and drain per timed region).
+    At least two lanes so that one lane's tail is covered by the other's next launch (24.3 -> 27.1 M on one stream
+    against two).  What it reproduces (rounds 4-5 found these by hand, tools/exp_*lanes*.py): BASELINE config 3, 4096 instances on
+    2048 slots -> 2 (two launches of exactly one round); the 35-coordinate COMAN stacks on the 40-lane kernel's 1792 slots -> 3
+    (1365 = one round; 2048 would be a round and a seventh); the null-space front-end at config 3 on 1536 slots -> 3; its 64-column
+    preparation on 1024 slots -> 2 (2048 = exactly two rounds)."""
+    B, resident = int(B), max(1, int(resident))
+    if B < 2 * min_lanes:
+        return 1
+    best, best_waste = min_lanes, None
+    for S in range(min_lanes, max_lanes + 1):
+        b = -(-B // S)                               # the largest lane (shard_range hands the remainder to the first lanes)
+        rounds = -(-b // resident)
+        waste = 1.0 - b / float(rounds * resident)
+        if best_waste is None or waste < best_waste - 1e-9:
+            best, best_waste = S, waste
+    return best
+
+
 class PipelinedCycle:
     """A rank's shard as S contiguous SUB-BATCHES ("lanes"), each with its own solver state and its own stream, and NO
     join between steps: lane j's step t+1 is enqueued behind lane j's step t only.  That is exactly the dependency the

@@ -336,6 +336,12 @@ class BatchedStack:
         abi.check(self._lib.osot_solver_resident_waves(self._h, C.byref(v)), "osot_solver_resident_waves")
         return v.value
 
+    def resident_waves_nhqp(self):
+        """the same for the null-space front-end (its level-preparation kernels; default options)"""
+        v = C.c_int(0)
+        abi.check(self._lib.osot_solver_resident_waves_nhqp(self._h, None, C.byref(v)), "osot_solver_resident_waves_nhqp")
+        return v.value
+
     def set_schedule(self, longest_first=True):
         """dispatch order inside solve(): longest-first from the previous solve's iteration counts (default)
         or plain instance order; results are identical either way."""

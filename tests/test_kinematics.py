@@ -620,6 +620,38 @@ def test_control_cycle_in_one_launch_matches_the_three_calls(mode, gpu_device):
 
 
 @pytest.mark.gpu
+def test_control_cycle_writes_pair_outputs_on_a_plan_without_rows(gpu_device):
+    """a plan WITHOUT constraint rows picks the BOX instantiation, whose kinematics stage is compiled without the
+    collision-pair stage; a model with pairs whose batch asks for pair_dist / pair_J must still get them written (the launch takes
+    the general instantiation) -- they used to keep stale data with no error.  Compared with osot_kinematics' own outputs."""
+    import torch
+    from opensot_amd.solver import BatchedStack
+    m = kin.humanoid32_pairs(kin.humanoid32())
+    n, B, P = m.n, 37, len(m.pairs)
+    dev = torch.device("cuda", 0)
+    f64 = dict(dtype=torch.float64, device=dev)
+    rng = np.random.default_rng(41)
+    q = torch.as_tensor(rng.uniform(-0.4, 0.4, (B, n)), **f64).contiguous()
+    levels = [[Task(abi.TASK_CARTESIAN, 6, lam=0.1, name="r_wrist")], [Task(abi.TASK_POSTURAL, n, lam=0.01, name="postural")]]
+    bounds = [Bound(abi.BOUND_VELOCITY_LIMITS, dT=0.01, name="vl")]
+    plan = StackPlan(n=n, levels=levels, bounds=bounds, rowblocks=[], eps_abs=eps_abs_from_factor(1e6))      # nc == 0: BOX
+    st = BatchedStack(plan, B, device=0, want_levels=False)
+    K = kin.Kinematics(m, device=0)
+    pose = torch.zeros((B, 12), **f64)
+    dist = torch.full((B, P), 7.0, **f64); Jd = torch.full((B, P, n), 7.0, **f64)
+    kw = dict(frame_pose={1: pose}, frame_J={1: (st.A[0], 0)}, pair_dist=dist, pair_J=(Jd, 0))
+    dist_ref = torch.zeros((B, P), **f64); Jd_ref = torch.zeros((B, P, n), **f64)
+    K.forward(q, frame_pose={1: pose}, frame_J={1: (st.A[0], 0)}, pair_dist=dist_ref, pair_J=(Jd_ref, 0))
+    torch.cuda.synchronize()
+    leaf = {"B": B, "task": [[(pose, pose.clone(), None)], [(q, q.clone(), None)]], "bound": [(torch.full((B, n), 2.0, **f64), None, None)], "rows": []}
+    st.control_cycle(K, K.batch_args(q, **kw), leaf, q_integrate=None)
+    torch.cuda.synchronize()
+    assert (st.status[:B] == 0).all()
+    assert torch.equal(dist, dist_ref) and torch.equal(Jd, Jd_ref)
+    assert float(dist.max()) < 5.0          # (not the fill value: written)
+
+
+@pytest.mark.gpu
 def test_control_cycle_in_one_launch_on_the_35_coordinate_coman(gpu_device):
     """osot_control_cycle on the reference's own robot (35 coordinates: the 56-lane kernels, the 64-joint producer with one
     robot per wavefront): the stack of coman_ik.cpp:425-449, 20 closed-loop steps, bit-identical to osot_kinematics + osot_cycle

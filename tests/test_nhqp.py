@@ -513,3 +513,32 @@ def test_nhqp_dense_weight_gpu(oracle, gpu_device, n, rows0, rows1):
     assert np.abs(st.dq[:B].cpu().numpy() - ref["dq"]).max() < 1e-8 * max(1.0, np.abs(ref["dq"]).max())
     with pytest.raises(RuntimeError, match="level_W"):
         st.solve_nhqp(B)
+
+
+@pytest.mark.gpu
+def test_nhqp_option_ranges_and_list_lengths_are_refused(gpu_device):
+    """ADVICE r5: nHQP::setMinSingularValueRatio throws outside [0, 1] and for a vector whose size is not the number of layers
+    (nHQP.cpp:127-152); here OSOT_ERR_INVALID / ValueError instead of a silently different lifting rule"""
+    import torch
+    from opensot_amd import abi, synth
+    from opensot_amd.solver import BatchedStack
+    B = 8
+    plan, leaf = synth.make_velocity_stack("C3", B, seed=3)
+    st = BatchedStack(plan, B, device=0, want_levels=False)
+    st.update(st.load_leaf(leaf))
+    for bad in (-0.1, 1.5, float("nan")):
+        with pytest.raises(RuntimeError):
+            st.solve_nhqp(B, min_sv_ratio=bad)
+        with pytest.raises(RuntimeError):
+            st.solve_nhqp(B, min_sv_ratio=[0.05, bad, 0.05])
+    with pytest.raises(ValueError):
+        st.solve_nhqp(B, min_sv_ratio=[0.05, 0.05])                 # two entries, three levels
+    with pytest.raises(ValueError):
+        st.solve_nhqp(B, ab_regularization=[True, True, True, True])
+    W = torch.eye(3, dtype=torch.float32, device="cuda").repeat(B, 1, 1)
+    with pytest.raises(ValueError):
+        st.solve_nhqp(B, level_W=[W, None, None])                   # float32
+    st.solve_nhqp(B, min_sv_ratio=[0.05, 0.0, 1.0])                 # the ends of the range are values
+    torch.cuda.synchronize()
+    assert (st.status[:B] == 0).all()
+    assert st.resident_waves_nhqp() >= 256 and st.resident_waves() >= 256
