@@ -446,11 +446,16 @@ __device__ inline int factor_tiles32(const WaveCtx<32>& w, double (&Hf)[16], dou
             const int j = 4 * p + qq;
             const int lj = (4 * rp + qq) + 16 * qq;   // lane (a = j & 15, q = qq) holds H[j][j] in Pn[Ip]
             double piv = bcast(Pn[Ip], lj);
+#ifdef OSOT_X_OLD_CHOL32
             if (!(piv > 0.0)) { bad = true; piv = 1.0; }
+#else
+            bad = bad || !(piv > 0.0);      // (a non-positive or NaN pivot poisons what follows; the routine returns NOT_PD and x = 0 then)
+#endif
             double sq, rs;
             fast_sqrt_rsqrt(piv, sq, rs);
             rsq[qq] = rs;
             const bool mine = (tq == qq);
+#ifdef OSOT_X_OLD_CHOL32
 #pragma unroll
             for (int X = 0; X < 2; ++X) {
                 const int i = 16 * X + ta;
@@ -458,6 +463,20 @@ __device__ inline int factor_tiles32(const WaveCtx<32>& w, double (&Hf)[16], dou
                 Pn[X] = mine ? scaled : Pn[X];
                 Rp[X] = mine ? Rp[X] * rs : Rp[X];
             }
+#else
+            // Round 6 (instruction diet): the column's quarter-row is scaled by ONE masked multiplier (1 / L[j][j] in the lanes that hold
+            // it, 1 elsewhere) instead of three selects per register.  The entries on and above the diagonal are NOT cleared here -- by
+            // symmetry they hold the upper triangle of the trailing matrix, which nothing below reads: the later columns of the panel take
+            // L[4p + q][j] from BELOW the diagonal, the trailing products mask the rows of the panel, and the forward substitution's
+            // staging clears them once per panel (below).  The entries below the diagonal get the same bits as before.
+            (void)sq;
+            const double mul = mine ? rs : 1.0;
+#pragma unroll
+            for (int X = 0; X < 2; ++X) {
+                if (!(Ip == 1 && X == 0)) Pn[X] *= mul;
+                if (!(Ip == 0 && X == 1)) Rp[X] *= mul;
+            }
+#endif
             if (qq < 3) {
                 const int src = ta + 16 * qq;                     // lane (a, qq): same row, column j
                 const double ljj = __shfl(Pn[Ip], (4 * rp + tq) + 16 * qq, 64);   // L[4p + q][j] for my column 4p + q
@@ -476,8 +495,15 @@ __device__ inline int factor_tiles32(const WaveCtx<32>& w, double (&Hf)[16], dou
             }
         }
         // finished panel (zeros above the diagonal included) -> staging; final rows of L^-1 back into their tiles
+#ifdef OSOT_X_OLD_CHOL32
         PB[tq * 32 + ta] = Pn[0];
         PB[tq * 32 + 16 + ta] = Pn[1];
+#else
+        // staged with zeros ON and above the diagonal (column 4p + tq at rows ta, 16 + ta): a step of the substitution below is then a
+        // plain fma in every lane -- rows at or above the column see a zero and keep their residual
+        PB[tq * 32 + ta] = (Ip == 0 && ta > 4 * p + tq) ? Pn[0] : 0.0;
+        PB[tq * 32 + 16 + ta] = (16 + ta > 4 * p + tq) ? Pn[1] : 0.0;
+#endif
         if (Ip) { L10[rp] = Rp[0]; L11[rp] = Rp[1]; } else { L00[rp] = Rp[0]; }
         wave_sync();
         {   // forward substitution through the panel's four columns: y_j = rhs_j / L[j][j], rhs_i -= L[i][j] y_j below it
@@ -488,7 +514,11 @@ __device__ inline int factor_tiles32(const WaveCtx<32>& w, double (&Hf)[16], dou
             for (int qq = 0; qq < 4; ++qq) {
                 const int j = 4 * p + qq;
                 const double yj = bcast(rhs, j) * rsq[qq];
+#ifdef OSOT_X_OLD_CHOL32
                 rhs = (c == j) ? yj : ((c > j) ? fma(-lrow[qq], yj, rhs) : rhs);
+#else
+                rhs = fma(-lrow[qq], yj, rhs);      // (lane j keeps its residual: y_j = rhs_j / L[j][j] is formed from it at the end)
+#endif
             }
         }
         wave_sync();   // the staging buffer is free for the next panel
@@ -520,6 +550,12 @@ __device__ inline int factor_tiles32(const WaveCtx<32>& w, double (&Hf)[16], dou
     OSOT_TT(1);   // L^-1 store
     OSOT_TT(2);   // (forward substitution: done panel by panel above)
     // L'x = y:  x_c = sum_j (L^-1)[j][c] y_j  (rhs holds y; rows of L^-1 = rows of JT)
+#ifndef OSOT_X_OLD_CHOL32
+    // y_c = (residual of row c) / L[c][c]: the reciprocal is the diagonal of L^-1 that has just been stored -- the very value the
+    // substitution multiplied by when it broadcast y_c (a row of L^-1 starts as a unit row, is scaled once, by 1 / L[c][c], and no
+    // later update reaches its diagonal: exact)
+    rhs *= M2[c * S + c];
+#endif
     if (w.h == 0) w.V[c] = valid ? rhs : 0.0;
     wave_sync();
     const double x = jt_cols_dot<32>(w, w.V);

@@ -205,6 +205,52 @@ __device__ __forceinline__ unsigned bcast_u32(unsigned v, int lane) { return (un
 __device__ __forceinline__ unsigned uniform_u32(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 
 // ---- reductions over the NP columns (lanes with equal h); every lane gets the result ------------------
+// Round 6, MEASURED AND NOT THE DEFAULT (OSOT_X_MFMA_SUM builds it): SUMS ON THE MATRIX CORE.  A sum over the wavefront as two
+// v_mfma_f64_16x16x4 with a constant operand and three additions:
+//   D1 = V B1 with A[m][k] = v(lane m + 16 k): D1[m][n] = sum_k v(m + 16 k) B1[k][n]; lane l holds D1[(l >> 4) + 4 r][l & 15], r = 0..3;
+//   t  = D1[0] + D1[1] + D1[2] + D1[3]      (the partial sums of the rows congruent to l >> 4 mod 4, at column l & 15);
+//   D2 = T 1 with A[m][k] = t(lane m + 16 k): D2[m][n] = sum_k t(m + 16 k) = the total of column m of D1, in EVERY lane.
+// With B1 = ones the total is the sum over all 64 lanes; with B1[k][n] = [(n < 8) == (k < 2)] the columns n < 8 of D1 collect the
+// lanes 0..31 and the columns n >= 8 the lanes 32..63, so D2's rows 0..7 (elements 0, 1 of every lane) carry the sum over the first
+// half of the wavefront and its rows 8..15 (elements 2, 3) the sum over the second: two sums for the price of one.
+// The idea: the DPP network of a 32-lane sum is 8 v_mov_dpp + 4 v_add_f64 + 2 v_permlane16_swap + 1 add on the VALU the two co-resident
+// wavefronts of a SIMD share, ~110 such sums per instance of BASELINE config 3 = 1.4 k of its 10.5 k VALU instructions, while the matrix
+// core is 7 % busy; here the VALU sees three additions.  The measurement (A/B on one box, tools/ab_headline.py, same answers to
+// round-off, all 136 GPU tests green): config 3 32.7 against 33.9 M solves/s at 4096, 32.2 against 33.6 M at 32768; COMAN35 S3 / S4
+// 6.39 / 4.53 against 6.58 / 4.67 M.  1.4 k fewer VALU instructions per instance made the kernel 4 % SLOWER: a sum this way is two
+// dependent 16-pass MFMAs (2 x 64 cycles + the read-after-MFMA wait states) where the network is ~137 cycles, and what bounds these
+// kernels is the length of each wavefront's dependent chain, not the VALU's issue rate ("Round 6").
+#ifdef OSOT_X_MFMA_SUM
+__device__ __forceinline__ double mfma_ones() { return 1.0; }
+// B1[k = lane >> 4][n = lane & 15] of the two-halves form: bit 3 and bit 5 of the lane agree
+__device__ __forceinline__ double mfma_half_selector() {
+    const unsigned l = threadIdx.x;
+    return (((l >> 3) ^ (l >> 5)) & 1u) ? 0.0 : 1.0;
+}
+// (sum over lanes 0..31, sum over lanes 32..63) of v, both in every lane
+__device__ __forceinline__ void wave_sum_halves(double v, double& s0, double& s1) {
+    const v4f64 z = {0.0, 0.0, 0.0, 0.0};
+    const v4f64 d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v, mfma_half_selector(), z, 0, 0, 0);
+    const double t = (d1[0] + d1[1]) + (d1[2] + d1[3]);
+    const v4f64 d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(t, mfma_ones(), z, 0, 0, 0);
+    s0 = d2[0]; s1 = d2[2];
+}
+// sum over all 64 lanes
+__device__ __forceinline__ double wave_sum64(double v) {
+    const v4f64 z = {0.0, 0.0, 0.0, 0.0};
+    const v4f64 d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v, mfma_ones(), z, 0, 0, 0);
+    const double t = (d1[0] + d1[1]) + (d1[2] + d1[3]);
+    const v4f64 d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(t, mfma_ones(), z, 0, 0, 0);
+    return d2[0];
+}
+template <int NP>
+__device__ __forceinline__ double colsum(double v) {
+    if (NP > 32) return wave_sum64(v);
+    double s0, s1;
+    wave_sum_halves(v, s0, s1);
+    return (threadIdx.x & 32u) ? s1 : s0;      // (each half its own sum: the contract of the DPP form, whatever the halves hold)
+}
+#else
 template <int NP>
 __device__ __forceinline__ double colsum(double v) {
     v = row16_sum(v);
@@ -214,6 +260,7 @@ __device__ __forceinline__ double colsum(double v) {
     if (NP > 32) { swap32_pair(v, a, b); v = a + b; }
     return v;
 }
+#endif
 // maximum over the NP columns (lanes with equal h); every lane gets it
 template <int NP>
 __device__ __forceinline__ double colmax(double v) {
@@ -254,6 +301,20 @@ __device__ __forceinline__ int first_lane_equal(double v, double m) {
 // halves exchange their totals (NP = 32; plain two reductions for NP = 64)
 template <int NP>
 __device__ __forceinline__ void colsum2(double va, double vb, double& ra, double& rb) {
+#ifdef OSOT_X_MFMA_SUM
+    if (NP > 32) {
+        // two sums over all 64 lanes: one first stage each, ONE second stage -- lane (m, k) hands over t_a for m < 8 and t_b otherwise,
+        // so rows 0..7 of the product carry sum(va) and rows 8..15 sum(vb)
+        const v4f64 z = {0.0, 0.0, 0.0, 0.0};
+        const v4f64 da = __builtin_amdgcn_mfma_f64_16x16x4f64(va, mfma_ones(), z, 0, 0, 0);
+        const v4f64 db = __builtin_amdgcn_mfma_f64_16x16x4f64(vb, mfma_ones(), z, 0, 0, 0);
+        const double ta = (da[0] + da[1]) + (da[2] + da[3]), tb = (db[0] + db[1]) + (db[2] + db[3]);
+        const v4f64 d2 = __builtin_amdgcn_mfma_f64_16x16x4f64((threadIdx.x & 8u) ? tb : ta, mfma_ones(), z, 0, 0, 0);
+        ra = d2[0]; rb = d2[2];
+        return;
+    }
+    wave_sum_halves((threadIdx.x >= 32) ? vb : va, ra, rb);
+#else
     if (NP > 32) { ra = colsum<64>(va); rb = colsum<64>(vb); return; }
     double v = (threadIdx.x >= 32) ? vb : va;
     v = row16_sum(v);
@@ -261,6 +322,7 @@ __device__ __forceinline__ void colsum2(double va, double vb, double& ra, double
     swap16_pair(v, a, b);
     v = a + b;
     swap32_pair(v, ra, rb);
+#endif
 }
 // v(c,0) + v(c,1): combines the partial results of the two halves (identity for NP = 64)
 template <int NP>

@@ -439,6 +439,9 @@ def test_closed_loop_default_humanoid_stack_relative_tasks(gpu_device):
     import torch
     from opensot_amd.solver import BatchedStack
     m = _relative_model()
+    # the base link of DefaultHumanoidStack is the robot's "Waist" = its PELVIS (the floating-base link): three waist joints and five arm
+    # joints lie between it and a wrist (a 6-D task relative to the torso link would face the arm's five joints alone)
+    m.frames[4] = ("waist", m.names.index("base_yaw"), kin._rpy(0.1, -0.2, 0.3), (0.01, 0.0, 0.05))
     n, B = m.n, 96
     dev = torch.device("cuda", 0)
     f64 = dict(dtype=torch.float64, device=dev)
@@ -481,7 +484,7 @@ def test_closed_loop_default_humanoid_stack_relative_tasks(gpu_device):
     assert (st.status[:B] == 0).all()
     err = [float((pose_d[f][:, 9:] - pose[f][:, 9:]).norm(dim=1).max()) for f in range(4)]
     assert err0[0] > 0.05 and err0[1] > 0.05
-    assert err[0] < 0.05 * err0[0] and err[1] < 0.05 * err0[1]        # the wrists reached their waist-frame targets
+    assert err[0] < 0.1 * err0[0] and err[1] < 0.1 * err0[1]          # the wrists reached their waist-frame targets (12 rows, 13 joints, one level)
     assert err[2] < 1e-4 and err[3] < 1e-4                            # the feet (first level) kept their world / relative poses
     i = 5
     o = pykin.forward(m, q[i].cpu().numpy())
