@@ -241,7 +241,7 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
 #endif
         bool lowrank = false;   // few stored rows: J and x in closed form, no H, no factorisation (lowrank_prepare32)
         double xprep = 0.0;
-        if constexpr (NP == 32) {
+        if constexpr (NP == 32 || (NP == 40 && kLowRank40)) {
 #ifndef OSOT_X_NO_LOWRANK
             // (five or six stored rows -- one Cartesian task -- only next to a Postural block over every variable, BASELINE config 2: D >= w
             //  there.  With D = eps alone the scaled rows carry 1 / sqrt(eps) and six of them lose what the Cholesky path keeps: at the
@@ -256,11 +256,10 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
                 const double wpost = postc ? (wk ? wk[ma + c] : 1.0) : 0.0;
                 double cvec = ((D.c[k] && valid) ? D.c[k][inst * n + c] : 0.0) + greg;
                 if (postc) cvec -= wpost * bk[ma + c];
-                const WaveCtx<32>& w32 = reinterpret_cast<const WaveCtx<32>&>(w);
                 const bool has_c = D.c[k] != nullptr || npost > 0 || D.b_reg != nullptr;
-                if (ma <= 3) lowrank_prepare32<3>(w32, Ak, bk, wk, ma, P.eps_abs + wpost + dreg, cvec, has_c, xprep);
-                else if (kLowRankMax <= 4 || ma <= 4) lowrank_prepare32<(kLowRankMax < 4 ? kLowRankMax : 4)>(w32, Ak, bk, wk, ma, P.eps_abs + wpost + dreg, cvec, has_c, xprep);
-                else lowrank_prepare32<kLowRankMax>(w32, Ak, bk, wk, ma, P.eps_abs + wpost + dreg, cvec, has_c, xprep);
+                if (ma <= 3) lowrank_prepare<NP, 3>(w, Ak, bk, wk, ma, P.eps_abs + wpost + dreg, cvec, has_c, xprep);
+                else if (kLowRankMax <= 4 || ma <= 4) lowrank_prepare<NP, (kLowRankMax < 4 ? kLowRankMax : 4)>(w, Ak, bk, wk, ma, P.eps_abs + wpost + dreg, cvec, has_c, xprep);
+                else lowrank_prepare<NP, kLowRankMax>(w, Ak, bk, wk, ma, P.eps_abs + wpost + dreg, cvec, has_c, xprep);
             }
         }
         if (lowrank) {
@@ -599,7 +598,7 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
         if (NP > 32) {   // must be inlined: hacc would otherwise be passed through scratch memory
             OSOT_ALWAYS_INLINE_CALL st = gi_solve<NP, PROF, BOX>(w, nrows, g, diag_h, hdiag, hacc,
                                                                    has_box, lb, ub, P.max_iter, any, x, x, iters, prof, slack,
-                                                                   false, 0.0, hotcode, hotk);
+                                                                   lowrank, xprep, hotcode, hotk);
         } else {          // NP = 32: inlined as well (as a CALL the solver spends ~50 % more cycles: the tiles travel through scratch)
             OSOT_ALWAYS_INLINE_CALL st = gi_solve<NP, PROF, BOX>(w, nrows, g, diag_h, hdiag, hacc,
                                            has_box, lb, ub, P.max_iter, any, x, x, iters, prof, slack, lowrank, xprep,

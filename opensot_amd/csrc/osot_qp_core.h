@@ -1065,6 +1065,230 @@ __device__ inline int nullspace_equalities32(const WaveCtx<32>& w, int n_eq, dou
     return me;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Round 6: the SAME null-space elimination for the 40-lane layout (33 .. 38 variables: the reference's own 35-coordinate COMAN).
+// There the last level of every published stack (examples/cpp/coman_ik.cpp:425-449) is the Postural task under 27 equality rows --
+// the feet as TaskToConstraint rows (12), the CoM level (3) and the wrists (12) -- and until now each of them was one Householder
+// reflection of the full 40 x 40 J: 159 k of an S3 solve's 550 k clocks (profiles/r06_phase_cycles_COMAN35.txt).  E lives in
+// 2 x 3 tiles of 16 x 16 (rows <= 32, columns <= 48, zero beyond n), the panel step is nullspace_equalities32's with three
+// column registers per quarter-row and six trailing products per panel; the column store (48 columns, stride 33) fits the idle M2
+// (41 x 41).  Phantom lanes (40 .. 63 of the layout) hold tile columns like every other lane here: the tile coordinates come from the
+// PHYSICAL lane, the vector phases behind the elimination from the layout's column index as everywhere else.
+template <int NP, bool PROF>
+__device__ inline int nullspace_equalities_wide(const WaveCtx<NP>& w, int n_eq, double hdiag, double g, double xprev,
+                                                double& x_out, long long* prof) {
+    static_assert(NP == 40, "three column tiles: the 40-lane layout (n <= 38)");
+    OSOT_SUB_BEGIN();
+    constexpr int S = WaveCtx<NP>::S;
+    constexpr int TC = 3;
+    const int c = w.c, n = w.n;
+    const int lane = phys_lane();
+    const bool valid = c < n;
+    double* M2 = w.M2;
+    const int ta = lane & 15, tq = lane >> 4;
+    v4f64 Et[2 * TC];   // Et[TC I + C]: tile (I, C) element r holds E[16 I + tq + 4 r][16 C + ta]
+    double emax = 0.0;
+    {
+        unsigned long long rp[8];
+        double ld[8 * TC];
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * I + tq + 4 * r;
+                rp[4 * I + r] = w.rptr[w.eqlist[(row < n_eq) ? row : 0]];
+            }
+        int cc[TC];
+#pragma unroll
+        for (int C = 0; C < TC; ++C) cc[C] = (16 * C + ta < n) ? 16 * C + ta : 0;
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned long long pr = rp[4 * I + r];
+                const auto* base = OSOT_GLOBAL_F64((pr & 1ull) ? w.safe_row : pr);
+#pragma unroll
+                for (int C = 0; C < TC; ++C) ld[TC * (4 * I + r) + C] = base[cc[C]];
+            }
+        // (all 24 loads in flight before the first select: see OSOT_KEEP16)
+        OSOT_KEEP12(ld, 0);
+        OSOT_KEEP12(ld, 12);
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned long long pr = rp[4 * I + r];
+                const bool unit = (pr & 1ull) != 0ull;
+                const int ucol = (int)(pr >> 1);
+                const bool in = (16 * I + tq + 4 * r) < n_eq;
+#pragma unroll
+                for (int C = 0; C < TC; ++C) {
+                    const int col = 16 * C + ta;
+                    const double v = unit ? ((col == ucol) ? 1.0 : 0.0) : ((col < n) ? ld[TC * (4 * I + r) + C] : 0.0);
+                    const double e = in ? v : 0.0;
+                    Et[TC * I + C][r] = e;
+                    emax = fmax(emax, fabs(e));
+                }
+            }
+    }
+    emax = colmax<64>(emax);
+    const double tol = 1.0e-9 * emax;
+    OSOT_SUB_END(PH_EQ_D);
+    // ---- Gauss-Jordan with column pivoting, four rows at a time (nullspace_equalities32's panel step; the column of a candidate is
+    // packed into the SIX low bits of its fp32 magnitude: 48 columns)
+    unsigned long long basicmask = 0ull;
+    double* colstore = M2;                                      // E by columns, stride 33: 48 x 33 doubles of the 41 x 41 M2
+    int* pivcol = reinterpret_cast<int*>(w.M1);
+    const unsigned tolbits = uniform_u32(f32_bits((float)tol));
+    const int ta4 = ta << 2, rowbase4 = (lane & 48) << 2;
+    bool nb[TC];
+#pragma unroll
+    for (int C = 0; C < TC; ++C) nb[C] = 16 * C + ta < n;
+    int mypk = -1;
+    auto panel = [&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        constexpr int Ip = p >> 2, rq = p & 3;
+        if (4 * p >= n_eq) return;
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int C = 0; C < TC; ++C)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) colstore[(16 * C + ta) * 33 + 16 * I + tq + 4 * r] = Et[TC * I + C][r];
+        double Pr[TC];
+#pragma unroll
+        for (int C = 0; C < TC; ++C) Pr[C] = Et[TC * Ip + C][rq];
+        int pcq = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = 4 * p + q;
+            if (k < n_eq) {
+                double rraw[TC];
+                unsigned cand = 0u;
+#pragma unroll
+                for (int C = 0; C < TC; ++C) {
+                    rraw[C] = permute_f64(Pr[C], ta4 + 64 * q);                                  // row k at my columns
+                    const unsigned cb = nb[C] ? ((f32_bits((float)fabs(Pr[C])) & ~63u) | (unsigned)(47 - 16 * C - ta)) : 0u;
+                    cand = umax(cand, cb);
+                }
+                const unsigned s = bcast_u32(row16_max_u32(cand), 16 * q);
+                const bool ok = (s & ~63u) > tolbits;
+                const int pcol = 47 - (int)(s & 63u);
+                const int ap = pcol & 15, pt = pcol >> 4;
+                const double fsel = (pt == 0) ? Pr[0] : ((pt == 1) ? Pr[1] : Pr[2]);              // the register that holds column pcol
+                const double piv = bcast(fsel, ap + 16 * q);
+                const double ipv = ok ? fast_rcp(piv) : 0.0;
+                const double f = permute_f64(fsel, (ap << 2) + rowbase4);                        // my panel row's entry at the pivot column
+                const bool myrow = (tq == q);
+                const int pk = ok ? pcol : -1;
+#pragma unroll
+                for (int C = 0; C < TC; ++C) {
+                    const double rs = rraw[C] * ipv;                                             // the scaled pivot row at my columns
+                    Pr[C] = myrow ? rs : fma(-f, rs, Pr[C]);
+                    nb[C] = nb[C] && (16 * C + ta != pk);
+                }
+                basicmask |= ok ? (1ull << pcol) : 0ull;
+                pcq = myrow ? pk : pcq;
+                mypk = (lane == k) ? pk : mypk;
+            } else {
+                pcq = (tq == q) ? -1 : pcq;
+            }
+        }
+        wave_sync();
+        double FA[2];
+#pragma unroll
+        for (int I = 0; I < 2; ++I) {
+            const double v = colstore[(pcq < 0 ? 0 : pcq) * 33 + 16 * I + ta];
+            const bool own = (I == Ip) && ((ta >> 2) == rq);
+            FA[I] = (pcq >= 0 && !own) ? -v : 0.0;
+        }
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int C = 0; C < TC; ++C) Et[TC * I + C] = mfma_f64_16x16x4(FA[I], Pr[C], Et[TC * I + C]);
+#pragma unroll
+        for (int C = 0; C < TC; ++C) Et[TC * Ip + C][rq] = Pr[C];      // the reduced panel back into its registers
+        wave_sync();
+    };
+    panel(std::integral_constant<int, 0>{}); panel(std::integral_constant<int, 1>{});
+    panel(std::integral_constant<int, 2>{}); panel(std::integral_constant<int, 3>{});
+    panel(std::integral_constant<int, 4>{}); panel(std::integral_constant<int, 5>{});
+    panel(std::integral_constant<int, 6>{}); panel(std::integral_constant<int, 7>{});
+    if (lane < 32) pivcol[lane] = mypk;
+    wave_sync();
+    OSOT_SUB_END(PH_EQ_RED);
+    const bool basic = valid && ((basicmask >> c) & 1ull);
+    const unsigned long long fmask = wave_ballot(valid && !basic && lane < NP);
+    const int nf = __builtin_popcountll(fmask);
+    if (nf > kNullMax) {   // the caller goes on with the generic path: JT = diag(1 / sqrt(h)) back into M2 (it held the column store)
+        for (int e = lane; e < WaveCtx<NP>::ROWS * S; e += 64) M2[e] = 0.0;
+        wave_sync();
+        if (valid && lane < NP) { double sq, rs; fast_sqrt_rsqrt(hdiag, sq, rs); M2[c * S + c] = rs; }
+        wave_sync();
+        return -1;
+    }
+    const bool is_free = valid && !basic && lane < NP;
+    const int t = __builtin_popcountll(fmask & ((1ull << c) - 1ull));
+    const int me = n - nf;
+    for (int e = lane; e < WaveCtx<NP>::ROWS * S; e += 64) M2[e] = 0.0;
+    wave_sync();
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * I + tq + 4 * r;
+            const int pk = (row < n_eq) ? pivcol[row] : -1;
+#pragma unroll
+            for (int C = 0; C < TC; ++C) {
+                const int col = 16 * C + ta;
+                const bool colfree = (col < n) && !((basicmask >> col) & 1ull);
+                if (colfree && pk >= 0) {
+                    const int tc = __builtin_popcountll(fmask & ((1ull << col) - 1ull));
+                    M2[(me + tc) * S + pk] = -Et[TC * I + C][r];
+                }
+            }
+        }
+    if (is_free) M2[(me + t) * S + c] = 1.0;
+    wave_sync();
+    // ---- modified Gram-Schmidt in the H metric: rows me.. of M2 become J2' (phantom lanes read the zero padding column)
+    const double hc = valid ? hdiag : 0.0;
+    double zr[kNullMax];
+#pragma unroll
+    for (int s = 0; s < kNullMax; ++s) zr[s] = (s < nf) ? M2[(me + s) * S + c] : 0.0;
+#pragma unroll
+    for (int s = 0; s < kNullMax; ++s) {
+        if (s < nf) {
+#pragma unroll
+            for (int q = 0; q < s; ++q) {
+                const double rq = colsum<NP>(hc * zr[q] * zr[s]);
+                zr[s] = fma(-rq, zr[q], zr[s]);
+            }
+            const double nn = colsum<NP>(hc * zr[s] * zr[s]);
+            double sq, rs;
+            fast_sqrt_rsqrt(nn, sq, rs);
+            zr[s] *= rs;
+            if (lane < NP) M2[(me + s) * S + c] = zr[s];
+        }
+    }
+    OSOT_SUB_END(PH_EQ_Z);
+    // ---- x = x_prev - J2 J2' (H x_prev + g)
+    const double grad = valid ? fma(hc, xprev, g) : 0.0;
+    double x = valid ? xprev : 0.0;
+#pragma unroll
+    for (int s = 0; s < kNullMax; s += 2) {
+        if (s < nf) {
+            double d0, d1;
+            colsum2<NP>(zr[s] * grad, (s + 1 < kNullMax) ? zr[s + 1] * grad : 0.0, d0, d1);
+            x = fma(-d0, zr[s], x);
+            if (s + 1 < kNullMax) x = fma(-d1, zr[s + 1], x);
+        }
+    }
+    wave_sync();
+    OSOT_SUB_END(PH_EQ_HH);
+    x_out = x;
+    return me;
+}
+
 // Is the part d2 = J2'n of a constraint normal outside the span of the working set a DIRECTION or round-off?
 // nd2 = |d2|^2, dd = |d|^2 (both uniform); d2 = this lane's component (0 below iq); nv = this lane's entry of the
 // normal n.  Second tier, per FREE COLUMN c of J: d2_c^2 / (|J_c|^2 |n|^2) = cos^2 of the angle between n and that
@@ -1168,11 +1392,18 @@ __device__ int gi_inequalities(const WaveCtx<NP>& w, int nrows, double x, int iq
 #define OSOT_LOWRANK_MAX 6      // round 5: one Cartesian task (six rows) next to a Postural block -- BASELINE config 2 -- takes the closed form too
 #endif
 constexpr int kLowRankMax = OSOT_LOWRANK_MAX;
+#ifndef OSOT_X_NO_LOWRANK40
+constexpr bool kLowRank40 = true;     // round 6: the closed form for the 40-lane layout as well (OSOT_X_NO_LOWRANK40: the factorisation, for A/B)
+#else
+constexpr bool kLowRank40 = false;
+#endif
 // MM = compile-time bound on the rows (3 for a CoM task, else kLowRankMax): the m x m algebra is fully unrolled
-template <int MM>
-__device__ inline void lowrank_prepare32(const WaveCtx<32>& w, const double* Ak, const double* bk, const double* wk,
+// (round 6: NP = 32 as before, and NP = 40 -- the CoM level of the reference's COMAN stacks on its own 35-coordinate robot)
+template <int NP, int MM>
+__device__ inline void lowrank_prepare(const WaveCtx<NP>& w, const double* Ak, const double* bk, const double* wk,
                                          int m, double dcol, double cvec, bool has_c, double& x_out) {
-    constexpr int S = WaveCtx<32>::S;
+    constexpr int S = WaveCtx<NP>::S, HV = WaveCtx<NP>::HV;
+    static_assert(MM * S <= WaveCtx<NP>::M1_DOUBLES, "the rows are staged in M1");
     const int c = w.c, h = w.h, n = w.n;
     const bool valid = c < n;
     double* M1 = w.M1;
@@ -1197,14 +1428,14 @@ __device__ inline void lowrank_prepare32(const WaveCtx<32>& w, const double* Ak,
     for (int r = 0; r < MM; ++r) {
         if (r < m) {
             double v = q[r];
-            const double n0 = colsum<32>(v * v);
+            const double n0 = colsum<NP>(v * v);
 #pragma unroll
             for (int s2 = 0; s2 < r; ++s2) {
-                const double d = colsum<32>(q[s2] * v);
+                const double d = colsum<NP>(q[s2] * v);
                 Rm[r][s2] = d;
                 v = fma(-d, q[s2], v);
             }
-            const double nn = (r == 0) ? n0 : colsum<32>(v * v);
+            const double nn = (r == 0) ? n0 : colsum<NP>(v * v);
             if (nn > 1.0e-24 * n0 && nn > 0.0) {
                 double sq, rs;
                 fast_sqrt_rsqrt(nn, sq, rs);
@@ -1264,7 +1495,7 @@ __device__ inline void lowrank_prepare32(const WaveCtx<32>& w, const double* Ak,
     double Qc[MM], t[MM], u[MM];
 #pragma unroll
     for (int s2 = 0; s2 < MM; ++s2) {
-        Qc[s2] = (has_c && s2 < m) ? colsum<32>(q[s2] * ch) : 0.0;
+        Qc[s2] = (has_c && s2 < m) ? colsum<NP>(q[s2] * ch) : 0.0;
         double acc = -Qc[s2];
 #pragma unroll
         for (int r = 0; r < MM; ++r) acc = fma(Rm[r][s2], bt[r], acc);
@@ -1307,8 +1538,8 @@ __device__ inline void lowrank_prepare32(const WaveCtx<32>& w, const double* Ak,
     }
     wave_sync();
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) {
-        const int j = 2 * jj + h;
+    for (int jj = 0; jj < NP / HV; ++jj) {
+        const int j = HV * jj + h;
         double acc = (j == c) ? dis : 0.0;
 #pragma unroll
         for (int s2 = 0; s2 < MM; ++s2) acc = fma(F[s2], M1[s2 * S + j], acc);
@@ -1415,6 +1646,14 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
         const int r_ns = uniform_i(nullspace_equalities32<PROF>(reinterpret_cast<const WaveCtx<32>&>(w), n_eq, hdiag, g, xprev, x, prof));
         if (r_ns >= 0) { iq = r_ns; iters += n_eq; used_nullspace = true; n_eq = 0; }
     }
+#ifndef OSOT_X_NO_NULLSPACE40
+    if constexpr (NP == 40) {     // round 6: the 40-lane layout (the reference's 35-coordinate COMAN) takes the same route
+        if (diag_h && have_prev && !local_eq && n_eq >= 8 && n_eq <= 32 && n - n_eq <= kNullMax) {
+            const int r_ns = uniform_i(nullspace_equalities_wide<NP, PROF>(w, n_eq, hdiag, g, xprev, x, prof));
+            if (r_ns >= 0) { iq = r_ns; iters += n_eq; used_nullspace = true; n_eq = 0; }
+        }
+    }
+#endif
     // (uniform_i / uniform_d below: table entries and reduction results ARE wave-uniform, said so that the loop's control flow
     // and its counters stay on the scalar unit -- see osot_team.h)
     // The equality rows are added IN PAIRS wherever two consecutive rows are both (clearly) independent of the working set: a pass

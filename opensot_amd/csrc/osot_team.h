@@ -24,6 +24,9 @@
 // sixteen round trips) and makes it wait once, for all of them.
 #define OSOT_KEEP16(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), \
                                          "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]))
+// the same for twelve values a[o] .. a[o + 11]
+#define OSOT_KEEP12(a, o) asm volatile("" : "+v"(a[(o) + 0]), "+v"(a[(o) + 1]), "+v"(a[(o) + 2]), "+v"(a[(o) + 3]), "+v"(a[(o) + 4]), "+v"(a[(o) + 5]), \
+                                            "+v"(a[(o) + 6]), "+v"(a[(o) + 7]), "+v"(a[(o) + 8]), "+v"(a[(o) + 9]), "+v"(a[(o) + 10]), "+v"(a[(o) + 11]))
 // the FIRST kernel parameter as memory: a pointer into the kernarg segment (taking the address of a by-value kernel
 // parameter would make the compiler copy it to scratch)
 #define OSOT_KERNARG_PTR(type, first_param) ((const type*)(__builtin_amdgcn_kernarg_segment_ptr()))

@@ -20,6 +20,7 @@
 #define OSOT_KERNARG_PTR(type, first_param) (&(first_param))
 #define OSOT_ALWAYS_INLINE_CALL
 #define OSOT_KEEP16(a) do { } while (0)
+#define OSOT_KEEP12(a, o) do { } while (0)
 #define OSOT_GLOBAL_F64(addr) (reinterpret_cast<const double*>(addr))
 
 namespace osot {

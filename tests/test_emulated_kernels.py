@@ -169,6 +169,30 @@ def test_small_generic_cascades(n, rows, n_eq, n_ineq, oracle):
         assert (rq["status"] == 1).all() and np.abs(dq - rq["dq"]).max() < 1e-6
 
 
+@pytest.mark.parametrize("rows,n_eq,n_ineq,dup", [([3, 12], 12, 0, None), ([3, 6, 6], 12, 0, None), ([5, 12], 12, 0, None), ([3, 12], 12, 4, None),
+                                                   ([3, 12], 6, 0, 0)])
+def test_nullspace_elimination_on_the_40_lane_layout(rows, n_eq, n_ineq, dup, oracle):
+    """round 6 -- nullspace_equalities_wide: the Postural last level of the reference's COMAN stacks (coman_ik.cpp:425-449; 35
+    coordinates: the 40-lane layout) under its 27 equality rows -- the feet as global equality rows (12), the CoM level (3), the wrists
+    (12) -- by Gauss-Jordan in 2 x 3 tiles instead of 27 reflections of the full J.  S3's and S4's shapes, 29 rows (six free columns),
+    with inequality rows beside the box (the general instantiation), and -- last case -- 27 rows of rank 21: fourteen free columns, more
+    than the elimination carries, so it hands the level back to the generic path with J' restored.  Against the restated eiQuadProg
+    cascade (1e-9) and the reference's qpOASES (1e-6)."""
+    plan, leaf = synth.make_generic_stack(6, 35, rows, n_eq=n_eq, n_ineq=n_ineq, seed=61 + len(rows) + n_ineq, box=0.3, duplicate_eq_in_level=dup)
+    asm = oracle.assemble(plan, leaf)
+    dq, xl, st, it = emu_cascade(plan, asm)
+    assert (st == 0).all()
+    res = np.einsum("bij,bj->bi", asm["C"][:, :n_eq], dq) - asm["lo"][:, :n_eq]
+    assert np.abs(res).max() < 1e-9
+    if dup is None:
+        ref = oracle.ihqp_solve_batch(asm, oracle.BE_EIQP_EQ, nthreads=1)
+        assert (ref["status"] == 1).all() and np.abs(dq - ref["dq"]).max() < 1e-9
+    if oracle.ref_available():
+        rq = oracle.ihqp_solve_batch(asm, oracle.BE_QPOASES_REF, nthreads=1)
+        ok = rq["status"] == 1
+        assert ok.sum() >= 5 and np.abs(dq[ok] - rq["dq"][ok]).max() < 1e-6
+
+
 def test_roundoff_violation_with_no_freedom_left(oracle):
     """an inequality active at an upper level re-appears at a level whose optimality rows leave no free direction:
     its slack is O(eps*cond) and must not be reported as infeasibility (instance 54 of this seeded family did)"""
