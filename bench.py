@@ -1063,6 +1063,7 @@ def lanes_auto(plan, B, device, front_end="iHQP"):
     from opensot_amd.solver import BatchedStack
     probe = BatchedStack(plan, 1, device=device, want_levels=False)
     resident = probe.resident_waves_nhqp() if front_end == "nHQP" else probe.resident_waves()
+    lanes_auto.last_resident = resident
     return suggest_lanes(B, resident)
 
 
@@ -1406,6 +1407,7 @@ def main():
                     nl = lanes_auto(coman_stack(which, 35), 4096, local_rank) if (streams is not None and S >= 2) else S
                     oc["COMAN35_" + which] = time_coman35(which, 4096, local_rank, lanes=nl, streams=streams_for(streams, nl, device))
                     oc["COMAN35_" + which]["lanes"] = nl
+                    oc["COMAN35_" + which]["resident_wavefronts"] = getattr(lanes_auto, "last_resident", None)
                 except Exception as e:
                     oc["COMAN35_" + which] = {"error": str(e)[:300]}
             for which in ("S1", "S2", "S3", "S4"):   # the same four through the reference's null-space front-end (published: 0.2969 / 0.2637 / 0.3191 / 0.3721 ms per solve)
@@ -1413,6 +1415,7 @@ def main():
                     nl = lanes_auto(coman_stack(which, 35), 4096, local_rank, front_end="nHQP") if (streams is not None and S >= 2) else S
                     oc[f"COMAN35_{which}_nHQP"] = time_coman35(which, 4096, local_rank, steps=6, warmup=2, front_end="nHQP", lanes=nl, streams=streams_for(streams, nl, device))
                     oc[f"COMAN35_{which}_nHQP"]["lanes"] = nl
+                    oc[f"COMAN35_{which}_nHQP"]["resident_wavefronts"] = getattr(lanes_auto, "last_resident", None)
                 except Exception as e:
                     oc[f"COMAN35_{which}_nHQP"] = {"error": str(e)[:300]}
             try:
@@ -1435,6 +1438,7 @@ def main():
                 n3 = lanes_auto(synth.make_velocity_stack("C3", 1, seed=1)[0], 4096, local_rank, front_end="nHQP") if (streams is not None and S >= 2) else S
                 oc["nHQP_C3"] = time_nhqp(4096, local_rank, steps=10, warmup=3, lanes=n3, streams=streams_for(streams, n3, device))      # (ten timed steps: at five the fill and drain of three lanes is a tenth of the region)
                 oc["nHQP_C3"]["lanes"] = n3
+                oc["nHQP_C3"]["resident_wavefronts"] = getattr(lanes_auto, "last_resident", None)
             except Exception as e:
                 oc["nHQP_C3"] = {"error": str(e)}
             try:

@@ -672,13 +672,19 @@ __device__ __forceinline__ void nhqp_tile_store(const double (&acc)[2 * T * (T +
 }
 
 // H (k x k, row stride ld) = X'diag(w) X + s2 Y2 Y2' through the tile products above, T = ceil(k / 16) tiles a side
+// TMAX (round 6): the largest tile count the CALLER can meet.  The 32-column preparation kernel never has k > 32, but the T = 3 / 4 branches
+// it could not take still cost it their accumulators -- 80 AGPRs beside 177 VGPRs: ONE register over the 256 that let two wavefronts share a
+// SIMD (profiles/r05_v4_kernel_resources.txt: every preparation kernel at occupancy 1).  With TMAX = 2 it keeps 24.
+template <int TMAX = 4>
 __device__ __forceinline__ void nhqp_gram_to(double* M, int ld, int k, const double* X, int S, int m, const double* w,
                                              const double* Y, int SY, int yrows, const int* idx2, int ns, double s2, int lane) {
     const int T = uniform_i((k + 15) >> 4);
     if (T <= 1) { double acc[4]; nhqp_tile_gram<1>(X, S, m, w, Y, SY, yrows, idx2, ns, s2, lane, acc); nhqp_tile_store<1>(acc, M, ld, k, lane); }
-    else if (T == 2) { double acc[12]; nhqp_tile_gram<2>(X, S, m, w, Y, SY, yrows, idx2, ns, s2, lane, acc); nhqp_tile_store<2>(acc, M, ld, k, lane); }
-    else if (T == 3) { double acc[24]; nhqp_tile_gram<3>(X, S, m, w, Y, SY, yrows, idx2, ns, s2, lane, acc); nhqp_tile_store<3>(acc, M, ld, k, lane); }
-    else { double acc[40]; nhqp_tile_gram<4>(X, S, m, w, Y, SY, yrows, idx2, ns, s2, lane, acc); nhqp_tile_store<4>(acc, M, ld, k, lane); }
+    else if (T == 2 || TMAX <= 2) { double acc[12]; nhqp_tile_gram<2>(X, S, m, w, Y, SY, yrows, idx2, ns, s2, lane, acc); nhqp_tile_store<2>(acc, M, ld, k, lane); }
+    else if constexpr (TMAX >= 3) {
+        if (T == 3 || TMAX == 3) { double acc[24]; nhqp_tile_gram<3>(X, S, m, w, Y, SY, yrows, idx2, ns, s2, lane, acc); nhqp_tile_store<3>(acc, M, ld, k, lane); }
+        else if constexpr (TMAX >= 4) { double acc[40]; nhqp_tile_gram<4>(X, S, m, w, Y, SY, yrows, idx2, ns, s2, lane, acc); nhqp_tile_store<4>(acc, M, ld, k, lane); }
+    }
 }
 
 // Sixteen rows 16 I .. 16 I + 15 of a row-major HBM matrix M (ld n, `rows` of them) against the LDS matrix Nl (n x nf, stride S, zero rows
@@ -1130,7 +1136,7 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
         if (h == 0 && c < nf) Q.g[inst * nf + c] = gacc;
         const bool sel = ns > 0 && Q.sel_reg;
 #ifndef OSOT_NHQP_H_VALU
-        nhqp_gram_to(Hg, nf, nf, AN, kNS, m, vec, V2, kNS, nf, nullptr, sel ? ns : 0, sv_max, lane);     // (round 5: on the matrix core)
+        nhqp_gram_to<2>(Hg, nf, nf, AN, kNS, m, vec, V2, kNS, nf, nullptr, sel ? ns : 0, sv_max, lane);     // (round 5: on the matrix core; nf <= 32 here)
 #else
         double v2c[16];                             // my row of V2 (zero beyond ns)
 #pragma unroll

@@ -57,7 +57,12 @@ def test_update_kernel_matches_oracle_assembly(oracle, gpu_device):
 @pytest.mark.parametrize("n,rows,n_eq,n_ineq,dup", [(7, [6], 0, 0, None), (7, [3, 3], 1, 2, None), (20, [5, 6], 4, 6, None),
                                                      (16, [4, 5], 6, 0, 0), (18, [2], 6, 0, 0),
                                                      (33, [8, 10], 2, 4, None), (48, [12, 16], 3, 6, None), (54, [12, 20], 4, 8, None),
-                                                     (55, [12, 20], 4, 8, None), (64, [16, 24], 5, 10, None)])
+                                                     (55, [12, 20], 4, 8, None), (64, [16, 24], 5, 10, None),
+                                                     # round 6 -- the 40-lane layout's null-space elimination and closed-form low-rank level: the reference's
+                                                     # COMAN S3 / S4 shapes (12 global equality rows = the feet, 35 variables, 27 equality rows at the Postural
+                                                     # level), 29 rows, inequality rows beside them, and the rank-deficient hand-back to the generic path
+                                                     (35, [3, 12], 12, 0, None), (35, [3, 6, 6], 12, 0, None), (35, [5, 12], 12, 0, None),
+                                                     (35, [3, 12], 12, 4, None), (35, [3, 12], 6, 0, 0), (38, [3, 14], 12, 2, None)])
 def test_small_generic_cascades_gpu(n, rows, n_eq, n_ineq, dup, oracle, gpu_device):
     """n < 32 (guarded factor instantiation), Panda-like 7-variable stacks, and a stack whose optimality rows
     duplicate its global equality rows (coman_ik.cpp:442; (18, [2]): with so many dependent rows that the null-space
