@@ -15,10 +15,28 @@ B = 192
 bad = 0
 counted = total = judged_by_cost = 0
 t0 = time.time()
+MODE = sys.argv[3] if len(sys.argv) > 3 else ""      # "coman40": only the round-6 shapes below (the default sweeps keep their random streams)
 for it in range(N):
     kind = rng.integers(0, 5)
     n = int(rng.integers(5, 33))
-    if kind == 0:
+    if MODE == "coman40":
+        # round 6 -- the 40-lane layout's null-space elimination and closed-form low-rank level: 33 .. 38 variables, the feet-like global
+        # equality rows (6 .. 14), one to three task levels of a few rows (the first often a CoM-like 3-row level), Postural last, sized so
+        # that the last level meets n - 10 .. n + 2 equality rows (inside and outside what the elimination carries), sometimes inequality rows
+        n = int(rng.integers(33, 39))
+        n_eq = int(rng.integers(6, 15))
+        L = int(rng.integers(1, 4))
+        target = n - int(rng.integers(-2, 11)) - n_eq
+        rows = [3 if (j == 0 and rng.integers(0, 2)) else int(rng.integers(1, 13)) for j in range(L)]
+        while sum(rows) > max(L, target): rows[int(np.argmax(rows))] -= 1
+        rows = [max(1, r) for r in rows]
+        kw = dict(n=n, level_rows=rows, n_eq=n_eq, n_ineq=int(rng.choice([0, 0, 3])), seed=int(rng.integers(1 << 30)), box=float(rng.choice([0.1, 0.3])),
+                  postural_last=True, eps_factor=float(rng.choice([1e6, 1e6, 2e2])))
+        plan, leaf = synth.make_generic_stack(B, kw.pop("n"), kw.pop("level_rows"), **kw); desc = ("coman40", n, rows, kw)
+        kind = -1
+    if kind == -1:
+        pass
+    elif kind == 0:
         L = int(rng.integers(1, 4))
         rows = [int(rng.integers(1, max(2, n - 2))) for _ in range(L)]
         while sum(rows) > n + 6: rows[int(np.argmax(rows))] -= 1

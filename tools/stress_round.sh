@@ -13,3 +13,6 @@ for s in 11 12 13; do python tests/stress_hotstart.py $s 90 2>&1 | grep -v amdgp
 { python tests/stress_closed_loop.py 41 1024 300 1e6 tasks; python tests/stress_closed_loop.py 42 1024 300 200 tasks;
   python tests/stress_closed_loop.py 41 1024 300 1e6 ttc; python tests/stress_closed_loop.py 42 1024 300 200 ttc; } 2>&1 | grep -v amdgpu.ids > $OUT/stress_closed_loop.txt
 tail -n 3 $OUT/*.txt
+# round 6: the 40-lane layout's null-space / low-rank paths (33 .. 38 variables, many equality rows)
+for s in 5 6; do python tests/stress_parity.py $s 400 coman40 2>&1 | grep -v amdgpu.ids; done > $OUT/stress_parity_coman40.txt
+tail -n 3 $OUT/stress_parity_coman40.txt
