@@ -1067,11 +1067,19 @@ def lanes_auto(plan, B, device, front_end="iHQP"):
     return suggest_lanes(B, resident)
 
 
+_EXTRA_STREAMS = {}
+
+
 def streams_for(streams, n, device):
-    """the caller's streams first (fresh ones can land on a hardware queue another lane already uses), more where a sub-line has more lanes"""
+    """the caller's streams first, more where a sub-line has more lanes -- from ONE pool per device, created once: HIP maps streams onto a
+    handful of hardware queues in creation order, so a fresh stream per sub-line sooner or later lands on the queue of another lane of the
+    same sub-line and the two serialise (seen: COMAN35 S3 / S4 at 6.0 / 3.4 M with a stream created per call against 8.3 / 5.3 M)"""
     if streams is None:
         return None
-    return list(streams[:n]) + [torch.cuda.Stream(device=device) for _ in range(max(0, n - len(streams)))]
+    pool = _EXTRA_STREAMS.setdefault(str(device), [])
+    while len(streams) + len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return list(streams[:n]) + pool[:max(0, n - len(streams))]
 
 
 def sub_leaf(lf, lo, hi):

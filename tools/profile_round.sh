@@ -3,7 +3,7 @@
 # configurations of the bench line: the headline lanes, C2 / C4 / C5, nHQP, eHQP, ADMM, kinematics), then separate --pmc
 # passes (one counter group each, as MI355X_MICROARCH.md prescribes; --kernel-trace only beside them) over the same command.
 # Output under gpurun_out/prof_<tag>/ ; the summaries are copied into profiles/ by hand.
-TAG=${1:-r04}
+TAG=${1:-r06}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -22,3 +22,5 @@ python $GRAFT_REPO_ROOT/tools/summarise_pmc.py $OUT > $OUT/pmc_kernels.json
 for cfg in C3 C5; do python $GRAFT_REPO_ROOT/tools/prof_phases.py $cfg $( [ $cfg = C5 ] && echo 1024 || echo 4096 ) > $OUT/phase_cycles_$cfg.txt 2>&1; done
 rm -rf $OUT/trace $OUT/pmc[0-9]
 ls -la $OUT
+# round 6: the phase census of the reference's COMAN stacks on the 40-lane layout
+python $GRAFT_REPO_ROOT/tools/prof_phases_coman.py S2 S3 S4 2>&1 | grep -v amdgpu.ids > $OUT/phase_cycles_COMAN35.txt
