@@ -239,6 +239,43 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
 #pragma unroll
         for (int ii = 0; ii < NP / HV; ++ii) hacc[ii] = 0.0;
 #endif
+        // round 6, 40-lane layout: a dense level (diagonal weights, every task active) under >= 8 equality rows that the previous level's
+        // solution satisfies -- the reference's COMAN stacks below their first level -- takes the null-space method AHEAD of the H build:
+        // no H, no 40-column factorisation, no row-by-row reflections (nullspace_dense_wide).  -1: not taken (or handed back: rank-deficient
+        // rows, more than 24 free columns), the level runs as before.
+        int dn_rank = -1, dn_neq = 0;
+        double dn_x = 0.0, dn_hinv = 0.0;
+        if constexpr (NP == 40 && kDenseNull40) {
+            if (!diag_h && ma <= kDenseNullRows && !dense && !inact && !regd) {
+                const int nrows_k = P.nc + P.optoff[k];
+                int ne = 0;
+                bool loc = false;
+                for (int r0 = 0; r0 < nrows_k; r0 += 64) {
+                    const int r = r0 + lane;
+                    bool is_eq = false, is_loc = false;
+                    if (r < nrows_k) {
+                        const double lo = w.rlo[r], up = w.rup[r];
+                        is_eq = (lo == up) && (lo > -kInfty) && (lo < kInfty);
+                        is_loc = is_eq && (w.rsrc[r] == -2);
+                    }
+                    loc = loc || (wave_ballot(is_loc) != 0ull);
+                    const unsigned long long mask = wave_ballot(is_eq);
+                    if (is_eq) w.eqlist[ne + lanes_below(mask)] = r;
+                    ne += __builtin_popcountll(mask);
+                }
+                wave_sync();
+                if (!loc && ne >= 8 && ne <= 32 && n - ne <= kDenseNullFree) {
+                    const int npost = m - ma;
+                    const bool postc = valid && c < npost;
+                    const double wpost = postc ? (wk ? wk[ma + c] : 1.0) : 0.0;
+                    double clin = ((D.c[k] && valid) ? D.c[k][inst * n + c] : 0.0) + greg;
+                    if (postc) clin -= wpost * bk[ma + c];
+                    dn_rank = uniform_i(nullspace_dense_wide<NP, PROF>(w, ne, Ak, bk, wk, ma, P.eps_abs + wpost + dreg, clin, any, x, dn_x, dn_hinv, prof));
+                    dn_neq = ne;
+                }
+            }
+        }
+        const bool dense_done = dn_rank >= 0;
         bool lowrank = false;   // few stored rows: J and x in closed form, no H, no factorisation (lowrank_prepare32)
         double xprep = 0.0;
         if constexpr (NP == 32 || (NP == 40 && kLowRank40)) {
@@ -246,7 +283,7 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
             // (five or six stored rows -- one Cartesian task -- only next to a Postural block over every variable, BASELINE config 2: D >= w
             //  there.  With D = eps alone the scaled rows carry 1 / sqrt(eps) and six of them lose what the Cholesky path keeps: at the
             //  default eps the closed-loop instance of default_eps_stuck_instances[tasks] ended lexicographically worse than eiQuadProg)
-            if (!diag_h && (ma <= 4 || (ma <= kLowRankMax && m - ma >= n)) && !dense && !inact && !regd) {
+            if (!dense_done && !diag_h && (ma <= 4 || (ma <= kLowRankMax && m - ma >= n)) && !dense && !inact && !regd) {
 #else
             if (false) {
 #endif
@@ -262,7 +299,7 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
                 else lowrank_prepare<NP, kLowRankMax>(w, Ak, bk, wk, ma, P.eps_abs + wpost + dreg, cvec, has_c, xprep);
             }
         }
-        if (lowrank) {
+        if (lowrank || dense_done) {
         } else if (!diag_h) {
           if constexpr (NP == 32) {
             // ---- H = A'WA + eps I on the fp64 MATRIX CORE, g = -A'Wb + c.  Four rows of A per step: lane
@@ -598,7 +635,7 @@ __device__ __forceinline__ void cascade_body(const DevPlan& P, const DevBatch& D
         if (NP > 32) {   // must be inlined: hacc would otherwise be passed through scratch memory
             OSOT_ALWAYS_INLINE_CALL st = gi_solve<NP, PROF, BOX>(w, nrows, g, diag_h, hdiag, hacc,
                                                                    has_box, lb, ub, P.max_iter, any, x, x, iters, prof, slack,
-                                                                   lowrank, xprep, hotcode, hotk);
+                                                                   lowrank, xprep, hotcode, hotk, dn_rank, dn_neq, dn_x, dn_hinv);
         } else {          // NP = 32: inlined as well (as a CALL the solver spends ~50 % more cycles: the tiles travel through scratch)
             OSOT_ALWAYS_INLINE_CALL st = gi_solve<NP, PROF, BOX>(w, nrows, g, diag_h, hdiag, hacc,
                                            has_box, lb, ub, P.max_iter, any, x, x, iters, prof, slack, lowrank, xprep,

@@ -414,7 +414,10 @@ __device__ __forceinline__ void drop_constraint(const WaveCtx<NP>& w, int qq, in
 //     idle during the factorisation) so that lane c picks up its row's four entries L[c][4p .. 4p+3]; the backward
 //     substitution L'x = y is the product x = (L^-1)'y with the rows of L^-1 that have just been stored.
 // In : Ht (H + eps I with a unit diagonal beyond n), g by lane c.   Out: M2 = JT = L^-1, x = -(H+eps I)^-1 g; M1 clobbered.
-template <bool TT = false>
+// SKIP (round 6, nullspace_dense_wide's borrowed context: a reduced Hessian of 14 .. 24 columns): panels that lie wholly in the identity
+// padding beyond n run under a uniform guard -- the padding factorises to itself, its off-diagonal entries are zero, so skipping them is
+// exact (factor_tiles_wide does the same).  The cascade's own calls keep SKIP = false: no branch in the headline's panel sequence.
+template <bool TT = false, bool SKIP = false>
 __device__ inline int factor_tiles32(const WaveCtx<32>& w, double (&Hf)[16], double g, double& x_out, long long* tt = nullptr) {
     long long tt0 = TT ? (long long)clock64() : 0;
 #define OSOT_TT(i) do { if (TT) { const long long t_ = (long long)clock64(); tt[i] += t_ - tt0; tt0 = t_; } } while (0)
@@ -434,6 +437,7 @@ __device__ inline int factor_tiles32(const WaveCtx<32>& w, double (&Hf)[16], dou
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         const int Ip = p >> 2, rp = p & 3;
+        if (SKIP && 4 * p >= n) continue;
         // panel columns (as rows, by symmetry) and the matching rows of L^-1
         double Pn[2], Rp[2];
         double rsq[4];                         // 1 / L[j][j] of the panel's four columns (uniform)
@@ -1074,19 +1078,21 @@ __device__ inline int nullspace_equalities32(const WaveCtx<32>& w, int n_eq, dou
 // column registers per quarter-row and six trailing products per panel; the column store (48 columns, stride 33) fits the idle M2
 // (41 x 41).  Phantom lanes (40 .. 63 of the layout) hold tile columns like every other lane here: the tile coordinates come from the
 // PHYSICAL lane, the vector phases behind the elimination from the layout's column index as everywhere else.
+// (the elimination itself: shared by the diagonal-Hessian form below and the dense-level form, nullspace_dense_wide)
 template <int NP, bool PROF>
-__device__ inline int nullspace_equalities_wide(const WaveCtx<NP>& w, int n_eq, double hdiag, double g, double xprev,
-                                                double& x_out, long long* prof) {
+// with_rhs: the rows' right-hand sides (rlo = rup of an equality row) ride along as tile column 47 -- never a pivot candidate (it lies beyond
+// n), reduced with the rest: after the elimination row k reads x_(pivot k) + sum_free E'[k][f] x_f = E'[k][47]
+__device__ inline void gj_reduce_wide(const WaveCtx<NP>& w, int n_eq, v4f64 (&Et)[6], unsigned long long& basicmask_out, long long* prof,
+                                      bool with_rhs = false) {
     static_assert(NP == 40, "three column tiles: the 40-lane layout (n <= 38)");
     OSOT_SUB_BEGIN();
     constexpr int S = WaveCtx<NP>::S;
     constexpr int TC = 3;
-    const int c = w.c, n = w.n;
+    const int n = w.n;
     const int lane = phys_lane();
-    const bool valid = c < n;
     double* M2 = w.M2;
     const int ta = lane & 15, tq = lane >> 4;
-    v4f64 Et[2 * TC];   // Et[TC I + C]: tile (I, C) element r holds E[16 I + tq + 4 r][16 C + ta]
+    // Et[TC I + C]: tile (I, C) element r holds E[16 I + tq + 4 r][16 C + ta]
     double emax = 0.0;
     {
         unsigned long long rp[8];
@@ -1129,6 +1135,7 @@ __device__ inline int nullspace_equalities_wide(const WaveCtx<NP>& w, int n_eq, 
                     Et[TC * I + C][r] = e;
                     emax = fmax(emax, fabs(e));
                 }
+                if (with_rhs && ta == 15 && in) Et[TC * I + 2][r] = w.rlo[w.eqlist[16 * I + tq + 4 * r]];     // column 47
             }
     }
     emax = colmax<64>(emax);
@@ -1217,6 +1224,25 @@ __device__ inline int nullspace_equalities_wide(const WaveCtx<NP>& w, int n_eq, 
     if (lane < 32) pivcol[lane] = mypk;
     wave_sync();
     OSOT_SUB_END(PH_EQ_RED);
+    basicmask_out = basicmask;
+}
+
+template <int NP, bool PROF>
+__device__ inline int nullspace_equalities_wide(const WaveCtx<NP>& w, int n_eq, double hdiag, double g, double xprev,
+                                                double& x_out, long long* prof) {
+    static_assert(NP == 40, "three column tiles: the 40-lane layout (n <= 38)");
+    OSOT_SUB_BEGIN();
+    constexpr int S = WaveCtx<NP>::S;
+    constexpr int TC = 3;
+    const int c = w.c, n = w.n;
+    const int lane = phys_lane();
+    const bool valid = c < n;
+    double* M2 = w.M2;
+    const int ta = lane & 15, tq = lane >> 4;
+    v4f64 Et[2 * TC];
+    unsigned long long basicmask = 0ull;
+    gj_reduce_wide<NP, PROF>(w, n_eq, Et, basicmask, prof);
+    int* pivcol = reinterpret_cast<int*>(w.M1);
     const bool basic = valid && ((basicmask >> c) & 1ull);
     const unsigned long long fmask = wave_ballot(valid && !basic && lane < NP);
     const int nf = __builtin_popcountll(fmask);
@@ -1286,6 +1312,259 @@ __device__ inline int nullspace_equalities_wide(const WaveCtx<NP>& w, int n_eq, 
     wave_sync();
     OSOT_SUB_END(PH_EQ_HH);
     x_out = x;
+    return me;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Round 6: a DENSE level under many equality rows, 40-lane layout (the reference's COMAN stacks, examples/cpp/coman_ik.cpp:425-449:
+// every task level below the first sits under the feet's 12 TaskToConstraint rows plus the optimality rows of the levels above --
+// 15 rows at S3's wrist level, 15 and 21 at S4's -- and each of them was one Householder reflection of the full 40 x 40 J BEHIND a
+// 40-column Cholesky + inverse: 45 % of an S3 / S4 solve, profiles/r06_phase_cycles_COMAN35.txt).  The null-space method instead,
+// for rows that x_prev satisfies (global equality rows and optimality rows do):
+//   Z = null(E)                      gj_reduce_wide, the elimination of the Postural level (n x nf, nf = n - rank <= 24)
+//   H = A'WA + D  (D diagonal: eps, a Postural block's weights, the regularisation task; A the level's <= 24 stored rows)
+//   G = Z'HZ = (W^1/2 A Z)'(W^1/2 A Z) + Z'DZ,   t = Z'(H x_prev + g) = (W^1/2 A Z)'W^1/2 (A x_prev - b) + Z'(D x_prev + c)   [no H, no g: the
+//                                    method runs AHEAD of the level's H build and takes its place]
+//                                    two tile products on the matrix core: x_prev rides along as column nf of Z, so t is column nf of G
+//   G = L L',  y = -G^-1 t           factor_tiles32<SKIP> on a BORROWED 32-lane context laid over the idle M1 / M2 (substitution included)
+//   x = x_prev + Z y,   J2 = Z L^-T  (J2'HJ2 = I, E J2 = 0: what the dual active-set loop needs; the equality part of J is never read)
+// The dual loop then runs as after the diagonal-level elimination: iq = rank, the equality rows of J zero, and the dependency test
+// measured against n'(J2 J2')n -- for a bound exactly the diagonal entry sum_s J2[c][s]^2, returned as hinv.
+// Returns the rank, or -1 (nothing the generic path relies on has been touched: it overwrites M1 and M2 itself) when more than
+// kDenseNullFree columns stay free, none does, or G is not positive definite.
+#ifndef OSOT_X_NO_DENSE_NULL40
+constexpr bool kDenseNull40 = true;
+#else
+constexpr bool kDenseNull40 = false;
+#endif
+constexpr int kDenseNullFree = 24;   // free columns carried (registers: the lane's row of Z)
+constexpr int kDenseNullRows = 24;   // stored rows of the level (their products with Z are staged in M1: 24 x 33 doubles)
+template <int NP, bool PROF>
+__device__ inline int nullspace_dense_wide(const WaveCtx<NP>& w, int n_eq, const double* Ak, const double* bk, const double* wk, int ma, double dcol,
+                                           double clin, bool have_prev, double xprev_in, double& x_out, double& hinv_out, long long* prof) {
+    static_assert(NP == 40, "the 40-lane layout (n <= 38)");
+    OSOT_SUB_BEGIN();
+    constexpr int S = WaveCtx<NP>::S, TC = 3, NF = kDenseNullFree;
+    const int c = w.c, n = w.n;
+    const int lane = phys_lane();
+    const bool valid = c < n;
+    double* M1 = w.M1;
+    double* M2 = w.M2;
+    double* V0 = w.V;
+    double* V1 = w.V + WaveCtx<NP>::LW;
+    double* V2 = w.V + 2 * WaveCtx<NP>::LW;
+    double* V3 = w.V + 3 * WaveCtx<NP>::LW;
+    const int ta = lane & 15, tq = lane >> 4;
+    v4f64 Et[2 * TC];
+    unsigned long long basicmask = 0ull;
+    // (the FIRST level has no x_prev: its equality rows are global rows with their own right-hand sides, which ride along in the
+    //  elimination -- a particular solution then is "basic variables = the reduced right-hand sides, free variables = 0")
+    gj_reduce_wide<NP, PROF>(w, n_eq, Et, basicmask, prof, !have_prev);
+    int* pivcol = reinterpret_cast<int*>(M1);
+    const bool basic = valid && ((basicmask >> c) & 1ull);
+    const unsigned long long fmask = wave_ballot(valid && !basic && lane < NP);
+    const int nf = __builtin_popcountll(fmask);
+    if (nf > NF || nf < 1) return -1;
+    double xprev = xprev_in;
+    if (!have_prev) {
+        bool inconsistent = false;
+        if (lane < NP) V2[c] = 0.0;
+        wave_sync();
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * I + tq + 4 * r;
+                if (ta == 15 && row < n_eq) {
+                    const int pk = pivcol[row];
+                    const double rv = Et[TC * I + 2][r];
+                    if (pk >= 0) V2[pk] = rv;
+                    else inconsistent = inconsistent || (fabs(rv) > kEqTol);      // a dependent row that its partners do not imply: the generic path reports it
+                }
+            }
+        if (wave_ballot(inconsistent) != 0ull) return -1;
+        wave_sync();
+        xprev = (basic && lane < NP) ? V2[c] : 0.0;
+        wave_sync();
+    }
+    const bool is_free = valid && !basic && lane < NP;
+    const int t = __builtin_popcountll(fmask & ((1ull << c) - 1ull));
+    const int me = n - nf;
+    // ---- Z' rows into M2[me + t][:] as after the diagonal-level elimination; row me + nf = x_prev (column nf of the products below)
+    for (int e = lane; e < WaveCtx<NP>::ROWS * S; e += 64) M2[e] = 0.0;
+    wave_sync();
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * I + tq + 4 * r;
+            const int pk = (row < n_eq) ? pivcol[row] : -1;
+#pragma unroll
+            for (int C = 0; C < TC; ++C) {
+                const int col = 16 * C + ta;
+                const bool colfree = (col < n) && !((basicmask >> col) & 1ull);
+                if (colfree && pk >= 0) {
+                    const int tc = __builtin_popcountll(fmask & ((1ull << col) - 1ull));
+                    M2[(me + tc) * S + pk] = -Et[TC * I + C][r];
+                }
+            }
+        }
+    if (is_free) M2[(me + t) * S + c] = 1.0;
+    if (lane < NP) {
+        M2[(me + nf) * S + c] = valid ? xprev : 0.0;
+        V0[c] = valid ? dcol : 0.0;                          // D
+        V1[c] = valid ? fma(dcol, xprev, clin) : 0.0;        // D x_prev + the linear term beside the stored rows' (-A'Wb is column nf of Ys'Ys)
+    }
+    wave_sync();     // (pivcol, at the head of M1, is dead from here on: M1 takes the staged products)
+    double zr[NF];   // my row of Z
+#pragma unroll
+    for (int s2 = 0; s2 < NF; ++s2) zr[s2] = (s2 < nf) ? M2[(me + s2) * S + c] : 0.0;
+    OSOT_SUB_END(PH_EQ_Z);
+    // ---- Yt = A [Z | x_prev]  (ma x 32): A operand lane (m = ta, k = tq) = A[16 I + ta][4 kk + tq] straight from HBM / L2 (the H build
+    // has just read these rows), B operand lane (k = tq, n = ta) = Z[4 kk + tq][16 J + ta] from the Z' rows in LDS
+    const int ksteps = (n + 3) >> 2;
+    const bool two_row_tiles = ma > 16;
+    v4f64 Yt[2][2];
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int J = 0; J < 2; ++J) Yt[I][J] = v4f64{0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < ksteps; k0 += 5) {
+        double a0[5], a1[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {       // (five steps of loads in flight before their products)
+            const int j = 4 * (k0 + u) + tq;
+            const bool jin = (k0 + u < ksteps) && j < n;
+            a0[u] = Ak[((ta < ma) ? ta : 0) * n + (jin ? j : 0)];
+            a1[u] = two_row_tiles ? Ak[((16 + ta < ma) ? 16 + ta : 0) * n + (jin ? j : 0)] : 0.0;
+            a0[u] = (jin && ta < ma) ? a0[u] : 0.0;
+            a1[u] = (jin && 16 + ta < ma) ? a1[u] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            if (k0 + u < ksteps) {
+                const int j = 4 * (k0 + u) + tq;
+                const int jj = (j < n) ? j : 0;
+                const double b0 = (ta <= nf && j < n) ? M2[(me + ta) * S + jj] : 0.0;
+                const double b1 = (16 + ta <= nf && j < n) ? M2[(me + ((16 + ta <= nf) ? 16 + ta : 0)) * S + jj] : 0.0;
+                Yt[0][0] = mfma_f64_16x16x4(a0[u], b0, Yt[0][0]);
+                Yt[0][1] = mfma_f64_16x16x4(a0[u], b1, Yt[0][1]);
+                if (two_row_tiles) {
+                    Yt[1][0] = mfma_f64_16x16x4(a1[u], b0, Yt[1][0]);
+                    Yt[1][1] = mfma_f64_16x16x4(a1[u], b1, Yt[1][1]);
+                }
+            }
+        }
+    }
+    // Ys = W^1/2 Yt -> M1 (row i, column s at i * 33 + s; rows 0 .. 23)
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * I + tq + 4 * r;
+            if (i < kDenseNullRows) {
+                const double wi = (i < ma) ? (wk ? wk[i] : 1.0) : 0.0;
+                const double bi = (i < ma) ? bk[i] : 0.0;
+                double sw, isw;
+                fast_sqrt_rsqrt((wi > 0.0) ? wi : 1.0, sw, isw);
+                sw = (wi > 0.0) ? sw : 0.0;
+#pragma unroll
+                for (int J = 0; J < 2; ++J) {
+                    // column nf: the level's residual at x_prev, A x_prev - b (so that column nf of G below is Z'(A'W(A x_prev - b) + ...))
+                    const double yv = (16 * J + ta == nf) ? Yt[I][J][r] - bi : Yt[I][J][r];
+                    M1[i * 33 + 16 * J + ta] = sw * yv;
+                }
+            }
+        }
+    wave_sync();
+    // ---- G (rows s, columns s') = Ys'Ys + Z'[D Z | D x_prev + g]: the first sum runs over the level's rows, the second over the variables
+    v4f64 Gt[2][2];
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int J = 0; J < 2; ++J) Gt[I][J] = v4f64{0.0, 0.0, 0.0, 0.0};
+    const int rsteps = ((ma < kDenseNullRows ? ma : kDenseNullRows) + 3) >> 2;
+    for (int kk = 0; kk < rsteps; ++kk) {
+        const int i = 4 * kk + tq;
+        const double y0 = M1[i * 33 + ta], y1 = M1[i * 33 + 16 + ta];
+        Gt[0][0] = mfma_f64_16x16x4(y0, y0, Gt[0][0]);
+        Gt[0][1] = mfma_f64_16x16x4(y0, y1, Gt[0][1]);
+        Gt[1][0] = mfma_f64_16x16x4(y1, y0, Gt[1][0]);
+        Gt[1][1] = mfma_f64_16x16x4(y1, y1, Gt[1][1]);
+    }
+    for (int kk = 0; kk < ksteps; ++kk) {
+        const int j = 4 * kk + tq;
+        const int jj = (j < n) ? j : 0;
+        const bool jin = j < n;
+        const double z0 = (ta < nf && jin) ? M2[(me + ta) * S + jj] : 0.0;
+        const double z1 = (16 + ta < nf && jin) ? M2[(me + ((16 + ta < nf) ? 16 + ta : 0)) * S + jj] : 0.0;
+        const double dj = jin ? V0[jj] : 0.0, hj = jin ? V1[jj] : 0.0;
+        const double b0 = (ta < nf) ? dj * z0 : ((ta == nf) ? hj : 0.0);
+        const double b1 = (16 + ta < nf) ? dj * z1 : ((16 + ta == nf) ? hj : 0.0);
+        Gt[0][0] = mfma_f64_16x16x4(z0, b0, Gt[0][0]);
+        Gt[0][1] = mfma_f64_16x16x4(z0, b1, Gt[0][1]);
+        Gt[1][0] = mfma_f64_16x16x4(z1, b0, Gt[1][0]);
+        Gt[1][1] = mfma_f64_16x16x4(z1, b1, Gt[1][1]);
+    }
+    // t = column nf of G (rows s < nf) -> V2; G itself masked to nf x nf with a unit diagonal beyond (the padding factor_tiles32 expects)
+    double Hf[16];
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int J = 0; J < 2; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int srow = 16 * I + tq + 4 * r, scol = 16 * J + ta;
+                const double v = Gt[I][J][r];
+                if (scol == nf && srow < nf) V2[srow] = v;
+                Hf[4 * (2 * I + J) + r] = (srow < nf && scol < nf) ? v : ((srow == scol) ? 1.0 : 0.0);
+            }
+    wave_sync();
+    const int c32 = lane & 31;
+    const double t32 = (c32 < nf) ? V2[c32] : 0.0;
+    wave_sync();
+    OSOT_SUB_END(PH_EQ_D);
+    // ---- G = L L', y = -G^-1 t on a borrowed 32-lane context: its 32 x 33 J' (= L^-1) over the head of M2 (the Z' rows are in registers
+    // by now), its panel staging over the head of M1, its staging vector the fourth of V
+    WaveCtx<32> w32;
+    w32.c = c32; w32.h = lane >> 5; w32.n = nf;
+    w32.M1 = M1; w32.M2 = M2; w32.V = V3;
+    w32.rlo = nullptr; w32.rup = nullptr; w32.rptr = nullptr; w32.rowstate = nullptr; w32.eqlist = nullptr; w32.rsrc = nullptr; w32.safe_row = 0ull;
+    double y32 = 0.0;
+    const int stf = uniform_i(factor_tiles32<false, true>(w32, Hf, t32, y32));
+    if (stf != QP_SOLVED) return -1;
+    OSOT_SUB_END(PH_CHOL);
+    // ---- x = x_prev + Z y
+    double x = valid ? xprev : 0.0;
+#pragma unroll
+    for (int s2 = 0; s2 < NF; ++s2) { if (s2 < nf) x = fma(zr[s2], bcast(y32, s2), x); }
+    // ---- J2' = L^-1 Z', IN PLACE in the lane's registers, last row first (row s2 needs the rows t2 <= s2 of Z' only), THEN -- behind a
+    // synchronisation: the rows of J2' land on top of the borrowed L^-1 -- into M2[(me + s2) S ..]
+    double hacc2 = 0.0;
+#pragma unroll
+    for (int s2 = NF - 1; s2 >= 0; --s2) {
+        if (s2 < nf) {
+            double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+            for (int t2 = 0; t2 <= s2; t2 += 2) {
+                acc0 = fma(M2[s2 * 33 + t2], zr[t2], acc0);
+                if (t2 + 1 <= s2) acc1 = fma(M2[s2 * 33 + t2 + 1], zr[t2 + 1], acc1);
+            }
+            zr[s2] = acc0 + acc1;
+            hacc2 = fma(zr[s2], zr[s2], hacc2);
+        }
+    }
+    wave_sync();
+#pragma unroll
+    for (int s2 = 0; s2 < NF; ++s2) { if (s2 < nf) M2[(me + s2) * S + c] = zr[s2]; }      // (phantom lanes: zeros -> the padding column stays zero)
+    wave_sync();
+    // the equality part of J', the borrowed context's remains below it, and the x_prev row: zero
+    for (int e = lane; e < me * S; e += 64) M2[e] = 0.0;
+    if (lane <= NP) M2[n * S + lane] = 0.0;
+    wave_sync();
+    OSOT_SUB_END(PH_EQ_HH);
+    x_out = x;
+    hinv_out = valid ? hacc2 : 0.0;
     return me;
 }
 
@@ -1554,7 +1833,8 @@ template <int NP, bool PROF, bool BOX = false>
 __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_h,
                         double hdiag, double (&Hc)[NP / WaveCtx<NP>::HV], bool has_box, double& lb, double& ub, int max_iter,
                         bool have_prev, double xprev, double& x_out, int& iters_out, long long* prof,
-                        double& slack_out, bool prepared = false, double xprep = 0.0, int hotcode = -1, int* hot_out = nullptr) {
+                        double& slack_out, bool prepared = false, double xprep = 0.0, int hotcode = -1, int* hot_out = nullptr,
+                        int dense_rank_in = -1, int dense_neq_in = 0, double dense_x_in = 0.0, double dense_hinv_in = 0.0) {
     constexpr int HV = WaveCtx<NP>::HV, S = WaveCtx<NP>::S;
     const int n = w_in.n;
     double* M1 = w_in.M1;
@@ -1565,6 +1845,13 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
     ub = clamp_inf(ub);
     double x;
     OSOT_PH_BEGIN();
+    // round 6, 40-lane layout: a DENSE level under many equality rows that x_prev satisfies has taken the null-space method INSTEAD of
+    // the H build, the factorisation and the row-by-row reflections (nullspace_dense_wide, called by the cascade AHEAD of the H build: its
+    // rank, the number of equality rows it eliminated, the equality-constrained minimiser and diag(J2 J2') arrive here)
+    const bool dense_ns = (NP == 40) && dense_rank_in >= 0;
+    const int dense_rank = dense_rank_in, dense_neq = dense_neq_in;
+    const double dense_hinv = dense_hinv_in;
+    if (dense_ns) x = dense_x_in;
     {   // ---------------- factorisation phase (own scope: see the launder_i note below) ----------------
     WaveCtx<NP> w1 = w_in;
     { const int l1 = launder_i(WaveCtx<NP>::lane_of(w_in.c, w_in.h)); w1.c = WaveCtx<NP>::col_of(l1); w1.h = WaveCtx<NP>::half_of(l1); }
@@ -1572,7 +1859,9 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
     const int c = w.c, h = w.h;
     const bool valid = c < n;
 
-    if (prepared) {
+    if (dense_ns) {
+        // (nothing to factorise: J2' is in M2, x is the equality-constrained minimiser)
+    } else if (prepared) {
         // JT is in M2 and the unconstrained minimiser is known already (lowrank_prepare32)
         x = xprep;
         OSOT_PH_END(PH_CHOL);
@@ -1619,7 +1908,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
     // elements already in flight (one HBM/L2 round trip per row would otherwise sit on the critical path)
     int n_eq = 0;
     bool local_eq = false;   // an equality among the level's task-local rows: x_prev does not satisfy it
-    for (int r0 = 0; r0 < nrows; r0 += 64) {
+    for (int r0 = 0; r0 < (dense_ns ? 0 : nrows); r0 += 64) {
         const int r = r0 + WaveCtx<NP>::lane_of(c, h);
         bool is_eq = false, is_loc = false;
         if (r < nrows) {
@@ -1638,6 +1927,18 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
     // global equality rows are; a task-local equality of this level is not: then the generic path runs): null-space
     // elimination instead of n_eq Householder updates of the full J (see nullspace_equalities32)
     bool used_nullspace = false;
+    if (dense_ns) {
+        // the rows' states as the walk above would have left them (the list itself was built ahead of the factorisation)
+        for (int r0 = 0; r0 < nrows; r0 += 64) {
+            const int r = r0 + WaveCtx<NP>::lane_of(c, h);
+            if (r < nrows) {
+                const double lo = w.rlo[r], up = w.rup[r];
+                w.rowstate[r] = ((lo == up) && (lo > -kInfty) && (lo < kInfty)) ? 3 : 0;
+            }
+        }
+        wave_sync();
+        iq = dense_rank; iters += dense_neq; used_nullspace = true;
+    }
 #ifdef OSOT_X_NO_NULLSPACE
     if (false) {
 #else
@@ -1802,7 +2103,7 @@ __device__ int gi_solve(const WaveCtx<NP>& w_in, int nrows, double g, bool diag_
     { const int l3 = launder_i(WaveCtx<NP>::lane_of(w_in.c, w_in.h)); w3.c = WaveCtx<NP>::col_of(l3); w3.h = WaveCtx<NP>::half_of(l3); }
     // after the null-space path the equality rows of J are zero, so |J'n|^2 no longer measures n'H^-1 n;
     // the diagonal of H^-1 does (hinv > 0 selects that in the dependency test)
-    const double hinv = (used_nullspace && valid) ? fast_rcp(hdiag) : 0.0;
+    const double hinv = dense_ns ? dense_hinv : ((used_nullspace && valid) ? fast_rcp(hdiag) : 0.0);
     return gi_inequalities<NP, PROF, BOX>(w3, nrows, x, iq, me, Aq, uq, iters, has_box, lb, ub, max_iter, used_nullspace, hinv,
                                      have_prev, xprev, slack_out, x_out, iters_out, prof, hotcode, hot_out);
 }

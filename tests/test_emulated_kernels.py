@@ -169,16 +169,23 @@ def test_small_generic_cascades(n, rows, n_eq, n_ineq, oracle):
         assert (rq["status"] == 1).all() and np.abs(dq - rq["dq"]).max() < 1e-6
 
 
-@pytest.mark.parametrize("rows,n_eq,n_ineq,dup", [([3, 12], 12, 0, None), ([3, 6, 6], 12, 0, None), ([5, 12], 12, 0, None), ([3, 12], 12, 4, None),
-                                                   ([3, 12], 6, 0, 0)])
-def test_nullspace_elimination_on_the_40_lane_layout(rows, n_eq, n_ineq, dup, oracle):
+@pytest.mark.parametrize("rows,n_eq,n_ineq,dup,eps", [([3, 12], 12, 0, None, 1e6), ([3, 6, 6], 12, 0, None, 1e6), ([5, 12], 12, 0, None, 1e6),
+                                                       ([3, 12], 12, 4, None, 1e6), ([3, 12], 6, 0, 0, 1e6),
+                                                       # the DENSE levels' null-space method (nullspace_dense_wide) with the bounds and inequality rows at work,
+                                                       # a 23-column reduced Hessian, a 20-row level, and the reference's default eps (factor 200)
+                                                       ([8, 10], 2, 4, None, 1e6), ([6, 20], 8, 3, None, 1e6), ([3, 12], 12, 4, None, 2e2), ([3, 6, 6], 12, 0, None, 2e2),
+                                                       # ... and at the FIRST level (no x_prev: the global rows' right-hand sides ride along in the elimination):
+                                                       # S2's shape (15 rows over the feet), one dense level, dependent consistent rows among the global ones
+                                                       ([15], 12, 0, None, 1e6), ([15], 12, 3, None, 2e2), ([20], 14, 0, None, 1e6)])
+def test_nullspace_elimination_on_the_40_lane_layout(rows, n_eq, n_ineq, dup, eps, oracle):
     """round 6 -- nullspace_equalities_wide: the Postural last level of the reference's COMAN stacks (coman_ik.cpp:425-449; 35
     coordinates: the 40-lane layout) under its 27 equality rows -- the feet as global equality rows (12), the CoM level (3), the wrists
     (12) -- by Gauss-Jordan in 2 x 3 tiles instead of 27 reflections of the full J.  S3's and S4's shapes, 29 rows (six free columns),
     with inequality rows beside the box (the general instantiation), and -- last case -- 27 rows of rank 21: fourteen free columns, more
     than the elimination carries, so it hands the level back to the generic path with J' restored.  Against the restated eiQuadProg
     cascade (1e-9) and the reference's qpOASES (1e-6)."""
-    plan, leaf = synth.make_generic_stack(6, 35, rows, n_eq=n_eq, n_ineq=n_ineq, seed=61 + len(rows) + n_ineq, box=0.3, duplicate_eq_in_level=dup)
+    plan, leaf = synth.make_generic_stack(6, 35, rows, n_eq=n_eq, n_ineq=n_ineq, seed=61 + len(rows) + n_ineq, box=(0.3 if n_eq == 12 else 0.05),
+                                          duplicate_eq_in_level=dup, eps_factor=eps)
     asm = oracle.assemble(plan, leaf)
     dq, xl, st, it = emu_cascade(plan, asm)
     assert (st == 0).all()
