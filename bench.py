@@ -477,7 +477,7 @@ def coman_stack(which, n):
     return StackPlan(n=n, levels=levels, bounds=bounds, rowblocks=rows, eps_abs=eps_abs_from_factor(1e6))
 
 
-def time_coman35(which, B, device, steps=20, warmup=5, front_end="iHQP", specialise=True, fused=True, lanes=1, streams=None, graph=True):
+def time_coman35(which, B, device, steps=20, warmup=5, front_end="iHQP", specialise=True, fused=True, lanes=1, streams=None, graph=True, hot=False):
     """the reference example's control loop (coman_ik.cpp:174-219) for B robots, everything resident: q -> frame poses, Jacobians,
     CoM (rows written straight into A_k / C) -> AutoStack::update + Solver::solve -> q += dq.  Each robot chases its own random
     wrist goals (+-0.2 m, as the reference's harness draws them), so the inputs of consecutive steps are the closed loop's own
@@ -513,6 +513,8 @@ def time_coman35(which, B, device, steps=20, warmup=5, front_end="iHQP", special
         st = BatchedStack(plan, Bl, device=device, want_levels=False)
         if not specialise:
             st.set_specialisation(False)
+        if hot:
+            st.set_hotstart(True)       # (every level's working set of the robot's previous control cycle: QPOasesBackEnd.cpp:258-285)
         # (the caller's streams where it has them: fresh ones can land on a hardware queue another lane already uses)
         stream = streams[len(work)] if (streams is not None and len(work) < len(streams)) else torch.cuda.Stream(device=dev)
         st.stream = stream

@@ -216,6 +216,91 @@ __device__ __forceinline__ void sym_tred2_32(double* K, double* E, int k, int c,
     d_out = scale_pow2(d, kexp); e_out = scale_pow2(e, kexp);
 }
 
+// Round 6: sym_tred2_32<false> with the matrix in REGISTERS.  The LDS form above pays, per reflector step, two chunked passes over the
+// lane's row (8 reads in flight, ~150 clocks per chunk and dependent on the one before) with two synchronisations around them: 4.5 k
+// clocks per step, 100 k of the 270 k clocks of a 24 x 29 level (BASELINE config 3's level 1).  Here lane c keeps row c of the
+// symmetric work matrix in 32 registers (both halves the same row: nothing is split, nothing is exchanged through LDS), the
+// reflector's entries u_kk and q_kk reach the other lanes as v_readlane broadcasts (scalar operands of the fma), the steps are unrolled
+// with compile-time bounds (steps at or beyond k are skipped by a scalar branch), and p = A u is a lane-local dot product -- no
+// reduction.  The arithmetic is the LDS form's operation by operation (the even / odd partial sums of p are the two halves' chunks) except
+// that a step takes row i of the symmetric matrix from the lanes' own COLUMN-i entries (the two triangles differ in the last bit: the
+// rank-two update rounds u_c q_k + q_c u_k differently on either side of the diagonal): (d, e) and the stored reflectors (row i of K = u,
+// column i = u / H: what sym_bisect_32<2> back-transforms through) agree with the LDS form's to round-off.
+template <int P, int N, class F>
+__device__ __forceinline__ void nh_static_for(F& f) {
+    if constexpr (P < N) { f(std::integral_constant<int, P>{}); nh_static_for<P + 1, N>(f); }
+}
+#ifndef OSOT_X_TRED2_LDS
+constexpr bool kTred2Regs = true;
+#else
+constexpr bool kTred2Regs = false;      // (A/B builds: the LDS form)
+#endif
+__device__ __forceinline__ void sym_tred2_32_regs(double* K, int k, int c, int h, double& d_out, double& e_out) {
+    double e = 0.0;
+    const bool wr = (h == 0);
+    double a[32];                        // row c of the work matrix
+    int kexp = 0;
+    {
+        double rmax = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) { a[kk] = K[c * kNS + kk]; rmax = fmax(rmax, fabs(a[kk])); }
+        kexp = frexp_exponent(uniform_d(colmax<32>(rmax)));
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) a[kk] = scale_pow2(a[kk], -kexp);
+    }
+    auto step = [&](auto ic) {
+        constexpr int I = 31 - decltype(ic)::value;      // i = 31 .. 1
+        constexpr int L = I - 1;
+        if (I >= k) return;                              // (uniform)
+        double e_i;
+        if constexpr (L > 0) {
+            double ai = (c <= L) ? a[I] : 0.0;           // row I at my column = my row at column I (the rows are kept symmetric)
+            double hv = uniform_d(colsum<32>(ai * ai));
+            if (hv < 1.0e-30) {                          // (round-off: no reflector -- see the LDS form)
+                e_i = 0.0;
+                if (wr && c <= L) { K[I * kNS + c] = 0.0; K[c * kNS + I] = 0.0; }
+            } else {
+                const double f0 = bcast(ai, L);
+                double sq, rs;
+                fast_sqrt_rsqrt(hv, sq, rs);
+                const double g0 = (f0 >= 0.0) ? -sq : sq;
+                e_i = g0;
+                hv -= f0 * g0;
+                if (c == L) ai = f0 - g0;
+                const double ih = fast_rcp(hv);
+                if (wr && c <= L) { K[I * kNS + c] = ai; K[c * kNS + I] = ai * ih; }    // row I <- u, column I <- u / H
+                double u[L + 1];
+#pragma unroll
+                for (int kk = 0; kk <= L; ++kk) u[kk] = bcast(ai, kk);
+                double pe = 0.0, po = 0.0;               // (the two halves' partial sums of the LDS form)
+#pragma unroll
+                for (int kk = 0; kk <= L; ++kk) {
+                    if (kk & 1) po = fma(a[kk], u[kk], po);
+                    else pe = fma(a[kk], u[kk], pe);
+                }
+                const double pj = (h ? po + pe : pe + po) * ih;
+                const double f1 = uniform_d(colsum<32>((c <= L) ? pj * ai : 0.0));
+                const double hh2 = 0.5 * f1 * ih;
+                const double qj = (c <= L) ? pj - hh2 * ai : 0.0;
+#pragma unroll
+                for (int kk = 0; kk <= L; ++kk) {
+                    const double nv = a[kk] - fma(ai, bcast(qj, kk), qj * u[kk]);
+                    a[kk] = (c <= L) ? nv : a[kk];
+                }
+            }
+        } else {
+            e_i = bcast(a[1], 0);                        // K[1][0]
+        }
+        if (c == I) e = e_i;
+    };
+    nh_static_for<0, 31>(step);
+    double dd = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) dd = (kk == c) ? a[kk] : dd;
+    wave_sync();
+    d_out = scale_pow2((c < k) ? dd : 0.0, kexp); e_out = scale_pow2(e, kexp);
+}
+
 // phase 3 of sym_eig32: implicit QL with shifts on (d, e) (lane c: d[c]; e[c] couples c - 1 and c on entry), rotations into the columns of K
 __device__ __forceinline__ void sym_ql_32(double* K, int k, int c, int h, double& d, double& e) {
     constexpr double kEps = 2.220446049250313e-16;
@@ -483,6 +568,38 @@ __device__ __forceinline__ bool sym_bisect_32(double* K, double* E, int k, int c
         // my column of Y normalised in place, then V = H_(k-1) .. H_2 Y for every column at once (lane = column, its entries split
         // over the halves): tred2 left reflector i as row i of K (u) and column i of K (u / H); what Q would have cost to build
         // and to multiply is k - 2 dot products and updates of a column here.  Only the first nl columns are used afterwards.
+        if constexpr (kTred2Regs) {
+            // (round 6) my column of Y in 32 registers, both halves the same column: the reflector's two vectors are uniform-address LDS
+            // reads in flight together, the dot product is lane-local, no synchronisation between the steps (a column belongs to its lane)
+            double y[32];
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) { const double v = E[kk * kNS + c]; y[kk] = (kk < k) ? v * rs : 0.0; }
+            auto bstep = [&](auto ic) {
+                constexpr int I = decltype(ic)::value;       // 2 .. 31
+                constexpr int L = I - 1;
+                if (I >= k) return;                          // (uniform)
+                double u[L + 1], uh[L + 1];
+#pragma unroll
+                for (int kk = 0; kk <= L; ++kk) { u[kk] = K[I * kNS + kk]; uh[kk] = K[kk * kNS + I]; }
+                double de = 0.0, dq = 0.0;                   // (the two halves' partial sums of the LDS form)
+#pragma unroll
+                for (int kk = 0; kk <= L; ++kk) {
+                    if (kk & 1) dq = fma(u[kk], y[kk], dq);
+                    else de = fma(u[kk], y[kk], de);
+                }
+                const double dot = h ? dq + de : de + dq;
+#pragma unroll
+                for (int kk = 0; kk <= L; ++kk) y[kk] = fma(-dot, uh[kk], y[kk]);
+            };
+            nh_static_for<2, 32>(bstep);
+            wave_sync();
+            if (in && h == 0) {
+#pragma unroll
+                for (int kk = 0; kk < 32; ++kk) if (kk < k) E[kk * kNS + c] = y[kk];
+            }
+            wave_sync();
+            return true;
+        }
 #pragma unroll
         for (int t = 0; t < 16; ++t) { const int r = 2 * t + h; const double v = E[r * kNS + c]; if (r < k && in) E[r * kNS + c] = v * rs; }
         wave_sync();
@@ -575,7 +692,8 @@ __device__ __forceinline__ void sym_eig32_fast(double* K, double* E, int k_in, i
 __device__ __forceinline__ bool sym_eig_selected32(double* K, double* E, int k_in, int c, int h, double thr2, double& lam, int& nl) {
     const int k = uniform_i(k_in);
     double d, e;
-    sym_tred2_32<false>(K, E, k, c, h, d, e);
+    if constexpr (kTred2Regs) sym_tred2_32_regs(K, k, c, h, d, e);
+    else sym_tred2_32<false>(K, E, k, c, h, d, e);
     int nsel = 0;
     const bool ok = uniform_b(sym_bisect_32<2>(K, E, k, c, h, d, e, thr2, &nsel));
     wave_sync();
@@ -587,7 +705,8 @@ __device__ __forceinline__ bool sym_eig_selected32(double* K, double* E, int k_i
 __device__ __forceinline__ double sym_eigvals32(double* K, double* E, int k_in, int c, int h) {
     const int k = uniform_i(k_in);
     double d, e;
-    sym_tred2_32<false>(K, E, k, c, h, d, e);
+    if constexpr (kTred2Regs) sym_tred2_32_regs(K, k, c, h, d, e);
+    else sym_tred2_32<false>(K, E, k, c, h, d, e);
     sym_bisect_32<0>(K, E, k, c, h, d, e);
     wave_sync();
     if (h == 0) { K[c * kNS + 32] = 0.0; E[c * kNS + 32] = 0.0; }
@@ -986,6 +1105,9 @@ __global__ void __launch_bounds__(64) osot_nhqp_prepare_kernel(const DevNhqp Q) 
         // Householder vectors: for column i, reflect x = V1[i:, i] onto alpha e_i; apply to the later columns.  The update of the
         // later columns is done with lane = COLUMN j (its 32 components split over the halves, fixed trip counts): with lane =
         // component it was one wave reduction and two barriers per (i, j) pair -- 276 of them for 24 reflectors.
+        // (round 6: lane j keeping column j in 32 registers through all the steps -- norms lane-local, the reflector as v_readlane
+        //  broadcasts, no LDS round trip inside the loop -- was built and measured 1.5-2 % SLOWER at config 3: twice the vector
+        //  instructions, both halves carrying all 32 components, for a shorter chain that the other sub-batches' kernels hide anyway)
         for (int i = 0; i < nrefl; ++i) {
             const double v1ci = V1[c * kNS + i];
             const double x = (c >= i && c < nf) ? v1ci : 0.0;

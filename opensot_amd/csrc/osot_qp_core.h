@@ -833,6 +833,7 @@ enum { PH_HBUILD = 0, PH_CHOL = 1, PH_INV = 2, PH_SUBST = 3, PH_EQ = 4, PH_INEQ 
        PH_IN_SCAN = 12, PH_IN_D = 13, PH_IN_Z = 14, PH_IN_R = 15, PH_IN_HH = 16, PH_IN_DROP = 17, PH_COUNT = 18 };
 #define OSOT_SUB_BEGIN() long long sub_t0_ = PROF ? (long long)clock64() : 0
 #define OSOT_SUB_END(idx) do { if (PROF) { const long long t_ = (long long)clock64(); prof[idx] += t_ - sub_t0_; sub_t0_ = t_; } } while (0)
+#define OSOT_SUB_RESET() do { if (PROF) sub_t0_ = (long long)clock64(); } while (0)      /* behind a callee that keeps its own sub-phase clock */
 #define OSOT_PH_BEGIN() long long ph_t0_ = PROF ? (long long)clock64() : 0
 #define OSOT_PH_END(idx) do { if (PROF) { const long long t_ = (long long)clock64(); prof[idx] += t_ - ph_t0_; ph_t0_ = t_; } } while (0)
 
@@ -1242,6 +1243,7 @@ __device__ inline int nullspace_equalities_wide(const WaveCtx<NP>& w, int n_eq, 
     v4f64 Et[2 * TC];
     unsigned long long basicmask = 0ull;
     gj_reduce_wide<NP, PROF>(w, n_eq, Et, basicmask, prof);
+    OSOT_SUB_RESET();
     int* pivcol = reinterpret_cast<int*>(w.M1);
     const bool basic = valid && ((basicmask >> c) & 1ull);
     const unsigned long long fmask = wave_ballot(valid && !basic && lane < NP);
@@ -1360,6 +1362,7 @@ __device__ inline int nullspace_dense_wide(const WaveCtx<NP>& w, int n_eq, const
     // (the FIRST level has no x_prev: its equality rows are global rows with their own right-hand sides, which ride along in the
     //  elimination -- a particular solution then is "basic variables = the reduced right-hand sides, free variables = 0")
     gj_reduce_wide<NP, PROF>(w, n_eq, Et, basicmask, prof, !have_prev);
+    OSOT_SUB_RESET();
     int* pivcol = reinterpret_cast<int*>(M1);
     const bool basic = valid && ((basicmask >> c) & 1ull);
     const unsigned long long fmask = wave_ballot(valid && !basic && lane < NP);
