@@ -42,6 +42,9 @@ extern "C" {
 #define OSOT_MAX_ROWBLOCKS 8  /* constraint-row blocks (global and task-local) */
 #define OSOT_MAX_BAND_ROWS 6  /* rows of a task used as a constraint (TaskToConstraint error band) */
 #define OSOT_MAX_VARS 64      /* one lane per variable        */
+#define OSOT_MAX_QP_VARS 128  /* the explicit-QP surface (osot_qp_solve_batch, osot_backend_*): 65 .. 128 variables run one
+                                 256-thread workgroup per QP instead of one wavefront (round 6; cold start, no graph capture);
+                                 plans (osot_solver_create), nHQP / eHQP and the ADMM kernel stay at OSOT_MAX_VARS */
 
 /* error codes (the reference returns bool / throws std::runtime_error) */
 enum {
@@ -430,7 +433,8 @@ int osot_ehqp_solve(osot_solver* s, const osot_qp_batch* batch, double sigma_min
 /* ---- batch-of-one BackEnd surface (host pointers; mirrors BackEnd.h) ------------------------ */
 typedef struct osot_backend osot_backend;
 /* create_instance(number_of_variables, number_of_constraints, hessian_type, eps_regularisation)
- * (QPOasesBackEnd.cpp:14-24). eps_regularisation is the FACTOR; absolute eps = 2.221e-13 * factor. */
+ * (QPOasesBackEnd.cpp:14-24). eps_regularisation is the FACTOR; absolute eps = 2.221e-13 * factor.
+ * number_of_variables <= OSOT_MAX_QP_VARS (128; see osot_qp_solve_batch for the path beyond 64). */
 int osot_backend_create(int number_of_variables, int number_of_constraints, int hessian_type,
                         double eps_regularisation, osot_backend** out);
 int osot_backend_destroy(osot_backend* be);
@@ -458,7 +462,12 @@ int osot_backend_get_num_variables(osot_backend* be, int* nv);
 int osot_backend_get_num_constraints(osot_backend* be, int* nc);
 
 /* batched generic QP: B independent problems of the SAME shape in BackEnd convention, device
- * pointers, one wavefront each.  H: [B][n][n], g: [B][n], A: [B][nc][n], ...; x out [B][n]. */
+ * pointers, one wavefront each.  H: [B][n][n], g: [B][n], A: [B][nc][n], ...; x out [B][n].
+ * n <= OSOT_MAX_QP_VARS (128).  Problems of 65 .. 128 variables -- wider than a wavefront: include/OpenSoT/Task.h:47-565 has no limit, a
+ * 45-DoF robot or a floating-base inverse-dynamics stack with five contacts is such a problem -- run one 256-thread WORKGROUP per QP
+ * (opensot_amd/csrc/osot_qp_big.h: the same dual active-set method; J in a stream-ordered device workspace of 2 n^2 doubles per
+ * resident QP, R and the vectors in LDS; nc <= 2048).  That path starts cold on every call (osot_backend_solve included: the plugin's
+ * hot-start record is for n <= 64) and allocates with hipMallocAsync on the caller's stream: do not capture it into a HIP graph. */
 int osot_qp_solve_batch(int B, int n, int nc, const double* H, const double* g, const double* A,
                         const double* lA, const double* uA, const double* l, const double* u,
                         double eps_abs, int max_iter, double* x, int* status, int* iterations,

@@ -6,6 +6,7 @@ import ctypes as C
 import os
 
 MAX_LEVELS, MAX_TASKS, MAX_BOUNDS, MAX_ROWBLOCKS, MAX_VARS = 8, 8, 4, 8, 64
+MAX_QP_VARS = 128      # the explicit-QP surface (osot_qp_solve_batch, osot_backend_*): OSOT_MAX_QP_VARS
 MAX_BAND_ROWS, ID_MAX_FORCE_VARS = 6, 24
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NOT_SOLVED, ERR_COMM = range(6)

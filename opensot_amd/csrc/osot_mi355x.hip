@@ -22,6 +22,7 @@
 #include "osot_id.h"
 #include "osot_nhqp_host.h"
 #include "osot_admm.h"
+#include "osot_qp_big.h"
 
 using namespace osot;
 
@@ -724,11 +725,34 @@ static int qp_solve_batch_impl(int B, int n, int nc, const double* H, const doub
                                const double* lA, const double* uA, const double* l, const double* u,
                                double eps_abs, int max_iter, double* x, int* status, int* iterations,
                                void* hip_stream, int* hot) {
-    if (B < 0 || n < 1 || n > OSOT_MAX_VARS || nc < 0) return fail(OSOT_ERR_INVALID, "bad sizes");
+    if (B < 0 || n < 1 || n > OSOT_MAX_QP_VARS || nc < 0) return fail(OSOT_ERR_INVALID, "bad sizes");
     if (B == 0) return OSOT_OK;
     if (!H || !g || !x || !status) return fail(OSOT_ERR_INVALID, "null H/g/x/status");
     if (nc > 0 && (!A || !lA || !uA)) return fail(OSOT_ERR_INVALID, "nc > 0 but A/lA/uA is null");
     if ((l == nullptr) != (u == nullptr)) return fail(OSOT_ERR_INVALID, "l and u must both be given or both be null");
+    if (n > OSOT_MAX_VARS) {
+        // wider than a wavefront (65 .. 128 variables): one 256-thread workgroup per QP (osot_qp_big.h).  Cold start (the hot-start
+        // record of the plugin route is not used), stream-ordered workspace: not for HIP graph capture.
+        if (nc > big::kMaxRows) return fail(OSOT_ERR_UNSUPPORTED, "more than 2048 constraint rows with more than 64 variables");
+        DevQPBig Q;
+        std::memset(&Q, 0, sizeof(Q));
+        Q.B = B; Q.n = n; Q.nc = nc;
+        Q.max_iter = max_iter > 0 ? max_iter : 20 * (n + nc) + 100;
+        Q.eps_abs = eps_abs;
+        Q.H = H; Q.g = g; Q.A = A; Q.lA = lA; Q.uA = uA; Q.l = l; Q.u = u;
+        Q.x = x; Q.status = status; Q.iterations = iterations;
+        const size_t lds = big::shared_bytes(n, nc);
+        int r = ensure_lds(osot_qp_big_kernel, lds);
+        if (r != OSOT_OK) return r;
+        const unsigned grid = (unsigned)(B < 512 ? B : 512);
+        const size_t wbytes = (size_t)grid * 2 * (size_t)n * n * sizeof(double);
+        HIP_TRY(hipMallocAsync((void**)&Q.work, wbytes, (hipStream_t)hip_stream));
+        hipLaunchKernelGGL(osot_qp_big_kernel, dim3(grid), dim3(256), lds, (hipStream_t)hip_stream, Q);
+        const hipError_t le = hipGetLastError();
+        HIP_TRY(hipFreeAsync(Q.work, (hipStream_t)hip_stream));
+        HIP_TRY(le);
+        return OSOT_OK;
+    }
     DevQP Q;
     std::memset(&Q, 0, sizeof(Q));
     Q.B = B; Q.n = n; Q.nc = nc;
@@ -876,8 +900,8 @@ int osot_backend_create(int number_of_variables, int number_of_constraints, int 
                         double eps_regularisation, osot_backend** out) {
     if (!out) return fail(OSOT_ERR_INVALID, "null out");
     *out = nullptr;
-    if (number_of_variables < 1 || number_of_variables > OSOT_MAX_VARS)
-        return fail(OSOT_ERR_INVALID, "number_of_variables out of range (1..64)");
+    if (number_of_variables < 1 || number_of_variables > OSOT_MAX_QP_VARS)
+        return fail(OSOT_ERR_INVALID, "number_of_variables out of range (1..128)");
     if (number_of_constraints < 0) return fail(OSOT_ERR_INVALID, "negative number_of_constraints");
     if (eps_regularisation < 0) return fail(OSOT_ERR_INVALID, "Negative eps is not allowed!");
     osot_backend* be = new osot_backend();

@@ -558,3 +558,106 @@ def judge_remainder(asm, dq_dev, results, active=None, tol=1e-6, feas_tol=1e-7, 
 def max_where(mask, values):
     """max of values[mask], 0 when the mask is empty (the remainder is judge_remainder's)"""
     return float(values[mask].max()) if np.any(mask) else 0.0
+
+
+_big = None
+
+
+def big_host_solve(H, g, A, lA, uA, l, u, eps_abs, max_iter=0):
+    """one QP through the WIDE solver (opensot_amd/csrc/osot_qp_big.h: 65 .. 128 variables) compiled for the host with a team of one
+    thread (tests/emu/big_host.cpp).  Returns (status, x, iterations)."""
+    global _big
+    if _big is None:
+        so = os.path.join(ROOT, "tests", "emu", "libosot_big_host.so")
+        srcs = [os.path.join(ROOT, "opensot_amd", "csrc", "osot_qp_big.h"), os.path.join(ROOT, "tests", "emu", "big_host.cpp")]
+        if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in srcs):
+            subprocess.check_call(["sh", os.path.join(ROOT, "tests", "emu", "build.sh")])
+        _big = C.CDLL(so)
+    dp = C.POINTER(C.c_double)
+    n = H.shape[0]
+    nc = 0 if A is None else A.shape[0]
+    keep = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (H, g, A, lA, uA, l, u)]
+    ptr = [None if a is None else a.ctypes.data_as(dp) for a in keep]
+    x = np.zeros(n)
+    st, it = C.c_int(-1), C.c_int(0)
+    rc = _big.osot_big_host_solve(n, nc, *ptr, C.c_double(eps_abs), int(max_iter), x.ctypes.data_as(dp), C.byref(st), C.byref(it))
+    assert rc == 0, "osot_big_host_solve refused the sizes"
+    return st.value, x, it.value
+
+
+def id_like_levels(rng, nv=56, ncon=5, tau_max=60.0):
+    """two levels of a floating-base inverse-dynamics stack WIDER than 64 variables as explicit QPs in BackEnd convention (the shape of
+    src/utils/InverseDynamics.cpp:12-28): x = [qddot (nv); F (3 per point contact)]; rows: dynamic feasibility (6 equalities), friction
+    pyramids (5 rows per contact), torque limits (nv - 6 bilateral rows); box: acceleration limits and force limits.  Level 0: 15 task
+    rows on qddot (a CoM and two Cartesian tasks), level 1: a Postural task on qddot under level 0's optimality rows.
+    Returns (n, level) with level(k, xs) -> (H, g, A, lA, uA, l, u), xs = the solutions of the levels above."""
+    nf = 3 * ncon
+    n = nv + nf
+    Q = rng.normal(size=(nv, nv)) * 0.3
+    M = Q.T @ Q + np.eye(nv) * 2.0
+    Jc = rng.normal(size=(nf, nv)) * 0.5
+    h = rng.normal(size=nv) * 2.0
+    h[2] += 9.81 * 5.0
+    dyn = np.hstack([M, -Jc.T])
+    rows, lo, up = [], [], []
+    for r in range(6):
+        rows.append(dyn[r]); lo.append(-h[r]); up.append(-h[r])
+    mu = 0.7
+    for c in range(ncon):
+        fx, fy, fz = nv + 3 * c, nv + 3 * c + 1, nv + 3 * c + 2
+        for (a, sgn) in ((fx, 1), (fx, -1), (fy, 1), (fy, -1)):
+            row = np.zeros(n); row[a] = sgn; row[fz] = -mu
+            rows.append(row); lo.append(-np.inf); up.append(0.0)
+        row = np.zeros(n); row[fz] = 1.0
+        rows.append(row); lo.append(0.0); up.append(1.0e3)
+    for r in range(6, nv):
+        rows.append(dyn[r]); lo.append(-tau_max - h[r]); up.append(tau_max - h[r])
+    Cm, lo, up = np.array(rows), np.array(lo), np.array(up)
+    l = np.concatenate([-np.full(nv, 80.0), np.full(nf, -1.0e3)])
+    u = np.concatenate([np.full(nv, 80.0), np.full(nf, 1.0e3)])
+    m0 = 15
+    A0 = np.hstack([rng.normal(size=(m0, nv)) * 0.6, np.zeros((m0, nf))])
+    b0 = rng.normal(size=m0) * 3.0
+    qref = rng.normal(size=nv) * 0.5
+
+    def level(k, xs):
+        if k == 0:
+            return A0.T @ A0, -A0.T @ b0, Cm, lo, up, l, u
+        H = np.zeros((n, n)); H[:nv, :nv] = np.eye(nv)
+        g = np.zeros(n); g[:nv] = -qref
+        t = A0 @ xs[0]
+        return H, g, np.vstack([Cm, A0]), np.concatenate([lo, t]), np.concatenate([up, t]), l, u
+    return n, level
+
+
+_refqp = None
+
+
+def ref_qpoases_solve(H, g, A, lA, uA, l, u, eps_factor, exact=False):
+    """one QP through the REFERENCE's own qpOASES 3.1 (oracle/_ref/libqpoases_ref.so, compiled in place from /root/reference by
+    oracle/Makefile; QPOasesBackEnd.cpp:51-76 option set, absolute eps = 2.221e-13 * eps_factor), cold-initialised.  exact: its
+    termination tolerance tightened to 1e-12 (the reference's MPC option set stops at 1e-7 relative).  Returns (ok, x) or None
+    where the reference build is not present."""
+    global _refqp
+    so = os.path.join(ROOT, "oracle", "_ref", "libqpoases_ref.so")
+    if not os.path.exists(so):
+        return None
+    if _refqp is None:
+        _refqp = C.CDLL(so)
+        _refqp.refqp_create.restype = C.c_void_p
+        _refqp.refqp_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
+        vp, dp = C.c_void_p, C.POINTER(C.c_double)
+        _refqp.refqp_init.argtypes = [vp, dp, dp, dp, dp, dp, dp, dp]
+        _refqp.refqp_get_solution.argtypes = [vp, dp]
+        _refqp.refqp_destroy.argtypes = [vp]
+    dp = C.POINTER(C.c_double)
+    n = H.shape[0]
+    nc = 0 if A is None else A.shape[0]
+    keep = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (H, g, A, lA, uA, l, u)]
+    ptr = [None if a is None else a.ctypes.data_as(dp) for a in keep]
+    h = _refqp.refqp_create(n, nc, abi.HST_UNKNOWN, float(eps_factor), 1.0e-12 if exact else -1.0)
+    ok = _refqp.refqp_init(h, *ptr)
+    x = np.zeros(n)
+    _refqp.refqp_get_solution(h, x.ctypes.data_as(dp))
+    _refqp.refqp_destroy(h)
+    return bool(ok), x

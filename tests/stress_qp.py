@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE (run on the GPU box by tests/test_gpu_backend.py, or by hand): randomised sweep of osot_qp_solve_batch (the BackEnd-convention kernel: explicit H, g,
-rows, box) over shapes n = 2..64 with full-rank and rank-deficient Hessians; every instance is checked by KKT and a
+rows, box) over shapes n = 2..64 (third argument "wide": 65..128, the workgroup-per-QP path) with full-rank and rank-deficient Hessians; every instance is checked by KKT and a
 sample against the oracle's single-QP solve (eiQuadProg restatement; qpOASES where oracle/_ref exists)."""
 import os, sys, time, ctypes as C
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,15 +7,19 @@ sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, 'tests'))
 import numpy as np, torch
 from opensot_amd import abi
 from oracle import pyoracle as oracle
-from helpers import random_qp, kkt_check
+from helpers import random_qp, kkt_check, ref_qpoases_solve
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+WIDE = len(sys.argv) > 3 and sys.argv[3] == "wide"      # 65 .. 128 variables: the workgroup-per-QP path (osot_qp_big.h, round 6)
 dev = torch.device("cuda", 0)
 bad = 0; t0 = time.time(); total = 0
 for it_ in range(N):
     n = int(rng.integers(2, 65)); nc = int(rng.integers(0, 40)); n_eq = int(rng.integers(0, min(nc, n // 2) + 1)) if nc else 0
     B = 64
+    if WIDE:
+        n = int(rng.integers(65, 129)); nc = int(rng.integers(0, 140)); n_eq = int(rng.integers(0, min(nc, n // 2) + 1)) if nc else 0
+        B = 16
     H, g, A, lA, uA, l, u = random_qp(rng, B, n, nc, n_eq, box=bool(rng.integers(0, 4) > 0))
     eps = float(rng.choice([1e-9, 2.221e-7, 4.442e-11]))
     deficient = bool(rng.integers(0, 3) == 0)
@@ -57,7 +61,12 @@ for it_ in range(N):
             ok, xo, _ = oracle.backend_solve(*args(i))
             if ok and np.abs(xs[i] - xo).max() > 1e-6 * max(1.0, np.abs(xo).max()):
                 msg = f"differs from the oracle by {np.abs(xs[i] - xo).max():.2e} (instance {i})"
+            rq = ref_qpoases_solve(*args(i)[:7], eps / 2.221e-13)       # the reference's own qpOASES 3.1 (oracle/_ref), where present
+            if rq is not None and rq[0] and np.abs(xs[i] - rq[1]).max() > 1e-6 * max(1.0, np.abs(rq[1]).max()):
+                # (qpOASES stops at its MPC option set's tolerance: the oracle's exact answer decides whether this is the reference's slack)
+                if not (ok and np.abs(xs[i] - xo).max() <= 1e-8 * max(1.0, np.abs(xo).max())):
+                    msg = f"differs from the reference's qpOASES by {np.abs(xs[i] - rq[1]).max():.2e} (instance {i})"
     if msg:
         bad += 1
         print("MISMATCH n=%d nc=%d n_eq=%d box=%s eps=%.1e deficient=%s: %s" % (n, nc, n_eq, l is not None, eps, deficient, msg), flush=True)
-print(f"{N} QP shapes x 64 instances ({total}) in {time.time() - t0:.0f} s: {bad} with a mismatch")
+print(f"{N} QP shapes x {B} instances ({total}) in {time.time() - t0:.0f} s: {bad} with a mismatch" + (" (65 .. 128 variables)" if WIDE else ""))

@@ -92,7 +92,8 @@ def test_plan_validation_errors(lib):
 def test_backend_argument_checks_without_gpu(lib):
     h = C.c_void_p()
     assert lib.osot_backend_create(0, 0, abi.HST_SEMIDEF, 1.0, C.byref(h)) == abi.ERR_INVALID
-    assert lib.osot_backend_create(65, 0, abi.HST_SEMIDEF, 1.0, C.byref(h)) == abi.ERR_INVALID
+    assert lib.osot_backend_create(abi.MAX_QP_VARS + 1, 0, abi.HST_SEMIDEF, 1.0, C.byref(h)) == abi.ERR_INVALID      # (128 since round 6: osot_qp_big.h)
+    assert lib.osot_backend_create(65, 0, abi.HST_SEMIDEF, 1.0, C.byref(h)) == abi.OK and lib.osot_backend_destroy(h) == abi.OK
     assert lib.osot_backend_create(3, -1, abi.HST_SEMIDEF, 1.0, C.byref(h)) == abi.ERR_INVALID
     assert lib.osot_backend_create(3, 1, abi.HST_SEMIDEF, -1.0, C.byref(h)) == abi.ERR_INVALID
     assert lib.osot_backend_create(3, 1, abi.HST_SEMIDEF, 1.0, C.byref(h)) == abi.OK
