@@ -938,6 +938,48 @@ def time_admm(B, device, steps=10, warmup=3):
                                      "by construction, the problem is read once and iterated on ~100 times)")}
 
 
+def time_wide_qp(B, device, steps=3, warmup=1, nv=55, ncon=5):
+    """the explicit-QP surface BEYOND the 64 lanes of a wavefront (osot_qp_big.h, round 6: one 256-thread workgroup per QP): the second
+    level of a floating-base inverse-dynamics stack of nv + 3 ncon = 70 variables -- a Postural task on the accelerations under the
+    optimality rows of the level above, dynamic-feasibility equalities, friction pyramids, torque limits -- as the reference's iHQP hands
+    it to its plugin (iHQP.cpp:263-358 -> BackEnd::solve), B problems per call through osot_qp_solve_batch"""
+    import ctypes as C
+    from opensot_amd import abi, synth
+    dev = torch.device("cuda", device)
+    n = nv + 3 * ncon
+    eps = 1.0e3 * 2.221e-16 * 1.0e6
+    gens = [synth.wide_id_levels(np.random.default_rng(7000 + b), nv, ncon)[1] for b in range(B)]
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    p = lambda a: C.c_void_p(a.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def solve(qs, nsteps):
+        nc = qs[0][2].shape[0]
+        ts = [t(np.stack([q[j] for q in qs])) for j in range(7)]
+        x = torch.zeros((B, n), dtype=torch.float64, device=dev)
+        st = torch.zeros((B,), dtype=torch.int32, device=dev); it = torch.zeros((B,), dtype=torch.int32, device=dev)
+        call = lambda: abi.lib().osot_qp_solve_batch(B, n, nc, *[p(a) for a in ts], eps, 0, p(x), p(st), p(it), stream)
+        for _ in range(warmup):
+            abi.check(call(), "osot_qp_solve_batch")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            abi.check(call(), "osot_qp_solve_batch")
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / max(1, nsteps), x, st, it, nc
+    _, x0, st0, _, _ = solve([g(0, []) for g in gens], 0)
+    xs0 = x0.cpu().numpy()
+    ms, x1, st1, it1, nc1 = solve([g(1, [xs0[b]]) for b, g in enumerate(gens)], steps)
+    nbytes = 8 * (n * n + n + nc1 * n + 2 * nc1 + 2 * n + n)
+    return {"workload": f"osot_qp_big_kernel: explicit QPs of {n} variables and {nc1} rows (level 1 of a floating-base inverse-dynamics stack, "
+                        f"{nv} accelerations + {ncon} point contacts) through osot_qp_solve_batch, one 256-thread workgroup per QP, cold",
+            "batch": B, "value": B / (ms * 1e-3), "unit": "solves/s", "ms_per_step": ms, "steps": steps,
+            "solved_ok": f"{int((st1 == 0).sum().item())}/{B}", "level0_solved_ok": f"{int((st0 == 0).sum().item())}/{B}",
+            "iterations_mean": float(it1.float().mean().item()),
+            "roofline": hbm_roofline(nbytes, B, ms, [("osot_qp_big_kernel", 4 * min(B, 1024 if n <= 96 else 512), 1)],
+                                     "osot_qp_big_kernel (a coverage path: ~10 barrier-separated sections per active-set iteration over an L2-resident J)")}
+
+
 def time_kinematics(B, device, steps=20, warmup=5):
     from opensot_amd import kinematics as kin
     m = kin.humanoid32()
@@ -1459,6 +1501,10 @@ def main():
                 oc["ADMM_qp"] = time_admm(1024, local_rank)
             except Exception as e:
                 oc["ADMM_qp"] = {"error": str(e)}
+            try:
+                oc["wide_qp_70"] = time_wide_qp(1024, local_rank)
+            except Exception as e:
+                oc["wide_qp_70"] = {"error": str(e)}
             for key, Bk in (("kinematics", 4096), ("kinematics_B32768", 32768)):
                 try:
                     oc[key] = time_kinematics(Bk, local_rank)

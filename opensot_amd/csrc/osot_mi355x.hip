@@ -744,7 +744,9 @@ static int qp_solve_batch_impl(int B, int n, int nc, const double* H, const doub
         const size_t lds = big::shared_bytes(n, nc);
         int r = ensure_lds(osot_qp_big_kernel, lds);
         if (r != OSOT_OK) return r;
-        const unsigned grid = (unsigned)(B < 512 ? B : 512);
+        // (workgroups in flight: 30 KB of LDS at n = 70 lets five share a CU, 82 KB at n = 128 one; the workspace is 2 n^2 doubles each)
+        const unsigned cap = n <= 96 ? 1024u : 512u;
+        const unsigned grid = (unsigned)B < cap ? (unsigned)B : cap;
         const size_t wbytes = (size_t)grid * 2 * (size_t)n * n * sizeof(double);
         HIP_TRY(hipMallocAsync((void**)&Q.work, wbytes, (hipStream_t)hip_stream));
         hipLaunchKernelGGL(osot_qp_big_kernel, dim3(grid), dim3(256), lds, (hipStream_t)hip_stream, Q);

@@ -440,3 +440,48 @@ def make_feature_stack(B, seed=0, n=32, eps_factor=1e6, body_frame=True, dense=T
     plan = StackPlan(n=n, levels=levels, bounds=bounds, rowblocks=rowblocks, eps_abs=eps_abs_from_factor(eps_factor))
     leaf = {"B": B, "A": A, "task": tleaf, "bound": bleaf, "rows": rleaf, "C": Cleaf, "W": Wl}
     return plan, leaf
+
+
+def wide_id_levels(rng, nv=56, ncon=5, tau_max=60.0):
+    """two levels of a floating-base inverse-dynamics stack WIDER than 64 variables as explicit QPs in BackEnd convention (the shape of
+    src/utils/InverseDynamics.cpp:12-28): x = [qddot (nv); F (3 per point contact)]; rows: dynamic feasibility (6 equalities), friction
+    pyramids (5 rows per contact), torque limits (nv - 6 bilateral rows); box: acceleration limits and force limits.  Level 0: 15 task
+    rows on qddot (a CoM and two Cartesian tasks), level 1: a Postural task on qddot under level 0's optimality rows.
+    Returns (n, level) with level(k, xs) -> (H, g, A, lA, uA, l, u), xs = the solutions of the levels above."""
+    nf = 3 * ncon
+    n = nv + nf
+    Q = rng.normal(size=(nv, nv)) * 0.3
+    M = Q.T @ Q + np.eye(nv) * 2.0
+    Jc = rng.normal(size=(nf, nv)) * 0.5
+    h = rng.normal(size=nv) * 2.0
+    h[2] += 9.81 * 5.0
+    dyn = np.hstack([M, -Jc.T])
+    rows, lo, up = [], [], []
+    for r in range(6):
+        rows.append(dyn[r]); lo.append(-h[r]); up.append(-h[r])
+    mu = 0.7
+    for c in range(ncon):
+        fx, fy, fz = nv + 3 * c, nv + 3 * c + 1, nv + 3 * c + 2
+        for (a, sgn) in ((fx, 1), (fx, -1), (fy, 1), (fy, -1)):
+            row = np.zeros(n); row[a] = sgn; row[fz] = -mu
+            rows.append(row); lo.append(-np.inf); up.append(0.0)
+        row = np.zeros(n); row[fz] = 1.0
+        rows.append(row); lo.append(0.0); up.append(1.0e3)
+    for r in range(6, nv):
+        rows.append(dyn[r]); lo.append(-tau_max - h[r]); up.append(tau_max - h[r])
+    Cm, lo, up = np.array(rows), np.array(lo), np.array(up)
+    l = np.concatenate([-np.full(nv, 80.0), np.full(nf, -1.0e3)])
+    u = np.concatenate([np.full(nv, 80.0), np.full(nf, 1.0e3)])
+    m0 = 15
+    A0 = np.hstack([rng.normal(size=(m0, nv)) * 0.6, np.zeros((m0, nf))])
+    b0 = rng.normal(size=m0) * 3.0
+    qref = rng.normal(size=nv) * 0.5
+
+    def level(k, xs):
+        if k == 0:
+            return A0.T @ A0, -A0.T @ b0, Cm, lo, up, l, u
+        H = np.zeros((n, n)); H[:nv, :nv] = np.eye(nv)
+        g = np.zeros(n); g[:nv] = -qref
+        t = A0 @ xs[0]
+        return H, g, np.vstack([Cm, A0]), np.concatenate([lo, t]), np.concatenate([up, t]), l, u
+    return n, level
