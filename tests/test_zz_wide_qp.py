@@ -182,3 +182,54 @@ def test_plugin_surface_with_70_and_with_88_variables_gpu(oracle, gpu_device):
         A0 = A1[A.shape[0]:]
         assert np.abs(A0 @ x1 - A0 @ x0).max() < 1e-8
         assert qp.solve() and np.abs(qp.getSolution() - x1).max() < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the committed golden vectors: answers of the reference's own qpOASES 3.1 (tests/golden/make_wide_golden.py)
+def _golden():
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wide_id_levels.npz"))
+    return z, len(z["cases"]), float(z["eps_factor"])
+
+
+def _golden_level(z, ci, k):
+    return tuple(z[f"c{ci}_k{k}_{nm}"] for nm in ("H", "g", "A", "lA", "uA", "l", "u"))
+
+
+def test_golden_qpoases_wider_than_64_host():
+    """strict: north_star's 1e-6 against the reference's qpOASES at OpenSoT's options, 1e-7 against its exact optimum"""
+    z, ncases, factor = _golden()
+    eps = 2.221e-13 * factor
+    for ci in range(ncases):
+        for k in range(2):
+            q = _golden_level(z, ci, k)
+            assert q[0].shape[0] > 64
+            st, x, _ = big_host_solve(*q, eps)
+            assert st == 0
+            assert np.abs(x - z[f"c{ci}_k{k}_x_qpoases"]).max() < 1e-6
+            assert np.abs(x - z[f"c{ci}_k{k}_x_qpoases_exact"]).max() < 1e-7
+
+
+@pytest.mark.gpu
+def test_golden_qpoases_wider_than_64_through_the_plugin_gpu(gpu_device):
+    """the same vectors through osot_backend_* (initProblem for level 0; updateTask + updateConstraints + solve for level 1, posed on
+    the reference's level-0 answer as the fixture was) and, as one batch, through osot_qp_solve_batch"""
+    from opensot_amd.solver import BackEnd
+    z, ncases, factor = _golden()
+    for ci in range(ncases):
+        H, g, A, lA, uA, l, u = _golden_level(z, ci, 0)
+        qp = BackEnd(H.shape[0], A.shape[0], abi.HST_SEMIDEF, factor)
+        assert qp.initProblem(H, g, A, lA, uA, l, u)
+        assert np.abs(qp.getSolution() - z[f"c{ci}_k0_x_qpoases"]).max() < 1e-6
+        H1, g1, A1, lA1, uA1, _, _ = _golden_level(z, ci, 1)
+        assert qp.updateTask(H1, g1) and qp.updateConstraints(A1, lA1, uA1) and qp.solve()
+        x1 = qp.getSolution()
+        assert np.abs(x1 - z[f"c{ci}_k1_x_qpoases"]).max() < 1e-6
+        assert np.abs(x1 - z[f"c{ci}_k1_x_qpoases_exact"]).max() < 1e-7
+    same = [ci for ci in range(ncases) if _golden_level(z, ci, 1)[2].shape == _golden_level(z, 0, 1)[2].shape]
+    args = tuple(np.stack([_golden_level(z, ci, 1)[j] for ci in same]) for j in range(7))
+    n, nc = args[0].shape[1], args[2].shape[1]
+    x, st, _ = _solve_batch_gpu(args, 2.221e-13 * factor, len(same), n, nc)
+    assert (st == 0).all()
+    for b, ci in enumerate(same):
+        assert np.abs(x[b] - z[f"c{ci}_k1_x_qpoases"]).max() < 1e-6
