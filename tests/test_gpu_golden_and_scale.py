@@ -261,9 +261,16 @@ def test_bench_rccl_path_with_a_world_of_one(gpu_device, mode):
         # what a world of MORE than one rank runs by default: plain launches, the collective asynchronous on its group's stream,
         # two alternating send / receive blocks (ShardGather overlap) -- forced here on the one GPU a test box has
         env.update(OSOT_GATHER_OVERLAP="1", OSOT_BENCH_DIST_GRAPH="0")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
-                        "--no-other-configs", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
-    assert r.returncode == 0, r.stderr[-3000:]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-other-configs", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    if r.returncode != 0:
+        # ONE more attempt on another rendezvous port: this is the only test of the suite that brings up a process group, and a
+        # rendezvous / RCCL bring-up hiccup of a fresh box must not read as a solver failure (seen once in ~40 runs of the suite,
+        # never reproduced in 28 isolated runs; a second failure is reported with both stderr tails)
+        first = r.stderr[-1500:]
+        env["MASTER_PORT"] = "29573"
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert r.returncode == 0, "first attempt:\n" + first + "\nsecond attempt:\n" + r.stderr[-1500:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     assert len(lines[0]) < 12288 and r.stdout.rstrip().endswith(lines[0])
