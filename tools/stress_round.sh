@@ -16,3 +16,6 @@ tail -n 3 $OUT/*.txt
 # round 6: the 40-lane layout's null-space / low-rank paths (33 .. 38 variables, many equality rows)
 for s in 5 6; do python tests/stress_parity.py $s 400 coman40 2>&1 | grep -v amdgpu.ids; done > $OUT/stress_parity_coman40.txt
 tail -n 3 $OUT/stress_parity_coman40.txt
+# round 6: the explicit-QP surface beyond 64 variables (osot_qp_big.h)
+for s in 3 4 5; do python tests/stress_qp.py $s 200 wide 2>&1 | grep -v amdgpu.ids; done > $OUT/stress_qp_wide.txt
+tail -n 3 $OUT/stress_qp_wide.txt
