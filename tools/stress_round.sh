@@ -19,3 +19,8 @@ tail -n 3 $OUT/stress_parity_coman40.txt
 # round 6: the explicit-QP surface beyond 64 variables (osot_qp_big.h)
 for s in 3 4 5; do python tests/stress_qp.py $s 200 wide 2>&1 | grep -v amdgpu.ids; done > $OUT/stress_qp_wide.txt
 tail -n 3 $OUT/stress_qp_wide.txt
+# round 6: the reference's own robot in closed loop (the 40-lane layout's null-space paths under real drift); the second block is the
+# out-of-reach regime whose census DESIGN.md section 5 discusses
+for st in S1 S2 S3 S4; do for sd in 1 2; do python tests/stress_closed_loop_coman.py $sd 1024 200 $st 0.3 2>&1 | grep -v amdgpu.ids | tail -4; done; done > $OUT/stress_closed_loop_coman35.txt
+for st in S1 S2 S3 S4; do for sd in 3 4; do python tests/stress_closed_loop_coman.py $sd 4096 400 $st 0.5 2>&1 | grep -v amdgpu.ids | tail -6; done; done > $OUT/stress_closed_loop_coman35_unreachable_goals.txt
+tail -n 3 $OUT/stress_closed_loop_coman35.txt
